@@ -1,0 +1,249 @@
+/*
+ * root_digger_amd.h -- C ABI of the MI355X (gfx950) likelihood core for
+ * RootDigger's root search.
+ *
+ * This is the drop-in boundary: plain C, plain pointers and sizes, no torch or
+ * HIP types.  Every entry point names the reference interface it replaces.
+ * The reference reaches its likelihood library (coraxlib, a C library) from
+ * src/model.cpp and src/tree.cpp; citations below are relative to
+ * /root/reference/.  A maintainer swaps `corax_` for `rdamd_` at the call
+ * sites listed.
+ *
+ * All CLV / P-matrix / scaler storage lives in HBM; host pointers passed in
+ * are borrowed for the duration of the call only.  Functions are NOT
+ * re-entrant on the same partition (one HIP stream per partition); different
+ * partitions may be driven from different host threads, as the reference does
+ * (src/model.cpp:397, :429, :1935).
+ */
+#ifndef ROOT_DIGGER_AMD_H_
+#define ROOT_DIGGER_AMD_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RDAMD_SUCCESS 1 /* CORAX_SUCCESS */
+#define RDAMD_FAILURE 0 /* CORAX_FAILURE */
+#define RDAMD_SCALE_BUFFER_NONE (-1)
+
+/* attribute bits accepted for source compatibility with src/model.cpp:145-157;
+ * the SIMD ones are meaningless on a GPU and ignored. */
+#define RDAMD_ATTRIB_ARCH_SSE (1u << 0)
+#define RDAMD_ATTRIB_ARCH_AVX (1u << 1)
+#define RDAMD_ATTRIB_ARCH_AVX2 (1u << 2)
+#define RDAMD_ATTRIB_SITE_REPEATS (1u << 10)
+#define RDAMD_ATTRIB_NONREV (1u << 11)
+
+#define RDAMD_GAMMA_RATES_MEAN 0   /* CORAX_GAMMA_RATES_MEAN   */
+#define RDAMD_GAMMA_RATES_MEDIAN 1 /* CORAX_GAMMA_RATES_MEDIAN */
+
+/* error channel: replaces the corax_errno / corax_errmsg globals read at
+ * src/model.cpp:439, :849 and src/msa.cpp:628-629 (thread-local here). */
+int         rdamd_errno(void);
+const char *rdamd_errmsg(void);
+
+/* replaces corax_operation_t (filled at src/tree.cpp:399-410, :425-436,
+ * :636-647; golden indices in test/src/tree.cpp:154-179). */
+typedef struct rdamd_operation {
+  unsigned int parent_clv_index;
+  int          parent_scaler_index;
+  unsigned int child1_clv_index;
+  unsigned int child1_matrix_index;
+  int          child1_scaler_index;
+  unsigned int child2_clv_index;
+  unsigned int child2_matrix_index;
+  int          child2_scaler_index;
+} rdamd_operation_t;
+
+typedef struct rdamd_partition rdamd_partition_t;
+
+/* ------------------------------------------------------------------------
+ * Partition life cycle and setters
+ * --------------------------------------------------------------------- */
+
+/* replaces corax_partition_create, src/model.cpp:159-168.  Returns NULL and
+ * sets rdamd_errmsg on failure (no GPU, out of memory, bad sizes). */
+rdamd_partition_t *rdamd_partition_create(unsigned int tips,
+                                          unsigned int clv_buffers,
+                                          unsigned int states,
+                                          unsigned int sites,
+                                          unsigned int rate_matrices,
+                                          unsigned int prob_matrices,
+                                          unsigned int rate_cats,
+                                          unsigned int scale_buffers,
+                                          unsigned int attributes);
+/* replaces corax_partition_destroy, src/model.cpp:180 */
+void rdamd_partition_destroy(rdamd_partition_t *p);
+
+/* replaces corax_set_tip_states, src/model.cpp:310.  `map` is a 256-entry
+ * char -> state-bitmask table (rdamd_map_nt / rdamd_map_bin or the caller's).
+ * Returns RDAMD_FAILURE on a character the map does not know. */
+int rdamd_set_tip_states(rdamd_partition_t *p, unsigned int tip_index,
+                         const uint64_t *map, const char *sequence);
+/* replaces corax_set_pattern_weights, src/model.cpp:324 */
+void rdamd_set_pattern_weights(rdamd_partition_t *p, const unsigned int *w);
+/* replaces corax_set_subst_params, src/model.cpp:185 (K*K-K values) */
+void rdamd_set_subst_params(rdamd_partition_t *p, unsigned int params_index,
+                            const double *params);
+/* replaces corax_set_frequencies, src/model.cpp:337, :347 */
+void rdamd_set_frequencies(rdamd_partition_t *p, unsigned int params_index,
+                           const double *freqs);
+/* replaces corax_set_category_rates, src/model.cpp:244-289 */
+void rdamd_set_category_rates(rdamd_partition_t *p, const double *rates);
+/* replaces corax_set_category_weights, src/model.cpp:205, :209 */
+void rdamd_set_category_weights(rdamd_partition_t *p, const double *weights);
+/* replaces corax_update_invariant_sites_proportion, src/model.cpp:297.  The
+ * reference only ever passes 0.0; any other value is rejected. */
+int rdamd_update_invariant_sites_proportion(rdamd_partition_t *p,
+                                            unsigned int       params_index,
+                                            double             prop_invar);
+/* replaces corax_msa_empirical_frequencies, src/model.cpp:329; malloc'd
+ * double[states], caller frees (src/model.cpp:338). */
+double *rdamd_msa_empirical_frequencies(rdamd_partition_t *p);
+/* replaces corax_compute_gamma_cats, src/model.cpp:239-270 */
+int rdamd_compute_gamma_cats(double alpha, unsigned int categories,
+                             double *output_rates, int rates_mode);
+
+/* struct reads the reference performs directly on corax_partition_t
+ * (src/model.cpp:330, :1043-1045, :1315): exposed as accessors. */
+unsigned int  rdamd_partition_states(const rdamd_partition_t *p);
+unsigned int  rdamd_partition_rate_cats(const rdamd_partition_t *p);
+unsigned int  rdamd_partition_sites(const rdamd_partition_t *p);
+unsigned int  rdamd_partition_tips(const rdamd_partition_t *p);
+const double *rdamd_partition_subst_params(const rdamd_partition_t *p,
+                                           unsigned int params_index);
+const double *rdamd_partition_frequencies(const rdamd_partition_t *p,
+                                          unsigned int params_index);
+
+/* ------------------------------------------------------------------------
+ * The hot path
+ * --------------------------------------------------------------------- */
+
+/* replaces corax_update_prob_matrices, src/model.cpp:367, :432, :842.
+ * P[m][r] = exp(Q * rate_r * t_m) computed on the device for the whole list in
+ * one launch. */
+int rdamd_update_prob_matrices(rdamd_partition_t  *p,
+                               const unsigned int *params_indices,
+                               const unsigned int *matrix_indices,
+                               const double       *branch_lengths,
+                               unsigned int        count);
+/* replaces corax_update_clvs, src/model.cpp:402, :440, :461, :851.  `ops` must
+ * be in dependency (post-) order, as corax_utree_create_operations emits. */
+void rdamd_update_clvs(rdamd_partition_t *p, const rdamd_operation_t *ops,
+                       unsigned int count);
+/* replaces corax_compute_root_loglikelihood, src/model.cpp:406, :441, :466.
+ * persite_lnl may be NULL (the reference always passes nullptr). */
+double rdamd_compute_root_loglikelihood(rdamd_partition_t  *p,
+                                        unsigned int        clv_index,
+                                        int                 scaler_index,
+                                        const unsigned int *freqs_indices,
+                                        double             *persite_lnl);
+
+/* Fused form of the three calls of model_t::compute_lh_root
+ * (src/model.cpp:432-445): two P-matrices + one root op + reduction in a
+ * single launch, for `n_alpha` root positions on the same edge at once
+ * (compute_dlh, src/model.cpp:481-519, needs two).  The root CLV/scaler of the
+ * LAST position is left in the partition exactly as the unfused calls would.
+ * lengths1/lengths2: child1/child2 branch length per position. */
+int rdamd_root_loglikelihood_fused(rdamd_partition_t       *p,
+                                   const rdamd_operation_t *root_op,
+                                   const unsigned int      *params_indices,
+                                   const double            *lengths1,
+                                   const double            *lengths2,
+                                   unsigned int             n_alpha,
+                                   double                  *lnl_out);
+
+/* parity/debug views: copy device buffers to host. */
+int rdamd_get_clv(rdamd_partition_t *p, unsigned int clv_index, double *out);
+int rdamd_get_scaler(rdamd_partition_t *p, unsigned int scaler_index,
+                     unsigned int *out);
+int rdamd_get_pmatrix(rdamd_partition_t *p, unsigned int matrix_index,
+                      double *out);
+
+/* blocks until all queued device work of the partition has finished. */
+void rdamd_partition_sync(rdamd_partition_t *p);
+
+
+/* ------------------------------------------------------------------------
+ * Host-side schedule generation: rooted_tree_t (src/tree.hpp:54-201)
+ *
+ * The C++ class lives in root_digger_amd/csrc/tree.hpp; these wrappers expose
+ * it to C / ctypes callers.  Functions returning int give RDAMD_SUCCESS or
+ * RDAMD_FAILURE (+ rdamd_errmsg) where the C++ method would throw.
+ * --------------------------------------------------------------------- */
+typedef struct rdamd_tree rdamd_tree_t;
+
+/* replaces root_location_t (src/tree.hpp:24-52); `edge` is a half-edge id. */
+typedef struct rdamd_root_location {
+  int      edge;
+  uint64_t id;
+  double   saved_brlen;
+  double   brlen_ratio;
+} rdamd_root_location_t;
+
+/* rooted_tree_t(const std::string &tree_filename), src/tree.hpp:58-66 */
+rdamd_tree_t *rdamd_tree_from_file(const char *filename);
+rdamd_tree_t *rdamd_tree_from_newick(const char *newick);
+void          rdamd_tree_destroy(rdamd_tree_t *t);
+unsigned int  rdamd_tree_tip_count(const rdamd_tree_t *t);    /* src/tree.cpp:102 */
+unsigned int  rdamd_tree_inner_count(const rdamd_tree_t *t);  /* src/tree.cpp:103 */
+unsigned int  rdamd_tree_branch_count(const rdamd_tree_t *t); /* src/tree.cpp:106 */
+unsigned int  rdamd_tree_root_count(const rdamd_tree_t *t);   /* src/tree.cpp:100 */
+unsigned int  rdamd_tree_root_clv_index(const rdamd_tree_t *t);   /* :110 */
+int           rdamd_tree_root_scaler_index(const rdamd_tree_t *t); /* :113 */
+int rdamd_tree_root_location(const rdamd_tree_t *t, unsigned int index,
+                             rdamd_root_location_t *out);        /* :74-82 */
+int rdamd_tree_root_location_by_label(const rdamd_tree_t *t, const char *label,
+                                      rdamd_root_location_t *out); /* :84-91 */
+/* label of a root location ("(null)" when unlabeled), src/tree.hpp:36-38 */
+const char *rdamd_tree_root_label(const rdamd_tree_t *t, unsigned int index);
+int rdamd_tree_root_is_internal(const rdamd_tree_t *t, unsigned int index);
+/* label_map(), src/tree.cpp:117-125: tip label -> tip clv index (or -1) */
+int         rdamd_tree_tip_index(const rdamd_tree_t *t, const char *label);
+const char *rdamd_tree_tip_label(const rdamd_tree_t *t, unsigned int clv_index);
+/* tip labels on the rl.edge side of a root branch, '\n'-joined, malloc'd */
+char *rdamd_tree_side_tips(const rdamd_tree_t *t, const rdamd_root_location_t *rl);
+
+/* generate_operations, src/tree.cpp:364-413.  ops must hold tip_count
+ * entries, pmatrix_indices/branch_lengths 2*tip_count entries. */
+int rdamd_tree_generate_operations(rdamd_tree_t *t, const rdamd_root_location_t *rl,
+                                   rdamd_operation_t *ops, unsigned int *n_ops,
+                                   unsigned int *pmatrix_indices,
+                                   double *branch_lengths, unsigned int *n_matrices);
+/* generate_derivative_operations, src/tree.cpp:415-441 (1 op, 2 matrices) */
+int rdamd_tree_generate_derivative_operations(rdamd_tree_t *t,
+                                              const rdamd_root_location_t *rl,
+                                              rdamd_operation_t *op,
+                                              unsigned int *pmatrix_indices,
+                                              double *branch_lengths);
+/* generate_root_update_operations, src/tree.cpp:572-657 */
+int rdamd_tree_generate_root_update_operations(rdamd_tree_t *t,
+                                               const rdamd_root_location_t *rl,
+                                               rdamd_operation_t *ops, unsigned int *n_ops,
+                                               unsigned int *pmatrix_indices,
+                                               double *branch_lengths,
+                                               unsigned int *n_matrices);
+int  rdamd_tree_root_by(rdamd_tree_t *t, const rdamd_root_location_t *rl); /* :273 */
+void rdamd_tree_unroot(rdamd_tree_t *t);                                   /* :334 */
+int  rdamd_tree_rooted(const rdamd_tree_t *t);                             /* :360 */
+int  rdamd_tree_sanity_check(const rdamd_tree_t *t);                       /* :519 */
+/* newick(annotations), src/tree.cpp:443-492; malloc'd, caller frees */
+char *rdamd_tree_newick(const rdamd_tree_t *t, int annotations);
+int   rdamd_tree_annotate_branch(rdamd_tree_t *t, const rdamd_root_location_t *rl,
+                                 const char *key, const char *value); /* :731 */
+
+/* character maps (replace corax_map_nt / corax_map_bin, src/main.cpp:484) */
+extern const uint64_t rdamd_map_nt[256];
+extern const uint64_t rdamd_map_bin[256];
+
+/* library / device info */
+const char *rdamd_version(void);
+int         rdamd_device_count(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ROOT_DIGGER_AMD_H_ */

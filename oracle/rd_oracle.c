@@ -1,0 +1,435 @@
+/*
+ * rd_oracle.c -- CPU ORACLE (test infrastructure, NOT product code).
+ * See rd_oracle.h for status ("parity unpinned" vs coraxlib absolute lnL;
+ * pinned vs closed forms + SciPy goldens + the reference's property tests).
+ *
+ * Layouts follow SURVEY.md Appendix A:
+ *   CLV      [site][rate][state] doubles            (A3)
+ *   P-matrix [rate][parent state][child state]      (A2)
+ *   scaler   [site] unsigned, per-site 2^256 rule   (A4)
+ */
+#include "rd_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* 2^256 exactly, and its reciprocal (the libpll/coraxlib scaling constants) */
+#define ORC_SCALE_FACTOR 115792089237316195423570985008687907853269984665640564039457584007913129639936.0
+#define ORC_SCALE_THRESHOLD (1.0 / ORC_SCALE_FACTOR)
+
+struct orc_partition {
+  unsigned int tips, clv_buffers, states, sites, rate_matrices, prob_matrices,
+      rate_cats, scale_buffers, attributes;
+  double      **clv;      /* tips + clv_buffers, each [S][R][K] */
+  unsigned int **scaler;  /* scale_buffers, each [S] */
+  double      **pmatrix;  /* prob_matrices, each [R][K][K] */
+  double      **subst;    /* rate_matrices, each [K*K-K] */
+  double      **freqs;    /* rate_matrices, each [K] */
+  double       *rates;    /* [R] */
+  double       *rate_weights; /* [R] */
+  double       *prop_invar;   /* rate_matrices (always 0, src/model.cpp:297) */
+  unsigned int *pattern_weights; /* [S] */
+};
+
+const uint64_t orc_map_nt[256] = {
+    ['A'] = 1,  ['a'] = 1,  ['C'] = 2,  ['c'] = 2,  ['G'] = 4,  ['g'] = 4,
+    ['T'] = 8,  ['t'] = 8,  ['U'] = 8,  ['u'] = 8,  ['R'] = 5,  ['r'] = 5,
+    ['Y'] = 10, ['y'] = 10, ['S'] = 6,  ['s'] = 6,  ['W'] = 9,  ['w'] = 9,
+    ['K'] = 12, ['k'] = 12, ['M'] = 3,  ['m'] = 3,  ['B'] = 14, ['b'] = 14,
+    ['D'] = 13, ['d'] = 13, ['H'] = 11, ['h'] = 11, ['V'] = 7,  ['v'] = 7,
+    ['N'] = 15, ['n'] = 15, ['O'] = 15, ['o'] = 15, ['X'] = 15, ['x'] = 15,
+    ['-'] = 15, ['?'] = 15,
+};
+
+orc_partition_t *orc_partition_create(unsigned int tips,
+                                      unsigned int clv_buffers,
+                                      unsigned int states,
+                                      unsigned int sites,
+                                      unsigned int rate_matrices,
+                                      unsigned int prob_matrices,
+                                      unsigned int rate_cats,
+                                      unsigned int scale_buffers,
+                                      unsigned int attributes) {
+  orc_partition_t *p = (orc_partition_t *)calloc(1, sizeof(*p));
+  if (!p) return NULL;
+  p->tips = tips; p->clv_buffers = clv_buffers; p->states = states;
+  p->sites = sites; p->rate_matrices = rate_matrices;
+  p->prob_matrices = prob_matrices; p->rate_cats = rate_cats;
+  p->scale_buffers = scale_buffers; p->attributes = attributes;
+  size_t clv_len = (size_t)sites * rate_cats * states;
+  p->clv = (double **)calloc(tips + clv_buffers, sizeof(double *));
+  for (unsigned int i = 0; i < tips + clv_buffers; ++i)
+    p->clv[i] = (double *)calloc(clv_len ? clv_len : 1, sizeof(double));
+  p->scaler = (unsigned int **)calloc(scale_buffers ? scale_buffers : 1,
+                                      sizeof(unsigned int *));
+  for (unsigned int i = 0; i < scale_buffers; ++i)
+    p->scaler[i] = (unsigned int *)calloc(sites ? sites : 1, sizeof(unsigned int));
+  p->pmatrix = (double **)calloc(prob_matrices ? prob_matrices : 1, sizeof(double *));
+  for (unsigned int i = 0; i < prob_matrices; ++i)
+    p->pmatrix[i] = (double *)calloc((size_t)rate_cats * states * states, sizeof(double));
+  p->subst = (double **)calloc(rate_matrices, sizeof(double *));
+  p->freqs = (double **)calloc(rate_matrices, sizeof(double *));
+  for (unsigned int i = 0; i < rate_matrices; ++i) {
+    p->subst[i] = (double *)calloc((size_t)states * states - states, sizeof(double));
+    p->freqs[i] = (double *)calloc(states, sizeof(double));
+    for (unsigned int k = 0; k < states * states - states; ++k) p->subst[i][k] = 1.0;
+    for (unsigned int k = 0; k < states; ++k) p->freqs[i][k] = 1.0 / states;
+  }
+  p->rates        = (double *)calloc(rate_cats, sizeof(double));
+  p->rate_weights = (double *)calloc(rate_cats, sizeof(double));
+  for (unsigned int k = 0; k < rate_cats; ++k) {
+    p->rates[k] = 1.0;
+    p->rate_weights[k] = 1.0 / rate_cats;
+  }
+  p->prop_invar = (double *)calloc(rate_matrices, sizeof(double));
+  p->pattern_weights = (unsigned int *)calloc(sites ? sites : 1, sizeof(unsigned int));
+  for (unsigned int s = 0; s < sites; ++s) p->pattern_weights[s] = 1;
+  return p;
+}
+
+void orc_partition_destroy(orc_partition_t *p) {
+  if (!p) return;
+  for (unsigned int i = 0; i < p->tips + p->clv_buffers; ++i) free(p->clv[i]);
+  free(p->clv);
+  for (unsigned int i = 0; i < p->scale_buffers; ++i) free(p->scaler[i]);
+  free(p->scaler);
+  for (unsigned int i = 0; i < p->prob_matrices; ++i) free(p->pmatrix[i]);
+  free(p->pmatrix);
+  for (unsigned int i = 0; i < p->rate_matrices; ++i) {
+    free(p->subst[i]);
+    free(p->freqs[i]);
+  }
+  free(p->subst); free(p->freqs); free(p->rates); free(p->rate_weights);
+  free(p->prop_invar); free(p->pattern_weights);
+  free(p);
+}
+
+/* Appendix A3: a tip is a full 0/1 CLV (the reference sets no PATTERN_TIP
+ * attribute, src/model.cpp:145-157); entry j = bit j of map[char]. */
+int orc_set_tip_states(orc_partition_t *p, unsigned int tip_index,
+                       const uint64_t *map, const char *sequence) {
+  double *clv = p->clv[tip_index];
+  for (unsigned int s = 0; s < p->sites; ++s) {
+    uint64_t st = map[(unsigned char)sequence[s]];
+    if (!st) return ORC_FAILURE;
+    for (unsigned int r = 0; r < p->rate_cats; ++r)
+      for (unsigned int j = 0; j < p->states; ++j)
+        clv[((size_t)s * p->rate_cats + r) * p->states + j] =
+            (double)((st >> j) & 1u);
+  }
+  return ORC_SUCCESS;
+}
+
+void orc_set_tip_clv(orc_partition_t *p, unsigned int tip_index,
+                     const double *v) {
+  double *clv = p->clv[tip_index];
+  for (unsigned int s = 0; s < p->sites; ++s)
+    for (unsigned int r = 0; r < p->rate_cats; ++r)
+      for (unsigned int j = 0; j < p->states; ++j)
+        clv[((size_t)s * p->rate_cats + r) * p->states + j] =
+            v[(size_t)s * p->states + j];
+}
+
+void orc_set_pattern_weights(orc_partition_t *p, const unsigned int *w) {
+  memcpy(p->pattern_weights, w, sizeof(unsigned int) * p->sites);
+}
+void orc_set_subst_params(orc_partition_t *p, unsigned int idx, const double *v) {
+  memcpy(p->subst[idx], v, sizeof(double) * (p->states * p->states - p->states));
+}
+void orc_set_frequencies(orc_partition_t *p, unsigned int idx, const double *f) {
+  memcpy(p->freqs[idx], f, sizeof(double) * p->states);
+}
+void orc_set_category_rates(orc_partition_t *p, const double *r) {
+  memcpy(p->rates, r, sizeof(double) * p->rate_cats);
+}
+void orc_set_category_weights(orc_partition_t *p, const double *w) {
+  memcpy(p->rate_weights, w, sizeof(double) * p->rate_cats);
+}
+
+/* corax_msa_empirical_frequencies (src/model.cpp:329): each tip character
+ * spreads one (weighted) count evenly over the states it is compatible with. */
+double *orc_msa_empirical_frequencies(orc_partition_t *p) {
+  unsigned int K = p->states;
+  double *f = (double *)calloc(K, sizeof(double));
+  double total = 0.0;
+  for (unsigned int s = 0; s < p->sites; ++s) total += p->pattern_weights[s];
+  for (unsigned int t = 0; t < p->tips; ++t) {
+    const double *clv = p->clv[t];
+    for (unsigned int s = 0; s < p->sites; ++s) {
+      const double *c = clv + (size_t)s * p->rate_cats * K;
+      double sum = 0.0;
+      for (unsigned int j = 0; j < K; ++j) sum += c[j];
+      for (unsigned int j = 0; j < K; ++j)
+        f[j] += p->pattern_weights[s] * c[j] / sum;
+    }
+  }
+  for (unsigned int j = 0; j < K; ++j) f[j] /= total * p->tips;
+  return f;
+}
+
+/* ---- discrete gamma (Appendix A6; Yang 1994) ----------------------------- */
+
+/* regularised lower incomplete gamma P(a, x) */
+static double inc_gamma_p(double a, double x) {
+  if (x <= 0.0) return 0.0;
+  double lg = lgamma(a);
+  if (x < a + 1.0) { /* series */
+    double ap = a, sum = 1.0 / a, del = sum;
+    for (int n = 0; n < 2000; ++n) {
+      ap += 1.0;
+      del *= x / ap;
+      sum += del;
+      if (fabs(del) < fabs(sum) * 1e-17) break;
+    }
+    return sum * exp(-x + a * log(x) - lg);
+  }
+  /* Lentz continued fraction for Q(a,x) */
+  double tiny = 1e-300;
+  double b = x + 1.0 - a, c = 1.0 / tiny, d = 1.0 / b, h = d;
+  for (int i = 1; i < 2000; ++i) {
+    double an = -i * (i - a);
+    b += 2.0;
+    d = an * d + b; if (fabs(d) < tiny) d = tiny;
+    c = b + an / c; if (fabs(c) < tiny) c = tiny;
+    d = 1.0 / d;
+    double del = d * c;
+    h *= del;
+    if (fabs(del - 1.0) < 1e-17) break;
+  }
+  return 1.0 - exp(-x + a * log(x) - lg) * h;
+}
+
+/* quantile of Gamma(shape a, rate b): bisection + Newton polish */
+static double gamma_quantile(double prob, double a, double b) {
+  double lo = 0.0, hi = a > 1.0 ? a : 1.0;
+  while (inc_gamma_p(a, hi) < prob) hi *= 2.0;
+  for (int i = 0; i < 200; ++i) {
+    double mid = 0.5 * (lo + hi);
+    if (inc_gamma_p(a, mid) < prob) lo = mid; else hi = mid;
+    if (hi - lo <= 1e-16 * hi) break;
+  }
+  double x = 0.5 * (lo + hi);
+  for (int i = 0; i < 3; ++i) { /* Newton on P(a,x) - prob */
+    double pdf = exp(-x + (a - 1.0) * log(x) - lgamma(a));
+    if (pdf <= 0.0) break;
+    double nx = x - (inc_gamma_p(a, x) - prob) / pdf;
+    if (nx > lo && nx < hi) x = nx;
+  }
+  return x / b;
+}
+
+int orc_compute_gamma_cats(double alpha, unsigned int cats, double *out,
+                           int mode) {
+  if (alpha <= 0.0 || cats < 1) return ORC_FAILURE;
+  if (cats == 1) { out[0] = 1.0; return ORC_SUCCESS; }
+  double beta = alpha, factor = alpha / beta * cats;
+  if (mode == ORC_GAMMA_RATES_MEDIAN) {
+    double t = 0.0;
+    for (unsigned int i = 0; i < cats; ++i) {
+      out[i] = gamma_quantile((2.0 * i + 1.0) / (2.0 * cats), alpha, beta);
+      t += out[i];
+    }
+    for (unsigned int i = 0; i < cats; ++i) out[i] *= factor / t;
+  } else {
+    double *g = (double *)malloc(sizeof(double) * cats);
+    for (unsigned int i = 0; i + 1 < cats; ++i)
+      g[i] = gamma_quantile((i + 1.0) / cats, alpha, beta);
+    for (unsigned int i = 0; i + 1 < cats; ++i)
+      g[i] = inc_gamma_p(alpha + 1.0, g[i] * beta);
+    out[0] = g[0] * factor;
+    out[cats - 1] = (1.0 - g[cats - 2]) * factor;
+    for (unsigned int i = 1; i + 1 < cats; ++i) out[i] = (g[i] - g[i - 1]) * factor;
+    free(g);
+  }
+  return ORC_SUCCESS;
+}
+
+/* ---- rate matrix and P(t) ------------------------------------------------ */
+
+/* Appendix A1 (UNVERIFIED vs coraxlib's CORAX_ATTRIB_NONREV build): the K*K-K
+ * parameters are the off-diagonals in row-major order; Q_ij = s_ij * pi_j;
+ * rows sum to zero; Q is scaled to one expected substitution per unit time
+ * under pi.  Isolated here so the convention is a one-function swap. */
+static void build_q(const orc_partition_t *p, unsigned int idx, double *q) {
+  unsigned int K = p->states, k = 0;
+  const double *s = p->subst[idx], *f = p->freqs[idx];
+  for (unsigned int i = 0; i < K; ++i) {
+    double row = 0.0;
+    for (unsigned int j = 0; j < K; ++j) {
+      if (i == j) continue;
+      q[i * K + j] = s[k++] * f[j];
+      row += q[i * K + j];
+    }
+    q[i * K + i] = -row;
+  }
+  double mean = 0.0;
+  for (unsigned int i = 0; i < K; ++i) mean -= f[i] * q[i * K + i];
+  for (unsigned int i = 0; i < K * K; ++i) q[i] /= mean;
+}
+
+void orc_get_qmatrix(const orc_partition_t *p, unsigned int idx, double *out) {
+  build_q(p, idx, out);
+}
+
+static void matmul(const double *a, const double *b, double *c, unsigned int n) {
+  for (unsigned int i = 0; i < n; ++i)
+    for (unsigned int j = 0; j < n; ++j) {
+      double s = 0.0;
+      for (unsigned int k = 0; k < n; ++k) s += a[i * n + k] * b[k * n + j];
+      c[i * n + j] = s;
+    }
+}
+
+/* exp(A): scale to ||A||_1 <= 1/4, Taylor to convergence, square back. */
+void orc_expm(const double *a, unsigned int n, double *out) {
+  size_t nn = (size_t)n * n;
+  double *x = (double *)malloc(sizeof(double) * nn * 3);
+  double *term = x + nn, *tmp = x + 2 * nn;
+  double norm = 0.0;
+  for (unsigned int j = 0; j < n; ++j) {
+    double cs = 0.0;
+    for (unsigned int i = 0; i < n; ++i) cs += fabs(a[i * n + j]);
+    if (cs > norm) norm = cs;
+  }
+  int s = 0;
+  double scale = 1.0;
+  while (norm * scale > 0.25) { scale *= 0.5; ++s; }
+  for (size_t i = 0; i < nn; ++i) x[i] = a[i] * scale;
+  for (size_t i = 0; i < nn; ++i) { out[i] = 0.0; term[i] = 0.0; }
+  for (unsigned int i = 0; i < n; ++i) { out[i * n + i] = 1.0; term[i * n + i] = 1.0; }
+  for (int k = 1; k <= 40; ++k) {
+    matmul(term, x, tmp, n);
+    double tn = 0.0;
+    for (size_t i = 0; i < nn; ++i) {
+      term[i] = tmp[i] / k;
+      out[i] += term[i];
+      if (fabs(term[i]) > tn) tn = fabs(term[i]);
+    }
+    if (tn < 1e-30) break;
+  }
+  for (int k = 0; k < s; ++k) {
+    matmul(out, out, tmp, n);
+    memcpy(out, tmp, sizeof(double) * nn);
+  }
+  free(x);
+}
+
+/* Appendix A2: P_r(t) = exp(Q * rate_r * t / (1 - p_inv)); p_inv is always 0
+ * in the reference (src/model.cpp:292-300). Negative round-off is clamped. */
+int orc_update_prob_matrices(orc_partition_t *p,
+                             const unsigned int *params_indices,
+                             const unsigned int *matrix_indices,
+                             const double *branch_lengths,
+                             unsigned int count) {
+  unsigned int K = p->states;
+  double *q = (double *)malloc(sizeof(double) * K * K * 2);
+  double *a = q + K * K;
+  for (unsigned int m = 0; m < count; ++m) {
+    if (matrix_indices[m] >= p->prob_matrices || !(branch_lengths[m] >= 0.0)) {
+      free(q);
+      return ORC_FAILURE;
+    }
+    double *pm = p->pmatrix[matrix_indices[m]];
+    for (unsigned int r = 0; r < p->rate_cats; ++r) {
+      unsigned int pi = params_indices[r];
+      build_q(p, pi, q);
+      double f = p->rates[r] * branch_lengths[m] / (1.0 - p->prop_invar[pi]);
+      for (unsigned int i = 0; i < K * K; ++i) a[i] = q[i] * f;
+      double *out = pm + (size_t)r * K * K;
+      orc_expm(a, K, out);
+      for (unsigned int i = 0; i < K * K; ++i)
+        if (out[i] < 0.0) out[i] = 0.0;
+    }
+  }
+  free(q);
+  return ORC_SUCCESS;
+}
+
+/* ---- CLV update (row a1 of SURVEY 8a; Appendix A4) ----------------------- */
+
+static void update_one(orc_partition_t *p, const orc_operation_t *op) {
+  unsigned int K = p->states, R = p->rate_cats, S = p->sites;
+  double *parent = p->clv[op->parent_clv_index];
+  const double *left = p->clv[op->child1_clv_index];
+  const double *right = p->clv[op->child2_clv_index];
+  const double *lm = p->pmatrix[op->child1_matrix_index];
+  const double *rm = p->pmatrix[op->child2_matrix_index];
+  unsigned int *psc = op->parent_scaler_index == ORC_SCALE_BUFFER_NONE
+                          ? NULL : p->scaler[op->parent_scaler_index];
+  const unsigned int *lsc = op->child1_scaler_index == ORC_SCALE_BUFFER_NONE
+                                ? NULL : p->scaler[op->child1_scaler_index];
+  const unsigned int *rsc = op->child2_scaler_index == ORC_SCALE_BUFFER_NONE
+                                ? NULL : p->scaler[op->child2_scaler_index];
+  /* parent scaler starts as the sum of the children's */
+  if (psc)
+    for (unsigned int s = 0; s < S; ++s)
+      psc[s] = (lsc ? lsc[s] : 0u) + (rsc ? rsc[s] : 0u);
+
+  size_t span = (size_t)R * K;
+  for (unsigned int s = 0; s < S; ++s) {
+    double *pc = parent + s * span;
+    const double *lc = left + s * span, *rc = right + s * span;
+    int scaling = psc ? 1 : 0;
+    for (unsigned int r = 0; r < R; ++r) {
+      const double *lmat = lm + (size_t)r * K * K, *rmat = rm + (size_t)r * K * K;
+      for (unsigned int i = 0; i < K; ++i) {
+        double ta = 0.0, tb = 0.0;
+        for (unsigned int j = 0; j < K; ++j) {
+          ta += lmat[i * K + j] * lc[r * K + j];
+          tb += rmat[i * K + j] * rc[r * K + j];
+        }
+        double v = ta * tb;
+        pc[r * K + i] = v;
+        scaling = scaling && (v < ORC_SCALE_THRESHOLD);
+      }
+    }
+    if (scaling) {
+      for (size_t i = 0; i < span; ++i) pc[i] *= ORC_SCALE_FACTOR;
+      psc[s] += 1;
+    }
+  }
+}
+
+void orc_update_clvs(orc_partition_t *p, const orc_operation_t *ops,
+                     unsigned int count) {
+  for (unsigned int i = 0; i < count; ++i) update_one(p, &ops[i]);
+}
+
+/* ---- root log-likelihood (row a3; Appendix A5) --------------------------- */
+
+double orc_compute_root_loglikelihood(orc_partition_t *p,
+                                      unsigned int clv_index,
+                                      int scaler_index,
+                                      const unsigned int *freqs_indices,
+                                      double *persite_lnl) {
+  unsigned int K = p->states, R = p->rate_cats;
+  const double *clv = p->clv[clv_index];
+  const unsigned int *sc =
+      scaler_index == ORC_SCALE_BUFFER_NONE ? NULL : p->scaler[scaler_index];
+  double logl = 0.0;
+  const double log_thr = log(ORC_SCALE_THRESHOLD);
+  for (unsigned int s = 0; s < p->sites; ++s) {
+    double term = 0.0;
+    for (unsigned int r = 0; r < R; ++r) {
+      const double *f = p->freqs[freqs_indices[r]];
+      double tr = 0.0;
+      for (unsigned int k = 0; k < K; ++k) tr += clv[k] * f[k];
+      term += tr * p->rate_weights[r];
+      clv += K;
+    }
+    term = log(term);
+    if (sc && sc[s]) term += sc[s] * log_thr;
+    term *= p->pattern_weights[s];
+    if (persite_lnl) persite_lnl[s] = term;
+    logl += term;
+  }
+  return logl;
+}
+
+const double *orc_get_clv(const orc_partition_t *p, unsigned int i) { return p->clv[i]; }
+const unsigned int *orc_get_scaler(const orc_partition_t *p, unsigned int i) { return p->scaler[i]; }
+const double *orc_get_pmatrix(const orc_partition_t *p, unsigned int i) { return p->pmatrix[i]; }
+unsigned int orc_states(const orc_partition_t *p) { return p->states; }
+unsigned int orc_rate_cats(const orc_partition_t *p) { return p->rate_cats; }
+unsigned int orc_sites(const orc_partition_t *p) { return p->sites; }

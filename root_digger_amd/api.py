@@ -1,0 +1,412 @@
+"""ctypes mirror of include/root_digger_amd.h (names follow the C ABI)."""
+import ctypes as C
+
+import numpy as np
+
+from ._lib import lib, RdamdError
+
+GAMMA_RATES_MEAN = 0
+GAMMA_RATES_MEDIAN = 1
+SCALE_BUFFER_NONE = -1
+
+
+class Operation(C.Structure):
+    """rdamd_operation_t == corax_operation_t (src/tree.cpp:399-410)."""
+    _fields_ = [
+        ("parent_clv_index", C.c_uint),
+        ("parent_scaler_index", C.c_int),
+        ("child1_clv_index", C.c_uint),
+        ("child1_matrix_index", C.c_uint),
+        ("child1_scaler_index", C.c_int),
+        ("child2_clv_index", C.c_uint),
+        ("child2_matrix_index", C.c_uint),
+        ("child2_scaler_index", C.c_int),
+    ]
+
+    def astuple(self):
+        return tuple(getattr(self, f) for f, _ in self._fields_)
+
+
+class RootLocation(C.Structure):
+    """rdamd_root_location_t == root_location_t (src/tree.hpp:24-52)."""
+    _fields_ = [("edge", C.c_int), ("id", C.c_uint64), ("saved_brlen", C.c_double),
+                ("brlen_ratio", C.c_double)]
+
+    def with_ratio(self, ratio):
+        r = RootLocation(self.edge, self.id, self.saved_brlen, ratio)
+        return r
+
+    def brlen(self):
+        return self.saved_brlen * self.brlen_ratio
+
+    def brlen_compliment(self):
+        return self.saved_brlen * (1 - self.brlen_ratio)
+
+
+def _sig(name, restype, *argtypes):
+    f = getattr(lib, name)
+    f.restype = restype
+    f.argtypes = list(argtypes)
+    return f
+
+
+_u = C.c_uint
+_pu = C.POINTER(C.c_uint)
+_pd = C.POINTER(C.c_double)
+_vp = C.c_void_p
+_pop = C.POINTER(Operation)
+_prl = C.POINTER(RootLocation)
+
+_errno = _sig("rdamd_errno", C.c_int)
+_errmsg = _sig("rdamd_errmsg", C.c_char_p)
+_sig("rdamd_version", C.c_char_p)
+_sig("rdamd_device_count", C.c_int)
+
+_sig("rdamd_partition_create", _vp, _u, _u, _u, _u, _u, _u, _u, _u, _u)
+_sig("rdamd_partition_destroy", None, _vp)
+_sig("rdamd_set_tip_states", C.c_int, _vp, _u, C.POINTER(C.c_uint64), C.c_char_p)
+_sig("rdamd_set_pattern_weights", None, _vp, _pu)
+_sig("rdamd_set_subst_params", None, _vp, _u, _pd)
+_sig("rdamd_set_frequencies", None, _vp, _u, _pd)
+_sig("rdamd_set_category_rates", None, _vp, _pd)
+_sig("rdamd_set_category_weights", None, _vp, _pd)
+_sig("rdamd_update_invariant_sites_proportion", C.c_int, _vp, _u, C.c_double)
+_sig("rdamd_msa_empirical_frequencies", C.POINTER(C.c_double), _vp)
+_sig("rdamd_compute_gamma_cats", C.c_int, C.c_double, _u, _pd, C.c_int)
+_sig("rdamd_partition_states", _u, _vp)
+_sig("rdamd_partition_rate_cats", _u, _vp)
+_sig("rdamd_partition_sites", _u, _vp)
+_sig("rdamd_partition_tips", _u, _vp)
+_sig("rdamd_partition_subst_params", C.POINTER(C.c_double), _vp, _u)
+_sig("rdamd_partition_frequencies", C.POINTER(C.c_double), _vp, _u)
+_sig("rdamd_update_prob_matrices", C.c_int, _vp, _pu, _pu, _pd, _u)
+_sig("rdamd_update_clvs", None, _vp, _pop, _u)
+_sig("rdamd_compute_root_loglikelihood", C.c_double, _vp, _u, C.c_int, _pu, _pd)
+_sig("rdamd_root_loglikelihood_fused", C.c_int, _vp, _pop, _pu, _pd, _pd, _u, _pd)
+_sig("rdamd_get_clv", C.c_int, _vp, _u, _pd)
+_sig("rdamd_get_scaler", C.c_int, _vp, _u, _pu)
+_sig("rdamd_get_pmatrix", C.c_int, _vp, _u, _pd)
+_sig("rdamd_partition_sync", None, _vp)
+
+_sig("rdamd_tree_from_file", _vp, C.c_char_p)
+_sig("rdamd_tree_from_newick", _vp, C.c_char_p)
+_sig("rdamd_tree_destroy", None, _vp)
+for _n in ("tip_count", "inner_count", "branch_count", "root_count", "root_clv_index"):
+    _sig("rdamd_tree_" + _n, _u, _vp)
+_sig("rdamd_tree_root_scaler_index", C.c_int, _vp)
+_sig("rdamd_tree_root_location", C.c_int, _vp, _u, _prl)
+_sig("rdamd_tree_root_location_by_label", C.c_int, _vp, C.c_char_p, _prl)
+_sig("rdamd_tree_root_label", C.c_char_p, _vp, _u)
+_sig("rdamd_tree_root_is_internal", C.c_int, _vp, _u)
+_sig("rdamd_tree_tip_index", C.c_int, _vp, C.c_char_p)
+_sig("rdamd_tree_tip_label", C.c_char_p, _vp, _u)
+_sig("rdamd_tree_side_tips", _vp, _vp, _prl)
+_sig("rdamd_tree_generate_operations", C.c_int, _vp, _prl, _pop, _pu, _pu, _pd, _pu)
+_sig("rdamd_tree_generate_derivative_operations", C.c_int, _vp, _prl, _pop, _pu, _pd)
+_sig("rdamd_tree_generate_root_update_operations", C.c_int, _vp, _prl, _pop, _pu, _pu, _pd, _pu)
+_sig("rdamd_tree_root_by", C.c_int, _vp, _prl)
+_sig("rdamd_tree_unroot", None, _vp)
+_sig("rdamd_tree_rooted", C.c_int, _vp)
+_sig("rdamd_tree_sanity_check", C.c_int, _vp)
+_sig("rdamd_tree_newick", _vp, _vp, C.c_int)
+_sig("rdamd_tree_annotate_branch", C.c_int, _vp, _prl, C.c_char_p, C.c_char_p)
+
+_libc = C.CDLL(None)
+_libc.free.argtypes = [_vp]
+_libc.free.restype = None
+
+MAP_NT = (C.c_uint64 * 256).in_dll(lib, "rdamd_map_nt")
+MAP_BIN = (C.c_uint64 * 256).in_dll(lib, "rdamd_map_bin")
+
+
+def _fail(where):
+    raise RdamdError("%s: %s" % (where, (_errmsg() or b"").decode()))
+
+
+def _take_string(ptr):
+    if not ptr:
+        _fail("string result")
+    s = C.string_at(ptr).decode()
+    _libc.free(ptr)
+    return s
+
+
+def device_count():
+    return lib.rdamd_device_count()
+
+
+def compute_gamma_cats(alpha, cats, mode=GAMMA_RATES_MEAN):
+    out = (C.c_double * cats)()
+    if lib.rdamd_compute_gamma_cats(alpha, cats, out, mode) != 1:
+        _fail("compute_gamma_cats")
+    return list(out)
+
+
+def _dptr(a):
+    return a.ctypes.data_as(_pd)
+
+
+def _uptr(a):
+    return a.ctypes.data_as(_pu)
+
+
+class Tree:
+    """rooted_tree_t (src/tree.hpp:54) through the C ABI."""
+
+    def __init__(self, handle):
+        if not handle:
+            _fail("Tree")
+        self._h = handle
+
+    @classmethod
+    def from_newick(cls, text):
+        return cls(lib.rdamd_tree_from_newick(text.encode()))
+
+    @classmethod
+    def from_file(cls, path):
+        return cls(lib.rdamd_tree_from_file(str(path).encode()))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib.rdamd_tree_destroy(self._h)
+            self._h = None
+
+    def tip_count(self):
+        return lib.rdamd_tree_tip_count(self._h)
+
+    def inner_count(self):
+        return lib.rdamd_tree_inner_count(self._h)
+
+    def branch_count(self):
+        return lib.rdamd_tree_branch_count(self._h)
+
+    def root_count(self):
+        return lib.rdamd_tree_root_count(self._h)
+
+    def root_clv_index(self):
+        return lib.rdamd_tree_root_clv_index(self._h)
+
+    def root_scaler_index(self):
+        return lib.rdamd_tree_root_scaler_index(self._h)
+
+    def root_location(self, key):
+        rl = RootLocation()
+        if isinstance(key, str):
+            ok = lib.rdamd_tree_root_location_by_label(self._h, key.encode(), C.byref(rl))
+        else:
+            ok = lib.rdamd_tree_root_location(self._h, int(key), C.byref(rl))
+        if ok != 1:
+            _fail("root_location")
+        return rl
+
+    def roots(self):
+        return [self.root_location(i) for i in range(self.root_count())]
+
+    def root_label(self, index):
+        return lib.rdamd_tree_root_label(self._h, index).decode()
+
+    def root_is_internal(self, index):
+        return bool(lib.rdamd_tree_root_is_internal(self._h, index))
+
+    def tip_index(self, label):
+        return lib.rdamd_tree_tip_index(self._h, label.encode())
+
+    def tip_label(self, clv_index):
+        return lib.rdamd_tree_tip_label(self._h, clv_index).decode()
+
+    def label_map(self):
+        return {self.tip_label(i): i for i in range(self.tip_count())}
+
+    def side_tips(self, rl):
+        return _take_string(lib.rdamd_tree_side_tips(self._h, C.byref(rl))).split("\n")
+
+    def _sched(self, fn, rl):
+        n = self.tip_count()
+        ops = (Operation * (2 * n))()
+        pmi = np.zeros(2 * n, dtype=np.uint32)
+        brl = np.zeros(2 * n, dtype=np.float64)
+        nops, nmat = C.c_uint(0), C.c_uint(0)
+        if fn(self._h, C.byref(rl), ops, C.byref(nops), _uptr(pmi), _dptr(brl),
+              C.byref(nmat)) != 1:
+            _fail("schedule")
+        out = (Operation * nops.value)()
+        for i in range(nops.value):
+            out[i] = ops[i]
+        return out, pmi[:nmat.value].copy(), brl[:nmat.value].copy()
+
+    def generate_operations(self, rl):
+        return self._sched(lib.rdamd_tree_generate_operations, rl)
+
+    def generate_root_update_operations(self, rl):
+        return self._sched(lib.rdamd_tree_generate_root_update_operations, rl)
+
+    def generate_derivative_operations(self, rl):
+        op = Operation()
+        pmi = np.zeros(2, dtype=np.uint32)
+        brl = np.zeros(2, dtype=np.float64)
+        if lib.rdamd_tree_generate_derivative_operations(
+                self._h, C.byref(rl), C.byref(op), _uptr(pmi), _dptr(brl)) != 1:
+            _fail("generate_derivative_operations")
+        return op, pmi, brl
+
+    def root_by(self, rl):
+        if lib.rdamd_tree_root_by(self._h, C.byref(rl)) != 1:
+            _fail("root_by")
+
+    def unroot(self):
+        lib.rdamd_tree_unroot(self._h)
+
+    def rooted(self):
+        return bool(lib.rdamd_tree_rooted(self._h))
+
+    def sanity_check(self):
+        return bool(lib.rdamd_tree_sanity_check(self._h))
+
+    def newick(self, annotations=True):
+        return _take_string(lib.rdamd_tree_newick(self._h, 1 if annotations else 0))
+
+    def annotate_branch(self, rl, key, value):
+        if lib.rdamd_tree_annotate_branch(self._h, C.byref(rl), key.encode(),
+                                          value.encode()) != 1:
+            _fail("annotate_branch")
+
+
+class Partition:
+    """The coraxlib partition subset RootDigger uses, in HBM."""
+
+    def __init__(self, tips, clv_buffers, states, sites, rate_matrices, prob_matrices,
+                 rate_cats, scale_buffers, attributes=0):
+        self._h = lib.rdamd_partition_create(tips, clv_buffers, states, sites,
+                                             rate_matrices, prob_matrices, rate_cats,
+                                             scale_buffers, attributes)
+        if not self._h:
+            _fail("partition_create")
+        self.tips, self.clv_buffers, self.states, self.sites = tips, clv_buffers, states, sites
+        self.rate_cats, self.prob_matrices, self.scale_buffers = rate_cats, prob_matrices, scale_buffers
+        self.params_indices = np.zeros(rate_cats, dtype=np.uint32)
+
+    @classmethod
+    def for_tree(cls, tree, states, sites, rate_cats, attributes=0):
+        """Sizes exactly as model_t's constructor picks them (src/model.cpp:159-168)."""
+        b = tree.branch_count()
+        return cls(tree.tip_count(), b, states, sites, 1, b, rate_cats, b, attributes)
+
+    def destroy(self):
+        if getattr(self, "_h", None):
+            lib.rdamd_partition_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.destroy()
+
+    @property
+    def handle(self):
+        return self._h
+
+    def set_tip_states(self, tip_index, cmap, sequence):
+        if isinstance(sequence, str):
+            sequence = sequence.encode()
+        if lib.rdamd_set_tip_states(self._h, tip_index, cmap, sequence) != 1:
+            _fail("set_tip_states")
+
+    def set_pattern_weights(self, w):
+        w = np.ascontiguousarray(w, dtype=np.uint32)
+        assert w.size == self.sites
+        lib.rdamd_set_pattern_weights(self._h, _uptr(w))
+
+    def set_subst_params(self, idx, params):
+        a = np.ascontiguousarray(params, dtype=np.float64)
+        assert a.size == self.states * self.states - self.states
+        lib.rdamd_set_subst_params(self._h, idx, _dptr(a))
+
+    def set_frequencies(self, idx, freqs):
+        a = np.ascontiguousarray(freqs, dtype=np.float64)
+        assert a.size == self.states
+        lib.rdamd_set_frequencies(self._h, idx, _dptr(a))
+
+    def set_category_rates(self, rates):
+        a = np.ascontiguousarray(rates, dtype=np.float64)
+        assert a.size == self.rate_cats
+        lib.rdamd_set_category_rates(self._h, _dptr(a))
+
+    def set_category_weights(self, w):
+        a = np.ascontiguousarray(w, dtype=np.float64)
+        assert a.size == self.rate_cats
+        lib.rdamd_set_category_weights(self._h, _dptr(a))
+
+    def update_invariant_sites_proportion(self, idx, p):
+        if lib.rdamd_update_invariant_sites_proportion(self._h, idx, p) != 1:
+            _fail("update_invariant_sites_proportion")
+
+    def empirical_frequencies(self):
+        ptr = lib.rdamd_msa_empirical_frequencies(self._h)
+        out = [ptr[i] for i in range(self.states)]
+        _libc.free(C.cast(ptr, _vp))
+        return out
+
+    def subst_params(self, idx=0):
+        ptr = lib.rdamd_partition_subst_params(self._h, idx)
+        return [ptr[i] for i in range(self.states * self.states - self.states)]
+
+    def update_prob_matrices(self, matrix_indices, branch_lengths, params_indices=None):
+        mi = np.ascontiguousarray(matrix_indices, dtype=np.uint32)
+        bl = np.ascontiguousarray(branch_lengths, dtype=np.float64)
+        pi = self.params_indices if params_indices is None else np.ascontiguousarray(
+            params_indices, dtype=np.uint32)
+        if lib.rdamd_update_prob_matrices(self._h, _uptr(pi), _uptr(mi), _dptr(bl),
+                                          mi.size) != 1:
+            _fail("update_prob_matrices")
+
+    def update_clvs(self, ops):
+        n = len(ops)
+        if not isinstance(ops, C.Array):
+            arr = (Operation * n)()
+            for i, o in enumerate(ops):
+                arr[i] = o
+            ops = arr
+        lib.rdamd_update_clvs(self._h, ops, n)
+        if _errno():
+            _fail("update_clvs")
+
+    def compute_root_loglikelihood(self, clv_index, scaler_index, freqs_indices=None,
+                                   persite=False):
+        fi = self.params_indices if freqs_indices is None else np.ascontiguousarray(
+            freqs_indices, dtype=np.uint32)
+        ps = np.zeros(self.sites, dtype=np.float64) if persite else None
+        v = lib.rdamd_compute_root_loglikelihood(
+            self._h, clv_index, scaler_index, _uptr(fi), _dptr(ps) if persite else None)
+        if _errno():
+            _fail("compute_root_loglikelihood")
+        return (v, ps) if persite else v
+
+    def root_loglikelihood_fused(self, root_op, lengths1, lengths2, params_indices=None):
+        l1 = np.ascontiguousarray(lengths1, dtype=np.float64)
+        l2 = np.ascontiguousarray(lengths2, dtype=np.float64)
+        out = np.zeros(l1.size, dtype=np.float64)
+        pi = self.params_indices if params_indices is None else np.ascontiguousarray(
+            params_indices, dtype=np.uint32)
+        if lib.rdamd_root_loglikelihood_fused(self._h, C.byref(root_op), _uptr(pi),
+                                              _dptr(l1), _dptr(l2), l1.size, _dptr(out)) != 1:
+            _fail("root_loglikelihood_fused")
+        return out
+
+    def get_clv(self, idx):
+        out = np.zeros((self.sites, self.rate_cats, self.states), dtype=np.float64)
+        if lib.rdamd_get_clv(self._h, idx, _dptr(out)) != 1:
+            _fail("get_clv")
+        return out
+
+    def get_scaler(self, idx):
+        out = np.zeros(self.sites, dtype=np.uint32)
+        if lib.rdamd_get_scaler(self._h, idx, _uptr(out)) != 1:
+            _fail("get_scaler")
+        return out
+
+    def get_pmatrix(self, idx):
+        out = np.zeros((self.rate_cats, self.states, self.states), dtype=np.float64)
+        if lib.rdamd_get_pmatrix(self._h, idx, _dptr(out)) != 1:
+            _fail("get_pmatrix")
+        return out
+
+    def sync(self):
+        lib.rdamd_partition_sync(self._h)

@@ -1,0 +1,123 @@
+// Internal declarations shared by the HIP translation units of librdamd.
+// Not part of the C ABI (see include/root_digger_amd.h).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../include/root_digger_amd.h"
+
+namespace rdamd {
+
+// 2^256 and 2^-256: the per-site scaling constants.
+constexpr double kScaleFactor =
+    115792089237316195423570985008687907853269984665640564039457584007913129639936.0;
+constexpr double kScaleThreshold = 1.0 / kScaleFactor;
+// log(2^-256)
+constexpr double kLogScaleThreshold = -177.44567822334599;
+
+void set_error(int code, const char *fmt, ...);
+void clear_error();
+
+#define RDAMD_HIP_TRY(expr, failret)                                            \
+  do {                                                                          \
+    hipError_t e_ = (expr);                                                     \
+    if (e_ != hipSuccess) {                                                     \
+      ::rdamd::set_error(100 + (int)e_, "%s failed: %s (%s:%d)", #expr,         \
+                         hipGetErrorString(e_), __FILE__, __LINE__);            \
+      return failret;                                                           \
+    }                                                                           \
+  } while (0)
+
+// Device-side view of one partition: everything the kernels need.
+struct DeviceView {
+  unsigned tips, states, sites, rate_cats, ncodes_cap;
+  const uint8_t *tipcodes;  // [tips][sites]      code index per tip character
+  double        *clv;       // [clv_buffers][sites][rate_cats][states]
+  unsigned      *scaler;    // [scale_buffers][sites]
+  double        *pmat;      // [prob_matrices][rate_cats][states][states]
+  double        *tiptab;    // [prob_matrices][rate_cats][ncodes_cap][states]
+  const uint64_t *codemask; // [256]
+  size_t clv_stride;        // sites*rate_cats*states
+};
+
+}  // namespace rdamd
+
+struct rdamd_partition {
+  unsigned tips = 0, clv_buffers = 0, states = 0, sites = 0, rate_matrices = 0,
+           prob_matrices = 0, rate_cats = 0, scale_buffers = 0, attributes = 0;
+  int device = 0;
+  hipStream_t stream = nullptr;
+
+  // ---- HBM-resident state ------------------------------------------------
+  uint8_t  *d_tipcodes = nullptr;
+  double   *d_clv = nullptr;
+  unsigned *d_scaler = nullptr;
+  double   *d_pmat = nullptr;
+  double   *d_tiptab = nullptr;
+  uint64_t *d_codemask = nullptr;
+  double   *d_q = nullptr;        // [rate_matrices][K][K]
+  double   *d_freqs = nullptr;    // [rate_matrices][K]
+  double   *d_rates = nullptr;    // [R]
+  double   *d_rate_weights = nullptr;
+  unsigned *d_pattern_weights = nullptr;
+  double   *d_tipclv_scratch = nullptr;  // expanded tip CLV for get_clv
+  // scratch
+  void     *d_scratch = nullptr;  // ops / matrix lists
+  size_t    scratch_bytes = 0;
+  double   *d_partials = nullptr; // per-block partial sums + result slots
+  double   *d_result = nullptr;
+  double   *d_persite = nullptr;
+  double   *h_result = nullptr;   // pinned
+  char     *h_stage = nullptr;    // pinned staging ring for small H2D copies
+  size_t    stage_bytes = 0, stage_off = 0;
+
+  // ---- host mirrors --------------------------------------------------------
+  std::vector<std::vector<double>> subst, freqs;
+  std::vector<double> rates, rate_weights, prop_invar;
+  std::vector<unsigned> pattern_weights;
+  std::vector<uint8_t> tipcodes;     // [tips][sites]
+  std::vector<uint64_t> codemask;    // code index -> state mask
+  unsigned ncodes = 0, ncodes_cap = 0;
+  std::vector<char> q_dirty;         // per rate matrix
+  bool tiptab_stale = false;
+
+  rdamd::DeviceView view() const {
+    rdamd::DeviceView v;
+    v.tips = tips; v.states = states; v.sites = sites; v.rate_cats = rate_cats;
+    v.ncodes_cap = ncodes_cap;
+    v.tipcodes = d_tipcodes; v.clv = d_clv; v.scaler = d_scaler; v.pmat = d_pmat;
+    v.tiptab = d_tiptab; v.codemask = d_codemask;
+    v.clv_stride = (size_t)sites * rate_cats * states;
+    return v;
+  }
+};
+
+namespace rdamd {
+
+// kernels_pmatrix.hip
+// Rebuild Q for one rate matrix on the host into q[K*K].
+void build_q_host(unsigned K, const double *subst, const double *freqs, double *q);
+hipError_t launch_pmatrix(rdamd_partition *p, const unsigned *d_params_indices,
+                          const unsigned *d_matrix_indices,
+                          const double *d_branch_lengths, unsigned count);
+hipError_t launch_tiptab_all(rdamd_partition *p);
+
+// kernels_clv.hip
+struct LevelOp {   // device-side op descriptor (one per blockIdx.y)
+  unsigned parent_clv, child1_clv, child2_clv;     // absolute clv indices
+  unsigned child1_mat, child2_mat;
+  int parent_sc, child1_sc, child2_sc;
+};
+hipError_t launch_clv_level(rdamd_partition *p, const LevelOp *d_ops, unsigned nops);
+
+// kernels_root.hip
+hipError_t launch_root_lnl(rdamd_partition *p, unsigned clv_index, int scaler_index,
+                           const unsigned *d_freqs_indices, double *d_persite,
+                           double *d_out);
+
+}  // namespace rdamd

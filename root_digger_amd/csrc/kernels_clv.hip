@@ -1,0 +1,197 @@
+// Conditional-likelihood-vector (CLV) updates.
+//
+// Replaces corax_update_clvs (called at /root/reference/src/model.cpp:402, :440,
+// :461, :851).  For every operation of a traversal
+//   parent[s][r][i] = (sum_j P1[r][i][j] c1[s][r][j]) * (sum_j P2[r][i][j] c2[s][r][j])
+// followed by the per-site 2^256 rescale rule:
+// the parent scaler starts as the sum of the children's scalers and is
+// incremented (and the site multiplied by 2^256) when EVERY entry of the site
+// is below 2^-256.
+//
+// HBM layout: CLV [site][rate][state] contiguous doubles, so consecutive lanes
+// read consecutive 32-byte (DNA) records.  Tips are never expanded to CLVs:
+// a tip child contributes tiptab[matrix][rate][code][i] (built next to the
+// P-matrices), read from LDS.  All operations of one dependency level run in
+// ONE launch (blockIdx.y = operation), so a 100-taxon traversal is ~10-20
+// launches instead of 99.
+#include "common.hpp"
+
+namespace rdamd {
+
+// ---------------------------------------------------------------------------
+// 4-state path: one lane per (site, rate); the R lanes of a site are adjacent
+// so the "all entries below threshold" test is an in-wave AND.
+// ---------------------------------------------------------------------------
+template <int R>
+__global__ void __launch_bounds__(256)
+clv_dna_level_kernel(DeviceView v, const LevelOp *__restrict__ ops) {
+  // per child: P-matrix [R][4][4] or tip table [R][16][4]
+  __shared__ double smat[2][R * 64];
+  const LevelOp op = ops[blockIdx.y];
+  const bool tip1 = op.child1_clv < v.tips, tip2 = op.child2_clv < v.tips;
+  const unsigned tid = threadIdx.x;
+  {
+    const double *src1 = tip1 ? v.tiptab + (size_t)op.child1_mat * R * 64
+                              : v.pmat + (size_t)op.child1_mat * R * 16;
+    const double *src2 = tip2 ? v.tiptab + (size_t)op.child2_mat * R * 64
+                              : v.pmat + (size_t)op.child2_mat * R * 16;
+    const unsigned n1 = tip1 ? R * 64 : R * 16, n2 = tip2 ? R * 64 : R * 16;
+    for (unsigned e = tid; e < n1; e += 256) smat[0][e] = src1[e];
+    for (unsigned e = tid; e < n2; e += 256) smat[1][e] = src2[e];
+  }
+  __syncthreads();
+
+  const unsigned S = v.sites;
+  const size_t total = (size_t)S * R;
+  const double2 *c1 = tip1 ? nullptr
+      : reinterpret_cast<const double2 *>(v.clv + (size_t)(op.child1_clv - v.tips) * v.clv_stride);
+  const double2 *c2 = tip2 ? nullptr
+      : reinterpret_cast<const double2 *>(v.clv + (size_t)(op.child2_clv - v.tips) * v.clv_stride);
+  double2 *pc = reinterpret_cast<double2 *>(v.clv + (size_t)(op.parent_clv - v.tips) * v.clv_stride);
+  const uint8_t *code1 = tip1 ? v.tipcodes + (size_t)op.child1_clv * S : nullptr;
+  const uint8_t *code2 = tip2 ? v.tipcodes + (size_t)op.child2_clv * S : nullptr;
+  unsigned *psc = op.parent_sc >= 0 ? v.scaler + (size_t)op.parent_sc * S : nullptr;
+  const unsigned *lsc = op.child1_sc >= 0 ? v.scaler + (size_t)op.child1_sc * S : nullptr;
+  const unsigned *rsc = op.child2_sc >= 0 ? v.scaler + (size_t)op.child2_sc * S : nullptr;
+
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (size_t idx = (size_t)blockIdx.x * 256 + tid; idx < total; idx += stride) {
+    const unsigned s = (unsigned)(idx / R), r = (unsigned)(idx % R);
+    double t1[4], t2[4];
+    if (tip1) {
+      const double *row = &smat[0][(r * 16 + code1[s]) * 4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) t1[i] = row[i];
+    } else {
+      const double2 a = c1[idx * 2], b = c1[idx * 2 + 1];
+      const double *m = &smat[0][r * 16];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        t1[i] = m[i * 4 + 0] * a.x + m[i * 4 + 1] * a.y + m[i * 4 + 2] * b.x + m[i * 4 + 3] * b.y;
+    }
+    if (tip2) {
+      const double *row = &smat[1][(r * 16 + code2[s]) * 4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) t2[i] = row[i];
+    } else {
+      const double2 a = c2[idx * 2], b = c2[idx * 2 + 1];
+      const double *m = &smat[1][r * 16];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        t2[i] = m[i * 4 + 0] * a.x + m[i * 4 + 1] * a.y + m[i * 4 + 2] * b.x + m[i * 4 + 3] * b.y;
+    }
+    double o[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = t1[i] * t2[i];
+    if (psc) {
+      int small = (o[0] < kScaleThreshold) & (o[1] < kScaleThreshold) &
+                  (o[2] < kScaleThreshold) & (o[3] < kScaleThreshold);
+#pragma unroll
+      for (int off = 1; off < R; off <<= 1) small &= __shfl_xor(small, off);
+      unsigned sc = (lsc ? lsc[s] : 0u) + (rsc ? rsc[s] : 0u);
+      if (small) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] *= kScaleFactor;
+        sc += 1;
+      }
+      if (r == 0) psc[s] = sc;
+    }
+    pc[idx * 2] = make_double2(o[0], o[1]);
+    pc[idx * 2 + 1] = make_double2(o[2], o[3]);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Generic path (any K <= 64, any R): one lane per site, looping over rates and
+// states.  Correct for every shape; the 20-state MFMA kernel supersedes it for
+// protein data.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+clv_generic_level_kernel(DeviceView v, const LevelOp *__restrict__ ops) {
+  const LevelOp op = ops[blockIdx.y];
+  const unsigned K = v.states, R = v.rate_cats, S = v.sites, cap = v.ncodes_cap;
+  const bool tip1 = op.child1_clv < v.tips, tip2 = op.child2_clv < v.tips;
+  const double *c1 = tip1 ? nullptr : v.clv + (size_t)(op.child1_clv - v.tips) * v.clv_stride;
+  const double *c2 = tip2 ? nullptr : v.clv + (size_t)(op.child2_clv - v.tips) * v.clv_stride;
+  double *pc = v.clv + (size_t)(op.parent_clv - v.tips) * v.clv_stride;
+  const double *p1 = v.pmat + (size_t)op.child1_mat * R * K * K;
+  const double *p2 = v.pmat + (size_t)op.child2_mat * R * K * K;
+  const double *tt1 = v.tiptab + (size_t)op.child1_mat * R * cap * K;
+  const double *tt2 = v.tiptab + (size_t)op.child2_mat * R * cap * K;
+  unsigned *psc = op.parent_sc >= 0 ? v.scaler + (size_t)op.parent_sc * S : nullptr;
+  const unsigned *lsc = op.child1_sc >= 0 ? v.scaler + (size_t)op.child1_sc * S : nullptr;
+  const unsigned *rsc = op.child2_sc >= 0 ? v.scaler + (size_t)op.child2_sc * S : nullptr;
+  const size_t span = (size_t)R * K;
+
+  for (unsigned s = blockIdx.x * blockDim.x + threadIdx.x; s < S;
+       s += gridDim.x * blockDim.x) {
+    const unsigned code1 = tip1 ? v.tipcodes[(size_t)op.child1_clv * S + s] : 0;
+    const unsigned code2 = tip2 ? v.tipcodes[(size_t)op.child2_clv * S + s] : 0;
+    bool small = psc != nullptr;
+    for (unsigned r = 0; r < R; ++r) {
+      const double *l = tip1 ? nullptr : c1 + s * span + (size_t)r * K;
+      const double *q = tip2 ? nullptr : c2 + s * span + (size_t)r * K;
+      for (unsigned i = 0; i < K; ++i) {
+        double ta, tb;
+        if (tip1) {
+          ta = tt1[((size_t)r * cap + code1) * K + i];
+        } else {
+          ta = 0.0;
+          const double *row = p1 + ((size_t)r * K + i) * K;
+          for (unsigned j = 0; j < K; ++j) ta += row[j] * l[j];
+        }
+        if (tip2) {
+          tb = tt2[((size_t)r * cap + code2) * K + i];
+        } else {
+          tb = 0.0;
+          const double *row = p2 + ((size_t)r * K + i) * K;
+          for (unsigned j = 0; j < K; ++j) tb += row[j] * q[j];
+        }
+        const double o = ta * tb;
+        pc[s * span + (size_t)r * K + i] = o;
+        small = small && (o < kScaleThreshold);
+      }
+    }
+    if (psc) {
+      unsigned sc = (lsc ? lsc[s] : 0u) + (rsc ? rsc[s] : 0u);
+      if (small) {
+        for (size_t e = 0; e < span; ++e) pc[s * span + e] *= kScaleFactor;
+        sc += 1;
+      }
+      psc[s] = sc;
+    }
+  }
+}
+
+static inline bool dna_fast_ok(unsigned K, unsigned R, unsigned cap) {
+  return K == 4 && cap == 16 && (R == 1 || R == 2 || R == 4 || R == 8 || R == 16);
+}
+
+hipError_t launch_clv_level(rdamd_partition *p, const LevelOp *d_ops, unsigned nops) {
+  if (nops == 0 || p->sites == 0) return hipSuccess;
+  DeviceView v = p->view();
+  const unsigned K = p->states, R = p->rate_cats;
+  if (dna_fast_ok(K, R, p->ncodes_cap)) {
+    size_t total = (size_t)p->sites * R;
+    unsigned gx = (unsigned)((total + 255) / 256);
+    // enough workgroups to fill 256 CUs x 8, but no more than the work needs
+    unsigned cap = (2048 + nops - 1) / nops;
+    if (cap < 32) cap = 32;
+    if (gx > cap) gx = cap;
+    dim3 grid(gx, nops);
+    switch (R) {
+      case 1: clv_dna_level_kernel<1><<<grid, 256, 0, p->stream>>>(v, d_ops); break;
+      case 2: clv_dna_level_kernel<2><<<grid, 256, 0, p->stream>>>(v, d_ops); break;
+      case 4: clv_dna_level_kernel<4><<<grid, 256, 0, p->stream>>>(v, d_ops); break;
+      case 8: clv_dna_level_kernel<8><<<grid, 256, 0, p->stream>>>(v, d_ops); break;
+      default: clv_dna_level_kernel<16><<<grid, 256, 0, p->stream>>>(v, d_ops); break;
+    }
+  } else {
+    unsigned gx = (p->sites + 255) / 256;
+    dim3 grid(gx, nops);
+    clv_generic_level_kernel<<<grid, 256, 0, p->stream>>>(v, d_ops);
+  }
+  return hipGetLastError();
+}
+
+}  // namespace rdamd

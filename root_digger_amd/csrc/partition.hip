@@ -1,0 +1,551 @@
+// C ABI: partition life cycle, setters and the three hot-path entry points.
+// Mirrors the coraxlib subset RootDigger calls; each
+// function cites the call site it replaces in include/root_digger_amd.h.
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdlib>
+#include <cstring>
+#include <unordered_map>
+
+#include "common.hpp"
+
+namespace rdamd {
+
+static thread_local int  g_errno = 0;
+static thread_local char g_errmsg[512] = "";
+
+void set_error(int code, const char *fmt, ...) {
+  g_errno = code;
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_errmsg, sizeof(g_errmsg), fmt, ap);
+  va_end(ap);
+}
+void clear_error() { g_errno = 0; g_errmsg[0] = 0; }
+
+// Small host->device copies go through a pinned ring so they can be queued on
+// the partition's stream without a blocking pageable copy.
+static void *stage_alloc(rdamd_partition *p, size_t bytes) {
+  bytes = (bytes + 255) & ~(size_t)255;
+  if (p->stage_off + bytes > p->stage_bytes) {
+    (void)hipStreamSynchronize(p->stream);
+    p->stage_off = 0;
+  }
+  void *r = p->h_stage + p->stage_off;
+  p->stage_off += bytes;
+  return r;
+}
+
+// upload `bytes` from host memory to `dst` on the partition stream
+static hipError_t upload(rdamd_partition *p, void *dst, const void *src, size_t bytes) {
+  if (bytes == 0) return hipSuccess;
+  if (bytes > p->stage_bytes / 2) {  // large: plain blocking copy
+    hipError_t e = hipStreamSynchronize(p->stream);
+    if (e != hipSuccess) return e;
+    return hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice);
+  }
+  void *st = stage_alloc(p, bytes);
+  memcpy(st, src, bytes);
+  return hipMemcpyAsync(dst, st, bytes, hipMemcpyHostToDevice, p->stream);
+}
+
+// device scratch carve-out (bump; reset per API call)
+struct Scratch {
+  rdamd_partition *p;
+  size_t off = 0;
+  void *take(size_t bytes) {
+    bytes = (bytes + 255) & ~(size_t)255;
+    if (off + bytes > p->scratch_bytes) return nullptr;
+    void *r = (char *)p->d_scratch + off;
+    off += bytes;
+    return r;
+  }
+};
+
+static hipError_t ensure_scratch(rdamd_partition *p, size_t bytes) {
+  if (bytes <= p->scratch_bytes) return hipSuccess;
+  hipError_t e = hipStreamSynchronize(p->stream);
+  if (e != hipSuccess) return e;
+  if (p->d_scratch) (void)hipFree(p->d_scratch);
+  p->d_scratch = nullptr;
+  p->scratch_bytes = 0;
+  size_t want = std::max(bytes * 2, (size_t)1 << 20);
+  e = hipMalloc(&p->d_scratch, want);
+  if (e == hipSuccess) p->scratch_bytes = want;
+  return e;
+}
+
+static hipError_t flush_q(rdamd_partition *p) {
+  const unsigned K = p->states;
+  std::vector<double> q((size_t)K * K);
+  for (unsigned i = 0; i < p->rate_matrices; ++i) {
+    if (!p->q_dirty[i]) continue;
+    build_q_host(K, p->subst[i].data(), p->freqs[i].data(), q.data());
+    hipError_t e = upload(p, p->d_q + (size_t)i * K * K, q.data(), sizeof(double) * K * K);
+    if (e != hipSuccess) return e;
+    e = upload(p, p->d_freqs + (size_t)i * K, p->freqs[i].data(), sizeof(double) * K);
+    if (e != hipSuccess) return e;
+    p->q_dirty[i] = 0;
+  }
+  return hipSuccess;
+}
+
+}  // namespace rdamd
+
+using namespace rdamd;
+
+extern "C" {
+
+int rdamd_errno(void) { return g_errno; }
+const char *rdamd_errmsg(void) { return g_errmsg; }
+const char *rdamd_version(void) { return "root_digger_amd 0.1 (gfx950)"; }
+
+int rdamd_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+#define NT(ch, v) [ch] = v, [ch + 32] = v
+const uint64_t rdamd_map_nt[256] = {
+    NT('A', 1),  NT('C', 2),  NT('G', 4),  NT('T', 8),  NT('U', 8),  NT('R', 5),
+    NT('Y', 10), NT('S', 6),  NT('W', 9),  NT('K', 12), NT('M', 3),  NT('B', 14),
+    NT('D', 13), NT('H', 11), NT('V', 7),  NT('N', 15), NT('O', 15), NT('X', 15),
+    ['-'] = 15,  ['?'] = 15,
+};
+#undef NT
+const uint64_t rdamd_map_bin[256] = {
+    ['0'] = 1, ['1'] = 2, ['-'] = 3, ['?'] = 3,
+};
+
+rdamd_partition_t *rdamd_partition_create(unsigned int tips, unsigned int clv_buffers,
+                                          unsigned int states, unsigned int sites,
+                                          unsigned int rate_matrices,
+                                          unsigned int prob_matrices,
+                                          unsigned int rate_cats,
+                                          unsigned int scale_buffers,
+                                          unsigned int attributes) {
+  clear_error();
+  if (states < 2 || states > 64 || rate_cats < 1 || rate_matrices < 1 || tips < 1) {
+    set_error(1, "rdamd_partition_create: unsupported sizes (states=%u rate_cats=%u "
+                 "rate_matrices=%u tips=%u)", states, rate_cats, rate_matrices, tips);
+    return nullptr;
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    set_error(2, "rdamd_partition_create: no HIP device available; this library has "
+                 "no CPU fallback");
+    return nullptr;
+  }
+  rdamd_partition *p = new rdamd_partition();
+  p->tips = tips; p->clv_buffers = clv_buffers; p->states = states; p->sites = sites;
+  p->rate_matrices = rate_matrices; p->prob_matrices = prob_matrices;
+  p->rate_cats = rate_cats; p->scale_buffers = scale_buffers; p->attributes = attributes;
+  p->ncodes_cap = states == 4 ? 16 : 64;
+  const unsigned K = states, R = rate_cats;
+  const size_t S = sites;
+
+#define TRY(expr) RDAMD_HIP_TRY(expr, (rdamd_partition_destroy(p), nullptr))
+  TRY(hipGetDevice(&p->device));
+  TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
+  TRY(hipMalloc(&p->d_tipcodes, std::max<size_t>(1, (size_t)tips * S)));
+  TRY(hipMalloc(&p->d_clv, std::max<size_t>(8, (size_t)clv_buffers * S * R * K * sizeof(double))));
+  TRY(hipMalloc(&p->d_scaler, std::max<size_t>(4, (size_t)scale_buffers * S * sizeof(unsigned))));
+  TRY(hipMalloc(&p->d_pmat, std::max<size_t>(8, (size_t)prob_matrices * R * K * K * sizeof(double))));
+  TRY(hipMalloc(&p->d_tiptab, std::max<size_t>(8, (size_t)prob_matrices * R * p->ncodes_cap * K * sizeof(double))));
+  TRY(hipMalloc(&p->d_codemask, 256 * sizeof(uint64_t)));
+  TRY(hipMalloc(&p->d_q, (size_t)rate_matrices * K * K * sizeof(double)));
+  TRY(hipMalloc(&p->d_freqs, (size_t)rate_matrices * K * sizeof(double)));
+  TRY(hipMalloc(&p->d_rates, R * sizeof(double)));
+  TRY(hipMalloc(&p->d_rate_weights, R * sizeof(double)));
+  TRY(hipMalloc(&p->d_pattern_weights, std::max<size_t>(4, S * sizeof(unsigned))));
+  TRY(hipMalloc(&p->d_partials, 4096 * sizeof(double)));
+  TRY(hipMalloc(&p->d_result, 64 * sizeof(double)));
+  p->stage_bytes = (size_t)4 << 20;
+  TRY(hipHostMalloc(&p->h_stage, p->stage_bytes, hipHostMallocDefault));
+  TRY(hipHostMalloc(&p->h_result, 64 * sizeof(double), hipHostMallocDefault));
+  TRY(ensure_scratch(p, (size_t)1 << 20));
+  TRY(hipMemsetAsync(p->d_scaler, 0, std::max<size_t>(4, (size_t)scale_buffers * S * sizeof(unsigned)), p->stream));
+  TRY(hipMemsetAsync(p->d_tipcodes, 0, std::max<size_t>(1, (size_t)tips * S), p->stream));
+
+  // defaults as corax_partition_create leaves them: weights 1, rates 1, 1/R
+  p->subst.assign(rate_matrices, std::vector<double>((size_t)K * K - K, 1.0));
+  p->freqs.assign(rate_matrices, std::vector<double>(K, 1.0 / K));
+  p->rates.assign(R, 1.0);
+  p->rate_weights.assign(R, 1.0 / R);
+  p->prop_invar.assign(rate_matrices, 0.0);
+  p->pattern_weights.assign(S, 1u);
+  p->tipcodes.assign((size_t)tips * S, 0);
+  p->q_dirty.assign(rate_matrices, 1);
+  p->codemask.assign(256, 0);
+  if (K == 4) {
+    for (unsigned c = 0; c < 16; ++c) p->codemask[c] = c;
+    p->ncodes = 16;
+  } else {
+    p->ncodes = 0;
+  }
+  TRY(upload(p, p->d_codemask, p->codemask.data(), 256 * sizeof(uint64_t)));
+  TRY(upload(p, p->d_rates, p->rates.data(), R * sizeof(double)));
+  TRY(upload(p, p->d_rate_weights, p->rate_weights.data(), R * sizeof(double)));
+  if (S) TRY(upload(p, p->d_pattern_weights, p->pattern_weights.data(), S * sizeof(unsigned)));
+  TRY(hipStreamSynchronize(p->stream));
+#undef TRY
+  return p;
+}
+
+void rdamd_partition_destroy(rdamd_partition_t *p) {
+  if (!p) return;
+  if (p->stream) (void)hipStreamSynchronize(p->stream);
+  void *dev[] = {p->d_tipcodes, p->d_clv, p->d_scaler, p->d_pmat, p->d_tiptab,
+                 p->d_codemask, p->d_q, p->d_freqs, p->d_rates, p->d_rate_weights,
+                 p->d_pattern_weights, p->d_tipclv_scratch, p->d_scratch,
+                 p->d_partials, p->d_result, p->d_persite};
+  for (void *d : dev)
+    if (d) (void)hipFree(d);
+  if (p->h_stage) (void)hipHostFree(p->h_stage);
+  if (p->h_result) (void)hipHostFree(p->h_result);
+  if (p->stream) (void)hipStreamDestroy(p->stream);
+  delete p;
+}
+
+int rdamd_set_tip_states(rdamd_partition_t *p, unsigned int tip_index,
+                         const uint64_t *map, const char *sequence) {
+  clear_error();
+  if (tip_index >= p->tips) {
+    set_error(3, "rdamd_set_tip_states: tip index %u out of range", tip_index);
+    return RDAMD_FAILURE;
+  }
+  const size_t S = p->sites;
+  uint8_t *row = p->tipcodes.data() + (size_t)tip_index * S;
+  const uint64_t full = p->states == 64 ? ~0ull : ((1ull << p->states) - 1);
+  bool new_code = false;
+  for (size_t s = 0; s < S; ++s) {
+    uint64_t st = map[(unsigned char)sequence[s]];
+    if (!st || (st & ~full)) {
+      set_error(4, "rdamd_set_tip_states: character '%c' (site %zu) has no valid state "
+                   "in the map", sequence[s], s);
+      return RDAMD_FAILURE;
+    }
+    if (p->states == 4) {
+      row[s] = (uint8_t)st;
+    } else {
+      unsigned c = 0;
+      for (; c < p->ncodes; ++c)
+        if (p->codemask[c] == st) break;
+      if (c == p->ncodes) {
+        if (p->ncodes >= p->ncodes_cap) {
+          set_error(5, "rdamd_set_tip_states: more than %u distinct state codes",
+                    p->ncodes_cap);
+          return RDAMD_FAILURE;
+        }
+        p->codemask[p->ncodes++] = st;
+        new_code = true;
+      }
+      row[s] = (uint8_t)c;
+    }
+  }
+  if (new_code) {
+    RDAMD_HIP_TRY(upload(p, p->d_codemask, p->codemask.data(), 256 * sizeof(uint64_t)),
+                  RDAMD_FAILURE);
+    p->tiptab_stale = true;
+  }
+  RDAMD_HIP_TRY(upload(p, p->d_tipcodes + (size_t)tip_index * S, row, S), RDAMD_FAILURE);
+  return RDAMD_SUCCESS;
+}
+
+void rdamd_set_pattern_weights(rdamd_partition_t *p, const unsigned int *w) {
+  p->pattern_weights.assign(w, w + p->sites);
+  (void)upload(p, p->d_pattern_weights, w, sizeof(unsigned) * p->sites);
+}
+
+void rdamd_set_subst_params(rdamd_partition_t *p, unsigned int idx, const double *v) {
+  if (idx >= p->rate_matrices) return;
+  p->subst[idx].assign(v, v + (size_t)p->states * p->states - p->states);
+  p->q_dirty[idx] = 1;
+}
+
+void rdamd_set_frequencies(rdamd_partition_t *p, unsigned int idx, const double *f) {
+  if (idx >= p->rate_matrices) return;
+  p->freqs[idx].assign(f, f + p->states);
+  p->q_dirty[idx] = 1;
+}
+
+void rdamd_set_category_rates(rdamd_partition_t *p, const double *r) {
+  p->rates.assign(r, r + p->rate_cats);
+  (void)upload(p, p->d_rates, r, sizeof(double) * p->rate_cats);
+}
+
+void rdamd_set_category_weights(rdamd_partition_t *p, const double *w) {
+  p->rate_weights.assign(w, w + p->rate_cats);
+  (void)upload(p, p->d_rate_weights, w, sizeof(double) * p->rate_cats);
+}
+
+int rdamd_update_invariant_sites_proportion(rdamd_partition_t *p, unsigned int idx,
+                                            double prop) {
+  clear_error();
+  if (idx >= p->rate_matrices || prop != 0.0) {
+    set_error(6, "rdamd_update_invariant_sites_proportion: only 0.0 is supported (the "
+                 "reference never sets anything else, src/model.cpp:292-300)");
+    return RDAMD_FAILURE;
+  }
+  p->prop_invar[idx] = 0.0;
+  return RDAMD_SUCCESS;
+}
+
+double *rdamd_msa_empirical_frequencies(rdamd_partition_t *p) {
+  const unsigned K = p->states;
+  double *f = (double *)calloc(K, sizeof(double));
+  if (!f) return nullptr;
+  double total = 0.0;
+  for (unsigned s = 0; s < p->sites; ++s) total += p->pattern_weights[s];
+  for (unsigned t = 0; t < p->tips; ++t) {
+    const uint8_t *row = p->tipcodes.data() + (size_t)t * p->sites;
+    for (unsigned s = 0; s < p->sites; ++s) {
+      uint64_t mask = p->codemask[row[s]];
+      double cnt = (double)__builtin_popcountll(mask);
+      if (cnt == 0.0) continue;  // tip never set
+      for (unsigned j = 0; j < K; ++j)
+        if ((mask >> j) & 1) f[j] += p->pattern_weights[s] * 1.0 / cnt;
+    }
+  }
+  for (unsigned j = 0; j < K; ++j) f[j] /= total * p->tips;
+  return f;
+}
+
+unsigned int rdamd_partition_states(const rdamd_partition_t *p) { return p->states; }
+unsigned int rdamd_partition_rate_cats(const rdamd_partition_t *p) { return p->rate_cats; }
+unsigned int rdamd_partition_sites(const rdamd_partition_t *p) { return p->sites; }
+unsigned int rdamd_partition_tips(const rdamd_partition_t *p) { return p->tips; }
+const double *rdamd_partition_subst_params(const rdamd_partition_t *p, unsigned int i) {
+  return i < p->rate_matrices ? p->subst[i].data() : nullptr;
+}
+const double *rdamd_partition_frequencies(const rdamd_partition_t *p, unsigned int i) {
+  return i < p->rate_matrices ? p->freqs[i].data() : nullptr;
+}
+
+int rdamd_update_prob_matrices(rdamd_partition_t *p, const unsigned int *params_indices,
+                               const unsigned int *matrix_indices,
+                               const double *branch_lengths, unsigned int count) {
+  clear_error();
+  if (count == 0) return RDAMD_SUCCESS;
+  const unsigned R = p->rate_cats;
+  for (unsigned r = 0; r < R; ++r)
+    if (params_indices[r] >= p->rate_matrices) {
+      set_error(7, "rdamd_update_prob_matrices: params index %u out of range",
+                params_indices[r]);
+      return RDAMD_FAILURE;
+    }
+  for (unsigned m = 0; m < count; ++m) {
+    if (matrix_indices[m] >= p->prob_matrices) {
+      set_error(8, "rdamd_update_prob_matrices: matrix index %u out of range",
+                matrix_indices[m]);
+      return RDAMD_FAILURE;
+    }
+    if (!(branch_lengths[m] >= 0.0) || !std::isfinite(branch_lengths[m])) {
+      set_error(9, "rdamd_update_prob_matrices: invalid branch length %g for matrix %u",
+                branch_lengths[m], matrix_indices[m]);
+      return RDAMD_FAILURE;
+    }
+  }
+  RDAMD_HIP_TRY(flush_q(p), RDAMD_FAILURE);
+  size_t need = 256 * 3 + sizeof(unsigned) * (R + count) + sizeof(double) * count;
+  RDAMD_HIP_TRY(ensure_scratch(p, need), RDAMD_FAILURE);
+  Scratch sc{p};
+  unsigned *d_pi = (unsigned *)sc.take(sizeof(unsigned) * R);
+  unsigned *d_mi = (unsigned *)sc.take(sizeof(unsigned) * count);
+  double *d_bl = (double *)sc.take(sizeof(double) * count);
+  RDAMD_HIP_TRY(upload(p, d_pi, params_indices, sizeof(unsigned) * R), RDAMD_FAILURE);
+  RDAMD_HIP_TRY(upload(p, d_mi, matrix_indices, sizeof(unsigned) * count), RDAMD_FAILURE);
+  RDAMD_HIP_TRY(upload(p, d_bl, branch_lengths, sizeof(double) * count), RDAMD_FAILURE);
+  RDAMD_HIP_TRY(launch_pmatrix(p, d_pi, d_mi, d_bl, count), RDAMD_FAILURE);
+  return RDAMD_SUCCESS;
+}
+
+void rdamd_update_clvs(rdamd_partition_t *p, const rdamd_operation_t *ops,
+                       unsigned int count) {
+  clear_error();
+  if (count == 0) return;
+  const unsigned nclv = p->tips + p->clv_buffers;
+  // dependency levels: an op sits one level above the latest op (of this call)
+  // that produces one of its children.
+  std::unordered_map<unsigned, unsigned> produced;  // clv index -> level
+  std::unordered_map<unsigned, unsigned> last_read; // clv index -> latest reader level
+  std::vector<unsigned> level(count);
+  unsigned nlevels = 0;
+  for (unsigned i = 0; i < count; ++i) {
+    const rdamd_operation_t &o = ops[i];
+    if (o.parent_clv_index < p->tips || o.parent_clv_index >= nclv ||
+        o.child1_clv_index >= nclv || o.child2_clv_index >= nclv ||
+        o.child1_matrix_index >= p->prob_matrices ||
+        o.child2_matrix_index >= p->prob_matrices ||
+        o.parent_scaler_index >= (int)p->scale_buffers ||
+        o.child1_scaler_index >= (int)p->scale_buffers ||
+        o.child2_scaler_index >= (int)p->scale_buffers) {
+      set_error(10, "rdamd_update_clvs: operation %u has an index out of range", i);
+      return;
+    }
+    unsigned l = 0;
+    auto it = produced.find(o.child1_clv_index);
+    if (it != produced.end()) l = std::max(l, it->second + 1);
+    it = produced.find(o.child2_clv_index);
+    if (it != produced.end()) l = std::max(l, it->second + 1);
+    // a buffer rewritten later in the same call must wait for its readers too
+    it = produced.find(o.parent_clv_index);
+    if (it != produced.end()) l = std::max(l, it->second + 1);
+    it = last_read.find(o.parent_clv_index);
+    if (it != last_read.end()) l = std::max(l, it->second + 1);
+    level[i] = l;
+    produced[o.parent_clv_index] = l;
+    for (unsigned c : {o.child1_clv_index, o.child2_clv_index}) {
+      auto rit = last_read.find(c);
+      if (rit == last_read.end() || rit->second < l) last_read[c] = l;
+    }
+    nlevels = std::max(nlevels, l + 1);
+  }
+  std::vector<unsigned> order(count);
+  for (unsigned i = 0; i < count; ++i) order[i] = i;
+  std::stable_sort(order.begin(), order.end(),
+                   [&](unsigned a, unsigned b) { return level[a] < level[b]; });
+  std::vector<LevelOp> lops(count);
+  std::vector<unsigned> level_start(nlevels + 1, 0);
+  for (unsigned k = 0; k < count; ++k) {
+    const rdamd_operation_t &o = ops[order[k]];
+    LevelOp &d = lops[k];
+    d.parent_clv = o.parent_clv_index; d.child1_clv = o.child1_clv_index;
+    d.child2_clv = o.child2_clv_index; d.child1_mat = o.child1_matrix_index;
+    d.child2_mat = o.child2_matrix_index; d.parent_sc = o.parent_scaler_index;
+    d.child1_sc = o.child1_scaler_index; d.child2_sc = o.child2_scaler_index;
+    level_start[level[order[k]] + 1] = k + 1;
+  }
+  for (unsigned l = 1; l <= nlevels; ++l)
+    level_start[l] = std::max(level_start[l], level_start[l - 1]);
+
+  hipError_t e = ensure_scratch(p, sizeof(LevelOp) * count + 256);
+  if (e == hipSuccess && p->tiptab_stale) {
+    e = launch_tiptab_all(p);
+    p->tiptab_stale = false;
+  }
+  Scratch sc{p};
+  LevelOp *d_ops = nullptr;
+  if (e == hipSuccess) {
+    d_ops = (LevelOp *)sc.take(sizeof(LevelOp) * count);
+    e = upload(p, d_ops, lops.data(), sizeof(LevelOp) * count);
+  }
+  for (unsigned l = 0; l < nlevels && e == hipSuccess; ++l) {
+    unsigned b = level_start[l], n = level_start[l + 1] - b;
+    // gridDim.y is limited to 65535
+    for (unsigned off = 0; off < n && e == hipSuccess; off += 32768)
+      e = launch_clv_level(p, d_ops + b + off, std::min(32768u, n - off));
+  }
+  if (e != hipSuccess)
+    set_error(100 + (int)e, "rdamd_update_clvs: %s", hipGetErrorString(e));
+}
+
+double rdamd_compute_root_loglikelihood(rdamd_partition_t *p, unsigned int clv_index,
+                                        int scaler_index,
+                                        const unsigned int *freqs_indices,
+                                        double *persite_lnl) {
+  clear_error();
+  const double nan = std::nan("");
+  if (clv_index < p->tips || clv_index >= p->tips + p->clv_buffers ||
+      scaler_index >= (int)p->scale_buffers) {
+    set_error(11, "rdamd_compute_root_loglikelihood: index out of range (clv %u, scaler %d)",
+              clv_index, scaler_index);
+    return nan;
+  }
+  for (unsigned r = 0; r < p->rate_cats; ++r)
+    if (freqs_indices[r] >= p->rate_matrices) {
+      set_error(7, "rdamd_compute_root_loglikelihood: freqs index out of range");
+      return nan;
+    }
+  RDAMD_HIP_TRY(flush_q(p), nan);
+  RDAMD_HIP_TRY(ensure_scratch(p, 1024 + sizeof(unsigned) * p->rate_cats), nan);
+  Scratch sc{p};
+  unsigned *d_fi = (unsigned *)sc.take(sizeof(unsigned) * p->rate_cats);
+  RDAMD_HIP_TRY(upload(p, d_fi, freqs_indices, sizeof(unsigned) * p->rate_cats), nan);
+  if (persite_lnl && !p->d_persite)
+    RDAMD_HIP_TRY(hipMalloc(&p->d_persite, std::max<size_t>(8, sizeof(double) * p->sites)), nan);
+  RDAMD_HIP_TRY(launch_root_lnl(p, clv_index, scaler_index, d_fi,
+                                persite_lnl ? p->d_persite : nullptr, p->d_result), nan);
+  RDAMD_HIP_TRY(hipMemcpyAsync(p->h_result, p->d_result, sizeof(double),
+                               hipMemcpyDeviceToHost, p->stream), nan);
+  RDAMD_HIP_TRY(hipStreamSynchronize(p->stream), nan);
+  if (persite_lnl)
+    RDAMD_HIP_TRY(hipMemcpy(persite_lnl, p->d_persite, sizeof(double) * p->sites,
+                            hipMemcpyDeviceToHost), nan);
+  return p->h_result[0];
+}
+
+int rdamd_root_loglikelihood_fused(rdamd_partition_t *p, const rdamd_operation_t *root_op,
+                                   const unsigned int *params_indices,
+                                   const double *lengths1, const double *lengths2,
+                                   unsigned int n_alpha, double *lnl_out) {
+  // First form: the three calls queued back to back on the partition stream
+  // (no host round trip between them except the final value).
+  for (unsigned a = 0; a < n_alpha; ++a) {
+    unsigned mi[2] = {root_op->child1_matrix_index, root_op->child2_matrix_index};
+    double bl[2] = {lengths1[a], lengths2[a]};
+    if (rdamd_update_prob_matrices(p, params_indices, mi, bl, 2) != RDAMD_SUCCESS)
+      return RDAMD_FAILURE;
+    rdamd_update_clvs(p, root_op, 1);
+    if (rdamd_errno()) return RDAMD_FAILURE;
+    lnl_out[a] = rdamd_compute_root_loglikelihood(
+        p, root_op->parent_clv_index, root_op->parent_scaler_index, params_indices, nullptr);
+    if (rdamd_errno()) return RDAMD_FAILURE;
+  }
+  return RDAMD_SUCCESS;
+}
+
+int rdamd_get_clv(rdamd_partition_t *p, unsigned int clv_index, double *out) {
+  clear_error();
+  const size_t S = p->sites, R = p->rate_cats, K = p->states;
+  if (clv_index < p->tips) {  // tips live as codes; expand on the host
+    const uint8_t *row = p->tipcodes.data() + (size_t)clv_index * S;
+    for (size_t s = 0; s < S; ++s) {
+      uint64_t mask = p->codemask[row[s]];
+      for (size_t r = 0; r < R; ++r)
+        for (size_t j = 0; j < K; ++j) out[(s * R + r) * K + j] = (double)((mask >> j) & 1);
+    }
+    return RDAMD_SUCCESS;
+  }
+  if (clv_index >= p->tips + p->clv_buffers) {
+    set_error(11, "rdamd_get_clv: index out of range");
+    return RDAMD_FAILURE;
+  }
+  RDAMD_HIP_TRY(hipStreamSynchronize(p->stream), RDAMD_FAILURE);
+  RDAMD_HIP_TRY(hipMemcpy(out, p->d_clv + (size_t)(clv_index - p->tips) * S * R * K,
+                          sizeof(double) * S * R * K, hipMemcpyDeviceToHost), RDAMD_FAILURE);
+  return RDAMD_SUCCESS;
+}
+
+int rdamd_get_scaler(rdamd_partition_t *p, unsigned int scaler_index, unsigned int *out) {
+  clear_error();
+  if (scaler_index >= p->scale_buffers) {
+    set_error(11, "rdamd_get_scaler: index out of range");
+    return RDAMD_FAILURE;
+  }
+  RDAMD_HIP_TRY(hipStreamSynchronize(p->stream), RDAMD_FAILURE);
+  RDAMD_HIP_TRY(hipMemcpy(out, p->d_scaler + (size_t)scaler_index * p->sites,
+                          sizeof(unsigned) * p->sites, hipMemcpyDeviceToHost), RDAMD_FAILURE);
+  return RDAMD_SUCCESS;
+}
+
+int rdamd_get_pmatrix(rdamd_partition_t *p, unsigned int matrix_index, double *out) {
+  clear_error();
+  if (matrix_index >= p->prob_matrices) {
+    set_error(8, "rdamd_get_pmatrix: index out of range");
+    return RDAMD_FAILURE;
+  }
+  const size_t n = (size_t)p->rate_cats * p->states * p->states;
+  RDAMD_HIP_TRY(hipStreamSynchronize(p->stream), RDAMD_FAILURE);
+  RDAMD_HIP_TRY(hipMemcpy(out, p->d_pmat + (size_t)matrix_index * n, sizeof(double) * n,
+                          hipMemcpyDeviceToHost), RDAMD_FAILURE);
+  return RDAMD_SUCCESS;
+}
+
+void rdamd_partition_sync(rdamd_partition_t *p) {
+  if (p && p->stream) (void)hipStreamSynchronize(p->stream);
+}
+
+}  // extern "C"
