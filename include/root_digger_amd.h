@@ -163,6 +163,15 @@ int rdamd_get_scaler(rdamd_partition_t *p, unsigned int scaler_index,
 int rdamd_get_pmatrix(rdamd_partition_t *p, unsigned int matrix_index,
                       double *out);
 
+/* Measurement hooks (bench.py): while enabled, every kernel launch of the
+ * partition is bracketed by HIP events on the partition's stream.
+ * rdamd_profile_read synchronises, returns accumulated kernel milliseconds and
+ * launch counts per kernel family {0: CLV level, 1: P-matrix, 2: root lnL},
+ * and resets the accumulators. */
+void rdamd_profile_enable(rdamd_partition_t *p, int on);
+int  rdamd_profile_read(rdamd_partition_t *p, double ms_out[3],
+                        unsigned int launches_out[3]);
+
 /* blocks until all queued device work of the partition has finished. */
 void rdamd_partition_sync(rdamd_partition_t *p);
 
@@ -242,6 +251,9 @@ extern const uint64_t rdamd_map_bin[256];
 /* library / device info */
 const char *rdamd_version(void);
 int         rdamd_device_count(void);
+/* selects the HIP device later rdamd_partition_create calls of this thread use
+ * (one process per GPU: call with LOCAL_RANK). */
+int         rdamd_set_device(int device);
 
 #ifdef __cplusplus
 }

@@ -19,10 +19,11 @@ from .api import (  # noqa: F401
     GAMMA_RATES_MEAN,
     GAMMA_RATES_MEDIAN,
     device_count,
+    set_device,
 )
 
 __all__ = [
     "lib", "lib_path", "RdamdError", "Operation", "RootLocation", "Tree", "Partition",
     "MAP_NT", "MAP_BIN", "compute_gamma_cats", "GAMMA_RATES_MEAN", "GAMMA_RATES_MEDIAN",
-    "device_count",
+    "device_count", "set_device",
 ]

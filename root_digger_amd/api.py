@@ -61,6 +61,7 @@ _errno = _sig("rdamd_errno", C.c_int)
 _errmsg = _sig("rdamd_errmsg", C.c_char_p)
 _sig("rdamd_version", C.c_char_p)
 _sig("rdamd_device_count", C.c_int)
+_sig("rdamd_set_device", C.c_int, C.c_int)
 
 _sig("rdamd_partition_create", _vp, _u, _u, _u, _u, _u, _u, _u, _u, _u)
 _sig("rdamd_partition_destroy", None, _vp)
@@ -87,6 +88,8 @@ _sig("rdamd_get_clv", C.c_int, _vp, _u, _pd)
 _sig("rdamd_get_scaler", C.c_int, _vp, _u, _pu)
 _sig("rdamd_get_pmatrix", C.c_int, _vp, _u, _pd)
 _sig("rdamd_partition_sync", None, _vp)
+_sig("rdamd_profile_enable", None, _vp, C.c_int)
+_sig("rdamd_profile_read", C.c_int, _vp, _pd, _pu)
 
 _sig("rdamd_tree_from_file", _vp, C.c_char_p)
 _sig("rdamd_tree_from_newick", _vp, C.c_char_p)
@@ -133,6 +136,11 @@ def _take_string(ptr):
 
 def device_count():
     return lib.rdamd_device_count()
+
+
+def set_device(device):
+    if lib.rdamd_set_device(int(device)) != 1:
+        _fail("set_device")
 
 
 def compute_gamma_cats(alpha, cats, mode=GAMMA_RATES_MEAN):
@@ -410,3 +418,15 @@ class Partition:
 
     def sync(self):
         lib.rdamd_partition_sync(self._h)
+
+    def profile_enable(self, on=True):
+        lib.rdamd_profile_enable(self._h, 1 if on else 0)
+
+    def profile_read(self):
+        """-> {family: (kernel ms, launches)} measured with HIP events on the
+        partition stream; resets the accumulators."""
+        ms = (C.c_double * 3)()
+        n = (C.c_uint * 3)()
+        if lib.rdamd_profile_read(self._h, ms, n) != 1:
+            _fail("profile_read")
+        return {"clv": (ms[0], n[0]), "pmatrix": (ms[1], n[1]), "root": (ms[2], n[2])}

@@ -76,6 +76,14 @@ struct rdamd_partition {
   char     *h_stage = nullptr;    // pinned staging ring for small H2D copies
   size_t    stage_bytes = 0, stage_off = 0;
 
+  // ---- measurement (rdamd_profile_*) -----------------------------------------
+  struct ProfSpan { hipEvent_t a, b; int kind; };
+  std::vector<ProfSpan> prof_spans;
+  std::vector<hipEvent_t> prof_pool;
+  bool profiling = false;
+  hipEvent_t prof_begin(int kind);
+  void prof_end();
+
   // ---- host mirrors --------------------------------------------------------
   std::vector<std::vector<double>> subst, freqs;
   std::vector<double> rates, rate_weights, prop_invar;

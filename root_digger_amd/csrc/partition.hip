@@ -93,6 +93,22 @@ static hipError_t flush_q(rdamd_partition *p) {
 
 }  // namespace rdamd
 
+hipEvent_t rdamd_partition::prof_begin(int kind) {
+  if (!profiling) return nullptr;
+  hipEvent_t ev[2];
+  for (auto &e : ev) {
+    if (!prof_pool.empty()) { e = prof_pool.back(); prof_pool.pop_back(); }
+    else if (hipEventCreate(&e) != hipSuccess) return nullptr;
+  }
+  (void)hipEventRecord(ev[0], stream);
+  prof_spans.push_back({ev[0], ev[1], kind});
+  return ev[1];
+}
+void rdamd_partition::prof_end() {
+  if (!profiling || prof_spans.empty()) return;
+  (void)hipEventRecord(prof_spans.back().b, stream);
+}
+
 using namespace rdamd;
 
 extern "C" {
@@ -105,6 +121,12 @@ int rdamd_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;
   return n;
+}
+
+int rdamd_set_device(int device) {
+  clear_error();
+  RDAMD_HIP_TRY(hipSetDevice(device), RDAMD_FAILURE);
+  return RDAMD_SUCCESS;
 }
 
 #define NT(ch, v) [ch] = v, [ch + 32] = v
@@ -203,6 +225,8 @@ void rdamd_partition_destroy(rdamd_partition_t *p) {
                  p->d_partials, p->d_result, p->d_persite};
   for (void *d : dev)
     if (d) (void)hipFree(d);
+  for (auto &sp : p->prof_spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
+  for (auto &e : p->prof_pool) (void)hipEventDestroy(e);
   if (p->h_stage) (void)hipHostFree(p->h_stage);
   if (p->h_result) (void)hipHostFree(p->h_result);
   if (p->stream) (void)hipStreamDestroy(p->stream);
@@ -358,7 +382,10 @@ int rdamd_update_prob_matrices(rdamd_partition_t *p, const unsigned int *params_
   RDAMD_HIP_TRY(upload(p, d_pi, params_indices, sizeof(unsigned) * R), RDAMD_FAILURE);
   RDAMD_HIP_TRY(upload(p, d_mi, matrix_indices, sizeof(unsigned) * count), RDAMD_FAILURE);
   RDAMD_HIP_TRY(upload(p, d_bl, branch_lengths, sizeof(double) * count), RDAMD_FAILURE);
-  RDAMD_HIP_TRY(launch_pmatrix(p, d_pi, d_mi, d_bl, count), RDAMD_FAILURE);
+  p->prof_begin(1);
+  hipError_t le = launch_pmatrix(p, d_pi, d_mi, d_bl, count);
+  p->prof_end();
+  RDAMD_HIP_TRY(le, RDAMD_FAILURE);
   return RDAMD_SUCCESS;
 }
 
@@ -435,8 +462,11 @@ void rdamd_update_clvs(rdamd_partition_t *p, const rdamd_operation_t *ops,
   for (unsigned l = 0; l < nlevels && e == hipSuccess; ++l) {
     unsigned b = level_start[l], n = level_start[l + 1] - b;
     // gridDim.y is limited to 65535
-    for (unsigned off = 0; off < n && e == hipSuccess; off += 32768)
+    for (unsigned off = 0; off < n && e == hipSuccess; off += 32768) {
+      p->prof_begin(0);
       e = launch_clv_level(p, d_ops + b + off, std::min(32768u, n - off));
+      p->prof_end();
+    }
   }
   if (e != hipSuccess)
     set_error(100 + (int)e, "rdamd_update_clvs: %s", hipGetErrorString(e));
@@ -466,8 +496,11 @@ double rdamd_compute_root_loglikelihood(rdamd_partition_t *p, unsigned int clv_i
   RDAMD_HIP_TRY(upload(p, d_fi, freqs_indices, sizeof(unsigned) * p->rate_cats), nan);
   if (persite_lnl && !p->d_persite)
     RDAMD_HIP_TRY(hipMalloc(&p->d_persite, std::max<size_t>(8, sizeof(double) * p->sites)), nan);
-  RDAMD_HIP_TRY(launch_root_lnl(p, clv_index, scaler_index, d_fi,
-                                persite_lnl ? p->d_persite : nullptr, p->d_result), nan);
+  p->prof_begin(2);
+  hipError_t le = launch_root_lnl(p, clv_index, scaler_index, d_fi,
+                                  persite_lnl ? p->d_persite : nullptr, p->d_result);
+  p->prof_end();
+  RDAMD_HIP_TRY(le, nan);
   RDAMD_HIP_TRY(hipMemcpyAsync(p->h_result, p->d_result, sizeof(double),
                                hipMemcpyDeviceToHost, p->stream), nan);
   RDAMD_HIP_TRY(hipStreamSynchronize(p->stream), nan);
@@ -541,6 +574,30 @@ int rdamd_get_pmatrix(rdamd_partition_t *p, unsigned int matrix_index, double *o
   RDAMD_HIP_TRY(hipStreamSynchronize(p->stream), RDAMD_FAILURE);
   RDAMD_HIP_TRY(hipMemcpy(out, p->d_pmat + (size_t)matrix_index * n, sizeof(double) * n,
                           hipMemcpyDeviceToHost), RDAMD_FAILURE);
+  return RDAMD_SUCCESS;
+}
+
+void rdamd_profile_enable(rdamd_partition_t *p, int on) {
+  (void)hipStreamSynchronize(p->stream);
+  for (auto &sp : p->prof_spans) { p->prof_pool.push_back(sp.a); p->prof_pool.push_back(sp.b); }
+  p->prof_spans.clear();
+  p->profiling = on != 0;
+}
+
+int rdamd_profile_read(rdamd_partition_t *p, double ms_out[3], unsigned int launches_out[3]) {
+  clear_error();
+  RDAMD_HIP_TRY(hipStreamSynchronize(p->stream), RDAMD_FAILURE);
+  for (int k = 0; k < 3; ++k) { ms_out[k] = 0.0; launches_out[k] = 0; }
+  for (auto &sp : p->prof_spans) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, sp.a, sp.b) == hipSuccess && sp.kind >= 0 && sp.kind < 3) {
+      ms_out[sp.kind] += ms;
+      launches_out[sp.kind] += 1;
+    }
+    p->prof_pool.push_back(sp.a);
+    p->prof_pool.push_back(sp.b);
+  }
+  p->prof_spans.clear();
   return RDAMD_SUCCESS;
 }
 

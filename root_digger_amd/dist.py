@@ -1,0 +1,55 @@
+"""Work partitioning for one-process-per-GPU runs.
+
+Candidate roots are split across ranks exactly as the reference splits them
+across MPI ranks (assign_indicies_by_rank_exhaustive,
+/root/reference/src/model.cpp:1867-1911: contiguous chunks, the first
+`mod` ranks take one extra).  Site blocks (new here) are
+contiguous slices of the pattern axis; their per-block log-likelihoods are
+summed with one all-reduce per batch of evaluations (RCCL on GPUs, gloo in
+the CPU tests)."""
+
+
+def chunk(count, rank, num_tasks):
+    """[beg, end) of `count` items for `rank` (src/model.cpp:1899-1907)."""
+    size, mod = count // num_tasks, count % num_tasks
+    beg = size * rank + min(mod, rank)
+    end = size * (rank + 1) + min(mod, rank + 1)
+    return beg, end
+
+
+def assign_candidates(root_count, rank, num_tasks, completed=()):
+    """Root ids this rank evaluates; `completed` ids (a resumed run) are removed
+    before chunking, as the reference does."""
+    done = set(completed)
+    left = [i for i in range(root_count) if i not in done]
+    beg, end = chunk(len(left), rank, num_tasks)
+    return left[beg:end]
+
+
+def site_block(n_sites, rank, num_tasks):
+    return chunk(n_sites, rank, num_tasks)
+
+
+def grid_2d(world_size, site_groups):
+    """BASELINE config c5: candidate groups x site shards.  Returns
+    (candidate_groups, site_groups) with candidate_groups*site_groups == world."""
+    if world_size % site_groups:
+        raise ValueError("site_groups must divide the world size")
+    return world_size // site_groups, site_groups
+
+
+def rank_coords(rank, site_groups):
+    """-> (candidate group index, site shard index) of a rank; ranks that share
+    a candidate group are adjacent so their all-reduce stays on neighbouring
+    xGMI links."""
+    return rank // site_groups, rank % site_groups
+
+
+def allreduce_lnl(values, group=None):
+    """Sum per-block log-likelihoods over the ranks of `group` in place.
+    `values` is a torch tensor (device tensor with RCCL, CPU tensor with gloo);
+    the sum order is fixed by the collective, so repeated calls are
+    bit-identical for a fixed world."""
+    import torch.distributed as dist
+    dist.all_reduce(values, op=dist.ReduceOp.SUM, group=group)
+    return values

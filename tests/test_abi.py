@@ -1,0 +1,70 @@
+"""The C-ABI library loads on a CPU-only box and exports every symbol that
+include/root_digger_amd.h declares (no compute calls are made here)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+import root_digger_amd as rd
+import util
+
+HEADER = os.path.join(util.ROOT, "include", "root_digger_amd.h")
+
+
+def declared_symbols():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    funcs = set(re.findall(r"\b(rdamd_[a-z0-9_]+)\s*\(", text))
+    data = set(re.findall(r"extern\s+const\s+\w+\s+(rdamd_[a-z0-9_]+)\s*\[", text))
+    return funcs, data
+
+
+def test_every_declared_symbol_is_exported():
+    funcs, data = declared_symbols()
+    assert len(funcs) >= 50
+    lib = ctypes.CDLL(rd.lib_path)
+    missing = [s for s in sorted(funcs | data) if not hasattr(lib, s)]
+    assert not missing, missing
+
+
+def test_no_torch_types_in_the_abi():
+    text = open(HEADER).read()
+    assert "torch" not in text.lower().replace("no torch", "")
+    assert "hipStream_t" not in text and "at::" not in text
+
+
+def test_header_cites_reference_interfaces():
+    text = open(HEADER).read()
+    assert text.count("src/model.cpp") >= 15 and text.count("src/tree.cpp") >= 8
+
+
+def test_partition_create_fails_loudly_without_gpu():
+    if rd.device_count() > 0:
+        pytest.skip("GPU present")
+    with pytest.raises(rd.RdamdError) as e:
+        rd.Partition(4, 6, 4, 10, 1, 6, 1, 6)
+    assert "no CPU fallback" in str(e.value)
+
+
+def test_product_does_not_link_the_oracle():
+    import subprocess
+    out = subprocess.run(["ldd", rd.lib_path], capture_output=True, text=True).stdout
+    assert "oracle" not in out
+    for root, _, files in os.walk(os.path.join(util.ROOT, "root_digger_amd")):
+        if "/build" in root:
+            continue
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".hpp", ".h")):
+                src = open(os.path.join(root, f), errors="ignore").read()
+                assert "rd_oracle" not in src and "oracle_lib" not in src, f
+
+
+def test_host_side_gamma_and_maps_work_without_gpu():
+    r = rd.compute_gamma_cats(1.0, 4)
+    assert abs(sum(r) / 4 - 1.0) < 1e-12
+    assert rd.MAP_NT[ord("A")] == 1 and rd.MAP_NT[ord("t")] == 8 and rd.MAP_NT[ord("-")] == 15
+    for g in util.golden("gamma.json"):
+        got = rd.compute_gamma_cats(g["alpha"], g["cats"],
+                                    rd.GAMMA_RATES_MEAN if g["mode"] == "mean" else rd.GAMMA_RATES_MEDIAN)
+        assert max(abs(a - b) for a, b in zip(got, g["rates"])) < 2e-9

@@ -1,0 +1,323 @@
+"""Parity tests proper: the HIP path (through the C ABI, librdamd.so) against the
+CPU oracle on the same inputs, against the committed golden vectors, and --
+at BASELINE.json's full c2 size -- through size-independent properties.
+
+Tolerances: P-matrices 1e-13 absolute; CLVs 1e-12 relative; scalers and every
+index bit-exact; lnL <= 1e-11 relative vs the oracle (north_star demands
+<= 1e-9 relative) and <= 1e-10 vs the SciPy goldens."""
+import math
+import os
+
+import numpy as np
+import pytest
+
+import root_digger_amd as rd
+from root_digger_amd import synth
+from oracle_lib import OraclePartition, ORC_MAP_NT
+import util
+
+pytestmark = pytest.mark.gpu
+
+LNL_TOL = 1e-11
+PARAMS = util.golden("ten_fasta.json")["cases"][0]["subst"], [.34, .42, .24, .74, .16, .88, .75, .54, .20, .06, .08, .41]
+
+
+def pair(tree, seqs, K, R, cmap_gpu=None, cmap_orc=None, weights=None):
+    nsites = len(next(iter(seqs.values())))
+    g = rd.Partition.for_tree(tree, K, nsites, R)
+    o = OraclePartition.for_tree(tree, K, nsites, R)
+    util.load_tips(g, tree, seqs, cmap_gpu or rd.MAP_NT, weights)
+    util.load_tips(o, tree, seqs, cmap_orc or ORC_MAP_NT, weights)
+    return g, o
+
+
+def set_model(parts, subst, freqs, rates, weights=None):
+    for p in parts:
+        p.set_subst_params(0, subst)
+        p.set_frequencies(0, freqs)
+        p.set_category_rates(rates)
+        if weights is not None:
+            p.set_category_weights(weights)
+
+
+def compare_state(g, o, ops, tree, clv_rtol=1e-12):
+    """every CLV and scaler an op list produced, GPU vs oracle."""
+    for op in ops:
+        a, b = g.get_clv(op.parent_clv_index), o.get_clv(op.parent_clv_index)
+        assert np.allclose(a, b, rtol=clv_rtol, atol=0.0), op.parent_clv_index
+        if op.parent_scaler_index >= 0:
+            assert np.array_equal(g.get_scaler(op.parent_scaler_index),
+                                  o.get_scaler(op.parent_scaler_index))
+
+
+def test_library_reports_a_device():
+    assert rd.device_count() >= 1
+
+
+@pytest.mark.parametrize("K,R", [(4, 1), (4, 4), (20, 4), (2, 2), (5, 3)])
+def test_prob_matrices(K, R):
+    rng = np.random.default_rng(7 + K)
+    nm = 37
+    g = rd.Partition(5, 8, K, 16, 1, nm, R, 8)
+    o = OraclePartition(5, 8, K, 16, 1, nm, R, 8)
+    subst = rng.uniform(1e-4, 1, K * K - K)
+    freqs = rng.dirichlet(np.ones(K) * 4)
+    rates = rd.compute_gamma_cats(0.6, R) if R > 1 else [1.0]
+    set_model((g, o), subst, freqs, rates)
+    idx = rng.permutation(nm).astype(np.uint32)
+    bl = np.concatenate([[0.0, 1e-8, 1e-6, 25.0], rng.exponential(0.3, nm - 4)])
+    g.update_prob_matrices(idx, bl)
+    o.update_prob_matrices(idx, bl)
+    for m in range(nm):
+        a, b = g.get_pmatrix(m), o.get_pmatrix(m)
+        assert np.max(np.abs(a - b)) < 1e-13
+        assert np.all(a >= 0.0)
+        assert np.allclose(a.sum(axis=2), 1.0, atol=1e-12)
+
+
+def test_gamma_cats_match_goldens():
+    for gm in util.golden("gamma.json"):
+        got = rd.compute_gamma_cats(gm["alpha"], gm["cats"],
+                                    rd.GAMMA_RATES_MEAN if gm["mode"] == "mean" else rd.GAMMA_RATES_MEDIAN)
+        assert np.allclose(got, gm["rates"], rtol=2e-9, atol=1e-12)
+
+
+@pytest.mark.parametrize("compressed", [False, True])
+def test_c1_ten_fasta_all_roots(compressed):
+    """BASELINE config c1 on the reference's own fixture, every root, every
+    parameter set of test/src/model.cpp:12-17."""
+    tree = rd.Tree.from_file(os.path.join(util.DATA, "10.tree"))
+    seqs = util.read_fasta(os.path.join(util.DATA, "10.fasta"))
+    weights = None
+    if compressed:
+        seqs, weights = util.compress(seqs)
+    gold = util.golden("ten_fasta.json")
+    parts = {}
+    for case in gold["cases"]:
+        R = case["rate_cats"]
+        if R not in parts:
+            parts[R] = pair(tree, seqs, 4, R, weights=weights)
+            assert np.allclose(parts[R][0].empirical_frequencies(), gold["empirical_freqs"], rtol=1e-12)
+        g, o = parts[R]
+        set_model((g, o), case["subst"], case["freqs"], case["rates"], [1.0 / R] * R)
+        for k, root in enumerate(case["roots"]):
+            rl = util.find_root(tree, root["near_tips"], root["far_tips"], root["alpha"])
+            a = util.compute_lh(g, tree, rl)
+            b = util.compute_lh(o, tree, rl)
+            assert util.rel_err(a, b) < LNL_TOL
+            assert util.rel_err(a, root["lnl"]) < 1e-10
+            assert a == util.compute_lh(g, tree, rl)            # test/src/model.cpp:73
+            assert util.rel_err(util.compute_lh_root(g, tree, rl), a) < 1e-13   # :285-286
+            if k % 5 == 0:
+                ops, _, _ = tree.generate_operations(rl)
+                compare_state(g, o, ops, tree)
+
+
+def test_hundred_one_ambiguity_and_move_root():
+    tree = rd.Tree.from_file(os.path.join(util.DATA, "101.tree"))
+    seqs, weights = util.compress(util.read_phylip(os.path.join(util.DATA, "101.phy")))
+    gold = util.golden("hundred_one.json")
+    for case in gold["cases"]:
+        R = case["rate_cats"]
+        g, o = pair(tree, seqs, 4, R, weights=weights)
+        set_model((g, o), case["subst"], case["freqs"], case["rates"])
+        for root in case["roots"]:
+            rl = util.find_root(tree, root["near_tips"], root["far_tips"], root["alpha"])
+            a, b = util.compute_lh(g, tree, rl), util.compute_lh(o, tree, rl)
+            assert util.rel_err(a, b) < LNL_TOL
+            assert util.rel_err(a, root["lnl"]) < 1e-10
+        # compute_all_root_lh (src/model.cpp:1737-1746): move_root sweep
+        first = util.compute_lh(g, tree, tree.root_location(0))
+        util.compute_lh(o, tree, tree.root_location(0))
+        t2 = rd.Tree.from_file(os.path.join(util.DATA, "101.tree"))
+        t2.root_by(t2.root_location(0))
+        for rl in tree.roots():
+            util.move_root(g, tree, rl)
+            a = util.compute_lh_root(g, tree, rl)
+            util.move_root(o, t2, rl)
+            b = util.compute_lh_root(o, t2, rl)
+            assert util.rel_err(a, b) < LNL_TOL
+            if case["name"] == "jc":     # test/src/model.cpp:367-387
+                assert abs(a - first) < 1e-7 * abs(first)
+        g.destroy()
+        o.destroy()
+
+
+def test_deep_tree_scalers_bit_exact():
+    gd = util.golden("deep_scaling.json")
+    tree = rd.Tree.from_newick(gd["newick"])
+    g, o = pair(tree, gd["seqs"], 4, 4)
+    set_model((g, o), gd["subst"], gd["freqs"], gd["rates"])
+    rl = tree.root_location(0)
+    ops, pmi, brl = tree.generate_operations(rl)
+    for p in (g, o):
+        p.update_prob_matrices(pmi, brl)
+        p.update_clvs(ops)
+    compare_state(g, o, ops, tree)
+    assert o.get_scaler(tree.root_scaler_index()).max() >= 1
+    a, pa = g.compute_root_loglikelihood(tree.root_clv_index(), tree.root_scaler_index(), persite=True)
+    b, pb = o.compute_root_loglikelihood(tree.root_clv_index(), tree.root_scaler_index(), persite=True)
+    assert util.rel_err(a, b) < LNL_TOL
+    assert np.allclose(pa, pb, rtol=1e-12)
+    # golden lnL for its own rooting
+    for cand in tree.roots():
+        if sorted(tree.side_tips(cand)) == sorted(gd["near_tips"]):
+            assert util.rel_err(util.compute_lh(g, tree, cand.with_ratio(gd["alpha"])), gd["lnl"]) < 1e-10
+
+
+def test_protein20_generic_path():
+    gd = util.golden("protein20.json")
+    tree = rd.Tree.from_newick(gd["newick"])
+    aa = gd["alphabet"]
+    extra = {"X": (1 << 20) - 1, "B": (1 << aa.index("N")) | (1 << aa.index("D"))}
+    cmap = util.make_map(aa, extra)
+    g, o = pair(tree, gd["seqs"], 20, 4, cmap, cmap)
+    set_model((g, o), gd["subst"], gd["freqs"], gd["rates"])
+    for k, root in enumerate(gd["roots"]):
+        rl = util.find_root(tree, root["near_tips"], root["far_tips"], root["alpha"])
+        a, b = util.compute_lh(g, tree, rl), util.compute_lh(o, tree, rl)
+        assert util.rel_err(a, b) < LNL_TOL
+        assert util.rel_err(a, root["lnl"]) < 1e-10
+        if k == 0:
+            ops, _, _ = tree.generate_operations(rl)
+            compare_state(g, o, ops, tree)
+
+
+@pytest.mark.parametrize("n,S,K,R,seed", [
+    (100, 3000, 4, 4, 11),      # c2 shape, oracle-sized
+    (60, 1531, 4, 1, 12),       # ragged site count, no rate het
+    (33, 777, 4, 2, 13),
+    (40, 513, 4, 8, 14),
+    (25, 300, 20, 4, 15),       # c3 shape
+    (12, 1, 4, 4, 16),          # a single site
+    (9, 65, 3, 3, 17),          # odd K, odd R -> generic kernels
+])
+def test_synthetic_vs_oracle(n, S, K, R, seed):
+    w = synth.workload(n, S, K, R, seed)
+    tree = rd.Tree.from_newick(w["newick"])
+    cmap = rd.MAP_NT if K == 4 else util.make_map(w["alphabet"])
+    g, o = pair(tree, w["seqs"], K, R, cmap, cmap if K != 4 else ORC_MAP_NT)
+    freqs = g.empirical_frequencies()
+    assert np.allclose(freqs, o.empirical_frequencies(), rtol=1e-13)
+    set_model((g, o), w["subst"], freqs, w["rates"])
+    rng = np.random.default_rng(seed)
+    for i in rng.choice(tree.root_count(), size=min(4, tree.root_count()), replace=False):
+        rl = tree.root_location(int(i)).with_ratio(float(rng.uniform(0.05, 0.95)))
+        a, b = util.compute_lh(g, tree, rl), util.compute_lh(o, tree, rl)
+        assert math.isfinite(a) and a < 0
+        assert util.rel_err(a, b) < LNL_TOL, (a, b)
+    ops, _, _ = tree.generate_operations(rl)
+    compare_state(g, o, ops, tree)
+
+
+def test_pattern_weights_and_category_weights():
+    w = synth.workload(20, 257, 4, 4, 21)
+    tree = rd.Tree.from_newick(w["newick"])
+    rng = np.random.default_rng(5)
+    weights = rng.integers(1, 9, size=257).astype(np.uint32)
+    g, o = pair(tree, w["seqs"], 4, 4, weights=weights)
+    cw = rng.dirichlet(np.ones(4))
+    set_model((g, o), w["subst"], [0.1, 0.2, 0.3, 0.4], w["rates"], cw)
+    rl = tree.root_location(3)
+    a, pa = util.compute_lh(g, tree, rl), None
+    b = util.compute_lh(o, tree, rl)
+    assert util.rel_err(a, b) < LNL_TOL
+    # linearity in the pattern weights: doubling every weight doubles lnL
+    g.set_pattern_weights(weights * 2)
+    assert util.rel_err(util.compute_lh(g, tree, rl), 2 * a) < 1e-13
+
+
+def test_fused_root_evaluation_matches_unfused():
+    """compute_dlh (src/model.cpp:481-519) evaluates alpha and alpha+1e-8."""
+    w = synth.workload(30, 1000, 4, 4, 31)
+    tree = rd.Tree.from_newick(w["newick"])
+    g, o = pair(tree, w["seqs"], 4, 4)
+    set_model((g, o), w["subst"], g.empirical_frequencies(), w["rates"])
+    rl = tree.root_location(7).with_ratio(0.3)
+    util.compute_lh(g, tree, rl)
+    util.compute_lh(o, tree, rl)
+    op, pmi, brl = tree.generate_derivative_operations(rl)
+    alphas = [0.3, 0.3 + 1e-8, 0.0, 1.0]
+    l1 = [rl.saved_brlen * a for a in alphas]
+    l2 = [rl.saved_brlen * (1 - a) for a in alphas]
+    got = g.root_loglikelihood_fused(op, l1, l2)
+    want = o.root_loglikelihood_fused(op, l1, l2)
+    for a, b in zip(got, want):
+        assert util.rel_err(a, b) < LNL_TOL
+    # the finite difference the reference forms from them is reproduced too
+    d_gpu = (got[1] - got[0]) / 1e-8
+    d_orc = (want[1] - want[0]) / 1e-8
+    assert abs(d_gpu - d_orc) <= 1e-3 * max(1.0, abs(d_orc))
+
+
+def test_error_paths():
+    tree = rd.Tree.from_file(os.path.join(util.DATA, "single.tree"))
+    g = rd.Partition.for_tree(tree, 4, 4, 1)
+    with pytest.raises(rd.RdamdError):
+        g.set_tip_states(0, rd.MAP_NT, "AC!T")          # unknown character
+    with pytest.raises(rd.RdamdError):
+        g.set_tip_states(99, rd.MAP_NT, "ACGT")
+    with pytest.raises(rd.RdamdError):
+        g.update_prob_matrices([99], [0.1])
+    with pytest.raises(rd.RdamdError):
+        g.update_prob_matrices([0], [-1.0])
+    with pytest.raises(rd.RdamdError):
+        g.update_prob_matrices([0], [float("nan")])
+    with pytest.raises(rd.RdamdError):
+        g.update_invariant_sites_proportion(0, 0.2)
+    with pytest.raises(rd.RdamdError):
+        rd.Partition(4, 6, 100, 4, 1, 6, 1, 6)          # states > 64
+
+
+@pytest.fixture(scope="module")
+def c2_full():
+    """BASELINE config c2 at full size: 100 taxa x 50,000 sites, UNREST + G4."""
+    w = synth.workload(100, 50000, 4, 4, 0xD166E5 + 1)
+    tree = rd.Tree.from_newick(w["newick"])
+    g = rd.Partition.for_tree(tree, 4, 50000, 4)
+    util.load_tips(g, tree, w["seqs"], rd.MAP_NT)
+    g.set_category_rates(w["rates"])
+    return w, tree, g
+
+
+def test_c2_full_size_properties(c2_full):
+    w, tree, g = c2_full
+    g.set_subst_params(0, w["subst"])
+    g.set_frequencies(0, g.empirical_frequencies())
+    rls = [tree.root_location(i) for i in (0, 50, 196)]
+    for rl in rls:
+        a = util.compute_lh(g, tree, rl)
+        assert math.isfinite(a) and a < 0
+        assert a == util.compute_lh(g, tree, rl)                      # determinism
+        assert util.rel_err(util.compute_lh_root(g, tree, rl), a) < 1e-13
+    # per-site values sum to the total (checksum of checksums)
+    a, ps = (lambda rl: (util.compute_lh(g, tree, rl),
+                         g.compute_root_loglikelihood(tree.root_clv_index(),
+                                                      tree.root_scaler_index(), persite=True)[1]))(rls[1])
+    assert util.rel_err(float(np.sum(ps)), a) < 1e-12
+    # pulley principle under a reversible model: all 197 rootings agree
+    g.set_subst_params(0, [1.0] * 12)
+    g.set_frequencies(0, [0.25] * 4)
+    base = util.compute_lh(g, tree, tree.root_location(0))
+    for rl in tree.roots():
+        util.move_root(g, tree, rl)
+        assert abs(util.compute_lh_root(g, tree, rl) - base) < 1e-9 * abs(base)
+
+
+def test_c2_full_site_slice_additivity(c2_full):
+    """lnL is a sum over sites: the first 20k + the remaining 30k sites evaluated
+    in separate partitions (the multi-GPU site sharding) add up to the whole."""
+    w, tree, g = c2_full
+    freqs = [0.22, 0.27, 0.24, 0.27]
+    rl = tree.root_location(17).with_ratio(0.4)
+    g.set_subst_params(0, w["subst"])
+    g.set_frequencies(0, freqs)
+    whole = util.compute_lh(g, tree, rl)
+    total = 0.0
+    for lo, hi in ((0, 20000), (20000, 50000)):
+        part = rd.Partition.for_tree(tree, 4, hi - lo, 4)
+        util.load_tips(part, tree, {k: v[lo:hi] for k, v in w["seqs"].items()}, rd.MAP_NT)
+        set_model((part,), w["subst"], freqs, w["rates"])
+        total += util.compute_lh(part, tree, rl)
+        part.destroy()
+    assert util.rel_err(total, whole) < 1e-12

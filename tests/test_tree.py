@@ -1,0 +1,205 @@
+"""Host schedule logic (rooted_tree_t mirror) against the golden vectors the
+reference's own tests hold (test/src/tree.cpp).  No GPU needed."""
+import os
+
+import pytest
+
+import root_digger_amd as rd
+import util
+
+DATASETS = {
+    "single": ("single.phy", "single.tree"),
+    "101.phy": ("101.phy", "101.tree"),
+    "10.fasta": ("10.fasta", "10.tree"),
+}
+
+
+def tree_of(key):
+    return rd.Tree.from_file(os.path.join(util.DATA, DATASETS[key][1]))
+
+
+@pytest.mark.parametrize("key", list(DATASETS))
+def test_string_constructor(key):          # test/src/tree.cpp:18-28
+    tree = tree_of(key)
+    assert tree.root_count() == 2 * tree.tip_count() - 3
+    for i, rl in enumerate(tree.roots()):
+        assert rl.id == i
+        assert rl.saved_brlen >= 0.0
+    if key != "101.phy":                   # 101.tree has zero-length branches
+        assert all(rl.saved_brlen > 0.0 for rl in tree.roots())
+
+
+@pytest.mark.parametrize("key", list(DATASETS))
+def test_two_constructions_consistent(key):    # test/src/tree.cpp:29-71
+    t1, t2 = tree_of(key), tree_of(key)
+    assert t1.root_count() == t2.root_count()
+    assert t1.newick() == t2.newick()
+    for i in range(t1.root_count()):
+        a, b = t1.root_location(i), t2.root_location(i)
+        assert (a.id, a.saved_brlen, t1.root_label(i)) == (b.id, b.saved_brlen, t2.root_label(i))
+
+
+@pytest.mark.parametrize("key", list(DATASETS))
+def test_generate_operations_all_roots(key):   # test/src/tree.cpp:118-140
+    tree = tree_of(key)
+    n = tree.tip_count()
+    for rl in tree.roots():
+        ops, pmi, brl = tree.generate_operations(rl)
+        assert len(ops) == n - 1
+        assert len(pmi) == len(brl) == 2 * n - 2
+        assert sorted(pmi) == list(range(2 * n - 2))
+        assert ops[len(ops) - 1].parent_clv_index == 2 * n - 2
+        assert ops[len(ops) - 1].parent_scaler_index == n - 2
+        # every op's children were produced earlier or are tips
+        have = set(range(n))
+        for op in ops:
+            assert op.child1_clv_index in have and op.child2_clv_index in have
+            have.add(op.parent_clv_index)
+
+
+def test_known_tree_schedule():                # test/src/tree.cpp:142-180
+    tree = tree_of("single")
+    ops, pmi, brl = tree.generate_operations(tree.root_location("n2"))
+    assert len(ops) == 3
+    # (parent_clv, parent_sc, c1_clv, c1_mat, c1_sc, c2_clv, c2_mat, c2_sc)
+    assert ops[0].astuple() == (4, 0, 0, 0, -1, 1, 1, -1)
+    assert ops[1].astuple() == (5, 1, 2, 2, -1, 3, 3, -1)
+    assert ops[2].astuple() == (6, 2, 4, 4, 0, 5, 5, 1)
+
+
+def test_root_operation():                     # test/src/tree.cpp:182-212
+    tree = tree_of("single")
+    op, pmi, brl = tree.generate_derivative_operations(tree.root_location("n2"))
+    assert op.astuple() == (6, 2, 4, 4, 0, 5, 5, 1)
+    assert list(pmi) == [4, 5]
+    assert list(brl) == [0.275, 0.275]
+
+
+@pytest.mark.parametrize("key", list(DATASETS))
+def test_root_unroot_cycle(key):               # test/src/tree.cpp:214-223
+    tree = tree_of(key)
+    before = tree.newick()
+    for rl in tree.roots():
+        tree.root_by(rl)
+        assert tree.rooted()
+        tree.unroot()
+        assert not tree.rooted()
+    # lengths are restored by unroot; topology is unchanged
+    t2 = tree_of(key)
+    assert sorted(r.saved_brlen for r in tree.roots()) == sorted(r.saved_brlen for r in t2.roots())
+    assert len(before) == len(tree.newick())
+
+
+NEWICK_GOLD = [   # test/src/tree.cpp:225-292
+    ("b", 0.25, "(b:0.025000,((c:0.100000,d:0.100000)n2:0.550000,a:0.100000)n1:0.075000);"),
+    ("b", 0.75, "(b:0.075000,((c:0.100000,d:0.100000)n2:0.550000,a:0.100000)n1:0.025000);"),
+    ("a", 0.25, "(a:0.025000,(b:0.100000,(c:0.100000,d:0.100000)n2:0.550000)n1:0.075000);"),
+    ("a", 0.75, "(a:0.075000,(b:0.100000,(c:0.100000,d:0.100000)n2:0.550000)n1:0.025000);"),
+    ("n2", 0.25, "((c:0.100000,d:0.100000)n2:0.137500,(a:0.100000,b:0.100000)n1:0.412500);"),
+    ("n2", 0.75, "((c:0.100000,d:0.100000)n2:0.412500,(a:0.100000,b:0.100000)n1:0.137500);"),
+    ("c", 0.25, "(c:0.025000,(d:0.100000,(a:0.100000,b:0.100000)n1:0.550000)n2:0.075000);"),
+    ("c", 0.75, "(c:0.075000,(d:0.100000,(a:0.100000,b:0.100000)n1:0.550000)n2:0.025000);"),
+    ("d", 0.25, "(d:0.025000,((a:0.100000,b:0.100000)n1:0.550000,c:0.100000)n2:0.075000);"),
+    ("d", 0.75, "(d:0.075000,((a:0.100000,b:0.100000)n1:0.550000,c:0.100000)n2:0.025000);"),
+]
+
+
+def test_newick_after_root_by():
+    tree = tree_of("single")
+    assert tree.root_count() == 5
+    for label, ratio, want in NEWICK_GOLD:     # same tree object, in the reference's order
+        tree.root_by(tree.root_location(label).with_ratio(ratio))
+        assert tree.newick() == want
+
+
+def test_derivative_vs_regular_ops():          # test/src/tree.cpp:298-334
+    tree = tree_of("single")
+    for rl in tree.roots():
+        ops, _, _ = tree.generate_operations(rl)
+        op, _, _ = tree.generate_derivative_operations(rl)
+        assert op.astuple() == ops[len(ops) - 1].astuple()
+
+
+def test_sanity_checks():                      # test/src/tree.cpp:336-345
+    def t(name):
+        return rd.Tree.from_file(os.path.join(util.DATA, name + ".tree"))
+    assert not t("sanity_check1").sanity_check()
+    assert not t("sanity_check2").sanity_check()
+    assert t("sanity_check3").sanity_check()
+
+
+ANNOT_BASIC = (   # test/src/tree.cpp:347-365
+    "(((j:0.854700[&&NHX:foo=bar:fizz=buzz],((h:0.983500[&&NHX:foo=bar:fizz=buzz],a:0.224900"
+    "[&&NHX:foo=bar:fizz=buzz]):0.416200[&&NHX:foo=bar:fizz=buzz],(c:0.540900[&&NHX:foo=bar:"
+    "fizz=buzz],f:0.422200[&&NHX:foo=bar:fizz=buzz]):0.785300[&&NHX:foo=bar:fizz=buzz]):0."
+    "614100[&&NHX:foo=bar:fizz=buzz]):0.446100[&&NHX:foo=bar:fizz=buzz],g:0.487400[&&NHX:foo="
+    "bar:fizz=buzz]):0.825200[&&NHX:foo=bar:fizz=buzz],((i:0.569700[&&NHX:foo=bar:fizz=buzz],"
+    "e:0.366600[&&NHX:foo=bar:fizz=buzz]):0.602800[&&NHX:foo=bar:fizz=buzz],b:0.445900[&&NHX:"
+    "foo=bar:fizz=buzz]):0.099300[&&NHX:foo=bar:fizz=buzz],d:0.639600[&&NHX:foo=bar:fizz=buzz]);")
+
+ANNOT_ALL_ROOTS = (   # test/src/tree.cpp:388-408
+    "(a:0.224900[&&NHX:foo=bar:fizz=buzz],((c:0.540900[&&NHX:foo=bar:fizz=buzz],f:0.422200[&&"
+    "NHX:foo=bar:fizz=buzz]):0.785300[&&NHX:foo=bar:fizz=buzz],((g:0.487400[&&NHX:foo=bar:fizz="
+    "buzz],(((i:0.569700[&&NHX:foo=bar:fizz=buzz],e:0.366600[&&NHX:foo=bar:fizz=buzz]):0.602800"
+    "[&&NHX:foo=bar:fizz=buzz],b:0.445900[&&NHX:foo=bar:fizz=buzz]):0.099300[&&NHX:foo=bar:fizz"
+    "=buzz],d:0.639600[&&NHX:foo=bar:fizz=buzz]):0.825200[&&NHX:foo=bar:fizz=buzz]):0.446100[&&"
+    "NHX:foo=bar:fizz=buzz],j:0.854700[&&NHX:foo=bar:fizz=buzz]):0.614100[&&NHX:foo=bar:fizz="
+    "buzz]):0.416200[&&NHX:foo=bar:fizz=buzz],h:0.983500[&&NHX:foo=bar:fizz=buzz]);")
+
+
+def test_annotations_basic():
+    tree = tree_of("10.fasta")
+    for rl in tree.roots():
+        tree.annotate_branch(rl, "foo", "bar")
+        tree.annotate_branch(rl, "fizz", "buzz")
+    assert tree.newick() == ANNOT_BASIC
+
+
+def test_annotations_all_roots():
+    tree = tree_of("10.fasta")
+    for rl in tree.roots():
+        tree.root_by(rl)
+        tree.annotate_branch(rl, "foo", "bar")
+        tree.annotate_branch(rl, "fizz", "buzz")
+    tree.root_by(tree.root_location("a"))
+    tree.unroot()
+    assert tree.newick() == ANNOT_ALL_ROOTS
+
+
+def test_root_update_operations():             # test/src/tree.cpp:410-433
+    t1 = tree_of("single")
+    t1.root_by(t1.root_location("a"))
+    ops, pmi, brl = t1.generate_root_update_operations(t1.root_location("d"))
+    assert (len(ops), len(pmi), len(brl)) == (3, 4, 4)
+    t2 = tree_of("single")
+    t2.root_by(t2.root_location("b"))
+    ops, pmi, brl = t2.generate_root_update_operations(t2.root_location("b"))
+    assert (len(ops), len(pmi), len(brl)) == (0, 0, 0)
+
+
+@pytest.mark.parametrize("key", ["10.fasta", "101.phy"])
+def test_root_update_is_path_only(key):
+    """move-root schedules touch only the old-root -> new-root path."""
+    tree = tree_of(key)
+    roots = tree.roots()
+    tree.root_by(roots[0])
+    n = tree.tip_count()
+    for rl in roots[1:] + roots[:1]:
+        ops, pmi, brl = tree.generate_root_update_operations(rl)
+        assert 1 <= len(ops) <= n - 1
+        assert ops[len(ops) - 1].parent_clv_index == 2 * n - 2
+        assert len(set(pmi)) == len(pmi)
+
+
+def test_bad_inputs():
+    with pytest.raises(rd.RdamdError):
+        rd.Tree.from_newick("(a:1,b:1);")
+    with pytest.raises(rd.RdamdError):
+        rd.Tree.from_newick("((a:1,b:1,c:1,d:1):1,e:1,f:1);")
+    with pytest.raises(rd.RdamdError):
+        rd.Tree.from_file("/nonexistent/tree.nwk")
+    tree = tree_of("single")
+    with pytest.raises(rd.RdamdError):
+        tree.root_location(99)
+    with pytest.raises(rd.RdamdError):
+        tree.root_location("nope")
