@@ -4,11 +4,15 @@
   python bench.py --gpus N --steps K --warmup W
 
 One "step" = one batch of `--batch` full-traversal candidate-root evaluations
-(2n-2 P-matrices + n-1 CLV operations + root reduction each; model_t::compute_lh,
-/root/reference/src/model.cpp:384-413) with a different root placement AND a
-different substitution-parameter set per evaluation (what the exhaustive
-search does, src/model.cpp:1154-1229).  Inputs (tip codes, weights) are
-resident in HBM before the timed region.
+(2n-2 P-matrices + n-1 CLV operations + root reduction each;
+model_t::compute_lh_partition, /root/reference/src/model.cpp:454-476) with a
+different root placement AND a different substitution-parameter set per
+evaluation (what the exhaustive search does, src/model.cpp:1154-1229), run as
+ONE fused launch (rdamd_evaluate_batch).  Parameters change every step, so
+every P-matrix and every CLV is recomputed inside the timed region.  Inputs
+(tip codes, pattern weights, compiled schedules) are resident in HBM before
+the timed region.  A short second leg times the materialising per-operation
+CLV kernel (rdamd_update_clvs) for its HBM roofline.
 
 Multi-GPU (one process per GPU, launched by torch.distributed.run): candidate
 roots are sharded across ranks the way the reference shards them across MPI
@@ -35,6 +39,12 @@ CONFIGS = {
     "c5": dict(n=1000, S=100000, K=4, R=4),
 }
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
+FP64_PEAK_TFLOPS = 78.6     # MI355X FP64 vector = matrix peak
+
+
+def full_eval_flops(n, S, R, K):
+    """2K(2K-1)+K flops per (site, rate) per operation."""
+    return (2 * K * (2 * K - 1) + K) * S * R * (n - 1)
 
 
 def clv_kernel_bytes(n, S, R, K):
@@ -57,7 +67,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
-    ap.add_argument("--batch", type=int, default=8,
+    ap.add_argument("--batch", type=int, default=64,
                     help="candidate-root evaluations per step per GPU")
     ap.add_argument("--cpu-seconds", type=float, default=15.0,
                     help="budget for the cpu_baseline leg (rank 0, N=1 only)")
@@ -109,8 +119,13 @@ def main():
     params = [synth.random_params(K * K - K, rng) for _ in range(len(mine))]
     roots = [tree.root_location(i) for i in mine]
 
-    def evaluate(k):
-        j = k % len(mine)
+    use_fused = (K == 4)
+    nb = min(args.batch, len(mine)) if use_fused else args.batch
+    params = np.array(params)
+    freqs_b = np.tile(np.asarray(freqs), (len(mine), 1))
+
+    def evaluate_unfused(j):
+        j %= len(mine)
         part.set_subst_params(0, params[j])
         ops, pmi, brl = tree.generate_operations(roots[j])
         part.update_prob_matrices(pmi, brl)
@@ -118,11 +133,18 @@ def main():
         return part.compute_root_loglikelihood(tree.root_clv_index(),
                                                tree.root_scaler_index())
 
+    if use_fused:
+        scheds = [part.schedule(*tree.generate_operations(rl)) for rl in roots]
+        depth = max(sc.stack_depth() for sc in scheds)
+
     def step(s):
-        out = 0.0
-        for b in range(args.batch):
-            out += evaluate(s * args.batch + b)
-        return out
+        """one batch: jobs rotate through this rank's candidates; parameters are
+        re-drawn around their base values so no step repeats an earlier one."""
+        if not use_fused:
+            return sum(evaluate_unfused(s * nb + b) for b in range(nb))
+        idx = [(s * nb + b) % len(mine) for b in range(nb)]
+        sub = params[idx] * (1.0 + 1e-3 * ((s % 97) + 1))
+        return float(part.evaluate_batch([scheds[i] for i in idx], sub, freqs_b[idx]).sum())
 
     def barrier():
         if world > 1:
@@ -150,23 +172,49 @@ def main():
         tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    evals_per_rank = args.steps * args.batch
+    evals_per_rank = args.steps * nb
     total_evals = evals_per_rank * world
     value = total_evals / elapsed
 
-    clv_ms, clv_launches = prof["clv"]
-    bytes_clv = clv_kernel_bytes(n, S, R, K) * evals_per_rank
-    avg_launch_ms = clv_ms / max(clv_launches, 1)
-    achieved = bytes_clv / (clv_ms * 1e-3) / 1e9 if clv_ms > 0 else 0.0
-    roofline = {
-        "kernel": "clv_dna_level_kernel" if K == 4 else "clv_generic_level_kernel",
-        "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-        "traffic": None,
-        "bytes_per_launch": bytes_clv / max(clv_launches, 1),
-        "avg_launch_ms": round(avg_launch_ms, 5), "launches": clv_launches,
-        "clv_share_of_step": round(clv_ms * 1e-3 / elapsed, 3),
-    }
+    def clv_roofline(ms, launches, evals):
+        bytes_clv = clv_kernel_bytes(n, S, R, K) * evals
+        achieved = bytes_clv / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        return {"kernel": "clv_dna_level_kernel" if K == 4 else "clv_generic_level_kernel",
+                "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "bytes_per_launch": round(bytes_clv / max(launches, 1)),
+                "avg_launch_ms": round(ms / max(launches, 1), 5), "launches": launches}
+
+    extra = {}
+    if use_fused:
+        ms, launches = prof["fused"]
+        flops = full_eval_flops(n, S, R, K) * evals_per_rank
+        tf = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        hbm_equiv = full_eval_bytes(n, S, R, K) * evals_per_rank / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        roofline = {
+            "kernel": "fused_dna_eval_kernel", "bound": "fp64",
+            "achieved": round(tf, 2), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(tf / FP64_PEAK_TFLOPS, 4), "traffic": None,
+            "flops_per_launch": flops / max(launches, 1),
+            "avg_launch_ms": round(ms / max(launches, 1), 4), "launches": launches,
+            "share_of_step": round(ms * 1e-3 / elapsed, 3),
+            "stack_depth": depth,
+            # what the same evaluations would need from HBM if every CLV were
+            # materialised (SURVEY 8d bytes_full): the fused kernel is not bound by it
+            "hbm_equivalent": {"achieved": round(hbm_equiv, 1), "peak": HBM_PEAK_GBS,
+                               "unit": "GB/s", "frac": round(hbm_equiv / HBM_PEAK_GBS, 3)},
+            "pmatrix_ms_per_launch": round(prof["fused_pmatrix"][0] / max(prof["fused_pmatrix"][1], 1), 4),
+        }
+        # second leg: the materialising per-operation CLV kernel (drop-in
+        # rdamd_update_clvs path), HBM-bound, a few evaluations only
+        part.profile_enable(True)
+        for j in range(6):
+            evaluate_unfused(j)
+        p2 = part.profile_read()
+        part.profile_enable(False)
+        extra["clv_kernel"] = clv_roofline(p2["clv"][0], p2["clv"][1], 6)
+    else:
+        roofline = clv_roofline(prof["clv"][0], prof["clv"][1], evals_per_rank)
 
     result = {
         "metric": "candidate-root lnL evals/sec", "value": round(value, 2),
@@ -176,16 +224,22 @@ def main():
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": "%s: %d-taxon %d-site %d-state UNREST+G%d full-traversal "
                                "root lnL" % (args.config, n, S, K, R),
-                   "batch_per_gpu": args.batch, "sharding": "candidate roots"},
+                   "batch_per_gpu": nb, "sharding": "candidate roots",
+                   "path": "fused batch" if use_fused else "per-operation"},
         "site_clv_updates_per_sec": round(value * (n - 1) * S, 1),
-        "algorithmic_GBps_full_eval": round(value / world * full_eval_bytes(n, S, R, K) / 1e9, 1),
         "roofline": roofline,
     }
+    result.update(extra)
+
+    def gpu_eval(j):
+        if not use_fused:
+            return evaluate_unfused(j)
+        return float(part.evaluate_batch([scheds[j]], params[j:j + 1], freqs_b[j:j + 1])[0])
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(w, tree, cmap, freqs, n, S, K, R,
                                               params, roots, args.cpu_seconds,
-                                              evaluate)
+                                              gpu_eval)
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:

@@ -156,6 +156,53 @@ int rdamd_root_loglikelihood_fused(rdamd_partition_t       *p,
                                    unsigned int             n_alpha,
                                    double                  *lnl_out);
 
+/* ------------------------------------------------------------------------
+ * Batched full-traversal evaluation (the exhaustive-search inner loop)
+ *
+ * model_t::compute_lh_partition (src/model.cpp:454-476) is the objective the
+ * L-BFGS-B driver calls 1 + n_params times per iteration with a pre-generated
+ * operation list (src/model.cpp:1488-1502), and the candidate-root loop
+ * (src/model.cpp:1154) repeats that per root.  These entry points evaluate a
+ * whole batch of such calls -- each job = one schedule (root placement) + one
+ * parameter set -- in ONE fused launch that never writes a CLV to HBM.  They
+ * are stateless with respect to the partition: its CLV / P-matrix / parameter
+ * state is neither read nor changed (tip states and pattern weights are).
+ * 4-state data only; other state counts use the three calls above.
+ * --------------------------------------------------------------------- */
+typedef struct rdamd_schedule rdamd_schedule_t;
+
+/* Compiles the (ops, matrix_indices, branch_lengths) triple that
+ * rooted_tree_t::generate_operations returns (src/tree.cpp:364-413) into a
+ * device-resident traversal program.  Borrowed inputs; NULL + rdamd_errmsg on a
+ * list that is not a complete post-order traversal ending in the root op. */
+rdamd_schedule_t *rdamd_schedule_create(rdamd_partition_t       *p,
+                                        const rdamd_operation_t *ops,
+                                        unsigned int             n_ops,
+                                        const unsigned int      *matrix_indices,
+                                        const double            *branch_lengths,
+                                        unsigned int             n_matrices);
+void         rdamd_schedule_destroy(rdamd_schedule_t *s);
+/* LDS stack slots per site the compiled traversal needs (diagnostic). */
+unsigned int rdamd_schedule_stack_depth(const rdamd_schedule_t *s);
+
+/* lnl_out[j] = log-likelihood of job j.  Row-major parameter blocks:
+ * subst [n_jobs][12] (corax_set_subst_params order), freqs [n_jobs][4],
+ * rates [n_jobs][rate_cats] and rate_weights [n_jobs][rate_cats] (either may be
+ * NULL: the partition's current category rates / weights are used). */
+int rdamd_evaluate_batch(rdamd_partition_t *p, unsigned int n_jobs,
+                         const rdamd_schedule_t *const *schedules,
+                         const double *subst, const double *freqs,
+                         const double *rates, const double *rate_weights,
+                         double *lnl_out);
+/* Same, but the n_jobs results are left in DEVICE memory at d_lnl_out (e.g. a
+ * tensor that an RCCL all-reduce sums over site-sharded ranks next); the call
+ * returns after the partition's stream has finished writing them. */
+int rdamd_evaluate_batch_device(rdamd_partition_t *p, unsigned int n_jobs,
+                                const rdamd_schedule_t *const *schedules,
+                                const double *subst, const double *freqs,
+                                const double *rates, const double *rate_weights,
+                                void *d_lnl_out);
+
 /* parity/debug views: copy device buffers to host. */
 int rdamd_get_clv(rdamd_partition_t *p, unsigned int clv_index, double *out);
 int rdamd_get_scaler(rdamd_partition_t *p, unsigned int scaler_index,
@@ -166,11 +213,12 @@ int rdamd_get_pmatrix(rdamd_partition_t *p, unsigned int matrix_index,
 /* Measurement hooks (bench.py): while enabled, every kernel launch of the
  * partition is bracketed by HIP events on the partition's stream.
  * rdamd_profile_read synchronises, returns accumulated kernel milliseconds and
- * launch counts per kernel family {0: CLV level, 1: P-matrix, 2: root lnL},
- * and resets the accumulators. */
+ * launch counts per kernel family {0: CLV level, 1: P-matrix, 2: root lnL,
+ * 3: fused traversal (+ its finishing reduction), 4: batched P-matrix, 5-7:
+ * reserved}, and resets the accumulators. */
 void rdamd_profile_enable(rdamd_partition_t *p, int on);
-int  rdamd_profile_read(rdamd_partition_t *p, double ms_out[3],
-                        unsigned int launches_out[3]);
+int  rdamd_profile_read(rdamd_partition_t *p, double ms_out[8],
+                        unsigned int launches_out[8]);
 
 /* blocks until all queued device work of the partition has finished. */
 void rdamd_partition_sync(rdamd_partition_t *p);

@@ -13,6 +13,7 @@ from .api import (  # noqa: F401
     RootLocation,
     Tree,
     Partition,
+    Schedule,
     MAP_NT,
     MAP_BIN,
     compute_gamma_cats,
@@ -23,7 +24,7 @@ from .api import (  # noqa: F401
 )
 
 __all__ = [
-    "lib", "lib_path", "RdamdError", "Operation", "RootLocation", "Tree", "Partition",
+    "lib", "lib_path", "RdamdError", "Operation", "RootLocation", "Tree", "Partition", "Schedule",
     "MAP_NT", "MAP_BIN", "compute_gamma_cats", "GAMMA_RATES_MEAN", "GAMMA_RATES_MEDIAN",
     "device_count", "set_device",
 ]

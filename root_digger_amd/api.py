@@ -84,6 +84,11 @@ _sig("rdamd_update_prob_matrices", C.c_int, _vp, _pu, _pu, _pd, _u)
 _sig("rdamd_update_clvs", None, _vp, _pop, _u)
 _sig("rdamd_compute_root_loglikelihood", C.c_double, _vp, _u, C.c_int, _pu, _pd)
 _sig("rdamd_root_loglikelihood_fused", C.c_int, _vp, _pop, _pu, _pd, _pd, _u, _pd)
+_sig("rdamd_schedule_create", _vp, _vp, _pop, _u, _pu, _pd, _u)
+_sig("rdamd_schedule_destroy", None, _vp)
+_sig("rdamd_schedule_stack_depth", _u, _vp)
+_sig("rdamd_evaluate_batch", C.c_int, _vp, _u, C.POINTER(_vp), _pd, _pd, _pd, _pd, _pd)
+_sig("rdamd_evaluate_batch_device", C.c_int, _vp, _u, C.POINTER(_vp), _pd, _pd, _pd, _pd, _vp)
 _sig("rdamd_get_clv", C.c_int, _vp, _u, _pd)
 _sig("rdamd_get_scaler", C.c_int, _vp, _u, _pu)
 _sig("rdamd_get_pmatrix", C.c_int, _vp, _u, _pd)
@@ -279,6 +284,35 @@ class Tree:
             _fail("annotate_branch")
 
 
+class Schedule:
+    """A traversal compiled for the fused evaluator (rdamd_schedule_t)."""
+
+    def __init__(self, part, ops, matrix_indices, branch_lengths):
+        n = len(ops)
+        if not isinstance(ops, C.Array):
+            arr = (Operation * n)()
+            for i, o in enumerate(ops):
+                arr[i] = o
+            ops = arr
+        mi = np.ascontiguousarray(matrix_indices, dtype=np.uint32)
+        bl = np.ascontiguousarray(branch_lengths, dtype=np.float64)
+        self._part = part
+        self._h = lib.rdamd_schedule_create(part.handle, ops, n, _uptr(mi), _dptr(bl), mi.size)
+        if not self._h:
+            _fail("schedule_create")
+
+    def stack_depth(self):
+        return lib.rdamd_schedule_stack_depth(self._h)
+
+    def destroy(self):
+        if getattr(self, "_h", None) and getattr(self._part, "_h", None):
+            lib.rdamd_schedule_destroy(self._h)
+        self._h = None
+
+    def __del__(self):
+        self.destroy()
+
+
 class Partition:
     """The coraxlib partition subset RootDigger uses, in HBM."""
 
@@ -425,8 +459,47 @@ class Partition:
     def profile_read(self):
         """-> {family: (kernel ms, launches)} measured with HIP events on the
         partition stream; resets the accumulators."""
-        ms = (C.c_double * 3)()
-        n = (C.c_uint * 3)()
+        ms = (C.c_double * 8)()
+        n = (C.c_uint * 8)()
         if lib.rdamd_profile_read(self._h, ms, n) != 1:
             _fail("profile_read")
-        return {"clv": (ms[0], n[0]), "pmatrix": (ms[1], n[1]), "root": (ms[2], n[2])}
+        names = ("clv", "pmatrix", "root", "fused", "fused_pmatrix")
+        return {k: (ms[i], n[i]) for i, k in enumerate(names)}
+
+    # ---- batched fused evaluation (rdamd_evaluate_batch) ---------------------
+    def schedule(self, ops, matrix_indices, branch_lengths):
+        return Schedule(self, ops, matrix_indices, branch_lengths)
+
+    def _batch_args(self, schedules, subst, freqs, rates, rate_weights):
+        n = len(schedules)
+        hs = (_vp * n)(*[s._h for s in schedules])
+        subst = np.ascontiguousarray(subst, dtype=np.float64).reshape(n, 12)
+        freqs = np.ascontiguousarray(freqs, dtype=np.float64).reshape(n, 4)
+        if rates is not None:
+            rates = np.ascontiguousarray(rates, dtype=np.float64).reshape(n, self.rate_cats)
+        if rate_weights is not None:
+            rate_weights = np.ascontiguousarray(rate_weights, dtype=np.float64).reshape(
+                n, self.rate_cats)
+        return n, hs, subst, freqs, rates, rate_weights
+
+    def evaluate_batch(self, schedules, subst, freqs, rates=None, rate_weights=None):
+        """lnL of every (schedule, parameter set) job in one fused launch."""
+        n, hs, subst, freqs, rates, rw = self._batch_args(schedules, subst, freqs, rates,
+                                                          rate_weights)
+        out = np.zeros(n, dtype=np.float64)
+        if lib.rdamd_evaluate_batch(self._h, n, hs, _dptr(subst), _dptr(freqs),
+                                    _dptr(rates) if rates is not None else None,
+                                    _dptr(rw) if rw is not None else None, _dptr(out)) != 1:
+            _fail("evaluate_batch")
+        return out
+
+    def evaluate_batch_device(self, schedules, subst, freqs, device_ptr, rates=None,
+                              rate_weights=None):
+        """Same, results left in device memory at `device_ptr` (n float64)."""
+        n, hs, subst, freqs, rates, rw = self._batch_args(schedules, subst, freqs, rates,
+                                                          rate_weights)
+        if lib.rdamd_evaluate_batch_device(self._h, n, hs, _dptr(subst), _dptr(freqs),
+                                           _dptr(rates) if rates is not None else None,
+                                           _dptr(rw) if rw is not None else None,
+                                           C.c_void_p(device_ptr)) != 1:
+            _fail("evaluate_batch_device")

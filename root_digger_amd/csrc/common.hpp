@@ -13,6 +13,9 @@
 
 namespace rdamd {
 
+struct FusedWorkspace;
+void fused_workspace_free(FusedWorkspace *w);
+
 // 2^256 and 2^-256: the per-site scaling constants.
 constexpr double kScaleFactor =
     115792089237316195423570985008687907853269984665640564039457584007913129639936.0;
@@ -75,6 +78,8 @@ struct rdamd_partition {
   double   *h_result = nullptr;   // pinned
   char     *h_stage = nullptr;    // pinned staging ring for small H2D copies
   size_t    stage_bytes = 0, stage_off = 0;
+
+  rdamd::FusedWorkspace *fused = nullptr;   // evaluate.hip
 
   // ---- measurement (rdamd_profile_*) -----------------------------------------
   struct ProfSpan { hipEvent_t a, b; int kind; };

@@ -225,6 +225,7 @@ void rdamd_partition_destroy(rdamd_partition_t *p) {
                  p->d_partials, p->d_result, p->d_persite};
   for (void *d : dev)
     if (d) (void)hipFree(d);
+  rdamd::fused_workspace_free(p->fused);
   for (auto &sp : p->prof_spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
   for (auto &e : p->prof_pool) (void)hipEventDestroy(e);
   if (p->h_stage) (void)hipHostFree(p->h_stage);
@@ -584,13 +585,13 @@ void rdamd_profile_enable(rdamd_partition_t *p, int on) {
   p->profiling = on != 0;
 }
 
-int rdamd_profile_read(rdamd_partition_t *p, double ms_out[3], unsigned int launches_out[3]) {
+int rdamd_profile_read(rdamd_partition_t *p, double ms_out[8], unsigned int launches_out[8]) {
   clear_error();
   RDAMD_HIP_TRY(hipStreamSynchronize(p->stream), RDAMD_FAILURE);
-  for (int k = 0; k < 3; ++k) { ms_out[k] = 0.0; launches_out[k] = 0; }
+  for (int k = 0; k < 8; ++k) { ms_out[k] = 0.0; launches_out[k] = 0; }
   for (auto &sp : p->prof_spans) {
     float ms = 0.f;
-    if (hipEventElapsedTime(&ms, sp.a, sp.b) == hipSuccess && sp.kind >= 0 && sp.kind < 3) {
+    if (hipEventElapsedTime(&ms, sp.a, sp.b) == hipSuccess && sp.kind >= 0 && sp.kind < 8) {
       ms_out[sp.kind] += ms;
       launches_out[sp.kind] += 1;
     }

@@ -321,3 +321,115 @@ def test_c2_full_site_slice_additivity(c2_full):
         total += util.compute_lh(part, tree, rl)
         part.destroy()
     assert util.rel_err(total, whole) < 1e-12
+
+
+# ---------------------------------------------------------------------------
+# fused batched evaluator (rdamd_evaluate_batch) vs the oracle
+# ---------------------------------------------------------------------------
+def _oracle_eval(o, tree, rl, subst, freqs, rates, weights=None):
+    o.set_subst_params(0, subst)
+    o.set_frequencies(0, freqs)
+    o.set_category_rates(rates)
+    if weights is not None:
+        o.set_category_weights(weights)
+    return util.compute_lh(o, tree, rl)
+
+
+@pytest.mark.parametrize("n,S,R,seed", [(100, 2000, 4, 41), (37, 1000, 1, 42),
+                                        (64, 333, 2, 43), (16, 65, 8, 44), (5, 7, 3, 45)])
+def test_fused_batch_vs_oracle(n, S, R, seed):
+    w = synth.workload(n, S, 4, R, seed)
+    tree = rd.Tree.from_newick(w["newick"])
+    rng = np.random.default_rng(seed)
+    weights = rng.integers(1, 4, size=S).astype(np.uint32)
+    g, o = pair(tree, w["seqs"], 4, R, weights=weights)
+    g.set_category_rates(w["rates"])
+    picks = rng.choice(tree.root_count(), size=min(6, tree.root_count()), replace=False)
+    rls = [tree.root_location(int(i)).with_ratio(float(rng.uniform(0.02, 0.98))) for i in picks]
+    scheds = [g.schedule(*tree.generate_operations(rl)) for rl in rls]
+    assert all(1 <= s.stack_depth() <= 12 for s in scheds)
+    subst = rng.uniform(1e-4, 1.0, (len(rls), 12))
+    freqs = rng.dirichlet(np.ones(4) * 5, len(rls))
+    rates = np.array([rd.compute_gamma_cats(a, R) for a in rng.uniform(0.3, 3.0, len(rls))])
+    cw = rng.dirichlet(np.ones(R) * 3, len(rls))
+    got = g.evaluate_batch(scheds, subst, freqs, rates, cw)
+    for j, rl in enumerate(rls):
+        want = _oracle_eval(o, tree, rl, subst[j], freqs[j], rates[j], cw[j])
+        assert util.rel_err(got[j], want) < LNL_TOL, (j, got[j], want)
+    # repeat call: bit-identical (test/src/model.cpp:73)
+    assert np.array_equal(got, g.evaluate_batch(scheds, subst, freqs, rates, cw))
+    # defaults: partition's own rates/weights
+    got2 = g.evaluate_batch(scheds[:2], subst[:2], freqs[:2])
+    for j in range(2):
+        o.set_category_weights([1.0 / R] * R)
+        want = _oracle_eval(o, tree, rls[j], subst[j], freqs[j], w["rates"])
+        assert util.rel_err(got2[j], want) < LNL_TOL
+
+
+def test_fused_matches_unfused_and_leaves_partition_state_alone():
+    w = synth.workload(50, 1500, 4, 4, 51)
+    tree = rd.Tree.from_newick(w["newick"])
+    g, o = pair(tree, w["seqs"], 4, 4)
+    freqs = g.empirical_frequencies()
+    set_model((g, o), w["subst"], freqs, w["rates"])
+    rl0 = tree.root_location(5)
+    base = util.compute_lh(g, tree, rl0)                  # partition state = rooting 5
+    rl = tree.root_location(20).with_ratio(0.7)
+    sched = g.schedule(*tree.generate_operations(rl))
+    other = np.array(w["subst"]) * 1.7
+    fused = g.evaluate_batch([sched, sched], [w["subst"], other], [freqs, freqs])
+    tree.root_by(rl0)
+    assert util.compute_lh_root(g, tree, rl0) == base     # state untouched by the batch
+    assert util.rel_err(fused[0], util.compute_lh(g, tree, rl)) < 1e-13
+    assert fused[0] != fused[1]
+
+
+def test_fused_deep_tree_per_rate_scaling():
+    """161-taxon caterpillar: scaling fires; the per-rate-count form must give
+    the same lnL as the per-site rule of the oracle."""
+    gd = util.golden("deep_scaling.json")
+    tree = rd.Tree.from_newick(gd["newick"])
+    g, o = pair(tree, gd["seqs"], 4, 4)
+    g.set_category_rates(gd["rates"])
+    for i in (0, 100, 250, tree.root_count() - 1):
+        rl = tree.root_location(i).with_ratio(0.31)
+        sched = g.schedule(*tree.generate_operations(rl))
+        got = g.evaluate_batch([sched], [gd["subst"]], [gd["freqs"]])[0]
+        want = _oracle_eval(o, tree, rl, gd["subst"], gd["freqs"], gd["rates"])
+        assert util.rel_err(got, want) < LNL_TOL
+        assert sched.stack_depth() <= 2      # a caterpillar needs (almost) no stack
+
+
+def test_fused_schedule_validation():
+    w = synth.workload(12, 64, 4, 1, 61)
+    tree = rd.Tree.from_newick(w["newick"])
+    g = rd.Partition.for_tree(tree, 4, 64, 1)
+    ops, pmi, brl = tree.generate_operations(tree.root_location(0))
+    with pytest.raises(rd.RdamdError):      # incomplete traversal
+        g.schedule([ops[i] for i in range(1, len(ops))], pmi, brl)
+    with pytest.raises(rd.RdamdError):
+        g.schedule(ops, pmi, -brl)
+    p20 = rd.Partition(4, 6, 20, 8, 1, 6, 1, 6)
+    with pytest.raises(rd.RdamdError):      # 4-state only
+        p20.schedule(ops, pmi, brl)
+
+
+def test_c2_full_size_fused_properties(c2_full):
+    w, tree, g = c2_full
+    rng = np.random.default_rng(99)
+    freqs = np.array(g.empirical_frequencies())
+    rls = [tree.root_location(int(i)) for i in rng.choice(197, 24, replace=False)]
+    scheds = [g.schedule(*tree.generate_operations(rl)) for rl in rls]
+    subst = rng.uniform(1e-4, 1.0, (24, 12))
+    got = g.evaluate_batch(scheds, subst, np.tile(freqs, (24, 1)))
+    assert np.all(np.isfinite(got)) and np.all(got < 0)
+    assert np.array_equal(got, g.evaluate_batch(scheds, subst, np.tile(freqs, (24, 1))))
+    # spot-check three jobs against the unfused HIP path (itself oracle-checked)
+    for j in (0, 11, 23):
+        g.set_subst_params(0, subst[j])
+        g.set_frequencies(0, freqs)
+        assert util.rel_err(got[j], util.compute_lh(g, tree, rls[j])) < 1e-12
+    # reversible model: all roots agree (pulley principle), one batch of 197 jobs
+    all_s = [g.schedule(*tree.generate_operations(rl)) for rl in tree.roots()]
+    jc = g.evaluate_batch(all_s, np.ones((197, 12)), np.full((197, 4), 0.25))
+    assert np.max(np.abs(jc - jc[0])) < 1e-9 * abs(jc[0])
