@@ -28,7 +28,7 @@ struct FusedWorkspace {
   unsigned cap_jobs = 0, blocks_x = 0;
   FusedJob *d_jobs = nullptr;
   double *d_q = nullptr, *d_rates = nullptr, *d_freqs = nullptr, *d_rw = nullptr;
-  double *d_pmat = nullptr, *d_partials = nullptr, *d_out = nullptr;
+  double *d_pmat = nullptr, *d_tiptab = nullptr, *d_partials = nullptr, *d_out = nullptr;
   double *h_out = nullptr;   // pinned
   char *h_in = nullptr;      // pinned parameter staging
   size_t h_in_bytes = 0;
@@ -37,7 +37,7 @@ struct FusedWorkspace {
 void fused_workspace_free(FusedWorkspace *w) {
   if (!w) return;
   void *dev[] = {w->d_jobs, w->d_q, w->d_rates, w->d_freqs, w->d_rw, w->d_pmat,
-                 w->d_partials, w->d_out};
+                 w->d_tiptab, w->d_partials, w->d_out};
   for (void *d : dev)
     if (d) (void)hipFree(d);
   if (w->h_out) (void)hipHostFree(w->h_out);
@@ -52,7 +52,7 @@ static hipError_t ensure_workspace(rdamd_partition *p, unsigned n_jobs) {
   hipError_t e = hipStreamSynchronize(p->stream);
   if (e != hipSuccess) return e;
   void *dev[] = {w->d_jobs, w->d_q, w->d_rates, w->d_freqs, w->d_rw, w->d_pmat,
-                 w->d_partials, w->d_out};
+                 w->d_tiptab, w->d_partials, w->d_out};
   for (void *d : dev)
     if (d) (void)hipFree(d);
   if (w->h_out) (void)hipHostFree(w->h_out);
@@ -72,6 +72,7 @@ static hipError_t ensure_workspace(rdamd_partition *p, unsigned n_jobs) {
   A(w->d_freqs, sizeof(double) * 4 * cap);
   A(w->d_rw, sizeof(double) * R * cap);
   A(w->d_pmat, sizeof(double) * pm_per_job * cap);
+  A(w->d_tiptab, sizeof(double) * pm_per_job * 4 * cap);
   A(w->d_partials, sizeof(double) * w->blocks_x * cap);
   A(w->d_out, sizeof(double) * cap);
 #undef A
@@ -118,30 +119,33 @@ struct Compiler {
     const bool i1 = is_inner(o.child1_clv_index), i2 = is_inner(o.child2_clv_index);
     FusedOp f;
     memset(&f, 0, sizeof(f));
+    unsigned matX = 0, matY = 0, kind = 0, spill = 0;
     if (!i1 && !i2) {
-      f.kind = kFusedTT;
-      f.spill = live ? 1 : 0;
-      f.tipX = o.child1_clv_index; f.matX = o.child1_matrix_index;
-      f.tipY = o.child2_clv_index; f.matY = o.child2_matrix_index;
+      kind = kFusedTT;
+      spill = live ? 1 : 0;
+      f.tipX = o.child1_clv_index; matX = o.child1_matrix_index;
+      f.tipY = o.child2_clv_index; matY = o.child2_matrix_index;
       if (live) { ++depth; max_depth = std::max(max_depth, depth); }
     } else if (i1 != i2) {
       const bool first_inner = i1;
       emit(producer.at(first_inner ? o.child1_clv_index : o.child2_clv_index), live);
-      f.kind = kFusedRT;
-      f.matX = first_inner ? o.child1_matrix_index : o.child2_matrix_index;
+      kind = kFusedRT;
+      matX = first_inner ? o.child1_matrix_index : o.child2_matrix_index;
       f.tipY = first_inner ? o.child2_clv_index : o.child1_clv_index;
-      f.matY = first_inner ? o.child2_matrix_index : o.child1_matrix_index;
+      matY = first_inner ? o.child2_matrix_index : o.child1_matrix_index;
     } else {
       const unsigned a = producer.at(o.child1_clv_index), b = producer.at(o.child2_clv_index);
       const bool a_first = need[a] >= need[b];
       const unsigned first = a_first ? a : b, second = a_first ? b : a;
       emit(first, live);     // parked by the first TT op of `second`
       emit(second, true);
-      f.kind = kFusedRP;     // X = register = second, Y = popped = first
-      f.matX = a_first ? o.child2_matrix_index : o.child1_matrix_index;
-      f.matY = a_first ? o.child1_matrix_index : o.child2_matrix_index;
+      kind = kFusedRP;     // X = register = second, Y = popped = first
+      matX = a_first ? o.child2_matrix_index : o.child1_matrix_index;
+      matY = a_first ? o.child1_matrix_index : o.child2_matrix_index;
       --depth;
     }
+    f.mats = matX | (matY << 16);
+    f.flags = kind | (spill << 8);
     out.push_back(f);
   }
 };
@@ -163,8 +167,8 @@ rdamd_schedule_t *rdamd_schedule_create(rdamd_partition_t *p, const rdamd_operat
                   "rdamd_update_clvs for %u states", p->states);
     return nullptr;
   }
-  if (n_ops == 0) {
-    set_error(41, "rdamd_schedule_create: empty operation list");
+  if (n_ops == 0 || p->prob_matrices > 65535) {
+    set_error(41, "rdamd_schedule_create: empty operation list or more than 65535 P-matrices");
     return nullptr;
   }
   Compiler c;
@@ -209,10 +213,13 @@ rdamd_schedule_t *rdamd_schedule_create(rdamd_partition_t *p, const rdamd_operat
   rdamd_schedule *s = new rdamd_schedule();
   s->part = p; s->n_ops = n_ops; s->depth = std::max(1u, c.max_depth);
   s->prog = c.out;
+  // two harmless tail entries: the kernel prefetches descriptor i + 2
+  c.out.push_back(c.out.back());
+  c.out.push_back(c.out.back());
 #define TRY(expr) RDAMD_HIP_TRY(expr, (rdamd_schedule_destroy(s), nullptr))
-  TRY(hipMalloc((void **)&s->d_prog, sizeof(FusedOp) * n_ops));
+  TRY(hipMalloc((void **)&s->d_prog, sizeof(FusedOp) * (n_ops + 2)));
   TRY(hipMalloc((void **)&s->d_brlen, sizeof(double) * p->prob_matrices));
-  TRY(hipMemcpy(s->d_prog, c.out.data(), sizeof(FusedOp) * n_ops, hipMemcpyHostToDevice));
+  TRY(hipMemcpy(s->d_prog, c.out.data(), sizeof(FusedOp) * (n_ops + 2), hipMemcpyHostToDevice));
   TRY(hipMemcpy(s->d_brlen, brlen.data(), sizeof(double) * p->prob_matrices, hipMemcpyHostToDevice));
 #undef TRY
   return s;
@@ -278,10 +285,11 @@ static int evaluate_batch_impl(rdamd_partition_t *p, unsigned int n_jobs,
 
   FusedArgs a;
   a.jobs = w->d_jobs; a.tipcodes = p->d_tipcodes; a.pattern_weights = p->d_pattern_weights;
-  a.pmat = w->d_pmat; a.freqs = w->d_freqs; a.rate_weights = w->d_rw;
+  a.pmat = w->d_pmat; a.tiptab = w->d_tiptab; a.freqs = w->d_freqs; a.rate_weights = w->d_rw;
   a.partials = w->d_partials; a.persite = nullptr;
   a.pmat_job_stride = (size_t)p->prob_matrices * R * 16;
   a.sites = p->sites; a.rate_cats = R;
+  a.tipcodes_bytes = (unsigned)std::min<size_t>((size_t)p->tips * p->sites, 0xffffffffu);
   p->prof_begin(4);
   hipError_t e = launch_fused_pmatrix(a, w->d_q, w->d_rates, n_jobs, p->prob_matrices, p->stream);
   p->prof_end();

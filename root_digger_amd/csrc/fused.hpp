@@ -15,13 +15,11 @@ enum : uint32_t {
   kFusedRP = 2,   // X = running CLV (register), Y = popped from the LDS stack
 };
 
-// One step of a compiled traversal ("program"), 32 bytes, read with scalar loads.
+// One step of a compiled traversal ("program"), 16 bytes, read with scalar loads.
 struct FusedOp {
-  uint32_t matX, matY;   // P-matrix indices of the two child branches
+  uint32_t mats;         // P-matrix indices of the two child branches: X | Y << 16
   uint32_t tipX, tipY;   // tip rows (0 when the operand is not a tip)
-  uint32_t kind;         // kFused*
-  uint32_t spill;        // push the running CLV before this op
-  uint32_t pad[2];
+  uint32_t flags;        // kind (kFused*) | spill << 8 (push the running CLV first)
 };
 
 struct FusedJob {
@@ -35,12 +33,14 @@ struct FusedArgs {
   const uint8_t  *tipcodes;          // [tips][sites]
   const unsigned *pattern_weights;   // [sites]
   const double   *pmat;              // [job][matrix][rate][16]
+  const double   *tiptab;            // [job][matrix][rate][16 codes][4]
   const double   *freqs;             // [job][4]
   const double   *rate_weights;      // [job][R]
   double         *partials;          // [job][blocks_x]
   double         *persite;           // [job][sites] or null
   size_t   pmat_job_stride;
   unsigned sites, rate_cats;
+  unsigned tipcodes_bytes;           // tips * sites
 };
 
 hipError_t launch_fused_pmatrix(const FusedArgs &a, const double *d_q, const double *d_rates,
