@@ -63,7 +63,9 @@ static hipError_t ensure_workspace(rdamd_partition *p, unsigned n_jobs) {
   // site blocks padded to a multiple of 8 so that blockIdx.x % 8 (the XCD a
   // workgroup lands on) is the same for every job: each XCD's L2 then only
   // ever sees 1/8 of the tip codes.
-  w->blocks_x = ((p->sites + 63) / 64 + 7) / 8 * 8;
+  const char *nsv = getenv("RDAMD_NS");
+  const unsigned per_block = 64 * (nsv ? atoi(nsv) : kFusedSitesPerLane);
+  w->blocks_x = ((p->sites + per_block - 1) / per_block + 7) / 8 * 8;
   const size_t pm_per_job = (size_t)p->prob_matrices * R * 16;
 #define A(ptr, bytes) do { e = hipMalloc((void **)&(ptr), (bytes)); if (e != hipSuccess) return e; } while (0)
   A(w->d_jobs, sizeof(FusedJob) * cap);
@@ -92,7 +94,7 @@ static hipError_t ensure_workspace(rdamd_partition *p, unsigned n_jobs) {
 // while the other child runs), plus the flags the kernel interprets.
 struct Compiler {
   const rdamd_operation_t *ops;
-  unsigned n_ops, tips;
+  unsigned n_ops, tips, sites, rate_cats;
   std::unordered_map<unsigned, unsigned> producer;   // clv -> op index
   std::vector<unsigned> need;                        // stack slots a subtree needs
   std::vector<FusedOp> out;
@@ -119,19 +121,19 @@ struct Compiler {
     const bool i1 = is_inner(o.child1_clv_index), i2 = is_inner(o.child2_clv_index);
     FusedOp f;
     memset(&f, 0, sizeof(f));
-    unsigned matX = 0, matY = 0, kind = 0, spill = 0;
+    unsigned matX = 0, matY = 0, kind = 0, spill = 0, tipX_row = 0, tipY_row = 0;
     if (!i1 && !i2) {
       kind = kFusedTT;
       spill = live ? 1 : 0;
-      f.tipX = o.child1_clv_index; matX = o.child1_matrix_index;
-      f.tipY = o.child2_clv_index; matY = o.child2_matrix_index;
+      tipX_row = o.child1_clv_index; matX = o.child1_matrix_index;
+      tipY_row = o.child2_clv_index; matY = o.child2_matrix_index;
       if (live) { ++depth; max_depth = std::max(max_depth, depth); }
     } else if (i1 != i2) {
       const bool first_inner = i1;
       emit(producer.at(first_inner ? o.child1_clv_index : o.child2_clv_index), live);
       kind = kFusedRT;
       matX = first_inner ? o.child1_matrix_index : o.child2_matrix_index;
-      f.tipY = first_inner ? o.child2_clv_index : o.child1_clv_index;
+      tipY_row = first_inner ? o.child2_clv_index : o.child1_clv_index;
       matY = first_inner ? o.child2_matrix_index : o.child1_matrix_index;
     } else {
       const unsigned a = producer.at(o.child1_clv_index), b = producer.at(o.child2_clv_index);
@@ -144,7 +146,10 @@ struct Compiler {
       matY = a_first ? o.child1_matrix_index : o.child2_matrix_index;
       --depth;
     }
-    f.mats = matX | (matY << 16);
+    f.pX = matX * rate_cats * 128u;
+    f.pY = matY * rate_cats * 128u;
+    f.cX = tipX_row * sites;
+    f.cY = tipY_row * sites;
     f.flags = kind | (spill << 8);
     out.push_back(f);
   }
@@ -167,12 +172,14 @@ rdamd_schedule_t *rdamd_schedule_create(rdamd_partition_t *p, const rdamd_operat
                   "rdamd_update_clvs for %u states", p->states);
     return nullptr;
   }
-  if (n_ops == 0 || p->prob_matrices > 65535) {
-    set_error(41, "rdamd_schedule_create: empty operation list or more than 65535 P-matrices");
+  if (n_ops == 0 || (size_t)p->tips * p->sites > 0xffffffffu ||
+      (size_t)p->prob_matrices * p->rate_cats * 512 > 0xffffffffu) {
+    set_error(41, "rdamd_schedule_create: empty operation list, or partition too large for "
+                  "32-bit offsets (tips*sites or matrices*rates*512 >= 4 GiB)");
     return nullptr;
   }
   Compiler c;
-  c.ops = ops; c.n_ops = n_ops; c.tips = p->tips;
+  c.ops = ops; c.n_ops = n_ops; c.tips = p->tips; c.sites = p->sites; c.rate_cats = p->rate_cats;
   const unsigned nclv = p->tips + p->clv_buffers;
   for (unsigned i = 0; i < n_ops; ++i) {
     const rdamd_operation_t &o = ops[i];
@@ -213,13 +220,12 @@ rdamd_schedule_t *rdamd_schedule_create(rdamd_partition_t *p, const rdamd_operat
   rdamd_schedule *s = new rdamd_schedule();
   s->part = p; s->n_ops = n_ops; s->depth = std::max(1u, c.max_depth);
   s->prog = c.out;
-  // two harmless tail entries: the kernel prefetches descriptor i + 2
-  c.out.push_back(c.out.back());
-  c.out.push_back(c.out.back());
+  // harmless tail entries: the kernel prefetches descriptors up to i + 3
+  for (int k = 0; k < 4; ++k) c.out.push_back(c.out.back());
 #define TRY(expr) RDAMD_HIP_TRY(expr, (rdamd_schedule_destroy(s), nullptr))
-  TRY(hipMalloc((void **)&s->d_prog, sizeof(FusedOp) * (n_ops + 2)));
+  TRY(hipMalloc((void **)&s->d_prog, sizeof(FusedOp) * (n_ops + 4)));
   TRY(hipMalloc((void **)&s->d_brlen, sizeof(double) * p->prob_matrices));
-  TRY(hipMemcpy(s->d_prog, c.out.data(), sizeof(FusedOp) * (n_ops + 2), hipMemcpyHostToDevice));
+  TRY(hipMemcpy(s->d_prog, c.out.data(), sizeof(FusedOp) * (n_ops + 4), hipMemcpyHostToDevice));
   TRY(hipMemcpy(s->d_brlen, brlen.data(), sizeof(double) * p->prob_matrices, hipMemcpyHostToDevice));
 #undef TRY
   return s;

@@ -15,11 +15,17 @@ enum : uint32_t {
   kFusedRP = 2,   // X = running CLV (register), Y = popped from the LDS stack
 };
 
-// One step of a compiled traversal ("program"), 16 bytes, read with scalar loads.
+// sites each lane of the fused kernel carries (independent chains per lane:
+// halves the scalar / latency overhead per unit of vector work)
+constexpr int kFusedSitesPerLane = 2;
+
+// One step of a compiled traversal ("program"), 32 bytes, one scalar load.
+// All offsets are precomputed on the host so the kernel adds at most the rate.
 struct FusedOp {
-  uint32_t mats;         // P-matrix indices of the two child branches: X | Y << 16
-  uint32_t tipX, tipY;   // tip rows (0 when the operand is not a tip)
-  uint32_t flags;        // kind (kFused*) | spill << 8 (push the running CLV first)
+  uint32_t pX, pY;       // byte offset of [matrix][rate 0] inside a job's P-matrix block
+  uint32_t cX, cY;       // byte offset of the tip row inside tipcodes (0 if not a tip)
+  uint32_t flags;        // kind (kFused*) | 0x100 when the running CLV is parked first
+  uint32_t pad[3];
 };
 
 struct FusedJob {

@@ -40,7 +40,8 @@ __device__ __forceinline__ unsigned uni(unsigned x) {   // assert wave-uniformit
 }
 
 // LDS per wave: [2][64] doubles of tip-table slots, then the CLV stack
-// [depth][64 lanes][4] doubles, then the rescale-count stack [depth][64] ints.
+// [depth][site slot][2 halves][64 lanes] double2, then the rescale-count stack
+// [depth][site slot][64] ints.  NS = sites per lane.
 constexpr unsigned kTabDoubles = 128;
 
 typedef unsigned v2u __attribute__((ext_vector_type(2)));
@@ -53,20 +54,62 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *p, unsig
   return __builtin_amdgcn_make_buffer_rsrc(q, 0, (int)uni(bytes), 0x00020000);
 }
 
+template <int NS>
+struct LaneState {
+  double v[NS][4];
+  int sc[NS];
+};
+
+// t = P . x  with the 4x4 P-matrix as scalar operands
+__device__ __forceinline__ void matvec(const double *__restrict__ p, const double (&x)[4],
+                                       double (&t)[4]) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    t[k] = p[k * 4 + 0] * x[0] + p[k * 4 + 1] * x[1] + p[k * 4 + 2] * x[2] + p[k * 4 + 3] * x[3];
+}
+
+__device__ __forceinline__ void read_row(const double *row, double (&t)[4]) {
+  const double2 lo = reinterpret_cast<const double2 *>(row)[0];
+  const double2 hi = reinterpret_cast<const double2 *>(row)[1];
+  t[0] = lo.x; t[1] = lo.y; t[2] = hi.x; t[3] = hi.y;
+}
+
+// v = tx * ty, then the 2^256 rescale when all four entries are < 2^-256
+// (entries are non-negative, so comparing the high words is exact; a NaN
+// compares as large and never rescales)
+__device__ __forceinline__ void combine(const double (&tx)[4], const double (&ty)[4],
+                                        double (&v)[4], int &sc) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) v[k] = tx[k] * ty[k];
+  const unsigned hmax = max(max((unsigned)__double2hiint(v[0]), (unsigned)__double2hiint(v[1])),
+                            max((unsigned)__double2hiint(v[2]), (unsigned)__double2hiint(v[3])));
+  if (hmax < 0x2FF00000u) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] *= kScaleFactor;
+    sc += 1;
+  }
+}
+
+template <int NS, int ABL>
 __global__ void __launch_bounds__(64)
 fused_dna_eval_kernel(FusedArgs a) {
   extern __shared__ double lds[];
   const unsigned lane = threadIdx.x;
   const unsigned job = blockIdx.y;
   const unsigned S = a.sites, R = a.rate_cats;
-  unsigned site = blockIdx.x * 64 + lane;
-  const bool valid = site < S;
-  if (!valid) site = S - 1;
+  unsigned site[NS];
+  bool valid[NS];
+#pragma unroll
+  for (int q = 0; q < NS; ++q) {
+    site[q] = (blockIdx.x * NS + q) * 64 + lane;
+    valid[q] = site[q] < S;
+    if (!valid[q]) site[q] = S - 1;
+  }
 
   const FusedJob jb = a.jobs[job];
   const FusedOp *__restrict__ prog = jb.prog;   // n_ops + 2 entries (tail padded)
   const unsigned nops = jb.n_ops;
-  const double *__restrict__ pm = a.pmat + (size_t)job * a.pmat_job_stride;
+  const char *__restrict__ pm = reinterpret_cast<const char *>(a.pmat + (size_t)job * a.pmat_job_stride);
   const double *__restrict__ freqs = a.freqs + (size_t)job * 4;
   const double *__restrict__ rw = a.rate_weights + (size_t)job * R;
   // tip codes and this job's tip tables through buffer descriptors: the
@@ -76,119 +119,141 @@ fused_dna_eval_kernel(FusedArgs a) {
   const __amdgpu_buffer_rsrc_t tab_rs =
       make_rsrc(a.tiptab + (size_t)job * a.pmat_job_stride * 4, (unsigned)(a.pmat_job_stride * 32));
   const int lane8 = (int)lane * 8;
-  const int site_off = (int)site;
+  int site_off[NS];
+#pragma unroll
+  for (int q = 0; q < NS; ++q) site_off[q] = (int)site[q];
   double *tabx = lds, *taby = lds + 64;
-  double *stk = lds + kTabDoubles;
-  int *stk_sc = reinterpret_cast<int *>(stk + (size_t)jb.depth * 64 * 4);
+  double2 *stk = reinterpret_cast<double2 *>(lds + kTabDoubles) + lane;
+  int *stk_sc = reinterpret_cast<int *>(lds + kTabDoubles + (size_t)jb.depth * NS * 256) + lane;
 
-  double term = 0.0;   // sum_r w_r f_r 2^(-256 (s_r - smin))
-  int smin = 0;
-
-#define RDAMD_LOAD_CODE(tiprow) \
-  ((unsigned)__builtin_amdgcn_raw_buffer_load_b8(tips_rs, site_off, (int)(uni(tiprow) * S), 0))
-#define RDAMD_LOAD_TAB(mat) \
-  __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64( \
-      tab_rs, lane8, (int)((uni(mat) * R + r) * 512u), 0))
+  double term[NS];   // sum_r w_r f_r 2^(-256 (s_r - smin))
+  int smin[NS];
 
   for (unsigned r = 0; r < R; ++r) {
-    double v[4] = {0.0, 0.0, 0.0, 0.0};
-    int sc = 0;
-    unsigned sp = 0;
-    // software pipeline: descriptor i+2 (scalar load), tip codes and tip-table
-    // entries of op i+1 (vector loads) are in flight while op i computes
-    FusedOp cur = prog[0];
-    FusedOp nxt = prog[1];
-    unsigned cx = RDAMD_LOAD_CODE(cur.tipX), cy = RDAMD_LOAD_CODE(cur.tipY);
-    double ex = RDAMD_LOAD_TAB(cur.mats & 0xffffu), ey = RDAMD_LOAD_TAB(cur.mats >> 16);
-    for (unsigned i = 0; i < nops; ++i) {
-      const FusedOp nn = prog[i + 2];
-      const unsigned kind = uni(cur.flags & 0xffu), spill = uni(cur.flags >> 8);
-      // stage A: hand the prefetched tip data of THIS op to LDS
-      const double *rowx = tabx + cx * 4, *rowy = taby + cy * 4;
-      if (kind == kFusedTT) tabx[lane] = ex;
-      if (kind != kFusedRP) taby[lane] = ey;
-      // stage B: refill the prefetch registers with the NEXT op's tip data
-      cx = RDAMD_LOAD_CODE(nxt.tipX);
-      cy = RDAMD_LOAD_CODE(nxt.tipY);
-      ex = RDAMD_LOAD_TAB(nxt.mats & 0xffffu);
-      ey = RDAMD_LOAD_TAB(nxt.mats >> 16);
-      // stage C: the operation itself
-      if (spill) {   // wave-uniform: park the running CLV for a later pop
-        double *d = stk + ((size_t)sp * 64 + lane) * 4;
-        reinterpret_cast<double2 *>(d)[0] = make_double2(v[0], v[1]);
-        reinterpret_cast<double2 *>(d)[1] = make_double2(v[2], v[3]);
-        stk_sc[sp * 64 + lane] = sc;
-        ++sp;
-      }
-      double tx[4], ty[4];
-      int scx, scy;
-      if (kind == kFusedTT) {
-        // tip operand: row `code` of the 16x4 table of this (matrix, rate)
-        const double2 lo = reinterpret_cast<const double2 *>(rowx)[0];
-        const double2 hi = reinterpret_cast<const double2 *>(rowx)[1];
-        tx[0] = lo.x; tx[1] = lo.y; tx[2] = hi.x; tx[3] = hi.y;
-        scx = 0;
-      } else {
-        const double *__restrict__ px = pm + (size_t)(uni(cur.mats & 0xffffu) * R + r) * 16;
+    LaneState<NS> st;
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-          tx[k] = px[k * 4 + 0] * v[0] + px[k * 4 + 1] * v[1] + px[k * 4 + 2] * v[2] + px[k * 4 + 3] * v[3];
-        scx = sc;
-      }
-      if (kind == kFusedRP) {
-        --sp;
-        const double *d = stk + ((size_t)sp * 64 + lane) * 4;
-        const double2 lo = reinterpret_cast<const double2 *>(d)[0];
-        const double2 hi = reinterpret_cast<const double2 *>(d)[1];
-        const double *__restrict__ py = pm + (size_t)(uni(cur.mats >> 16) * R + r) * 16;
+    for (int q = 0; q < NS; ++q) {
+      st.sc[q] = 0;
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-          ty[k] = py[k * 4 + 0] * lo.x + py[k * 4 + 1] * lo.y + py[k * 4 + 2] * hi.x + py[k * 4 + 3] * hi.y;
-        scy = stk_sc[sp * 64 + lane];
-      } else {
-        const double2 lo = reinterpret_cast<const double2 *>(rowy)[0];
-        const double2 hi = reinterpret_cast<const double2 *>(rowy)[1];
-        ty[0] = lo.x; ty[1] = lo.y; ty[2] = hi.x; ty[3] = hi.y;
-        scy = 0;
-      }
-#pragma unroll
-      for (int k = 0; k < 4; ++k) v[k] = tx[k] * ty[k];
-      sc = scx + scy;
-      // all four entries < 2^-256  <=>  the largest high word < that of 2^-256
-      // (entries are non-negative; a NaN compares as large and never rescales)
-      const unsigned hmax = max(max((unsigned)__double2hiint(v[0]), (unsigned)__double2hiint(v[1])),
-                                max((unsigned)__double2hiint(v[2]), (unsigned)__double2hiint(v[3])));
-      if (hmax < 0x2FF00000u) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] *= kScaleFactor;
-        sc += 1;
-      }
-      cur = nxt;
-      nxt = nn;
+      for (int k = 0; k < 4; ++k) st.v[q][k] = 0.0;
     }
+    unsigned sp = 0;
+    const unsigned roff = uni(r * 128u);   // byte offset of rate r inside a matrix slot
+    // Software pipeline, unrolled by two with ping-pong register sets (A/B) so
+    // that no prefetched value is ever copied at the loop edge (a copy would
+    // force the wait for the prefetch into the same iteration): while op i
+    // computes, the tip codes / tip-table entries of op i+1 and the descriptor
+    // of op i+2 are in flight.
+#define RDAMD_LOAD_TIPS(op, cx, cy, ex, ey)                                                     \
+  _Pragma("unroll") for (int q = 0; q < NS; ++q) {                                              \
+    if (!(ABL & 4)) {                                                                           \
+    cx[q] = (unsigned)__builtin_amdgcn_raw_buffer_load_b8(tips_rs, site_off[q], (int)uni(op.cX), 0); \
+    cy[q] = (unsigned)__builtin_amdgcn_raw_buffer_load_b8(tips_rs, site_off[q], (int)uni(op.cY), 0); } \
+  }                                                                                             \
+  if (!(ABL & 2)) {                                                                             \
+  ex = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(                          \
+      tab_rs, lane8, (int)((uni(op.pX) + roff) * 4u), 0));                                      \
+  ey = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(                          \
+      tab_rs, lane8, (int)((uni(op.pY) + roff) * 4u), 0)); }
+
+    // one traversal step: `cur`/c?/e? hold op i (all arrived), `nxt` is the
+    // descriptor of op i+1 whose tip data is fetched into nc?/ne?; finally the
+    // `cur` slot is refilled with the descriptor of op i+2.
+#define RDAMD_STEP(cur, nxt, cx, cy, ex, ey, ncx, ncy, nex, ney, idx2)                          \
+  {                                                                                             \
+    const unsigned kind = uni(cur.flags);                                                       \
+    const double *__restrict__ px = reinterpret_cast<const double *>(pm + ((ABL & 1) ? 0u : uni(cur.pX)) + roff);   \
+    const double *__restrict__ py = reinterpret_cast<const double *>(pm + ((ABL & 1) ? 256u : uni(cur.pY)) + roff); \
+    cur = prog[idx2];                                                                           \
+    const double *rowx[NS], *rowy[NS];                                                          \
+    _Pragma("unroll") for (int q = 0; q < NS; ++q) { rowx[q] = tabx + cx[q] * 4; rowy[q] = taby + cy[q] * 4; } \
+    double tx[NS][4], ty[NS][4];                                                                \
+    if (kind & 0x100u) { /* cherry that must park the running CLV first */                      \
+      _Pragma("unroll") for (int q = 0; q < NS; ++q) {                                          \
+        double2 *d = stk + (size_t)(sp * NS + q) * 128;                                         \
+        d[0] = make_double2(st.v[q][0], st.v[q][1]);                                            \
+        d[64] = make_double2(st.v[q][2], st.v[q][3]);                                           \
+        stk_sc[(sp * NS + q) * 64] = st.sc[q];                                                  \
+      }                                                                                         \
+      ++sp;                                                                                     \
+    }                                                                                           \
+    const unsigned k3 = kind & 3u;                                                              \
+    if (k3 == kFusedTT) {                                                                       \
+      tabx[lane] = ex;                                                                          \
+      taby[lane] = ey;                                                                          \
+      _Pragma("unroll") for (int q = 0; q < NS; ++q) { read_row(rowx[q], tx[q]); read_row(rowy[q], ty[q]); } \
+      RDAMD_LOAD_TIPS(nxt, ncx, ncy, nex, ney)                                                  \
+      _Pragma("unroll") for (int q = 0; q < NS; ++q) { st.sc[q] = 0; combine(tx[q], ty[q], st.v[q], st.sc[q]); } \
+    } else if (k3 == kFusedRT) {                                                                \
+      taby[lane] = ey;                                                                          \
+      _Pragma("unroll") for (int q = 0; q < NS; ++q) read_row(rowy[q], ty[q]);                  \
+      RDAMD_LOAD_TIPS(nxt, ncx, ncy, nex, ney)                                                  \
+      _Pragma("unroll") for (int q = 0; q < NS; ++q) matvec(px, st.v[q], tx[q]);                \
+      _Pragma("unroll") for (int q = 0; q < NS; ++q) combine(tx[q], ty[q], st.v[q], st.sc[q]);  \
+    } else { /* kFusedRP: X = running CLV, Y = popped sibling */                                \
+      --sp;                                                                                     \
+      double y[NS][4];                                                                          \
+      int scy[NS];                                                                              \
+      _Pragma("unroll") for (int q = 0; q < NS; ++q) {                                          \
+        const double2 *d = stk + (size_t)(sp * NS + q) * 128;                                   \
+        const double2 lo = d[0], hi = d[64];                                                    \
+        y[q][0] = lo.x; y[q][1] = lo.y; y[q][2] = hi.x; y[q][3] = hi.y;                         \
+        scy[q] = stk_sc[(sp * NS + q) * 64];                                                    \
+      }                                                                                         \
+      RDAMD_LOAD_TIPS(nxt, ncx, ncy, nex, ney)                                                  \
+      _Pragma("unroll") for (int q = 0; q < NS; ++q) matvec(px, st.v[q], tx[q]);                \
+      _Pragma("unroll") for (int q = 0; q < NS; ++q) matvec(py, y[q], ty[q]);                   \
+      _Pragma("unroll") for (int q = 0; q < NS; ++q) { st.sc[q] += scy[q]; combine(tx[q], ty[q], st.v[q], st.sc[q]); } \
+    }                                                                                           \
+  }
+
+    FusedOp dA = prog[0];
+    FusedOp dB = prog[1];
+    unsigned cxA[NS], cyA[NS], cxB[NS], cyB[NS];
+    double exA = 0.5, eyA = 0.25, exB = 0.5, eyB = 0.25;
+#pragma unroll
+    for (int q = 0; q < NS; ++q) { cxA[q] = cxB[q] = 1; cyA[q] = cyB[q] = 2; }
+    RDAMD_LOAD_TIPS(dA, cxA, cyA, exA, eyA)
+    unsigned i = 0;
+    for (; i + 1 < nops; i += 2) {
+      RDAMD_STEP(dA, dB, cxA, cyA, exA, eyA, cxB, cyB, exB, eyB, i + 2)
+      RDAMD_STEP(dB, dA, cxB, cyB, exB, eyB, cxA, cyA, exA, eyA, i + 3)
+    }
+    if (i < nops) {   // odd tail (the program is padded, so the prefetches stay in bounds)
+      RDAMD_STEP(dA, dB, cxA, cyA, exA, eyA, cxB, cyB, exB, eyB, i + 2)
+    }
+#undef RDAMD_STEP
     // root: f_r = sum_k pi_k v[k]; fold into the running rate sum
-    double f = v[0] * freqs[0] + v[1] * freqs[1] + v[2] * freqs[2] + v[3] * freqs[3];
-    f *= rw[r];
-    if (r == 0) {
-      term = f;
-      smin = sc;
-    } else if (sc >= smin) {
-      term += f * pow2_neg256(sc - smin);
-    } else {
-      term = term * pow2_neg256(smin - sc) + f;
-      smin = sc;
+    const double w = rw[r];
+#pragma unroll
+    for (int q = 0; q < NS; ++q) {
+      double f = st.v[q][0] * freqs[0] + st.v[q][1] * freqs[1] + st.v[q][2] * freqs[2] +
+                 st.v[q][3] * freqs[3];
+      f *= w;
+      if (r == 0) {
+        term[q] = f;
+        smin[q] = st.sc[q];
+      } else if (st.sc[q] >= smin[q]) {
+        term[q] += f * pow2_neg256(st.sc[q] - smin[q]);
+      } else {
+        term[q] = term[q] * pow2_neg256(smin[q] - st.sc[q]) + f;
+        smin[q] = st.sc[q];
+      }
     }
   }
-#undef RDAMD_LOAD_CODE
-#undef RDAMD_LOAD_TAB
 
-  double l = log(term) + (double)smin * kLogScaleThreshold;
-  l *= (double)a.pattern_weights[site];
-  if (!valid) l = 0.0;
-  if (a.persite && valid) a.persite[(size_t)job * S + site] = l;
+  double total = 0.0;
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) l += __shfl_down(l, off);
-  if (lane == 0) a.partials[(size_t)job * gridDim.x + blockIdx.x] = l;
+  for (int q = 0; q < NS; ++q) {
+    double l = log(term[q]) + (double)smin[q] * kLogScaleThreshold;
+    l *= (double)a.pattern_weights[site[q]];
+    if (!valid[q]) l = 0.0;
+    if (a.persite && valid[q]) a.persite[(size_t)job * S + site[q]] = l;
+    total += l;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) total += __shfl_down(total, off);
+  if (lane == 0) a.partials[(size_t)job * gridDim.x + blockIdx.x] = total;
 }
 
 // fixed-order finish, one workgroup per job
@@ -301,17 +366,26 @@ hipError_t launch_fused_pmatrix(const FusedArgs &a, const double *d_q, const dou
 hipError_t launch_fused_eval(const FusedArgs &a, unsigned n_jobs, unsigned max_depth,
                              unsigned blocks_x, double *d_out, hipStream_t stream) {
   if (!n_jobs) return hipSuccess;
+  const char *nsv = getenv("RDAMD_NS");
+  const int ns = nsv ? atoi(nsv) : kFusedSitesPerLane;
   const size_t lds = kTabDoubles * sizeof(double) +
-                     (size_t)(max_depth ? max_depth : 1) * 64 * (4 * sizeof(double) + sizeof(int));
-  static size_t lds_limit_set = 0;
-  if (lds > 48 * 1024 && lds > lds_limit_set) {
-    hipError_t e = hipFuncSetAttribute((const void *)fused_dna_eval_kernel,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    lds_limit_set = lds;
-  }
+                     (size_t)(max_depth ? max_depth : 1) * ns * 64 *
+                         (4 * sizeof(double) + sizeof(int));
   dim3 grid(blocks_x, n_jobs);
-  fused_dna_eval_kernel<<<grid, 64, lds, stream>>>(a);
+  const char *ab = getenv("RDAMD_ABL");
+  int abl = ab ? atoi(ab) : 0;
+  if (ns == 1) {
+    fused_dna_eval_kernel<1, 0><<<grid, 64, lds, stream>>>(a);
+  } else
+  switch (abl) {
+    case 1: fused_dna_eval_kernel<kFusedSitesPerLane, 1><<<grid, 64, lds, stream>>>(a); break;
+    case 2: fused_dna_eval_kernel<kFusedSitesPerLane, 2><<<grid, 64, lds, stream>>>(a); break;
+    case 3: fused_dna_eval_kernel<kFusedSitesPerLane, 3><<<grid, 64, lds, stream>>>(a); break;
+    case 4: fused_dna_eval_kernel<kFusedSitesPerLane, 4><<<grid, 64, lds, stream>>>(a); break;
+    case 6: fused_dna_eval_kernel<kFusedSitesPerLane, 6><<<grid, 64, lds, stream>>>(a); break;
+    case 7: fused_dna_eval_kernel<kFusedSitesPerLane, 7><<<grid, 64, lds, stream>>>(a); break;
+    default: fused_dna_eval_kernel<kFusedSitesPerLane, 0><<<grid, 64, lds, stream>>>(a); break;
+  }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   fused_finish_kernel<<<n_jobs, 256, 0, stream>>>(a.partials, blocks_x, d_out);
