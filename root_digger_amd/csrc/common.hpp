@@ -121,12 +121,12 @@ hipError_t launch_pmatrix(rdamd_partition *p, const unsigned *d_params_indices,
 hipError_t launch_tiptab_all(rdamd_partition *p);
 
 // kernels_clv.hip
-struct LevelOp {   // device-side op descriptor (one per blockIdx.y)
+struct LevelOp {   // device-side op descriptor
   unsigned parent_clv, child1_clv, child2_clv;     // absolute clv indices
   unsigned child1_mat, child2_mat;
   int parent_sc, child1_sc, child2_sc;
 };
-hipError_t launch_clv_level(rdamd_partition *p, const LevelOp *d_ops, unsigned nops);
+hipError_t launch_clv_traversal(rdamd_partition *p, const LevelOp *d_ops, unsigned nops);
 
 // kernels_root.hip
 hipError_t launch_root_lnl(rdamd_partition *p, unsigned clv_index, int scaler_index,

@@ -63,8 +63,7 @@ static hipError_t ensure_workspace(rdamd_partition *p, unsigned n_jobs) {
   // site blocks padded to a multiple of 8 so that blockIdx.x % 8 (the XCD a
   // workgroup lands on) is the same for every job: each XCD's L2 then only
   // ever sees 1/8 of the tip codes.
-  const char *nsv = getenv("RDAMD_NS");
-  const unsigned per_block = 64 * (nsv ? atoi(nsv) : kFusedSitesPerLane);
+  const unsigned per_block = 64 * kFusedSitesPerLane;
   w->blocks_x = ((p->sites + per_block - 1) / per_block + 7) / 8 * 8;
   const size_t pm_per_job = (size_t)p->prob_matrices * R * 16;
 #define A(ptr, bytes) do { e = hipMalloc((void **)&(ptr), (bytes)); if (e != hipSuccess) return e; } while (0)

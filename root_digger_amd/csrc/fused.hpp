@@ -15,9 +15,10 @@ enum : uint32_t {
   kFusedRP = 2,   // X = running CLV (register), Y = popped from the LDS stack
 };
 
-// sites each lane of the fused kernel carries (independent chains per lane:
-// halves the scalar / latency overhead per unit of vector work)
-constexpr int kFusedSitesPerLane = 2;
+// sites each lane of the fused kernel carries.  2 halves the scalar work per
+// site but doubles the LDS stack per wave (half the waves per CU); measured
+// equal within 3 % on c2, so the simpler 1 is used.
+constexpr int kFusedSitesPerLane = 1;
 
 // One step of a compiled traversal ("program"), 32 bytes, one scalar load.
 // All offsets are precomputed on the host so the kernel adds at most the rate.

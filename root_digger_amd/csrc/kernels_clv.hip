@@ -11,9 +11,15 @@
 // HBM layout: CLV [site][rate][state] contiguous doubles, so consecutive lanes
 // read consecutive 32-byte (DNA) records.  Tips are never expanded to CLVs:
 // a tip child contributes tiptab[matrix][rate][code][i] (built next to the
-// P-matrices), read from LDS.  All operations of one dependency level run in
-// ONE launch (blockIdx.y = operation), so a 100-taxon traversal is ~10-20
-// launches instead of 99.
+// P-matrices), read from LDS.
+//
+// A whole operation list runs in ONE launch.  Every dependency of the
+// traversal is site-local -- parent[s][r] needs only child[s][r] -- and the
+// lane -> (site, rate) assignment is the same for every operation, so a lane
+// only ever reads what it (or, for the per-site scaler, a neighbour lane of its
+// own wave) wrote earlier in the same kernel: no grid-wide synchronisation,
+// and a child CLV written a few operations earlier is usually still in L2
+// when its parent reads it.
 #include "common.hpp"
 
 namespace rdamd {
@@ -24,80 +30,94 @@ namespace rdamd {
 // ---------------------------------------------------------------------------
 template <int R>
 __global__ void __launch_bounds__(256)
-clv_dna_level_kernel(DeviceView v, const LevelOp *__restrict__ ops) {
-  // per child: P-matrix [R][4][4] or tip table [R][16][4]
-  __shared__ double smat[2][R * 64];
-  const LevelOp op = ops[blockIdx.y];
-  const bool tip1 = op.child1_clv < v.tips, tip2 = op.child2_clv < v.tips;
+clv_dna_traversal_kernel(DeviceView v, const LevelOp *__restrict__ ops, unsigned nops) {
+  // per child: P-matrix [R][4][4] or tip table [R][16][4]; double-buffered so
+  // the matrices of operation i+1 are staged while operation i computes
+  __shared__ double smat[2][2][R * 64];
   const unsigned tid = threadIdx.x;
-  {
-    const double *src1 = tip1 ? v.tiptab + (size_t)op.child1_mat * R * 64
-                              : v.pmat + (size_t)op.child1_mat * R * 16;
-    const double *src2 = tip2 ? v.tiptab + (size_t)op.child2_mat * R * 64
-                              : v.pmat + (size_t)op.child2_mat * R * 16;
-    const unsigned n1 = tip1 ? R * 64 : R * 16, n2 = tip2 ? R * 64 : R * 16;
-    for (unsigned e = tid; e < n1; e += 256) smat[0][e] = src1[e];
-    for (unsigned e = tid; e < n2; e += 256) smat[1][e] = src2[e];
-  }
-  __syncthreads();
-
   const unsigned S = v.sites;
   const size_t total = (size_t)S * R;
-  const double2 *c1 = tip1 ? nullptr
-      : reinterpret_cast<const double2 *>(v.clv + (size_t)(op.child1_clv - v.tips) * v.clv_stride);
-  const double2 *c2 = tip2 ? nullptr
-      : reinterpret_cast<const double2 *>(v.clv + (size_t)(op.child2_clv - v.tips) * v.clv_stride);
-  double2 *pc = reinterpret_cast<double2 *>(v.clv + (size_t)(op.parent_clv - v.tips) * v.clv_stride);
-  const uint8_t *code1 = tip1 ? v.tipcodes + (size_t)op.child1_clv * S : nullptr;
-  const uint8_t *code2 = tip2 ? v.tipcodes + (size_t)op.child2_clv * S : nullptr;
-  unsigned *psc = op.parent_sc >= 0 ? v.scaler + (size_t)op.parent_sc * S : nullptr;
-  const unsigned *lsc = op.child1_sc >= 0 ? v.scaler + (size_t)op.child1_sc * S : nullptr;
-  const unsigned *rsc = op.child2_sc >= 0 ? v.scaler + (size_t)op.child2_sc * S : nullptr;
-
   const size_t stride = (size_t)gridDim.x * 256;
-  for (size_t idx = (size_t)blockIdx.x * 256 + tid; idx < total; idx += stride) {
-    const unsigned s = (unsigned)(idx / R), r = (unsigned)(idx % R);
-    double t1[4], t2[4];
-    if (tip1) {
-      const double *row = &smat[0][(r * 16 + code1[s]) * 4];
+
+  auto stage = [&](unsigned i, unsigned buf) {
+    const LevelOp op = ops[i];
+    const bool t1 = op.child1_clv < v.tips, t2 = op.child2_clv < v.tips;
+    const double *src1 = t1 ? v.tiptab + (size_t)op.child1_mat * R * 64
+                            : v.pmat + (size_t)op.child1_mat * R * 16;
+    const double *src2 = t2 ? v.tiptab + (size_t)op.child2_mat * R * 64
+                            : v.pmat + (size_t)op.child2_mat * R * 16;
+    const unsigned n1 = t1 ? R * 64 : R * 16, n2 = t2 ? R * 64 : R * 16;
+    for (unsigned e = tid; e < n1; e += 256) smat[buf][0][e] = src1[e];
+    for (unsigned e = tid; e < n2; e += 256) smat[buf][1][e] = src2[e];
+  };
+
+  stage(0, 0);
+  __syncthreads();
+  for (unsigned i = 0; i < nops; ++i) {
+    const unsigned buf = i & 1;
+    if (i + 1 < nops) stage(i + 1, buf ^ 1);
+    const LevelOp op = ops[i];
+    const bool tip1 = op.child1_clv < v.tips, tip2 = op.child2_clv < v.tips;
+    const double2 *c1 = tip1 ? nullptr
+        : reinterpret_cast<const double2 *>(v.clv + (size_t)(op.child1_clv - v.tips) * v.clv_stride);
+    const double2 *c2 = tip2 ? nullptr
+        : reinterpret_cast<const double2 *>(v.clv + (size_t)(op.child2_clv - v.tips) * v.clv_stride);
+    double2 *pc = reinterpret_cast<double2 *>(v.clv + (size_t)(op.parent_clv - v.tips) * v.clv_stride);
+    const uint8_t *code1 = tip1 ? v.tipcodes + (size_t)op.child1_clv * S : nullptr;
+    const uint8_t *code2 = tip2 ? v.tipcodes + (size_t)op.child2_clv * S : nullptr;
+    unsigned *psc = op.parent_sc >= 0 ? v.scaler + (size_t)op.parent_sc * S : nullptr;
+    const unsigned *lsc = op.child1_sc >= 0 ? v.scaler + (size_t)op.child1_sc * S : nullptr;
+    const unsigned *rsc = op.child2_sc >= 0 ? v.scaler + (size_t)op.child2_sc * S : nullptr;
+
+    for (size_t idx = (size_t)blockIdx.x * 256 + tid; idx < total; idx += stride) {
+      const unsigned s = (unsigned)(idx / R), r = (unsigned)(idx % R);
+      double t1[4], t2[4];
+      if (tip1) {
+        const double *row = &smat[buf][0][(r * 16 + code1[s]) * 4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) t1[i] = row[i];
-    } else {
-      const double2 a = c1[idx * 2], b = c1[idx * 2 + 1];
-      const double *m = &smat[0][r * 16];
+        for (int k = 0; k < 4; ++k) t1[k] = row[k];
+      } else {
+        const double2 a = c1[idx * 2], b = c1[idx * 2 + 1];
+        const double *m = &smat[buf][0][r * 16];
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-        t1[i] = m[i * 4 + 0] * a.x + m[i * 4 + 1] * a.y + m[i * 4 + 2] * b.x + m[i * 4 + 3] * b.y;
-    }
-    if (tip2) {
-      const double *row = &smat[1][(r * 16 + code2[s]) * 4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) t2[i] = row[i];
-    } else {
-      const double2 a = c2[idx * 2], b = c2[idx * 2 + 1];
-      const double *m = &smat[1][r * 16];
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-        t2[i] = m[i * 4 + 0] * a.x + m[i * 4 + 1] * a.y + m[i * 4 + 2] * b.x + m[i * 4 + 3] * b.y;
-    }
-    double o[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) o[i] = t1[i] * t2[i];
-    if (psc) {
-      int small = (o[0] < kScaleThreshold) & (o[1] < kScaleThreshold) &
-                  (o[2] < kScaleThreshold) & (o[3] < kScaleThreshold);
-#pragma unroll
-      for (int off = 1; off < R; off <<= 1) small &= __shfl_xor(small, off);
-      unsigned sc = (lsc ? lsc[s] : 0u) + (rsc ? rsc[s] : 0u);
-      if (small) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) o[i] *= kScaleFactor;
-        sc += 1;
+        for (int k = 0; k < 4; ++k)
+          t1[k] = m[k * 4 + 0] * a.x + m[k * 4 + 1] * a.y + m[k * 4 + 2] * b.x + m[k * 4 + 3] * b.y;
       }
-      if (r == 0) psc[s] = sc;
+      if (tip2) {
+        const double *row = &smat[buf][1][(r * 16 + code2[s]) * 4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) t2[k] = row[k];
+      } else {
+        const double2 a = c2[idx * 2], b = c2[idx * 2 + 1];
+        const double *m = &smat[buf][1][r * 16];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          t2[k] = m[k * 4 + 0] * a.x + m[k * 4 + 1] * a.y + m[k * 4 + 2] * b.x + m[k * 4 + 3] * b.y;
+      }
+      double o[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) o[k] = t1[k] * t2[k];
+      if (psc) {
+        int small = (o[0] < kScaleThreshold) & (o[1] < kScaleThreshold) &
+                    (o[2] < kScaleThreshold) & (o[3] < kScaleThreshold);
+#pragma unroll
+        for (int off = 1; off < R; off <<= 1) small &= __shfl_xor(small, off);
+        unsigned sc = (lsc ? lsc[s] : 0u) + (rsc ? rsc[s] : 0u);
+        if (small) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) o[k] *= kScaleFactor;
+          sc += 1;
+        }
+        if (r == 0) psc[s] = sc;
+      }
+      pc[idx * 2] = make_double2(o[0], o[1]);
+      pc[idx * 2 + 1] = make_double2(o[2], o[3]);
     }
-    pc[idx * 2] = make_double2(o[0], o[1]);
-    pc[idx * 2 + 1] = make_double2(o[2], o[3]);
+    // (a) the staged matrices of op i+1 become visible, (b) nobody still reads
+    // buffer `buf` when op i+2 is staged into it, (c) this workgroup's CLV and
+    // scaler stores are ordered before its later loads of them
+    __threadfence_block();
+    __syncthreads();
   }
 }
 
@@ -107,8 +127,9 @@ clv_dna_level_kernel(DeviceView v, const LevelOp *__restrict__ ops) {
 // protein data.
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
-clv_generic_level_kernel(DeviceView v, const LevelOp *__restrict__ ops) {
-  const LevelOp op = ops[blockIdx.y];
+clv_generic_traversal_kernel(DeviceView v, const LevelOp *__restrict__ ops, unsigned nops) {
+ for (unsigned oi = 0; oi < nops; ++oi) {
+  const LevelOp op = ops[oi];
   const unsigned K = v.states, R = v.rate_cats, S = v.sites, cap = v.ncodes_cap;
   const bool tip1 = op.child1_clv < v.tips, tip2 = op.child2_clv < v.tips;
   const double *c1 = tip1 ? nullptr : v.clv + (size_t)(op.child1_clv - v.tips) * v.clv_stride;
@@ -161,35 +182,34 @@ clv_generic_level_kernel(DeviceView v, const LevelOp *__restrict__ ops) {
       psc[s] = sc;
     }
   }
+  __threadfence_block();   // a lane re-reads only its own site's earlier stores
+ }
 }
 
 static inline bool dna_fast_ok(unsigned K, unsigned R, unsigned cap) {
   return K == 4 && cap == 16 && (R == 1 || R == 2 || R == 4 || R == 8 || R == 16);
 }
 
-hipError_t launch_clv_level(rdamd_partition *p, const LevelOp *d_ops, unsigned nops) {
+hipError_t launch_clv_traversal(rdamd_partition *p, const LevelOp *d_ops, unsigned nops) {
   if (nops == 0 || p->sites == 0) return hipSuccess;
   DeviceView v = p->view();
   const unsigned K = p->states, R = p->rate_cats;
   if (dna_fast_ok(K, R, p->ncodes_cap)) {
+    // one (site, rate) pair per lane where possible: maximum memory-level
+    // parallelism; the lane -> pair map is identical for every operation
     size_t total = (size_t)p->sites * R;
     unsigned gx = (unsigned)((total + 255) / 256);
-    // enough workgroups to fill 256 CUs x 8, but no more than the work needs
-    unsigned cap = (2048 + nops - 1) / nops;
-    if (cap < 32) cap = 32;
-    if (gx > cap) gx = cap;
-    dim3 grid(gx, nops);
+    if (gx > 8192) gx = 8192;
     switch (R) {
-      case 1: clv_dna_level_kernel<1><<<grid, 256, 0, p->stream>>>(v, d_ops); break;
-      case 2: clv_dna_level_kernel<2><<<grid, 256, 0, p->stream>>>(v, d_ops); break;
-      case 4: clv_dna_level_kernel<4><<<grid, 256, 0, p->stream>>>(v, d_ops); break;
-      case 8: clv_dna_level_kernel<8><<<grid, 256, 0, p->stream>>>(v, d_ops); break;
-      default: clv_dna_level_kernel<16><<<grid, 256, 0, p->stream>>>(v, d_ops); break;
+      case 1: clv_dna_traversal_kernel<1><<<gx, 256, 0, p->stream>>>(v, d_ops, nops); break;
+      case 2: clv_dna_traversal_kernel<2><<<gx, 256, 0, p->stream>>>(v, d_ops, nops); break;
+      case 4: clv_dna_traversal_kernel<4><<<gx, 256, 0, p->stream>>>(v, d_ops, nops); break;
+      case 8: clv_dna_traversal_kernel<8><<<gx, 256, 0, p->stream>>>(v, d_ops, nops); break;
+      default: clv_dna_traversal_kernel<16><<<gx, 256, 0, p->stream>>>(v, d_ops, nops); break;
     }
   } else {
     unsigned gx = (p->sites + 255) / 256;
-    dim3 grid(gx, nops);
-    clv_generic_level_kernel<<<grid, 256, 0, p->stream>>>(v, d_ops);
+    clv_generic_traversal_kernel<<<gx, 256, 0, p->stream>>>(v, d_ops, nops);
   }
   return hipGetLastError();
 }

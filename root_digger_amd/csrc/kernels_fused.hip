@@ -90,7 +90,7 @@ __device__ __forceinline__ void combine(const double (&tx)[4], const double (&ty
   }
 }
 
-template <int NS, int ABL>
+template <int NS>
 __global__ void __launch_bounds__(64)
 fused_dna_eval_kernel(FusedArgs a) {
   extern __shared__ double lds[];
@@ -146,15 +146,13 @@ fused_dna_eval_kernel(FusedArgs a) {
     // of op i+2 are in flight.
 #define RDAMD_LOAD_TIPS(op, cx, cy, ex, ey)                                                     \
   _Pragma("unroll") for (int q = 0; q < NS; ++q) {                                              \
-    if (!(ABL & 4)) {                                                                           \
     cx[q] = (unsigned)__builtin_amdgcn_raw_buffer_load_b8(tips_rs, site_off[q], (int)uni(op.cX), 0); \
-    cy[q] = (unsigned)__builtin_amdgcn_raw_buffer_load_b8(tips_rs, site_off[q], (int)uni(op.cY), 0); } \
+    cy[q] = (unsigned)__builtin_amdgcn_raw_buffer_load_b8(tips_rs, site_off[q], (int)uni(op.cY), 0); \
   }                                                                                             \
-  if (!(ABL & 2)) {                                                                             \
   ex = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(                          \
       tab_rs, lane8, (int)((uni(op.pX) + roff) * 4u), 0));                                      \
   ey = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(                          \
-      tab_rs, lane8, (int)((uni(op.pY) + roff) * 4u), 0)); }
+      tab_rs, lane8, (int)((uni(op.pY) + roff) * 4u), 0));
 
     // one traversal step: `cur`/c?/e? hold op i (all arrived), `nxt` is the
     // descriptor of op i+1 whose tip data is fetched into nc?/ne?; finally the
@@ -162,8 +160,8 @@ fused_dna_eval_kernel(FusedArgs a) {
 #define RDAMD_STEP(cur, nxt, cx, cy, ex, ey, ncx, ncy, nex, ney, idx2)                          \
   {                                                                                             \
     const unsigned kind = uni(cur.flags);                                                       \
-    const double *__restrict__ px = reinterpret_cast<const double *>(pm + ((ABL & 1) ? 0u : uni(cur.pX)) + roff);   \
-    const double *__restrict__ py = reinterpret_cast<const double *>(pm + ((ABL & 1) ? 256u : uni(cur.pY)) + roff); \
+    const double *__restrict__ px = reinterpret_cast<const double *>(pm + uni(cur.pX) + roff); \
+    const double *__restrict__ py = reinterpret_cast<const double *>(pm + uni(cur.pY) + roff); \
     cur = prog[idx2];                                                                           \
     const double *rowx[NS], *rowy[NS];                                                          \
     _Pragma("unroll") for (int q = 0; q < NS; ++q) { rowx[q] = tabx + cx[q] * 4; rowy[q] = taby + cy[q] * 4; } \
@@ -366,26 +364,18 @@ hipError_t launch_fused_pmatrix(const FusedArgs &a, const double *d_q, const dou
 hipError_t launch_fused_eval(const FusedArgs &a, unsigned n_jobs, unsigned max_depth,
                              unsigned blocks_x, double *d_out, hipStream_t stream) {
   if (!n_jobs) return hipSuccess;
-  const char *nsv = getenv("RDAMD_NS");
-  const int ns = nsv ? atoi(nsv) : kFusedSitesPerLane;
   const size_t lds = kTabDoubles * sizeof(double) +
-                     (size_t)(max_depth ? max_depth : 1) * ns * 64 *
+                     (size_t)(max_depth ? max_depth : 1) * kFusedSitesPerLane * 64 *
                          (4 * sizeof(double) + sizeof(int));
-  dim3 grid(blocks_x, n_jobs);
-  const char *ab = getenv("RDAMD_ABL");
-  int abl = ab ? atoi(ab) : 0;
-  if (ns == 1) {
-    fused_dna_eval_kernel<1, 0><<<grid, 64, lds, stream>>>(a);
-  } else
-  switch (abl) {
-    case 1: fused_dna_eval_kernel<kFusedSitesPerLane, 1><<<grid, 64, lds, stream>>>(a); break;
-    case 2: fused_dna_eval_kernel<kFusedSitesPerLane, 2><<<grid, 64, lds, stream>>>(a); break;
-    case 3: fused_dna_eval_kernel<kFusedSitesPerLane, 3><<<grid, 64, lds, stream>>>(a); break;
-    case 4: fused_dna_eval_kernel<kFusedSitesPerLane, 4><<<grid, 64, lds, stream>>>(a); break;
-    case 6: fused_dna_eval_kernel<kFusedSitesPerLane, 6><<<grid, 64, lds, stream>>>(a); break;
-    case 7: fused_dna_eval_kernel<kFusedSitesPerLane, 7><<<grid, 64, lds, stream>>>(a); break;
-    default: fused_dna_eval_kernel<kFusedSitesPerLane, 0><<<grid, 64, lds, stream>>>(a); break;
+  static size_t lds_limit_set = 0;
+  if (lds > 48 * 1024 && lds > lds_limit_set) {
+    hipError_t e = hipFuncSetAttribute((const void *)fused_dna_eval_kernel<kFusedSitesPerLane>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    lds_limit_set = lds;
   }
+  dim3 grid(blocks_x, n_jobs);
+  fused_dna_eval_kernel<kFusedSitesPerLane><<<grid, 64, lds, stream>>>(a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   fused_finish_kernel<<<n_jobs, 256, 0, stream>>>(a.partials, blocks_x, d_out);

@@ -395,12 +395,7 @@ void rdamd_update_clvs(rdamd_partition_t *p, const rdamd_operation_t *ops,
   clear_error();
   if (count == 0) return;
   const unsigned nclv = p->tips + p->clv_buffers;
-  // dependency levels: an op sits one level above the latest op (of this call)
-  // that produces one of its children.
-  std::unordered_map<unsigned, unsigned> produced;  // clv index -> level
-  std::unordered_map<unsigned, unsigned> last_read; // clv index -> latest reader level
-  std::vector<unsigned> level(count);
-  unsigned nlevels = 0;
+  std::vector<LevelOp> lops(count);
   for (unsigned i = 0; i < count; ++i) {
     const rdamd_operation_t &o = ops[i];
     if (o.parent_clv_index < p->tips || o.parent_clv_index >= nclv ||
@@ -413,59 +408,26 @@ void rdamd_update_clvs(rdamd_partition_t *p, const rdamd_operation_t *ops,
       set_error(10, "rdamd_update_clvs: operation %u has an index out of range", i);
       return;
     }
-    unsigned l = 0;
-    auto it = produced.find(o.child1_clv_index);
-    if (it != produced.end()) l = std::max(l, it->second + 1);
-    it = produced.find(o.child2_clv_index);
-    if (it != produced.end()) l = std::max(l, it->second + 1);
-    // a buffer rewritten later in the same call must wait for its readers too
-    it = produced.find(o.parent_clv_index);
-    if (it != produced.end()) l = std::max(l, it->second + 1);
-    it = last_read.find(o.parent_clv_index);
-    if (it != last_read.end()) l = std::max(l, it->second + 1);
-    level[i] = l;
-    produced[o.parent_clv_index] = l;
-    for (unsigned c : {o.child1_clv_index, o.child2_clv_index}) {
-      auto rit = last_read.find(c);
-      if (rit == last_read.end() || rit->second < l) last_read[c] = l;
-    }
-    nlevels = std::max(nlevels, l + 1);
-  }
-  std::vector<unsigned> order(count);
-  for (unsigned i = 0; i < count; ++i) order[i] = i;
-  std::stable_sort(order.begin(), order.end(),
-                   [&](unsigned a, unsigned b) { return level[a] < level[b]; });
-  std::vector<LevelOp> lops(count);
-  std::vector<unsigned> level_start(nlevels + 1, 0);
-  for (unsigned k = 0; k < count; ++k) {
-    const rdamd_operation_t &o = ops[order[k]];
-    LevelOp &d = lops[k];
+    LevelOp &d = lops[i];
     d.parent_clv = o.parent_clv_index; d.child1_clv = o.child1_clv_index;
     d.child2_clv = o.child2_clv_index; d.child1_mat = o.child1_matrix_index;
     d.child2_mat = o.child2_matrix_index; d.parent_sc = o.parent_scaler_index;
     d.child1_sc = o.child1_scaler_index; d.child2_sc = o.child2_scaler_index;
-    level_start[level[order[k]] + 1] = k + 1;
   }
-  for (unsigned l = 1; l <= nlevels; ++l)
-    level_start[l] = std::max(level_start[l], level_start[l - 1]);
-
+  // The whole list runs as one launch in the caller's order: every dependency
+  // is site-local, so the kernel needs no level structure (kernels_clv.hip).
   hipError_t e = ensure_scratch(p, sizeof(LevelOp) * count + 256);
   if (e == hipSuccess && p->tiptab_stale) {
     e = launch_tiptab_all(p);
     p->tiptab_stale = false;
   }
   Scratch sc{p};
-  LevelOp *d_ops = nullptr;
   if (e == hipSuccess) {
-    d_ops = (LevelOp *)sc.take(sizeof(LevelOp) * count);
+    LevelOp *d_ops = (LevelOp *)sc.take(sizeof(LevelOp) * count);
     e = upload(p, d_ops, lops.data(), sizeof(LevelOp) * count);
-  }
-  for (unsigned l = 0; l < nlevels && e == hipSuccess; ++l) {
-    unsigned b = level_start[l], n = level_start[l + 1] - b;
-    // gridDim.y is limited to 65535
-    for (unsigned off = 0; off < n && e == hipSuccess; off += 32768) {
+    if (e == hipSuccess) {
       p->prof_begin(0);
-      e = launch_clv_level(p, d_ops + b + off, std::min(32768u, n - off));
+      e = launch_clv_traversal(p, d_ops, count);
       p->prof_end();
     }
   }
