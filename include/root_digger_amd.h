@@ -292,6 +292,55 @@ char *rdamd_tree_newick(const rdamd_tree_t *t, int annotations);
 int   rdamd_tree_annotate_branch(rdamd_tree_t *t, const rdamd_root_location_t *rl,
                                  const char *key, const char *value); /* :731 */
 
+/* ------------------------------------------------------------------------
+ * Host-side likelihood facade: model_t (src/model.hpp:47-277)
+ *
+ * C wrappers over the C++ class in root_digger_amd/csrc/model.hpp for one
+ * partition (the C++ class takes any number).  Rows a4-a9, a16, a17 of
+ * SURVEY.md section 8a.
+ * --------------------------------------------------------------------- */
+typedef struct rdamd_model rdamd_model_t;
+
+/* model_t(tree, {msa}, {rate_cats}, invariant_sites=false, seed, early_stop),
+ * src/model.cpp:99-176; the tree is copied.  weights may be NULL (all 1). */
+rdamd_model_t *rdamd_model_create(const rdamd_tree_t *tree, unsigned int n_taxa,
+                                  const char *const *labels, const char *const *sequences,
+                                  const unsigned int *weights, unsigned int states,
+                                  const uint64_t *map, unsigned int rate_cats,
+                                  uint64_t seed, int early_stop);
+void rdamd_model_destroy(rdamd_model_t *m);
+/* initialize_partitions / initialize_partitions_uniform_freqs, :1297-1321 */
+int rdamd_model_initialize_partitions(rdamd_model_t *m, int uniform_freqs);
+int rdamd_model_set_subst_rates(rdamd_model_t *m, const double *rates);      /* :184 */
+int rdamd_model_set_subst_rates_uniform(rdamd_model_t *m);                   /* :1748 */
+int rdamd_model_set_freqs(rdamd_model_t *m, const double *freqs);            /* :341 */
+int rdamd_model_set_empirical_freqs(rdamd_model_t *m);                       /* :327 */
+int rdamd_model_set_gamma_alpha(rdamd_model_t *m, double alpha);             /* :224 */
+/* compute_lh / compute_lh_root, :384-452 (NaN + rdamd_errmsg on failure) */
+double rdamd_model_compute_lh(rdamd_model_t *m, const rdamd_root_location_t *rl);
+double rdamd_model_compute_lh_root(rdamd_model_t *m, const rdamd_root_location_t *rl);
+/* compute_dlh, :481-519: out = {lh, dlh} */
+int rdamd_model_compute_dlh(rdamd_model_t *m, const rdamd_root_location_t *rl, double out[2]);
+int rdamd_model_move_root(rdamd_model_t *m, const rdamd_root_location_t *rl);  /* :823 */
+/* compute_all_root_lh, :1737-1746: out holds root_count values */
+int rdamd_model_compute_all_root_lh(rdamd_model_t *m, double *out);
+/* optimize_alpha, :679-794 */
+int rdamd_model_optimize_alpha(rdamd_model_t *m, const rdamd_root_location_t *rl, double atol,
+                               rdamd_root_location_t *out);
+/* batched objective over (root, parameter) pairs: subst [n][K*K-K], freqs
+ * [n][K], gamma_alpha [n] (NULL = 1.0); through rdamd_evaluate_batch */
+int rdamd_model_compute_lh_batch(rdamd_model_t *m, unsigned int n,
+                                 const rdamd_root_location_t *rls, const double *subst,
+                                 const double *freqs, const double *gamma_alpha, double *out);
+/* assign_indicies_by_rank_exhaustive, :1867-1911 */
+int rdamd_model_assign_by_rank(rdamd_model_t *m, unsigned int rank, unsigned int num_tasks);
+/* exhaustive_search, :1139-1272, over the assigned roots.  root_id / llh /
+ * alpha hold root_count entries; *n_results is set; best_* may be NULL. */
+int rdamd_model_exhaustive_search(rdamd_model_t *m, double atol, double pgtol, double brtol,
+                                  double factor, uint64_t *root_id, double *llh, double *alpha,
+                                  unsigned int *n_results, rdamd_root_location_t *best_rl,
+                                  double *best_llh);
+
 /* character maps (replace corax_map_nt / corax_map_bin, src/main.cpp:484) */
 extern const uint64_t rdamd_map_nt[256];
 extern const uint64_t rdamd_map_bin[256];

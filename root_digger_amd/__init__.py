@@ -14,6 +14,7 @@ from .api import (  # noqa: F401
     Tree,
     Partition,
     Schedule,
+    Model,
     MAP_NT,
     MAP_BIN,
     compute_gamma_cats,
@@ -24,7 +25,7 @@ from .api import (  # noqa: F401
 )
 
 __all__ = [
-    "lib", "lib_path", "RdamdError", "Operation", "RootLocation", "Tree", "Partition", "Schedule",
+    "lib", "lib_path", "RdamdError", "Operation", "RootLocation", "Tree", "Partition", "Schedule", "Model",
     "MAP_NT", "MAP_BIN", "compute_gamma_cats", "GAMMA_RATES_MEAN", "GAMMA_RATES_MEDIAN",
     "device_count", "set_device",
 ]

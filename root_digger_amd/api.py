@@ -119,6 +119,26 @@ _sig("rdamd_tree_sanity_check", C.c_int, _vp)
 _sig("rdamd_tree_newick", _vp, _vp, C.c_int)
 _sig("rdamd_tree_annotate_branch", C.c_int, _vp, _prl, C.c_char_p, C.c_char_p)
 
+_sig("rdamd_model_create", _vp, _vp, _u, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), _pu, _u,
+     C.POINTER(C.c_uint64), _u, C.c_uint64, C.c_int)
+_sig("rdamd_model_destroy", None, _vp)
+_sig("rdamd_model_initialize_partitions", C.c_int, _vp, C.c_int)
+_sig("rdamd_model_set_subst_rates", C.c_int, _vp, _pd)
+_sig("rdamd_model_set_subst_rates_uniform", C.c_int, _vp)
+_sig("rdamd_model_set_freqs", C.c_int, _vp, _pd)
+_sig("rdamd_model_set_empirical_freqs", C.c_int, _vp)
+_sig("rdamd_model_set_gamma_alpha", C.c_int, _vp, C.c_double)
+_sig("rdamd_model_compute_lh", C.c_double, _vp, _prl)
+_sig("rdamd_model_compute_lh_root", C.c_double, _vp, _prl)
+_sig("rdamd_model_compute_dlh", C.c_int, _vp, _prl, _pd)
+_sig("rdamd_model_move_root", C.c_int, _vp, _prl)
+_sig("rdamd_model_compute_all_root_lh", C.c_int, _vp, _pd)
+_sig("rdamd_model_optimize_alpha", C.c_int, _vp, _prl, C.c_double, _prl)
+_sig("rdamd_model_compute_lh_batch", C.c_int, _vp, _u, _prl, _pd, _pd, _pd, _pd)
+_sig("rdamd_model_assign_by_rank", C.c_int, _vp, _u, _u)
+_sig("rdamd_model_exhaustive_search", C.c_int, _vp, C.c_double, C.c_double, C.c_double,
+     C.c_double, C.POINTER(C.c_uint64), _pd, _pd, _pu, _prl, _pd)
+
 _libc = C.CDLL(None)
 _libc.free.argtypes = [_vp]
 _libc.free.restype = None
@@ -503,3 +523,122 @@ class Partition:
                                            _dptr(rw) if rw is not None else None,
                                            C.c_void_p(device_ptr)) != 1:
             _fail("evaluate_batch_device")
+
+
+class Model:
+    """model_t (src/model.hpp:47) through the C ABI, one partition."""
+
+    def __init__(self, tree, seqs, states=4, cmap=None, rate_cats=1, weights=None, seed=1,
+                 early_stop=False):
+        labels = list(seqs)
+        n = len(labels)
+        lab = (C.c_char_p * n)(*[l.encode() for l in labels])
+        sq = (C.c_char_p * n)(*[seqs[l].encode() for l in labels])
+        w = None
+        if weights is not None:
+            w = np.ascontiguousarray(weights, dtype=np.uint32)
+        self._tree = tree
+        self.states = states
+        self._h = lib.rdamd_model_create(tree._h, n, lab, sq, _uptr(w) if w is not None else None,
+                                         states, cmap if cmap is not None else MAP_NT, rate_cats,
+                                         seed, 1 if early_stop else 0)
+        if not self._h:
+            _fail("model_create")
+
+    def destroy(self):
+        if getattr(self, "_h", None):
+            lib.rdamd_model_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.destroy()
+
+    def _ok(self, rc, what):
+        if rc != 1:
+            _fail(what)
+
+    def initialize_partitions(self):
+        self._ok(lib.rdamd_model_initialize_partitions(self._h, 0), "initialize_partitions")
+
+    def initialize_partitions_uniform_freqs(self):
+        self._ok(lib.rdamd_model_initialize_partitions(self._h, 1), "initialize_partitions")
+
+    def set_subst_rates(self, rates):
+        a = np.ascontiguousarray(rates, dtype=np.float64)
+        self._ok(lib.rdamd_model_set_subst_rates(self._h, _dptr(a)), "set_subst_rates")
+
+    def set_subst_rates_uniform(self):
+        self._ok(lib.rdamd_model_set_subst_rates_uniform(self._h), "set_subst_rates_uniform")
+
+    def set_freqs(self, freqs):
+        a = np.ascontiguousarray(freqs, dtype=np.float64)
+        self._ok(lib.rdamd_model_set_freqs(self._h, _dptr(a)), "set_freqs")
+
+    def set_empirical_freqs(self):
+        self._ok(lib.rdamd_model_set_empirical_freqs(self._h), "set_empirical_freqs")
+
+    def set_gamma_alpha(self, alpha):
+        self._ok(lib.rdamd_model_set_gamma_alpha(self._h, alpha), "set_gamma_alpha")
+
+    def compute_lh(self, rl):
+        v = lib.rdamd_model_compute_lh(self._h, C.byref(rl))
+        if _errno():
+            _fail("compute_lh")
+        return v
+
+    def compute_lh_root(self, rl):
+        v = lib.rdamd_model_compute_lh_root(self._h, C.byref(rl))
+        if _errno():
+            _fail("compute_lh_root")
+        return v
+
+    def compute_dlh(self, rl):
+        out = (C.c_double * 2)()
+        self._ok(lib.rdamd_model_compute_dlh(self._h, C.byref(rl), out), "compute_dlh")
+        return out[0], out[1]
+
+    def move_root(self, rl):
+        self._ok(lib.rdamd_model_move_root(self._h, C.byref(rl)), "move_root")
+
+    def compute_all_root_lh(self):
+        out = np.zeros(self._tree.root_count(), dtype=np.float64)
+        self._ok(lib.rdamd_model_compute_all_root_lh(self._h, _dptr(out)), "compute_all_root_lh")
+        return out
+
+    def optimize_alpha(self, rl, atol):
+        out = RootLocation()
+        self._ok(lib.rdamd_model_optimize_alpha(self._h, C.byref(rl), atol, C.byref(out)),
+                 "optimize_alpha")
+        return out
+
+    def compute_lh_batch(self, rls, subst, freqs, gamma_alpha=None):
+        n = len(rls)
+        arr = (RootLocation * n)(*rls)
+        k = self.states
+        subst = np.ascontiguousarray(subst, dtype=np.float64).reshape(n, k * k - k)
+        freqs = np.ascontiguousarray(freqs, dtype=np.float64).reshape(n, k)
+        ga = None if gamma_alpha is None else np.ascontiguousarray(gamma_alpha, dtype=np.float64)
+        out = np.zeros(n, dtype=np.float64)
+        self._ok(lib.rdamd_model_compute_lh_batch(self._h, n, arr, _dptr(subst), _dptr(freqs),
+                                                  _dptr(ga) if ga is not None else None,
+                                                  _dptr(out)), "compute_lh_batch")
+        return out
+
+    def assign_by_rank(self, rank, num_tasks):
+        self._ok(lib.rdamd_model_assign_by_rank(self._h, rank, num_tasks), "assign_by_rank")
+
+    def exhaustive_search(self, atol, pgtol, brtol, factor):
+        n = self._tree.root_count()
+        ids = (C.c_uint64 * n)()
+        llh = np.zeros(n, dtype=np.float64)
+        alpha = np.zeros(n, dtype=np.float64)
+        cnt = C.c_uint(0)
+        best = RootLocation()
+        best_llh = C.c_double(0.0)
+        self._ok(lib.rdamd_model_exhaustive_search(self._h, atol, pgtol, brtol, factor, ids,
+                                                   _dptr(llh), _dptr(alpha), C.byref(cnt),
+                                                   C.byref(best), C.byref(best_llh)),
+                 "exhaustive_search")
+        k = cnt.value
+        return {"root_id": [int(ids[i]) for i in range(k)], "llh": llh[:k].copy(),
+                "alpha": alpha[:k].copy(), "best": best, "best_llh": best_llh.value}

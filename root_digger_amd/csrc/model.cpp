@@ -1,0 +1,576 @@
+// model_t on the rdamd C ABI; behaviour follows /root/reference/src/model.cpp
+// (cited per function).
+#include "model.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <limits>
+#include <numeric>
+#include <unordered_map>
+
+namespace rdamd {
+
+namespace {
+[[noreturn]] void fail(const std::string &what) {
+  std::string m = what;
+  const char *e = rdamd_errmsg();
+  if (e && *e) m += std::string(": ") + e;
+  throw std::runtime_error(m);
+}
+}  // namespace
+
+unsigned int msa_t::total_weight() const {
+  if (weights.empty()) return (unsigned int)length();
+  unsigned int t = 0;
+  for (auto w : weights) t += w;
+  return t;
+}
+
+model_params_t random_params(size_t size, uint64_t seed) {
+  model_params_t mp(size);
+  std::minstd_rand engine((std::minstd_rand::result_type)seed);
+  std::uniform_real_distribution<> dist(1e-4, 1.0);
+  for (auto &f : mp) f = dist(engine);
+  return mp;
+}
+
+// src/model.cpp:99-176
+model_t::model_t(rooted_tree_t tree, const std::vector<msa_t> &msas,
+                 const std::vector<ratehet_opts_t> &rate_cats, bool invariant_sites,
+                 uint64_t seed, bool early_stop)
+    : _invariant_sites(invariant_sites), _early_stop(early_stop), _seed(seed) {
+  _random_engine = std::minstd_rand((std::minstd_rand::result_type)_seed);
+  _tree = std::move(tree);
+  if (rate_cats.size() != msas.size())
+    throw std::invalid_argument("one rate-heterogeneity option per partition is required");
+  for (const auto &rc : rate_cats) {
+    _rate_rates.emplace_back(rc.rate_cats, rc.alpha);
+    _rate_weights.emplace_back(rc.rate_cats, 1.0 / rc.rate_cats);
+    _rate_category_types.push_back(rc.rate_category_type);
+    _rate_user_init.push_back(rc.alpha_init);
+    _param_indicies.emplace_back(rc.rate_cats, 0u);
+  }
+  auto labels = _tree.label_set();
+  for (const auto &msa : msas) {
+    if ((size_t)msa.count() != labels.size())
+      throw std::invalid_argument("Taxa on the tree and in the MSA are inconsistient");
+    for (const auto &l : msa.labels)
+      if (!labels.count(l))
+        throw std::invalid_argument("Taxa on the tree and in the MSA are inconsistient");
+  }
+  for (size_t p = 0; p < msas.size(); ++p) {
+    const auto &msa = msas[p];
+    unsigned int attributes = RDAMD_ATTRIB_NONREV;
+    if (msa.states == 4) attributes |= RDAMD_ATTRIB_SITE_REPEATS;
+    rdamd_partition_t *part = rdamd_partition_create(
+        _tree.tip_count(), _tree.branch_count(), msa.states, (unsigned)msa.length(), 1,
+        _tree.branch_count(), (unsigned)_rate_rates[p].size(), _tree.branch_count(), attributes);
+    if (!part) fail("partition_create");
+    _partitions.push_back(part);
+    set_gamma_rates(p);
+  }
+  assign_indicies();
+}
+
+model_t::~model_t() {
+  for (auto p : _partitions)
+    if (p) rdamd_partition_destroy(p);
+}
+
+// ---- setters ----------------------------------------------------------------
+void model_t::set_subst_rates(size_t p, const model_params_t &mp) {
+  rdamd_set_subst_params(_partitions[p], 0, mp.data());
+}
+
+void model_t::set_subst_rates_uniform() {
+  for (size_t i = 0; i < _partitions.size(); ++i) {
+    unsigned states = rdamd_partition_states(_partitions[i]);
+    unsigned params = states * states - states;
+    set_subst_rates(i, model_params_t(params, 1.0 / params));
+  }
+}
+
+void model_t::set_gamma_weights(size_t p, model_params_t w) {
+  double sum = 0.0;
+  for (auto f : w) sum += f;
+  for (auto &f : w) f /= sum;
+  rdamd_set_category_weights(_partitions[p], w.data());
+}
+
+// src/model.cpp:208-290.  The reference's mean/median setters swap the two
+// enum values: the initial call uses MEAN at alpha = 1,
+// every later call uses MEDIAN at the given alpha, for both declared types.
+// That observable behaviour is kept.
+void model_t::set_gamma_rates(size_t p) {
+  rdamd_set_category_weights(_partitions[p], _rate_weights[p].data());
+  if (_rate_category_types[p] == rate_category::FREE) {
+    for (auto &r : _rate_rates[p]) r = 1.0;
+  } else {
+    rdamd_compute_gamma_cats(1.0, (unsigned)_rate_rates[p].size(), _rate_rates[p].data(),
+                             RDAMD_GAMMA_RATES_MEAN);
+  }
+  rdamd_set_category_rates(_partitions[p], _rate_rates[p].data());
+}
+
+void model_t::set_gamma_rates(size_t p, const model_params_t &alpha) {
+  if (_rate_category_types[p] != rate_category::FREE)
+    rdamd_compute_gamma_cats(alpha[0], (unsigned)_rate_rates[p].size(), _rate_rates[p].data(),
+                             RDAMD_GAMMA_RATES_MEDIAN);
+  // FREE: the reference normalises a local copy and uploads the unchanged
+  // member (all ones), src/model.cpp:279-290 -- free rates never take effect
+  rdamd_set_category_rates(_partitions[p], _rate_rates[p].data());
+}
+
+void model_t::update_invariant_sites(size_t p) {
+  // src/model.cpp:292-300: the proportion is only ever 0.0 (+I is inert)
+  if (rdamd_update_invariant_sites_proportion(_partitions[p], 0, 0.0) != RDAMD_SUCCESS)
+    fail("update_invariant_sites");
+}
+
+void model_t::set_tip_states(size_t p, const msa_t &msa) {
+  auto label_map = _tree.label_map();
+  for (int i = 0; i < msa.count(); ++i) {
+    auto it = label_map.find(msa.labels[i]);
+    if (it == label_map.end())
+      throw std::runtime_error("Could not find taxa " + msa.labels[i] + " in tree");
+    if (rdamd_set_tip_states(_partitions[p], it->second, msa.map, msa.sequences[i].c_str()) !=
+        RDAMD_SUCCESS)
+      fail("failed to set tip " + std::to_string(i));
+  }
+  if (!msa.weights.empty()) rdamd_set_pattern_weights(_partitions[p], msa.weights.data());
+}
+
+void model_t::set_empirical_freqs(size_t p) {
+  double *f = rdamd_msa_empirical_frequencies(_partitions[p]);
+  unsigned states = rdamd_partition_states(_partitions[p]);
+  for (unsigned i = 0; i < states; ++i)
+    if (f[i] <= 0) {
+      free(f);
+      throw std::runtime_error("One of the state frequenices is zero while using emperical "
+                               "frequencies");
+    }
+  rdamd_set_frequencies(_partitions[p], 0, f);
+  free(f);
+}
+
+void model_t::set_empirical_freqs() {
+  for (size_t i = 0; i < _partitions.size(); ++i) set_empirical_freqs(i);
+}
+
+void model_t::set_freqs(size_t p, const model_params_t &freqs) {
+  for (auto f : freqs)
+    if (f <= 0.0) throw std::runtime_error("Frequencies with 0 entries are not allowed");
+  rdamd_set_frequencies(_partitions[p], 0, freqs.data());
+}
+
+void model_t::set_freqs_all_free(size_t p, model_params_t freqs) {
+  double sum = 0.0;
+  for (auto f : freqs) sum += f;
+  for (auto &f : freqs) f /= sum;
+  set_freqs(p, freqs);
+}
+
+void model_t::set_model_params(const std::vector<partition_parameters_t> &params) {
+  for (size_t i = 0; i < params.size(); ++i) {
+    set_subst_rates(i, params[i].subst_rates);
+    set_freqs(i, params[i].freqs);
+    set_gamma_rates(i, params[i].gamma_alpha);
+    if (_rate_category_types[i] == rate_category::FREE) set_gamma_weights(i, params[i].gamma_weights);
+  }
+}
+
+partition_parameters_t model_t::make_partition_parameters(size_t states, rate_category rc,
+                                                          size_t cats) {
+  // src/model.cpp:979-1005: uniform rates, uniform freqs, alpha 1; FREE draws
+  // its category weights from the model's engine
+  partition_parameters_t pp;
+  pp.subst_rates.assign(states * states - states, 1.0 / (states * states - states));
+  pp.freqs.assign(states, 1.0 / states);
+  if (rc == rate_category::FREE) {
+    pp.gamma_alpha.assign(cats, 1.0);
+    std::uniform_real_distribution<> dis(0.0, 1.0);
+    pp.gamma_weights.resize(cats);
+    for (auto &v : pp.gamma_weights) v = dis(_random_engine);
+  } else {
+    pp.gamma_alpha.assign(1, 1.0);
+  }
+  return pp;
+}
+
+void model_t::initialize_partitions(const std::vector<msa_t> &msa) {
+  for (size_t p = 0; p < _partitions.size(); ++p) {
+    set_tip_states(p, msa[p]);
+    update_invariant_sites(p);
+    set_empirical_freqs(p);
+    set_subst_rates(p, random_params(msa[p].states * msa[p].states - msa[p].states,
+                                     _random_engine()));
+  }
+}
+
+void model_t::initialize_partitions_uniform_freqs(const std::vector<msa_t> &msa) {
+  for (size_t p = 0; p < _partitions.size(); ++p) {
+    set_tip_states(p, msa[p]);
+    update_invariant_sites(p);
+    unsigned states = rdamd_partition_states(_partitions[p]);
+    set_freqs(p, model_params_t(states, 1.0 / states));
+    set_subst_rates(p, random_params(states * states - states, _random_engine()));
+    set_gamma_rates(p);
+  }
+}
+
+// ---- likelihood facade ----------------------------------------------------------
+void model_t::update_pmatrices(const std::vector<unsigned int> &pmi,
+                               const std::vector<double> &brl) {
+  // the reference loops branch by branch under OpenMP (src/model.cpp:362-369);
+  // here the whole list is one device launch per partition
+  for (size_t i = 0; i < _partitions.size(); ++i)
+    if (rdamd_update_prob_matrices(_partitions[i], _param_indicies[i].data(), pmi.data(),
+                                   brl.data(), (unsigned)pmi.size()) != RDAMD_SUCCESS)
+      fail("update_prob_matrices");
+}
+
+double model_t::compute_lh(const root_location_t &root_location) {
+  auto sched = _tree.generate_operations(root_location);
+  const auto &ops = std::get<0>(sched);
+  update_pmatrices(std::get<1>(sched), std::get<2>(sched));
+  double lh = 0.0;
+  for (size_t i = 0; i < _partitions.size(); ++i) {
+    rdamd_update_clvs(_partitions[i], ops.data(), (unsigned)ops.size());
+    if (rdamd_errno()) fail("update_clvs");
+    lh += rdamd_compute_root_loglikelihood(_partitions[i], _tree.root_clv_index(),
+                                           _tree.root_scaler_index(),
+                                           _param_indicies[i].data(), nullptr);
+  }
+  return lh;
+}
+
+double model_t::compute_lh_root(const root_location_t &root) {
+  auto res = _tree.generate_derivative_operations(root);
+  const rdamd_operation_t &op = std::get<0>(res);
+  const auto &brl = std::get<2>(res);
+  double lh = 0.0;
+  for (size_t i = 0; i < _partitions.size(); ++i) {
+    double v = 0.0;
+    if (rdamd_root_loglikelihood_fused(_partitions[i], &op, _param_indicies[i].data(), &brl[0],
+                                       &brl[1], 1, &v) != RDAMD_SUCCESS)
+      fail("compute_lh_root");
+    lh += v;
+  }
+  if (std::isnan(lh)) throw std::runtime_error("lh at root is not a number: " + std::to_string(lh));
+  return lh;
+}
+
+// src/model.cpp:481-519: one-sided difference with EPSILON = 1e-8 (backward
+// when alpha + eps would reach 1); both positions go to the device in one call.
+dlh_t model_t::compute_dlh(const root_location_t &root) {
+  constexpr double EPSILON = 1e-8;
+  root_location_t root_prime{root};
+  root_prime.brlen_ratio += EPSILON;
+  double sign = 1.0;
+  if (root_prime.brlen_ratio >= 1.0) {
+    root_prime.brlen_ratio = root.brlen_ratio - EPSILON;
+    sign = -1.0;
+  }
+  auto res = _tree.generate_derivative_operations(root);
+  const rdamd_operation_t &op = std::get<0>(res);
+  // evaluate alpha' first and alpha last: the partition is left at `root`,
+  // where generate_derivative_operations put the tree
+  const double l1[2] = {root_prime.brlen(), root.brlen()};
+  const double l2[2] = {root_prime.brlen_compliment(), root.brlen_compliment()};
+  double fx = 0.0, fxh = 0.0;
+  for (size_t i = 0; i < _partitions.size(); ++i) {
+    double v[2];
+    if (rdamd_root_loglikelihood_fused(_partitions[i], &op, _param_indicies[i].data(), l1, l2, 2,
+                                       v) != RDAMD_SUCCESS)
+      fail("compute_dlh");
+    fxh += v[0];
+    fx += v[1];
+  }
+  if (std::isnan(fx))
+    throw std::runtime_error("fx is not finite when computing derivative: " +
+                             std::to_string(root.saved_brlen));
+  if (std::isnan(fxh))
+    throw std::runtime_error("fxh is not finite when computing derivative: " +
+                             std::to_string(root.saved_brlen));
+  if (std::isinf(fxh) && std::isinf(fx)) return {fx, 0};
+  return {fx, (fxh - fx) / EPSILON * sign};
+}
+
+void model_t::move_root(const root_location_t &new_root) {
+  auto sched = _tree.generate_root_update_operations(new_root);
+  const auto &ops = std::get<0>(sched);
+  if (ops.empty()) return;
+  for (size_t i = 0; i < _partitions.size(); ++i) {
+    if (rdamd_update_prob_matrices(_partitions[i], _param_indicies[i].data(),
+                                   std::get<1>(sched).data(), std::get<2>(sched).data(),
+                                   (unsigned)std::get<1>(sched).size()) != RDAMD_SUCCESS)
+      fail("move_root");
+    rdamd_update_clvs(_partitions[i], ops.data(), (unsigned)ops.size());
+    if (rdamd_errno()) fail("move_root");
+  }
+}
+
+std::vector<double> model_t::compute_all_root_lh() {
+  std::vector<double> out;
+  for (const auto &rl : _tree.roots()) {
+    move_root(rl);
+    out.push_back(compute_lh_root(rl));
+  }
+  return out;
+}
+
+std::vector<double> model_t::compute_lh_batch(
+    const std::vector<root_location_t> &roots,
+    const std::vector<std::vector<partition_parameters_t>> &params) {
+  const size_t n = roots.size();
+  if (params.size() != n) throw std::invalid_argument("one parameter vector per root");
+  std::vector<double> total(n, 0.0);
+  // schedules are per (partition, distinct root): compile once per root
+  for (size_t p = 0; p < _partitions.size(); ++p) {
+    const unsigned R = rdamd_partition_rate_cats(_partitions[p]);
+    std::vector<rdamd_schedule_t *> owned;
+    std::vector<const rdamd_schedule_t *> scheds(n);
+    std::vector<double> subst(n * 12), freqs(n * 4), rates(n * R), weights(n * R), out(n);
+    for (size_t j = 0; j < n; ++j) {
+      auto sc = _tree.generate_operations(roots[j]);
+      rdamd_schedule_t *s = rdamd_schedule_create(
+          _partitions[p], std::get<0>(sc).data(), (unsigned)std::get<0>(sc).size(),
+          std::get<1>(sc).data(), std::get<2>(sc).data(), (unsigned)std::get<1>(sc).size());
+      if (!s) {
+        for (auto o : owned) rdamd_schedule_destroy(o);
+        fail("schedule_create");
+      }
+      owned.push_back(s);
+      scheds[j] = s;
+      const partition_parameters_t &pp = params[j][p];
+      std::copy(pp.subst_rates.begin(), pp.subst_rates.end(), subst.begin() + j * 12);
+      double fs = 0.0;
+      for (auto f : pp.freqs) fs += f;
+      for (size_t k = 0; k < 4; ++k) freqs[j * 4 + k] = pp.freqs[k] / fs;
+      std::vector<double> r(R, 1.0);
+      if (_rate_category_types[p] != rate_category::FREE)
+        rdamd_compute_gamma_cats(pp.gamma_alpha.empty() ? 1.0 : pp.gamma_alpha[0], R, r.data(),
+                                 RDAMD_GAMMA_RATES_MEDIAN);
+      for (unsigned k = 0; k < R; ++k) {
+        rates[j * R + k] = r[k];
+        weights[j * R + k] = _rate_weights[p][k];
+      }
+    }
+    int ok = rdamd_evaluate_batch(_partitions[p], (unsigned)n, scheds.data(), subst.data(),
+                                  freqs.data(), rates.data(), weights.data(), out.data());
+    for (auto o : owned) rdamd_schedule_destroy(o);
+    if (ok != RDAMD_SUCCESS) fail("evaluate_batch");
+    for (size_t j = 0; j < n; ++j) total[j] += out[j];
+  }
+  return total;
+}
+
+// ---- root placement on one branch -------------------------------------------------
+// Brent's method on d lnL / d alpha (src/model.cpp:606-676): bracket [a, b] with b
+// the best iterate and c the previous contrapoint; inverse quadratic / secant step
+// when it stays inside the bracket and shrinks fast enough, bisection otherwise;
+// at most 64 derivative evaluations.
+std::pair<root_location_t, double> model_t::brents(root_location_t beg, dlh_t d_beg,
+                                                   root_location_t end, dlh_t d_end,
+                                                   double atol) {
+  if (!(d_beg.dlh * d_end.dlh < 0))
+    throw std::runtime_error("Brents called with endpoints which don't bracket");
+  struct pt { root_location_t rl; dlh_t f; };
+  pt a{beg, d_beg}, b{end, d_end}, c{end, d_end};
+  double step = b.rl.brlen_ratio - a.rl.brlen_ratio, prev_step = step;
+  for (size_t it = 0; it < 64; ++it) {
+    if (b.f.dlh * c.f.dlh > 0.0) {   // c must sit across the root from b
+      c = a;
+      step = prev_step = b.rl.brlen_ratio - a.rl.brlen_ratio;
+    }
+    if (std::fabs(c.f.dlh) < std::fabs(b.f.dlh)) {   // keep b the better of the two
+      a = b; b = c; c = a;
+    }
+    const double tol = 2.0 * std::fabs(b.rl.brlen_ratio) * std::numeric_limits<double>::epsilon() +
+                       0.5 * atol;
+    const double half = 0.5 * (c.rl.brlen_ratio - b.rl.brlen_ratio);
+    if (std::fabs(half) <= tol || std::fabs(b.f.dlh) <= 1e-12) return {b.rl, b.f.lh};
+    if (std::fabs(prev_step) >= tol && std::fabs(a.f.dlh) > std::fabs(b.f.dlh)) {
+      const double s = b.f.dlh / a.f.dlh;
+      double p, q;
+      if (std::fabs(a.rl.brlen_ratio - c.rl.brlen_ratio) < 1e-12) {   // secant
+        p = 2.0 * half * s;
+        q = 1.0 - s;
+      } else {                                                        // inverse quadratic
+        const double qa = a.f.dlh / c.f.dlh, r = b.f.dlh / c.f.dlh;
+        p = s * (2.0 * half * qa * (qa - r) - (b.rl.brlen_ratio - a.rl.brlen_ratio) * (r - 1.0));
+        q = (qa - 1.0) * (r - 1.0) * (s - 1.0);
+      }
+      if (p > 0.0) q = -q;
+      p = std::fabs(p);
+      const double lim1 = 3.0 * half * q - std::fabs(half * q), lim2 = std::fabs(prev_step * q);
+      if (2.0 * p < std::min(lim1, lim2)) {
+        prev_step = step;
+        step = p / q;
+      } else {
+        step = prev_step = half;
+      }
+    } else {
+      step = prev_step = half;
+    }
+    a = b;
+    if (std::fabs(step) > tol) b.rl.brlen_ratio += step;
+    else b.rl.brlen_ratio += half >= 0.0 ? tol : -tol;
+    b.f = compute_dlh(b.rl);
+  }
+  throw std::runtime_error("Brents method failed to converge");
+}
+
+// src/model.cpp:679-794
+root_location_t model_t::optimize_alpha(const root_location_t &root, double atol) {
+  if (std::isnan(compute_lh_root(root)))
+    throw std::runtime_error("initial likelihood calculation is not finite");
+  root_location_t beg{root}, end{root};
+  beg.brlen_ratio = 0.0;
+  end.brlen_ratio = 1.0;
+  const dlh_t d_beg = compute_dlh(beg), d_end = compute_dlh(end);
+  if (std::isnan(d_beg.dlh) || std::isnan(d_end.dlh))
+    throw std::runtime_error("Initial derivatives failed when optimizing alpha: " +
+                             std::to_string(root.saved_brlen));
+  root_location_t best_endpoint = d_beg.lh >= d_end.lh ? beg : end;
+  dlh_t lh_best_endpoint = d_beg.lh >= d_end.lh ? d_beg : d_end;
+  if (std::fabs(d_beg.dlh) < atol || std::fabs(d_end.dlh) < atol) return best_endpoint;
+  if (d_beg.dlh * d_end.dlh < 0.0) {
+    auto mid = brents(beg, d_beg, end, d_end, atol);
+    return lh_best_endpoint.lh > mid.second ? best_endpoint : mid.first;
+  }
+  // same sign at both ends: scan alpha = k/2, k/4, ... k/32 (odd k) for a sign
+  // change and solve on both sides of it
+  const bool both_pos = d_beg.dlh > 0.0 && d_end.dlh > 0.0;
+  dlh_t best_mid_lh{-std::numeric_limits<double>::infinity(), 0};
+  root_location_t best_mid;
+  bool found_mid = false;
+  for (size_t parts = 2; parts <= 32; parts *= 2) {
+    for (size_t k = 1; k <= parts; k += 2) {
+      root_location_t mid{beg};
+      mid.brlen_ratio = 1.0 / (double)parts * k;
+      const dlh_t d_mid = compute_dlh(mid);
+      if (std::fabs(d_mid.dlh) < atol && best_mid_lh.lh < d_mid.lh) {
+        best_mid_lh = d_mid;
+        best_mid = mid;
+        found_mid = true;
+      }
+      if ((both_pos && d_mid.dlh < 0.0) || (!both_pos && d_mid.dlh > 0.0)) {
+        auto r1 = brents(beg, d_beg, mid, d_mid, atol);
+        auto r2 = brents(mid, d_mid, end, d_end, atol);
+        if (lh_best_endpoint.lh < best_mid_lh.lh) {
+          lh_best_endpoint = best_mid_lh;
+          best_endpoint = best_mid;
+        }
+        if (r1.second < r2.second) return lh_best_endpoint.lh >= r2.second ? best_endpoint : r2.first;
+        return lh_best_endpoint.lh >= r1.second ? best_endpoint : r1.first;
+      }
+    }
+  }
+  if (found_mid) return best_mid;
+  return both_pos ? end : beg;
+}
+
+std::vector<root_location_t> model_t::suggest_roots_lh(size_t min, double ratio) {
+  std::vector<std::pair<root_location_t, double>> v;
+  for (auto rl : _tree.roots()) {
+    move_root(rl);
+    v.emplace_back(rl, compute_lh_root(rl));
+  }
+  size_t keep = std::max((size_t)(v.size() * ratio), min);
+  keep = std::min(keep, v.size());
+  std::partial_sort(v.begin(), v.begin() + (std::ptrdiff_t)keep, v.end(),
+                    [](const auto &a, const auto &b) { return a.second > b.second; });
+  std::vector<root_location_t> out;
+  for (size_t i = 0; i < keep; ++i) out.push_back(v[i].first);
+  return out;
+}
+
+std::pair<root_location_t, double> model_t::optimize_root_location(size_t min_roots,
+                                                                   double root_ratio) {
+  std::pair<root_location_t, double> best;
+  best.second = -std::numeric_limits<double>::infinity();
+  for (auto &rl : suggest_roots_lh(min_roots, root_ratio)) {
+    move_root(rl);
+    rl = optimize_alpha(rl, 1e-14);
+    double lh = compute_lh_root(rl);
+    if (lh > best.second) best = {rl, lh};
+  }
+  return best;
+}
+
+// ---- work assignment -------------------------------------------------------------
+void model_t::assign_indicies() {
+  _assigned_idx.resize(_tree.root_count());
+  std::iota(_assigned_idx.begin(), _assigned_idx.end(), 0);
+}
+
+void model_t::assign_indicies_by_rank_exhaustive(size_t rank, size_t num_tasks,
+                                                 const std::vector<size_t> &completed) {
+  if (_tree.root_count() < completed.size())
+    throw std::runtime_error("There are too many results in the checkpoint for this tree, are "
+                             "you sure the checkpoint matches?");
+  std::vector<size_t> done(completed);
+  std::sort(done.begin(), done.end());
+  std::vector<size_t> left;
+  for (size_t i = 0; i < _tree.root_count(); ++i)
+    if (!std::binary_search(done.begin(), done.end(), i)) left.push_back(i);
+  const size_t chunk = left.size() / num_tasks, mod = left.size() % num_tasks;
+  const size_t beg = chunk * rank + std::min(mod, rank);
+  const size_t end = chunk * (rank + 1) + std::min(mod, rank + 1);
+  _assigned_idx.assign(left.begin() + (std::ptrdiff_t)beg, left.begin() + (std::ptrdiff_t)end);
+}
+
+// ---- exhaustive outer loop (src/model.cpp:1139-1272) ----------------------------------
+std::pair<root_location_t, double> model_t::exhaustive_search(double atol, double pgtol,
+                                                              double brtol, double factor,
+                                                              std::vector<rd_result_t> *results) {
+  root_location_t best_rl;
+  double best_llh = -std::numeric_limits<double>::infinity();
+  for (auto rl_index : _assigned_idx) {
+    root_location_t rl = _tree.root_location(rl_index);
+    set_subst_rates_uniform();
+    set_empirical_freqs();
+    _tree.root_by(rl);
+    compute_lh(rl);
+    std::vector<partition_parameters_t> params;
+    for (size_t p = 0; p < _partitions.size(); ++p)
+      params.push_back(make_partition_parameters(rdamd_partition_states(_partitions[p]),
+                                                 _rate_category_types[p],
+                                                 rdamd_partition_rate_cats(_partitions[p])));
+    root_location_t cur_best_rl = rl;
+    double cur_best_llh = -std::numeric_limits<double>::infinity();
+    for (size_t iter = 0; iter < 1000; ++iter) {
+      if (_optimizer) _optimizer(*this, params, rl, pgtol, factor, iter % 10 == 0);
+      if (std::fabs(compute_lh(rl) - cur_best_llh) < atol) break;
+      root_location_t cur_rl = optimize_alpha(rl, brtol);
+      double cur_llh = compute_lh_root(cur_rl);
+      if (_early_stop && std::fabs(rl.brlen_ratio - cur_rl.brlen_ratio) < brtol) {
+        cur_best_rl = cur_rl;
+        cur_best_llh = cur_llh;
+        break;
+      }
+      if ((cur_llh - cur_best_llh) < atol) {
+        if (cur_llh > cur_best_llh) { cur_best_rl = cur_rl; cur_best_llh = cur_llh; }
+        break;
+      }
+      if (cur_llh > cur_best_llh) { cur_best_rl = cur_rl; cur_best_llh = cur_llh; }
+      rl = cur_rl;
+    }
+    if (results) results->push_back({cur_best_rl.id, cur_best_llh, cur_best_rl.brlen_ratio});
+    if (cur_best_llh > best_llh) { best_rl = cur_best_rl; best_llh = cur_best_llh; }
+  }
+  return {best_rl, best_llh};
+}
+
+std::vector<double> model_t::likelihood_weight_ratios(const std::vector<rd_result_t> &results) {
+  double max_llh = -std::numeric_limits<double>::infinity();
+  for (const auto &r : results) max_llh = std::max(max_llh, r.llh);
+  double total = 0.0;
+  for (const auto &r : results) total += std::exp(r.llh - max_llh);
+  std::vector<double> out;
+  for (const auto &r : results) out.push_back(std::exp(r.llh - max_llh) / total);
+  return out;
+}
+
+}  // namespace rdamd

@@ -1,0 +1,162 @@
+// Host-side likelihood facade: mirrors model_t of the reference
+// (/root/reference/src/model.hpp:47-277) for the rows of SURVEY.md section 8a
+// that sit above the three library calls -- compute_lh (a4), the per-partition
+// objective (a5), compute_lh_root (a6), compute_dlh (a7), move_root (a8),
+// update_pmatrices (a9), the parameter setters (a16), optimize_alpha / Brent
+// and the exhaustive outer loop (a17) -- on top of the C ABI of this library.
+//
+// The L-BFGS-B parameter optimiser of the reference (lib/lbfgsb, out of scope:
+// SURVEY 2.1) is reached through a callback so the caller keeps its own;
+// its objective is served in batches by compute_lh_batch().
+#pragma once
+
+#include <cstdint>
+#include <functional>
+#include <random>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/root_digger_amd.h"
+#include "tree.hpp"
+
+namespace rdamd {
+
+typedef std::vector<double> model_params_t;
+
+struct dlh_t {   // src/model.hpp:21-24
+  double lh;
+  double dlh;
+};
+
+enum class rate_category { MEAN, MEDIAN, FREE };   // src/util.hpp
+
+struct ratehet_opts_t {   // src/util.hpp (rate heterogeneity part)
+  rate_category rate_category_type = rate_category::MEAN;
+  size_t        rate_cats = 1;
+  bool          alpha_init = false;
+  double        alpha = 1.0;
+  ratehet_opts_t() = default;
+  ratehet_opts_t(size_t cats) : rate_cats(cats) {}
+};
+
+struct partition_parameters_t {   // src/util.hpp:119-124
+  model_params_t subst_rates, freqs, gamma_alpha, gamma_weights;
+};
+
+struct rd_result_t {   // src/util.hpp:126-130
+  size_t root_id;
+  double llh;
+  double alpha;
+};
+
+// In-memory alignment (one partition).  File parsing and pattern compression
+// (src/msa.cpp) are a later row of SURVEY 8f; callers hand over sequences.
+struct msa_t {
+  std::vector<std::string>  labels, sequences;
+  std::vector<unsigned int> weights;        // pattern weights; empty = all 1
+  unsigned int              states = 4;
+  const uint64_t           *map = rdamd_map_nt;
+  size_t length() const { return sequences.empty() ? 0 : sequences[0].size(); }
+  int    count() const { return (int)sequences.size(); }
+  unsigned int total_weight() const;
+};
+
+model_params_t random_params(size_t size, uint64_t seed);   // src/model.cpp:87-93
+
+class model_t {
+public:
+  model_t(rooted_tree_t t, const std::vector<msa_t> &msa,
+          const std::vector<ratehet_opts_t> &rate_cats, bool invariant_sites,
+          uint64_t seed, bool early_stop);
+  ~model_t();
+  model_t(const model_t &) = delete;
+  model_t &operator=(const model_t &) = delete;
+
+  // ---- likelihood facade (hot-path callers) -------------------------------
+  double compute_lh(const root_location_t &root_location);      // src/model.cpp:384-413
+  double compute_lh_root(const root_location_t &root);          // :415-452
+  dlh_t  compute_dlh(const root_location_t &root_location);     // :481-519
+  void   move_root(const root_location_t &new_root);            // :823-854
+  std::vector<double> compute_all_root_lh();                    // :1737-1746
+
+  // batched objective: lnL of (root, parameter set) pairs, all partitions,
+  // through rdamd_evaluate_batch (one fused launch per partition)
+  std::vector<double> compute_lh_batch(const std::vector<root_location_t> &roots,
+                                       const std::vector<std::vector<partition_parameters_t>> &params);
+
+  // ---- root placement ------------------------------------------------------
+  root_location_t optimize_alpha(const root_location_t &root, double atol);   // :679-794
+  std::pair<root_location_t, double> optimize_root_location(size_t min_roots,
+                                                            double root_ratio);  // :796-821
+  std::vector<root_location_t> suggest_roots_lh(size_t min, double ratio);   // :865-889
+
+  // parameter optimiser hook: called where the reference calls optimize_params
+  // (src/model.cpp:1174); receives the current parameters and root and returns
+  // improved ones.  Default: none (parameters stay as initialised).
+  using param_optimizer_t = std::function<void(model_t &, std::vector<partition_parameters_t> &,
+                                               const root_location_t &, double pgtol,
+                                               double factor, bool optimize_gamma)>;
+  void set_param_optimizer(param_optimizer_t f) { _optimizer = std::move(f); }
+
+  // src/model.cpp:1139-1272; results (one per assigned root) are returned
+  // instead of going through the checkpoint file.
+  std::pair<root_location_t, double> exhaustive_search(double atol, double pgtol, double brtol,
+                                                       double factor,
+                                                       std::vector<rd_result_t> *results = nullptr);
+  // LWR = exp(llh - max) / sum, src/model.cpp:1239-1258
+  static std::vector<double> likelihood_weight_ratios(const std::vector<rd_result_t> &results);
+
+  void initialize() { compute_lh(_tree.root_location(0)); }   // :1274
+  void finalize() { _tree.unroot(); }                         // :1276
+
+  // ---- parameters (a16) -----------------------------------------------------
+  void initialize_partitions(const std::vector<msa_t> &);                 // :1297-1306
+  void initialize_partitions_uniform_freqs(const std::vector<msa_t> &);   // :1308-1321
+  void set_subst_rates(size_t p, const model_params_t &);                 // :184
+  void set_subst_rates_uniform();                                         // :1748-1755
+  void set_freqs(size_t p, const model_params_t &);                       // :341
+  void set_freqs_all_free(size_t p, model_params_t);                      // :350
+  void set_empirical_freqs(size_t p);                                     // :327
+  void set_empirical_freqs();
+  void set_gamma_rates(size_t p);                                         // :208
+  void set_gamma_rates(size_t p, const model_params_t &alpha);            // :224
+  void set_gamma_weights(size_t p, model_params_t w);                     // :199
+  void set_model_params(const std::vector<partition_parameters_t> &);     // :1913-1923
+  partition_parameters_t make_partition_parameters(size_t states, rate_category rc,
+                                                   size_t rate_cat_count);   // :979-1005
+
+  // ---- work assignment (src/model.cpp:1761-1911) ------------------------------
+  void assign_indicies();
+  void assign_indicies(const std::vector<size_t> &idx) { _assigned_idx = idx; }
+  void assign_indicies_by_rank_exhaustive(size_t rank, size_t num_tasks,
+                                          const std::vector<size_t> &completed = {});
+  std::vector<size_t> assigned_indicies() const { return _assigned_idx; }
+
+  rooted_tree_t       &tree() { return _tree; }
+  size_t               partition_count() const { return _partitions.size(); }
+  rdamd_partition_t   *partition(size_t i) { return _partitions[i]; }
+
+private:
+  std::pair<root_location_t, double> brents(root_location_t beg, dlh_t d_beg,
+                                            root_location_t end, dlh_t d_end, double atol);
+  void set_tip_states(size_t p, const msa_t &msa);   // :302-325
+  void update_invariant_sites(size_t p);             // :292-300
+  void update_pmatrices(const std::vector<unsigned int> &pmatrix_indices,
+                        const std::vector<double> &branch_lengths);   // :357-382 (one call per partition)
+
+  rooted_tree_t                          _tree;
+  std::vector<rdamd_partition_t *>       _partitions;
+  std::vector<rate_category>             _rate_category_types;
+  std::vector<model_params_t>            _rate_rates, _rate_weights;
+  std::vector<bool>                      _rate_user_init;
+  std::vector<std::vector<unsigned int>> _param_indicies;
+  std::vector<size_t>                    _assigned_idx;
+  std::minstd_rand                       _random_engine;
+  bool                                   _invariant_sites, _early_stop;   // +I is inert (:292-300)
+  uint64_t                               _seed;
+  param_optimizer_t                      _optimizer;
+};
+
+}  // namespace rdamd

@@ -1,0 +1,167 @@
+// C wrappers over model_t (declared in include/root_digger_amd.h).
+#include <cmath>
+#include <cstring>
+
+#include "common.hpp"
+#include "model.hpp"
+#include "tree_c_api.hpp"
+
+struct rdamd_model {
+  rdamd::model_t *model = nullptr;
+  rdamd::msa_t    msa;
+  ~rdamd_model() { delete model; }
+};
+
+using rdamd::root_location_t;
+
+namespace {
+root_location_t to_cpp(const rdamd_root_location_t *rl) {
+  root_location_t r;
+  r.edge = rl->edge; r.id = (size_t)rl->id; r.saved_brlen = rl->saved_brlen;
+  r.brlen_ratio = rl->brlen_ratio;
+  return r;
+}
+void to_c(const root_location_t &r, rdamd_root_location_t *out) {
+  out->edge = r.edge; out->id = r.id; out->saved_brlen = r.saved_brlen;
+  out->brlen_ratio = r.brlen_ratio;
+}
+}  // namespace
+
+#define GUARD(failret, ...)                             \
+  try {                                                 \
+    rdamd::clear_error();                               \
+    __VA_ARGS__                                         \
+  } catch (const std::exception &e) {                   \
+    rdamd::set_error(50, "%s", e.what());               \
+    return failret;                                     \
+  }
+
+extern "C" {
+
+rdamd_model_t *rdamd_model_create(const rdamd_tree_t *tree, unsigned int n_taxa,
+                                  const char *const *labels, const char *const *sequences,
+                                  const unsigned int *weights, unsigned int states,
+                                  const uint64_t *map, unsigned int rate_cats, uint64_t seed,
+                                  int early_stop) {
+  GUARD(nullptr, {
+    auto *m = new rdamd_model();
+    m->msa.states = states;
+    m->msa.map = map ? map : rdamd_map_nt;
+    for (unsigned i = 0; i < n_taxa; ++i) {
+      m->msa.labels.emplace_back(labels[i]);
+      m->msa.sequences.emplace_back(sequences[i]);
+    }
+    if (weights) m->msa.weights.assign(weights, weights + m->msa.length());
+    try {
+      m->model = new rdamd::model_t(rdamd_tree_cpp(tree), {m->msa},
+                                    {rdamd::ratehet_opts_t(rate_cats)}, false, seed,
+                                    early_stop != 0);
+    } catch (...) {
+      delete m;
+      throw;
+    }
+    return m;
+  })
+}
+void rdamd_model_destroy(rdamd_model_t *m) { delete m; }
+
+int rdamd_model_initialize_partitions(rdamd_model_t *m, int uniform_freqs) {
+  GUARD(RDAMD_FAILURE, {
+    if (uniform_freqs) m->model->initialize_partitions_uniform_freqs({m->msa});
+    else m->model->initialize_partitions({m->msa});
+    return RDAMD_SUCCESS;
+  })
+}
+int rdamd_model_set_subst_rates(rdamd_model_t *m, const double *rates) {
+  GUARD(RDAMD_FAILURE, {
+    unsigned k = m->msa.states;
+    m->model->set_subst_rates(0, rdamd::model_params_t(rates, rates + k * k - k));
+    return RDAMD_SUCCESS;
+  })
+}
+int rdamd_model_set_subst_rates_uniform(rdamd_model_t *m) {
+  GUARD(RDAMD_FAILURE, { m->model->set_subst_rates_uniform(); return RDAMD_SUCCESS; })
+}
+int rdamd_model_set_freqs(rdamd_model_t *m, const double *freqs) {
+  GUARD(RDAMD_FAILURE, {
+    m->model->set_freqs(0, rdamd::model_params_t(freqs, freqs + m->msa.states));
+    return RDAMD_SUCCESS;
+  })
+}
+int rdamd_model_set_empirical_freqs(rdamd_model_t *m) {
+  GUARD(RDAMD_FAILURE, { m->model->set_empirical_freqs(); return RDAMD_SUCCESS; })
+}
+int rdamd_model_set_gamma_alpha(rdamd_model_t *m, double alpha) {
+  GUARD(RDAMD_FAILURE, { m->model->set_gamma_rates(0, {alpha}); return RDAMD_SUCCESS; })
+}
+double rdamd_model_compute_lh(rdamd_model_t *m, const rdamd_root_location_t *rl) {
+  GUARD(std::nan(""), { return m->model->compute_lh(to_cpp(rl)); })
+}
+double rdamd_model_compute_lh_root(rdamd_model_t *m, const rdamd_root_location_t *rl) {
+  GUARD(std::nan(""), { return m->model->compute_lh_root(to_cpp(rl)); })
+}
+int rdamd_model_compute_dlh(rdamd_model_t *m, const rdamd_root_location_t *rl, double out[2]) {
+  GUARD(RDAMD_FAILURE, {
+    auto d = m->model->compute_dlh(to_cpp(rl));
+    out[0] = d.lh; out[1] = d.dlh;
+    return RDAMD_SUCCESS;
+  })
+}
+int rdamd_model_move_root(rdamd_model_t *m, const rdamd_root_location_t *rl) {
+  GUARD(RDAMD_FAILURE, { m->model->move_root(to_cpp(rl)); return RDAMD_SUCCESS; })
+}
+int rdamd_model_compute_all_root_lh(rdamd_model_t *m, double *out) {
+  GUARD(RDAMD_FAILURE, {
+    auto v = m->model->compute_all_root_lh();
+    for (size_t i = 0; i < v.size(); ++i) out[i] = v[i];
+    return RDAMD_SUCCESS;
+  })
+}
+int rdamd_model_optimize_alpha(rdamd_model_t *m, const rdamd_root_location_t *rl, double atol,
+                               rdamd_root_location_t *out) {
+  GUARD(RDAMD_FAILURE, { to_c(m->model->optimize_alpha(to_cpp(rl), atol), out); return RDAMD_SUCCESS; })
+}
+int rdamd_model_compute_lh_batch(rdamd_model_t *m, unsigned int n,
+                                 const rdamd_root_location_t *rls, const double *subst,
+                                 const double *freqs, const double *gamma_alpha, double *out) {
+  GUARD(RDAMD_FAILURE, {
+    const unsigned k = m->msa.states, np = k * k - k;
+    std::vector<root_location_t> roots;
+    std::vector<std::vector<rdamd::partition_parameters_t>> params(n);
+    for (unsigned j = 0; j < n; ++j) {
+      roots.push_back(to_cpp(&rls[j]));
+      rdamd::partition_parameters_t pp;
+      pp.subst_rates.assign(subst + (size_t)j * np, subst + (size_t)(j + 1) * np);
+      pp.freqs.assign(freqs + (size_t)j * k, freqs + (size_t)(j + 1) * k);
+      pp.gamma_alpha.assign(1, gamma_alpha ? gamma_alpha[j] : 1.0);
+      params[j].push_back(pp);
+    }
+    auto v = m->model->compute_lh_batch(roots, params);
+    for (unsigned j = 0; j < n; ++j) out[j] = v[j];
+    return RDAMD_SUCCESS;
+  })
+}
+int rdamd_model_assign_by_rank(rdamd_model_t *m, unsigned int rank, unsigned int num_tasks) {
+  GUARD(RDAMD_FAILURE, {
+    m->model->assign_indicies_by_rank_exhaustive(rank, num_tasks);
+    return RDAMD_SUCCESS;
+  })
+}
+int rdamd_model_exhaustive_search(rdamd_model_t *m, double atol, double pgtol, double brtol,
+                                  double factor, uint64_t *root_id, double *llh, double *alpha,
+                                  unsigned int *n_results, rdamd_root_location_t *best_rl,
+                                  double *best_llh) {
+  GUARD(RDAMD_FAILURE, {
+    std::vector<rdamd::rd_result_t> res;
+    auto best = m->model->exhaustive_search(atol, pgtol, brtol, factor, &res);
+    for (size_t i = 0; i < res.size(); ++i) {
+      root_id[i] = res[i].root_id; llh[i] = res[i].llh; alpha[i] = res[i].alpha;
+    }
+    *n_results = (unsigned)res.size();
+    if (best_rl) to_c(best.first, best_rl);
+    if (best_llh) *best_llh = best.second;
+    return RDAMD_SUCCESS;
+  })
+}
+
+}  // extern "C"

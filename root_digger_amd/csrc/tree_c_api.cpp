@@ -4,6 +4,7 @@
 
 #include "common.hpp"
 #include "tree.hpp"
+#include "tree_c_api.hpp"
 
 struct rdamd_tree {
   rdamd::rooted_tree_t tree;
@@ -11,6 +12,8 @@ struct rdamd_tree {
 };
 
 using rdamd::root_location_t;
+
+const rdamd::rooted_tree_t &rdamd_tree_cpp(const rdamd_tree_t *t) { return t->tree; }
 
 namespace {
 root_location_t to_cpp(const rdamd_root_location_t *rl) {

@@ -1,0 +1,145 @@
+"""model_t surface (rows a4-a9, a16, a17 of SURVEY 8a) on the GPU: the
+reference's own model tests (test/src/model.cpp) restated, plus parity of the
+facade against the oracle-driven call sequences."""
+import math
+import os
+
+import numpy as np
+import pytest
+
+import root_digger_amd as rd
+from oracle_lib import OraclePartition, ORC_MAP_NT
+import util
+
+pytestmark = pytest.mark.gpu
+
+PARAMS3 = [.34, .42, .24, .74, .16, .88, .75, .54, .20, .06, .08, .41]
+
+
+def ten():
+    tree = rd.Tree.from_file(os.path.join(util.DATA, "10.tree"))
+    seqs = util.read_fasta(os.path.join(util.DATA, "10.fasta"))
+    return tree, seqs
+
+
+def test_compute_lh_finite_negative_repeatable():      # test/src/model.cpp:59-75
+    tree, seqs = ten()
+    m = rd.Model(tree, seqs, rate_cats=1, seed=7)
+    m.initialize_partitions_uniform_freqs()
+    for rl in tree.roots():
+        lh = m.compute_lh(rl)
+        assert math.isfinite(lh) and lh < 0.0
+        assert lh == m.compute_lh(rl)
+
+
+def test_compute_dlh_finite():                          # test/src/model.cpp:95-110
+    tree, seqs = ten()
+    m = rd.Model(tree, seqs, rate_cats=1, seed=7)
+    m.initialize_partitions_uniform_freqs()
+    for rl in tree.roots():
+        m.compute_lh(rl)
+        lh, dlh = m.compute_dlh(rl)
+        assert math.isfinite(lh) and math.isfinite(dlh)
+
+
+@pytest.mark.parametrize("start", [0.5, 0.0, 1.0])      # test/src/model.cpp:132-218
+def test_optimize_alpha(start):
+    tree, seqs = ten()
+    m = rd.Model(tree, seqs, rate_cats=1, seed=7)
+    m.initialize_partitions_uniform_freqs()
+    for rl in tree.roots():
+        rl = rl.with_ratio(start)
+        m.compute_lh(rl)
+        got = m.optimize_alpha(rl, 1e-7)
+        assert 0.0 <= got.brlen_ratio <= 1.0
+        assert got.edge == rl.edge
+        # the optimum is at least as good as the start and as both ends
+        best = m.compute_lh_root(got)
+        for a in (start, 0.0, 1.0):
+            assert best >= m.compute_lh_root(rl.with_ratio(a)) - 1e-6
+
+
+def test_full_vs_root_only():                           # test/src/model.cpp:271-288
+    tree, seqs = ten()
+    m = rd.Model(tree, seqs, rate_cats=4, seed=3)
+    m.initialize_partitions_uniform_freqs()
+    for rl in tree.roots():
+        lh1 = m.compute_lh(rl)
+        assert abs(m.compute_lh_root(rl) - lh1) < 1e-9 * abs(lh1)
+
+
+def test_facade_matches_oracle_sequences():
+    tree, seqs = ten()
+    m = rd.Model(tree, seqs, rate_cats=4, seed=3)
+    m.initialize_partitions()
+    m.set_subst_rates(PARAMS3)
+    o = OraclePartition.for_tree(tree, 4, 1000, 4)
+    util.load_tips(o, tree, seqs, ORC_MAP_NT)
+    o.set_subst_params(0, PARAMS3)
+    o.set_frequencies(0, o.empirical_frequencies())
+    o.set_category_rates(rd.compute_gamma_cats(1.0, 4))
+    t2 = rd.Tree.from_file(os.path.join(util.DATA, "10.tree"))
+    for i in (0, 4, 11, 16):
+        rl = tree.root_location(i).with_ratio(0.3)
+        assert util.rel_err(m.compute_lh(rl), util.compute_lh(o, t2, rl)) < 1e-11
+        # derivative: same one-sided difference as the reference (eps = 1e-8)
+        lh, dlh = m.compute_dlh(rl)
+        a = util.compute_lh_root(o, t2, rl)
+        b = util.compute_lh_root(o, t2, rl.with_ratio(0.3 + 1e-8))
+        assert util.rel_err(lh, a) < 1e-11
+        assert abs(dlh - (b - a) / 1e-8) <= 2e-3 * max(1.0, abs(dlh))
+
+
+def test_move_root_jc_invariance():                     # test/src/model.cpp:367-387
+    tree = rd.Tree.from_file(os.path.join(util.DATA, "101.tree"))
+    seqs, weights = util.compress(util.read_phylip(os.path.join(util.DATA, "101.phy")))
+    m = rd.Model(tree, seqs, rate_cats=1, weights=weights, seed=5)
+    m.initialize_partitions()
+    m.set_subst_rates([1.0] * 12)
+    m.set_freqs([0.25] * 4)
+    m.compute_lh(tree.root_location(0))
+    lhs = m.compute_all_root_lh()
+    assert len(lhs) == 199
+    assert np.max(np.abs(lhs - lhs[0])) < 1.2e-5 * abs(lhs[0])      # Catch Approx default
+
+
+def test_compute_lh_batch_matches_single_calls():
+    tree, seqs = ten()
+    m = rd.Model(tree, seqs, rate_cats=4, seed=3)
+    m.initialize_partitions()
+    rng = np.random.default_rng(3)
+    rls = [tree.root_location(int(i)).with_ratio(float(a))
+           for i, a in zip(rng.choice(17, 6, replace=False), rng.uniform(0.1, 0.9, 6))]
+    subst = rng.uniform(1e-4, 1, (6, 12))
+    freqs = rng.dirichlet(np.ones(4) * 4, 6)
+    alphas = rng.uniform(0.3, 3.0, 6)
+    got = m.compute_lh_batch(rls, subst, freqs, alphas)
+    for j, rl in enumerate(rls):
+        m.set_subst_rates(subst[j])
+        m.set_freqs(freqs[j])
+        m.set_gamma_alpha(alphas[j])
+        assert util.rel_err(got[j], m.compute_lh(rl)) < 1e-12
+
+
+def test_exhaustive_search_runs_and_ranks_roots():       # test/src/model.cpp:389-401
+    tree, seqs = ten()
+    m = rd.Model(tree, seqs, rate_cats=1, seed=11)
+    m.initialize_partitions()
+    m.compute_lh(tree.root_location(0))
+    res = m.exhaustive_search(1e-3, 1e-3, 1e-3, 1e12)
+    assert sorted(res["root_id"]) == list(range(17))
+    assert np.all(np.isfinite(res["llh"])) and np.all(res["llh"] < 0)
+    assert np.all((res["alpha"] >= 0) & (res["alpha"] <= 1))
+    assert res["best_llh"] == res["llh"].max()
+    # every reported (root, alpha) reproduces its lnL under the search's model
+    m.set_subst_rates_uniform()
+    m.set_empirical_freqs()
+    for rid, llh, a in zip(res["root_id"], res["llh"], res["alpha"]):
+        rl = tree.root_location(rid).with_ratio(float(a))
+        assert util.rel_err(m.compute_lh(rl), llh) < 1e-9
+    # rank split covers the same roots (src/model.cpp:1867-1911)
+    seen = []
+    for rank in range(3):
+        m.assign_by_rank(rank, 3)
+        seen += m.exhaustive_search(1e-3, 1e-3, 1e-3, 1e12)["root_id"]
+    assert sorted(seen) == list(range(17))
