@@ -179,7 +179,7 @@ def main():
     def clv_roofline(ms, launches, evals):
         bytes_clv = clv_kernel_bytes(n, S, R, K) * evals
         achieved = bytes_clv / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-        return {"kernel": "clv_dna_level_kernel" if K == 4 else "clv_generic_level_kernel",
+        return {"kernel": ("clv_dna_traversal_kernel" if K == 4 else "clv_k20_traversal_kernel" if K == 20 else "clv_generic_traversal_kernel"),
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                 "bytes_per_launch": round(bytes_clv / max(launches, 1)),

@@ -22,6 +22,8 @@ constexpr double kScaleFactor =
 constexpr double kScaleThreshold = 1.0 / kScaleFactor;
 // log(2^-256)
 constexpr double kLogScaleThreshold = -177.44567822334599;
+// scratch P-matrix slots behind the caller's (root alpha variants)
+constexpr unsigned kExtraMatrices = 8;
 
 void set_error(int code, const char *fmt, ...);
 void clear_error();
@@ -62,6 +64,7 @@ struct rdamd_partition {
   unsigned *d_scaler = nullptr;
   double   *d_pmat = nullptr;
   double   *d_tiptab = nullptr;
+  double   *d_pmat_mfma = nullptr;   // 20-state only: MFMA-ready copy of d_pmat
   uint64_t *d_codemask = nullptr;
   double   *d_q = nullptr;        // [rate_matrices][K][K]
   double   *d_freqs = nullptr;    // [rate_matrices][K]
@@ -125,12 +128,21 @@ struct LevelOp {   // device-side op descriptor
   unsigned parent_clv, child1_clv, child2_clv;     // absolute clv indices
   unsigned child1_mat, child2_mat;
   int parent_sc, child1_sc, child2_sc;
+  unsigned src1, src2;   // 0 tip, 1 memory, 2 register (= parent of the previous op)
 };
 hipError_t launch_clv_traversal(rdamd_partition *p, const LevelOp *d_ops, unsigned nops);
+
+// kernels_clv_mfma.hip (20 states)
+hipError_t launch_pmat_to_mfma(rdamd_partition *p, const unsigned *d_matrix_indices, unsigned count);
+hipError_t launch_clv_k20_traversal(rdamd_partition *p, const LevelOp *d_ops, unsigned nops);
 
 // kernels_root.hip
 hipError_t launch_root_lnl(rdamd_partition *p, unsigned clv_index, int scaler_index,
                            const unsigned *d_freqs_indices, double *d_persite,
                            double *d_out);
+// one root operation + reduction for n_alpha (<= kExtraMatrices/2) positions;
+// d_mats = [n_alpha][2] matrix slots; the last position's root CLV is stored
+hipError_t launch_root_fused(rdamd_partition *p, const LevelOp &op, const unsigned *d_mats,
+                             unsigned n_alpha, const unsigned *d_freqs_indices, double *d_out);
 
 }  // namespace rdamd

@@ -14,12 +14,14 @@
 // P-matrices), read from LDS.
 //
 // A whole operation list runs in ONE launch.  Every dependency of the
-// traversal is site-local -- parent[s][r] needs only child[s][r] -- and the
-// lane -> (site, rate) assignment is the same for every operation, so a lane
-// only ever reads what it (or, for the per-site scaler, a neighbour lane of its
-// own wave) wrote earlier in the same kernel: no grid-wide synchronisation,
-// and a child CLV written a few operations earlier is usually still in L2
-// when its parent reads it.
+// traversal is site-local -- parent[s][r] needs only child[s][r] -- and each
+// lane owns one (site, rate) pair for the whole list, so there is no
+// synchronisation at all between waves.  A child produced by the operation
+// just before (every inner child of a tip+inner node, the second child of an
+// inner+inner node) is taken from the lane's registers instead of being read
+// back; an older sibling is prefetched one operation ahead; every CLV is
+// still written (the reference's state contract).  What is left on the memory
+// pipe is an almost pure store stream.
 #include "common.hpp"
 
 namespace rdamd {
@@ -28,96 +30,130 @@ namespace rdamd {
 // 4-state path: one lane per (site, rate); the R lanes of a site are adjacent
 // so the "all entries below threshold" test is an in-wave AND.
 // ---------------------------------------------------------------------------
+// LevelOp::src* values
+enum : unsigned { kSrcTip = 0, kSrcMem = 1, kSrcReg = 2 };
+
 template <int R>
 __global__ void __launch_bounds__(256)
 clv_dna_traversal_kernel(DeviceView v, const LevelOp *__restrict__ ops, unsigned nops) {
-  // per child: P-matrix [R][4][4] or tip table [R][16][4]; double-buffered so
-  // the matrices of operation i+1 are staged while operation i computes
-  __shared__ double smat[2][2][R * 64];
-  const unsigned tid = threadIdx.x;
+  // Per WAVE, double-buffered: P-matrix [R][4][4] or tip table [R][16][4] of
+  // both children.  Waves never synchronise with each other: each stages the
+  // matrices of operation i+1 itself while operation i computes.
+  __shared__ double smat_all[4][2][2][R * 64];
+  const unsigned tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  double (*smat)[2][R * 64] = smat_all[wave];
   const unsigned S = v.sites;
   const size_t total = (size_t)S * R;
-  const size_t stride = (size_t)gridDim.x * 256;
+  const size_t idx = (size_t)blockIdx.x * 256 + tid;   // one (site, rate) pair per lane
+  const bool active = idx < total;
+  const size_t cidx = active ? idx : total - 1;        // clamped for loads
+  const unsigned s = (unsigned)(cidx / R), r = (unsigned)(cidx % R);
 
   auto stage = [&](unsigned i, unsigned buf) {
     const LevelOp op = ops[i];
-    const bool t1 = op.child1_clv < v.tips, t2 = op.child2_clv < v.tips;
+    const bool t1 = op.src1 == kSrcTip, t2 = op.src2 == kSrcTip;
     const double *src1 = t1 ? v.tiptab + (size_t)op.child1_mat * R * 64
                             : v.pmat + (size_t)op.child1_mat * R * 16;
     const double *src2 = t2 ? v.tiptab + (size_t)op.child2_mat * R * 64
                             : v.pmat + (size_t)op.child2_mat * R * 16;
     const unsigned n1 = t1 ? R * 64 : R * 16, n2 = t2 ? R * 64 : R * 16;
-    for (unsigned e = tid; e < n1; e += 256) smat[buf][0][e] = src1[e];
-    for (unsigned e = tid; e < n2; e += 256) smat[buf][1][e] = src2[e];
+    for (unsigned e = lane; e < n1; e += 64) smat[buf][0][e] = src1[e];
+    for (unsigned e = lane; e < n2; e += 64) smat[buf][1][e] = src2[e];
+  };
+  // an older sibling (not produced by the operation just before) comes from
+  // HBM/L2; it is fetched one operation ahead
+  auto fetch = [&](const LevelOp &op, int which, double (&x)[4], unsigned &sc) {
+    const unsigned clv = which ? op.child2_clv : op.child1_clv;
+    const int scb = which ? op.child2_sc : op.child1_sc;
+    const double2 *c = reinterpret_cast<const double2 *>(v.clv + (size_t)(clv - v.tips) * v.clv_stride);
+    const double2 a = c[cidx * 2], b = c[cidx * 2 + 1];
+    x[0] = a.x; x[1] = a.y; x[2] = b.x; x[3] = b.y;
+    sc = scb >= 0 ? v.scaler[(size_t)scb * S + s] : 0u;
   };
 
+  double o[4] = {0, 0, 0, 0};       // the CLV this lane produced last
+  unsigned osc = 0;
+  double m1[4] = {0, 0, 0, 0}, m2[4] = {0, 0, 0, 0};   // prefetched memory operands
+  unsigned m1sc = 0, m2sc = 0;
   stage(0, 0);
-  __syncthreads();
+  {
+    const LevelOp op0 = ops[0];
+    if (op0.src1 == kSrcMem) fetch(op0, 0, m1, m1sc);
+    if (op0.src2 == kSrcMem) fetch(op0, 1, m2, m2sc);
+  }
   for (unsigned i = 0; i < nops; ++i) {
     const unsigned buf = i & 1;
-    if (i + 1 < nops) stage(i + 1, buf ^ 1);
     const LevelOp op = ops[i];
-    const bool tip1 = op.child1_clv < v.tips, tip2 = op.child2_clv < v.tips;
-    const double2 *c1 = tip1 ? nullptr
-        : reinterpret_cast<const double2 *>(v.clv + (size_t)(op.child1_clv - v.tips) * v.clv_stride);
-    const double2 *c2 = tip2 ? nullptr
-        : reinterpret_cast<const double2 *>(v.clv + (size_t)(op.child2_clv - v.tips) * v.clv_stride);
-    double2 *pc = reinterpret_cast<double2 *>(v.clv + (size_t)(op.parent_clv - v.tips) * v.clv_stride);
-    const uint8_t *code1 = tip1 ? v.tipcodes + (size_t)op.child1_clv * S : nullptr;
-    const uint8_t *code2 = tip2 ? v.tipcodes + (size_t)op.child2_clv * S : nullptr;
-    unsigned *psc = op.parent_sc >= 0 ? v.scaler + (size_t)op.parent_sc * S : nullptr;
-    const unsigned *lsc = op.child1_sc >= 0 ? v.scaler + (size_t)op.child1_sc * S : nullptr;
-    const unsigned *rsc = op.child2_sc >= 0 ? v.scaler + (size_t)op.child2_sc * S : nullptr;
-
-    for (size_t idx = (size_t)blockIdx.x * 256 + tid; idx < total; idx += stride) {
-      const unsigned s = (unsigned)(idx / R), r = (unsigned)(idx % R);
-      double t1[4], t2[4];
-      if (tip1) {
-        const double *row = &smat[buf][0][(r * 16 + code1[s]) * 4];
+    double x[4], y[4];
+    unsigned xsc = 0, ysc = 0, cx = 0, cy = 0;
+    if (op.src1 == kSrcTip) cx = v.tipcodes[(size_t)op.child1_clv * S + s];
+    else if (op.src1 == kSrcReg) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) t1[k] = row[k];
-      } else {
-        const double2 a = c1[idx * 2], b = c1[idx * 2 + 1];
-        const double *m = &smat[buf][0][r * 16];
+      for (int k = 0; k < 4; ++k) x[k] = o[k];
+      xsc = osc;
+    } else {
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-          t1[k] = m[k * 4 + 0] * a.x + m[k * 4 + 1] * a.y + m[k * 4 + 2] * b.x + m[k * 4 + 3] * b.y;
+      for (int k = 0; k < 4; ++k) x[k] = m1[k];
+      xsc = m1sc;
+    }
+    if (op.src2 == kSrcTip) cy = v.tipcodes[(size_t)op.child2_clv * S + s];
+    else if (op.src2 == kSrcReg) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) y[k] = o[k];
+      ysc = osc;
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) y[k] = m2[k];
+      ysc = m2sc;
+    }
+    if (i + 1 < nops) {   // next operation: matrices into the other buffer, older siblings into registers
+      stage(i + 1, buf ^ 1);
+      const LevelOp nx = ops[i + 1];
+      if (nx.src1 == kSrcMem) fetch(nx, 0, m1, m1sc);
+      if (nx.src2 == kSrcMem) fetch(nx, 1, m2, m2sc);
+    }
+    double t1[4], t2[4];
+    if (op.src1 == kSrcTip) {
+      const double *row = &smat[buf][0][(r * 16 + cx) * 4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) t1[k] = row[k];
+    } else {
+      const double *m = &smat[buf][0][r * 16];
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        t1[k] = m[k * 4 + 0] * x[0] + m[k * 4 + 1] * x[1] + m[k * 4 + 2] * x[2] + m[k * 4 + 3] * x[3];
+    }
+    if (op.src2 == kSrcTip) {
+      const double *row = &smat[buf][1][(r * 16 + cy) * 4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) t2[k] = row[k];
+    } else {
+      const double *m = &smat[buf][1][r * 16];
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        t2[k] = m[k * 4 + 0] * y[0] + m[k * 4 + 1] * y[1] + m[k * 4 + 2] * y[2] + m[k * 4 + 3] * y[3];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[k] = t1[k] * t2[k];
+    osc = 0;
+    if (op.parent_sc >= 0) {
+      int small = (o[0] < kScaleThreshold) & (o[1] < kScaleThreshold) &
+                  (o[2] < kScaleThreshold) & (o[3] < kScaleThreshold);
+#pragma unroll
+      for (int off = 1; off < R; off <<= 1) small &= __shfl_xor(small, off);
+      osc = xsc + ysc;
+      if (small) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] *= kScaleFactor;
+        osc += 1;
       }
-      if (tip2) {
-        const double *row = &smat[buf][1][(r * 16 + code2[s]) * 4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) t2[k] = row[k];
-      } else {
-        const double2 a = c2[idx * 2], b = c2[idx * 2 + 1];
-        const double *m = &smat[buf][1][r * 16];
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-          t2[k] = m[k * 4 + 0] * a.x + m[k * 4 + 1] * a.y + m[k * 4 + 2] * b.x + m[k * 4 + 3] * b.y;
-      }
-      double o[4];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) o[k] = t1[k] * t2[k];
-      if (psc) {
-        int small = (o[0] < kScaleThreshold) & (o[1] < kScaleThreshold) &
-                    (o[2] < kScaleThreshold) & (o[3] < kScaleThreshold);
-#pragma unroll
-        for (int off = 1; off < R; off <<= 1) small &= __shfl_xor(small, off);
-        unsigned sc = (lsc ? lsc[s] : 0u) + (rsc ? rsc[s] : 0u);
-        if (small) {
-#pragma unroll
-          for (int k = 0; k < 4; ++k) o[k] *= kScaleFactor;
-          sc += 1;
-        }
-        if (r == 0) psc[s] = sc;
-      }
+      if (r == 0 && active) v.scaler[(size_t)op.parent_sc * S + s] = osc;
+    }
+    if (active) {
+      double2 *pc = reinterpret_cast<double2 *>(v.clv + (size_t)(op.parent_clv - v.tips) * v.clv_stride);
       pc[idx * 2] = make_double2(o[0], o[1]);
       pc[idx * 2 + 1] = make_double2(o[2], o[3]);
     }
-    // (a) the staged matrices of op i+1 become visible, (b) nobody still reads
-    // buffer `buf` when op i+2 is staged into it, (c) this workgroup's CLV and
-    // scaler stores are ordered before its later loads of them
-    __threadfence_block();
-    __syncthreads();
   }
 }
 
@@ -187,7 +223,7 @@ clv_generic_traversal_kernel(DeviceView v, const LevelOp *__restrict__ ops, unsi
 }
 
 static inline bool dna_fast_ok(unsigned K, unsigned R, unsigned cap) {
-  return K == 4 && cap == 16 && (R == 1 || R == 2 || R == 4 || R == 8 || R == 16);
+  return K == 4 && cap == 16 && (R == 1 || R == 2 || R == 4 || R == 8);
 }
 
 hipError_t launch_clv_traversal(rdamd_partition *p, const LevelOp *d_ops, unsigned nops) {
@@ -199,13 +235,11 @@ hipError_t launch_clv_traversal(rdamd_partition *p, const LevelOp *d_ops, unsign
     // parallelism; the lane -> pair map is identical for every operation
     size_t total = (size_t)p->sites * R;
     unsigned gx = (unsigned)((total + 255) / 256);
-    if (gx > 8192) gx = 8192;
     switch (R) {
       case 1: clv_dna_traversal_kernel<1><<<gx, 256, 0, p->stream>>>(v, d_ops, nops); break;
       case 2: clv_dna_traversal_kernel<2><<<gx, 256, 0, p->stream>>>(v, d_ops, nops); break;
       case 4: clv_dna_traversal_kernel<4><<<gx, 256, 0, p->stream>>>(v, d_ops, nops); break;
-      case 8: clv_dna_traversal_kernel<8><<<gx, 256, 0, p->stream>>>(v, d_ops, nops); break;
-      default: clv_dna_traversal_kernel<16><<<gx, 256, 0, p->stream>>>(v, d_ops, nops); break;
+      default: clv_dna_traversal_kernel<8><<<gx, 256, 0, p->stream>>>(v, d_ops, nops); break;
     }
   } else {
     unsigned gx = (p->sites + 255) / 256;

@@ -27,6 +27,14 @@ __device__ inline double block_sum_256(double v, double *lds) {
   return r;
 }
 
+// sum_k c[k] * f[k] with a pinned evaluation order (one fma chain), so the
+// separate and the fused root kernels produce bit-identical terms
+__device__ __forceinline__ double dot_freq(const double *c, const double *f, unsigned K) {
+  double tr = 0.0;
+  for (unsigned k = 0; k < K; ++k) tr = __builtin_fma(c[k], f[k], tr);
+  return tr;
+}
+
 // one lane per (site, rate); R in {1,2,4,8,16}
 template <int R>
 __global__ void __launch_bounds__(256)
@@ -43,9 +51,7 @@ root_lnl_group_kernel(const double *__restrict__ clv, const unsigned *__restrict
     const unsigned s = (unsigned)(idx / R), r = (unsigned)(idx % R);
     const double *c = clv + idx * K;
     const double *f = freqs + (size_t)fidx[r] * K;
-    double tr = 0.0;
-    for (unsigned k = 0; k < K; ++k) tr += c[k] * f[k];
-    tr *= rate_w[r];
+    double tr = dot_freq(c, f, K) * rate_w[r];
     // sum the R rate terms in rate order (same order as the reference loop)
     double term = 0.0;
     const int base = (int)(threadIdx.x & 63) & ~(R - 1);
@@ -80,9 +86,7 @@ root_lnl_site_kernel(const double *__restrict__ clv, const unsigned *__restrict_
     double term = 0.0;
     for (unsigned r = 0; r < R; ++r) {
       const double *f = freqs + (size_t)fidx[r] * K;
-      double tr = 0.0;
-      for (unsigned k = 0; k < K; ++k) tr += c[(size_t)r * K + k] * f[k];
-      term += tr * rate_w[r];
+      term += dot_freq(c + (size_t)r * K, f, K) * rate_w[r];
     }
     double l = log(term);
     if (scaler) {
@@ -101,10 +105,127 @@ root_lnl_site_kernel(const double *__restrict__ clv, const unsigned *__restrict_
 __global__ void __launch_bounds__(256)
 finish_sum_kernel(const double *__restrict__ partials, unsigned n, double *__restrict__ out) {
   __shared__ double lds[4];
+  const double *p = partials + (size_t)blockIdx.x * n;   // one workgroup per result
   double acc = 0.0;
-  for (unsigned i = threadIdx.x; i < n; i += 256) acc += partials[i];
+  for (unsigned i = threadIdx.x; i < n; i += 256) acc += p[i];
   double b = block_sum_256(acc, lds);
-  if (threadIdx.x == 0) *out = b;
+  if (threadIdx.x == 0) out[blockIdx.x] = b;
+}
+
+// ---------------------------------------------------------------------------
+// Fused root evaluation for 4-state data: the root operation (both child
+// CLVs read ONCE) and the log-likelihood reduction for NA root positions on
+// the same branch -- the body of model_t::compute_lh_root / compute_dlh
+// (/root/reference/src/model.cpp:415-452, :481-519).  Grid shape, per-lane
+// accumulation order and reduction tree are those of root_lnl_group_kernel,
+// so each returned value is bit-identical to update_clvs + that kernel.
+// The last position's root CLV and scaler are stored.
+// ---------------------------------------------------------------------------
+template <int R, int NA>
+__global__ void __launch_bounds__(256)
+root_fused_dna_kernel(DeviceView v, LevelOp op, const unsigned *__restrict__ mats,
+                      const double *__restrict__ freqs, const unsigned *__restrict__ fidx,
+                      const double *__restrict__ rate_w, const unsigned *__restrict__ pw,
+                      double *__restrict__ partials) {
+  __shared__ double smat[NA][2][R * 64];
+  __shared__ double lds[4];
+  const unsigned tid = threadIdx.x, S = v.sites;
+  const bool tip1 = op.child1_clv < v.tips, tip2 = op.child2_clv < v.tips;
+  for (int a = 0; a < NA; ++a) {
+    const unsigned m1 = mats[2 * a], m2 = mats[2 * a + 1];
+    const double *src1 = tip1 ? v.tiptab + (size_t)m1 * R * 64 : v.pmat + (size_t)m1 * R * 16;
+    const double *src2 = tip2 ? v.tiptab + (size_t)m2 * R * 64 : v.pmat + (size_t)m2 * R * 16;
+    const unsigned n1 = tip1 ? R * 64 : R * 16, n2 = tip2 ? R * 64 : R * 16;
+    for (unsigned e = tid; e < n1; e += 256) smat[a][0][e] = src1[e];
+    for (unsigned e = tid; e < n2; e += 256) smat[a][1][e] = src2[e];
+  }
+  __syncthreads();
+
+  const size_t total = (size_t)S * R, stride = (size_t)gridDim.x * 256;
+  const double2 *c1 = tip1 ? nullptr
+      : reinterpret_cast<const double2 *>(v.clv + (size_t)(op.child1_clv - v.tips) * v.clv_stride);
+  const double2 *c2 = tip2 ? nullptr
+      : reinterpret_cast<const double2 *>(v.clv + (size_t)(op.child2_clv - v.tips) * v.clv_stride);
+  double2 *pc = reinterpret_cast<double2 *>(v.clv + (size_t)(op.parent_clv - v.tips) * v.clv_stride);
+  const uint8_t *code1 = tip1 ? v.tipcodes + (size_t)op.child1_clv * S : nullptr;
+  const uint8_t *code2 = tip2 ? v.tipcodes + (size_t)op.child2_clv * S : nullptr;
+  unsigned *psc = v.scaler + (size_t)op.parent_sc * S;
+  const unsigned *lsc = op.child1_sc >= 0 ? v.scaler + (size_t)op.child1_sc * S : nullptr;
+  const unsigned *rsc = op.child2_sc >= 0 ? v.scaler + (size_t)op.child2_sc * S : nullptr;
+
+  double acc[NA];
+#pragma unroll
+  for (int a = 0; a < NA; ++a) acc[a] = 0.0;
+  for (size_t idx = (size_t)blockIdx.x * 256 + tid; idx < total; idx += stride) {
+    const unsigned s = (unsigned)(idx / R), r = (unsigned)(idx % R);
+    double x[4] = {0, 0, 0, 0}, y[4] = {0, 0, 0, 0};
+    unsigned cx = 0, cy = 0;
+    if (tip1) cx = code1[s];
+    else { const double2 a = c1[idx * 2], b = c1[idx * 2 + 1]; x[0] = a.x; x[1] = a.y; x[2] = b.x; x[3] = b.y; }
+    if (tip2) cy = code2[s];
+    else { const double2 a = c2[idx * 2], b = c2[idx * 2 + 1]; y[0] = a.x; y[1] = a.y; y[2] = b.x; y[3] = b.y; }
+    const unsigned sc0 = (lsc ? lsc[s] : 0u) + (rsc ? rsc[s] : 0u);
+    const double *f = freqs + (size_t)fidx[r] * 4;
+    const double w = rate_w[r];
+    const double weight = (double)pw[s];
+    const int base = (int)(threadIdx.x & 63) & ~(R - 1);
+#pragma unroll
+    for (int a = 0; a < NA; ++a) {
+      double t1[4], t2[4], o[4];
+      if (tip1) {
+        const double *row = &smat[a][0][(r * 16 + cx) * 4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) t1[k] = row[k];
+      } else {
+        const double *m = &smat[a][0][r * 16];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          t1[k] = m[k * 4 + 0] * x[0] + m[k * 4 + 1] * x[1] + m[k * 4 + 2] * x[2] + m[k * 4 + 3] * x[3];
+      }
+      if (tip2) {
+        const double *row = &smat[a][1][(r * 16 + cy) * 4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) t2[k] = row[k];
+      } else {
+        const double *m = &smat[a][1][r * 16];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          t2[k] = m[k * 4 + 0] * y[0] + m[k * 4 + 1] * y[1] + m[k * 4 + 2] * y[2] + m[k * 4 + 3] * y[3];
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) o[k] = t1[k] * t2[k];
+      int small = (o[0] < kScaleThreshold) & (o[1] < kScaleThreshold) &
+                  (o[2] < kScaleThreshold) & (o[3] < kScaleThreshold);
+#pragma unroll
+      for (int off = 1; off < R; off <<= 1) small &= __shfl_xor(small, off);
+      unsigned sc = sc0;
+      if (small) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] *= kScaleFactor;
+        sc += 1;
+      }
+      const double tr = dot_freq(o, f, 4) * w;
+      double term = 0.0;
+#pragma unroll
+      for (int q = 0; q < R; ++q) term += __shfl(tr, base + q);
+      if (r == 0) {
+        double l = log(term);
+        if (sc) l += (double)sc * kLogScaleThreshold;
+        acc[a] += l * weight;
+      }
+      if (a == NA - 1) {
+        if (r == 0) psc[s] = sc;
+        pc[idx * 2] = make_double2(o[0], o[1]);
+        pc[idx * 2 + 1] = make_double2(o[2], o[3]);
+      }
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < NA; ++a) {
+    const double b = block_sum_256(acc[a], lds);
+    if (threadIdx.x == 0) partials[(size_t)a * gridDim.x + blockIdx.x] = b;
+    __syncthreads();
+  }
 }
 
 hipError_t launch_root_lnl(rdamd_partition *p, unsigned clv_index, int scaler_index,
@@ -138,6 +259,45 @@ hipError_t launch_root_lnl(rdamd_partition *p, unsigned clv_index, int scaler_in
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   finish_sum_kernel<<<1, 256, 0, p->stream>>>(p->d_partials, blocks, d_out);
+  return hipGetLastError();
+}
+
+template <int R>
+static hipError_t launch_root_fused_r(rdamd_partition *p, const DeviceView &v, const LevelOp &op,
+                                      const unsigned *d_mats, unsigned n_alpha,
+                                      const unsigned *d_fidx, unsigned blocks) {
+#define RDAMD_RF(NA)                                                                        \
+  root_fused_dna_kernel<R, NA><<<blocks, 256, 0, p->stream>>>(                              \
+      v, op, d_mats, p->d_freqs, d_fidx, p->d_rate_weights, p->d_pattern_weights, p->d_partials)
+  switch (n_alpha) {
+    case 1: RDAMD_RF(1); break;
+    case 2: RDAMD_RF(2); break;
+    case 3: RDAMD_RF(3); break;
+    default: RDAMD_RF(4); break;
+  }
+#undef RDAMD_RF
+  return hipGetLastError();
+}
+
+hipError_t launch_root_fused(rdamd_partition *p, const LevelOp &op, const unsigned *d_mats,
+                             unsigned n_alpha, const unsigned *d_fidx, double *d_out) {
+  const unsigned S = p->sites, R = p->rate_cats;
+  if (n_alpha == 0 || n_alpha > 4) return hipErrorInvalidValue;
+  size_t total = (size_t)S * R;
+  unsigned blocks = (unsigned)((total + 255) / 256);
+  if (blocks > kRootBlocks) blocks = kRootBlocks;   // same shape as launch_root_lnl
+  if (blocks == 0) blocks = 1;
+  DeviceView v = p->view();
+  hipError_t e;
+  switch (R) {
+    case 1: e = launch_root_fused_r<1>(p, v, op, d_mats, n_alpha, d_fidx, blocks); break;
+    case 2: e = launch_root_fused_r<2>(p, v, op, d_mats, n_alpha, d_fidx, blocks); break;
+    case 4: e = launch_root_fused_r<4>(p, v, op, d_mats, n_alpha, d_fidx, blocks); break;
+    case 8: e = launch_root_fused_r<8>(p, v, op, d_mats, n_alpha, d_fidx, blocks); break;
+    default: return hipErrorInvalidValue;
+  }
+  if (e != hipSuccess) return e;
+  finish_sum_kernel<<<n_alpha, 256, 0, p->stream>>>(p->d_partials, blocks, d_out);
   return hipGetLastError();
 }
 

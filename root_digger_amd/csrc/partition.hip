@@ -174,15 +174,18 @@ rdamd_partition_t *rdamd_partition_create(unsigned int tips, unsigned int clv_bu
   TRY(hipMalloc(&p->d_tipcodes, std::max<size_t>(1, (size_t)tips * S)));
   TRY(hipMalloc(&p->d_clv, std::max<size_t>(8, (size_t)clv_buffers * S * R * K * sizeof(double))));
   TRY(hipMalloc(&p->d_scaler, std::max<size_t>(4, (size_t)scale_buffers * S * sizeof(unsigned))));
-  TRY(hipMalloc(&p->d_pmat, std::max<size_t>(8, (size_t)prob_matrices * R * K * K * sizeof(double))));
-  TRY(hipMalloc(&p->d_tiptab, std::max<size_t>(8, (size_t)prob_matrices * R * p->ncodes_cap * K * sizeof(double))));
+  // kExtraMatrices scratch slots behind the caller's: alpha variants of the fused root evaluation
+  TRY(hipMalloc(&p->d_pmat, (size_t)(prob_matrices + kExtraMatrices) * R * K * K * sizeof(double)));
+  TRY(hipMalloc(&p->d_tiptab, (size_t)(prob_matrices + kExtraMatrices) * R * p->ncodes_cap * K * sizeof(double)));
+  if (K == 20 && R <= 16)
+    TRY(hipMalloc(&p->d_pmat_mfma, (size_t)(prob_matrices + kExtraMatrices) * R * 640 * sizeof(double)));
   TRY(hipMalloc(&p->d_codemask, 256 * sizeof(uint64_t)));
   TRY(hipMalloc(&p->d_q, (size_t)rate_matrices * K * K * sizeof(double)));
   TRY(hipMalloc(&p->d_freqs, (size_t)rate_matrices * K * sizeof(double)));
   TRY(hipMalloc(&p->d_rates, R * sizeof(double)));
   TRY(hipMalloc(&p->d_rate_weights, R * sizeof(double)));
   TRY(hipMalloc(&p->d_pattern_weights, std::max<size_t>(4, S * sizeof(unsigned))));
-  TRY(hipMalloc(&p->d_partials, 4096 * sizeof(double)));
+  TRY(hipMalloc(&p->d_partials, 8192 * sizeof(double)));
   TRY(hipMalloc(&p->d_result, 64 * sizeof(double)));
   p->stage_bytes = (size_t)4 << 20;
   TRY(hipHostMalloc(&p->h_stage, p->stage_bytes, hipHostMallocDefault));
@@ -219,7 +222,7 @@ rdamd_partition_t *rdamd_partition_create(unsigned int tips, unsigned int clv_bu
 void rdamd_partition_destroy(rdamd_partition_t *p) {
   if (!p) return;
   if (p->stream) (void)hipStreamSynchronize(p->stream);
-  void *dev[] = {p->d_tipcodes, p->d_clv, p->d_scaler, p->d_pmat, p->d_tiptab,
+  void *dev[] = {p->d_tipcodes, p->d_clv, p->d_scaler, p->d_pmat, p->d_tiptab, p->d_pmat_mfma,
                  p->d_codemask, p->d_q, p->d_freqs, p->d_rates, p->d_rate_weights,
                  p->d_pattern_weights, p->d_tipclv_scratch, p->d_scratch,
                  p->d_partials, p->d_result, p->d_persite};
@@ -385,6 +388,7 @@ int rdamd_update_prob_matrices(rdamd_partition_t *p, const unsigned int *params_
   RDAMD_HIP_TRY(upload(p, d_bl, branch_lengths, sizeof(double) * count), RDAMD_FAILURE);
   p->prof_begin(1);
   hipError_t le = launch_pmatrix(p, d_pi, d_mi, d_bl, count);
+  if (le == hipSuccess && p->d_pmat_mfma) le = launch_pmat_to_mfma(p, d_mi, count);
   p->prof_end();
   RDAMD_HIP_TRY(le, RDAMD_FAILURE);
   return RDAMD_SUCCESS;
@@ -413,6 +417,10 @@ void rdamd_update_clvs(rdamd_partition_t *p, const rdamd_operation_t *ops,
     d.child2_clv = o.child2_clv_index; d.child1_mat = o.child1_matrix_index;
     d.child2_mat = o.child2_matrix_index; d.parent_sc = o.parent_scaler_index;
     d.child1_sc = o.child1_scaler_index; d.child2_sc = o.child2_scaler_index;
+    const unsigned prev = i ? ops[i - 1].parent_clv_index : ~0u;
+    d.src1 = o.child1_clv_index < p->tips ? 0u : (o.child1_clv_index == prev ? 2u : 1u);
+    d.src2 = o.child2_clv_index < p->tips ? 0u : (o.child2_clv_index == prev ? 2u : 1u);
+    if (d.src1 == 2u && d.src2 == 2u) d.src2 = 1u;   // same CLV twice: read one back
   }
   // The whole list runs as one launch in the caller's order: every dependency
   // is site-local, so the kernel needs no level structure (kernels_clv.hip).
@@ -427,7 +435,8 @@ void rdamd_update_clvs(rdamd_partition_t *p, const rdamd_operation_t *ops,
     e = upload(p, d_ops, lops.data(), sizeof(LevelOp) * count);
     if (e == hipSuccess) {
       p->prof_begin(0);
-      e = launch_clv_traversal(p, d_ops, count);
+      e = p->d_pmat_mfma ? launch_clv_k20_traversal(p, d_ops, count)
+                         : launch_clv_traversal(p, d_ops, count);
       p->prof_end();
     }
   }
@@ -477,18 +486,95 @@ int rdamd_root_loglikelihood_fused(rdamd_partition_t *p, const rdamd_operation_t
                                    const unsigned int *params_indices,
                                    const double *lengths1, const double *lengths2,
                                    unsigned int n_alpha, double *lnl_out) {
-  // First form: the three calls queued back to back on the partition stream
-  // (no host round trip between them except the final value).
-  for (unsigned a = 0; a < n_alpha; ++a) {
-    unsigned mi[2] = {root_op->child1_matrix_index, root_op->child2_matrix_index};
-    double bl[2] = {lengths1[a], lengths2[a]};
-    if (rdamd_update_prob_matrices(p, params_indices, mi, bl, 2) != RDAMD_SUCCESS)
+  clear_error();
+  if (n_alpha == 0) return RDAMD_SUCCESS;
+  const unsigned R = p->rate_cats, K = p->states;
+  const bool fast = K == 4 && p->ncodes_cap == 16 &&
+                    (R == 1 || R == 2 || R == 4 || R == 8) &&
+                    root_op->parent_scaler_index >= 0;
+  if (!fast) {
+    // generic shapes: the three calls queued back to back on the partition stream
+    for (unsigned a = 0; a < n_alpha; ++a) {
+      unsigned mi[2] = {root_op->child1_matrix_index, root_op->child2_matrix_index};
+      double bl[2] = {lengths1[a], lengths2[a]};
+      if (rdamd_update_prob_matrices(p, params_indices, mi, bl, 2) != RDAMD_SUCCESS)
+        return RDAMD_FAILURE;
+      rdamd_update_clvs(p, root_op, 1);
+      if (rdamd_errno()) return RDAMD_FAILURE;
+      lnl_out[a] = rdamd_compute_root_loglikelihood(
+          p, root_op->parent_clv_index, root_op->parent_scaler_index, params_indices, nullptr);
+      if (rdamd_errno()) return RDAMD_FAILURE;
+    }
+    return RDAMD_SUCCESS;
+  }
+  const unsigned nclv = p->tips + p->clv_buffers;
+  if (root_op->parent_clv_index < p->tips || root_op->parent_clv_index >= nclv ||
+      root_op->child1_clv_index >= nclv || root_op->child2_clv_index >= nclv ||
+      root_op->child1_matrix_index >= p->prob_matrices ||
+      root_op->child2_matrix_index >= p->prob_matrices ||
+      root_op->parent_scaler_index >= (int)p->scale_buffers ||
+      root_op->child1_scaler_index >= (int)p->scale_buffers ||
+      root_op->child2_scaler_index >= (int)p->scale_buffers) {
+    set_error(10, "rdamd_root_loglikelihood_fused: index out of range");
+    return RDAMD_FAILURE;
+  }
+  for (unsigned r = 0; r < R; ++r)
+    if (params_indices[r] >= p->rate_matrices) {
+      set_error(7, "rdamd_root_loglikelihood_fused: params index out of range");
       return RDAMD_FAILURE;
-    rdamd_update_clvs(p, root_op, 1);
-    if (rdamd_errno()) return RDAMD_FAILURE;
-    lnl_out[a] = rdamd_compute_root_loglikelihood(
-        p, root_op->parent_clv_index, root_op->parent_scaler_index, params_indices, nullptr);
-    if (rdamd_errno()) return RDAMD_FAILURE;
+    }
+  RDAMD_HIP_TRY(flush_q(p), RDAMD_FAILURE);
+  if (p->tiptab_stale) {
+    RDAMD_HIP_TRY(launch_tiptab_all(p), RDAMD_FAILURE);
+    p->tiptab_stale = false;
+  }
+  // positions are processed in chunks of kExtraMatrices / 2; the LAST position of
+  // the call uses the caller's own matrix slots and leaves the root CLV / scaler
+  // in the partition, exactly as the unfused call sequence would.
+  const unsigned per_chunk = kExtraMatrices / 2;
+  for (unsigned base = 0; base < n_alpha; base += per_chunk) {
+    const unsigned n = std::min(per_chunk, n_alpha - base);
+    std::vector<unsigned> mi(2 * n);
+    std::vector<double> bl(2 * n);
+    for (unsigned a = 0; a < n; ++a) {
+      const bool last = base + a + 1 == n_alpha;
+      mi[2 * a] = last ? root_op->child1_matrix_index : p->prob_matrices + 2 * a;
+      mi[2 * a + 1] = last ? root_op->child2_matrix_index : p->prob_matrices + 2 * a + 1;
+      bl[2 * a] = lengths1[base + a];
+      bl[2 * a + 1] = lengths2[base + a];
+      if (!(bl[2 * a] >= 0.0) || !(bl[2 * a + 1] >= 0.0) || !std::isfinite(bl[2 * a]) ||
+          !std::isfinite(bl[2 * a + 1])) {
+        set_error(9, "rdamd_root_loglikelihood_fused: invalid branch length");
+        return RDAMD_FAILURE;
+      }
+    }
+    RDAMD_HIP_TRY(ensure_scratch(p, 4096 + sizeof(unsigned) * (R + 2 * n) + sizeof(double) * 2 * n),
+                  RDAMD_FAILURE);
+    Scratch sc{p};
+    unsigned *d_pi = (unsigned *)sc.take(sizeof(unsigned) * R);
+    unsigned *d_mi = (unsigned *)sc.take(sizeof(unsigned) * 2 * n);
+    double *d_bl = (double *)sc.take(sizeof(double) * 2 * n);
+    RDAMD_HIP_TRY(upload(p, d_pi, params_indices, sizeof(unsigned) * R), RDAMD_FAILURE);
+    RDAMD_HIP_TRY(upload(p, d_mi, mi.data(), sizeof(unsigned) * 2 * n), RDAMD_FAILURE);
+    RDAMD_HIP_TRY(upload(p, d_bl, bl.data(), sizeof(double) * 2 * n), RDAMD_FAILURE);
+    p->prof_begin(1);
+    hipError_t e = launch_pmatrix(p, d_pi, d_mi, d_bl, 2 * n);
+    p->prof_end();
+    RDAMD_HIP_TRY(e, RDAMD_FAILURE);
+    LevelOp op;
+    op.parent_clv = root_op->parent_clv_index; op.child1_clv = root_op->child1_clv_index;
+    op.child2_clv = root_op->child2_clv_index; op.child1_mat = root_op->child1_matrix_index;
+    op.child2_mat = root_op->child2_matrix_index; op.parent_sc = root_op->parent_scaler_index;
+    op.child1_sc = root_op->child1_scaler_index; op.child2_sc = root_op->child2_scaler_index;
+    op.src1 = op.src2 = 0;
+    p->prof_begin(2);
+    e = launch_root_fused(p, op, d_mi, n, d_pi, p->d_result);
+    p->prof_end();
+    RDAMD_HIP_TRY(e, RDAMD_FAILURE);
+    RDAMD_HIP_TRY(hipMemcpyAsync(p->h_result, p->d_result, sizeof(double) * n,
+                                 hipMemcpyDeviceToHost, p->stream), RDAMD_FAILURE);
+    RDAMD_HIP_TRY(hipStreamSynchronize(p->stream), RDAMD_FAILURE);
+    for (unsigned a = 0; a < n; ++a) lnl_out[base + a] = p->h_result[a];
   }
   return RDAMD_SUCCESS;
 }

@@ -433,3 +433,47 @@ def test_c2_full_size_fused_properties(c2_full):
     all_s = [g.schedule(*tree.generate_operations(rl)) for rl in tree.roots()]
     jc = g.evaluate_batch(all_s, np.ones((197, 12)), np.full((197, 4), 0.25))
     assert np.max(np.abs(jc - jc[0])) < 1e-9 * abs(jc[0])
+
+
+# ---------------------------------------------------------------------------
+# 20-state MFMA kernel (BASELINE config c3 shape)
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("R,S", [(1, 47), (3, 33), (4, 130)])
+def test_protein_mfma_rescaling_and_ragged_tiles(R, S):
+    """Deep 20-state caterpillar: the per-site 2^256 rule must fire and the
+    scalers must equal the oracle's bit for bit; S is not a multiple of the
+    32-site tile, R covers 1 / odd / 4."""
+    rng = np.random.default_rng(200 + R)
+    aa = synth.AA
+    n = 140
+    names = ["q%03d" % i for i in range(n)]
+    nw = names[0]
+    for i in range(1, n - 2):
+        nw = "(%s:0.8,%s:0.6)" % (nw, names[i])
+    nw = "(%s:0.8,%s:0.6,%s:0.7);" % (nw, names[n - 2], names[n - 1])
+    seqs = {k: "".join(rng.choice(list(aa + "X"), S)) for k in names}
+    tree = rd.Tree.from_newick(nw)
+    cmap = util.make_map(aa, {"X": (1 << 20) - 1})
+    g, o = pair(tree, seqs, 20, R, cmap, cmap)
+    subst = rng.uniform(1e-4, 1, 380)
+    freqs = rng.dirichlet(np.ones(20) * 6)
+    rates = rd.compute_gamma_cats(0.5, R) if R > 1 else [1.0]
+    set_model((g, o), subst, freqs, rates)
+    rl = tree.root_location(3).with_ratio(0.4)
+    ops, pmi, brl = tree.generate_operations(rl)
+    for p in (g, o):
+        p.update_prob_matrices(pmi, brl)
+        p.update_clvs(ops)
+    assert o.get_scaler(tree.root_scaler_index()).max() >= 1
+    compare_state(g, o, ops, tree)
+    a = g.compute_root_loglikelihood(tree.root_clv_index(), tree.root_scaler_index())
+    b = o.compute_root_loglikelihood(tree.root_clv_index(), tree.root_scaler_index())
+    assert util.rel_err(a, b) < LNL_TOL
+    # move_root + root-only path on the MFMA kernel too
+    t2 = rd.Tree.from_newick(nw)
+    t2.root_by(rl)
+    for i in (0, 50, 200):
+        r2 = tree.root_location(i)
+        util.move_root(g, tree, r2)
+        util.move_root(o, t2, r2)
+        assert util.rel_err(util.compute_lh_root(g, tree, r2), util.compute_lh_root(o, t2, r2)) < LNL_TOL
