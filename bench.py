@@ -61,6 +61,27 @@ def full_eval_bytes(n, S, R, K):
     return (2 * n - 2) * W + n * S + (2 * n - 2) * 4 * S
 
 
+def profiled_traffic(kernel, batch, config):
+    """HBM bytes per launch of `kernel` from the committed PMC passes
+    (profiles/collect.sh + profiles/summarize.py: FETCH_SIZE/WRITE_SIZE in
+    separate rocprofv3 passes, corrected per MI355X_MICROARCH.md).  The passes
+    were taken on the default command (c2, batch 64); other shapes get null."""
+    if config != "c2" or batch != 64:
+        return None, None
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_summary.json")))
+    if not files:
+        return None, None
+    try:
+        d = json.load(open(files[-1]))
+        for k, v in d.items():
+            if k.startswith(kernel) and "hbm_bytes_per_launch" in v:
+                return int(v["hbm_bytes_per_launch"]), os.path.relpath(files[-1], ROOT)
+    except Exception:
+        pass
+    return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -205,6 +226,8 @@ def main():
                                "unit": "GB/s", "frac": round(hbm_equiv / HBM_PEAK_GBS, 3)},
             "pmatrix_ms_per_launch": round(prof["fused_pmatrix"][0] / max(prof["fused_pmatrix"][1], 1), 4),
         }
+        roofline["traffic"], roofline["traffic_source"] = profiled_traffic(
+            "fused_dna_eval_kernel", nb, args.config)
         # second leg: the materialising per-operation CLV kernel (drop-in
         # rdamd_update_clvs path), HBM-bound, a few evaluations only
         part.profile_enable(True)
@@ -213,6 +236,8 @@ def main():
         p2 = part.profile_read()
         part.profile_enable(False)
         extra["clv_kernel"] = clv_roofline(p2["clv"][0], p2["clv"][1], 6)
+        extra["clv_kernel"]["traffic"], extra["clv_kernel"]["traffic_source"] = profiled_traffic(
+            "clv_dna_traversal_kernel", nb, args.config)
     else:
         roofline = clv_roofline(prof["clv"][0], prof["clv"][1], evals_per_rank)
 
