@@ -228,11 +228,17 @@ def main():
         }
         roofline["traffic"], roofline["traffic_source"] = profiled_traffic(
             "fused_dna_eval_kernel", nb, args.config)
-        # second leg: the materialising per-operation CLV kernel (drop-in
-        # rdamd_update_clvs path), HBM-bound, a few evaluations only
-        part.profile_enable(True)
-        for j in range(6):
-            evaluate_unfused(j)
+        # second leg: the materialising CLV kernel (drop-in rdamd_update_clvs
+        # path), HBM-bound.  The traversals are queued back to back without a
+        # host sync in between, so the event-timed spans carry no launch gaps.
+        scheds_unfused = [tree.generate_operations(roots[j % len(mine)]) for j in range(6)]
+        for rep in range(2):
+            if rep == 1:
+                part.profile_enable(True)
+            for j, (ops_j, pmi_j, brl_j) in enumerate(scheds_unfused):
+                part.set_subst_params(0, params[j % len(mine)])
+                part.update_prob_matrices(pmi_j, brl_j)
+                part.update_clvs(ops_j)
         p2 = part.profile_read()
         part.profile_enable(False)
         extra["clv_kernel"] = clv_roofline(p2["clv"][0], p2["clv"][1], 6)
