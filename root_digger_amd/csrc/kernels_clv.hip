@@ -49,16 +49,31 @@ clv_dna_traversal_kernel(DeviceView v, const LevelOp *__restrict__ ops, unsigned
   const size_t cidx = active ? idx : total - 1;        // clamped for loads
   const unsigned s = (unsigned)(cidx / R), r = (unsigned)(cidx % R);
 
-  auto stage = [&](unsigned i, unsigned buf) {
-    const LevelOp op = ops[i];
+  // Staging is split (load early into registers, write to LDS late) so that no
+  // wave ever sits on a global load it has just issued: while operation i
+  // computes, the matrices, tip codes and older-sibling CLVs of operation i+1
+  // are all in flight.
+  constexpr int kStageRegs = (R * 64 + 63) / 64;   // doubles per lane per child
+  auto stage_load = [&](const LevelOp &op, double (&s1)[kStageRegs], double (&s2)[kStageRegs]) {
     const bool t1 = op.src1 == kSrcTip, t2 = op.src2 == kSrcTip;
     const double *src1 = t1 ? v.tiptab + (size_t)op.child1_mat * R * 64
                             : v.pmat + (size_t)op.child1_mat * R * 16;
     const double *src2 = t2 ? v.tiptab + (size_t)op.child2_mat * R * 64
                             : v.pmat + (size_t)op.child2_mat * R * 16;
     const unsigned n1 = t1 ? R * 64 : R * 16, n2 = t2 ? R * 64 : R * 16;
-    for (unsigned e = lane; e < n1; e += 64) smat[buf][0][e] = src1[e];
-    for (unsigned e = lane; e < n2; e += 64) smat[buf][1][e] = src2[e];
+#pragma unroll
+    for (int k = 0; k < kStageRegs; ++k) {
+      const unsigned e = lane + 64 * k;
+      s1[k] = e < n1 ? src1[e] : 0.0;
+      s2[k] = e < n2 ? src2[e] : 0.0;
+    }
+  };
+  auto stage_write = [&](unsigned buf, const double (&s1)[kStageRegs], const double (&s2)[kStageRegs]) {
+#pragma unroll
+    for (int k = 0; k < kStageRegs; ++k) {
+      smat[buf][0][lane + 64 * k] = s1[k];
+      smat[buf][1][lane + 64 * k] = s2[k];
+    }
   };
   // an older sibling (not produced by the operation just before) comes from
   // HBM/L2; it is fetched one operation ahead
@@ -70,51 +85,66 @@ clv_dna_traversal_kernel(DeviceView v, const LevelOp *__restrict__ ops, unsigned
     x[0] = a.x; x[1] = a.y; x[2] = b.x; x[3] = b.y;
     sc = scb >= 0 ? v.scaler[(size_t)scb * S + s] : 0u;
   };
+  // everything operation `op` needs from global memory, into registers
+  auto prefetch = [&](const LevelOp &op, double (&m1)[4], unsigned &m1sc, double (&m2)[4],
+                      unsigned &m2sc, unsigned &cx, unsigned &cy) {
+    if (op.src1 == kSrcTip) cx = v.tipcodes[(size_t)op.child1_clv * S + s];
+    else if (op.src1 == kSrcMem) fetch(op, 0, m1, m1sc);
+    if (op.src2 == kSrcTip) cy = v.tipcodes[(size_t)op.child2_clv * S + s];
+    else if (op.src2 == kSrcMem) fetch(op, 1, m2, m2sc);
+  };
 
   double o[4] = {0, 0, 0, 0};       // the CLV this lane produced last
   unsigned osc = 0;
   double m1[4] = {0, 0, 0, 0}, m2[4] = {0, 0, 0, 0};   // prefetched memory operands
-  unsigned m1sc = 0, m2sc = 0;
-  stage(0, 0);
+  unsigned m1sc = 0, m2sc = 0, cx = 0, cy = 0;
   {
+    double s1[kStageRegs], s2[kStageRegs];
     const LevelOp op0 = ops[0];
-    if (op0.src1 == kSrcMem) fetch(op0, 0, m1, m1sc);
-    if (op0.src2 == kSrcMem) fetch(op0, 1, m2, m2sc);
+    stage_load(op0, s1, s2);
+    prefetch(op0, m1, m1sc, m2, m2sc, cx, cy);
+    stage_write(0, s1, s2);
   }
+  // (A prefetch distance of two was tried: an older sibling may be the parent of
+  // operation i, which is not stored yet when operation i+2 would fetch it, and
+  // the conditional loads defeat counted vmcnt waits; one operation ahead is
+  // both correct by construction and faster.)
   for (unsigned i = 0; i < nops; ++i) {
     const unsigned buf = i & 1;
     const LevelOp op = ops[i];
+    const bool more = i + 1 < nops;
+    const LevelOp nx = ops[more ? i + 1 : i];
+    // operands of THIS operation out of the prefetch registers
     double x[4], y[4];
-    unsigned xsc = 0, ysc = 0, cx = 0, cy = 0;
-    if (op.src1 == kSrcTip) cx = v.tipcodes[(size_t)op.child1_clv * S + s];
-    else if (op.src1 == kSrcReg) {
+    unsigned xsc = 0, ysc = 0;
+    const unsigned ccx = cx, ccy = cy;
+    if (op.src1 == kSrcReg) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) x[k] = o[k];
       xsc = osc;
-    } else {
+    } else if (op.src1 == kSrcMem) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) x[k] = m1[k];
       xsc = m1sc;
     }
-    if (op.src2 == kSrcTip) cy = v.tipcodes[(size_t)op.child2_clv * S + s];
-    else if (op.src2 == kSrcReg) {
+    if (op.src2 == kSrcReg) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) y[k] = o[k];
       ysc = osc;
-    } else {
+    } else if (op.src2 == kSrcMem) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) y[k] = m2[k];
       ysc = m2sc;
     }
-    if (i + 1 < nops) {   // next operation: matrices into the other buffer, older siblings into registers
-      stage(i + 1, buf ^ 1);
-      const LevelOp nx = ops[i + 1];
-      if (nx.src1 == kSrcMem) fetch(nx, 0, m1, m1sc);
-      if (nx.src2 == kSrcMem) fetch(nx, 1, m2, m2sc);
+    // issue everything the NEXT operation needs
+    double s1[kStageRegs], s2[kStageRegs];
+    if (more) {
+      stage_load(nx, s1, s2);
+      prefetch(nx, m1, m1sc, m2, m2sc, cx, cy);
     }
     double t1[4], t2[4];
     if (op.src1 == kSrcTip) {
-      const double *row = &smat[buf][0][(r * 16 + cx) * 4];
+      const double *row = &smat[buf][0][(r * 16 + ccx) * 4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) t1[k] = row[k];
     } else {
@@ -124,7 +154,7 @@ clv_dna_traversal_kernel(DeviceView v, const LevelOp *__restrict__ ops, unsigned
         t1[k] = m[k * 4 + 0] * x[0] + m[k * 4 + 1] * x[1] + m[k * 4 + 2] * x[2] + m[k * 4 + 3] * x[3];
     }
     if (op.src2 == kSrcTip) {
-      const double *row = &smat[buf][1][(r * 16 + cy) * 4];
+      const double *row = &smat[buf][1][(r * 16 + ccy) * 4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) t2[k] = row[k];
     } else {
@@ -154,6 +184,7 @@ clv_dna_traversal_kernel(DeviceView v, const LevelOp *__restrict__ ops, unsigned
       pc[idx * 2] = make_double2(o[0], o[1]);
       pc[idx * 2 + 1] = make_double2(o[2], o[3]);
     }
+    if (more) stage_write(buf ^ 1, s1, s2);
   }
 }
 
