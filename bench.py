@@ -36,6 +36,7 @@ CONFIGS = {
     "c1": dict(n=10, S=1000, K=4, R=1),
     "c2": dict(n=100, S=50000, K=4, R=4),
     "c3": dict(n=200, S=10000, K=20, R=4),
+    "c4": dict(n=500, S=500000, K=4, R=4),
     "c5": dict(n=1000, S=100000, K=4, R=4),
 }
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
@@ -93,6 +94,10 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0,
                     help="budget for the cpu_baseline leg (rank 0, N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--shard", default="candidates", choices=["candidates", "sites"],
+                    help="N>1: split candidate roots (no collective, weak scaling; default) or "
+                         "split site blocks and all-reduce the per-block lnLs (strong scaling; "
+                         "BASELINE config c4 pattern)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -118,6 +123,12 @@ def main():
     n, S, K, R = cfg["n"], cfg["S"], cfg["K"], cfg["R"]
     seed = 0xD166E5 + sorted(CONFIGS).index(args.config)
     w = synth.workload(n, S, K, R, seed)
+    site_sharded = args.shard == "sites" and K == 4
+    S_total = S
+    if site_sharded:   # this rank's contiguous block of patterns (dist.site_block)
+        lo, hi = rdist.site_block(S, rank, world)
+        w["seqs"] = {k: v[lo:hi] for k, v in w["seqs"].items()}
+        S = hi - lo
     tree = rd.Tree.from_newick(w["newick"])
     cmap = rd.MAP_NT
     if K != 4:
@@ -135,13 +146,17 @@ def main():
 
     # this rank's candidate roots (src/model.cpp:1899-1907) and per-candidate
     # parameter sets (random_params, src/model.cpp:87-93)
-    mine = rdist.assign_candidates(tree.root_count(), rank, world)
-    rng = np.random.default_rng(seed + 1000 + rank)
+    if site_sharded:   # every rank sees every candidate, on its own sites
+        mine = list(range(tree.root_count()))
+        rng = np.random.default_rng(seed + 1000)
+    else:
+        mine = rdist.assign_candidates(tree.root_count(), rank, world)
+        rng = np.random.default_rng(seed + 1000 + rank)
     params = [synth.random_params(K * K - K, rng) for _ in range(len(mine))]
     roots = [tree.root_location(i) for i in mine]
 
     use_fused = (K == 4)
-    nb = min(args.batch, len(mine)) if use_fused else args.batch
+    nb = args.batch   # fixed per GPU whatever N is (weak scaling)
     params = np.array(params)
     freqs_b = np.tile(np.asarray(freqs), (len(mine), 1))
 
@@ -164,7 +179,15 @@ def main():
         if not use_fused:
             return sum(evaluate_unfused(s * nb + b) for b in range(nb))
         idx = [(s * nb + b) % len(mine) for b in range(nb)]
-        sub = params[idx] * (1.0 + 1e-3 * ((s % 97) + 1))
+        # every job of every step is a distinct (root, parameter set) pair
+        jitter = 1.0 + 1e-3 * (((s % 97) + 1) + np.arange(nb)[:, None] / (4.0 * nb))
+        sub = params[idx] * jitter * (1.0 + 0.05 * np.sin(np.arange(12) + s))
+        if site_sharded:
+            part.evaluate_batch_device([scheds[i] for i in idx], sub, freqs_b[idx],
+                                       lnl_dev.data_ptr())
+            if world > 1:
+                rdist.allreduce_lnl(lnl_dev)     # RCCL sum of the per-block lnLs
+            return lnl_dev
         return float(part.evaluate_batch([scheds[i] for i in idx], sub, freqs_b[idx]).sum())
 
     def barrier():
@@ -173,6 +196,7 @@ def main():
         torch.cuda.synchronize()
         part.sync()
 
+    lnl_dev = torch.zeros(nb, dtype=torch.float64, device="cuda") if site_sharded else None
     for s in range(args.warmup):
         step(s)
     part.profile_enable(True)
@@ -180,9 +204,13 @@ def main():
     t0 = time.perf_counter()
     check = 0.0
     for s in range(args.steps):
-        check += step(args.warmup + s)
+        out = step(args.warmup + s)
+        if not site_sharded:
+            check += out
     barrier()
     elapsed = time.perf_counter() - t0
+    if site_sharded:
+        check = float(lnl_dev.sum().item())
     prof = part.profile_read()
     part.profile_enable(False)
     if not np.isfinite(check):
@@ -194,7 +222,7 @@ def main():
         elapsed = float(t.item())
 
     evals_per_rank = args.steps * nb
-    total_evals = evals_per_rank * world
+    total_evals = evals_per_rank * (1 if site_sharded else world)
     value = total_evals / elapsed
 
     def clv_roofline(ms, launches, evals):
@@ -251,13 +279,15 @@ def main():
         "metric": "candidate-root lnL evals/sec", "value": round(value, 2),
         "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "higher_is_better": True, "scaling": "strong" if site_sharded else "weak",
+        "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": "%s: %d-taxon %d-site %d-state UNREST+G%d full-traversal "
                                "root lnL" % (args.config, n, S, K, R),
-                   "batch_per_gpu": nb, "sharding": "candidate roots",
+                   "batch_per_gpu": nb,
+                   "sharding": "site blocks + RCCL all-reduce" if site_sharded else "candidate roots",
                    "path": "fused batch" if use_fused else "per-operation"},
-        "site_clv_updates_per_sec": round(value * (n - 1) * S, 1),
+        "site_clv_updates_per_sec": round(value * (n - 1) * S_total, 1),
         "roofline": roofline,
     }
     result.update(extra)
