@@ -332,6 +332,18 @@ int rdamd_model_optimize_alpha(rdamd_model_t *m, const rdamd_root_location_t *rl
 int rdamd_model_compute_lh_batch(rdamd_model_t *m, unsigned int n,
                                  const rdamd_root_location_t *rls, const double *subst,
                                  const double *freqs, const double *gamma_alpha, double *out);
+/* Hands the model the caller's L-BFGS-B entry point (the reference's vendored
+ * `setulb`, lib/lbfgsb/lbfgsb.h:196-201).  exhaustive_search then optimises
+ * rates / frequencies / gamma alpha as optimize_params does
+ * (src/model.cpp:1925-1984), with every objective + finite-difference
+ * gradient evaluation (src/model.cpp:1488-1502) as ONE batched launch. */
+void rdamd_model_set_lbfgsb(rdamd_model_t *m, void *setulb_entry_point);
+/* optimize_params for the current parameters at root rl; returns them
+ * (subst [12], freqs [4], gamma_alpha [1]) and the objective statistics. */
+int rdamd_model_optimize_params(rdamd_model_t *m, const rdamd_root_location_t *rl,
+                                double pgtol, double factor, int optimize_gamma,
+                                double *subst, double *freqs, double *gamma_alpha,
+                                uint64_t *n_batches, uint64_t *n_evaluations);
 /* assign_indicies_by_rank_exhaustive, :1867-1911 */
 int rdamd_model_assign_by_rank(rdamd_model_t *m, unsigned int rank, unsigned int num_tasks);
 /* exhaustive_search, :1139-1272, over the assigned roots.  root_id / llh /

@@ -136,6 +136,9 @@ _sig("rdamd_model_compute_all_root_lh", C.c_int, _vp, _pd)
 _sig("rdamd_model_optimize_alpha", C.c_int, _vp, _prl, C.c_double, _prl)
 _sig("rdamd_model_compute_lh_batch", C.c_int, _vp, _u, _prl, _pd, _pd, _pd, _pd)
 _sig("rdamd_model_assign_by_rank", C.c_int, _vp, _u, _u)
+_sig("rdamd_model_set_lbfgsb", None, _vp, _vp)
+_sig("rdamd_model_optimize_params", C.c_int, _vp, _prl, C.c_double, C.c_double, C.c_int, _pd, _pd,
+     _pd, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64))
 _sig("rdamd_model_exhaustive_search", C.c_int, _vp, C.c_double, C.c_double, C.c_double,
      C.c_double, C.POINTER(C.c_uint64), _pd, _pd, _pu, _prl, _pd)
 
@@ -623,6 +626,23 @@ class Model:
                                                   _dptr(ga) if ga is not None else None,
                                                   _dptr(out)), "compute_lh_batch")
         return out
+
+    def set_lbfgsb(self, setulb):
+        """`setulb`: the caller's L-BFGS-B entry point (a ctypes function or address)."""
+        addr = setulb if isinstance(setulb, int) else C.cast(setulb, _vp).value
+        lib.rdamd_model_set_lbfgsb(self._h, C.c_void_p(addr))
+
+    def optimize_params(self, rl, subst, freqs, gamma_alpha, pgtol, factor, optimize_gamma=True):
+        subst = np.array(subst, dtype=np.float64)
+        freqs = np.array(freqs, dtype=np.float64)
+        ga = C.c_double(gamma_alpha)
+        nb, ne = C.c_uint64(0), C.c_uint64(0)
+        self._ok(lib.rdamd_model_optimize_params(self._h, C.byref(rl), pgtol, factor,
+                                                 1 if optimize_gamma else 0, _dptr(subst),
+                                                 _dptr(freqs), C.byref(ga), C.byref(nb),
+                                                 C.byref(ne)), "optimize_params")
+        return {"subst": subst, "freqs": freqs, "gamma_alpha": ga.value,
+                "batches": nb.value, "evaluations": ne.value}
 
     def assign_by_rank(self, rank, num_tasks):
         self._ok(lib.rdamd_model_assign_by_rank(self._h, rank, num_tasks), "assign_by_rank")

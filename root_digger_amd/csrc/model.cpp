@@ -311,6 +311,7 @@ void model_t::move_root(const root_location_t &new_root) {
 }
 
 std::vector<double> model_t::compute_all_root_lh() {
+  compute_lh(_tree.roots()[0]);
   std::vector<double> out;
   for (const auto &rl : _tree.roots()) {
     move_root(rl);
@@ -521,6 +522,127 @@ void model_t::assign_indicies_by_rank_exhaustive(size_t rank, size_t num_tasks,
   _assigned_idx.assign(left.begin() + (std::ptrdiff_t)beg, left.begin() + (std::ptrdiff_t)end);
 }
 
+// ---- parameter optimisation (src/model.cpp:1430-1522, :1925-1984) ------------------
+// The reference evaluates the objective once and then once per parameter for
+// the one-sided finite-difference gradient (h = max(eps |x_i|, eps)), each a
+// full traversal with different parameters.  Here those 1 + n evaluations are
+// one rdamd_evaluate_batch call on a schedule compiled once per optimize_params.
+double model_t::bfgs_params(model_params_t &initial, size_t pi, bfgs_target what,
+                            rdamd_schedule_t *sched, double p_min, double p_max,
+                            double epsilon, double pgtol, double factor) {
+  rdamd_partition_t *part = _partitions[pi];
+  const unsigned R = rdamd_partition_rate_cats(part);
+  int n = (int)initial.size();
+  // state of the partition that this optimiser does not vary
+  const double *cur_subst = rdamd_partition_subst_params(part, 0);
+  const double *cur_freqs = rdamd_partition_frequencies(part, 0);
+  const model_params_t base_subst(cur_subst, cur_subst + 12), base_freqs(cur_freqs, cur_freqs + 4);
+  const model_params_t base_rates(_rate_rates[pi]);
+
+  auto apply = [&](const model_params_t &x) {   // set_func of the reference
+    if (what == bfgs_target::rates) set_subst_rates(pi, x);
+    else if (what == bfgs_target::freqs) set_freqs_all_free(pi, x);
+    else set_gamma_rates(pi, x);
+  };
+  // -lnL for a list of parameter vectors, one fused launch
+  auto objective = [&](const std::vector<model_params_t> &xs) {
+    const size_t m = xs.size();
+    std::vector<const rdamd_schedule_t *> scheds(m, sched);
+    std::vector<double> subst(m * 12), freqs(m * 4), rates(m * R), weights(m * R), out(m);
+    for (size_t j = 0; j < m; ++j) {
+      model_params_t s = base_subst, f = base_freqs, r = base_rates;
+      if (what == bfgs_target::rates) s = xs[j];
+      else if (what == bfgs_target::freqs) {
+        f = xs[j];
+        double sum = 0.0;
+        for (auto v : f) sum += v;
+        for (auto &v : f) v /= sum;
+      } else if (_rate_category_types[pi] != rate_category::FREE) {
+        rdamd_compute_gamma_cats(xs[j][0], R, r.data(), RDAMD_GAMMA_RATES_MEDIAN);
+      }
+      std::copy(s.begin(), s.end(), subst.begin() + j * 12);
+      std::copy(f.begin(), f.end(), freqs.begin() + j * 4);
+      std::copy(r.begin(), r.end(), rates.begin() + j * R);
+      std::copy(_rate_weights[pi].begin(), _rate_weights[pi].end(), weights.begin() + j * R);
+    }
+    if (rdamd_evaluate_batch(part, (unsigned)m, scheds.data(), subst.data(), freqs.data(),
+                             rates.data(), weights.data(), out.data()) != RDAMD_SUCCESS)
+      fail("evaluate_batch");
+    _objective_batches += 1;
+    _objective_evals += m;
+    for (auto &v : out) {
+      if (std::isnan(v)) throw std::runtime_error("lh at root is not a number");
+      v = -v;
+    }
+    return out;
+  };
+
+  int task = 1 /* START */, csave = 0, iprint = -1, m_corr = 20;
+  double score = objective({initial})[0];
+  const double initial_score = score;
+  std::vector<double> gradient((size_t)n, 0.0);
+  std::vector<double> wa((2 * (size_t)m_corr + 5) * (size_t)n + 12 * (size_t)m_corr * ((size_t)m_corr + 1), 0.0);
+  std::vector<int> iwa(3 * (size_t)n, 0), bound_type((size_t)n, 2);
+  std::vector<double> x(initial), lo((size_t)n, p_min), hi((size_t)n, p_max);
+  int lsave[4] = {0, 0, 0, 0}, isave[44] = {0};
+  double dsave[29] = {0};
+  for (size_t iters = 0; iters < 500; ++iters) {
+    _setulb(&n, &m_corr, x.data(), lo.data(), hi.data(), bound_type.data(), &score,
+            gradient.data(), &factor, &pgtol, wa.data(), iwa.data(), &task, &iprint, &csave,
+            lsave, isave, dsave);
+    const bool fg = task >= 10 && task <= 15;   // IS_FG, lib/lbfgsb/lbfgsb.h:84-86
+    if (fg) {
+      std::vector<model_params_t> xs(1, x);
+      std::vector<double> h((size_t)n);
+      for (int i = 0; i < n; ++i) {
+        h[i] = std::max(epsilon * std::fabs(x[i]), epsilon);
+        xs.push_back(x);
+        xs.back()[i] += h[i];
+      }
+      auto f = objective(xs);
+      score = f[0];
+      for (int i = 0; i < n; ++i) gradient[i] = (f[i + 1] - score) / h[i];
+    } else {
+      score = objective({x})[0];   // the reference re-evaluates after every return
+      if (task != 2 /* NEW_X */) break;
+    }
+  }
+  score = objective({x})[0];
+  if (initial_score >= score) initial = x;   // improved (scores are -lnL)
+  apply(initial);
+  return score;
+}
+
+void model_t::optimize_params(std::vector<partition_parameters_t> &params,
+                              const root_location_t &rl, double pgtol, double factor,
+                              bool optimize_gamma) {
+  if (!_setulb)
+    throw std::runtime_error("optimize_params: no L-BFGS-B entry point set (set_lbfgsb)");
+  auto sc = _tree.generate_operations(rl);
+  for (size_t i = 0; i < _partitions.size(); ++i) {
+    if (rdamd_partition_states(_partitions[i]) != 4)
+      throw std::runtime_error("optimize_params: the batched objective handles 4-state data");
+    set_subst_rates(i, params[i].subst_rates);
+    set_freqs_all_free(i, params[i].freqs);
+    set_gamma_rates(i, params[i].gamma_alpha);
+    if (_rate_category_types[i] == rate_category::FREE) set_gamma_weights(i, params[i].gamma_weights);
+    rdamd_schedule_t *sched = rdamd_schedule_create(
+        _partitions[i], std::get<0>(sc).data(), (unsigned)std::get<0>(sc).size(),
+        std::get<1>(sc).data(), std::get<2>(sc).data(), (unsigned)std::get<1>(sc).size());
+    if (!sched) fail("schedule_create");
+    try {
+      bfgs_params(params[i].subst_rates, i, bfgs_target::rates, sched, 1e-4, 1e4, 1e-4, pgtol, factor);
+      bfgs_params(params[i].freqs, i, bfgs_target::freqs, sched, 1e-4, 1.0 - 1e-4 * 3, 1e-4, pgtol, factor);
+      if (optimize_gamma && !_rate_user_init[i] && _rate_category_types[i] != rate_category::FREE)
+        bfgs_params(params[i].gamma_alpha, i, bfgs_target::gamma, sched, 0.2, 10000.0, 1e-4, pgtol, factor);
+    } catch (...) {
+      rdamd_schedule_destroy(sched);
+      throw;
+    }
+    rdamd_schedule_destroy(sched);
+  }
+}
+
 // ---- exhaustive outer loop (src/model.cpp:1139-1272) ----------------------------------
 std::pair<root_location_t, double> model_t::exhaustive_search(double atol, double pgtol,
                                                               double brtol, double factor,
@@ -542,6 +664,7 @@ std::pair<root_location_t, double> model_t::exhaustive_search(double atol, doubl
     double cur_best_llh = -std::numeric_limits<double>::infinity();
     for (size_t iter = 0; iter < 1000; ++iter) {
       if (_optimizer) _optimizer(*this, params, rl, pgtol, factor, iter % 10 == 0);
+      else if (_setulb) optimize_params(params, rl, pgtol, factor, iter % 10 == 0);
       if (std::fabs(compute_lh(rl) - cur_best_llh) < atol) break;
       root_location_t cur_rl = optimize_alpha(rl, brtol);
       double cur_llh = compute_lh_root(cur_rl);

@@ -100,6 +100,22 @@ public:
                                                double factor, bool optimize_gamma)>;
   void set_param_optimizer(param_optimizer_t f) { _optimizer = std::move(f); }
 
+  // The caller's L-BFGS-B (the reference vendors lib/lbfgsb; its reverse-
+  // communication entry point setulb, lib/lbfgsb/lbfgsb.h:196-201).  Once set,
+  // optimize_params() drives it exactly as bfgs_params does
+  // (src/model.cpp:1430-1522), except that the objective and its n finite-
+  // difference perturbations are ONE batched device launch per iteration.
+  typedef int (*setulb_fn)(int *n, int *m, double *x, double *l, double *u, int *nbd, double *f,
+                           double *g, double *factr, double *pgtol, double *wa, int *iwa,
+                           int *task, int *iprint, int *csave, int *lsave, int *isave,
+                           double *dsave);
+  void set_lbfgsb(setulb_fn fn) { _setulb = fn; }
+  // src/model.cpp:1925-1984
+  void optimize_params(std::vector<partition_parameters_t> &params, const root_location_t &rl,
+                       double pgtol, double factor, bool optimize_gamma);
+  size_t objective_batches() const { return _objective_batches; }
+  size_t objective_evaluations() const { return _objective_evals; }
+
   // src/model.cpp:1139-1272; results (one per assigned root) are returned
   // instead of going through the checkpoint file.
   std::pair<root_location_t, double> exhaustive_search(double atol, double pgtol, double brtol,
@@ -157,6 +173,13 @@ private:
   bool                                   _invariant_sites, _early_stop;   // +I is inert (:292-300)
   uint64_t                               _seed;
   param_optimizer_t                      _optimizer;
+  setulb_fn                              _setulb = nullptr;
+  size_t                                 _objective_batches = 0, _objective_evals = 0;
+
+  enum class bfgs_target { rates, freqs, gamma };
+  double bfgs_params(model_params_t &initial, size_t partition, bfgs_target what,
+                     rdamd_schedule_t *sched, double p_min, double p_max, double epsilon,
+                     double pgtol, double factor);
 };
 
 }  // namespace rdamd

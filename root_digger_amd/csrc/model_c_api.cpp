@@ -141,6 +141,29 @@ int rdamd_model_compute_lh_batch(rdamd_model_t *m, unsigned int n,
     return RDAMD_SUCCESS;
   })
 }
+void rdamd_model_set_lbfgsb(rdamd_model_t *m, void *fn) {
+  m->model->set_lbfgsb(reinterpret_cast<rdamd::model_t::setulb_fn>(fn));
+}
+int rdamd_model_optimize_params(rdamd_model_t *m, const rdamd_root_location_t *rl, double pgtol,
+                                double factor, int optimize_gamma, double *subst, double *freqs,
+                                double *gamma_alpha, uint64_t *n_batches,
+                                uint64_t *n_evaluations) {
+  GUARD(RDAMD_FAILURE, {
+    const unsigned k = m->msa.states;
+    std::vector<rdamd::partition_parameters_t> params(1);
+    params[0].subst_rates.assign(subst, subst + k * k - k);
+    params[0].freqs.assign(freqs, freqs + k);
+    params[0].gamma_alpha.assign(1, *gamma_alpha);
+    const size_t b0 = m->model->objective_batches(), e0 = m->model->objective_evaluations();
+    m->model->optimize_params(params, to_cpp(rl), pgtol, factor, optimize_gamma != 0);
+    std::copy(params[0].subst_rates.begin(), params[0].subst_rates.end(), subst);
+    std::copy(params[0].freqs.begin(), params[0].freqs.end(), freqs);
+    *gamma_alpha = params[0].gamma_alpha[0];
+    if (n_batches) *n_batches = m->model->objective_batches() - b0;
+    if (n_evaluations) *n_evaluations = m->model->objective_evaluations() - e0;
+    return RDAMD_SUCCESS;
+  })
+}
 int rdamd_model_assign_by_rank(rdamd_model_t *m, unsigned int rank, unsigned int num_tasks) {
   GUARD(RDAMD_FAILURE, {
     m->model->assign_indicies_by_rank_exhaustive(rank, num_tasks);

@@ -1,0 +1,143 @@
+"""Parameter optimisation on the batched objective: the reference's own
+L-BFGS-B (lib/lbfgsb, compiled from /root/reference into oracle/_ref/ by
+`make -C oracle ref`; test infrastructure) drives model_t::optimize_params
+through its reverse-communication interface, exactly as bfgs_params does
+(src/model.cpp:1430-1522), with each objective + finite-difference gradient as
+one fused launch.  The same procedure is replayed on the CPU oracle."""
+import ctypes as C
+import math
+import os
+
+import numpy as np
+import pytest
+
+import root_digger_amd as rd
+from oracle_lib import OraclePartition, ORC_MAP_NT
+import util
+
+pytestmark = pytest.mark.gpu
+
+REF = os.path.join(util.ROOT, "oracle", "_ref", "liblbfgsb_ref.so")
+
+
+@pytest.fixture(scope="module")
+def lbfgsb():
+    if not os.path.exists(REF):
+        pytest.skip("oracle/_ref/liblbfgsb_ref.so not built (needs /root/reference at build time)")
+    return C.CDLL(REF)
+
+
+def bfgs_on(objective, x0, lo, hi, eps, pgtol, factor, setulb):
+    """bfgs_params (src/model.cpp:1430-1522) with a Python objective (-lnL)."""
+    n = len(x0)
+    m = 20
+    x = np.array(x0, dtype=np.float64)
+    l = np.full(n, lo)
+    u = np.full(n, hi)
+    nbd = np.full(n, 2, dtype=np.int32)
+    g = np.zeros(n)
+    wa = np.zeros((2 * m + 5) * n + 12 * m * (m + 1))
+    iwa = np.zeros(3 * n, dtype=np.int32)
+    task, csave, iprint = C.c_int(1), C.c_int(0), C.c_int(-1)
+    lsave = (C.c_int * 4)()
+    isave = (C.c_int * 44)()
+    dsave = (C.c_double * 29)()
+    f = C.c_double(objective(x))
+    initial = f.value
+    nn, mm = C.c_int(n), C.c_int(m)
+    fac, pg = C.c_double(factor), C.c_double(pgtol)
+    P = lambda a, t: a.ctypes.data_as(C.POINTER(t))
+    for _ in range(500):
+        setulb(C.byref(nn), C.byref(mm), P(x, C.c_double), P(l, C.c_double), P(u, C.c_double),
+               P(nbd, C.c_int), C.byref(f), P(g, C.c_double), C.byref(fac), C.byref(pg),
+               P(wa, C.c_double), P(iwa, C.c_int), C.byref(task), C.byref(iprint), C.byref(csave),
+               lsave, isave, dsave)
+        f.value = objective(x)
+        if 10 <= task.value <= 15:
+            for i in range(n):
+                h = max(eps * abs(x[i]), eps)
+                xi = x.copy()
+                xi[i] += h
+                g[i] = (objective(xi) - f.value) / h
+        elif task.value != 2:
+            break
+    final = objective(x)
+    return (x, final) if initial >= final else (np.array(x0, dtype=np.float64), final)
+
+
+def test_optimize_params_with_reference_lbfgsb(lbfgsb):
+    tree = rd.Tree.from_file(os.path.join(util.DATA, "10.tree"))
+    seqs = util.read_fasta(os.path.join(util.DATA, "10.fasta"))
+    R = 4
+    m = rd.Model(tree, seqs, rate_cats=R, seed=5)
+    m.initialize_partitions()
+    m.set_lbfgsb(lbfgsb.setulb)
+    rl = tree.root_location(3)
+    subst0, freqs0 = [1.0 / 12] * 12, [0.25] * 4
+    m.set_subst_rates(subst0)
+    m.set_freqs(freqs0)
+    m.set_gamma_alpha(1.0)
+    before = m.compute_lh(rl)
+    res = m.optimize_params(rl, subst0, freqs0, 1.0, pgtol=1e-5, factor=1e7)
+    m.set_subst_rates(res["subst"])
+    m.set_freqs(np.array(res["freqs"]) / np.sum(res["freqs"]))
+    m.set_gamma_alpha(res["gamma_alpha"])
+    after = m.compute_lh(rl)
+    assert after > before + 10.0                      # a real improvement on real data
+    assert res["evaluations"] > 3 * res["batches"]    # the gradients ride in the batches
+
+    # the same three optimisations on the CPU oracle, same optimiser
+    o = OraclePartition.for_tree(tree, 4, 1000, R)
+    util.load_tips(o, tree, seqs, ORC_MAP_NT)
+    t2 = rd.Tree.from_file(os.path.join(util.DATA, "10.tree"))
+    ops, pmi, brl = t2.generate_operations(rl)
+    state = {"subst": np.array(subst0), "freqs": np.array(freqs0), "alpha": 1.0}
+
+    def lnl():
+        o.set_subst_params(0, state["subst"])
+        o.set_frequencies(0, state["freqs"] / state["freqs"].sum())
+        o.set_category_rates(rd.compute_gamma_cats(state["alpha"], R, rd.GAMMA_RATES_MEDIAN))
+        o.update_prob_matrices(pmi, brl)
+        o.update_clvs(ops)
+        return o.compute_root_loglikelihood(t2.root_clv_index(), t2.root_scaler_index())
+
+    def obj(key):
+        def f(x):
+            old = state[key]
+            state[key] = np.array(x) if key != "alpha" else float(x[0])
+            v = -lnl()
+            state[key] = old
+            return v
+        return f
+
+    x, _ = bfgs_on(obj("subst"), state["subst"], 1e-4, 1e4, 1e-4, 1e-5, 1e7, lbfgsb.setulb)
+    state["subst"] = x
+    x, _ = bfgs_on(obj("freqs"), state["freqs"], 1e-4, 1 - 3e-4, 1e-4, 1e-5, 1e7, lbfgsb.setulb)
+    state["freqs"] = x
+    x, _ = bfgs_on(obj("alpha"), [state["alpha"]], 0.2, 1e4, 1e-4, 1e-5, 1e7, lbfgsb.setulb)
+    state["alpha"] = float(x[0])
+    cpu_after = lnl()
+    # optimiser trajectories are sensitive to the last bits; the optimum is not
+    assert abs(after - cpu_after) < 1e-4 * abs(cpu_after)
+    assert np.allclose(res["subst"] / np.sum(res["subst"]), state["subst"] / state["subst"].sum(),
+                       rtol=5e-2, atol=5e-3)
+
+
+def test_exhaustive_search_with_parameter_optimisation(lbfgsb):
+    """The full per-candidate loop of src/model.cpp:1139-1272 (optimize_params,
+    optimize_alpha, stopping rules) on the reference's 10.fasta fixture."""
+    tree = rd.Tree.from_file(os.path.join(util.DATA, "10.tree"))
+    seqs = util.read_fasta(os.path.join(util.DATA, "10.fasta"))
+    m = rd.Model(tree, seqs, rate_cats=1, seed=9, early_stop=True)
+    m.initialize_partitions()
+    m.compute_lh(tree.root_location(0))
+    plain = m.exhaustive_search(1e-3, 1e-3, 1e-3, 1e12)
+    m.set_lbfgsb(lbfgsb.setulb)
+    opt = m.exhaustive_search(1e-3, 1e-3, 1e-3, 1e12)     # tolerances of test/src/model.cpp:400
+    assert sorted(opt["root_id"]) == list(range(17))
+    assert np.all(np.isfinite(opt["llh"]))
+    # optimised parameters can only improve each candidate's likelihood
+    by_id = dict(zip(plain["root_id"], plain["llh"]))
+    for rid, llh in zip(opt["root_id"], opt["llh"]):
+        assert llh >= by_id[rid] - 1e-6
+    assert opt["best_llh"] > plain["best_llh"]
