@@ -308,6 +308,19 @@ rdamd_model_t *rdamd_model_create(const rdamd_tree_t *tree, unsigned int n_taxa,
                                   const unsigned int *weights, unsigned int states,
                                   const uint64_t *map, unsigned int rate_cats,
                                   uint64_t seed, int early_stop);
+/* Same, reading the alignment from a PHYLIP / FASTA file with site-pattern
+ * compression (msa_t(filename), src/msa.hpp:23-37).  *n_patterns (may be NULL)
+ * receives the compressed length. */
+rdamd_model_t *rdamd_model_create_from_file(const rdamd_tree_t *tree, const char *msa_filename,
+                                            unsigned int states, const uint64_t *map,
+                                            unsigned int rate_cats, uint64_t seed,
+                                            int early_stop, int compress,
+                                            unsigned int *n_patterns);
+/* Parses an alignment file the way msa_t(filename) does and reports its shape
+ * (host only; no GPU needed). */
+int rdamd_msa_probe(const char *msa_filename, const uint64_t *map, int compress,
+                    unsigned int *n_taxa, unsigned int *n_patterns,
+                    unsigned int *total_weight);
 void rdamd_model_destroy(rdamd_model_t *m);
 /* initialize_partitions / initialize_partitions_uniform_freqs, :1297-1321 */
 int rdamd_model_initialize_partitions(rdamd_model_t *m, int uniform_freqs);

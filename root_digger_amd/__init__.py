@@ -22,10 +22,11 @@ from .api import (  # noqa: F401
     GAMMA_RATES_MEDIAN,
     device_count,
     set_device,
+    msa_probe,
 )
 
 __all__ = [
     "lib", "lib_path", "RdamdError", "Operation", "RootLocation", "Tree", "Partition", "Schedule", "Model",
     "MAP_NT", "MAP_BIN", "compute_gamma_cats", "GAMMA_RATES_MEAN", "GAMMA_RATES_MEDIAN",
-    "device_count", "set_device",
+    "device_count", "set_device", "msa_probe",
 ]

@@ -121,6 +121,9 @@ _sig("rdamd_tree_annotate_branch", C.c_int, _vp, _prl, C.c_char_p, C.c_char_p)
 
 _sig("rdamd_model_create", _vp, _vp, _u, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), _pu, _u,
      C.POINTER(C.c_uint64), _u, C.c_uint64, C.c_int)
+_sig("rdamd_model_create_from_file", _vp, _vp, C.c_char_p, _u, C.POINTER(C.c_uint64), _u,
+     C.c_uint64, C.c_int, C.c_int, _pu)
+_sig("rdamd_msa_probe", C.c_int, C.c_char_p, C.POINTER(C.c_uint64), C.c_int, _pu, _pu, _pu)
 _sig("rdamd_model_destroy", None, _vp)
 _sig("rdamd_model_initialize_partitions", C.c_int, _vp, C.c_int)
 _sig("rdamd_model_set_subst_rates", C.c_int, _vp, _pd)
@@ -169,6 +172,15 @@ def device_count():
 def set_device(device):
     if lib.rdamd_set_device(int(device)) != 1:
         _fail("set_device")
+
+
+def msa_probe(path, cmap=None, compress=True):
+    """(taxa, patterns, total weight) of an alignment file (msa_t(filename))."""
+    a, b, c = C.c_uint(0), C.c_uint(0), C.c_uint(0)
+    if lib.rdamd_msa_probe(str(path).encode(), cmap if cmap is not None else MAP_NT,
+                           1 if compress else 0, C.byref(a), C.byref(b), C.byref(c)) != 1:
+        _fail("msa_probe")
+    return a.value, b.value, c.value
 
 
 def compute_gamma_cats(alpha, cats, mode=GAMMA_RATES_MEAN):
@@ -547,6 +559,21 @@ class Model:
                                          seed, 1 if early_stop else 0)
         if not self._h:
             _fail("model_create")
+
+    @classmethod
+    def from_file(cls, tree, msa_path, states=4, cmap=None, rate_cats=1, seed=1,
+                  early_stop=False, compress=True):
+        """model_t over msa_t(filename): PHYLIP / FASTA ingest + pattern compression."""
+        self = cls.__new__(cls)
+        self._tree, self.states = tree, states
+        n = C.c_uint(0)
+        self._h = lib.rdamd_model_create_from_file(
+            tree._h, str(msa_path).encode(), states, cmap if cmap is not None else MAP_NT,
+            rate_cats, seed, 1 if early_stop else 0, 1 if compress else 0, C.byref(n))
+        if not self._h:
+            _fail("model_create_from_file")
+        self.patterns = n.value
+        return self
 
     def destroy(self):
         if getattr(self, "_h", None):

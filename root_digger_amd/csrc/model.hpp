@@ -15,6 +15,7 @@
 #include <random>
 #include <stdexcept>
 #include <string>
+#include <unordered_set>
 #include <utility>
 #include <vector>
 
@@ -51,8 +52,8 @@ struct rd_result_t {   // src/util.hpp:126-130
   double alpha;
 };
 
-// In-memory alignment (one partition).  File parsing and pattern compression
-// (src/msa.cpp) are a later row of SURVEY 8f; callers hand over sequences.
+// Alignment of one partition (src/msa.hpp:21-68): in memory, or read from a
+// PHYLIP / FASTA file with optional site-pattern compression (msa.cpp).
 struct msa_t {
   std::vector<std::string>  labels, sequences;
   std::vector<unsigned int> weights;        // pattern weights; empty = all 1
@@ -61,6 +62,12 @@ struct msa_t {
   size_t length() const { return sequences.empty() ? 0 : sequences[0].size(); }
   int    count() const { return (int)sequences.size(); }
   unsigned int total_weight() const;
+
+  static msa_t from_file(const std::string &filename, const uint64_t *map = nullptr,
+                         unsigned int states = 4, bool compress_patterns = true);
+  void compress();                                                    // src/msa.cpp:621-633
+  bool constiency_check(const std::unordered_set<std::string> &tree_labels) const;   // :641-668
+  void valid_data() const;                                            // :670-686
 };
 
 model_params_t random_params(size_t size, uint64_t seed);   // src/model.cpp:87-93

@@ -63,6 +63,39 @@ rdamd_model_t *rdamd_model_create(const rdamd_tree_t *tree, unsigned int n_taxa,
     return m;
   })
 }
+rdamd_model_t *rdamd_model_create_from_file(const rdamd_tree_t *tree, const char *msa_filename,
+                                            unsigned int states, const uint64_t *map,
+                                            unsigned int rate_cats, uint64_t seed,
+                                            int early_stop, int compress,
+                                            unsigned int *n_patterns) {
+  GUARD(nullptr, {
+    auto *m = new rdamd_model();
+    try {
+      m->msa = rdamd::msa_t::from_file(msa_filename, map, states, compress != 0);
+      if (!m->msa.constiency_check(rdamd_tree_cpp(tree).label_set()))
+        throw std::invalid_argument("Taxa on the tree and in the MSA are inconsistient");
+      m->model = new rdamd::model_t(rdamd_tree_cpp(tree), {m->msa},
+                                    {rdamd::ratehet_opts_t(rate_cats)}, false, seed,
+                                    early_stop != 0);
+    } catch (...) {
+      delete m;
+      throw;
+    }
+    if (n_patterns) *n_patterns = (unsigned)m->msa.length();
+    return m;
+  })
+}
+int rdamd_msa_probe(const char *msa_filename, const uint64_t *map, int compress,
+                    unsigned int *n_taxa, unsigned int *n_patterns,
+                    unsigned int *total_weight) {
+  GUARD(RDAMD_FAILURE, {
+    rdamd::msa_t m = rdamd::msa_t::from_file(msa_filename, map, 4, compress != 0);
+    if (n_taxa) *n_taxa = (unsigned)m.count();
+    if (n_patterns) *n_patterns = (unsigned)m.length();
+    if (total_weight) *total_weight = m.total_weight();
+    return RDAMD_SUCCESS;
+  })
+}
 void rdamd_model_destroy(rdamd_model_t *m) { delete m; }
 
 int rdamd_model_initialize_partitions(rdamd_model_t *m, int uniform_freqs) {

@@ -143,3 +143,45 @@ def test_exhaustive_search_runs_and_ranks_roots():       # test/src/model.cpp:38
         m.assign_by_rank(rank, 3)
         seen += m.exhaustive_search(1e-3, 1e-3, 1e-3, 1e12)["root_id"]
     assert sorted(seen) == list(range(17))
+
+
+def test_msa_ingest_and_pattern_compression():
+    """msa_t(filename) (src/msa.hpp:23-37): FASTA and PHYLIP fixtures of the
+    reference, compressed vs uncompressed lnL identical."""
+    tree = rd.Tree.from_file(os.path.join(util.DATA, "10.tree"))
+    fasta = os.path.join(util.DATA, "10.fasta")
+    mc = rd.Model.from_file(tree, fasta, rate_cats=4, seed=2, compress=True)
+    mu = rd.Model.from_file(tree, fasta, rate_cats=4, seed=2, compress=False)
+    assert mc.patterns == 991 and mu.patterns == 1000      # SURVEY 2.1: 991 patterns
+    for m in (mc, mu):
+        m.initialize_partitions()
+        m.set_subst_rates(PARAMS3)
+    for i in (0, 9, 16):
+        rl = tree.root_location(i)
+        assert util.rel_err(mc.compute_lh(rl), mu.compute_lh(rl)) < 1e-12
+    # against the Python-side reader used by the other tests
+    mp = rd.Model(tree, util.read_fasta(fasta), rate_cats=4, seed=2)
+    mp.initialize_partitions()
+    mp.set_subst_rates(PARAMS3)
+    assert util.rel_err(mp.compute_lh(tree.root_location(4)), mu.compute_lh(tree.root_location(4))) < 1e-13
+    # PHYLIP with ambiguity codes
+    t101 = rd.Tree.from_file(os.path.join(util.DATA, "101.tree"))
+    m101 = rd.Model.from_file(t101, os.path.join(util.DATA, "101.phy"), rate_cats=1, seed=2)
+    seqs, w = util.compress(util.read_phylip(os.path.join(util.DATA, "101.phy")))
+    assert m101.patterns <= len(w)          # merging N/X/-/? can only fuse more columns
+    m101.initialize_partitions()
+    m101.set_subst_rates([1.0] * 12)
+    m101.set_freqs([0.25] * 4)
+    ref = rd.Model(t101, seqs, rate_cats=1, weights=w, seed=2)
+    ref.initialize_partitions()
+    ref.set_subst_rates([1.0] * 12)
+    ref.set_freqs([0.25] * 4)
+    rl = t101.root_location(7)
+    assert util.rel_err(m101.compute_lh(rl), ref.compute_lh(rl)) < 1e-12
+    single = rd.Tree.from_file(os.path.join(util.DATA, "single.tree"))
+    ms = rd.Model.from_file(single, os.path.join(util.DATA, "single.phy"))
+    assert ms.patterns == 1
+    with pytest.raises(rd.RdamdError):
+        rd.Model.from_file(tree, os.path.join(util.DATA, "101.phy"))     # taxa mismatch
+    with pytest.raises(rd.RdamdError):
+        rd.Model.from_file(tree, "/nonexistent.fasta")

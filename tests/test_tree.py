@@ -203,3 +203,13 @@ def test_bad_inputs():
         tree.root_location(99)
     with pytest.raises(rd.RdamdError):
         tree.root_location("nope")
+
+
+def test_msa_ingest_shapes():                  # test/src/msa.cpp:8-15 + SURVEY 2.1 fixture facts
+    assert rd.msa_probe(os.path.join(util.DATA, "10.fasta")) == (10, 991, 1000)
+    assert rd.msa_probe(os.path.join(util.DATA, "10.fasta"), compress=False) == (10, 1000, 1000)
+    assert rd.msa_probe(os.path.join(util.DATA, "single.phy")) == (4, 1, 1)
+    taxa, patterns, total = rd.msa_probe(os.path.join(util.DATA, "101.phy"))
+    assert (taxa, total) == (101, 1858) and patterns <= 1858
+    with pytest.raises(rd.RdamdError):
+        rd.msa_probe(os.path.join(util.DATA, "10.tree"))
