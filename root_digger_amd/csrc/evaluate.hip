@@ -126,7 +126,11 @@ struct Compiler {
       spill = live ? 1 : 0;
       tipX_row = o.child1_clv_index; matX = o.child1_matrix_index;
       tipY_row = o.child2_clv_index; matY = o.child2_matrix_index;
-      if (live) { ++depth; max_depth = std::max(max_depth, depth); }
+      if (live) {
+        if (depth == 0) spill |= 2;   // level 0 is a register slot in the kernel
+        ++depth;
+        max_depth = std::max(max_depth, depth);
+      }
     } else if (i1 != i2) {
       const bool first_inner = i1;
       emit(producer.at(first_inner ? o.child1_clv_index : o.child2_clv_index), live);
@@ -144,6 +148,7 @@ struct Compiler {
       matX = a_first ? o.child2_matrix_index : o.child1_matrix_index;
       matY = a_first ? o.child1_matrix_index : o.child2_matrix_index;
       --depth;
+      if (depth == 0) spill |= 4;     // the popped sibling sits in the register slot
     }
     f.pX = matX * rate_cats * 128u;
     f.pY = matY * rate_cats * 128u;
@@ -217,7 +222,8 @@ rdamd_schedule_t *rdamd_schedule_create(rdamd_partition_t *p, const rdamd_operat
     brlen[matrix_indices[m]] = branch_lengths[m];
   }
   rdamd_schedule *s = new rdamd_schedule();
-  s->part = p; s->n_ops = n_ops; s->depth = std::max(1u, c.max_depth);
+  // LDS levels = stack depth minus the register level (at least one is allocated)
+  s->part = p; s->n_ops = n_ops; s->depth = std::max(1u, c.max_depth > 0 ? c.max_depth - 1 : 0);
   s->prog = c.out;
   // harmless tail entries: the kernel prefetches descriptors up to i + 3
   for (int k = 0; k < 4; ++k) c.out.push_back(c.out.back());

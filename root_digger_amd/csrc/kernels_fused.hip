@@ -8,8 +8,8 @@
 //
 // Mapping: one wave = 64 site patterns, one lane = one site.  A lane walks the
 // traversal once per rate category; the running CLV (4 doubles) lives in
-// registers, pending sibling CLVs on a per-wave LDS stack whose depth the host
-// minimises (Sethi-Ullman order).  Because the rate is wave-uniform, the 4x4
+// registers, pending sibling CLVs on a stack whose depth the host minimises
+// (Sethi-Ullman order): level 0 in registers, deeper levels in per-wave LDS.  Because the rate is wave-uniform, the 4x4
 // P-matrix of an inner operand is a set of scalar (SGPR) operands of the FMAs:
 // no LDS or VGPR traffic for it.  A tip operand costs no FMA at all: its 16x4
 // table (one row per ambiguity code, built next to the P-matrices) is exactly
@@ -167,13 +167,20 @@ fused_dna_eval_kernel(FusedArgs a) {
     _Pragma("unroll") for (int q = 0; q < NS; ++q) { rowx[q] = tabx + cx[q] * 4; rowy[q] = taby + cy[q] * 4; } \
     double tx[NS][4], ty[NS][4];                                                                \
     if (kind & 0x100u) { /* cherry that must park the running CLV first */                      \
-      _Pragma("unroll") for (int q = 0; q < NS; ++q) {                                          \
-        double2 *d = stk + (size_t)(sp * NS + q) * 128;                                         \
-        d[0] = make_double2(st.v[q][0], st.v[q][1]);                                            \
-        d[64] = make_double2(st.v[q][2], st.v[q][3]);                                           \
-        stk_sc[(sp * NS + q) * 64] = st.sc[q];                                                  \
+      if (kind & 0x200u) { /* stack level 0 lives in registers */                               \
+        _Pragma("unroll") for (int q = 0; q < NS; ++q) {                                        \
+          _Pragma("unroll") for (int k = 0; k < 4; ++k) s0[q][k] = st.v[q][k];                  \
+          s0sc[q] = st.sc[q];                                                                   \
+        }                                                                                       \
+      } else {                                                                                  \
+        _Pragma("unroll") for (int q = 0; q < NS; ++q) {                                        \
+          double2 *d = stk + (size_t)(sp * NS + q) * 128;                                       \
+          d[0] = make_double2(st.v[q][0], st.v[q][1]);                                          \
+          d[64] = make_double2(st.v[q][2], st.v[q][3]);                                         \
+          stk_sc[(sp * NS + q) * 64] = st.sc[q];                                                \
+        }                                                                                       \
+        ++sp;                                                                                   \
       }                                                                                         \
-      ++sp;                                                                                     \
     }                                                                                           \
     const unsigned k3 = kind & 3u;                                                              \
     if (k3 == kFusedTT) {                                                                       \
@@ -189,14 +196,21 @@ fused_dna_eval_kernel(FusedArgs a) {
       _Pragma("unroll") for (int q = 0; q < NS; ++q) matvec(px, st.v[q], tx[q]);                \
       _Pragma("unroll") for (int q = 0; q < NS; ++q) combine(tx[q], ty[q], st.v[q], st.sc[q]);  \
     } else { /* kFusedRP: X = running CLV, Y = popped sibling */                                \
-      --sp;                                                                                     \
       double y[NS][4];                                                                          \
       int scy[NS];                                                                              \
-      _Pragma("unroll") for (int q = 0; q < NS; ++q) {                                          \
-        const double2 *d = stk + (size_t)(sp * NS + q) * 128;                                   \
-        const double2 lo = d[0], hi = d[64];                                                    \
-        y[q][0] = lo.x; y[q][1] = lo.y; y[q][2] = hi.x; y[q][3] = hi.y;                         \
-        scy[q] = stk_sc[(sp * NS + q) * 64];                                                    \
+      if (kind & 0x400u) { /* the sibling was parked in the register level */                   \
+        _Pragma("unroll") for (int q = 0; q < NS; ++q) {                                        \
+          _Pragma("unroll") for (int k = 0; k < 4; ++k) y[q][k] = s0[q][k];                     \
+          scy[q] = s0sc[q];                                                                     \
+        }                                                                                       \
+      } else {                                                                                  \
+        --sp;                                                                                   \
+        _Pragma("unroll") for (int q = 0; q < NS; ++q) {                                        \
+          const double2 *d = stk + (size_t)(sp * NS + q) * 128;                                 \
+          const double2 lo = d[0], hi = d[64];                                                  \
+          y[q][0] = lo.x; y[q][1] = lo.y; y[q][2] = hi.x; y[q][3] = hi.y;                       \
+          scy[q] = stk_sc[(sp * NS + q) * 64];                                                  \
+        }                                                                                       \
       }                                                                                         \
       RDAMD_LOAD_TIPS(nxt, ncx, ncy, nex, ney)                                                  \
       _Pragma("unroll") for (int q = 0; q < NS; ++q) matvec(px, st.v[q], tx[q]);                \
@@ -205,6 +219,14 @@ fused_dna_eval_kernel(FusedArgs a) {
     }                                                                                           \
   }
 
+    double s0[NS][4];   // stack level 0 (the most frequently used) stays in registers
+    int s0sc[NS];
+#pragma unroll
+    for (int q = 0; q < NS; ++q) {
+      s0sc[q] = 0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) s0[q][k] = 0.0;
+    }
     FusedOp dA = prog[0];
     FusedOp dB = prog[1];
     unsigned cxA[NS], cyA[NS], cxB[NS], cyB[NS];
