@@ -477,3 +477,57 @@ def test_protein_mfma_rescaling_and_ragged_tiles(R, S):
         util.move_root(g, tree, r2)
         util.move_root(o, t2, r2)
         assert util.rel_err(util.compute_lh_root(g, tree, r2), util.compute_lh_root(o, t2, r2)) < LNL_TOL
+
+
+# ---------------------------------------------------------------------------
+# edge cases: smallest tree, all-gap columns, empty calls, a 1000-taxon tree
+# ---------------------------------------------------------------------------
+def test_three_taxon_tree_and_all_gap_columns():
+    tree = rd.Tree.from_newick("(a:0.1,b:0.2,c:0.3);")
+    assert tree.root_count() == 3
+    seqs = {"a": "AC-N?", "b": "AG-NX", "c": "TT-N-"}      # columns 2..4 carry no data
+    g, o = pair(tree, seqs, 4, 4)
+    set_model((g, o), PARAMS[1], [0.1, 0.2, 0.3, 0.4], rd.compute_gamma_cats(0.8, 4))
+    for rl in tree.roots():
+        rl = rl.with_ratio(0.25)
+        a, b = util.compute_lh(g, tree, rl), util.compute_lh(o, tree, rl)
+        assert util.rel_err(a, b) < LNL_TOL
+        _, ps = g.compute_root_loglikelihood(tree.root_clv_index(), tree.root_scaler_index(),
+                                             persite=True)
+        assert np.allclose(ps[2:], 0.0, atol=1e-14)         # an all-gap site has likelihood 1
+        sched = g.schedule(*tree.generate_operations(rl))
+        f = g.evaluate_batch([sched], [PARAMS[1]], [[0.1, 0.2, 0.3, 0.4]])[0]
+        assert util.rel_err(f, b) < LNL_TOL
+
+
+def test_empty_calls_are_no_ops():
+    tree = rd.Tree.from_file(os.path.join(util.DATA, "single.tree"))
+    g = rd.Partition.for_tree(tree, 4, 3, 1)
+    g.update_prob_matrices([], [])
+    g.update_clvs([])
+    assert len(g.evaluate_batch([], np.zeros((0, 12)), np.zeros((0, 4)))) == 0
+
+
+def test_thousand_taxon_tree_vs_oracle():
+    """BASELINE config c5's tree size (1000 taxa, 1997 candidate roots) at an
+    oracle-sized site count: deep stacks in the fused kernel, long operation
+    lists in the traversal kernel."""
+    w = synth.workload(1000, 1200, 4, 4, 71)
+    tree = rd.Tree.from_newick(w["newick"])
+    assert tree.root_count() == 1997
+    g, o = pair(tree, w["seqs"], 4, 4)
+    freqs = g.empirical_frequencies()
+    set_model((g, o), w["subst"], freqs, w["rates"])
+    rng = np.random.default_rng(71)
+    rls = [tree.root_location(int(i)).with_ratio(float(a))
+           for i, a in zip(rng.choice(1997, 3, replace=False), rng.uniform(0.1, 0.9, 3))]
+    want = [util.compute_lh(o, tree, rl) for rl in rls]
+    got = [util.compute_lh(g, tree, rl) for rl in rls]
+    scheds = [g.schedule(*tree.generate_operations(rl)) for rl in rls]
+    fused = g.evaluate_batch(scheds, [w["subst"]] * 3, [freqs] * 3)
+    for a, b, c in zip(got, want, fused):
+        assert util.rel_err(a, b) < LNL_TOL
+        assert util.rel_err(c, b) < LNL_TOL
+    assert max(s.stack_depth() for s in scheds) <= 10
+    ops, _, _ = tree.generate_operations(rls[2])
+    compare_state(g, o, [ops[i] for i in (0, 500, 998)], tree)
