@@ -291,6 +291,10 @@ int  rdamd_tree_sanity_check(const rdamd_tree_t *t);                       /* :5
 char *rdamd_tree_newick(const rdamd_tree_t *t, int annotations);
 int   rdamd_tree_annotate_branch(rdamd_tree_t *t, const rdamd_root_location_t *rl,
                                  const char *key, const char *value); /* :731 */
+/* annotate_branch(rl, key, left_value, right_value), src/tree.cpp:737-760 */
+int   rdamd_tree_annotate_branch_lr(rdamd_tree_t *t, const rdamd_root_location_t *rl,
+                                    const char *key, const char *left_value,
+                                    const char *right_value);
 
 /* ------------------------------------------------------------------------
  * Host-side likelihood facade: model_t (src/model.hpp:47-277)

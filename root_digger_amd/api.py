@@ -118,6 +118,7 @@ _sig("rdamd_tree_rooted", C.c_int, _vp)
 _sig("rdamd_tree_sanity_check", C.c_int, _vp)
 _sig("rdamd_tree_newick", _vp, _vp, C.c_int)
 _sig("rdamd_tree_annotate_branch", C.c_int, _vp, _prl, C.c_char_p, C.c_char_p)
+_sig("rdamd_tree_annotate_branch_lr", C.c_int, _vp, _prl, C.c_char_p, C.c_char_p, C.c_char_p)
 
 _sig("rdamd_model_create", _vp, _vp, _u, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), _pu, _u,
      C.POINTER(C.c_uint64), _u, C.c_uint64, C.c_int)
@@ -313,9 +314,10 @@ class Tree:
     def newick(self, annotations=True):
         return _take_string(lib.rdamd_tree_newick(self._h, 1 if annotations else 0))
 
-    def annotate_branch(self, rl, key, value):
-        if lib.rdamd_tree_annotate_branch(self._h, C.byref(rl), key.encode(),
-                                          value.encode()) != 1:
+    def annotate_branch(self, rl, key, value, right_value=None):
+        right = value if right_value is None else right_value
+        if lib.rdamd_tree_annotate_branch_lr(self._h, C.byref(rl), key.encode(),
+                                             value.encode(), right.encode()) != 1:
             _fail("annotate_branch")
 
 

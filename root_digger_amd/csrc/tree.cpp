@@ -529,7 +529,7 @@ std::string rooted_tree_t::newick(bool annotations) const {
 
 // src/tree.cpp:731-760
 void rooted_tree_t::annotate_branch(const root_location_t &rl, const std::string &key,
-                                    const std::string &value) {
+                                    const std::string &value, const std::string &right_value) {
   _annotations[rl.edge].emplace_back(key, value);
   int other = _back[rl.edge];
   size_t ring = 1;
@@ -538,8 +538,8 @@ void rooted_tree_t::annotate_branch(const root_location_t &rl, const std::string
     int c = other;
     do { ++ring; c = _next[c]; } while (c != other);
   }
-  if (ring > 2) _annotations[other].emplace_back(key, value);
-  else _annotations[_back[_next[other]]].emplace_back(key, value);
+  if (ring > 2) _annotations[other].emplace_back(key, right_value);
+  else _annotations[_back[_next[other]]].emplace_back(key, right_value);
 }
 
 std::vector<std::string> rooted_tree_t::side_tips(const root_location_t &rl) const {

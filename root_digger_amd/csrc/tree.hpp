@@ -84,7 +84,14 @@ public:
 
   std::string newick(bool annotations = true) const;   // src/tree.cpp:443-492
   void annotate_branch(const root_location_t &rl, const std::string &key,
-                       const std::string &value);
+                       const std::string &value) { annotate_branch(rl, key, value, value); }
+  void annotate_branch(const root_location_t &rl, const std::string &key,
+                       const std::string &left_value, const std::string &right_value);
+  // src/tree.cpp:709-726
+  void annotate_lh(const root_location_t &rl, double lh) { annotate_branch(rl, "LLH", std::to_string(lh)); }
+  void annotate_ratio(const root_location_t &rl, double ratio) {
+    annotate_branch(rl, "alpha", std::to_string(ratio), std::to_string(1 - ratio));
+  }
   void clear_newick_annotations() { _annotations.clear(); }
 
   // tips below each side of a root edge (test/diagnostic helper, not in the

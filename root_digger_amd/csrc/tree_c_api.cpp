@@ -150,4 +150,10 @@ int rdamd_tree_annotate_branch(rdamd_tree_t *t, const rdamd_root_location_t *rl,
   GUARD({ t->tree.annotate_branch(to_cpp(rl), key, value); return RDAMD_SUCCESS; })
 }
 
+int rdamd_tree_annotate_branch_lr(rdamd_tree_t *t, const rdamd_root_location_t *rl,
+                                  const char *key, const char *left_value,
+                                  const char *right_value) {
+  GUARD({ t->tree.annotate_branch(to_cpp(rl), key, left_value, right_value); return RDAMD_SUCCESS; })
+}
+
 }  // extern "C"

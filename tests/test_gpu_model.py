@@ -185,3 +185,22 @@ def test_msa_ingest_and_pattern_compression():
         rd.Model.from_file(tree, os.path.join(util.DATA, "101.phy"))     # taxa mismatch
     with pytest.raises(rd.RdamdError):
         rd.Model.from_file(tree, "/nonexistent.fasta")
+
+
+def test_cli_exhaustive_outputs(tmp_path):
+    """`rd --exhaustive` outputs (src/main.cpp:636-654): .lwr.tree with LWR / LLH /
+    alpha on every branch, .rooted.tree rooted at the best placement."""
+    from root_digger_amd import cli
+    prefix = str(tmp_path / "ten")
+    rc = cli.main(["--msa", os.path.join(util.DATA, "10.fasta"),
+                   "--tree", os.path.join(util.DATA, "10.tree"), "--prefix", prefix,
+                   "--atol", "1e-3", "--brtol", "1e-3", "--silent"])
+    assert rc == 0
+    lwr = open(prefix + ".lwr.tree").read()
+    rooted = open(prefix + ".rooted.tree").read()
+    assert lwr.count("LWR=") == 17 and lwr.count("LLH=") == 17 and lwr.count("alpha=") == 17
+    import re
+    w = [float(x) for x in re.findall(r"LWR=([0-9.]+)", lwr)]
+    assert abs(sum(w) - 1.0) < 1e-4                # one annotation per branch, weights sum to 1
+    t = rd.Tree.from_newick(rooted)                # a binary-rooted tree parses (and unroots)
+    assert t.tip_count() == 10 and "NHX" not in rooted
