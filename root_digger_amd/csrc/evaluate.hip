@@ -115,43 +115,47 @@ struct Compiler {
     return r;
   }
 
-  void emit(unsigned i, bool live) {
+  // park_mat: the matrix the CURRENTLY running CLV will meet at its parent if it
+  // has to be parked while this subtree is evaluated
+  void emit(unsigned i, bool live, unsigned park_mat) {
     const rdamd_operation_t &o = ops[i];
     const bool i1 = is_inner(o.child1_clv_index), i2 = is_inner(o.child2_clv_index);
     FusedOp f;
     memset(&f, 0, sizeof(f));
-    unsigned matX = 0, matY = 0, kind = 0, spill = 0, tipX_row = 0, tipY_row = 0;
+    unsigned matM = 0, matX = 0, matY = 0, kind = 0, spill = 0, tipX_row = 0, tipY_row = 0;
     if (!i1 && !i2) {
       kind = kFusedTT;
       spill = live ? 1 : 0;
       tipX_row = o.child1_clv_index; matX = o.child1_matrix_index;
       tipY_row = o.child2_clv_index; matY = o.child2_matrix_index;
       if (live) {
+        matM = park_mat;              // pre-multiply the parked CLV
         if (depth == 0) spill |= 2;   // level 0 is a register slot in the kernel
         ++depth;
         max_depth = std::max(max_depth, depth);
       }
     } else if (i1 != i2) {
       const bool first_inner = i1;
-      emit(producer.at(first_inner ? o.child1_clv_index : o.child2_clv_index), live);
+      emit(producer.at(first_inner ? o.child1_clv_index : o.child2_clv_index), live, park_mat);
       kind = kFusedRT;
-      matX = first_inner ? o.child1_matrix_index : o.child2_matrix_index;
+      matM = first_inner ? o.child1_matrix_index : o.child2_matrix_index;
       tipY_row = first_inner ? o.child2_clv_index : o.child1_clv_index;
       matY = first_inner ? o.child2_matrix_index : o.child1_matrix_index;
     } else {
       const unsigned a = producer.at(o.child1_clv_index), b = producer.at(o.child2_clv_index);
       const bool a_first = need[a] >= need[b];
       const unsigned first = a_first ? a : b, second = a_first ? b : a;
-      emit(first, live);     // parked by the first TT op of `second`
-      emit(second, true);
-      kind = kFusedRP;     // X = register = second, Y = popped = first
-      matX = a_first ? o.child2_matrix_index : o.child1_matrix_index;
-      matY = a_first ? o.child1_matrix_index : o.child2_matrix_index;
+      const unsigned mat_first = a_first ? o.child1_matrix_index : o.child2_matrix_index;
+      emit(first, live, park_mat);    // parked (times mat_first) by the first TT op of `second`
+      emit(second, true, mat_first);
+      kind = kFusedRP;                // running CLV = second; popped = mat_first . first
+      matM = a_first ? o.child2_matrix_index : o.child1_matrix_index;
       --depth;
       if (depth == 0) spill |= 4;     // the popped sibling sits in the register slot
     }
-    f.pX = matX * rate_cats * 128u;
-    f.pY = matY * rate_cats * 128u;
+    f.pM = matM * rate_cats * 128u;
+    f.tX = matX * rate_cats * 128u;
+    f.tY = matY * rate_cats * 128u;
     f.cX = tipX_row * sites;
     f.cY = tipY_row * sites;
     f.flags = kind | (spill << 8);
@@ -205,7 +209,7 @@ rdamd_schedule_t *rdamd_schedule_create(rdamd_partition_t *p, const rdamd_operat
   c.need.assign(n_ops, 0);
   c.compute_need(n_ops - 1);
   c.out.reserve(n_ops);
-  c.emit(n_ops - 1, false);
+  c.emit(n_ops - 1, false, 0);
   if (c.out.size() != n_ops) {
     set_error(43, "rdamd_schedule_create: %u of %u operations are not reachable from the "
                   "root operation", (unsigned)(n_ops - c.out.size()), n_ops);

@@ -22,11 +22,17 @@ constexpr int kFusedSitesPerLane = 1;
 
 // One step of a compiled traversal ("program"), 32 bytes, one scalar load.
 // All offsets are precomputed on the host so the kernel adds at most the rate.
+// Every operation multiplies the running CLV by at most ONE matrix (pM):
+//   RT / RP : the branch matrix of the running (register) child;
+//   TT that parks the running CLV first: the branch matrix the parked CLV will
+//   meet at its parent -- it is applied BEFORE parking, so the later pop needs
+//   no matrix at all (one 4x4 matrix in SGPRs at a time, prefetchable).
 struct FusedOp {
-  uint32_t pX, pY;       // byte offset of [matrix][rate 0] inside a job's P-matrix block
-  uint32_t cX, cY;       // byte offset of the tip row inside tipcodes (0 if not a tip)
-  uint32_t flags;        // kind (kFused*) | 0x100 when the running CLV is parked first
-  uint32_t pad[3];
+  uint32_t pM;           // byte offset of [matrix][rate 0] for the running-CLV product
+  uint32_t tX, tY;       // byte offsets (x4 = tip-table offsets) of the tip operands' matrices
+  uint32_t cX, cY;       // byte offset of the tip rows inside tipcodes
+  uint32_t flags;        // kind | 0x100 park first | 0x200 park in registers | 0x400 pop registers
+  uint32_t pad[2];
 };
 
 struct FusedJob {

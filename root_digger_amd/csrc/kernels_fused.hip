@@ -150,57 +150,65 @@ fused_dna_eval_kernel(FusedArgs a) {
     cy[q] = (unsigned)__builtin_amdgcn_raw_buffer_load_b8(tips_rs, site_off[q], (int)uni(op.cY), 0); \
   }                                                                                             \
   ex = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(                          \
-      tab_rs, lane8, (int)((uni(op.pX) + roff) * 4u), 0));                                      \
+      tab_rs, lane8, (int)((uni(op.tX) + roff) * 4u), 0));                                      \
   ey = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(                          \
-      tab_rs, lane8, (int)((uni(op.pY) + roff) * 4u), 0));
+      tab_rs, lane8, (int)((uni(op.tY) + roff) * 4u), 0));
+    // the ONE matrix an operation applies to the running CLV, into SGPRs
+#define RDAMD_LOAD_M(op, M)                                                                     \
+  {                                                                                             \
+    const double *__restrict__ pp = reinterpret_cast<const double *>(pm + uni(op.pM) + roff);   \
+    _Pragma("unroll") for (int k = 0; k < 16; ++k) M[k] = pp[k];                                \
+  }
 
-    // one traversal step: `cur`/c?/e? hold op i (all arrived), `nxt` is the
-    // descriptor of op i+1 whose tip data is fetched into nc?/ne?; finally the
-    // `cur` slot is refilled with the descriptor of op i+2.
+    // one traversal step: `cur`/c?/e?/M hold op i (all arrived), `nxt` is the
+    // descriptor of op i+1 whose tip data and matrix are fetched into
+    // nc?/ne?/M (M is consumed before it is refilled); finally the `cur` slot is
+    // refilled with the descriptor of op i+2.
 #define RDAMD_STEP(cur, nxt, cx, cy, ex, ey, ncx, ncy, nex, ney, idx2)                          \
   {                                                                                             \
     const unsigned kind = uni(cur.flags);                                                       \
-    const double *__restrict__ px = reinterpret_cast<const double *>(pm + uni(cur.pX) + roff); \
-    const double *__restrict__ py = reinterpret_cast<const double *>(pm + uni(cur.pY) + roff); \
     cur = prog[idx2];                                                                           \
     const double *rowx[NS], *rowy[NS];                                                          \
     _Pragma("unroll") for (int q = 0; q < NS; ++q) { rowx[q] = tabx + cx[q] * 4; rowy[q] = taby + cy[q] * 4; } \
     double tx[NS][4], ty[NS][4];                                                                \
-    if (kind & 0x100u) { /* cherry that must park the running CLV first */                      \
-      if (kind & 0x200u) { /* stack level 0 lives in registers */                               \
-        _Pragma("unroll") for (int q = 0; q < NS; ++q) {                                        \
-          _Pragma("unroll") for (int k = 0; k < 4; ++k) s0[q][k] = st.v[q][k];                  \
-          s0sc[q] = st.sc[q];                                                                   \
-        }                                                                                       \
-      } else {                                                                                  \
-        _Pragma("unroll") for (int q = 0; q < NS; ++q) {                                        \
-          double2 *d = stk + (size_t)(sp * NS + q) * 128;                                       \
-          d[0] = make_double2(st.v[q][0], st.v[q][1]);                                          \
-          d[64] = make_double2(st.v[q][2], st.v[q][3]);                                         \
-          stk_sc[(sp * NS + q) * 64] = st.sc[q];                                                \
-        }                                                                                       \
-        ++sp;                                                                                   \
-      }                                                                                         \
-    }                                                                                           \
     const unsigned k3 = kind & 3u;                                                              \
     if (k3 == kFusedTT) {                                                                       \
       tabx[lane] = ex;                                                                          \
       taby[lane] = ey;                                                                          \
       _Pragma("unroll") for (int q = 0; q < NS; ++q) { read_row(rowx[q], tx[q]); read_row(rowy[q], ty[q]); } \
       RDAMD_LOAD_TIPS(nxt, ncx, ncy, nex, ney)                                                  \
+      if (kind & 0x100u) { /* park M . (running CLV) for the later inner-inner node */          \
+        double tp[NS][4];                                                                       \
+        _Pragma("unroll") for (int q = 0; q < NS; ++q) matvec(M, st.v[q], tp[q]);               \
+        if (kind & 0x200u) { /* stack level 0 lives in registers */                             \
+          _Pragma("unroll") for (int q = 0; q < NS; ++q) {                                      \
+            _Pragma("unroll") for (int k = 0; k < 4; ++k) s0[q][k] = tp[q][k];                  \
+            s0sc[q] = st.sc[q];                                                                 \
+          }                                                                                     \
+        } else {                                                                                \
+          _Pragma("unroll") for (int q = 0; q < NS; ++q) {                                      \
+            double2 *d = stk + (size_t)(sp * NS + q) * 128;                                     \
+            d[0] = make_double2(tp[q][0], tp[q][1]);                                            \
+            d[64] = make_double2(tp[q][2], tp[q][3]);                                           \
+            stk_sc[(sp * NS + q) * 64] = st.sc[q];                                              \
+          }                                                                                     \
+          ++sp;                                                                                 \
+        }                                                                                       \
+      }                                                                                         \
+      RDAMD_LOAD_M(nxt, M)                                                                      \
       _Pragma("unroll") for (int q = 0; q < NS; ++q) { st.sc[q] = 0; combine(tx[q], ty[q], st.v[q], st.sc[q]); } \
     } else if (k3 == kFusedRT) {                                                                \
       taby[lane] = ey;                                                                          \
       _Pragma("unroll") for (int q = 0; q < NS; ++q) read_row(rowy[q], ty[q]);                  \
       RDAMD_LOAD_TIPS(nxt, ncx, ncy, nex, ney)                                                  \
-      _Pragma("unroll") for (int q = 0; q < NS; ++q) matvec(px, st.v[q], tx[q]);                \
+      _Pragma("unroll") for (int q = 0; q < NS; ++q) matvec(M, st.v[q], tx[q]);                 \
+      RDAMD_LOAD_M(nxt, M)                                                                      \
       _Pragma("unroll") for (int q = 0; q < NS; ++q) combine(tx[q], ty[q], st.v[q], st.sc[q]);  \
-    } else { /* kFusedRP: X = running CLV, Y = popped sibling */                                \
-      double y[NS][4];                                                                          \
+    } else { /* kFusedRP: running CLV times M, sibling already multiplied when parked */        \
       int scy[NS];                                                                              \
-      if (kind & 0x400u) { /* the sibling was parked in the register level */                   \
+      if (kind & 0x400u) {                                                                      \
         _Pragma("unroll") for (int q = 0; q < NS; ++q) {                                        \
-          _Pragma("unroll") for (int k = 0; k < 4; ++k) y[q][k] = s0[q][k];                     \
+          _Pragma("unroll") for (int k = 0; k < 4; ++k) ty[q][k] = s0[q][k];                    \
           scy[q] = s0sc[q];                                                                     \
         }                                                                                       \
       } else {                                                                                  \
@@ -208,13 +216,13 @@ fused_dna_eval_kernel(FusedArgs a) {
         _Pragma("unroll") for (int q = 0; q < NS; ++q) {                                        \
           const double2 *d = stk + (size_t)(sp * NS + q) * 128;                                 \
           const double2 lo = d[0], hi = d[64];                                                  \
-          y[q][0] = lo.x; y[q][1] = lo.y; y[q][2] = hi.x; y[q][3] = hi.y;                       \
+          ty[q][0] = lo.x; ty[q][1] = lo.y; ty[q][2] = hi.x; ty[q][3] = hi.y;                   \
           scy[q] = stk_sc[(sp * NS + q) * 64];                                                  \
         }                                                                                       \
       }                                                                                         \
       RDAMD_LOAD_TIPS(nxt, ncx, ncy, nex, ney)                                                  \
-      _Pragma("unroll") for (int q = 0; q < NS; ++q) matvec(px, st.v[q], tx[q]);                \
-      _Pragma("unroll") for (int q = 0; q < NS; ++q) matvec(py, y[q], ty[q]);                   \
+      _Pragma("unroll") for (int q = 0; q < NS; ++q) matvec(M, st.v[q], tx[q]);                 \
+      RDAMD_LOAD_M(nxt, M)                                                                      \
       _Pragma("unroll") for (int q = 0; q < NS; ++q) { st.sc[q] += scy[q]; combine(tx[q], ty[q], st.v[q], st.sc[q]); } \
     }                                                                                           \
   }
@@ -234,6 +242,8 @@ fused_dna_eval_kernel(FusedArgs a) {
 #pragma unroll
     for (int q = 0; q < NS; ++q) { cxA[q] = cxB[q] = 1; cyA[q] = cyB[q] = 2; }
     RDAMD_LOAD_TIPS(dA, cxA, cyA, exA, eyA)
+    double M[16];
+    RDAMD_LOAD_M(dA, M)
     unsigned i = 0;
     for (; i + 1 < nops; i += 2) {
       RDAMD_STEP(dA, dB, cxA, cyA, exA, eyA, cxB, cyB, exB, eyB, i + 2)
