@@ -66,8 +66,8 @@ def profiled_traffic(kernel, batch, config):
     """HBM bytes per launch of `kernel` from the committed PMC passes
     (profiles/collect.sh + profiles/summarize.py: FETCH_SIZE/WRITE_SIZE in
     separate rocprofv3 passes, corrected per MI355X_MICROARCH.md).  The passes
-    were taken on the default command (c2, batch 64); other shapes get null."""
-    if config != "c2" or batch != 64:
+    were taken on the default command (c2, batch 197); other shapes get null."""
+    if config != "c2" or batch != 197:
         return None, None
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_summary.json")))
@@ -89,8 +89,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
-    ap.add_argument("--batch", type=int, default=64,
-                    help="candidate-root evaluations per step per GPU")
+    ap.add_argument("--batch", type=int, default=197,
+                    help="candidate-root evaluations per step per GPU (default: one sweep "
+                         "over the 2n-3 = 197 candidate roots of c2)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0,
                     help="budget for the cpu_baseline leg (rank 0, N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
