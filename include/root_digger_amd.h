@@ -369,6 +369,15 @@ int rdamd_model_exhaustive_search(rdamd_model_t *m, double atol, double pgtol, d
                                   double factor, uint64_t *root_id, double *llh, double *alpha,
                                   unsigned int *n_results, rdamd_root_location_t *best_rl,
                                   double *best_llh);
+/* The same loop with `workers` host threads, each driving its own replica of the
+ * model (own partition, own HIP stream) and pulling candidates from a shared
+ * counter: the one-GPU form of the reference's one-MPI-rank-per-chunk split
+ * (src/model.cpp:1867-1911).  Results come back sorted by root id. */
+int rdamd_model_exhaustive_search_parallel(rdamd_model_t *m, unsigned int workers,
+                                           double atol, double pgtol, double brtol,
+                                           double factor, uint64_t *root_id, double *llh,
+                                           double *alpha, unsigned int *n_results,
+                                           rdamd_root_location_t *best_rl, double *best_llh);
 
 /* character maps (replace corax_map_nt / corax_map_bin, src/main.cpp:484) */
 extern const uint64_t rdamd_map_nt[256];

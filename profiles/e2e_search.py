@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""End-to-end timing of the exhaustive per-candidate loop (src/model.cpp:1139-1272)
+on BASELINE config c2 with the reference's L-BFGS-B (oracle/_ref) driving the
+batched GPU objective.  Diagnostic, not the bench line."""
+import ctypes, os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import root_digger_amd as rd
+from root_digger_amd import synth
+
+ncand = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+n, S = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (100, 50000)
+w = synth.workload(n, S, 4, 4, 0xD166E5 + 1)
+tree = rd.Tree.from_newick(w["newick"])
+m = rd.Model(tree, w["seqs"], rate_cats=4, seed=3)
+m.initialize_partitions()
+ref = os.path.join(ROOT, "oracle", "_ref", "liblbfgsb_ref.so")
+lb = ctypes.CDLL(ref)
+m.set_lbfgsb(lb.setulb)
+m.compute_lh(tree.root_location(0))
+lib = rd.lib
+import ctypes as C
+workers = int(os.environ.get("WORKERS", "0"))
+if workers:
+    import numpy as _np
+    lib.rdamd_model_assign_by_rank  # noqa
+    # first `ncand` candidates in one call, `workers` threads
+    m._ok(lib.rdamd_model_assign_by_rank(m._h, 0, max(1, tree.root_count() // ncand)), "assign")
+    t1 = time.time()
+    res = m.exhaustive_search(1e-7, 1e-7, 1e-12, 1e4, workers=workers)
+    dt = time.time() - t1
+    print("%d candidates, %d workers: %.2fs  (%.3fs per candidate)" % (len(res["root_id"]), workers, dt, dt / len(res["root_id"])))
+    sys.exit(0)
+t0 = time.time()
+tot = 0
+for rank in range(ncand):
+    m.assign_by_rank(rank, tree.root_count())      # one candidate each
+    t1 = time.time()
+    res = m.exhaustive_search(1e-7, 1e-7, 1e-12, 1e4)
+    print("candidate %3d  llh %.4f alpha %.4f  %.2fs" % (res["root_id"][0], res["llh"][0], res["alpha"][0], time.time() - t1), flush=True)
+print("total %.2fs for %d candidates" % (time.time() - t0, ncand))

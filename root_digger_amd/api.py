@@ -140,6 +140,8 @@ _sig("rdamd_model_compute_all_root_lh", C.c_int, _vp, _pd)
 _sig("rdamd_model_optimize_alpha", C.c_int, _vp, _prl, C.c_double, _prl)
 _sig("rdamd_model_compute_lh_batch", C.c_int, _vp, _u, _prl, _pd, _pd, _pd, _pd)
 _sig("rdamd_model_assign_by_rank", C.c_int, _vp, _u, _u)
+_sig("rdamd_model_exhaustive_search_parallel", C.c_int, _vp, _u, C.c_double, C.c_double,
+     C.c_double, C.c_double, C.POINTER(C.c_uint64), _pd, _pd, _pu, _prl, _pd)
 _sig("rdamd_model_set_lbfgsb", None, _vp, _vp)
 _sig("rdamd_model_optimize_params", C.c_int, _vp, _prl, C.c_double, C.c_double, C.c_int, _pd, _pd,
      _pd, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64))
@@ -676,7 +678,8 @@ class Model:
     def assign_by_rank(self, rank, num_tasks):
         self._ok(lib.rdamd_model_assign_by_rank(self._h, rank, num_tasks), "assign_by_rank")
 
-    def exhaustive_search(self, atol, pgtol, brtol, factor):
+    def exhaustive_search(self, atol, pgtol, brtol, factor, workers=0):
+        """workers > 0: that many host threads, each with its own model replica."""
         n = self._tree.root_count()
         ids = (C.c_uint64 * n)()
         llh = np.zeros(n, dtype=np.float64)
@@ -684,10 +687,15 @@ class Model:
         cnt = C.c_uint(0)
         best = RootLocation()
         best_llh = C.c_double(0.0)
-        self._ok(lib.rdamd_model_exhaustive_search(self._h, atol, pgtol, brtol, factor, ids,
-                                                   _dptr(llh), _dptr(alpha), C.byref(cnt),
-                                                   C.byref(best), C.byref(best_llh)),
-                 "exhaustive_search")
+        if workers > 0:
+            self._ok(lib.rdamd_model_exhaustive_search_parallel(
+                self._h, workers, atol, pgtol, brtol, factor, ids, _dptr(llh), _dptr(alpha),
+                C.byref(cnt), C.byref(best), C.byref(best_llh)), "exhaustive_search_parallel")
+        else:
+            self._ok(lib.rdamd_model_exhaustive_search(self._h, atol, pgtol, brtol, factor, ids,
+                                                       _dptr(llh), _dptr(alpha), C.byref(cnt),
+                                                       C.byref(best), C.byref(best_llh)),
+                     "exhaustive_search")
         k = cnt.value
         return {"root_id": [int(ids[i]) for i in range(k)], "llh": llh[:k].copy(),
                 "alpha": alpha[:k].copy(), "best": best, "best_llh": best_llh.value}

@@ -36,6 +36,9 @@ def main(argv=None):
     ap.add_argument("--early-stop", action="store_true")
     ap.add_argument("--lbfgsb", default=None,
                     help="shared library exporting the L-BFGS-B entry point `setulb`")
+    ap.add_argument("--workers", type=int, default=4,
+                    help="host threads, each with its own model replica / HIP stream "
+                         "(0 = the plain sequential loop)")
     ap.add_argument("--device", type=int, default=0)
     ap.add_argument("--silent", action="store_true")
     args = ap.parse_args(argv)
@@ -52,7 +55,8 @@ def main(argv=None):
         keep = ctypes.CDLL(args.lbfgsb)
         model.set_lbfgsb(keep.setulb)
     model.compute_lh(tree.root_location(0))                    # model.initialize()
-    res = model.exhaustive_search(args.atol, args.bfgstol, args.brtol, args.factor)
+    res = model.exhaustive_search(args.atol, args.bfgstol, args.brtol, args.factor,
+                                  workers=args.workers)
 
     # likelihood weight ratios, src/model.cpp:1239-1258
     mx = max(res["llh"])

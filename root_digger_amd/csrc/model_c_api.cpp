@@ -1,6 +1,11 @@
 // C wrappers over model_t (declared in include/root_digger_amd.h).
+#include <atomic>
 #include <cmath>
 #include <cstring>
+#include <mutex>
+#include <thread>
+
+#include <algorithm>
 
 #include "common.hpp"
 #include "model.hpp"
@@ -9,6 +14,11 @@
 struct rdamd_model {
   rdamd::model_t *model = nullptr;
   rdamd::msa_t    msa;
+  // what a replica needs (parallel exhaustive search)
+  unsigned rate_cats = 1;
+  uint64_t seed = 0;
+  bool     early_stop = false;
+  void    *setulb = nullptr;
   ~rdamd_model() { delete model; }
 };
 
@@ -52,6 +62,7 @@ rdamd_model_t *rdamd_model_create(const rdamd_tree_t *tree, unsigned int n_taxa,
       m->msa.sequences.emplace_back(sequences[i]);
     }
     if (weights) m->msa.weights.assign(weights, weights + m->msa.length());
+    m->rate_cats = rate_cats; m->seed = seed; m->early_stop = early_stop != 0;
     try {
       m->model = new rdamd::model_t(rdamd_tree_cpp(tree), {m->msa},
                                     {rdamd::ratehet_opts_t(rate_cats)}, false, seed,
@@ -70,6 +81,7 @@ rdamd_model_t *rdamd_model_create_from_file(const rdamd_tree_t *tree, const char
                                             unsigned int *n_patterns) {
   GUARD(nullptr, {
     auto *m = new rdamd_model();
+    m->rate_cats = rate_cats; m->seed = seed; m->early_stop = early_stop != 0;
     try {
       m->msa = rdamd::msa_t::from_file(msa_filename, map, states, compress != 0);
       if (!m->msa.constiency_check(rdamd_tree_cpp(tree).label_set()))
@@ -175,7 +187,76 @@ int rdamd_model_compute_lh_batch(rdamd_model_t *m, unsigned int n,
   })
 }
 void rdamd_model_set_lbfgsb(rdamd_model_t *m, void *fn) {
+  m->setulb = fn;
   m->model->set_lbfgsb(reinterpret_cast<rdamd::model_t::setulb_fn>(fn));
+}
+
+// The candidate-root loop of exhaustive_search (src/model.cpp:1154) is
+// embarrassingly parallel: the reference runs it on one MPI rank per chunk
+// (src/model.cpp:1867-1911).  On one GPU the same thing is `workers` host
+// threads, each with its own model replica (own partition, own HIP stream),
+// pulling candidates from a shared counter -- their small launches (13-job
+// L-BFGS-B batches, root-only Brent steps) overlap on the device.
+int rdamd_model_exhaustive_search_parallel(rdamd_model_t *m, unsigned int workers, double atol,
+                                           double pgtol, double brtol, double factor,
+                                           uint64_t *root_id, double *llh, double *alpha,
+                                           unsigned int *n_results,
+                                           rdamd_root_location_t *best_rl, double *best_llh) {
+  GUARD(RDAMD_FAILURE, {
+    const std::vector<size_t> todo = m->model->assigned_indicies();
+    if (workers < 1) workers = 1;
+    workers = (unsigned)std::min<size_t>(workers, std::max<size_t>(todo.size(), 1));
+    int device = 0;
+    if (hipGetDevice(&device) != hipSuccess) throw std::runtime_error("no HIP device");
+    std::atomic<size_t> next{0};
+    std::mutex mu;
+    std::vector<rdamd::rd_result_t> results;
+    std::string first_error;
+    auto work = [&](unsigned wid) {
+      try {
+        if (hipSetDevice(device) != hipSuccess) throw std::runtime_error("hipSetDevice failed");
+        rdamd::model_t replica(m->model->tree(), {m->msa}, {rdamd::ratehet_opts_t(m->rate_cats)},
+                               false, m->seed + wid, m->early_stop);
+        replica.initialize_partitions({m->msa});
+        if (m->setulb) replica.set_lbfgsb(reinterpret_cast<rdamd::model_t::setulb_fn>(m->setulb));
+        replica.initialize();
+        for (;;) {
+          const size_t k = next.fetch_add(1);
+          if (k >= todo.size()) break;
+          replica.assign_indicies(std::vector<size_t>{todo[k]});
+          std::vector<rdamd::rd_result_t> r;
+          replica.exhaustive_search(atol, pgtol, brtol, factor, &r);
+          std::lock_guard<std::mutex> g(mu);
+          results.insert(results.end(), r.begin(), r.end());
+        }
+      } catch (const std::exception &e) {
+        std::lock_guard<std::mutex> g(mu);
+        if (first_error.empty()) first_error = e.what();
+        next.store(todo.size());
+      }
+    };
+    std::vector<std::thread> pool;
+    for (unsigned w = 0; w < workers; ++w) pool.emplace_back(work, w);
+    for (auto &t : pool) t.join();
+    if (!first_error.empty()) throw std::runtime_error(first_error);
+    std::sort(results.begin(), results.end(),
+              [](const rdamd::rd_result_t &a, const rdamd::rd_result_t &b) { return a.root_id < b.root_id; });
+    double bl = -INFINITY;
+    for (size_t i = 0; i < results.size(); ++i) {
+      root_id[i] = results[i].root_id; llh[i] = results[i].llh; alpha[i] = results[i].alpha;
+      if (results[i].llh > bl) {
+        bl = results[i].llh;
+        if (best_rl) {
+          auto rl = m->model->tree().root_location(results[i].root_id);
+          rl.brlen_ratio = results[i].alpha;
+          to_c(rl, best_rl);
+        }
+      }
+    }
+    *n_results = (unsigned)results.size();
+    if (best_llh) *best_llh = bl;
+    return RDAMD_SUCCESS;
+  })
 }
 int rdamd_model_optimize_params(rdamd_model_t *m, const rdamd_root_location_t *rl, double pgtol,
                                 double factor, int optimize_gamma, double *subst, double *freqs,

@@ -141,3 +141,22 @@ def test_exhaustive_search_with_parameter_optimisation(lbfgsb):
     for rid, llh in zip(opt["root_id"], opt["llh"]):
         assert llh >= by_id[rid] - 1e-6
     assert opt["best_llh"] > plain["best_llh"]
+
+
+def test_parallel_exhaustive_search_equals_sequential(lbfgsb):
+    """worker replicas (one partition + stream each) pull candidates from a shared
+    counter; every candidate is computed by the same code on the same data, so the
+    results are identical to the sequential loop."""
+    tree = rd.Tree.from_file(os.path.join(util.DATA, "10.tree"))
+    seqs = util.read_fasta(os.path.join(util.DATA, "10.fasta"))
+    m = rd.Model(tree, seqs, rate_cats=4, seed=9)
+    m.initialize_partitions()
+    m.set_lbfgsb(lbfgsb.setulb)
+    m.compute_lh(tree.root_location(0))
+    seq = m.exhaustive_search(1e-3, 1e-3, 1e-3, 1e12)
+    par = m.exhaustive_search(1e-3, 1e-3, 1e-3, 1e12, workers=4)
+    order = np.argsort(seq["root_id"])
+    assert par["root_id"] == sorted(seq["root_id"])
+    assert np.array_equal(par["llh"], seq["llh"][order])
+    assert np.array_equal(par["alpha"], seq["alpha"][order])
+    assert par["best_llh"] == seq["best_llh"]
