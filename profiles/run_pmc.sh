@@ -1,4 +1,4 @@
-# usage: bash profiles/run_pmc.sh <tag> [env assignments...]; PMC passes over bench.py
+# usage: bash profiles/run_pmc.sh <tag>; SQ counter passes over bench.py (diagnostic)
 TAG=$1; shift
 export TMPDIR=/tmp; R=/root/repo; OUT=$R/gpurun_out/$TAG; mkdir -p $OUT; cd /tmp
 for e in "$@"; do export "$e"; done

@@ -262,6 +262,12 @@ static int evaluate_batch_impl(rdamd_partition_t *p, unsigned int n_jobs,
     return RDAMD_FAILURE;
   }
   const unsigned R = p->rate_cats, NP = 12;
+  if (p->sites == 0) {   // an empty alignment has likelihood 1
+    if (lnl_host) std::fill(lnl_host, lnl_host + n_jobs, 0.0);
+    if (lnl_device)
+      RDAMD_HIP_TRY(hipMemset(lnl_device, 0, sizeof(double) * n_jobs), RDAMD_FAILURE);
+    return RDAMD_SUCCESS;
+  }
   RDAMD_HIP_TRY(ensure_workspace(p, n_jobs), RDAMD_FAILURE);
   FusedWorkspace *w = p->fused;
   // the pinned input block must not be rewritten while an earlier batch's

@@ -399,12 +399,10 @@ hipError_t launch_fused_eval(const FusedArgs &a, unsigned n_jobs, unsigned max_d
   const size_t lds = kTabDoubles * sizeof(double) +
                      (size_t)(max_depth ? max_depth : 1) * kFusedSitesPerLane * 64 *
                          (4 * sizeof(double) + sizeof(int));
-  static size_t lds_limit_set = 0;
-  if (lds > 48 * 1024 && lds > lds_limit_set) {
+  if (lds > 48 * 1024) {   // deep stacks (very unbalanced 10^3-taxon trees): raise the limit
     hipError_t e = hipFuncSetAttribute((const void *)fused_dna_eval_kernel<kFusedSitesPerLane>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    lds_limit_set = lds;
   }
   dim3 grid(blocks_x, n_jobs);
   fused_dna_eval_kernel<kFusedSitesPerLane><<<grid, 64, lds, stream>>>(a);

@@ -461,6 +461,7 @@ double rdamd_compute_root_loglikelihood(rdamd_partition_t *p, unsigned int clv_i
       set_error(7, "rdamd_compute_root_loglikelihood: freqs index out of range");
       return nan;
     }
+  if (p->sites == 0) return 0.0;   // an empty alignment has likelihood 1
   RDAMD_HIP_TRY(flush_q(p), nan);
   RDAMD_HIP_TRY(ensure_scratch(p, 1024 + sizeof(unsigned) * p->rate_cats), nan);
   Scratch sc{p};
@@ -489,6 +490,10 @@ int rdamd_root_loglikelihood_fused(rdamd_partition_t *p, const rdamd_operation_t
   clear_error();
   if (n_alpha == 0) return RDAMD_SUCCESS;
   const unsigned R = p->rate_cats, K = p->states;
+  if (p->sites == 0) {
+    std::fill(lnl_out, lnl_out + n_alpha, 0.0);
+    return RDAMD_SUCCESS;
+  }
   const bool fast = K == 4 && p->ncodes_cap == 16 &&
                     (R == 1 || R == 2 || R == 4 || R == 8) &&
                     root_op->parent_scaler_index >= 0;

@@ -531,3 +531,12 @@ def test_thousand_taxon_tree_vs_oracle():
     assert max(s.stack_depth() for s in scheds) <= 10
     ops, _, _ = tree.generate_operations(rls[2])
     compare_state(g, o, [ops[i] for i in (0, 500, 998)], tree)
+
+
+def test_zero_site_partition():
+    tree = rd.Tree.from_file(os.path.join(util.DATA, "single.tree"))
+    g = rd.Partition.for_tree(tree, 4, 0, 4)
+    rl = tree.root_location(0)
+    assert util.compute_lh(g, tree, rl) == 0.0
+    sched = g.schedule(*tree.generate_operations(rl))
+    assert g.evaluate_batch([sched], [[1.0] * 12], [[0.25] * 4])[0] == 0.0
