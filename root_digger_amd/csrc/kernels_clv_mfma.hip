@@ -13,7 +13,9 @@
 //
 // One wave = (32 sites, one rate); the waves of a workgroup are the R rates of
 // the same 32 sites, so the per-site "all entries < 2^-256" rule is one LDS
-// exchange.  A-operands come from an MFMA-ready copy of the P-matrices that
+// exchange (one barrier per operation).  A child produced by the operation just
+// before is consumed straight from the D registers; A operands, tip masks and
+// older-sibling CLVs of operation i+1 are fetched while operation i computes.  A-operands come from an MFMA-ready copy of the P-matrices that
 // the P-matrix kernel writes ([matrix][rate][tile][step][lane], fully
 // coalesced 512-B rows).  Tips are expanded from their state masks in
 // registers (a 0/1 B operand), so no tip table and no tip CLV is read.
@@ -28,7 +30,7 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 constexpr int kMfmaK = 20;        // states
 constexpr int kMfmaSteps = 5;     // k steps of 4
 constexpr int kMfmaTiles = 2;     // row tiles of 16 (rows 20..31 are padding)
-constexpr int kMfmaNT = 2;        // 16-site column tiles per wave
+constexpr int kMfmaNT = 1;        // 16-site column tiles per wave
 
 // MFMA-ready copy of one 20x20 P-matrix: element (tile t, step s, lane l) =
 // P[16 t + l%16][4 s + l/16]  (0 for padded rows)
@@ -47,69 +49,115 @@ pmat_to_mfma_kernel(const double *__restrict__ pmat, double *__restrict__ out,
   }
 }
 
-__global__ void __launch_bounds__(1024)
+// B operands of one child for the kMfmaNT site tiles of a wave
+struct ChildB {
+  double b[kMfmaNT][kMfmaSteps];
+};
+
+template <int MAXT>   // 64 * rate categories, rounded up to 256 or 1024
+__global__ void __launch_bounds__(MAXT)
 clv_k20_traversal_kernel(DeviceView v, const double *__restrict__ pmfma,
                          const LevelOp *__restrict__ ops, unsigned nops) {
-  // flags[rate][site in block]: "this rate's 20 entries are all < 2^-256"
-  __shared__ unsigned flags[16][16 * kMfmaNT];
+  // flags[parity][rate][site in block]: "this rate's 20 entries are all < 2^-256";
+  // double-buffered by operation parity so one barrier per operation suffices
+  __shared__ unsigned flags[2][16][16 * kMfmaNT];
+  __shared__ uint64_t masks[256];   // code -> state mask
   const unsigned R = v.rate_cats, S = v.sites;
   const unsigned lane = threadIdx.x & 63, r = threadIdx.x >> 6;   // wave = rate
   const unsigned col = lane & 15, grp = lane >> 4;
   const unsigned site0 = blockIdx.x * (16 * kMfmaNT);
+  for (unsigned e = threadIdx.x; e < 256; e += blockDim.x) masks[e] = v.codemask[e];
+  __syncthreads();
+
+  unsigned site[kMfmaNT], ls[kMfmaNT];
+#pragma unroll
+  for (int nt = 0; nt < kMfmaNT; ++nt) {
+    site[nt] = site0 + nt * 16 + col;
+    ls[nt] = site[nt] < S ? site[nt] : S - 1;   // clamped for loads
+  }
+  const bool sc_lane = r == 0 && grp == 0;      // the lanes that own the per-site scalers
+
+  // everything operation `op` needs from memory, one operation ahead:
+  // A operands (MFMA-ready P), B operands of tip / older-sibling children, scalers
+  auto load_a = [&](const LevelOp &op, double (&a1)[kMfmaTiles][kMfmaSteps],
+                    double (&a2)[kMfmaTiles][kMfmaSteps]) {
+    const double *p1 = pmfma + ((size_t)op.child1_mat * R + r) * (kMfmaTiles * kMfmaSteps * 64) + lane;
+    const double *p2 = pmfma + ((size_t)op.child2_mat * R + r) * (kMfmaTiles * kMfmaSteps * 64) + lane;
+#pragma unroll
+    for (int t = 0; t < kMfmaTiles; ++t)
+#pragma unroll
+      for (int s = 0; s < kMfmaSteps; ++s) {
+        a1[t][s] = p1[(t * kMfmaSteps + s) * 64];
+        a2[t][s] = p2[(t * kMfmaSteps + s) * 64];
+      }
+  };
+  auto load_b = [&](unsigned src, unsigned clv, int scb, ChildB &cb, unsigned (&sc)[kMfmaNT]) {
+    if (src == 2u) return;   // produced by the previous operation: stays in registers
+#pragma unroll
+    for (int nt = 0; nt < kMfmaNT; ++nt) {
+      if (src == 0u) {       // tip: a 0/1 operand straight from the state mask
+        const uint64_t mask = masks[v.tipcodes[(size_t)clv * S + ls[nt]]];
+#pragma unroll
+        for (int s = 0; s < kMfmaSteps; ++s) cb.b[nt][s] = ((mask >> (4 * s + grp)) & 1) ? 1.0 : 0.0;
+        sc[nt] = 0;
+      } else {               // an older sibling from HBM / L2
+        const double *c = v.clv + (size_t)(clv - v.tips) * v.clv_stride +
+                          ((size_t)ls[nt] * R + r) * kMfmaK + grp;
+#pragma unroll
+        for (int s = 0; s < kMfmaSteps; ++s) cb.b[nt][s] = c[4 * s];
+        sc[nt] = (sc_lane && scb >= 0) ? v.scaler[(size_t)scb * S + ls[nt]] : 0u;
+      }
+    }
+  };
+
+  double a1[kMfmaTiles][kMfmaSteps], a2[kMfmaTiles][kMfmaSteps];
+  ChildB b1, b2;
+  unsigned sc1[kMfmaNT] = {0}, sc2[kMfmaNT] = {0};
+  v4d res[kMfmaNT][kMfmaTiles];       // the CLV this wave produced last (D layout = B layout)
+  unsigned osc[kMfmaNT] = {0};
+#pragma unroll
+  for (int nt = 0; nt < kMfmaNT; ++nt)
+#pragma unroll
+    for (int t = 0; t < kMfmaTiles; ++t) res[nt][t] = v4d{0, 0, 0, 0};
+  {
+    const LevelOp op0 = ops[0];
+    load_a(op0, a1, a2);
+    load_b(op0.src1, op0.child1_clv, op0.child1_sc, b1, sc1);
+    load_b(op0.src2, op0.child2_clv, op0.child2_sc, b2, sc2);
+  }
 
   for (unsigned oi = 0; oi < nops; ++oi) {
     const LevelOp op = ops[oi];
-    const bool tip1 = op.src1 == 0, tip2 = op.src2 == 0;
-    // A operands of both children for this wave's rate
-    double a1[kMfmaTiles][kMfmaSteps], a2[kMfmaTiles][kMfmaSteps];
-    {
-      const double *p1 = pmfma + ((size_t)op.child1_mat * R + r) * (kMfmaTiles * kMfmaSteps * 64) + lane;
-      const double *p2 = pmfma + ((size_t)op.child2_mat * R + r) * (kMfmaTiles * kMfmaSteps * 64) + lane;
+    const bool more = oi + 1 < nops;
+    const LevelOp nx = ops[more ? oi + 1 : oi];
+    // a child produced by the previous operation: its D registers ARE the B operand
+    if (op.src1 == 2u) {
 #pragma unroll
-      for (int t = 0; t < kMfmaTiles; ++t)
+      for (int nt = 0; nt < kMfmaNT; ++nt) {
 #pragma unroll
-        for (int s = 0; s < kMfmaSteps; ++s) {
-          a1[t][s] = p1[(t * kMfmaSteps + s) * 64];
-          a2[t][s] = p2[(t * kMfmaSteps + s) * 64];
-        }
+        for (int s = 0; s < kMfmaSteps; ++s) b1.b[nt][s] = res[nt][s / 4][s % 4];
+        sc1[nt] = osc[nt];
+      }
     }
-    const double *c1 = tip1 ? nullptr : v.clv + (size_t)(op.child1_clv - v.tips) * v.clv_stride;
-    const double *c2 = tip2 ? nullptr : v.clv + (size_t)(op.child2_clv - v.tips) * v.clv_stride;
-    double *pc = v.clv + (size_t)(op.parent_clv - v.tips) * v.clv_stride;
-
-    v4d res[kMfmaNT][kMfmaTiles];
+    if (op.src2 == 2u) {
+#pragma unroll
+      for (int nt = 0; nt < kMfmaNT; ++nt) {
+#pragma unroll
+        for (int s = 0; s < kMfmaSteps; ++s) b2.b[nt][s] = res[nt][s / 4][s % 4];
+        sc2[nt] = osc[nt];
+      }
+    }
+    // the MFMAs of this operation
 #pragma unroll
     for (int nt = 0; nt < kMfmaNT; ++nt) {
-      const unsigned site = site0 + nt * 16 + col;
-      const unsigned ls = site < S ? site : S - 1;   // clamped for loads
-      // B operands: child state (4 step + grp) of site `col`
-      double b1[kMfmaSteps], b2[kMfmaSteps];
-      if (tip1) {
-        const uint64_t mask = v.codemask[v.tipcodes[(size_t)op.child1_clv * S + ls]];
-#pragma unroll
-        for (int s = 0; s < kMfmaSteps; ++s) b1[s] = ((mask >> (4 * s + grp)) & 1) ? 1.0 : 0.0;
-      } else {
-        const double *c = c1 + ((size_t)ls * R + r) * kMfmaK + grp;
-#pragma unroll
-        for (int s = 0; s < kMfmaSteps; ++s) b1[s] = c[4 * s];
-      }
-      if (tip2) {
-        const uint64_t mask = v.codemask[v.tipcodes[(size_t)op.child2_clv * S + ls]];
-#pragma unroll
-        for (int s = 0; s < kMfmaSteps; ++s) b2[s] = ((mask >> (4 * s + grp)) & 1) ? 1.0 : 0.0;
-      } else {
-        const double *c = c2 + ((size_t)ls * R + r) * kMfmaK + grp;
-#pragma unroll
-        for (int s = 0; s < kMfmaSteps; ++s) b2[s] = c[4 * s];
-      }
       bool small = true;
 #pragma unroll
       for (int t = 0; t < kMfmaTiles; ++t) {
         v4d d1 = {0, 0, 0, 0}, d2 = {0, 0, 0, 0};
 #pragma unroll
         for (int s = 0; s < kMfmaSteps; ++s) {
-          d1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[t][s], b1[s], d1, 0, 0, 0);
-          d2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a2[t][s], b2[s], d2, 0, 0, 0);
+          d1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[t][s], b1.b[nt][s], d1, 0, 0, 0);
+          d2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a2[t][s], b2.b[nt][s], d2, 0, 0, 0);
         }
         v4d o;
 #pragma unroll
@@ -119,41 +167,42 @@ clv_k20_traversal_kernel(DeviceView v, const double *__restrict__ pmfma,
         }
         res[nt][t] = o;
       }
-      // across the 4 lane groups that hold the other rows of this site
-      int sm = small ? 1 : 0;
+      int sm = small ? 1 : 0;   // across the 4 lane groups that hold the other rows of this site
       sm &= __shfl_xor(sm, 16);
       sm &= __shfl_xor(sm, 32);
-      if (grp == 0) flags[r][nt * 16 + col] = (unsigned)sm;
+      if (grp == 0) flags[oi & 1][r][nt * 16 + col] = (unsigned)sm;
     }
     __syncthreads();
     const bool scaled_buffer = op.parent_sc >= 0;
+    double *pc = v.clv + (size_t)(op.parent_clv - v.tips) * v.clv_stride;
 #pragma unroll
     for (int nt = 0; nt < kMfmaNT; ++nt) {
-      const unsigned site = site0 + nt * 16 + col;
       bool all_small = scaled_buffer;
-      for (unsigned q = 0; q < R; ++q) all_small = all_small && flags[q][nt * 16 + col];
-      if (site < S) {
-        if (scaled_buffer && r == 0 && grp == 0) {
-          const unsigned sc = (op.child1_sc >= 0 ? v.scaler[(size_t)op.child1_sc * S + site] : 0u) +
-                              (op.child2_sc >= 0 ? v.scaler[(size_t)op.child2_sc * S + site] : 0u) +
-                              (all_small ? 1u : 0u);
-          v.scaler[(size_t)op.parent_sc * S + site] = sc;
-        }
-        double *dst = pc + ((size_t)site * R + r) * kMfmaK + grp;
+      for (unsigned q = 0; q < R; ++q) all_small = all_small && flags[oi & 1][q][nt * 16 + col];
+      if (all_small) {
+#pragma unroll
+        for (int t = 0; t < kMfmaTiles; ++t)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) res[nt][t][q] *= kScaleFactor;
+      }
+      osc[nt] = scaled_buffer ? sc1[nt] + sc2[nt] + (all_small ? 1u : 0u) : 0u;
+      if (site[nt] < S) {
+        if (scaled_buffer && sc_lane) v.scaler[(size_t)op.parent_sc * S + site[nt]] = osc[nt];
+        double *dst = pc + ((size_t)site[nt] * R + r) * kMfmaK + grp;
 #pragma unroll
         for (int t = 0; t < kMfmaTiles; ++t)
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const int row = 16 * t + 4 * q;   // + grp
-            if (row + (int)grp < kMfmaK)
-              dst[row] = all_small ? res[nt][t][q] * kScaleFactor : res[nt][t][q];
+            if (row + (int)grp < kMfmaK) dst[row] = res[nt][t][q];
           }
       }
     }
-    // stores of this operation are ordered before the next operation's loads
-    // of them (same workgroup), and the flags array may be rewritten
-    __threadfence_block();
-    __syncthreads();
+    if (more) {   // operands of the next operation (other waves of the CU cover the latency)
+      load_a(nx, a1, a2);
+      load_b(nx.src1, nx.child1_clv, nx.child1_sc, b1, sc1);
+      load_b(nx.src2, nx.child2_clv, nx.child2_sc, b2, sc2);
+    }
   }
 }
 
@@ -169,7 +218,10 @@ hipError_t launch_clv_k20_traversal(rdamd_partition *p, const LevelOp *d_ops, un
   DeviceView v = p->view();
   const unsigned per_block = 16 * kMfmaNT;
   const unsigned gx = (p->sites + per_block - 1) / per_block;
-  clv_k20_traversal_kernel<<<gx, 64 * p->rate_cats, 0, p->stream>>>(v, p->d_pmat_mfma, d_ops, nops);
+  if (p->rate_cats <= 4)
+    clv_k20_traversal_kernel<256><<<gx, 64 * p->rate_cats, 0, p->stream>>>(v, p->d_pmat_mfma, d_ops, nops);
+  else
+    clv_k20_traversal_kernel<1024><<<gx, 64 * p->rate_cats, 0, p->stream>>>(v, p->d_pmat_mfma, d_ops, nops);
   return hipGetLastError();
 }
 
