@@ -341,6 +341,13 @@ int rdamd_model_compute_dlh(rdamd_model_t *m, const rdamd_root_location_t *rl, d
 int rdamd_model_move_root(rdamd_model_t *m, const rdamd_root_location_t *rl);  /* :823 */
 /* compute_all_root_lh, :1737-1746: out holds root_count values */
 int rdamd_model_compute_all_root_lh(rdamd_model_t *m, double *out);
+/* the same sweep as ONE fused launch (every root a job), partition untouched */
+int rdamd_model_compute_all_root_lh_batched(rdamd_model_t *m, double *out);
+/* heuristic search(min_roots, root_ratio, atol, pgtol, brtol, factor), :1008-1137
+ * (needs rdamd_model_set_lbfgsb); best placement and its lnL are returned. */
+int rdamd_model_search(rdamd_model_t *m, unsigned int min_roots, double root_ratio, double atol,
+                       double pgtol, double brtol, double factor,
+                       rdamd_root_location_t *best_rl, double *best_llh);
 /* optimize_alpha, :679-794 */
 int rdamd_model_optimize_alpha(rdamd_model_t *m, const rdamd_root_location_t *rl, double atol,
                                rdamd_root_location_t *out);

@@ -138,6 +138,9 @@ _sig("rdamd_model_compute_dlh", C.c_int, _vp, _prl, _pd)
 _sig("rdamd_model_move_root", C.c_int, _vp, _prl)
 _sig("rdamd_model_compute_all_root_lh", C.c_int, _vp, _pd)
 _sig("rdamd_model_optimize_alpha", C.c_int, _vp, _prl, C.c_double, _prl)
+_sig("rdamd_model_compute_all_root_lh_batched", C.c_int, _vp, _pd)
+_sig("rdamd_model_search", C.c_int, _vp, _u, C.c_double, C.c_double, C.c_double, C.c_double,
+     C.c_double, _prl, _pd)
 _sig("rdamd_model_compute_lh_batch", C.c_int, _vp, _u, _prl, _pd, _pd, _pd, _pd)
 _sig("rdamd_model_assign_by_rank", C.c_int, _vp, _u, _u)
 _sig("rdamd_model_exhaustive_search_parallel", C.c_int, _vp, _u, C.c_double, C.c_double,
@@ -638,6 +641,19 @@ class Model:
         out = np.zeros(self._tree.root_count(), dtype=np.float64)
         self._ok(lib.rdamd_model_compute_all_root_lh(self._h, _dptr(out)), "compute_all_root_lh")
         return out
+
+    def compute_all_root_lh_batched(self):
+        out = np.zeros(self._tree.root_count(), dtype=np.float64)
+        self._ok(lib.rdamd_model_compute_all_root_lh_batched(self._h, _dptr(out)),
+                 "compute_all_root_lh_batched")
+        return out
+
+    def search(self, min_roots, root_ratio, atol, pgtol, brtol, factor):
+        best = RootLocation()
+        llh = C.c_double(0.0)
+        self._ok(lib.rdamd_model_search(self._h, min_roots, root_ratio, atol, pgtol, brtol, factor,
+                                        C.byref(best), C.byref(llh)), "search")
+        return best, llh.value
 
     def optimize_alpha(self, rl, atol):
         out = RootLocation()

@@ -173,7 +173,11 @@ void model_t::set_freqs_all_free(size_t p, model_params_t freqs) {
 void model_t::set_model_params(const std::vector<partition_parameters_t> &params) {
   for (size_t i = 0; i < params.size(); ++i) {
     set_subst_rates(i, params[i].subst_rates);
-    set_freqs(i, params[i].freqs);
+    // the optimiser's frequency vector is unnormalised (bfgs_freqs applies it
+    // through set_freqs_all_free); the reference re-applies it here with the
+    // plain setter (src/model.cpp:1917), which silently changes the model --
+    // normalise instead so that the reported lnL reproduces
+    set_freqs_all_free(i, params[i].freqs);
     set_gamma_rates(i, params[i].gamma_alpha);
     if (_rate_category_types[i] == rate_category::FREE) set_gamma_weights(i, params[i].gamma_weights);
   }
@@ -318,6 +322,45 @@ std::vector<double> model_t::compute_all_root_lh() {
     out.push_back(compute_lh_root(rl));
   }
   return out;
+}
+
+std::vector<double> model_t::compute_all_root_lh_batched() {
+  const auto &roots = _tree.roots();
+  const size_t n = roots.size();
+  std::vector<double> total(n, 0.0);
+  rooted_tree_t scratch(_tree);   // schedules are generated on a copy: _tree keeps its rooting
+  for (size_t p = 0; p < _partitions.size(); ++p) {
+    rdamd_partition_t *part = _partitions[p];
+    if (rdamd_partition_states(part) != 4)
+      throw std::runtime_error("compute_all_root_lh_batched: 4-state data only");
+    const unsigned R = rdamd_partition_rate_cats(part);
+    const double *cs = rdamd_partition_subst_params(part, 0), *cf = rdamd_partition_frequencies(part, 0);
+    std::vector<rdamd_schedule_t *> owned;
+    std::vector<const rdamd_schedule_t *> scheds(n);
+    std::vector<double> subst(n * 12), freqs(n * 4), rates(n * R), weights(n * R), out(n);
+    for (size_t j = 0; j < n; ++j) {
+      auto sc = scratch.generate_operations(roots[j]);
+      rdamd_schedule_t *s = rdamd_schedule_create(
+          part, std::get<0>(sc).data(), (unsigned)std::get<0>(sc).size(), std::get<1>(sc).data(),
+          std::get<2>(sc).data(), (unsigned)std::get<1>(sc).size());
+      if (!s) {
+        for (auto o : owned) rdamd_schedule_destroy(o);
+        fail("schedule_create");
+      }
+      owned.push_back(s);
+      scheds[j] = s;
+      std::copy(cs, cs + 12, subst.begin() + j * 12);
+      std::copy(cf, cf + 4, freqs.begin() + j * 4);
+      std::copy(_rate_rates[p].begin(), _rate_rates[p].end(), rates.begin() + j * R);
+      std::copy(_rate_weights[p].begin(), _rate_weights[p].end(), weights.begin() + j * R);
+    }
+    int ok = rdamd_evaluate_batch(part, (unsigned)n, scheds.data(), subst.data(), freqs.data(),
+                                  rates.data(), weights.data(), out.data());
+    for (auto o : owned) rdamd_schedule_destroy(o);
+    if (ok != RDAMD_SUCCESS) fail("evaluate_batch");
+    for (size_t j = 0; j < n; ++j) total[j] += out[j];
+  }
+  return total;
 }
 
 std::vector<double> model_t::compute_lh_batch(
@@ -474,9 +517,16 @@ root_location_t model_t::optimize_alpha(const root_location_t &root, double atol
 
 std::vector<root_location_t> model_t::suggest_roots_lh(size_t min, double ratio) {
   std::vector<std::pair<root_location_t, double>> v;
-  for (auto rl : _tree.roots()) {
-    move_root(rl);
-    v.emplace_back(rl, compute_lh_root(rl));
+  bool all_dna = true;
+  for (auto p : _partitions) all_dna = all_dna && rdamd_partition_states(p) == 4;
+  if (all_dna) {   // every root in one fused launch; the partition state is not disturbed
+    auto lh = compute_all_root_lh_batched();
+    for (size_t i = 0; i < lh.size(); ++i) v.emplace_back(_tree.roots()[i], lh[i]);
+  } else {
+    for (auto rl : _tree.roots()) {
+      move_root(rl);
+      v.emplace_back(rl, compute_lh_root(rl));
+    }
   }
   size_t keep = std::max((size_t)(v.size() * ratio), min);
   keep = std::min(keep, v.size());
@@ -641,6 +691,68 @@ void model_t::optimize_params(std::vector<partition_parameters_t> &params,
     }
     rdamd_schedule_destroy(sched);
   }
+}
+
+// ---- heuristic search (src/model.cpp:1008-1137) ---------------------------------------
+std::pair<root_location_t, double> model_t::search(size_t min_roots, double root_ratio,
+                                                   double atol, double pgtol, double brtol,
+                                                   double factor,
+                                                   std::vector<rd_result_t> *results) {
+  if (!_setulb && !_optimizer)
+    throw std::runtime_error("search: no parameter optimiser set (set_lbfgsb)");
+  set_subst_rates_uniform();
+  set_empirical_freqs();
+  std::vector<rd_result_t> local;
+  std::vector<std::vector<partition_parameters_t>> local_params;
+  for (auto rl_index : _assigned_idx) {
+    root_location_t rl = _tree.root_location(rl_index);
+    set_subst_rates_uniform();
+    set_empirical_freqs();
+    std::vector<partition_parameters_t> params, saved;
+    for (size_t p = 0; p < _partitions.size(); ++p)
+      params.push_back(make_partition_parameters(rdamd_partition_states(_partitions[p]),
+                                                 _rate_category_types[p],
+                                                 rdamd_partition_rate_cats(_partitions[p])));
+    root_location_t cur_best_rl = rl;
+    double cur_best_lh = -std::numeric_limits<double>::infinity();
+    for (size_t iter = 0; iter < 1000; ++iter) {
+      saved = params;
+      if (_optimizer) _optimizer(*this, params, rl, pgtol, factor, true);
+      else optimize_params(params, rl, pgtol, factor, true);
+      compute_lh(rl);   // CLVs consistent with the new parameters before roots are moved
+      auto cur = optimize_root_location(min_roots, root_ratio);
+      if (cur.second < cur_best_lh) {   // no progress: restore and give up
+        set_model_params(saved);
+        params = saved;
+        break;
+      }
+      if (_early_stop && rl.edge == cur.first.edge &&
+          std::fabs(rl.brlen_ratio - cur.first.brlen_ratio) < brtol) {
+        cur_best_rl = cur.first; cur_best_lh = cur.second;
+        break;
+      }
+      if (std::fabs(cur.second - cur_best_lh) < atol) {
+        cur_best_rl = cur.first; cur_best_lh = cur.second;
+        break;
+      }
+      cur_best_rl = cur.first; cur_best_lh = cur.second;
+      rl = cur_best_rl;
+    }
+    local.push_back({cur_best_rl.id, cur_best_lh, cur_best_rl.brlen_ratio});
+    local_params.push_back(params);
+  }
+  root_location_t best_rl;
+  double best_llh = -std::numeric_limits<double>::infinity();
+  for (size_t i = 0; i < local.size(); ++i)
+    if (local[i].llh > best_llh) {
+      best_llh = local[i].llh;
+      best_rl = _tree.root_location(local[i].root_id);
+      best_rl.brlen_ratio = local[i].alpha;
+      set_model_params(local_params[i]);
+    }
+  if (!local.empty()) compute_lh(best_rl);
+  if (results) *results = local;
+  return {best_rl, best_llh};
 }
 
 // ---- exhaustive outer loop (src/model.cpp:1139-1272) ----------------------------------

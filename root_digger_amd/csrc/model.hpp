@@ -87,6 +87,10 @@ public:
   dlh_t  compute_dlh(const root_location_t &root_location);     // :481-519
   void   move_root(const root_location_t &new_root);            // :823-854
   std::vector<double> compute_all_root_lh();                    // :1737-1746
+  // the same sweep at the current parameters as ONE fused launch (every root a
+  // job; 4-state data): what the all-directions CLV cache of SURVEY 8f item 2
+  // was meant to buy, without storing any CLV.  Partition state is untouched.
+  std::vector<double> compute_all_root_lh_batched();
 
   // batched objective: lnL of (root, parameter set) pairs, all partitions,
   // through rdamd_evaluate_batch (one fused launch per partition)
@@ -123,6 +127,10 @@ public:
   size_t objective_batches() const { return _objective_batches; }
   size_t objective_evaluations() const { return _objective_evals; }
 
+  // heuristic search, src/model.cpp:1008-1137 (needs set_lbfgsb)
+  std::pair<root_location_t, double> search(size_t min_roots, double root_ratio, double atol,
+                                            double pgtol, double brtol, double factor,
+                                            std::vector<rd_result_t> *results = nullptr);
   // src/model.cpp:1139-1272; results (one per assigned root) are returned
   // instead of going through the checkpoint file.
   std::pair<root_location_t, double> exhaustive_search(double atol, double pgtol, double brtol,

@@ -162,6 +162,23 @@ int rdamd_model_compute_all_root_lh(rdamd_model_t *m, double *out) {
     return RDAMD_SUCCESS;
   })
 }
+int rdamd_model_compute_all_root_lh_batched(rdamd_model_t *m, double *out) {
+  GUARD(RDAMD_FAILURE, {
+    auto v = m->model->compute_all_root_lh_batched();
+    for (size_t i = 0; i < v.size(); ++i) out[i] = v[i];
+    return RDAMD_SUCCESS;
+  })
+}
+int rdamd_model_search(rdamd_model_t *m, unsigned int min_roots, double root_ratio, double atol,
+                       double pgtol, double brtol, double factor,
+                       rdamd_root_location_t *best_rl, double *best_llh) {
+  GUARD(RDAMD_FAILURE, {
+    auto best = m->model->search(min_roots, root_ratio, atol, pgtol, brtol, factor, nullptr);
+    if (best_rl) to_c(best.first, best_rl);
+    if (best_llh) *best_llh = best.second;
+    return RDAMD_SUCCESS;
+  })
+}
 int rdamd_model_optimize_alpha(rdamd_model_t *m, const rdamd_root_location_t *rl, double atol,
                                rdamd_root_location_t *out) {
   GUARD(RDAMD_FAILURE, { to_c(m->model->optimize_alpha(to_cpp(rl), atol), out); return RDAMD_SUCCESS; })

@@ -160,3 +160,38 @@ def test_parallel_exhaustive_search_equals_sequential(lbfgsb):
     assert np.array_equal(par["llh"], seq["llh"][order])
     assert np.array_equal(par["alpha"], seq["alpha"][order])
     assert par["best_llh"] == seq["best_llh"]
+
+
+def test_batched_root_sweep_equals_move_root_sweep():
+    """all 2n-3 root lnLs at fixed parameters: one fused launch vs the reference's
+    move_root sweep (src/model.cpp:865-889, :1737-1746)."""
+    tree = rd.Tree.from_file(os.path.join(util.DATA, "101.tree"))
+    seqs, w = util.compress(util.read_phylip(os.path.join(util.DATA, "101.phy")))
+    m = rd.Model(tree, seqs, rate_cats=4, weights=w, seed=4)
+    m.initialize_partitions()
+    m.set_gamma_alpha(0.6)
+    a = m.compute_all_root_lh_batched()
+    b = m.compute_all_root_lh()
+    assert len(a) == 199
+    assert np.max(np.abs(a - b) / np.abs(b)) < 1e-12
+    # the batch leaves model state alone: the sweep state (last root) is still valid
+    last = tree.root_location(198)
+    assert util.rel_err(m.compute_lh_root(last), b[198]) < 1e-13
+
+
+def test_heuristic_search(lbfgsb):
+    """model_t::search (src/model.cpp:1008-1137) as test/src/model.cpp:310-346 checks
+    it: the final lnL reproduces under compute_lh and beats the start."""
+    tree = rd.Tree.from_file(os.path.join(util.DATA, "10.tree"))
+    seqs = util.read_fasta(os.path.join(util.DATA, "10.fasta"))
+    m = rd.Model(tree, seqs, rate_cats=1, seed=21, early_stop=True)
+    m.initialize_partitions()
+    m.set_lbfgsb(lbfgsb.setulb)
+    m.set_subst_rates_uniform()
+    m.set_empirical_freqs()
+    initial = m.compute_lh(tree.root_location(0))
+    m.assign_by_rank(0, 17)                       # one starting root, like min_roots = 1
+    best, llh = m.search(1, 0.0, 1e-5, 1e-5, 1e-7, 1e7)
+    assert llh >= initial
+    assert 0.0 <= best.brlen_ratio <= 1.0
+    assert abs(m.compute_lh(best) - llh) < 1e-6 * abs(llh)
