@@ -36,12 +36,14 @@ enum : unsigned { kSrcTip = 0, kSrcMem = 1, kSrcReg = 2 };
 template <int R>
 __global__ void __launch_bounds__(256)
 clv_dna_traversal_kernel(DeviceView v, const LevelOp *__restrict__ ops, unsigned nops) {
-  // Per WAVE, double-buffered: P-matrix [R][4][4] or tip table [R][16][4] of
-  // both children.  Waves never synchronise with each other: each stages the
-  // matrices of operation i+1 itself while operation i computes.
-  __shared__ double smat_all[4][2][2][R * 64];
+  // Per WAVE, double-buffered: the P-matrices [R][4][4] of both children.
+  // Waves never synchronise with each other: each stages the matrices of
+  // operation i+1 itself while operation i computes.  (A tip child is expanded
+  // from its code to a 0/1 vector and goes through the same product: this kernel
+  // is bound by HBM, not by FMAs, and P is a quarter of the tip table to stage.)
+  __shared__ double smat_all[4][2][2][R * 16];
   const unsigned tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  double (*smat)[2][R * 64] = smat_all[wave];
+  double (*smat)[2][R * 16] = smat_all[wave];
   const unsigned S = v.sites;
   const size_t total = (size_t)S * R;
   const size_t idx = (size_t)blockIdx.x * 256 + tid;   // one (site, rate) pair per lane
@@ -53,26 +55,25 @@ clv_dna_traversal_kernel(DeviceView v, const LevelOp *__restrict__ ops, unsigned
   // wave ever sits on a global load it has just issued: while operation i
   // computes, the matrices, tip codes and older-sibling CLVs of operation i+1
   // are all in flight.
-  constexpr int kStageRegs = (R * 64 + 63) / 64;   // doubles per lane per child
+  constexpr int kStageRegs = (R * 16 + 63) / 64;   // doubles per lane per child
   auto stage_load = [&](const LevelOp &op, double (&s1)[kStageRegs], double (&s2)[kStageRegs]) {
-    const bool t1 = op.src1 == kSrcTip, t2 = op.src2 == kSrcTip;
-    const double *src1 = t1 ? v.tiptab + (size_t)op.child1_mat * R * 64
-                            : v.pmat + (size_t)op.child1_mat * R * 16;
-    const double *src2 = t2 ? v.tiptab + (size_t)op.child2_mat * R * 64
-                            : v.pmat + (size_t)op.child2_mat * R * 16;
-    const unsigned n1 = t1 ? R * 64 : R * 16, n2 = t2 ? R * 64 : R * 16;
+    const double *src1 = v.pmat + (size_t)op.child1_mat * R * 16;
+    const double *src2 = v.pmat + (size_t)op.child2_mat * R * 16;
 #pragma unroll
     for (int k = 0; k < kStageRegs; ++k) {
       const unsigned e = lane + 64 * k;
-      s1[k] = e < n1 ? src1[e] : 0.0;
-      s2[k] = e < n2 ? src2[e] : 0.0;
+      s1[k] = e < R * 16 ? src1[e] : 0.0;
+      s2[k] = e < R * 16 ? src2[e] : 0.0;
     }
   };
   auto stage_write = [&](unsigned buf, const double (&s1)[kStageRegs], const double (&s2)[kStageRegs]) {
 #pragma unroll
     for (int k = 0; k < kStageRegs; ++k) {
-      smat[buf][0][lane + 64 * k] = s1[k];
-      smat[buf][1][lane + 64 * k] = s2[k];
+      const unsigned e = lane + 64 * k;
+      if (e < R * 16) {
+        smat[buf][0][e] = s1[k];
+        smat[buf][1][e] = s2[k];
+      }
     }
   };
   // an older sibling (not produced by the operation just before) comes from
@@ -126,6 +127,9 @@ clv_dna_traversal_kernel(DeviceView v, const LevelOp *__restrict__ ops, unsigned
 #pragma unroll
       for (int k = 0; k < 4; ++k) x[k] = m1[k];
       xsc = m1sc;
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) x[k] = ((ccx >> k) & 1u) ? 1.0 : 0.0;
     }
     if (op.src2 == kSrcReg) {
 #pragma unroll
@@ -135,6 +139,9 @@ clv_dna_traversal_kernel(DeviceView v, const LevelOp *__restrict__ ops, unsigned
 #pragma unroll
       for (int k = 0; k < 4; ++k) y[k] = m2[k];
       ysc = m2sc;
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) y[k] = ((ccy >> k) & 1u) ? 1.0 : 0.0;
     }
     // issue everything the NEXT operation needs
     double s1[kStageRegs], s2[kStageRegs];
@@ -143,22 +150,12 @@ clv_dna_traversal_kernel(DeviceView v, const LevelOp *__restrict__ ops, unsigned
       prefetch(nx, m1, m1sc, m2, m2sc, cx, cy);
     }
     double t1[4], t2[4];
-    if (op.src1 == kSrcTip) {
-      const double *row = &smat[buf][0][(r * 16 + ccx) * 4];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) t1[k] = row[k];
-    } else {
+    {
       const double *m = &smat[buf][0][r * 16];
 #pragma unroll
       for (int k = 0; k < 4; ++k)
         t1[k] = m[k * 4 + 0] * x[0] + m[k * 4 + 1] * x[1] + m[k * 4 + 2] * x[2] + m[k * 4 + 3] * x[3];
-    }
-    if (op.src2 == kSrcTip) {
-      const double *row = &smat[buf][1][(r * 16 + ccy) * 4];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) t2[k] = row[k];
-    } else {
-      const double *m = &smat[buf][1][r * 16];
+      m = &smat[buf][1][r * 16];
 #pragma unroll
       for (int k = 0; k < 4; ++k)
         t2[k] = m[k * 4 + 0] * y[0] + m[k * 4 + 1] * y[1] + m[k * 4 + 2] * y[2] + m[k * 4 + 3] * y[3];
