@@ -128,9 +128,18 @@ struct LevelOp {   // device-side op descriptor
   unsigned parent_clv, child1_clv, child2_clv;     // absolute clv indices
   unsigned child1_mat, child2_mat;
   int parent_sc, child1_sc, child2_sc;
-  unsigned src1, src2;   // 0 tip, 1 memory, 2 register (= parent of the previous op)
+  // where each child comes from: 0 tip, 1 memory, 2 register (= parent of the
+  // previous op), 3+s = LDS parking slot s (4-state kernel only)
+  unsigned src1, src2;
+  unsigned park;         // 1+s: also park the parent in LDS slot s; 0: do not
+  unsigned late;         // bit c: memory child c is written by the op just before (no prefetch)
 };
-hipError_t launch_clv_traversal(rdamd_partition *p, const LevelOp *d_ops, unsigned nops);
+// LDS parking slots per lane the 4-state traversal kernel will have for this
+// partition (0 for the other kernels): an older sibling waits there instead of
+// being read back from HBM.
+unsigned clv_traversal_slots(const rdamd_partition *p);
+hipError_t launch_clv_traversal(rdamd_partition *p, const LevelOp *d_ops, unsigned nops,
+                                unsigned slots);
 
 // kernels_clv_mfma.hip (20 states)
 hipError_t launch_pmat_to_mfma(rdamd_partition *p, const unsigned *d_matrix_indices, unsigned count);

@@ -24,6 +24,8 @@
 // pipe is an almost pure store stream.
 #include "common.hpp"
 
+#include <algorithm>
+
 namespace rdamd {
 
 // ---------------------------------------------------------------------------
@@ -31,17 +33,22 @@ namespace rdamd {
 // so the "all entries below threshold" test is an in-wave AND.
 // ---------------------------------------------------------------------------
 // LevelOp::src* values
-enum : unsigned { kSrcTip = 0, kSrcMem = 1, kSrcReg = 2 };
+enum : unsigned { kSrcTip = 0, kSrcMem = 1, kSrcReg = 2, kSrcPark = 3 };
 
 template <int R>
 __global__ void __launch_bounds__(256)
-clv_dna_traversal_kernel(DeviceView v, const LevelOp *__restrict__ ops, unsigned nops) {
+clv_dna_traversal_kernel(DeviceView v, const LevelOp *__restrict__ ops, unsigned nops,
+                         unsigned slots) {
   // Per WAVE, double-buffered: the P-matrices [R][4][4] of both children.
   // Waves never synchronise with each other: each stages the matrices of
   // operation i+1 itself while operation i computes.  (A tip child is expanded
   // from its code to a 0/1 vector and goes through the same product: this kernel
   // is bound by HBM, not by FMAs, and P is a quarter of the tip table to stage.)
   __shared__ double smat_all[4][2][2][R * 16];
+  // LDS parking: `slots` CLVs (+ scaler counts) per lane, [slot][half][lane] so
+  // every 16-byte access of a wave is conflict-free.  An older sibling waits
+  // here for its operation instead of being read back from HBM.
+  extern __shared__ double2 park_lds[];
   const unsigned tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   double (*smat)[2][R * 16] = smat_all[wave];
   const unsigned S = v.sites;
@@ -90,9 +97,15 @@ clv_dna_traversal_kernel(DeviceView v, const LevelOp *__restrict__ ops, unsigned
   auto prefetch = [&](const LevelOp &op, double (&m1)[4], unsigned &m1sc, double (&m2)[4],
                       unsigned &m2sc, unsigned &cx, unsigned &cy) {
     if (op.src1 == kSrcTip) cx = v.tipcodes[(size_t)op.child1_clv * S + s];
-    else if (op.src1 == kSrcMem) fetch(op, 0, m1, m1sc);
+    else if (op.src1 == kSrcMem && !(op.late & 1u)) fetch(op, 0, m1, m1sc);
     if (op.src2 == kSrcTip) cy = v.tipcodes[(size_t)op.child2_clv * S + s];
-    else if (op.src2 == kSrcMem) fetch(op, 1, m2, m2sc);
+    else if (op.src2 == kSrcMem && !(op.late & 2u)) fetch(op, 1, m2, m2sc);
+  };
+  unsigned *park_sc = reinterpret_cast<unsigned *>(park_lds + (size_t)slots * 512);
+  auto unpark = [&](unsigned slot, double (&x)[4], unsigned &sc) {
+    const double2 a = park_lds[(slot * 2) * 256 + tid], b = park_lds[(slot * 2 + 1) * 256 + tid];
+    x[0] = a.x; x[1] = a.y; x[2] = b.x; x[3] = b.y;
+    sc = park_sc[slot * 256 + tid];
   };
 
   double o[4] = {0, 0, 0, 0};       // the CLV this lane produced last
@@ -124,24 +137,30 @@ clv_dna_traversal_kernel(DeviceView v, const LevelOp *__restrict__ ops, unsigned
       for (int k = 0; k < 4; ++k) x[k] = o[k];
       xsc = osc;
     } else if (op.src1 == kSrcMem) {
+      if (op.late & 1u) fetch(op, 0, m1, m1sc);
 #pragma unroll
       for (int k = 0; k < 4; ++k) x[k] = m1[k];
       xsc = m1sc;
-    } else {
+    } else if (op.src1 == kSrcTip) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) x[k] = ((ccx >> k) & 1u) ? 1.0 : 0.0;
+    } else {
+      unpark(op.src1 - kSrcPark, x, xsc);
     }
     if (op.src2 == kSrcReg) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) y[k] = o[k];
       ysc = osc;
     } else if (op.src2 == kSrcMem) {
+      if (op.late & 2u) fetch(op, 1, m2, m2sc);
 #pragma unroll
       for (int k = 0; k < 4; ++k) y[k] = m2[k];
       ysc = m2sc;
-    } else {
+    } else if (op.src2 == kSrcTip) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) y[k] = ((ccy >> k) & 1u) ? 1.0 : 0.0;
+    } else {
+      unpark(op.src2 - kSrcPark, y, ysc);
     }
     // issue everything the NEXT operation needs
     double s1[kStageRegs], s2[kStageRegs];
@@ -180,6 +199,12 @@ clv_dna_traversal_kernel(DeviceView v, const LevelOp *__restrict__ ops, unsigned
       double2 *pc = reinterpret_cast<double2 *>(v.clv + (size_t)(op.parent_clv - v.tips) * v.clv_stride);
       pc[idx * 2] = make_double2(o[0], o[1]);
       pc[idx * 2 + 1] = make_double2(o[2], o[3]);
+    }
+    if (op.park) {
+      const unsigned slot = op.park - 1;
+      park_lds[(slot * 2) * 256 + tid] = make_double2(o[0], o[1]);
+      park_lds[(slot * 2 + 1) * 256 + tid] = make_double2(o[2], o[3]);
+      park_sc[slot * 256 + tid] = osc;
     }
     if (more) stage_write(buf ^ 1, s1, s2);
   }
@@ -254,7 +279,25 @@ static inline bool dna_fast_ok(unsigned K, unsigned R, unsigned cap) {
   return K == 4 && cap == 16 && (R == 1 || R == 2 || R == 4 || R == 8);
 }
 
-hipError_t launch_clv_traversal(rdamd_partition *p, const LevelOp *d_ops, unsigned nops) {
+constexpr size_t kComputeUnits = 256;   // MI355X: 8 XCDs x 32 CUs
+constexpr size_t kMaxParkSlots = 6;   // static + dynamic LDS stays under 64 KB per block
+
+// Slots are sized so that every block of the launch is resident at once (the
+// blocks of one CU share its 160 KB of LDS): a second dispatch round would cost
+// more than the read-backs the extra slots save.
+unsigned clv_traversal_slots(const rdamd_partition *p) {
+  if (!dna_fast_ok(p->states, p->rate_cats, p->ncodes_cap) || p->sites == 0) return 0;
+  const size_t total = (size_t)p->sites * p->rate_cats;
+  const size_t blocks = (total + 255) / 256;
+  const size_t per_cu = (blocks + kComputeUnits - 1) / kComputeUnits;
+  const size_t lds_static = 8u * 1024, per_slot = 256 * (32 + 4);
+  const size_t budget = (size_t)(160 * 1024) / std::max<size_t>(per_cu, 1);
+  if (budget <= lds_static) return 0;
+  return (unsigned)std::min<size_t>((budget - lds_static) / per_slot, kMaxParkSlots);
+}
+
+hipError_t launch_clv_traversal(rdamd_partition *p, const LevelOp *d_ops, unsigned nops,
+                                unsigned slots) {
   if (nops == 0 || p->sites == 0) return hipSuccess;
   DeviceView v = p->view();
   const unsigned K = p->states, R = p->rate_cats;
@@ -263,11 +306,12 @@ hipError_t launch_clv_traversal(rdamd_partition *p, const LevelOp *d_ops, unsign
     // parallelism; the lane -> pair map is identical for every operation
     size_t total = (size_t)p->sites * R;
     unsigned gx = (unsigned)((total + 255) / 256);
+    const size_t lds = (size_t)slots * 256 * (32 + 4);
     switch (R) {
-      case 1: clv_dna_traversal_kernel<1><<<gx, 256, 0, p->stream>>>(v, d_ops, nops); break;
-      case 2: clv_dna_traversal_kernel<2><<<gx, 256, 0, p->stream>>>(v, d_ops, nops); break;
-      case 4: clv_dna_traversal_kernel<4><<<gx, 256, 0, p->stream>>>(v, d_ops, nops); break;
-      default: clv_dna_traversal_kernel<8><<<gx, 256, 0, p->stream>>>(v, d_ops, nops); break;
+      case 1: clv_dna_traversal_kernel<1><<<gx, 256, lds, p->stream>>>(v, d_ops, nops, slots); break;
+      case 2: clv_dna_traversal_kernel<2><<<gx, 256, lds, p->stream>>>(v, d_ops, nops, slots); break;
+      case 4: clv_dna_traversal_kernel<4><<<gx, 256, lds, p->stream>>>(v, d_ops, nops, slots); break;
+      default: clv_dna_traversal_kernel<8><<<gx, 256, lds, p->stream>>>(v, d_ops, nops, slots); break;
     }
   } else {
     unsigned gx = (p->sites + 255) / 256;

@@ -417,10 +417,85 @@ void rdamd_update_clvs(rdamd_partition_t *p, const rdamd_operation_t *ops,
     d.child2_clv = o.child2_clv_index; d.child1_mat = o.child1_matrix_index;
     d.child2_mat = o.child2_matrix_index; d.parent_sc = o.parent_scaler_index;
     d.child1_sc = o.child1_scaler_index; d.child2_sc = o.child2_scaler_index;
-    const unsigned prev = i ? ops[i - 1].parent_clv_index : ~0u;
-    d.src1 = o.child1_clv_index < p->tips ? 0u : (o.child1_clv_index == prev ? 2u : 1u);
-    d.src2 = o.child2_clv_index < p->tips ? 0u : (o.child2_clv_index == prev ? 2u : 1u);
-    if (d.src1 == 2u && d.src2 == 2u) d.src2 = 1u;   // same CLV twice: read one back
+    d.src1 = o.child1_clv_index < p->tips ? 0u : 1u;
+    d.src2 = o.child2_clv_index < p->tips ? 0u : 1u;
+    d.park = d.late = 0;
+  }
+  // Where does each inner child come from?  The parent of the operation just
+  // before stays in the lane's registers; an older sibling waits in one of the
+  // kernel's LDS parking slots when one is free (shortest wait wins: when the
+  // slots are full the value needed furthest in the future gives its slot up
+  // and is read back from HBM instead -- every CLV is written there anyway).
+  // A child is forwarded only when its scaler index is the producer's.
+  const unsigned nslots = clv_traversal_slots(p);
+  {
+    std::vector<int> producer(nclv, -1);            // clv -> op that last wrote it
+    std::vector<int> consumer(count, -1);           // op -> first later op reading its parent
+    std::vector<int> which(count, 0);
+    for (unsigned i = 0; i < count; ++i) {
+      const rdamd_operation_t &o = ops[i];
+      const unsigned ch[2] = {o.child1_clv_index, o.child2_clv_index};
+      const int chsc[2] = {o.child1_scaler_index, o.child2_scaler_index};
+      for (int c = 0; c < 2; ++c) {
+        if (ch[c] < p->tips || (c == 1 && ch[1] == ch[0])) continue;
+        const int j = producer[ch[c]];
+        if (j >= 0 && consumer[j] < 0 && ops[j].parent_scaler_index == chsc[c]) {
+          consumer[j] = (int)i;
+          which[j] = c;
+        }
+      }
+      producer[o.parent_clv_index] = (int)i;
+    }
+    // a memory child that the operation just before writes cannot be fetched
+    // ahead of that store (bit 0 / 1 of `late`); forwarded children overwrite
+    // their src below and the bit is then ignored
+    for (unsigned i = 1; i < count; ++i) {
+      if (ops[i].child1_clv_index == ops[i - 1].parent_clv_index) lops[i].late |= 1u;
+      if (ops[i].child2_clv_index == ops[i - 1].parent_clv_index) lops[i].late |= 2u;
+    }
+    // a value overwritten before its consumer runs cannot be forwarded
+    // (cannot happen in a tree traversal; guards arbitrary lists)
+    std::fill(producer.begin(), producer.end(), -1);
+    std::vector<int> slot_owner(nslots, -1);
+    auto set_src = [&](int j, unsigned kind) {
+      LevelOp &c = lops[consumer[j]];
+      (which[j] ? c.src2 : c.src1) = kind;
+    };
+    for (unsigned i = 0; i < count; ++i) {
+      for (unsigned sl = 0; sl < nslots; ++sl)      // slots whose value is consumed now
+        if (slot_owner[sl] >= 0 && consumer[slot_owner[sl]] == (int)i) slot_owner[sl] = -1;
+      const int c = consumer[i];
+      if (c < 0) continue;
+      bool clobbered = false;
+      for (int k = (int)i + 1; k < c; ++k)
+        if (ops[k].parent_clv_index == ops[i].parent_clv_index) clobbered = true;
+      if (clobbered) continue;
+      if (c == (int)i + 1) {
+        set_src((int)i, 2u);
+        // the same CLV as both children: both come from the registers
+        if (ops[c].child1_clv_index == ops[c].child2_clv_index &&
+            ops[c].child1_scaler_index == ops[c].child2_scaler_index)
+          lops[c].src1 = lops[c].src2 = 2u;
+        continue;
+      }
+      if (nslots == 0) continue;
+      int take = -1, far = -1;
+      for (unsigned sl = 0; sl < nslots; ++sl) {
+        if (slot_owner[sl] < 0) { take = (int)sl; far = -1; break; }
+        if (far < 0 || consumer[slot_owner[sl]] > consumer[slot_owner[far]]) far = (int)sl;
+      }
+      if (take < 0 && far >= 0 && consumer[slot_owner[far]] > c) {
+        const int ev = slot_owner[far];             // give the slot to the shorter wait
+        set_src(ev, 1u);
+        lops[ev].park = 0;
+        take = far;
+      }
+      if (take >= 0) {
+        slot_owner[take] = (int)i;
+        lops[i].park = 1u + (unsigned)take;
+        set_src((int)i, 3u + (unsigned)take);
+      }
+    }
   }
   // The whole list runs as one launch in the caller's order: every dependency
   // is site-local, so the kernel needs no level structure (kernels_clv.hip).
@@ -436,7 +511,7 @@ void rdamd_update_clvs(rdamd_partition_t *p, const rdamd_operation_t *ops,
     if (e == hipSuccess) {
       p->prof_begin(0);
       e = p->d_pmat_mfma ? launch_clv_k20_traversal(p, d_ops, count)
-                         : launch_clv_traversal(p, d_ops, count);
+                         : launch_clv_traversal(p, d_ops, count, nslots);
       p->prof_end();
     }
   }

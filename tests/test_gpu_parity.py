@@ -533,6 +533,73 @@ def test_thousand_taxon_tree_vs_oracle():
     compare_state(g, o, [ops[i] for i in (0, 500, 998)], tree)
 
 
+@pytest.mark.parametrize("n,S,R,seed", [(64, 700, 4, 71), (150, 300, 2, 72), (40, 9000, 4, 73)])
+def test_arbitrary_operation_orders(n, S, R, seed):
+    """rdamd_update_clvs takes ANY valid list (corax_update_clvs contract), not
+    only the post-order the tree emits.  The 4-state kernel forwards children
+    through registers and LDS parking slots depending on the order, so feed it
+    orders that stress each route: level order (every sibling waits long ->
+    slots overflow, values evicted to HBM), reversed-sibling order, the same
+    CLV as both children, a child read with a different scaler index than it
+    was written with, and a partial list over CLVs left by an earlier call."""
+    w = synth.workload(n, S, 4, R, seed)
+    tree = rd.Tree.from_newick(w["newick"])
+    g, o = pair(tree, w["seqs"], 4, R)
+    set_model((g, o), w["subst"], g.empirical_frequencies(), w["rates"])
+    rl = tree.root_location(seed % tree.root_count())
+    ops, pmi, brl = tree.generate_operations(rl)
+    ops = [rd.Operation(*op.astuple()) for op in ops]
+    for p in (g, o):
+        p.update_prob_matrices(pmi, brl)
+
+    def run(op_list):
+        for p in (g, o):
+            p.update_clvs(op_list)
+        compare_state(g, o, op_list, tree)
+
+    # 1. level order: an operation runs as soon as both children exist
+    done = set(range(n))
+    pending, level_order = list(ops), []
+    while pending:
+        ready = [op for op in pending if op.child1_clv_index in done and op.child2_clv_index in done]
+        assert ready
+        level_order += ready
+        done |= {op.parent_clv_index for op in ready}
+        pending = [op for op in pending if op.parent_clv_index not in done]
+    run(level_order)
+    a = g.compute_root_loglikelihood(tree.root_clv_index(), tree.root_scaler_index())
+    b = o.compute_root_loglikelihood(tree.root_clv_index(), tree.root_scaler_index())
+    assert util.rel_err(a, b) < LNL_TOL
+    # 2. deepest-first order (reverse of level order within the constraints)
+    rng = np.random.default_rng(seed)
+    done, pending, rand_order = set(range(n)), list(ops), []
+    while pending:
+        ready = [op for op in pending if op.child1_clv_index in done and op.child2_clv_index in done]
+        pick = ready[int(rng.integers(len(ready)))]
+        rand_order.append(pick)
+        done.add(pick.parent_clv_index)
+        pending.remove(pick)
+    run(rand_order)
+    # 3. extra operations on spare buffers (for_tree allocates 2n-2 inner CLVs,
+    #    the traversal uses n-1): same CLV twice straight after it is written,
+    #    and a child consumed with scaler -1 although it was written with one
+    spare_clv, spare_sc = 2 * n - 1, n - 1
+    last = ops[-1]
+    twice = rd.Operation(spare_clv, spare_sc, last.parent_clv_index, last.child1_matrix_index,
+                         last.parent_scaler_index, last.parent_clv_index,
+                         last.child2_matrix_index, last.parent_scaler_index)
+    mismatch = rd.Operation(spare_clv + 1, spare_sc + 1, spare_clv, last.child1_matrix_index, -1,
+                            0, last.child2_matrix_index, -1)
+    older = rd.Operation(spare_clv + 2, -1, spare_clv + 1, last.child2_matrix_index, spare_sc + 1,
+                         ops[0].parent_clv_index, last.child1_matrix_index,
+                         ops[0].parent_scaler_index)
+    run(list(ops) + [twice, mismatch, older])
+    # 4. a partial list reading CLVs a previous call left in HBM
+    run([older, twice])
+    g.destroy()
+    o.destroy()
+
+
 def test_zero_site_partition():
     tree = rd.Tree.from_file(os.path.join(util.DATA, "single.tree"))
     g = rd.Partition.for_tree(tree, 4, 0, 4)
