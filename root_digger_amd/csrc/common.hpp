@@ -132,7 +132,7 @@ struct LevelOp {   // device-side op descriptor
   // previous op), 3+s = LDS parking slot s (4-state kernel only)
   unsigned src1, src2;
   unsigned park;         // 1+s: also park the parent in LDS slot s; 0: do not
-  unsigned late;         // bit c: memory child c is written by the op just before (no prefetch)
+  unsigned pad;
 };
 // LDS parking slots per lane the 4-state traversal kernel will have for this
 // partition (0 for the other kernels): an older sibling waits there instead of

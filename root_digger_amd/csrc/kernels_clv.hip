@@ -35,15 +35,33 @@ namespace rdamd {
 // LevelOp::src* values
 enum : unsigned { kSrcTip = 0, kSrcMem = 1, kSrcReg = 2, kSrcPark = 3 };
 
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned uni(unsigned x) {   // assert wave-uniformity
+  return (unsigned)__builtin_amdgcn_readfirstlane((int)x);
+}
+// Buffer descriptor over [p, p+bytes); bytes == 0 makes every access through it
+// a no-op (loads return 0, stores are dropped) -- how a wave-uniform "this
+// operand is not needed" is expressed WITHOUT a branch around the memory
+// instruction: every iteration issues the same instruction sequence, so the
+// s_waitcnt vmcnt counts are exact and no wait ever covers a store.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *p, unsigned bytes) {
+  const unsigned long long u = reinterpret_cast<unsigned long long>(p);
+  const unsigned lo = uni((unsigned)u), hi = uni((unsigned)(u >> 32));
+  void *q = reinterpret_cast<void *>(((unsigned long long)hi << 32) | lo);
+  return __builtin_amdgcn_make_buffer_rsrc(q, 0, (int)uni(bytes), 0x00020000);
+}
+constexpr unsigned kOutOfRange = 0x80000000u;   // offset no descriptor here reaches
+
 template <int R>
 __global__ void __launch_bounds__(256)
 clv_dna_traversal_kernel(DeviceView v, const LevelOp *__restrict__ ops, unsigned nops,
-                         unsigned slots) {
+                         unsigned slots, unsigned pmat_bytes) {
   // Per WAVE, double-buffered: the P-matrices [R][4][4] of both children.
   // Waves never synchronise with each other: each stages the matrices of
   // operation i+1 itself while operation i computes.  (A tip child is expanded
   // from its code to a 0/1 vector and goes through the same product: this kernel
-  // is bound by HBM, not by FMAs, and P is a quarter of the tip table to stage.)
+  // is bound by memory, not by FMAs, and P is a quarter of the tip table to stage.)
   __shared__ double smat_all[4][2][2][R * 16];
   // LDS parking: `slots` CLVs (+ scaler counts) per lane, [slot][half][lane] so
   // every 16-byte access of a wave is conflict-free.  An older sibling waits
@@ -52,26 +70,56 @@ clv_dna_traversal_kernel(DeviceView v, const LevelOp *__restrict__ ops, unsigned
   const unsigned tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   double (*smat)[2][R * 16] = smat_all[wave];
   const unsigned S = v.sites;
-  const size_t total = (size_t)S * R;
-  const size_t idx = (size_t)blockIdx.x * 256 + tid;   // one (site, rate) pair per lane
+  const unsigned total = S * R;                      // < 2^26 (launch_clv_traversal)
+  const unsigned idx = blockIdx.x * 256 + tid;       // one (site, rate) pair per lane
   const bool active = idx < total;
-  const size_t cidx = active ? idx : total - 1;        // clamped for loads
-  const unsigned s = (unsigned)(cidx / R), r = (unsigned)(cidx % R);
+  const unsigned cidx = active ? idx : total - 1;    // clamped for loads
+  const unsigned s = cidx / R, r = cidx % R;
 
-  // Staging is split (load early into registers, write to LDS late) so that no
-  // wave ever sits on a global load it has just issued: while operation i
-  // computes, the matrices, tip codes and older-sibling CLVs of operation i+1
-  // are all in flight.
-  constexpr int kStageRegs = (R * 16 + 63) / 64;   // doubles per lane per child
-  auto stage_load = [&](const LevelOp &op, double (&s1)[kStageRegs], double (&s2)[kStageRegs]) {
-    const double *src1 = v.pmat + (size_t)op.child1_mat * R * 16;
-    const double *src2 = v.pmat + (size_t)op.child2_mat * R * 16;
+  const unsigned clv_bytes = (unsigned)(v.clv_stride * sizeof(double));
+  const unsigned off_clv_ld = cidx * 32u;
+  const unsigned off_clv_st = active ? idx * 32u : kOutOfRange;
+  const unsigned off_sc_st = (active && r == 0) ? s * 4u : kOutOfRange;
+  const __amdgpu_buffer_rsrc_t pmat_rs = make_rsrc(v.pmat, pmat_bytes);
+  auto clv_rs = [&](unsigned clv, bool on) {
+    return make_rsrc(v.clv + (size_t)(on ? clv - v.tips : 0u) * v.clv_stride, on ? clv_bytes : 0u);
+  };
+  auto sc_rs = [&](int scb, bool on) {
+    on = on && scb >= 0;
+    return make_rsrc(v.scaler + (size_t)(on ? scb : 0) * S, on ? S * 4u : 0u);
+  };
+  auto tip_rs = [&](unsigned clv, bool on) {
+    return make_rsrc(v.tipcodes + (size_t)(on ? clv : 0u) * S, on ? S : 0u);
+  };
+
+  struct Child {          // one child operand in flight
+    v4u lo, hi;           // CLV entries 0-1 / 2-3 (memory child)
+    unsigned sc, code;    // its scaler count / tip code
+  };
+  constexpr int kStageRegs = (R * 16 + 63) / 64;     // doubles per lane per child matrix
+  // everything operation `op` needs from memory, issued as ONE fixed
+  // instruction sequence (descriptors with 0 bytes switch parts of it off)
+  auto issue = [&](const LevelOp &op, Child &c1, Child &c2, double (&s1)[kStageRegs],
+                   double (&s2)[kStageRegs]) {
 #pragma unroll
     for (int k = 0; k < kStageRegs; ++k) {
       const unsigned e = lane + 64 * k;
-      s1[k] = e < R * 16 ? src1[e] : 0.0;
-      s2[k] = e < R * 16 ? src2[e] : 0.0;
+      const unsigned off = e < R * 16 ? e * 8u : kOutOfRange;
+      s1[k] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(
+                  pmat_rs, off, (int)uni(op.child1_mat * (R * 128u)), 0));
+      s2[k] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(
+                  pmat_rs, off, (int)uni(op.child2_mat * (R * 128u)), 0));
     }
+    c1.code = (unsigned)__builtin_amdgcn_raw_buffer_load_b8(tip_rs(op.child1_clv, op.src1 == kSrcTip), s, 0, 0);
+    c2.code = (unsigned)__builtin_amdgcn_raw_buffer_load_b8(tip_rs(op.child2_clv, op.src2 == kSrcTip), s, 0, 0);
+    const bool mem1 = op.src1 == kSrcMem, mem2 = op.src2 == kSrcMem;
+    const __amdgpu_buffer_rsrc_t r1 = clv_rs(op.child1_clv, mem1), r2 = clv_rs(op.child2_clv, mem2);
+    c1.lo = __builtin_amdgcn_raw_buffer_load_b128(r1, off_clv_ld, 0, 0);
+    c1.hi = __builtin_amdgcn_raw_buffer_load_b128(r1, off_clv_ld + 16, 0, 0);
+    c2.lo = __builtin_amdgcn_raw_buffer_load_b128(r2, off_clv_ld, 0, 0);
+    c2.hi = __builtin_amdgcn_raw_buffer_load_b128(r2, off_clv_ld + 16, 0, 0);
+    c1.sc = __builtin_amdgcn_raw_buffer_load_b32(sc_rs(op.child1_sc, mem1), s * 4u, 0, 0);
+    c2.sc = __builtin_amdgcn_raw_buffer_load_b32(sc_rs(op.child2_sc, mem2), s * 4u, 0, 0);
   };
   auto stage_write = [&](unsigned buf, const double (&s1)[kStageRegs], const double (&s2)[kStageRegs]) {
 #pragma unroll
@@ -83,91 +131,60 @@ clv_dna_traversal_kernel(DeviceView v, const LevelOp *__restrict__ ops, unsigned
       }
     }
   };
-  // an older sibling (not produced by the operation just before) comes from
-  // HBM/L2; it is fetched one operation ahead
-  auto fetch = [&](const LevelOp &op, int which, double (&x)[4], unsigned &sc) {
-    const unsigned clv = which ? op.child2_clv : op.child1_clv;
-    const int scb = which ? op.child2_sc : op.child1_sc;
-    const double2 *c = reinterpret_cast<const double2 *>(v.clv + (size_t)(clv - v.tips) * v.clv_stride);
-    const double2 a = c[cidx * 2], b = c[cidx * 2 + 1];
-    x[0] = a.x; x[1] = a.y; x[2] = b.x; x[3] = b.y;
-    sc = scb >= 0 ? v.scaler[(size_t)scb * S + s] : 0u;
-  };
-  // everything operation `op` needs from global memory, into registers
-  auto prefetch = [&](const LevelOp &op, double (&m1)[4], unsigned &m1sc, double (&m2)[4],
-                      unsigned &m2sc, unsigned &cx, unsigned &cy) {
-    if (op.src1 == kSrcTip) cx = v.tipcodes[(size_t)op.child1_clv * S + s];
-    else if (op.src1 == kSrcMem && !(op.late & 1u)) fetch(op, 0, m1, m1sc);
-    if (op.src2 == kSrcTip) cy = v.tipcodes[(size_t)op.child2_clv * S + s];
-    else if (op.src2 == kSrcMem && !(op.late & 2u)) fetch(op, 1, m2, m2sc);
-  };
   unsigned *park_sc = reinterpret_cast<unsigned *>(park_lds + (size_t)slots * 512);
-  auto unpark = [&](unsigned slot, double (&x)[4], unsigned &sc) {
-    const double2 a = park_lds[(slot * 2) * 256 + tid], b = park_lds[(slot * 2 + 1) * 256 + tid];
-    x[0] = a.x; x[1] = a.y; x[2] = b.x; x[3] = b.y;
-    sc = park_sc[slot * 256 + tid];
+  // operand of THIS operation: registers / prefetched memory / tip code / LDS slot
+  auto operand = [&](unsigned src, const Child &c, const double (&o)[4], unsigned osc,
+                     double (&x)[4], unsigned &xsc) {
+    xsc = 0;
+    if (src == kSrcReg) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) x[k] = o[k];
+      xsc = osc;
+    } else if (src == kSrcMem) {
+      const double2 a = __builtin_bit_cast(double2, c.lo), b = __builtin_bit_cast(double2, c.hi);
+      x[0] = a.x; x[1] = a.y; x[2] = b.x; x[3] = b.y;
+      xsc = c.sc;
+    } else if (src == kSrcTip) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) x[k] = ((c.code >> k) & 1u) ? 1.0 : 0.0;
+    } else {
+      const unsigned slot = src - kSrcPark;
+      const double2 a = park_lds[(slot * 2) * 256 + tid], b = park_lds[(slot * 2 + 1) * 256 + tid];
+      x[0] = a.x; x[1] = a.y; x[2] = b.x; x[3] = b.y;
+      xsc = park_sc[slot * 256 + tid];
+    }
   };
 
   double o[4] = {0, 0, 0, 0};       // the CLV this lane produced last
   unsigned osc = 0;
-  double m1[4] = {0, 0, 0, 0}, m2[4] = {0, 0, 0, 0};   // prefetched memory operands
-  unsigned m1sc = 0, m2sc = 0, cx = 0, cy = 0;
+  Child c1, c2;
   {
     double s1[kStageRegs], s2[kStageRegs];
-    const LevelOp op0 = ops[0];
-    stage_load(op0, s1, s2);
-    prefetch(op0, m1, m1sc, m2, m2sc, cx, cy);
+    issue(ops[0], c1, c2, s1, s2);
+    // three no-op stores (0-byte descriptor): the loop body ends with three
+    // stores after its loads, so entering the loop with the same sequence in
+    // flight lets the compiler count its vmcnt waits past them exactly
+    const __amdgpu_buffer_rsrc_t none = make_rsrc(v.clv, 0u);
+    __builtin_amdgcn_raw_buffer_store_b32(0u, none, kOutOfRange, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(v4u{0, 0, 0, 0}, none, kOutOfRange, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(v4u{0, 0, 0, 0}, none, kOutOfRange + 16, 0, 0);
     stage_write(0, s1, s2);
   }
   // (A prefetch distance of two was tried: an older sibling may be the parent of
-  // operation i, which is not stored yet when operation i+2 would fetch it, and
-  // the conditional loads defeat counted vmcnt waits; one operation ahead is
-  // both correct by construction and faster.)
+  // operation i, which is not stored yet when operation i+2 would fetch it;
+  // one operation ahead is correct by construction.)
   for (unsigned i = 0; i < nops; ++i) {
     const unsigned buf = i & 1;
     const LevelOp op = ops[i];
-    const bool more = i + 1 < nops;
-    const LevelOp nx = ops[more ? i + 1 : i];
-    // operands of THIS operation out of the prefetch registers
+    const LevelOp nx = ops[i + 1 < nops ? i + 1 : i];
     double x[4], y[4];
-    unsigned xsc = 0, ysc = 0;
-    const unsigned ccx = cx, ccy = cy;
-    if (op.src1 == kSrcReg) {
-#pragma unroll
-      for (int k = 0; k < 4; ++k) x[k] = o[k];
-      xsc = osc;
-    } else if (op.src1 == kSrcMem) {
-      if (op.late & 1u) fetch(op, 0, m1, m1sc);
-#pragma unroll
-      for (int k = 0; k < 4; ++k) x[k] = m1[k];
-      xsc = m1sc;
-    } else if (op.src1 == kSrcTip) {
-#pragma unroll
-      for (int k = 0; k < 4; ++k) x[k] = ((ccx >> k) & 1u) ? 1.0 : 0.0;
-    } else {
-      unpark(op.src1 - kSrcPark, x, xsc);
-    }
-    if (op.src2 == kSrcReg) {
-#pragma unroll
-      for (int k = 0; k < 4; ++k) y[k] = o[k];
-      ysc = osc;
-    } else if (op.src2 == kSrcMem) {
-      if (op.late & 2u) fetch(op, 1, m2, m2sc);
-#pragma unroll
-      for (int k = 0; k < 4; ++k) y[k] = m2[k];
-      ysc = m2sc;
-    } else if (op.src2 == kSrcTip) {
-#pragma unroll
-      for (int k = 0; k < 4; ++k) y[k] = ((ccy >> k) & 1u) ? 1.0 : 0.0;
-    } else {
-      unpark(op.src2 - kSrcPark, y, ysc);
-    }
-    // issue everything the NEXT operation needs
+    unsigned xsc, ysc;
+    operand(op.src1, c1, o, osc, x, xsc);
+    operand(op.src2, c2, o, osc, y, ysc);
+    // everything the NEXT operation needs (after the last one: a harmless repeat)
     double s1[kStageRegs], s2[kStageRegs];
-    if (more) {
-      stage_load(nx, s1, s2);
-      prefetch(nx, m1, m1sc, m2, m2sc, cx, cy);
-    }
+    issue(nx, c1, c2, s1, s2);
+
     double t1[4], t2[4];
     {
       const double *m = &smat[buf][0][r * 16];
@@ -193,20 +210,18 @@ clv_dna_traversal_kernel(DeviceView v, const LevelOp *__restrict__ ops, unsigned
         for (int k = 0; k < 4; ++k) o[k] *= kScaleFactor;
         osc += 1;
       }
-      if (r == 0 && active) v.scaler[(size_t)op.parent_sc * S + s] = osc;
     }
-    if (active) {
-      double2 *pc = reinterpret_cast<double2 *>(v.clv + (size_t)(op.parent_clv - v.tips) * v.clv_stride);
-      pc[idx * 2] = make_double2(o[0], o[1]);
-      pc[idx * 2 + 1] = make_double2(o[2], o[3]);
-    }
+    __builtin_amdgcn_raw_buffer_store_b32(osc, sc_rs(op.parent_sc, true), off_sc_st, 0, 0);
+    const __amdgpu_buffer_rsrc_t prs = clv_rs(op.parent_clv, true);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, make_double2(o[0], o[1])), prs, off_clv_st, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, make_double2(o[2], o[3])), prs, off_clv_st + 16, 0, 0);
     if (op.park) {
       const unsigned slot = op.park - 1;
       park_lds[(slot * 2) * 256 + tid] = make_double2(o[0], o[1]);
       park_lds[(slot * 2 + 1) * 256 + tid] = make_double2(o[2], o[3]);
       park_sc[slot * 256 + tid] = osc;
     }
-    if (more) stage_write(buf ^ 1, s1, s2);
+    stage_write(buf ^ 1, s1, s2);
   }
 }
 
@@ -275,8 +290,12 @@ clv_generic_traversal_kernel(DeviceView v, const LevelOp *__restrict__ ops, unsi
  }
 }
 
-static inline bool dna_fast_ok(unsigned K, unsigned R, unsigned cap) {
-  return K == 4 && cap == 16 && (R == 1 || R == 2 || R == 4 || R == 8);
+// 4-state kernel: 32-bit buffer offsets, so one CLV must stay under 2 GB
+// (64 M (site, rate) pairs); beyond that the generic kernel takes over
+static inline bool dna_fast_ok(const rdamd_partition *p) {
+  const unsigned R = p->rate_cats;
+  return p->states == 4 && p->ncodes_cap == 16 && (R == 1 || R == 2 || R == 4 || R == 8) &&
+         (size_t)p->sites * R < ((size_t)1 << 26);
 }
 
 constexpr size_t kComputeUnits = 256;   // MI355X: 8 XCDs x 32 CUs
@@ -286,7 +305,7 @@ constexpr size_t kMaxParkSlots = 6;   // static + dynamic LDS stays under 64 KB 
 // blocks of one CU share its 160 KB of LDS): a second dispatch round would cost
 // more than the read-backs the extra slots save.
 unsigned clv_traversal_slots(const rdamd_partition *p) {
-  if (!dna_fast_ok(p->states, p->rate_cats, p->ncodes_cap) || p->sites == 0) return 0;
+  if (!dna_fast_ok(p) || p->sites == 0) return 0;
   const size_t total = (size_t)p->sites * p->rate_cats;
   const size_t blocks = (total + 255) / 256;
   const size_t per_cu = (blocks + kComputeUnits - 1) / kComputeUnits;
@@ -300,18 +319,19 @@ hipError_t launch_clv_traversal(rdamd_partition *p, const LevelOp *d_ops, unsign
                                 unsigned slots) {
   if (nops == 0 || p->sites == 0) return hipSuccess;
   DeviceView v = p->view();
-  const unsigned K = p->states, R = p->rate_cats;
-  if (dna_fast_ok(K, R, p->ncodes_cap)) {
+  const unsigned R = p->rate_cats;
+  if (dna_fast_ok(p)) {
     // one (site, rate) pair per lane where possible: maximum memory-level
     // parallelism; the lane -> pair map is identical for every operation
     size_t total = (size_t)p->sites * R;
     unsigned gx = (unsigned)((total + 255) / 256);
     const size_t lds = (size_t)slots * 256 * (32 + 4);
+    const unsigned pmat_bytes = (unsigned)((size_t)(p->prob_matrices + kExtraMatrices) * R * 16 * sizeof(double));
     switch (R) {
-      case 1: clv_dna_traversal_kernel<1><<<gx, 256, lds, p->stream>>>(v, d_ops, nops, slots); break;
-      case 2: clv_dna_traversal_kernel<2><<<gx, 256, lds, p->stream>>>(v, d_ops, nops, slots); break;
-      case 4: clv_dna_traversal_kernel<4><<<gx, 256, lds, p->stream>>>(v, d_ops, nops, slots); break;
-      default: clv_dna_traversal_kernel<8><<<gx, 256, lds, p->stream>>>(v, d_ops, nops, slots); break;
+      case 1: clv_dna_traversal_kernel<1><<<gx, 256, lds, p->stream>>>(v, d_ops, nops, slots, pmat_bytes); break;
+      case 2: clv_dna_traversal_kernel<2><<<gx, 256, lds, p->stream>>>(v, d_ops, nops, slots, pmat_bytes); break;
+      case 4: clv_dna_traversal_kernel<4><<<gx, 256, lds, p->stream>>>(v, d_ops, nops, slots, pmat_bytes); break;
+      default: clv_dna_traversal_kernel<8><<<gx, 256, lds, p->stream>>>(v, d_ops, nops, slots, pmat_bytes); break;
     }
   } else {
     unsigned gx = (p->sites + 255) / 256;

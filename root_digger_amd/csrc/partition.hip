@@ -419,7 +419,7 @@ void rdamd_update_clvs(rdamd_partition_t *p, const rdamd_operation_t *ops,
     d.child1_sc = o.child1_scaler_index; d.child2_sc = o.child2_scaler_index;
     d.src1 = o.child1_clv_index < p->tips ? 0u : 1u;
     d.src2 = o.child2_clv_index < p->tips ? 0u : 1u;
-    d.park = d.late = 0;
+    d.park = d.pad = 0;
   }
   // Where does each inner child come from?  The parent of the operation just
   // before stays in the lane's registers; an older sibling waits in one of the
@@ -427,12 +427,27 @@ void rdamd_update_clvs(rdamd_partition_t *p, const rdamd_operation_t *ops,
   // slots are full the value needed furthest in the future gives its slot up
   // and is read back from HBM instead -- every CLV is written there anyway).
   // A child is forwarded only when its scaler index is the producer's.
+  //
+  // Memory children are fetched one operation ahead, i.e. before the previous
+  // operation stores.  A child that the previous operation writes but that
+  // cannot be forwarded (read with another scaler index) therefore cuts the
+  // list: the rest runs as its own launch.  Tree traversals never cut.
   const unsigned nslots = clv_traversal_slots(p);
-  {
-    std::vector<int> producer(nclv, -1);            // clv -> op that last wrote it
-    std::vector<int> consumer(count, -1);           // op -> first later op reading its parent
-    std::vector<int> which(count, 0);
-    for (unsigned i = 0; i < count; ++i) {
+  std::vector<unsigned> cuts{0u};
+  for (unsigned i = 1; i < count; ++i) {
+    const unsigned prev = ops[i - 1].parent_clv_index;
+    const int prev_sc = ops[i - 1].parent_scaler_index;
+    if ((ops[i].child1_clv_index == prev && ops[i].child1_scaler_index != prev_sc) ||
+        (ops[i].child2_clv_index == prev && ops[i].child2_scaler_index != prev_sc))
+      cuts.push_back(i);
+  }
+  cuts.push_back(count);
+  std::vector<int> producer(nclv), consumer(count), which(count);
+  for (size_t seg = 0; seg + 1 < cuts.size(); ++seg) {
+    const unsigned lo = cuts[seg], hi = cuts[seg + 1];
+    std::fill(producer.begin(), producer.end(), -1);   // clv -> op of this segment that wrote it
+    for (unsigned i = lo; i < hi; ++i) consumer[i] = -1;   // op -> first later op reading its parent
+    for (unsigned i = lo; i < hi; ++i) {
       const rdamd_operation_t &o = ops[i];
       const unsigned ch[2] = {o.child1_clv_index, o.child2_clv_index};
       const int chsc[2] = {o.child1_scaler_index, o.child2_scaler_index};
@@ -446,26 +461,18 @@ void rdamd_update_clvs(rdamd_partition_t *p, const rdamd_operation_t *ops,
       }
       producer[o.parent_clv_index] = (int)i;
     }
-    // a memory child that the operation just before writes cannot be fetched
-    // ahead of that store (bit 0 / 1 of `late`); forwarded children overwrite
-    // their src below and the bit is then ignored
-    for (unsigned i = 1; i < count; ++i) {
-      if (ops[i].child1_clv_index == ops[i - 1].parent_clv_index) lops[i].late |= 1u;
-      if (ops[i].child2_clv_index == ops[i - 1].parent_clv_index) lops[i].late |= 2u;
-    }
-    // a value overwritten before its consumer runs cannot be forwarded
-    // (cannot happen in a tree traversal; guards arbitrary lists)
-    std::fill(producer.begin(), producer.end(), -1);
     std::vector<int> slot_owner(nslots, -1);
     auto set_src = [&](int j, unsigned kind) {
       LevelOp &c = lops[consumer[j]];
       (which[j] ? c.src2 : c.src1) = kind;
     };
-    for (unsigned i = 0; i < count; ++i) {
+    for (unsigned i = lo; i < hi; ++i) {
       for (unsigned sl = 0; sl < nslots; ++sl)      // slots whose value is consumed now
         if (slot_owner[sl] >= 0 && consumer[slot_owner[sl]] == (int)i) slot_owner[sl] = -1;
       const int c = consumer[i];
       if (c < 0) continue;
+      // a value overwritten before its consumer runs is not forwarded (cannot
+      // happen in a tree traversal; guards arbitrary lists)
       bool clobbered = false;
       for (int k = (int)i + 1; k < c; ++k)
         if (ops[k].parent_clv_index == ops[i].parent_clv_index) clobbered = true;
@@ -497,8 +504,9 @@ void rdamd_update_clvs(rdamd_partition_t *p, const rdamd_operation_t *ops,
       }
     }
   }
-  // The whole list runs as one launch in the caller's order: every dependency
-  // is site-local, so the kernel needs no level structure (kernels_clv.hip).
+  // Each segment (normally the whole list) runs as one launch in the caller's
+  // order: every dependency is site-local, so the kernel needs no level
+  // structure (kernels_clv.hip).
   hipError_t e = ensure_scratch(p, sizeof(LevelOp) * count + 256);
   if (e == hipSuccess && p->tiptab_stale) {
     e = launch_tiptab_all(p);
@@ -508,12 +516,13 @@ void rdamd_update_clvs(rdamd_partition_t *p, const rdamd_operation_t *ops,
   if (e == hipSuccess) {
     LevelOp *d_ops = (LevelOp *)sc.take(sizeof(LevelOp) * count);
     e = upload(p, d_ops, lops.data(), sizeof(LevelOp) * count);
-    if (e == hipSuccess) {
-      p->prof_begin(0);
-      e = p->d_pmat_mfma ? launch_clv_k20_traversal(p, d_ops, count)
-                         : launch_clv_traversal(p, d_ops, count, nslots);
-      p->prof_end();
+    p->prof_begin(0);
+    for (size_t seg = 0; e == hipSuccess && seg + 1 < cuts.size(); ++seg) {
+      const unsigned lo = cuts[seg], n = cuts[seg + 1] - lo;
+      e = p->d_pmat_mfma ? launch_clv_k20_traversal(p, d_ops + lo, n)
+                         : launch_clv_traversal(p, d_ops + lo, n, nslots);
     }
+    p->prof_end();
   }
   if (e != hipSuccess)
     set_error(100 + (int)e, "rdamd_update_clvs: %s", hipGetErrorString(e));
