@@ -23,6 +23,7 @@ constexpr double kScaleThreshold = 1.0 / kScaleFactor;
 // log(2^-256)
 constexpr double kLogScaleThreshold = -177.44567822334599;
 // scratch P-matrix slots behind the caller's (root alpha variants)
+constexpr unsigned kTipcodePad = 256;   // bytes of slack after the tip-code rows
 constexpr unsigned kExtraMatrices = 8;
 
 void set_error(int code, const char *fmt, ...);
@@ -41,7 +42,8 @@ void clear_error();
 // Device-side view of one partition: everything the kernels need.
 struct DeviceView {
   unsigned tips, states, sites, rate_cats, ncodes_cap;
-  const uint8_t *tipcodes;  // [tips][sites]      code index per tip character
+  const uint8_t *tipcodes;  // [tips][tip_stride] code index per tip character
+  unsigned tip_stride;      // sites rounded up to a multiple of 4 (dword-aligned rows)
   double        *clv;       // [clv_buffers][sites][rate_cats][states]
   unsigned      *scaler;    // [scale_buffers][sites]
   double        *pmat;      // [prob_matrices][rate_cats][states][states]
@@ -102,11 +104,12 @@ struct rdamd_partition {
   std::vector<char> q_dirty;         // per rate matrix
   bool tiptab_stale = false;
 
+  unsigned tip_stride() const { return (sites + 3u) & ~3u; }
   rdamd::DeviceView view() const {
     rdamd::DeviceView v;
     v.tips = tips; v.states = states; v.sites = sites; v.rate_cats = rate_cats;
     v.ncodes_cap = ncodes_cap;
-    v.tipcodes = d_tipcodes; v.clv = d_clv; v.scaler = d_scaler; v.pmat = d_pmat;
+    v.tipcodes = d_tipcodes; v.tip_stride = tip_stride(); v.clv = d_clv; v.scaler = d_scaler; v.pmat = d_pmat;
     v.tiptab = d_tiptab; v.codemask = d_codemask;
     v.clv_stride = (size_t)sites * rate_cats * states;
     return v;

@@ -93,7 +93,7 @@ static hipError_t ensure_workspace(rdamd_partition *p, unsigned n_jobs) {
 // while the other child runs), plus the flags the kernel interprets.
 struct Compiler {
   const rdamd_operation_t *ops;
-  unsigned n_ops, tips, sites, rate_cats;
+  unsigned n_ops, tips, sites, tip_stride, rate_cats;
   std::unordered_map<unsigned, unsigned> producer;   // clv -> op index
   std::vector<unsigned> need;                        // stack slots a subtree needs
   std::vector<FusedOp> out;
@@ -156,8 +156,8 @@ struct Compiler {
     f.pM = matM * rate_cats * 128u;
     f.tX = matX * rate_cats * 128u;
     f.tY = matY * rate_cats * 128u;
-    f.cX = tipX_row * sites;
-    f.cY = tipY_row * sites;
+    f.cX = tipX_row * tip_stride;
+    f.cY = tipY_row * tip_stride;
     f.flags = kind | (spill << 8);
     out.push_back(f);
   }
@@ -180,14 +180,14 @@ rdamd_schedule_t *rdamd_schedule_create(rdamd_partition_t *p, const rdamd_operat
                   "rdamd_update_clvs for %u states", p->states);
     return nullptr;
   }
-  if (n_ops == 0 || (size_t)p->tips * p->sites > 0xffffffffu ||
+  if (n_ops == 0 || (size_t)p->tips * p->tip_stride() > 0xffffffffu ||
       (size_t)p->prob_matrices * p->rate_cats * 512 > 0xffffffffu) {
     set_error(41, "rdamd_schedule_create: empty operation list, or partition too large for "
                   "32-bit offsets (tips*sites or matrices*rates*512 >= 4 GiB)");
     return nullptr;
   }
   Compiler c;
-  c.ops = ops; c.n_ops = n_ops; c.tips = p->tips; c.sites = p->sites; c.rate_cats = p->rate_cats;
+  c.ops = ops; c.n_ops = n_ops; c.tips = p->tips; c.sites = p->sites; c.tip_stride = p->tip_stride(); c.rate_cats = p->rate_cats;
   const unsigned nclv = p->tips + p->clv_buffers;
   for (unsigned i = 0; i < n_ops; ++i) {
     const rdamd_operation_t &o = ops[i];
@@ -310,7 +310,7 @@ static int evaluate_batch_impl(rdamd_partition_t *p, unsigned int n_jobs,
   a.partials = w->d_partials; a.persite = nullptr;
   a.pmat_job_stride = (size_t)p->prob_matrices * R * 16;
   a.sites = p->sites; a.rate_cats = R;
-  a.tipcodes_bytes = (unsigned)std::min<size_t>((size_t)p->tips * p->sites, 0xffffffffu);
+  a.tipcodes_bytes = (unsigned)std::min<size_t>((size_t)p->tips * p->tip_stride(), 0xffffffffu);
   p->prof_begin(4);
   hipError_t e = launch_fused_pmatrix(a, w->d_q, w->d_rates, n_jobs, p->prob_matrices, p->stream);
   p->prof_end();

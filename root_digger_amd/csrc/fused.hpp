@@ -43,7 +43,7 @@ struct FusedJob {
 
 struct FusedArgs {
   const FusedJob *jobs;
-  const uint8_t  *tipcodes;          // [tips][sites]
+  const uint8_t  *tipcodes;          // [tips][tip_stride]
   const unsigned *pattern_weights;   // [sites]
   const double   *pmat;              // [job][matrix][rate][16]
   const double   *tiptab;            // [job][matrix][rate][16 codes][4]
@@ -53,7 +53,7 @@ struct FusedArgs {
   double         *persite;           // [job][sites] or null
   size_t   pmat_job_stride;
   unsigned sites, rate_cats;
-  unsigned tipcodes_bytes;           // tips * sites
+  unsigned tipcodes_bytes;           // tips * tip_stride
 };
 
 hipError_t launch_fused_pmatrix(const FusedArgs &a, const double *d_q, const double *d_rates,

@@ -40,11 +40,8 @@ typedef unsigned v4u __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ unsigned uni(unsigned x) {   // assert wave-uniformity
   return (unsigned)__builtin_amdgcn_readfirstlane((int)x);
 }
-// Buffer descriptor over [p, p+bytes); bytes == 0 makes every access through it
-// a no-op (loads return 0, stores are dropped) -- how a wave-uniform "this
-// operand is not needed" is expressed WITHOUT a branch around the memory
-// instruction: every iteration issues the same instruction sequence, so the
-// s_waitcnt vmcnt counts are exact and no wait ever covers a store.
+// Buffer descriptor over [p, p+bytes): lanes whose offset lies outside are
+// dropped by the hardware, so stores need no branch around them.
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *p, unsigned bytes) {
   const unsigned long long u = reinterpret_cast<unsigned long long>(p);
   const unsigned lo = uni((unsigned)u), hi = uni((unsigned)(u >> 32));
@@ -53,22 +50,39 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *p, unsig
 }
 constexpr unsigned kOutOfRange = 0x80000000u;   // offset no descriptor here reaches
 
+// read-only data through the scalar cache: a load from the constant address
+// space at a wave-uniform address is an s_load
+typedef const __attribute__((address_space(4))) unsigned *const_u32_ptr;
+
+// The tip codes of the 64/R sites of one wave for one tip, fetched by scalar loads.
+template <int NW>
+struct TipCodes {
+  unsigned w[NW];
+};
+
+// Operations per staging chunk: the block stages the P-matrices of kChunk
+// operations at a time (double-buffered, one barrier per chunk).
+constexpr unsigned kChunk = 4;
+
 template <int R>
 __global__ void __launch_bounds__(256)
 clv_dna_traversal_kernel(DeviceView v, const LevelOp *__restrict__ ops, unsigned nops,
-                         unsigned slots, unsigned pmat_bytes) {
-  // Per WAVE, double-buffered: the P-matrices [R][4][4] of both children.
-  // Waves never synchronise with each other: each stages the matrices of
-  // operation i+1 itself while operation i computes.  (A tip child is expanded
-  // from its code to a 0/1 vector and goes through the same product: this kernel
-  // is bound by memory, not by FMAs, and P is a quarter of the tip table to stage.)
-  __shared__ double smat_all[4][2][2][R * 16];
+                         unsigned slots) {
+  // Why the memory pipe sees (almost) only stores inside the loop: vector-memory
+  // operations retire in issue order, so a load queued behind the CLV stores of
+  // the previous operation cannot return before they are acknowledged, and with
+  // three waves per SIMD that round trip is exposed on every operation.  So:
+  //   * P-matrices are staged by the whole block kChunk operations at a time,
+  //     loaded one chunk ahead;
+  //   * tip codes come through the SCALAR cache (s_load, its own counter);
+  //   * a child produced by the previous operation stays in registers, an older
+  //     sibling waits in an LDS parking slot (host: rdamd_update_clvs);
+  //   * only a sibling that found no slot is read back (one operation ahead).
+  __shared__ double smat[2][kChunk][2][R * 16];
   // LDS parking: `slots` CLVs (+ scaler counts) per lane, [slot][half][lane] so
-  // every 16-byte access of a wave is conflict-free.  An older sibling waits
-  // here for its operation instead of being read back from HBM.
+  // every 16-byte access of a wave is conflict-free.
   extern __shared__ double2 park_lds[];
-  const unsigned tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  double (*smat)[2][R * 16] = smat_all[wave];
+  const unsigned tid = threadIdx.x, lane = tid & 63;
   const unsigned S = v.sites;
   const unsigned total = S * R;                      // < 2^26 (launch_clv_traversal)
   const unsigned idx = blockIdx.x * 256 + tid;       // one (site, rate) pair per lane
@@ -77,76 +91,86 @@ clv_dna_traversal_kernel(DeviceView v, const LevelOp *__restrict__ ops, unsigned
   const unsigned s = cidx / R, r = cidx % R;
 
   const unsigned clv_bytes = (unsigned)(v.clv_stride * sizeof(double));
-  const unsigned off_clv_ld = cidx * 32u;
   const unsigned off_clv_st = active ? idx * 32u : kOutOfRange;
   const unsigned off_sc_st = (active && r == 0) ? s * 4u : kOutOfRange;
-  const __amdgpu_buffer_rsrc_t pmat_rs = make_rsrc(v.pmat, pmat_bytes);
-  auto clv_rs = [&](unsigned clv, bool on) {
-    return make_rsrc(v.clv + (size_t)(on ? clv - v.tips : 0u) * v.clv_stride, on ? clv_bytes : 0u);
-  };
-  auto sc_rs = [&](int scb, bool on) {
-    on = on && scb >= 0;
-    return make_rsrc(v.scaler + (size_t)(on ? scb : 0) * S, on ? S * 4u : 0u);
-  };
-  auto tip_rs = [&](unsigned clv, bool on) {
-    return make_rsrc(v.tipcodes + (size_t)(on ? clv : 0u) * S, on ? S : 0u);
-  };
 
-  struct Child {          // one child operand in flight
-    v4u lo, hi;           // CLV entries 0-1 / 2-3 (memory child)
-    unsigned sc, code;    // its scaler count / tip code
-  };
-  constexpr int kStageRegs = (R * 16 + 63) / 64;     // doubles per lane per child matrix
-  // everything operation `op` needs from memory, issued as ONE fixed
-  // instruction sequence (descriptors with 0 bytes switch parts of it off)
-  auto issue = [&](const LevelOp &op, Child &c1, Child &c2, double (&s1)[kStageRegs],
-                   double (&s2)[kStageRegs]) {
+  // ---- P-matrix staging, one chunk ahead ------------------------------------
+  // wave w stages the (operation, child) pairs w, w+4, ... of the chunk: the
+  // matrix index is wave-uniform (scalar load), the matrix one coalesced read
+  constexpr int kPairsPerWave = (2 * kChunk) / 4;
+  constexpr int kMatRegs = (R * 16 + 63) / 64;
+  const unsigned wave = uni(tid >> 6);
+  auto stage_load = [&](unsigned first_op, double (&st)[kPairsPerWave][kMatRegs]) {
 #pragma unroll
-    for (int k = 0; k < kStageRegs; ++k) {
-      const unsigned e = lane + 64 * k;
-      const unsigned off = e < R * 16 ? e * 8u : kOutOfRange;
-      s1[k] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(
-                  pmat_rs, off, (int)uni(op.child1_mat * (R * 128u)), 0));
-      s2[k] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(
-                  pmat_rs, off, (int)uni(op.child2_mat * (R * 128u)), 0));
-    }
-    c1.code = (unsigned)__builtin_amdgcn_raw_buffer_load_b8(tip_rs(op.child1_clv, op.src1 == kSrcTip), s, 0, 0);
-    c2.code = (unsigned)__builtin_amdgcn_raw_buffer_load_b8(tip_rs(op.child2_clv, op.src2 == kSrcTip), s, 0, 0);
-    const bool mem1 = op.src1 == kSrcMem, mem2 = op.src2 == kSrcMem;
-    const __amdgpu_buffer_rsrc_t r1 = clv_rs(op.child1_clv, mem1), r2 = clv_rs(op.child2_clv, mem2);
-    c1.lo = __builtin_amdgcn_raw_buffer_load_b128(r1, off_clv_ld, 0, 0);
-    c1.hi = __builtin_amdgcn_raw_buffer_load_b128(r1, off_clv_ld + 16, 0, 0);
-    c2.lo = __builtin_amdgcn_raw_buffer_load_b128(r2, off_clv_ld, 0, 0);
-    c2.hi = __builtin_amdgcn_raw_buffer_load_b128(r2, off_clv_ld + 16, 0, 0);
-    c1.sc = __builtin_amdgcn_raw_buffer_load_b32(sc_rs(op.child1_sc, mem1), s * 4u, 0, 0);
-    c2.sc = __builtin_amdgcn_raw_buffer_load_b32(sc_rs(op.child2_sc, mem2), s * 4u, 0, 0);
-  };
-  auto stage_write = [&](unsigned buf, const double (&s1)[kStageRegs], const double (&s2)[kStageRegs]) {
+    for (int q = 0; q < kPairsPerWave; ++q) {
+      const unsigned pair = wave + 4 * q, oi = first_op + pair / 2;
+      const unsigned oc = oi < nops ? oi : nops - 1;
+      const unsigned mat = (pair & 1u) ? ops[oc].child2_mat : ops[oc].child1_mat;
 #pragma unroll
-    for (int k = 0; k < kStageRegs; ++k) {
-      const unsigned e = lane + 64 * k;
-      if (e < R * 16) {
-        smat[buf][0][e] = s1[k];
-        smat[buf][1][e] = s2[k];
+      for (int k = 0; k < kMatRegs; ++k) {
+        const unsigned e = lane + 64 * k;
+        st[q][k] = e < R * 16 ? v.pmat[(size_t)mat * (R * 16) + e] : 0.0;
       }
     }
   };
+  auto stage_write = [&](unsigned buf, const double (&st)[kPairsPerWave][kMatRegs]) {
+#pragma unroll
+    for (int q = 0; q < kPairsPerWave; ++q) {
+      const unsigned pair = wave + 4 * q;
+#pragma unroll
+      for (int k = 0; k < kMatRegs; ++k) {
+        const unsigned e = lane + 64 * k;
+        if (e < R * 16) smat[buf][pair / 2][pair & 1u][e] = st[q][k];
+      }
+    }
+  };
+
+  // ---- tip codes through the scalar cache -------------------------------------
+  // a wave covers 64/R consecutive sites starting at a multiple of 64/R >= 8 and
+  // tip rows are dword-aligned (tip_stride), so its codes are NW aligned dwords;
+  // which dword and which byte a lane wants never changes
+  constexpr int NW = 64 / R / 4;
+  const unsigned wave_first = uni((blockIdx.x * 256 + (tid & ~63u)) / R);   // first site of this wave
+  const unsigned wave_site0 = wave_first < S ? wave_first : 0u;
+  const unsigned lane_word = (lane / R) >> 2, lane_shift = ((lane / R) & 3u) * 8u;
+  auto load_codes = [&](unsigned tip, bool on, TipCodes<NW> &t) {
+    const unsigned long long a = reinterpret_cast<unsigned long long>(v.tipcodes) +
+                                 (size_t)(on ? tip : 0u) * v.tip_stride + wave_site0;
+    const unsigned lo = uni((unsigned)a), hi = uni((unsigned)(a >> 32));
+    const_u32_ptr p = (const_u32_ptr)(((unsigned long long)hi << 32) | lo);
+#pragma unroll
+    for (int k = 0; k < NW; ++k) t.w[k] = p[k];
+  };
+  auto lane_code = [&](const TipCodes<NW> &t) {
+    unsigned word = 0;   // (masks, not selects: a select chain over w[] is turned into a scratch array)
+#pragma unroll
+    for (int k = 0; k < NW; ++k) word |= t.w[k] & (lane_word == (unsigned)k ? ~0u : 0u);
+    return (word >> lane_shift) & 0xffu;
+  };
+
   unsigned *park_sc = reinterpret_cast<unsigned *>(park_lds + (size_t)slots * 512);
   // operand of THIS operation: registers / prefetched memory / tip code / LDS slot
-  auto operand = [&](unsigned src, const Child &c, const double (&o)[4], unsigned osc,
-                     double (&x)[4], unsigned &xsc) {
+  auto operand = [&](unsigned src, unsigned clv, int scb, const TipCodes<NW> &t,
+                     const double (&o)[4], unsigned osc, double (&x)[4], unsigned &xsc) {
     xsc = 0;
     if (src == kSrcReg) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) x[k] = o[k];
       xsc = osc;
     } else if (src == kSrcMem) {
-      const double2 a = __builtin_bit_cast(double2, c.lo), b = __builtin_bit_cast(double2, c.hi);
+      // a sibling that found no parking slot (or was left by an earlier call):
+      // read back here, after every earlier store of this lane in program order
+      const double2 *p = reinterpret_cast<const double2 *>(v.clv + (size_t)(clv - v.tips) * v.clv_stride);
+      const double2 a = p[(size_t)cidx * 2], b = p[(size_t)cidx * 2 + 1];
       x[0] = a.x; x[1] = a.y; x[2] = b.x; x[3] = b.y;
-      xsc = c.sc;
+      xsc = scb >= 0 ? v.scaler[(size_t)scb * S + s] : 0u;
+      // wait HERE (vmcnt(0)): left to the compiler the wait sinks to the join
+      // below and every other route would pay for it
+      __builtin_amdgcn_s_waitcnt(0x0F70);
     } else if (src == kSrcTip) {
+      const unsigned code = lane_code(t);
 #pragma unroll
-      for (int k = 0; k < 4; ++k) x[k] = ((c.code >> k) & 1u) ? 1.0 : 0.0;
+      for (int k = 0; k < 4; ++k) x[k] = ((code >> k) & 1u) ? 1.0 : 0.0;
     } else {
       const unsigned slot = src - kSrcPark;
       const double2 a = park_lds[(slot * 2) * 256 + tid], b = park_lds[(slot * 2 + 1) * 256 + tid];
@@ -157,71 +181,76 @@ clv_dna_traversal_kernel(DeviceView v, const LevelOp *__restrict__ ops, unsigned
 
   double o[4] = {0, 0, 0, 0};       // the CLV this lane produced last
   unsigned osc = 0;
-  Child c1, c2;
+  TipCodes<NW> t1, t2;
   {
-    double s1[kStageRegs], s2[kStageRegs];
-    issue(ops[0], c1, c2, s1, s2);
-    // three no-op stores (0-byte descriptor): the loop body ends with three
-    // stores after its loads, so entering the loop with the same sequence in
-    // flight lets the compiler count its vmcnt waits past them exactly
-    const __amdgpu_buffer_rsrc_t none = make_rsrc(v.clv, 0u);
-    __builtin_amdgcn_raw_buffer_store_b32(0u, none, kOutOfRange, 0, 0);
-    __builtin_amdgcn_raw_buffer_store_b128(v4u{0, 0, 0, 0}, none, kOutOfRange, 0, 0);
-    __builtin_amdgcn_raw_buffer_store_b128(v4u{0, 0, 0, 0}, none, kOutOfRange + 16, 0, 0);
-    stage_write(0, s1, s2);
+    double st[kPairsPerWave][kMatRegs];
+    stage_load(0, st);
+    const LevelOp op0 = ops[0];
+    load_codes(op0.child1_clv, op0.src1 == kSrcTip, t1);
+    load_codes(op0.child2_clv, op0.src2 == kSrcTip, t2);
+    stage_write(0, st);
+    __syncthreads();
   }
-  // (A prefetch distance of two was tried: an older sibling may be the parent of
-  // operation i, which is not stored yet when operation i+2 would fetch it;
-  // one operation ahead is correct by construction.)
-  for (unsigned i = 0; i < nops; ++i) {
-    const unsigned buf = i & 1;
-    const LevelOp op = ops[i];
-    const LevelOp nx = ops[i + 1 < nops ? i + 1 : i];
-    double x[4], y[4];
-    unsigned xsc, ysc;
-    operand(op.src1, c1, o, osc, x, xsc);
-    operand(op.src2, c2, o, osc, y, ysc);
-    // everything the NEXT operation needs (after the last one: a harmless repeat)
-    double s1[kStageRegs], s2[kStageRegs];
-    issue(nx, c1, c2, s1, s2);
+  for (unsigned base = 0; base < nops; base += kChunk) {
+    const unsigned buf = (base / kChunk) & 1u;
+    double st[kPairsPerWave][kMatRegs];
+    stage_load(base + kChunk, st);                    // the NEXT chunk's matrices
+#pragma unroll 1
+    for (unsigned j = 0; j < kChunk && base + j < nops; ++j) {
+      const unsigned i = base + j;
+      const LevelOp op = ops[i];
+      const LevelOp nx = ops[i + 1 < nops ? i + 1 : i];
+      double x[4], y[4];
+      unsigned xsc, ysc;
+      operand(op.src1, op.child1_clv, op.child1_sc, t1, o, osc, x, xsc);
+      operand(op.src2, op.child2_clv, op.child2_sc, t2, o, osc, y, ysc);
+      // what the NEXT operation needs (after the last one: a harmless repeat)
+      load_codes(nx.child1_clv, nx.src1 == kSrcTip, t1);
+      load_codes(nx.child2_clv, nx.src2 == kSrcTip, t2);
 
-    double t1[4], t2[4];
-    {
-      const double *m = &smat[buf][0][r * 16];
+      double p1[4], p2[4];
+      {
+        const double *m = &smat[buf][j][0][r * 16];
 #pragma unroll
-      for (int k = 0; k < 4; ++k)
-        t1[k] = m[k * 4 + 0] * x[0] + m[k * 4 + 1] * x[1] + m[k * 4 + 2] * x[2] + m[k * 4 + 3] * x[3];
-      m = &smat[buf][1][r * 16];
+        for (int k = 0; k < 4; ++k)
+          p1[k] = m[k * 4 + 0] * x[0] + m[k * 4 + 1] * x[1] + m[k * 4 + 2] * x[2] + m[k * 4 + 3] * x[3];
+        m = &smat[buf][j][1][r * 16];
 #pragma unroll
-      for (int k = 0; k < 4; ++k)
-        t2[k] = m[k * 4 + 0] * y[0] + m[k * 4 + 1] * y[1] + m[k * 4 + 2] * y[2] + m[k * 4 + 3] * y[3];
-    }
+        for (int k = 0; k < 4; ++k)
+          p2[k] = m[k * 4 + 0] * y[0] + m[k * 4 + 1] * y[1] + m[k * 4 + 2] * y[2] + m[k * 4 + 3] * y[3];
+      }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) o[k] = t1[k] * t2[k];
-    osc = 0;
-    if (op.parent_sc >= 0) {
-      int small = (o[0] < kScaleThreshold) & (o[1] < kScaleThreshold) &
-                  (o[2] < kScaleThreshold) & (o[3] < kScaleThreshold);
+      for (int k = 0; k < 4; ++k) o[k] = p1[k] * p2[k];
+      osc = 0;
+      if (op.parent_sc >= 0) {
+        int small = (o[0] < kScaleThreshold) & (o[1] < kScaleThreshold) &
+                    (o[2] < kScaleThreshold) & (o[3] < kScaleThreshold);
 #pragma unroll
-      for (int off = 1; off < R; off <<= 1) small &= __shfl_xor(small, off);
-      osc = xsc + ysc;
-      if (small) {
+        for (int off = 1; off < R; off <<= 1) small &= __shfl_xor(small, off);
+        osc = xsc + ysc;
+        if (small) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) o[k] *= kScaleFactor;
-        osc += 1;
+          for (int k = 0; k < 4; ++k) o[k] *= kScaleFactor;
+          osc += 1;
+        }
+      }
+      const bool has_sc = op.parent_sc >= 0;
+      __builtin_amdgcn_raw_buffer_store_b32(
+          osc, make_rsrc(v.scaler + (size_t)(has_sc ? op.parent_sc : 0) * S, has_sc ? S * 4u : 0u),
+          off_sc_st, 0, 0);
+      const __amdgpu_buffer_rsrc_t prs =
+          make_rsrc(v.clv + (size_t)(op.parent_clv - v.tips) * v.clv_stride, clv_bytes);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, make_double2(o[0], o[1])), prs, off_clv_st, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, make_double2(o[2], o[3])), prs, off_clv_st + 16, 0, 0);
+      if (op.park) {
+        const unsigned slot = op.park - 1;
+        park_lds[(slot * 2) * 256 + tid] = make_double2(o[0], o[1]);
+        park_lds[(slot * 2 + 1) * 256 + tid] = make_double2(o[2], o[3]);
+        park_sc[slot * 256 + tid] = osc;
       }
     }
-    __builtin_amdgcn_raw_buffer_store_b32(osc, sc_rs(op.parent_sc, true), off_sc_st, 0, 0);
-    const __amdgpu_buffer_rsrc_t prs = clv_rs(op.parent_clv, true);
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, make_double2(o[0], o[1])), prs, off_clv_st, 0, 0);
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, make_double2(o[2], o[3])), prs, off_clv_st + 16, 0, 0);
-    if (op.park) {
-      const unsigned slot = op.park - 1;
-      park_lds[(slot * 2) * 256 + tid] = make_double2(o[0], o[1]);
-      park_lds[(slot * 2 + 1) * 256 + tid] = make_double2(o[2], o[3]);
-      park_sc[slot * 256 + tid] = osc;
-    }
-    stage_write(buf ^ 1, s1, s2);
+    stage_write(buf ^ 1u, st);
+    __syncthreads();
   }
 }
 
@@ -250,8 +279,8 @@ clv_generic_traversal_kernel(DeviceView v, const LevelOp *__restrict__ ops, unsi
 
   for (unsigned s = blockIdx.x * blockDim.x + threadIdx.x; s < S;
        s += gridDim.x * blockDim.x) {
-    const unsigned code1 = tip1 ? v.tipcodes[(size_t)op.child1_clv * S + s] : 0;
-    const unsigned code2 = tip2 ? v.tipcodes[(size_t)op.child2_clv * S + s] : 0;
+    const unsigned code1 = tip1 ? v.tipcodes[(size_t)op.child1_clv * v.tip_stride + s] : 0;
+    const unsigned code2 = tip2 ? v.tipcodes[(size_t)op.child2_clv * v.tip_stride + s] : 0;
     bool small = psc != nullptr;
     for (unsigned r = 0; r < R; ++r) {
       const double *l = tip1 ? nullptr : c1 + s * span + (size_t)r * K;
@@ -326,12 +355,11 @@ hipError_t launch_clv_traversal(rdamd_partition *p, const LevelOp *d_ops, unsign
     size_t total = (size_t)p->sites * R;
     unsigned gx = (unsigned)((total + 255) / 256);
     const size_t lds = (size_t)slots * 256 * (32 + 4);
-    const unsigned pmat_bytes = (unsigned)((size_t)(p->prob_matrices + kExtraMatrices) * R * 16 * sizeof(double));
     switch (R) {
-      case 1: clv_dna_traversal_kernel<1><<<gx, 256, lds, p->stream>>>(v, d_ops, nops, slots, pmat_bytes); break;
-      case 2: clv_dna_traversal_kernel<2><<<gx, 256, lds, p->stream>>>(v, d_ops, nops, slots, pmat_bytes); break;
-      case 4: clv_dna_traversal_kernel<4><<<gx, 256, lds, p->stream>>>(v, d_ops, nops, slots, pmat_bytes); break;
-      default: clv_dna_traversal_kernel<8><<<gx, 256, lds, p->stream>>>(v, d_ops, nops, slots, pmat_bytes); break;
+      case 1: clv_dna_traversal_kernel<1><<<gx, 256, lds, p->stream>>>(v, d_ops, nops, slots); break;
+      case 2: clv_dna_traversal_kernel<2><<<gx, 256, lds, p->stream>>>(v, d_ops, nops, slots); break;
+      case 4: clv_dna_traversal_kernel<4><<<gx, 256, lds, p->stream>>>(v, d_ops, nops, slots); break;
+      default: clv_dna_traversal_kernel<8><<<gx, 256, lds, p->stream>>>(v, d_ops, nops, slots); break;
     }
   } else {
     unsigned gx = (p->sites + 255) / 256;

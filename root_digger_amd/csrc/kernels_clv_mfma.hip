@@ -96,7 +96,7 @@ clv_k20_traversal_kernel(DeviceView v, const double *__restrict__ pmfma,
 #pragma unroll
     for (int nt = 0; nt < kMfmaNT; ++nt) {
       if (src == 0u) {       // tip: a 0/1 operand straight from the state mask
-        const uint64_t mask = masks[v.tipcodes[(size_t)clv * S + ls[nt]]];
+        const uint64_t mask = masks[v.tipcodes[(size_t)clv * v.tip_stride + ls[nt]]];
 #pragma unroll
         for (int s = 0; s < kMfmaSteps; ++s) cb.b[nt][s] = ((mask >> (4 * s + grp)) & 1) ? 1.0 : 0.0;
         sc[nt] = 0;

@@ -147,8 +147,8 @@ root_fused_dna_kernel(DeviceView v, LevelOp op, const unsigned *__restrict__ mat
   const double2 *c2 = tip2 ? nullptr
       : reinterpret_cast<const double2 *>(v.clv + (size_t)(op.child2_clv - v.tips) * v.clv_stride);
   double2 *pc = reinterpret_cast<double2 *>(v.clv + (size_t)(op.parent_clv - v.tips) * v.clv_stride);
-  const uint8_t *code1 = tip1 ? v.tipcodes + (size_t)op.child1_clv * S : nullptr;
-  const uint8_t *code2 = tip2 ? v.tipcodes + (size_t)op.child2_clv * S : nullptr;
+  const uint8_t *code1 = tip1 ? v.tipcodes + (size_t)op.child1_clv * v.tip_stride : nullptr;
+  const uint8_t *code2 = tip2 ? v.tipcodes + (size_t)op.child2_clv * v.tip_stride : nullptr;
   unsigned *psc = v.scaler + (size_t)op.parent_sc * S;
   const unsigned *lsc = op.child1_sc >= 0 ? v.scaler + (size_t)op.child1_sc * S : nullptr;
   const unsigned *rsc = op.child2_sc >= 0 ? v.scaler + (size_t)op.child2_sc * S : nullptr;

@@ -171,7 +171,9 @@ rdamd_partition_t *rdamd_partition_create(unsigned int tips, unsigned int clv_bu
 #define TRY(expr) RDAMD_HIP_TRY(expr, (rdamd_partition_destroy(p), nullptr))
   TRY(hipGetDevice(&p->device));
   TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
-  TRY(hipMalloc(&p->d_tipcodes, std::max<size_t>(1, (size_t)tips * S)));
+  // + kTipcodePad: the traversal kernel reads tip codes with dword-wide scalar
+  // loads that may run a few bytes past the last row
+  TRY(hipMalloc(&p->d_tipcodes, (size_t)tips * p->tip_stride() + kTipcodePad));
   TRY(hipMalloc(&p->d_clv, std::max<size_t>(8, (size_t)clv_buffers * S * R * K * sizeof(double))));
   TRY(hipMalloc(&p->d_scaler, std::max<size_t>(4, (size_t)scale_buffers * S * sizeof(unsigned))));
   // kExtraMatrices scratch slots behind the caller's: alpha variants of the fused root evaluation
@@ -192,7 +194,7 @@ rdamd_partition_t *rdamd_partition_create(unsigned int tips, unsigned int clv_bu
   TRY(hipHostMalloc(&p->h_result, 64 * sizeof(double), hipHostMallocDefault));
   TRY(ensure_scratch(p, (size_t)1 << 20));
   TRY(hipMemsetAsync(p->d_scaler, 0, std::max<size_t>(4, (size_t)scale_buffers * S * sizeof(unsigned)), p->stream));
-  TRY(hipMemsetAsync(p->d_tipcodes, 0, std::max<size_t>(1, (size_t)tips * S), p->stream));
+  TRY(hipMemsetAsync(p->d_tipcodes, 0, (size_t)tips * p->tip_stride() + kTipcodePad, p->stream));
 
   // defaults as corax_partition_create leaves them: weights 1, rates 1, 1/R
   p->subst.assign(rate_matrices, std::vector<double>((size_t)K * K - K, 1.0));
@@ -278,7 +280,7 @@ int rdamd_set_tip_states(rdamd_partition_t *p, unsigned int tip_index,
                   RDAMD_FAILURE);
     p->tiptab_stale = true;
   }
-  RDAMD_HIP_TRY(upload(p, p->d_tipcodes + (size_t)tip_index * S, row, S), RDAMD_FAILURE);
+  RDAMD_HIP_TRY(upload(p, p->d_tipcodes + (size_t)tip_index * p->tip_stride(), row, S), RDAMD_FAILURE);
   return RDAMD_SUCCESS;
 }
 
@@ -427,21 +429,10 @@ void rdamd_update_clvs(rdamd_partition_t *p, const rdamd_operation_t *ops,
   // slots are full the value needed furthest in the future gives its slot up
   // and is read back from HBM instead -- every CLV is written there anyway).
   // A child is forwarded only when its scaler index is the producer's.
-  //
-  // Memory children are fetched one operation ahead, i.e. before the previous
-  // operation stores.  A child that the previous operation writes but that
-  // cannot be forwarded (read with another scaler index) therefore cuts the
-  // list: the rest runs as its own launch.  Tree traversals never cut.
   const unsigned nslots = clv_traversal_slots(p);
-  std::vector<unsigned> cuts{0u};
-  for (unsigned i = 1; i < count; ++i) {
-    const unsigned prev = ops[i - 1].parent_clv_index;
-    const int prev_sc = ops[i - 1].parent_scaler_index;
-    if ((ops[i].child1_clv_index == prev && ops[i].child1_scaler_index != prev_sc) ||
-        (ops[i].child2_clv_index == prev && ops[i].child2_scaler_index != prev_sc))
-      cuts.push_back(i);
-  }
-  cuts.push_back(count);
+  // (`cuts` splits a list into separate launches; nothing needs that today:
+  // memory children are read at use, after every earlier store of the lane.)
+  std::vector<unsigned> cuts{0u, count};
   std::vector<int> producer(nclv), consumer(count), which(count);
   for (size_t seg = 0; seg + 1 < cuts.size(); ++seg) {
     const unsigned lo = cuts[seg], hi = cuts[seg + 1];
