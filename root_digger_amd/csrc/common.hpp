@@ -135,12 +135,14 @@ struct LevelOp {   // device-side op descriptor
   // previous op), 3+s = LDS parking slot s (4-state kernel only)
   unsigned src1, src2;
   unsigned park;         // 1+s: also park the parent in LDS slot s; 0: do not
-  unsigned pad;
+  unsigned noop;         // padding entry (4-state kernel: lists are padded to whole chunks)
 };
 // LDS parking slots per lane the 4-state traversal kernel will have for this
 // partition (0 for the other kernels): an older sibling waits there instead of
 // being read back from HBM.
 unsigned clv_traversal_slots(const rdamd_partition *p);
+// the 4-state kernel wants its list padded with no-ops to a multiple of this (else 1)
+unsigned clv_traversal_chunk(const rdamd_partition *p);
 hipError_t launch_clv_traversal(rdamd_partition *p, const LevelOp *d_ops, unsigned nops,
                                 unsigned slots);
 

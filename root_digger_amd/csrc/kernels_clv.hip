@@ -195,8 +195,12 @@ clv_dna_traversal_kernel(DeviceView v, const LevelOp *__restrict__ ops, unsigned
     const unsigned buf = (base / kChunk) & 1u;
     double st[kPairsPerWave][kMatRegs];
     stage_load(base + kChunk, st);                    // the NEXT chunk's matrices
-#pragma unroll 1
-    for (unsigned j = 0; j < kChunk && base + j < nops; ++j) {
+    // nops is a multiple of kChunk (the host pads with no-ops whose stores go
+    // through 0-byte descriptors): the chunk is straight-line code with a fixed
+    // number of stores, so the wait for the staged matrices below is counted
+    // past them instead of draining the store queue
+#pragma unroll
+    for (unsigned j = 0; j < kChunk; ++j) {
       const unsigned i = base + j;
       const LevelOp op = ops[i];
       const LevelOp nx = ops[i + 1 < nops ? i + 1 : i];
@@ -234,12 +238,12 @@ clv_dna_traversal_kernel(DeviceView v, const LevelOp *__restrict__ ops, unsigned
           osc += 1;
         }
       }
-      const bool has_sc = op.parent_sc >= 0;
+      const bool has_sc = op.parent_sc >= 0 && !op.noop;
       __builtin_amdgcn_raw_buffer_store_b32(
           osc, make_rsrc(v.scaler + (size_t)(has_sc ? op.parent_sc : 0) * S, has_sc ? S * 4u : 0u),
           off_sc_st, 0, 0);
       const __amdgpu_buffer_rsrc_t prs =
-          make_rsrc(v.clv + (size_t)(op.parent_clv - v.tips) * v.clv_stride, clv_bytes);
+          make_rsrc(v.clv + (size_t)(op.parent_clv - v.tips) * v.clv_stride, op.noop ? 0u : clv_bytes);
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, make_double2(o[0], o[1])), prs, off_clv_st, 0, 0);
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, make_double2(o[2], o[3])), prs, off_clv_st + 16, 0, 0);
       if (op.park) {
@@ -343,6 +347,8 @@ unsigned clv_traversal_slots(const rdamd_partition *p) {
   if (budget <= lds_static) return 0;
   return (unsigned)std::min<size_t>((budget - lds_static) / per_slot, kMaxParkSlots);
 }
+
+unsigned clv_traversal_chunk(const rdamd_partition *p) { return dna_fast_ok(p) ? kChunk : 1u; }
 
 hipError_t launch_clv_traversal(rdamd_partition *p, const LevelOp *d_ops, unsigned nops,
                                 unsigned slots) {

@@ -421,7 +421,7 @@ void rdamd_update_clvs(rdamd_partition_t *p, const rdamd_operation_t *ops,
     d.child1_sc = o.child1_scaler_index; d.child2_sc = o.child2_scaler_index;
     d.src1 = o.child1_clv_index < p->tips ? 0u : 1u;
     d.src2 = o.child2_clv_index < p->tips ? 0u : 1u;
-    d.park = d.pad = 0;
+    d.park = d.noop = 0;
   }
   // Where does each inner child come from?  The parent of the operation just
   // before stays in the lane's registers; an older sibling waits in one of the
@@ -498,15 +498,27 @@ void rdamd_update_clvs(rdamd_partition_t *p, const rdamd_operation_t *ops,
   // Each segment (normally the whole list) runs as one launch in the caller's
   // order: every dependency is site-local, so the kernel needs no level
   // structure (kernels_clv.hip).
-  hipError_t e = ensure_scratch(p, sizeof(LevelOp) * count + 256);
+  if (!p->d_pmat_mfma) {   // pad to whole chunks with no-ops (a copy of the last op, stores off)
+    const unsigned chunk = clv_traversal_chunk(p);
+    while (lops.size() % chunk) {
+      LevelOp pad = lops[count - 1];
+      pad.src1 = pad.src2 = 2u;
+      pad.park = 0;
+      pad.noop = 1;
+      lops.push_back(pad);
+    }
+    cuts.back() = (unsigned)lops.size();
+  }
+  const size_t padded = lops.size();
+  hipError_t e = ensure_scratch(p, sizeof(LevelOp) * padded + 256);
   if (e == hipSuccess && p->tiptab_stale) {
     e = launch_tiptab_all(p);
     p->tiptab_stale = false;
   }
   Scratch sc{p};
   if (e == hipSuccess) {
-    LevelOp *d_ops = (LevelOp *)sc.take(sizeof(LevelOp) * count);
-    e = upload(p, d_ops, lops.data(), sizeof(LevelOp) * count);
+    LevelOp *d_ops = (LevelOp *)sc.take(sizeof(LevelOp) * padded);
+    e = upload(p, d_ops, lops.data(), sizeof(LevelOp) * padded);
     p->prof_begin(0);
     for (size_t seg = 0; e == hipSuccess && seg + 1 < cuts.size(); ++seg) {
       const unsigned lo = cuts[seg], n = cuts[seg + 1] - lo;
