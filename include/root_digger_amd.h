@@ -368,6 +368,11 @@ int rdamd_model_optimize_params(rdamd_model_t *m, const rdamd_root_location_t *r
                                 double pgtol, double factor, int optimize_gamma,
                                 double *subst, double *freqs, double *gamma_alpha,
                                 uint64_t *n_batches, uint64_t *n_evaluations);
+/* work counters since the model was created: out[0] objective batches (fused
+ * launches), [1] objective evaluations, [2] full traversals through
+ * compute_lh, [3] root-only positions (compute_lh_root / compute_dlh),
+ * [4] move_root calls, [5] setulb calls.  Diagnostic. */
+void rdamd_model_counters(const rdamd_model_t *m, uint64_t out[6]);
 /* assign_indicies_by_rank_exhaustive, :1867-1911 */
 int rdamd_model_assign_by_rank(rdamd_model_t *m, unsigned int rank, unsigned int num_tasks);
 /* exhaustive_search, :1139-1272, over the assigned roots.  root_id / llh /

@@ -34,9 +34,13 @@ if workers:
     sys.exit(0)
 t0 = time.time()
 tot = 0
+c0 = m.counters()
 for rank in range(ncand):
     m.assign_by_rank(rank, tree.root_count())      # one candidate each
     t1 = time.time()
     res = m.exhaustive_search(1e-7, 1e-7, 1e-12, 1e4)
-    print("candidate %3d  llh %.4f alpha %.4f  %.2fs" % (res["root_id"][0], res["llh"][0], res["alpha"][0], time.time() - t1), flush=True)
+    c1 = m.counters()
+    print("candidate %3d  llh %.4f alpha %.4f  %.2fs  %s" % (res["root_id"][0], res["llh"][0], res["alpha"][0], time.time() - t1,
+          {k: c1[k] - c0.get(k, 0) for k in c1}), flush=True)
+    c0 = c1
 print("total %.2fs for %d candidates" % (time.time() - t0, ncand))

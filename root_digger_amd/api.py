@@ -142,6 +142,7 @@ _sig("rdamd_model_compute_all_root_lh_batched", C.c_int, _vp, _pd)
 _sig("rdamd_model_search", C.c_int, _vp, _u, C.c_double, C.c_double, C.c_double, C.c_double,
      C.c_double, _prl, _pd)
 _sig("rdamd_model_compute_lh_batch", C.c_int, _vp, _u, _prl, _pd, _pd, _pd, _pd)
+_sig("rdamd_model_counters", None, C.c_void_p, C.POINTER(C.c_uint64))
 _sig("rdamd_model_assign_by_rank", C.c_int, _vp, _u, _u)
 _sig("rdamd_model_exhaustive_search_parallel", C.c_int, _vp, _u, C.c_double, C.c_double,
      C.c_double, C.c_double, C.POINTER(C.c_uint64), _pd, _pd, _pu, _prl, _pd)
@@ -690,6 +691,14 @@ class Model:
                                                  C.byref(ne)), "optimize_params")
         return {"subst": subst, "freqs": freqs, "gamma_alpha": ga.value,
                 "batches": nb.value, "evaluations": ne.value}
+
+    def counters(self):
+        """work counters since creation (rdamd_model_counters)."""
+        out = (C.c_uint64 * 6)()
+        lib.rdamd_model_counters(self._h, out)
+        names = ("objective_batches", "objective_evaluations", "full_traversals",
+                 "root_positions", "move_root_calls", "setulb_calls")
+        return dict(zip(names, (int(v) for v in out)))
 
     def assign_by_rank(self, rank, num_tasks):
         self._ok(lib.rdamd_model_assign_by_rank(self._h, rank, num_tasks), "assign_by_rank")

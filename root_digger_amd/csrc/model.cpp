@@ -237,6 +237,7 @@ double model_t::compute_lh(const root_location_t &root_location) {
   auto sched = _tree.generate_operations(root_location);
   const auto &ops = std::get<0>(sched);
   update_pmatrices(std::get<1>(sched), std::get<2>(sched));
+  ++_n_full;
   double lh = 0.0;
   for (size_t i = 0; i < _partitions.size(); ++i) {
     rdamd_update_clvs(_partitions[i], ops.data(), (unsigned)ops.size());
@@ -252,6 +253,7 @@ double model_t::compute_lh_root(const root_location_t &root) {
   auto res = _tree.generate_derivative_operations(root);
   const rdamd_operation_t &op = std::get<0>(res);
   const auto &brl = std::get<2>(res);
+  ++_n_root_positions;
   double lh = 0.0;
   for (size_t i = 0; i < _partitions.size(); ++i) {
     double v = 0.0;
@@ -281,6 +283,7 @@ dlh_t model_t::compute_dlh(const root_location_t &root) {
   // where generate_derivative_operations put the tree
   const double l1[2] = {root_prime.brlen(), root.brlen()};
   const double l2[2] = {root_prime.brlen_compliment(), root.brlen_compliment()};
+  _n_root_positions += 2;
   double fx = 0.0, fxh = 0.0;
   for (size_t i = 0; i < _partitions.size(); ++i) {
     double v[2];
@@ -304,6 +307,7 @@ void model_t::move_root(const root_location_t &new_root) {
   auto sched = _tree.generate_root_update_operations(new_root);
   const auto &ops = std::get<0>(sched);
   if (ops.empty()) return;
+  ++_n_move_root;
   for (size_t i = 0; i < _partitions.size(); ++i) {
     if (rdamd_update_prob_matrices(_partitions[i], _param_indicies[i].data(),
                                    std::get<1>(sched).data(), std::get<2>(sched).data(),
@@ -636,10 +640,18 @@ double model_t::bfgs_params(model_params_t &initial, size_t pi, bfgs_target what
   std::vector<double> x(initial), lo((size_t)n, p_min), hi((size_t)n, p_max);
   int lsave[4] = {0, 0, 0, 0}, isave[44] = {0};
   double dsave[29] = {0};
+  // f(x) is deterministic: a point evaluated by the last FG request is not launched again
+  model_params_t last_x;
+  double last_f = 0.0;
+  auto value_at = [&](const model_params_t &at) {
+    if (at == last_x) return last_f;
+    return objective({at})[0];
+  };
   for (size_t iters = 0; iters < 500; ++iters) {
     _setulb(&n, &m_corr, x.data(), lo.data(), hi.data(), bound_type.data(), &score,
             gradient.data(), &factor, &pgtol, wa.data(), iwa.data(), &task, &iprint, &csave,
             lsave, isave, dsave);
+    ++_n_lbfgsb_iters;
     const bool fg = task >= 10 && task <= 15;   // IS_FG, lib/lbfgsb/lbfgsb.h:84-86
     if (fg) {
       std::vector<model_params_t> xs(1, x);
@@ -651,13 +663,17 @@ double model_t::bfgs_params(model_params_t &initial, size_t pi, bfgs_target what
       }
       auto f = objective(xs);
       score = f[0];
+      last_x = x;
+      last_f = score;
       for (int i = 0; i < n; ++i) gradient[i] = (f[i + 1] - score) / h[i];
     } else {
-      score = objective({x})[0];   // the reference re-evaluates after every return
+      // the reference re-evaluates after every return (src/model.cpp:1500-1503);
+      // NEW_X hands back the point of the last FG request, whose value is known
+      score = value_at(x);
       if (task != 2 /* NEW_X */) break;
     }
   }
-  score = objective({x})[0];
+  score = value_at(x);
   if (initial_score >= score) initial = x;   // improved (scores are -lnL)
   apply(initial);
   return score;

@@ -14,6 +14,7 @@
 #include <functional>
 #include <random>
 #include <stdexcept>
+#include <array>
 #include <string>
 #include <unordered_set>
 #include <utility>
@@ -125,6 +126,12 @@ public:
   void optimize_params(std::vector<partition_parameters_t> &params, const root_location_t &rl,
                        double pgtol, double factor, bool optimize_gamma);
   size_t objective_batches() const { return _objective_batches; }
+  // work counters since construction: {objective batches, objective evaluations,
+  // full traversals (compute_lh), root-only positions (compute_lh_root/compute_dlh),
+  // move_root calls, L-BFGS-B iterations}
+  std::array<uint64_t, 6> counters() const {
+    return {_objective_batches, _objective_evals, _n_full, _n_root_positions, _n_move_root, _n_lbfgsb_iters};
+  }
   size_t objective_evaluations() const { return _objective_evals; }
 
   // heuristic search, src/model.cpp:1008-1137 (needs set_lbfgsb)
@@ -190,6 +197,7 @@ private:
   param_optimizer_t                      _optimizer;
   setulb_fn                              _setulb = nullptr;
   size_t                                 _objective_batches = 0, _objective_evals = 0;
+  uint64_t _n_full = 0, _n_root_positions = 0, _n_move_root = 0, _n_lbfgsb_iters = 0;
 
   enum class bfgs_target { rates, freqs, gamma };
   double bfgs_params(model_params_t &initial, size_t partition, bfgs_target what,

@@ -295,6 +295,11 @@ int rdamd_model_optimize_params(rdamd_model_t *m, const rdamd_root_location_t *r
     return RDAMD_SUCCESS;
   })
 }
+void rdamd_model_counters(const rdamd_model_t *m, uint64_t out[6]) {
+  const auto c = m->model->counters();
+  for (int i = 0; i < 6; ++i) out[i] = c[i];
+}
+
 int rdamd_model_assign_by_rank(rdamd_model_t *m, unsigned int rank, unsigned int num_tasks) {
   GUARD(RDAMD_FAILURE, {
     m->model->assign_indicies_by_rank_exhaustive(rank, num_tasks);
