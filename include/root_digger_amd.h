@@ -391,6 +391,71 @@ int rdamd_model_exhaustive_search_parallel(rdamd_model_t *m, unsigned int worker
                                            double *alpha, unsigned int *n_results,
                                            rdamd_root_location_t *best_rl, double *best_llh);
 
+/* ------------------------------------------------------------------------
+ * Result log / checkpoint: byte-compatible with the reference's <prefix>.ckp
+ * (checkpoint_t, src/checkpoint.hpp:231-300, src/checkpoint.cpp).  A search
+ * appends (root id, lnL, alpha, parameters) per finished candidate under an
+ * fcntl lock, so one file is shared by every process of a multi-GPU run the
+ * way the reference's MPI ranks share it, and an interrupted run resumes from
+ * it (by either program).
+ * ---------------------------------------------------------------------- */
+typedef struct rdamd_checkpoint rdamd_checkpoint_t;
+
+typedef struct {   /* ratehet_opts_t, src/util.hpp:50-70 */
+  int32_t  type;                 /* param_type: 0 emperical 1 estimate 2 equal 3 user */
+  int32_t  rate_category_type;   /* 0 MEDIAN 1 MEAN 2 FREE */
+  uint64_t rate_cats;
+  int32_t  alpha_init;
+  double   alpha;
+} rdamd_ratehet_opts_t;
+
+typedef struct {   /* the serialised fields of cli_options_t, src/checkpoint.cpp:60-91 */
+  const char *msa_filename, *tree_filename, *prefix, *prefix_dir, *model_filename,
+             *freqs_filename, *partition_filename, *data_type, *model_string;
+  const rdamd_ratehet_opts_t *rate_cats;
+  uint64_t n_rate_cats;
+  uint64_t seed, min_roots, threads;
+  double   root_ratio, abs_tolerance, factor, br_tolerance, bfgs_tol;
+  int32_t  silent, exhaustive, echo, invariant_sites;
+  int32_t  early_stop;             /* 0 unset, 1 true, 2 false (initialized_flag_t) */
+  int32_t  initial_root_strategy;  /* 0 random, 1 midpoint, 2 modified_mad */
+} rdamd_cli_options_t;
+
+/* checkpoint_t(prefix): opens or creates <prefix>.ckp */
+rdamd_checkpoint_t *rdamd_checkpoint_open(const char *prefix);
+void        rdamd_checkpoint_close(rdamd_checkpoint_t *c);
+int         rdamd_checkpoint_existing(const rdamd_checkpoint_t *c);   /* existing_checkpoint() */
+const char *rdamd_checkpoint_filename(rdamd_checkpoint_t *c);
+/* save_options (new file only) / load_options (existing file only; the strings
+ * stay valid until the next load or close) */
+int rdamd_checkpoint_save_options(rdamd_checkpoint_t *c, const rdamd_cli_options_t *o);
+int rdamd_checkpoint_load_options(rdamd_checkpoint_t *c, rdamd_cli_options_t *o);
+/* write(result, parameters): counts[n_partitions][4] = lengths of subst_rates,
+ * freqs, gamma_alpha, gamma_weights; values = those vectors back to back */
+int rdamd_checkpoint_write(rdamd_checkpoint_t *c, uint64_t root_id, double llh, double alpha,
+                           unsigned int n_partitions, const uint64_t *counts,
+                           const double *values);
+/* read_results(): takes a snapshot; its entries are then read one by one */
+int rdamd_checkpoint_read_results(rdamd_checkpoint_t *c, unsigned int *n_results);
+int rdamd_checkpoint_result(const rdamd_checkpoint_t *c, unsigned int index, uint64_t *root_id,
+                            double *llh, double *alpha, unsigned int *n_partitions,
+                            uint64_t *n_values);
+int rdamd_checkpoint_result_params(const rdamd_checkpoint_t *c, unsigned int index,
+                                   uint64_t *counts, double *values);
+int rdamd_checkpoint_needs_cleaning(rdamd_checkpoint_t *c);   /* 1 / 0, -1 on error */
+int rdamd_checkpoint_clean(rdamd_checkpoint_t *c);
+/* the file's record checksums (the reference's Adler-32 variant) */
+uint32_t rdamd_checkpoint_checksum_result(uint64_t root_id, double llh, double alpha);
+uint32_t rdamd_checkpoint_checksum_params(unsigned int n_partitions, const uint64_t *counts,
+                                          const double *values);
+/* searches of this model append every finished candidate to `c` (NULL detaches),
+ * src/model.cpp:1107 and :1215 */
+int rdamd_model_set_checkpoint(rdamd_model_t *m, rdamd_checkpoint_t *c);
+/* assign_indicies_by_rank_exhaustive(rank, num_tasks, checkpoint), :1867-1911:
+ * the roots already in the log are skipped */
+int rdamd_model_assign_by_rank_checkpoint(rdamd_model_t *m, unsigned int rank,
+                                          unsigned int num_tasks, rdamd_checkpoint_t *c);
+
 /* character maps (replace corax_map_nt / corax_map_bin, src/main.cpp:484) */
 extern const uint64_t rdamd_map_nt[256];
 extern const uint64_t rdamd_map_bin[256];

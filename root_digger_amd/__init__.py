@@ -15,6 +15,9 @@ from .api import (  # noqa: F401
     Partition,
     Schedule,
     Model,
+    Checkpoint,
+    checkpoint_checksum_result,
+    checkpoint_checksum_params,
     MAP_NT,
     MAP_BIN,
     compute_gamma_cats,
@@ -26,7 +29,8 @@ from .api import (  # noqa: F401
 )
 
 __all__ = [
-    "lib", "lib_path", "RdamdError", "Operation", "RootLocation", "Tree", "Partition", "Schedule", "Model",
+    "lib", "lib_path", "RdamdError", "Operation", "RootLocation", "Tree", "Partition", "Schedule", "Model", "Checkpoint",
+    "checkpoint_checksum_result", "checkpoint_checksum_params",
     "MAP_NT", "MAP_BIN", "compute_gamma_cats", "GAMMA_RATES_MEAN", "GAMMA_RATES_MEDIAN",
     "device_count", "set_device", "msa_probe",
 ]

@@ -1,5 +1,6 @@
 """ctypes mirror of include/root_digger_amd.h (names follow the C ABI)."""
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -142,6 +143,44 @@ _sig("rdamd_model_compute_all_root_lh_batched", C.c_int, _vp, _pd)
 _sig("rdamd_model_search", C.c_int, _vp, _u, C.c_double, C.c_double, C.c_double, C.c_double,
      C.c_double, _prl, _pd)
 _sig("rdamd_model_compute_lh_batch", C.c_int, _vp, _u, _prl, _pd, _pd, _pd, _pd)
+class RatehetOpts(C.Structure):
+    """rdamd_ratehet_opts_t == ratehet_opts_t (src/util.hpp:50-70)."""
+    _fields_ = [("type", C.c_int32), ("rate_category_type", C.c_int32), ("rate_cats", C.c_uint64),
+                ("alpha_init", C.c_int32), ("alpha", C.c_double)]
+
+
+class CliOptions(C.Structure):
+    """rdamd_cli_options_t: the fields of cli_options_t the checkpoint header
+    holds (src/checkpoint.cpp:60-91)."""
+    _fields_ = ([(n, C.c_char_p) for n in (
+        "msa_filename", "tree_filename", "prefix", "prefix_dir", "model_filename",
+        "freqs_filename", "partition_filename", "data_type", "model_string")] + [
+        ("rate_cats", C.POINTER(RatehetOpts)), ("n_rate_cats", C.c_uint64),
+        ("seed", C.c_uint64), ("min_roots", C.c_uint64), ("threads", C.c_uint64),
+        ("root_ratio", C.c_double), ("abs_tolerance", C.c_double), ("factor", C.c_double),
+        ("br_tolerance", C.c_double), ("bfgs_tol", C.c_double),
+        ("silent", C.c_int32), ("exhaustive", C.c_int32), ("echo", C.c_int32),
+        ("invariant_sites", C.c_int32), ("early_stop", C.c_int32),
+        ("initial_root_strategy", C.c_int32)])
+
+
+_pu64 = C.POINTER(C.c_uint64)
+_sig("rdamd_checkpoint_open", _vp, C.c_char_p)
+_sig("rdamd_checkpoint_close", None, _vp)
+_sig("rdamd_checkpoint_existing", C.c_int, _vp)
+_sig("rdamd_checkpoint_filename", C.c_char_p, _vp)
+_sig("rdamd_checkpoint_save_options", C.c_int, _vp, C.POINTER(CliOptions))
+_sig("rdamd_checkpoint_load_options", C.c_int, _vp, C.POINTER(CliOptions))
+_sig("rdamd_checkpoint_write", C.c_int, _vp, C.c_uint64, C.c_double, C.c_double, _u, _pu64, _pd)
+_sig("rdamd_checkpoint_read_results", C.c_int, _vp, _pu)
+_sig("rdamd_checkpoint_result", C.c_int, _vp, _u, _pu64, _pd, _pd, _pu, _pu64)
+_sig("rdamd_checkpoint_result_params", C.c_int, _vp, _u, _pu64, _pd)
+_sig("rdamd_checkpoint_needs_cleaning", C.c_int, _vp)
+_sig("rdamd_checkpoint_clean", C.c_int, _vp)
+_sig("rdamd_checkpoint_checksum_result", C.c_uint32, C.c_uint64, C.c_double, C.c_double)
+_sig("rdamd_checkpoint_checksum_params", C.c_uint32, _u, _pu64, _pd)
+_sig("rdamd_model_set_checkpoint", C.c_int, _vp, _vp)
+_sig("rdamd_model_assign_by_rank_checkpoint", C.c_int, _vp, _u, _u, _vp)
 _sig("rdamd_model_counters", None, C.c_void_p, C.POINTER(C.c_uint64))
 _sig("rdamd_model_assign_by_rank", C.c_int, _vp, _u, _u)
 _sig("rdamd_model_exhaustive_search_parallel", C.c_int, _vp, _u, C.c_double, C.c_double,
@@ -548,6 +587,149 @@ class Partition:
             _fail("evaluate_batch_device")
 
 
+_OPTION_STRINGS = ("msa_filename", "tree_filename", "prefix", "prefix_dir", "model_filename",
+                   "freqs_filename", "partition_filename", "data_type", "model_string")
+_OPTION_SCALARS = ("seed", "min_roots", "threads", "root_ratio", "abs_tolerance", "factor",
+                   "br_tolerance", "bfgs_tol", "silent", "exhaustive", "echo",
+                   "invariant_sites", "early_stop", "initial_root_strategy")
+PARAM_FIELDS = ("subst_rates", "freqs", "gamma_alpha", "gamma_weights")
+
+
+def _flatten_params(params):
+    """[{subst_rates, freqs, gamma_alpha, gamma_weights}, ...] -> (counts, values)"""
+    counts = np.array([len(p.get(f, ())) for p in params for f in PARAM_FIELDS], dtype=np.uint64)
+    values = np.array([v for p in params for f in PARAM_FIELDS for v in p.get(f, ())],
+                      dtype=np.float64)
+    return counts, np.ascontiguousarray(values if values.size else np.zeros(1))
+
+
+class Checkpoint:
+    """checkpoint_t of the reference (src/checkpoint.hpp:231-300): the
+    `<prefix>.ckp` result log, byte-compatible, shared between processes under
+    an fcntl lock."""
+
+    def __init__(self, prefix):
+        self._h = lib.rdamd_checkpoint_open(os.fsencode(prefix))
+        if not self._h:
+            _fail("checkpoint_open")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.rdamd_checkpoint_close(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    @property
+    def handle(self):
+        return self._h
+
+    def existing_checkpoint(self):
+        return bool(lib.rdamd_checkpoint_existing(self._h))
+
+    def get_filename(self):
+        return os.fsdecode(lib.rdamd_checkpoint_filename(self._h))
+
+    def save_options(self, options):
+        """options: dict of the cli_options_t fields (missing ones keep the
+        reference's defaults); rate_cats = list of dicts or ints."""
+        o = CliOptions()
+        keep = []
+        for k in _OPTION_STRINGS:
+            b = os.fsencode(str(options.get(k, "")))
+            keep.append(b)
+            setattr(o, k, b)
+        cats = options.get("rate_cats", [1])
+        arr = (RatehetOpts * len(cats))()
+        for i, c in enumerate(cats):
+            c = {"rate_cats": c} if isinstance(c, int) else c
+            arr[i] = RatehetOpts(c.get("type", 1), c.get("rate_category_type", 1),
+                                 c.get("rate_cats", 1), int(c.get("alpha_init", False)),
+                                 c.get("alpha", 1.0))
+        o.rate_cats, o.n_rate_cats = arr, len(cats)
+        defaults = dict(seed=0, min_roots=1, threads=0, root_ratio=0.01, abs_tolerance=1e-7,
+                        factor=1e4, br_tolerance=1e-12, bfgs_tol=1e-7, silent=0, exhaustive=0,
+                        echo=0, invariant_sites=0, early_stop=0, initial_root_strategy=2)
+        for k in _OPTION_SCALARS:
+            v = options.get(k, defaults[k])
+            setattr(o, k, int(v) if isinstance(v, bool) else v)
+        if lib.rdamd_checkpoint_save_options(self._h, C.byref(o)) != 1:
+            _fail("checkpoint_save_options")
+
+    def load_options(self):
+        """the header of an existing checkpoint as a dict (None for a new file)."""
+        if not self.existing_checkpoint():
+            return None
+        o = CliOptions()
+        if lib.rdamd_checkpoint_load_options(self._h, C.byref(o)) != 1:
+            _fail("checkpoint_load_options")
+        out = {k: os.fsdecode(getattr(o, k) or b"") for k in _OPTION_STRINGS}
+        out["rate_cats"] = [
+            {f: getattr(o.rate_cats[i], f) for f, _ in RatehetOpts._fields_}
+            for i in range(o.n_rate_cats)]
+        out.update({k: getattr(o, k) for k in _OPTION_SCALARS})
+        return out
+
+    def write(self, root_id, llh, alpha, params):
+        counts, values = _flatten_params(params)
+        if lib.rdamd_checkpoint_write(self._h, root_id, llh, alpha, len(params),
+                                      counts.ctypes.data_as(_pu64), _dptr(values)) != 1:
+            _fail("checkpoint_write")
+
+    def read_results(self):
+        """[(root_id, llh, alpha, [params per partition]), ...] in file order."""
+        n = C.c_uint(0)
+        if lib.rdamd_checkpoint_read_results(self._h, C.byref(n)) != 1:
+            _fail("checkpoint_read_results")
+        out = []
+        for i in range(n.value):
+            rid, npart, nval = C.c_uint64(0), C.c_uint(0), C.c_uint64(0)
+            llh, alpha = C.c_double(0), C.c_double(0)
+            lib.rdamd_checkpoint_result(self._h, i, C.byref(rid), C.byref(llh), C.byref(alpha),
+                                        C.byref(npart), C.byref(nval))
+            counts = np.zeros(4 * npart.value, dtype=np.uint64)
+            values = np.zeros(max(nval.value, 1), dtype=np.float64)
+            lib.rdamd_checkpoint_result_params(self._h, i, counts.ctypes.data_as(_pu64),
+                                               _dptr(values))
+            params, at = [], 0
+            for p in range(npart.value):
+                d = {}
+                for k, f in enumerate(PARAM_FIELDS):
+                    c = int(counts[4 * p + k])
+                    d[f] = values[at:at + c].tolist()
+                    at += c
+                params.append(d)
+            out.append((int(rid.value), llh.value, alpha.value, params))
+        return out
+
+    def current_progress(self):
+        return [(r, l, a) for r, l, a, _ in self.read_results()]
+
+    def completed_indicies(self):
+        return [r for r, _, _, _ in self.read_results()]
+
+    def needs_cleaning(self):
+        r = lib.rdamd_checkpoint_needs_cleaning(self._h)
+        if r < 0:
+            _fail("checkpoint_needs_cleaning")
+        return bool(r)
+
+    def clean(self):
+        if lib.rdamd_checkpoint_clean(self._h) != 1:
+            _fail("checkpoint_clean")
+
+
+def checkpoint_checksum_result(root_id, llh, alpha):
+    return int(lib.rdamd_checkpoint_checksum_result(root_id, llh, alpha))
+
+
+def checkpoint_checksum_params(params):
+    counts, values = _flatten_params(params)
+    return int(lib.rdamd_checkpoint_checksum_params(len(params), counts.ctypes.data_as(_pu64),
+                                                    _dptr(values)))
+
+
 class Model:
     """model_t (src/model.hpp:47) through the C ABI, one partition."""
 
@@ -700,8 +882,19 @@ class Model:
                  "root_positions", "move_root_calls", "setulb_calls")
         return dict(zip(names, (int(v) for v in out)))
 
-    def assign_by_rank(self, rank, num_tasks):
-        self._ok(lib.rdamd_model_assign_by_rank(self._h, rank, num_tasks), "assign_by_rank")
+    def assign_by_rank(self, rank, num_tasks, checkpoint=None):
+        """assign_indicies_by_rank_exhaustive; with a Checkpoint, the roots it
+        already holds are skipped (src/model.cpp:1867-1911)."""
+        if checkpoint is not None:
+            self._ok(lib.rdamd_model_assign_by_rank_checkpoint(self._h, rank, num_tasks,
+                                                               checkpoint.handle), "assign_by_rank")
+        else:
+            self._ok(lib.rdamd_model_assign_by_rank(self._h, rank, num_tasks), "assign_by_rank")
+
+    def set_checkpoint(self, checkpoint):
+        """searches append every finished candidate to this Checkpoint (None detaches)."""
+        self._checkpoint = checkpoint          # keep it alive
+        lib.rdamd_model_set_checkpoint(self._h, checkpoint.handle if checkpoint else None)
 
     def exhaustive_search(self, atol, pgtol, brtol, factor, workers=0):
         """workers > 0: that many host threads, each with its own model replica."""

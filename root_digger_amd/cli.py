@@ -1,10 +1,16 @@
 #!/usr/bin/env python3
 """Exhaustive root search from the command line (the `rd --msa M --tree T
---exhaustive` entry of the reference, /root/reference/src/main.cpp:411-680,
-without its MPI / checkpoint control plane):
+--exhaustive` entry of the reference, /root/reference/src/main.cpp:411-680):
 
   python -m root_digger_amd.cli --msa aln.fasta --tree t.nwk --prefix out \\
          [--rate-cats 4] [--lbfgsb /path/to/liblbfgsb.so] [--early-stop]
+
+Every finished candidate root goes into <prefix>.ckp, the reference's own
+checkpoint format (csrc/checkpoint.hpp): an interrupted run resumes from it,
+`--clean` repairs it, and the processes of a multi-GPU run -- one per GPU,
+started by `python -m torch.distributed.run`, which sets RANK / LOCAL_RANK /
+WORLD_SIZE -- take the candidate chunks the reference's MPI ranks take
+(src/model.cpp:1867-1911) and meet in that file; rank 0 writes the trees.
 
 Writes <prefix>.lwr.tree (every branch annotated with LWR, LLH and alpha,
 src/model.cpp:1237-1268) and <prefix>.rooted.tree (the tree rooted at the best
@@ -16,10 +22,11 @@ objective.  Code defaults follow src/util.hpp:159-177."""
 import argparse
 import ctypes
 import math
+import os
 import sys
 import time
 
-from . import Model, Tree, set_device
+from . import Checkpoint, Model, Tree, set_device
 
 
 def main(argv=None):
@@ -39,13 +46,70 @@ def main(argv=None):
     ap.add_argument("--workers", type=int, default=4,
                     help="host threads, each with its own model replica / HIP stream "
                          "(0 = the plain sequential loop)")
-    ap.add_argument("--device", type=int, default=0)
+    ap.add_argument("--device", type=int, default=None,
+                    help="HIP device (default: LOCAL_RANK, else 0)")
     ap.add_argument("--silent", action="store_true")
+    ap.add_argument("--clean", action="store_true",
+                    help="repair the checkpoint file and exit (src/main.cpp:138-146)")
+    ap.add_argument("--no-checkpoint", action="store_true",
+                    help="keep results in memory only (single process)")
     args = ap.parse_args(argv)
     prefix = args.prefix or args.msa
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1 and args.no_checkpoint:
+        ap.error("--no-checkpoint: the ranks of a multi-process run meet in the checkpoint file")
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as tdist
+            if not tdist.is_initialized():
+                tdist.init_process_group("gloo")     # host-side rendezvous only
+            tdist.barrier()
 
     t0 = time.time()
-    set_device(args.device)
+    # the HIP device is claimed BEFORE the rendezvous: a multi-rank gloo group
+    # created first leaves this process without visible devices
+    device = args.device if args.device is not None else int(os.environ.get("LOCAL_RANK", "0"))
+    set_device(device)
+    # mpi_create_checkpoint, src/main.cpp:366-409: rank 0 creates / repairs the
+    # file and writes the header, the others open it afterwards; an existing
+    # header overrides the search options given here (merge_options_checkpoint)
+    ckp = None
+    if not args.no_checkpoint:
+        if rank == 0:
+            ckp = Checkpoint(prefix)
+            if args.clean:
+                ckp.clean()
+                return 0
+            stored = ckp.load_options()
+            if stored is None:
+                ckp.save_options({
+                    "msa_filename": args.msa, "tree_filename": args.tree, "prefix": prefix,
+                    "data_type": "nt", "rate_cats": [args.rate_cats], "seed": args.seed,
+                    "threads": args.workers, "abs_tolerance": args.atol, "factor": args.factor,
+                    "br_tolerance": args.brtol, "bfgs_tol": args.bfgstol,
+                    "silent": args.silent, "exhaustive": True,
+                    "early_stop": 1 if args.early_stop else 2})
+            if ckp.needs_cleaning():
+                ckp.clean()
+        elif args.clean:
+            return 0
+        barrier()
+        if rank != 0:
+            ckp = Checkpoint(prefix)
+        stored = ckp.load_options()
+        if stored is not None and ckp.existing_checkpoint():
+            if not args.silent and rank == 0:
+                print("Loading options from the checkpoint file. Some cli options are ignored. "
+                      "If the program is not working, try deleting the checkpoint file",
+                      file=sys.stderr)
+            args.msa, args.tree = stored["msa_filename"], stored["tree_filename"]
+            args.rate_cats = int(stored["rate_cats"][0]["rate_cats"])
+            args.seed, args.atol, args.factor = stored["seed"], stored["abs_tolerance"], stored["factor"]
+            args.brtol, args.bfgstol = stored["br_tolerance"], stored["bfgs_tol"]
+            args.early_stop = stored["early_stop"] == 1
+
     tree = Tree.from_file(args.tree)
     model = Model.from_file(tree, args.msa, rate_cats=args.rate_cats, seed=args.seed,
                             early_stop=args.early_stop)
@@ -55,8 +119,26 @@ def main(argv=None):
         keep = ctypes.CDLL(args.lbfgsb)
         model.set_lbfgsb(keep.setulb)
     model.compute_lh(tree.root_location(0))                    # model.initialize()
+    if ckp is not None:
+        model.set_checkpoint(ckp)
+    model.assign_by_rank(rank, world, ckp)                     # src/main.cpp:612-615
+    barrier()
     res = model.exhaustive_search(args.atol, args.bfgstol, args.brtol, args.factor,
                                   workers=args.workers)
+    barrier()
+    if rank != 0:
+        return 0
+    if ckp is not None:
+        # rank 0 reads everybody's results (and an earlier run's) back from the
+        # log, src/model.cpp:1237-1268
+        done = ckp.current_progress()
+        res = {"root_id": [r for r, _, _ in done], "llh": [l for _, l, _ in done],
+               "alpha": [a for _, _, a in done]}
+        k = max(range(len(done)), key=lambda i: done[i][1])    # first maximum, as std::max_element
+        res["best_llh"] = done[k][1]
+        res["best"] = tree.root_location(done[k][0]).with_ratio(done[k][2])
+    if not res["root_id"]:
+        raise SystemExit("no candidate root was evaluated")
 
     # likelihood weight ratios, src/model.cpp:1239-1258
     mx = max(res["llh"])

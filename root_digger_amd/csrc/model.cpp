@@ -1,6 +1,7 @@
 // model_t on the rdamd C ABI; behaviour follows /root/reference/src/model.cpp
 // (cited per function).
 #include "model.hpp"
+#include "checkpoint.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -754,6 +755,7 @@ std::pair<root_location_t, double> model_t::search(size_t min_roots, double root
       cur_best_rl = cur.first; cur_best_lh = cur.second;
       rl = cur_best_rl;
     }
+    if (_checkpoint) _checkpoint->write({cur_best_rl.id, cur_best_lh, cur_best_rl.brlen_ratio}, params);
     local.push_back({cur_best_rl.id, cur_best_lh, cur_best_rl.brlen_ratio});
     local_params.push_back(params);
   }
@@ -808,6 +810,7 @@ std::pair<root_location_t, double> model_t::exhaustive_search(double atol, doubl
       if (cur_llh > cur_best_llh) { cur_best_rl = cur_rl; cur_best_llh = cur_llh; }
       rl = cur_rl;
     }
+    if (_checkpoint) _checkpoint->write({cur_best_rl.id, cur_best_llh, cur_best_rl.brlen_ratio}, params);
     if (results) results->push_back({cur_best_rl.id, cur_best_llh, cur_best_rl.brlen_ratio});
     if (cur_best_llh > best_llh) { best_rl = cur_best_rl; best_llh = cur_best_llh; }
   }

@@ -25,6 +25,8 @@
 
 namespace rdamd {
 
+class checkpoint_t;
+
 typedef std::vector<double> model_params_t;
 
 struct dlh_t {   // src/model.hpp:21-24
@@ -32,16 +34,21 @@ struct dlh_t {   // src/model.hpp:21-24
   double dlh;
 };
 
-enum class rate_category { MEAN, MEDIAN, FREE };   // src/util.hpp
+// src/util.hpp:37-70.  Values and member order are the reference's: the struct
+// goes into the checkpoint file as its raw 32 bytes (checkpoint.hpp).
+enum class param_type : int32_t { emperical, estimate, equal, user };
+enum class rate_category : int32_t { MEDIAN, MEAN, FREE };
 
-struct ratehet_opts_t {   // src/util.hpp (rate heterogeneity part)
+struct ratehet_opts_t {
+  param_type    type = param_type::estimate;
   rate_category rate_category_type = rate_category::MEAN;
-  size_t        rate_cats = 1;
+  uint64_t      rate_cats = 1;
   bool          alpha_init = false;
   double        alpha = 1.0;
   ratehet_opts_t() = default;
   ratehet_opts_t(size_t cats) : rate_cats(cats) {}
 };
+static_assert(sizeof(ratehet_opts_t) == 32, "checkpoint layout");
 
 struct partition_parameters_t {   // src/util.hpp:119-124
   model_params_t subst_rates, freqs, gamma_alpha, gamma_weights;
@@ -122,6 +129,9 @@ public:
                            int *task, int *iprint, int *csave, int *lsave, int *isave,
                            double *dsave);
   void set_lbfgsb(setulb_fn fn) { _setulb = fn; }
+  // every finished candidate is appended to this result log (checkpoint.hpp), as
+  // the reference's searches do (src/model.cpp:1107, :1215); not owned
+  void set_checkpoint(checkpoint_t *c) { _checkpoint = c; }
   // src/model.cpp:1925-1984
   void optimize_params(std::vector<partition_parameters_t> &params, const root_location_t &rl,
                        double pgtol, double factor, bool optimize_gamma);
@@ -192,6 +202,7 @@ private:
   std::vector<std::vector<unsigned int>> _param_indicies;
   std::vector<size_t>                    _assigned_idx;
   std::minstd_rand                       _random_engine;
+  checkpoint_t                          *_checkpoint = nullptr;
   bool                                   _invariant_sites, _early_stop;   // +I is inert (:292-300)
   uint64_t                               _seed;
   param_optimizer_t                      _optimizer;

@@ -8,6 +8,7 @@
 #include <algorithm>
 
 #include "common.hpp"
+#include "checkpoint.hpp"
 #include "model.hpp"
 #include "tree_c_api.hpp"
 
@@ -19,10 +20,13 @@ struct rdamd_model {
   uint64_t seed = 0;
   bool     early_stop = false;
   void    *setulb = nullptr;
+  rdamd::checkpoint_t *checkpoint = nullptr;
   ~rdamd_model() { delete model; }
 };
 
 using rdamd::root_location_t;
+
+rdamd::checkpoint_t *rdamd_checkpoint_cpp(rdamd_checkpoint_t *c);   // checkpoint_c_api.cpp
 
 namespace {
 root_location_t to_cpp(const rdamd_root_location_t *rl) {
@@ -236,6 +240,7 @@ int rdamd_model_exhaustive_search_parallel(rdamd_model_t *m, unsigned int worker
                                false, m->seed + wid, m->early_stop);
         replica.initialize_partitions({m->msa});
         if (m->setulb) replica.set_lbfgsb(reinterpret_cast<rdamd::model_t::setulb_fn>(m->setulb));
+        replica.set_checkpoint(m->checkpoint);
         replica.initialize();
         for (;;) {
           const size_t k = next.fetch_add(1);
@@ -300,6 +305,20 @@ void rdamd_model_counters(const rdamd_model_t *m, uint64_t out[6]) {
   for (int i = 0; i < 6; ++i) out[i] = c[i];
 }
 
+int rdamd_model_set_checkpoint(rdamd_model_t *m, rdamd_checkpoint_t *c) {
+  m->checkpoint = rdamd_checkpoint_cpp(c);
+  m->model->set_checkpoint(m->checkpoint);
+  return RDAMD_SUCCESS;
+}
+int rdamd_model_assign_by_rank_checkpoint(rdamd_model_t *m, unsigned int rank,
+                                          unsigned int num_tasks, rdamd_checkpoint_t *c) {
+  GUARD(RDAMD_FAILURE, {
+    std::vector<size_t> done;
+    if (c) done = rdamd_checkpoint_cpp(c)->completed_indicies();
+    m->model->assign_indicies_by_rank_exhaustive(rank, num_tasks, done);
+    return RDAMD_SUCCESS;
+  })
+}
 int rdamd_model_assign_by_rank(rdamd_model_t *m, unsigned int rank, unsigned int num_tasks) {
   GUARD(RDAMD_FAILURE, {
     m->model->assign_indicies_by_rank_exhaustive(rank, num_tasks);

@@ -204,3 +204,57 @@ def test_cli_exhaustive_outputs(tmp_path):
     assert abs(sum(w) - 1.0) < 1e-4                # one annotation per branch, weights sum to 1
     t = rd.Tree.from_newick(rooted)                # a binary-rooted tree parses (and unroots)
     assert t.tip_count() == 10 and "NHX" not in rooted
+
+
+def test_cli_checkpoint_resume_and_two_ranks(tmp_path):
+    """The <prefix>.ckp control flow of the reference's main (src/main.cpp:366-460,
+    :612-635): a finished run leaves every candidate in the log; a rerun finds
+    nothing left to do and reproduces the trees from the log alone; a log cut
+    short is repaired and only the missing candidates are recomputed; two
+    processes (RANK/WORLD_SIZE, as torch.distributed.run sets them) split the
+    candidates like the reference's MPI ranks and meet in the same file."""
+    import subprocess
+    import sys
+    from root_digger_amd import cli
+    msa, tre = os.path.join(util.DATA, "10.fasta"), os.path.join(util.DATA, "10.tree")
+    base = ["--msa", msa, "--tree", tre, "--atol", "1e-3", "--brtol", "1e-3", "--silent"]
+    one = str(tmp_path / "one")
+    assert cli.main(base + ["--prefix", one]) == 0
+    ck = rd.Checkpoint(one)
+    first = sorted(ck.read_results())
+    assert [r[0] for r in first] == list(range(17))
+    assert ck.load_options()["exhaustive"] == 1 and ck.load_options()["msa_filename"] == msa
+    lwr = open(one + ".lwr.tree").read()
+
+    os.remove(one + ".lwr.tree")                       # rerun: all work is in the log
+    assert cli.main(["--msa", "ignored", "--tree", "ignored", "--prefix", one, "--silent"]) == 0
+    assert open(one + ".lwr.tree").read() == lwr
+    assert sorted(rd.Checkpoint(one).read_results()) == first
+
+    raw = open(one + ".ckp", "rb").read()              # tear the last record
+    open(one + ".ckp", "wb").write(raw[:-9])
+    assert rd.Checkpoint(one).needs_cleaning()
+    assert cli.main(base + ["--prefix", one]) == 0
+    again = rd.Checkpoint(one)
+    assert not again.needs_cleaning()
+    got = sorted(again.read_results())
+    assert [r[0] for r in got] == list(range(17))
+    for a, b in zip(got, first):                       # the recomputed one matches the first run
+        assert a[0] == b[0] and abs(a[1] - b[1]) < 1e-6 * abs(b[1])
+
+    two = str(tmp_path / "two")                        # two ranks, one GPU, one shared log
+    env = dict(os.environ, WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533",
+               PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    procs = [subprocess.Popen([sys.executable, "-m", "root_digger_amd.cli"] + base +
+                              ["--prefix", two, "--device", "0", "--workers", "0"],
+                              env=dict(env, RANK=str(r), LOCAL_RANK=str(r)))
+             for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=600) == 0
+    both = sorted(rd.Checkpoint(two).read_results())
+    assert [r[0] for r in both] == list(range(17))
+    for a, b in zip(both, first):
+        assert abs(a[1] - b[1]) < 1e-6 * abs(b[1]) and abs(a[2] - b[2]) < 1e-3
+    import re
+    w = [float(x) for x in re.findall(r"LWR=([0-9.]+)", open(two + ".lwr.tree").read())]
+    assert len(w) == 17 and abs(sum(w) - 1.0) < 1e-4
