@@ -390,6 +390,16 @@ int rdamd_model_exhaustive_search_parallel(rdamd_model_t *m, unsigned int worker
                                            double factor, uint64_t *root_id, double *llh,
                                            double *alpha, unsigned int *n_results,
                                            rdamd_root_location_t *best_rl, double *best_llh);
+/* Lock-stepped form: `in_flight` candidates advance together; whenever all of
+ * those that are inside optimize_params have asked for their next objective
+ * batch (the n+1 evaluations of one L-BFGS-B step, src/model.cpp:1430-1522),
+ * ONE fused launch on m's own partition serves them all.  Same results as the
+ * sequential loop; launch-bound (small) alignments gain the most. */
+int rdamd_model_exhaustive_search_lockstep(rdamd_model_t *m, unsigned int in_flight,
+                                           double atol, double pgtol, double brtol,
+                                           double factor, uint64_t *root_id, double *llh,
+                                           double *alpha, unsigned int *n_results,
+                                           rdamd_root_location_t *best_rl, double *best_llh);
 
 /* ------------------------------------------------------------------------
  * Result log / checkpoint: byte-compatible with the reference's <prefix>.ckp

@@ -22,15 +22,18 @@ m.compute_lh(tree.root_location(0))
 lib = rd.lib
 import ctypes as C
 workers = int(os.environ.get("WORKERS", "0"))
-if workers:
+lockstep = int(os.environ.get("LOCKSTEP", "0"))
+if workers or lockstep:
     import numpy as _np
     lib.rdamd_model_assign_by_rank  # noqa
     # first `ncand` candidates in one call, `workers` threads
     m._ok(lib.rdamd_model_assign_by_rank(m._h, 0, max(1, tree.root_count() // ncand)), "assign")
     t1 = time.time()
-    res = m.exhaustive_search(1e-7, 1e-7, 1e-12, 1e4, workers=workers)
+    res = m.exhaustive_search(1e-7, 1e-7, 1e-12, 1e4, workers=workers, lockstep=lockstep)
     dt = time.time() - t1
-    print("%d candidates, %d workers: %.2fs  (%.3fs per candidate)" % (len(res["root_id"]), workers, dt, dt / len(res["root_id"])))
+    print("%d candidates, %s: %.2fs  (%.3fs per candidate)  sum llh %.6f" % (
+        len(res["root_id"]), "%d in lock step" % lockstep if lockstep else "%d workers" % workers,
+        dt, dt / len(res["root_id"]), float(sum(res["llh"]))))
     sys.exit(0)
 t0 = time.time()
 tot = 0

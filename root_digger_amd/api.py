@@ -185,6 +185,8 @@ _sig("rdamd_model_counters", None, C.c_void_p, C.POINTER(C.c_uint64))
 _sig("rdamd_model_assign_by_rank", C.c_int, _vp, _u, _u)
 _sig("rdamd_model_exhaustive_search_parallel", C.c_int, _vp, _u, C.c_double, C.c_double,
      C.c_double, C.c_double, C.POINTER(C.c_uint64), _pd, _pd, _pu, _prl, _pd)
+_sig("rdamd_model_exhaustive_search_lockstep", C.c_int, _vp, _u, C.c_double, C.c_double,
+     C.c_double, C.c_double, C.POINTER(C.c_uint64), _pd, _pd, _pu, _prl, _pd)
 _sig("rdamd_model_set_lbfgsb", None, _vp, _vp)
 _sig("rdamd_model_optimize_params", C.c_int, _vp, _prl, C.c_double, C.c_double, C.c_int, _pd, _pd,
      _pd, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64))
@@ -896,8 +898,10 @@ class Model:
         self._checkpoint = checkpoint          # keep it alive
         lib.rdamd_model_set_checkpoint(self._h, checkpoint.handle if checkpoint else None)
 
-    def exhaustive_search(self, atol, pgtol, brtol, factor, workers=0):
-        """workers > 0: that many host threads, each with its own model replica."""
+    def exhaustive_search(self, atol, pgtol, brtol, factor, workers=0, lockstep=0):
+        """workers > 0: that many host threads, each with its own model replica.
+        lockstep > 0: that many candidates in flight, their objective batches
+        combined into one launch (rdamd_model_exhaustive_search_lockstep)."""
         n = self._tree.root_count()
         ids = (C.c_uint64 * n)()
         llh = np.zeros(n, dtype=np.float64)
@@ -905,7 +909,11 @@ class Model:
         cnt = C.c_uint(0)
         best = RootLocation()
         best_llh = C.c_double(0.0)
-        if workers > 0:
+        if lockstep > 0:
+            self._ok(lib.rdamd_model_exhaustive_search_lockstep(
+                self._h, lockstep, atol, pgtol, brtol, factor, ids, _dptr(llh), _dptr(alpha),
+                C.byref(cnt), C.byref(best), C.byref(best_llh)), "exhaustive_search_lockstep")
+        elif workers > 0:
             self._ok(lib.rdamd_model_exhaustive_search_parallel(
                 self._h, workers, atol, pgtol, brtol, factor, ids, _dptr(llh), _dptr(alpha),
                 C.byref(cnt), C.byref(best), C.byref(best_llh)), "exhaustive_search_parallel")

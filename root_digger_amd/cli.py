@@ -46,6 +46,9 @@ def main(argv=None):
     ap.add_argument("--workers", type=int, default=4,
                     help="host threads, each with its own model replica / HIP stream "
                          "(0 = the plain sequential loop)")
+    ap.add_argument("--lockstep", type=int, default=0,
+                    help="candidates advanced in lock step, their optimiser batches merged "
+                         "into one launch (overrides --workers)")
     ap.add_argument("--device", type=int, default=None,
                     help="HIP device (default: LOCAL_RANK, else 0)")
     ap.add_argument("--silent", action="store_true")
@@ -124,7 +127,7 @@ def main(argv=None):
     model.assign_by_rank(rank, world, ckp)                     # src/main.cpp:612-615
     barrier()
     res = model.exhaustive_search(args.atol, args.bfgstol, args.brtol, args.factor,
-                                  workers=args.workers)
+                                  workers=args.workers, lockstep=args.lockstep)
     barrier()
     if rank != 0:
         return 0

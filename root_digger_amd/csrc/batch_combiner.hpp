@@ -1,0 +1,147 @@
+// Lock-step batching of the optimiser's objective across candidate roots
+// (SURVEY.md 8(f)1).  The reference optimises one candidate root per MPI rank
+// (src/model.cpp:1154-1229, :1899-1907); each L-BFGS-B step asks for n+1
+// likelihood evaluations (:1430-1522).  Here several candidates run on host
+// threads of one process, and instead of each launching its own 13-job batch,
+// their requests meet in this combiner: when every candidate that is currently
+// inside optimize_params has asked, ONE fused launch on a shared partition
+// evaluates all of them.  Small alignments, whose single batches are
+// launch-bound, gain the most; large ones keep the GPU at its wide-batch rate
+// with a single copy of the tip data for the objective.
+#pragma once
+
+#include <condition_variable>
+#include <mutex>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/root_digger_amd.h"
+
+namespace rdamd {
+
+class batch_combiner_t {
+public:
+  // `shared`: the partition every combined launch runs on (not owned)
+  explicit batch_combiner_t(rdamd_partition_t *shared) : _part(shared) {}
+
+  rdamd_partition_t *partition() const { return _part; }
+
+  // a candidate enters / leaves the phase in which it submits requests
+  void enter() {
+    std::lock_guard<std::mutex> g(_mu);
+    ++_active;
+  }
+  void leave() {
+    {
+      std::lock_guard<std::mutex> g(_mu);
+      --_active;
+    }
+    _cv.notify_all();   // the others may now be complete without this one
+  }
+  struct scope_t {   // RAII enter/leave
+    batch_combiner_t *c;
+    explicit scope_t(batch_combiner_t *c_) : c(c_) { if (c) c->enter(); }
+    ~scope_t() { if (c) c->leave(); }
+    scope_t(const scope_t &) = delete;
+    scope_t &operator=(const scope_t &) = delete;
+  };
+
+  // schedules live on the shared partition; its stream is used by one thread at a time
+  rdamd_schedule_t *schedule_create(const rdamd_operation_t *ops, unsigned n_ops,
+                                    const unsigned *matrix_indices, const double *branch_lengths,
+                                    unsigned n_matrices) {
+    std::lock_guard<std::mutex> g(_launch_mu);
+    return rdamd_schedule_create(_part, ops, n_ops, matrix_indices, branch_lengths, n_matrices);
+  }
+  void schedule_destroy(rdamd_schedule_t *s) {
+    std::lock_guard<std::mutex> g(_launch_mu);
+    rdamd_schedule_destroy(s);
+  }
+
+  // n jobs of one candidate (same schedule): subst [n][12], freqs [n][4],
+  // rates / weights [n][R].  Returns when the launch that carried them is done.
+  void evaluate(unsigned n, const rdamd_schedule_t *sched, const double *subst,
+                const double *freqs, const double *rates, const double *weights, double *out) {
+    request_t req{n, sched, subst, freqs, rates, weights, out};
+    std::unique_lock<std::mutex> lk(_mu);
+    _pending.push_back(&req);
+    for (;;) {
+      if (req.done) break;
+      if (!_launching && !_pending.empty() && _pending.size() >= (size_t)_active) {
+        // everyone who can ask has asked: this thread launches for all of them
+        std::vector<request_t *> batch;
+        batch.swap(_pending);
+        _launching = true;
+        lk.unlock();
+        std::string err = launch(batch);
+        lk.lock();
+        _launching = false;
+        for (request_t *r : batch) {
+          r->error = err;
+          r->done = true;
+        }
+        ++_launches;
+        _jobs += count(batch);
+        _cv.notify_all();
+        continue;
+      }
+      _cv.wait(lk);
+    }
+    if (!req.error.empty()) throw std::runtime_error(req.error);
+  }
+
+  size_t launches() const { return _launches; }
+  size_t jobs() const { return _jobs; }
+
+private:
+  struct request_t {
+    unsigned n;
+    const rdamd_schedule_t *sched;
+    const double *subst, *freqs, *rates, *weights;
+    double *out;
+    bool done = false;
+    std::string error;
+  };
+  static size_t count(const std::vector<request_t *> &b) {
+    size_t n = 0;
+    for (auto *r : b) n += r->n;
+    return n;
+  }
+  std::string launch(const std::vector<request_t *> &batch) {
+    const unsigned R = rdamd_partition_rate_cats(_part);
+    const size_t total = count(batch);
+    std::vector<const rdamd_schedule_t *> scheds;
+    std::vector<double> subst, freqs, rates, weights, out(total);
+    scheds.reserve(total);
+    for (auto *r : batch) {
+      scheds.insert(scheds.end(), r->n, r->sched);
+      subst.insert(subst.end(), r->subst, r->subst + (size_t)r->n * 12);
+      freqs.insert(freqs.end(), r->freqs, r->freqs + (size_t)r->n * 4);
+      rates.insert(rates.end(), r->rates, r->rates + (size_t)r->n * R);
+      weights.insert(weights.end(), r->weights, r->weights + (size_t)r->n * R);
+    }
+    {
+      std::lock_guard<std::mutex> g(_launch_mu);
+      if (rdamd_evaluate_batch(_part, (unsigned)total, scheds.data(), subst.data(), freqs.data(),
+                               rates.data(), weights.data(), out.data()) != RDAMD_SUCCESS)
+        return std::string("combined evaluate_batch failed: ") + rdamd_errmsg();
+    }
+    size_t at = 0;
+    for (auto *r : batch) {
+      std::copy(out.begin() + (std::ptrdiff_t)at, out.begin() + (std::ptrdiff_t)(at + r->n), r->out);
+      at += r->n;
+    }
+    return std::string();
+  }
+
+  rdamd_partition_t *_part;
+  std::mutex _mu, _launch_mu;
+  std::condition_variable _cv;
+  std::vector<request_t *> _pending;
+  int _active = 0;
+  bool _launching = false;
+  size_t _launches = 0, _jobs = 0;
+};
+
+}  // namespace rdamd

@@ -1,6 +1,7 @@
 // model_t on the rdamd C ABI; behaviour follows /root/reference/src/model.cpp
 // (cited per function).
 #include "model.hpp"
+#include "batch_combiner.hpp"
 #include "checkpoint.hpp"
 
 #include <algorithm>
@@ -620,8 +621,11 @@ double model_t::bfgs_params(model_params_t &initial, size_t pi, bfgs_target what
       std::copy(r.begin(), r.end(), rates.begin() + j * R);
       std::copy(_rate_weights[pi].begin(), _rate_weights[pi].end(), weights.begin() + j * R);
     }
-    if (rdamd_evaluate_batch(part, (unsigned)m, scheds.data(), subst.data(), freqs.data(),
-                             rates.data(), weights.data(), out.data()) != RDAMD_SUCCESS)
+    if (_combiner)   // meets the other candidates' requests in one launch
+      _combiner->evaluate((unsigned)m, sched, subst.data(), freqs.data(), rates.data(),
+                          weights.data(), out.data());
+    else if (rdamd_evaluate_batch(part, (unsigned)m, scheds.data(), subst.data(), freqs.data(),
+                                  rates.data(), weights.data(), out.data()) != RDAMD_SUCCESS)
       fail("evaluate_batch");
     _objective_batches += 1;
     _objective_evals += m;
@@ -686,6 +690,9 @@ void model_t::optimize_params(std::vector<partition_parameters_t> &params,
   if (!_setulb)
     throw std::runtime_error("optimize_params: no L-BFGS-B entry point set (set_lbfgsb)");
   auto sc = _tree.generate_operations(rl);
+  if (_combiner && _partitions.size() != 1)
+    throw std::runtime_error("optimize_params: the batch combiner handles one partition");
+  batch_combiner_t::scope_t in_lockstep(_combiner);
   for (size_t i = 0; i < _partitions.size(); ++i) {
     if (rdamd_partition_states(_partitions[i]) != 4)
       throw std::runtime_error("optimize_params: the batched objective handles 4-state data");
@@ -693,9 +700,17 @@ void model_t::optimize_params(std::vector<partition_parameters_t> &params,
     set_freqs_all_free(i, params[i].freqs);
     set_gamma_rates(i, params[i].gamma_alpha);
     if (_rate_category_types[i] == rate_category::FREE) set_gamma_weights(i, params[i].gamma_weights);
-    rdamd_schedule_t *sched = rdamd_schedule_create(
-        _partitions[i], std::get<0>(sc).data(), (unsigned)std::get<0>(sc).size(),
-        std::get<1>(sc).data(), std::get<2>(sc).data(), (unsigned)std::get<1>(sc).size());
+    auto destroy = [&](rdamd_schedule_t *s) {
+      if (_combiner) _combiner->schedule_destroy(s);
+      else rdamd_schedule_destroy(s);
+    };
+    rdamd_schedule_t *sched =
+        _combiner ? _combiner->schedule_create(std::get<0>(sc).data(), (unsigned)std::get<0>(sc).size(),
+                                               std::get<1>(sc).data(), std::get<2>(sc).data(),
+                                               (unsigned)std::get<1>(sc).size())
+                  : rdamd_schedule_create(_partitions[i], std::get<0>(sc).data(),
+                                          (unsigned)std::get<0>(sc).size(), std::get<1>(sc).data(),
+                                          std::get<2>(sc).data(), (unsigned)std::get<1>(sc).size());
     if (!sched) fail("schedule_create");
     try {
       bfgs_params(params[i].subst_rates, i, bfgs_target::rates, sched, 1e-4, 1e4, 1e-4, pgtol, factor);
@@ -703,10 +718,10 @@ void model_t::optimize_params(std::vector<partition_parameters_t> &params,
       if (optimize_gamma && !_rate_user_init[i] && _rate_category_types[i] != rate_category::FREE)
         bfgs_params(params[i].gamma_alpha, i, bfgs_target::gamma, sched, 0.2, 10000.0, 1e-4, pgtol, factor);
     } catch (...) {
-      rdamd_schedule_destroy(sched);
+      destroy(sched);
       throw;
     }
-    rdamd_schedule_destroy(sched);
+    destroy(sched);
   }
 }
 

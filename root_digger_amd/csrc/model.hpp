@@ -26,6 +26,7 @@
 namespace rdamd {
 
 class checkpoint_t;
+class batch_combiner_t;
 
 typedef std::vector<double> model_params_t;
 
@@ -132,6 +133,9 @@ public:
   // every finished candidate is appended to this result log (checkpoint.hpp), as
   // the reference's searches do (src/model.cpp:1107, :1215); not owned
   void set_checkpoint(checkpoint_t *c) { _checkpoint = c; }
+  // the optimiser's objective batches go through this combiner (batch_combiner.hpp)
+  // instead of being launched on this model's own partition; not owned
+  void set_combiner(batch_combiner_t *c) { _combiner = c; }
   // src/model.cpp:1925-1984
   void optimize_params(std::vector<partition_parameters_t> &params, const root_location_t &rl,
                        double pgtol, double factor, bool optimize_gamma);
@@ -203,6 +207,7 @@ private:
   std::vector<size_t>                    _assigned_idx;
   std::minstd_rand                       _random_engine;
   checkpoint_t                          *_checkpoint = nullptr;
+  batch_combiner_t                      *_combiner = nullptr;
   bool                                   _invariant_sites, _early_stop;   // +I is inert (:292-300)
   uint64_t                               _seed;
   param_optimizer_t                      _optimizer;

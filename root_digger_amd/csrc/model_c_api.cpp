@@ -2,12 +2,14 @@
 #include <atomic>
 #include <cmath>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <thread>
 
 #include <algorithm>
 
 #include "common.hpp"
+#include "batch_combiner.hpp"
 #include "checkpoint.hpp"
 #include "model.hpp"
 #include "tree_c_api.hpp"
@@ -218,12 +220,15 @@ void rdamd_model_set_lbfgsb(rdamd_model_t *m, void *fn) {
 // threads, each with its own model replica (own partition, own HIP stream),
 // pulling candidates from a shared counter -- their small launches (13-job
 // L-BFGS-B batches, root-only Brent steps) overlap on the device.
-int rdamd_model_exhaustive_search_parallel(rdamd_model_t *m, unsigned int workers, double atol,
-                                           double pgtol, double brtol, double factor,
-                                           uint64_t *root_id, double *llh, double *alpha,
-                                           unsigned int *n_results,
-                                           rdamd_root_location_t *best_rl, double *best_llh) {
+static int search_with_replicas(rdamd_model_t *m, unsigned int workers, bool lockstep, double atol,
+                                double pgtol, double brtol, double factor, uint64_t *root_id,
+                                double *llh, double *alpha, unsigned int *n_results,
+                                rdamd_root_location_t *best_rl, double *best_llh) {
   GUARD(RDAMD_FAILURE, {
+    // lock-step: the replicas' objective batches meet in one launch on THIS
+    // model's partition (batch_combiner.hpp); it does nothing else meanwhile
+    std::unique_ptr<rdamd::batch_combiner_t> combiner;
+    if (lockstep) combiner.reset(new rdamd::batch_combiner_t(m->model->partition(0)));
     const std::vector<size_t> todo = m->model->assigned_indicies();
     if (workers < 1) workers = 1;
     workers = (unsigned)std::min<size_t>(workers, std::max<size_t>(todo.size(), 1));
@@ -241,6 +246,7 @@ int rdamd_model_exhaustive_search_parallel(rdamd_model_t *m, unsigned int worker
         replica.initialize_partitions({m->msa});
         if (m->setulb) replica.set_lbfgsb(reinterpret_cast<rdamd::model_t::setulb_fn>(m->setulb));
         replica.set_checkpoint(m->checkpoint);
+        replica.set_combiner(combiner.get());
         replica.initialize();
         for (;;) {
           const size_t k = next.fetch_add(1);
@@ -279,6 +285,22 @@ int rdamd_model_exhaustive_search_parallel(rdamd_model_t *m, unsigned int worker
     if (best_llh) *best_llh = bl;
     return RDAMD_SUCCESS;
   })
+}
+int rdamd_model_exhaustive_search_parallel(rdamd_model_t *m, unsigned int workers, double atol,
+                                           double pgtol, double brtol, double factor,
+                                           uint64_t *root_id, double *llh, double *alpha,
+                                           unsigned int *n_results,
+                                           rdamd_root_location_t *best_rl, double *best_llh) {
+  return search_with_replicas(m, workers, false, atol, pgtol, brtol, factor, root_id, llh, alpha,
+                              n_results, best_rl, best_llh);
+}
+int rdamd_model_exhaustive_search_lockstep(rdamd_model_t *m, unsigned int in_flight, double atol,
+                                           double pgtol, double brtol, double factor,
+                                           uint64_t *root_id, double *llh, double *alpha,
+                                           unsigned int *n_results,
+                                           rdamd_root_location_t *best_rl, double *best_llh) {
+  return search_with_replicas(m, in_flight, true, atol, pgtol, brtol, factor, root_id, llh, alpha,
+                              n_results, best_rl, best_llh);
 }
 int rdamd_model_optimize_params(rdamd_model_t *m, const rdamd_root_location_t *rl, double pgtol,
                                 double factor, int optimize_gamma, double *subst, double *freqs,

@@ -160,6 +160,16 @@ def test_parallel_exhaustive_search_equals_sequential(lbfgsb):
     assert np.array_equal(par["llh"], seq["llh"][order])
     assert np.array_equal(par["alpha"], seq["alpha"][order])
     assert par["best_llh"] == seq["best_llh"]
+    # lock-stepped: the candidates' L-BFGS-B batches meet in one launch on the
+    # shared partition (batch_combiner.hpp).  A job's result does not depend on
+    # what else is in its launch, so the trajectories are the sequential ones.
+    before = m.counters()["objective_batches"]
+    for in_flight in (3, 17):
+        lock = m.exhaustive_search(1e-3, 1e-3, 1e-3, 1e12, lockstep=in_flight)
+        assert lock["root_id"] == sorted(seq["root_id"])
+        assert np.array_equal(lock["llh"], seq["llh"][order])
+        assert np.array_equal(lock["alpha"], seq["alpha"][order])
+    assert m.counters()["objective_batches"] == before    # the replicas did the asking
 
 
 def test_batched_root_sweep_equals_move_root_sweep():
