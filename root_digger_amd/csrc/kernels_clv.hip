@@ -78,7 +78,10 @@ clv_dna_traversal_kernel(DeviceView v, const LevelOp *__restrict__ ops, unsigned
   //   * a child produced by the previous operation stays in registers, an older
   //     sibling waits in an LDS parking slot (host: rdamd_update_clvs);
   //   * only a sibling that found no slot is read back (one operation ahead).
-  __shared__ double smat[2][kChunk][2][R * 16];
+  // (a rate's matrix starts kRateStride doubles after the previous one: with a
+  // stride of 16 the R lanes of a site would hit the same LDS banks on every read)
+  constexpr unsigned kRateStride = 18;
+  __shared__ double smat[2][kChunk][2][R * kRateStride];
   // LDS parking: `slots` CLVs (+ scaler counts) per lane, [slot][half][lane] so
   // every 16-byte access of a wave is conflict-free.
   extern __shared__ double2 park_lds[];
@@ -120,7 +123,7 @@ clv_dna_traversal_kernel(DeviceView v, const LevelOp *__restrict__ ops, unsigned
 #pragma unroll
       for (int k = 0; k < kMatRegs; ++k) {
         const unsigned e = lane + 64 * k;
-        if (e < R * 16) smat[buf][pair / 2][pair & 1u][e] = st[q][k];
+        if (e < R * 16) smat[buf][pair / 2][pair & 1u][(e / 16) * kRateStride + (e % 16)] = st[q][k];
       }
     }
   };
@@ -214,11 +217,11 @@ clv_dna_traversal_kernel(DeviceView v, const LevelOp *__restrict__ ops, unsigned
 
       double p1[4], p2[4];
       {
-        const double *m = &smat[buf][j][0][r * 16];
+        const double *m = &smat[buf][j][0][r * kRateStride];
 #pragma unroll
         for (int k = 0; k < 4; ++k)
           p1[k] = m[k * 4 + 0] * x[0] + m[k * 4 + 1] * x[1] + m[k * 4 + 2] * x[2] + m[k * 4 + 3] * x[3];
-        m = &smat[buf][j][1][r * 16];
+        m = &smat[buf][j][1][r * kRateStride];
 #pragma unroll
         for (int k = 0; k < 4; ++k)
           p2[k] = m[k * 4 + 0] * y[0] + m[k * 4 + 1] * y[1] + m[k * 4 + 2] * y[2] + m[k * 4 + 3] * y[3];
@@ -342,7 +345,7 @@ unsigned clv_traversal_slots(const rdamd_partition *p) {
   const size_t total = (size_t)p->sites * p->rate_cats;
   const size_t blocks = (total + 255) / 256;
   const size_t per_cu = (blocks + kComputeUnits - 1) / kComputeUnits;
-  const size_t lds_static = 8u * 1024, per_slot = 256 * (32 + 4);
+  const size_t lds_static = 10u * 1024, per_slot = 256 * (32 + 4);
   const size_t budget = (size_t)(160 * 1024) / std::max<size_t>(per_cu, 1);
   if (budget <= lds_static) return 0;
   return (unsigned)std::min<size_t>((budget - lds_static) / per_slot, kMaxParkSlots);
