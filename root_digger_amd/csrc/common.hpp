@@ -136,7 +136,14 @@ struct LevelOp {   // device-side op descriptor
   unsigned src1, src2;
   unsigned park;         // 1+s: also park the parent in LDS slot s; 0: do not
   unsigned noop;         // padding entry (4-state kernel: lists are padded to whole chunks)
+  // 4-state kernel only: byte offsets worked out on the host, so the kernel's
+  // scalar unit does no 64-bit index arithmetic.  *_off of a child: its row in
+  // the tip codes (tip) or its CLV (memory); kNoOffset where there is none.
+  uint64_t parent_off, parent_sc_off;
+  uint64_t child1_off, child1_sc_off;
+  uint64_t child2_off, child2_sc_off;
 };
+constexpr uint64_t kNoOffset = ~0ull;
 // LDS parking slots per lane the 4-state traversal kernel will have for this
 // partition (0 for the other kernels): an older sibling waits there instead of
 // being read back from HBM.

@@ -136,9 +136,9 @@ clv_dna_traversal_kernel(DeviceView v, const LevelOp *__restrict__ ops, unsigned
   const unsigned wave_first = uni((blockIdx.x * 256 + (tid & ~63u)) / R);   // first site of this wave
   const unsigned wave_site0 = wave_first < S ? wave_first : 0u;
   const unsigned lane_word = (lane / R) >> 2, lane_shift = ((lane / R) & 3u) * 8u;
-  auto load_codes = [&](unsigned tip, bool on, TipCodes<NW> &t) {
-    const unsigned long long a = reinterpret_cast<unsigned long long>(v.tipcodes) +
-                                 (size_t)(on ? tip : 0u) * v.tip_stride + wave_site0;
+  const unsigned long long tip_base = reinterpret_cast<unsigned long long>(v.tipcodes) + wave_site0;
+  auto load_codes = [&](uint64_t row_off, bool on, TipCodes<NW> &t) {
+    const unsigned long long a = tip_base + (on ? row_off : 0ull);
     const unsigned lo = uni((unsigned)a), hi = uni((unsigned)(a >> 32));
     const_u32_ptr p = (const_u32_ptr)(((unsigned long long)hi << 32) | lo);
 #pragma unroll
@@ -153,7 +153,9 @@ clv_dna_traversal_kernel(DeviceView v, const LevelOp *__restrict__ ops, unsigned
 
   unsigned *park_sc = reinterpret_cast<unsigned *>(park_lds + (size_t)slots * 512);
   // operand of THIS operation: registers / prefetched memory / tip code / LDS slot
-  auto operand = [&](unsigned src, unsigned clv, int scb, const TipCodes<NW> &t,
+  const char *clv_bytes_base = reinterpret_cast<const char *>(v.clv);
+  const char *sc_bytes_base = reinterpret_cast<const char *>(v.scaler);
+  auto operand = [&](unsigned src, uint64_t off, uint64_t sc_off, const TipCodes<NW> &t,
                      const double (&o)[4], unsigned osc, double (&x)[4], unsigned &xsc) {
     xsc = 0;
     if (src == kSrcReg) {
@@ -163,23 +165,41 @@ clv_dna_traversal_kernel(DeviceView v, const LevelOp *__restrict__ ops, unsigned
     } else if (src == kSrcMem) {
       // a sibling that found no parking slot (or was left by an earlier call):
       // read back here, after every earlier store of this lane in program order
-      const double2 *p = reinterpret_cast<const double2 *>(v.clv + (size_t)(clv - v.tips) * v.clv_stride);
+      const double2 *p = reinterpret_cast<const double2 *>(clv_bytes_base + off);
       const double2 a = p[(size_t)cidx * 2], b = p[(size_t)cidx * 2 + 1];
       x[0] = a.x; x[1] = a.y; x[2] = b.x; x[3] = b.y;
-      xsc = scb >= 0 ? v.scaler[(size_t)scb * S + s] : 0u;
+      xsc = sc_off != kNoOffset ? reinterpret_cast<const unsigned *>(sc_bytes_base + sc_off)[s] : 0u;
       // wait HERE (vmcnt(0)): left to the compiler the wait sinks to the join
       // below and every other route would pay for it
       __builtin_amdgcn_s_waitcnt(0x0F70);
     } else if (src == kSrcTip) {
+      // bit k of the code -> 1.0 / 0.0: the sign-extended bit masks the high
+      // word of 1.0 (two integer instructions per entry)
       const unsigned code = lane_code(t);
 #pragma unroll
-      for (int k = 0; k < 4; ++k) x[k] = ((code >> k) & 1u) ? 1.0 : 0.0;
+      for (int k = 0; k < 4; ++k) {
+        const int bit = (int)(code << (31 - k)) >> 31;
+        x[k] = __hiloint2double(bit & 0x3FF00000, 0);
+      }
     } else {
       const unsigned slot = src - kSrcPark;
       const double2 a = park_lds[(slot * 2) * 256 + tid], b = park_lds[(slot * 2 + 1) * 256 + tid];
       x[0] = a.x; x[1] = a.y; x[2] = b.x; x[3] = b.y;
       xsc = park_sc[slot * 256 + tid];
     }
+  };
+  // lanes of the wave whose SITE (R adjacent lanes) is small in every rate:
+  // folded on the scalar unit from the ballot, no cross-lane traffic
+  constexpr unsigned long long kGroupMask = R == 1 ? ~0ull : R == 2 ? 0x5555555555555555ull
+                                          : R == 4 ? 0x1111111111111111ull : 0x0101010101010101ull;
+  auto site_small = [&](bool lane_small) {
+    unsigned long long m = __builtin_amdgcn_ballot_w64(lane_small);
+#pragma unroll
+    for (int off = 1; off < R; off <<= 1) m &= m >> off;
+    m &= kGroupMask;
+#pragma unroll
+    for (int off = 1; off < R; off <<= 1) m |= m << off;
+    return ((m >> lane) & 1ull) != 0;
   };
 
   double o[4] = {0, 0, 0, 0};       // the CLV this lane produced last
@@ -189,11 +209,13 @@ clv_dna_traversal_kernel(DeviceView v, const LevelOp *__restrict__ ops, unsigned
     double st[kPairsPerWave][kMatRegs];
     stage_load(0, st);
     const LevelOp op0 = ops[0];
-    load_codes(op0.child1_clv, op0.src1 == kSrcTip, t1);
-    load_codes(op0.child2_clv, op0.src2 == kSrcTip, t2);
+    load_codes(op0.child1_off, op0.src1 == kSrcTip, t1);
+    load_codes(op0.child2_off, op0.src2 == kSrcTip, t2);
     stage_write(0, st);
     __syncthreads();
   }
+  const unsigned sc_bytes = S * 4u;
+  const LevelOp *opp = ops;   // the host ends the list with a terminator: opp[1] always exists
   for (unsigned base = 0; base < nops; base += kChunk) {
     const unsigned buf = (base / kChunk) & 1u;
     double st[kPairsPerWave][kMatRegs];
@@ -203,17 +225,16 @@ clv_dna_traversal_kernel(DeviceView v, const LevelOp *__restrict__ ops, unsigned
     // number of stores, so the wait for the staged matrices below is counted
     // past them instead of draining the store queue
 #pragma unroll
-    for (unsigned j = 0; j < kChunk; ++j) {
-      const unsigned i = base + j;
-      const LevelOp op = ops[i];
-      const LevelOp nx = ops[i + 1 < nops ? i + 1 : i];
+    for (unsigned j = 0; j < kChunk; ++j, ++opp) {
+      const LevelOp op = opp[0];
+      const LevelOp nx = opp[1];
       double x[4], y[4];
       unsigned xsc, ysc;
-      operand(op.src1, op.child1_clv, op.child1_sc, t1, o, osc, x, xsc);
-      operand(op.src2, op.child2_clv, op.child2_sc, t2, o, osc, y, ysc);
-      // what the NEXT operation needs (after the last one: a harmless repeat)
-      load_codes(nx.child1_clv, nx.src1 == kSrcTip, t1);
-      load_codes(nx.child2_clv, nx.src2 == kSrcTip, t2);
+      operand(op.src1, op.child1_off, op.child1_sc_off, t1, o, osc, x, xsc);
+      operand(op.src2, op.child2_off, op.child2_sc_off, t2, o, osc, y, ysc);
+      // what the NEXT operation needs
+      load_codes(nx.child1_off, nx.src1 == kSrcTip, t1);
+      load_codes(nx.child2_off, nx.src2 == kSrcTip, t2);
 
       double p1[4], p2[4];
       {
@@ -229,24 +250,23 @@ clv_dna_traversal_kernel(DeviceView v, const LevelOp *__restrict__ ops, unsigned
 #pragma unroll
       for (int k = 0; k < 4; ++k) o[k] = p1[k] * p2[k];
       osc = 0;
-      if (op.parent_sc >= 0) {
-        int small = (o[0] < kScaleThreshold) & (o[1] < kScaleThreshold) &
-                    (o[2] < kScaleThreshold) & (o[3] < kScaleThreshold);
-#pragma unroll
-        for (int off = 1; off < R; off <<= 1) small &= __shfl_xor(small, off);
+      const bool has_sc = op.parent_sc_off != kNoOffset && !op.noop;
+      if (op.parent_sc_off != kNoOffset) {
+        // entries are non-negative, so o < 2^-256 is a comparison of high words
+        const unsigned hmax = max(max((unsigned)__double2hiint(o[0]), (unsigned)__double2hiint(o[1])),
+                                  max((unsigned)__double2hiint(o[2]), (unsigned)__double2hiint(o[3])));
         osc = xsc + ysc;
-        if (small) {
+        if (site_small(hmax < 0x2FF00000u)) {
 #pragma unroll
           for (int k = 0; k < 4; ++k) o[k] *= kScaleFactor;
           osc += 1;
         }
       }
-      const bool has_sc = op.parent_sc >= 0 && !op.noop;
       __builtin_amdgcn_raw_buffer_store_b32(
-          osc, make_rsrc(v.scaler + (size_t)(has_sc ? op.parent_sc : 0) * S, has_sc ? S * 4u : 0u),
+          osc, make_rsrc(sc_bytes_base + (has_sc ? op.parent_sc_off : 0ull), has_sc ? sc_bytes : 0u),
           off_sc_st, 0, 0);
       const __amdgpu_buffer_rsrc_t prs =
-          make_rsrc(v.clv + (size_t)(op.parent_clv - v.tips) * v.clv_stride, op.noop ? 0u : clv_bytes);
+          make_rsrc(clv_bytes_base + op.parent_off, op.noop ? 0u : clv_bytes);
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, make_double2(o[0], o[1])), prs, off_clv_st, 0, 0);
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, make_double2(o[2], o[3])), prs, off_clv_st + 16, 0, 0);
       if (op.park) {

@@ -422,6 +422,17 @@ void rdamd_update_clvs(rdamd_partition_t *p, const rdamd_operation_t *ops,
     d.src1 = o.child1_clv_index < p->tips ? 0u : 1u;
     d.src2 = o.child2_clv_index < p->tips ? 0u : 1u;
     d.park = d.noop = 0;
+    const uint64_t clv_bytes = (uint64_t)p->sites * p->rate_cats * p->states * sizeof(double);
+    auto sc_off = [&](int scb) {
+      return scb >= 0 ? (uint64_t)scb * p->sites * sizeof(unsigned) : kNoOffset;
+    };
+    auto child_off = [&](unsigned clv) {
+      return clv < p->tips ? (uint64_t)clv * p->tip_stride() : (uint64_t)(clv - p->tips) * clv_bytes;
+    };
+    d.parent_off = (uint64_t)(d.parent_clv - p->tips) * clv_bytes;
+    d.parent_sc_off = sc_off(d.parent_sc);
+    d.child1_off = child_off(d.child1_clv); d.child1_sc_off = sc_off(d.child1_sc);
+    d.child2_off = child_off(d.child2_clv); d.child2_sc_off = sc_off(d.child2_sc);
   }
   // Where does each inner child come from?  The parent of the operation just
   // before stays in the lane's registers; an older sibling waits in one of the
@@ -500,14 +511,13 @@ void rdamd_update_clvs(rdamd_partition_t *p, const rdamd_operation_t *ops,
   // structure (kernels_clv.hip).
   if (!p->d_pmat_mfma) {   // pad to whole chunks with no-ops (a copy of the last op, stores off)
     const unsigned chunk = clv_traversal_chunk(p);
-    while (lops.size() % chunk) {
-      LevelOp pad = lops[count - 1];
-      pad.src1 = pad.src2 = 2u;
-      pad.park = 0;
-      pad.noop = 1;
-      lops.push_back(pad);
-    }
+    LevelOp pad = lops[count - 1];
+    pad.src1 = pad.src2 = 2u;
+    pad.park = 0;
+    pad.noop = 1;
+    while (lops.size() % chunk) lops.push_back(pad);
     cuts.back() = (unsigned)lops.size();
+    lops.push_back(pad);   // terminator: the kernel looks one operation ahead
   }
   const size_t padded = lops.size();
   hipError_t e = ensure_scratch(p, sizeof(LevelOp) * padded + 256);
