@@ -215,19 +215,20 @@ clv_dna_traversal_kernel(DeviceView v, const LevelOp *__restrict__ ops, unsigned
     __syncthreads();
   }
   const unsigned sc_bytes = S * 4u;
-  const LevelOp *opp = ops;   // the host ends the list with a terminator: opp[1] always exists
   for (unsigned base = 0; base < nops; base += kChunk) {
     const unsigned buf = (base / kChunk) & 1u;
     double st[kPairsPerWave][kMatRegs];
     stage_load(base + kChunk, st);                    // the NEXT chunk's matrices
+    // (the host ends the list with a terminator: chunk_ops[kChunk] always exists)
+    const LevelOp *chunk_ops = ops + base;
     // nops is a multiple of kChunk (the host pads with no-ops whose stores go
     // through 0-byte descriptors): the chunk is straight-line code with a fixed
     // number of stores, so the wait for the staged matrices below is counted
     // past them instead of draining the store queue
 #pragma unroll
-    for (unsigned j = 0; j < kChunk; ++j, ++opp) {
-      const LevelOp op = opp[0];
-      const LevelOp nx = opp[1];
+    for (unsigned j = 0; j < kChunk; ++j) {
+      const LevelOp op = chunk_ops[j];
+      const LevelOp nx = chunk_ops[j + 1];
       double x[4], y[4];
       unsigned xsc, ysc;
       operand(op.src1, op.child1_off, op.child1_sc_off, t1, o, osc, x, xsc);
