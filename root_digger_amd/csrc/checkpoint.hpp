@@ -14,9 +14,13 @@
 // second sum is never reduced, and a parameter vector's fold ends with one
 // extra step over the running first sum), restated in checkpoint.cpp.
 //
-// Parity status: UNPINNED.  The reference's checkpoint code cannot be built
-// here (it includes tree.hpp -> coraxlib) and its tests hold no golden file;
-// tests/test_checkpoint.py pins the layout against hand-assembled bytes.
+// Parity status: the raw-written structs (rd_result_t, ratehet_opts_t), enum
+// values and defaults are pinned against the reference's own util.hpp
+// (oracle/ref_layout.cpp -> tests/golden/ref_layout.json).  The byte stream as a
+// whole is UNPINNED: the reference's checkpoint code cannot be built here (it
+// includes tree.hpp -> coraxlib) and its tests hold no golden file;
+// tests/test_checkpoint.py checks it against an independent restatement
+// (oracle/ckp_oracle.py) and hand-assembled bytes.
 #pragma once
 
 #include <cstdint>

@@ -155,3 +155,45 @@ def test_header_is_required(tmp_path):
     c = rd.Checkpoint(str(tmp_path / "bad"))
     with pytest.raises(rd.RdamdError):
         c.read_results()
+
+
+def test_struct_layouts_match_the_reference_header():
+    """tests/golden/ref_layout.json is what the reference's own util.hpp says
+    about the types it writes raw into the file (printed by oracle/ref_layout.cpp,
+    compiled against /root/reference/src by `make -C oracle ref`).  The writer,
+    the C ABI mirror and the Python restatement must agree with it."""
+    import ctypes
+    import json
+    import subprocess
+    here = os.path.dirname(os.path.abspath(__file__))
+    gold = json.load(open(os.path.join(here, "golden", "ref_layout.json")))
+    exe = os.path.join(here, "..", "oracle", "_ref", "ref_layout")
+    if os.path.exists(exe):                       # the fixture is still what the header says
+        assert json.loads(subprocess.run([exe], capture_output=True, text=True, check=True).stdout) == gold
+    assert gold["sizeof_rd_result_t"] == struct.calcsize("<Qdd") == 24
+    assert gold["offsetof_rd_result_t"] == [0, 8, 16]
+    assert gold["sizeof_ratehet_opts_t"] == struct.calcsize("<iiQB7xd") == 32
+    assert gold["offsetof_ratehet_opts_t"] == [0, 4, 8, 16, 24]
+    assert gold["sizeof_enums"] == [4, 4, 4, 4]
+    assert gold["sizeof_scalars"] == {"seed": 8, "min_roots": 8, "threads": 8, "bool": 1, "field_flags_t": 4}
+    assert gold["enum_rate_category"] == {"MEDIAN": 0, "MEAN": 1, "FREE": 2}
+    assert gold["enum_param_type"]["estimate"] == 1 and gold["enum_initial_root_strategy"]["modified_mad"] == 2
+    # the ABI mirror has the reference's field order (its own padding is irrelevant: the
+    # writer assembles the 32-byte image field by field)
+    assert [f for f, _ in rd.api.RatehetOpts._fields_] == ["type", "rate_category_type", "rate_cats",
+                                                          "alpha_init", "alpha"]
+    # a header written with defaults reads back as the reference's defaults
+    d = gold["cli_defaults"]
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        c = rd.Checkpoint(os.path.join(tmp, "d"))
+        c.save_options({})
+        c.close()
+        back = rd.Checkpoint(os.path.join(tmp, "d")).load_options()
+    for k in ("min_roots", "threads", "root_ratio", "abs_tolerance", "factor", "br_tolerance",
+              "bfgs_tol", "initial_root_strategy"):
+        assert back[k] == d[k], k
+    assert len(back["rate_cats"]) == d["n_rate_cats"] and back["rate_cats"][0]["rate_cats"] == d["rate_cats0"]
+    r = gold["ratehet_from_size_t"]
+    assert (back["rate_cats"][0]["type"], back["rate_cats"][0]["rate_category_type"]) == (r["type"], r["rate_category_type"])
+    assert back["early_stop"] == 0 and d["early_stop_initialized"] == 0
