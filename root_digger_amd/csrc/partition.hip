@@ -473,12 +473,9 @@ void rdamd_update_clvs(rdamd_partition_t *p, const rdamd_operation_t *ops,
         if (slot_owner[sl] >= 0 && consumer[slot_owner[sl]] == (int)i) slot_owner[sl] = -1;
       const int c = consumer[i];
       if (c < 0) continue;
-      // a value overwritten before its consumer runs is not forwarded (cannot
-      // happen in a tree traversal; guards arbitrary lists)
-      bool clobbered = false;
-      for (int k = (int)i + 1; k < c; ++k)
-        if (ops[k].parent_clv_index == ops[i].parent_clv_index) clobbered = true;
-      if (clobbered) continue;
+      // (consumer[i] was taken from producer[] at the time the consumer was
+      // scanned, i.e. op i is the LAST writer of that CLV before it: nothing
+      // in between can have overwritten the value)
       if (c == (int)i + 1) {
         set_src((int)i, 2u);
         // the same CLV as both children: both come from the registers
