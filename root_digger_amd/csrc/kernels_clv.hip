@@ -9,19 +9,19 @@
 // is below 2^-256.
 //
 // HBM layout: CLV [site][rate][state] contiguous doubles, so consecutive lanes
-// read consecutive 32-byte (DNA) records.  Tips are never expanded to CLVs:
-// a tip child contributes tiptab[matrix][rate][code][i] (built next to the
-// P-matrices), read from LDS.
+// read consecutive 32-byte (DNA) records.  Tips are never expanded to CLVs in
+// memory: a tip child is its 1-byte code per site (4-state kernel: turned into
+// a 0/1 vector in registers; generic kernel: a row of the tip table built next
+// to the P-matrices).
 //
 // A whole operation list runs in ONE launch.  Every dependency of the
 // traversal is site-local -- parent[s][r] needs only child[s][r] -- and each
-// lane owns one (site, rate) pair for the whole list, so there is no
-// synchronisation at all between waves.  A child produced by the operation
-// just before (every inner child of a tip+inner node, the second child of an
-// inner+inner node) is taken from the lane's registers instead of being read
-// back; an older sibling is prefetched one operation ahead; every CLV is
-// still written (the reference's state contract).  What is left on the memory
-// pipe is an almost pure store stream.
+// lane owns one (site, rate) pair for the whole list.  A child produced by the
+// operation just before stays in the lane's registers, an older sibling waits
+// in an LDS parking slot (host-side liveness analysis in rdamd_update_clvs);
+// every CLV is still written (the reference's state contract).  What is left
+// on the vector-memory pipe is an almost pure store stream -- see the comment
+// in clv_dna_traversal_kernel for why that matters.
 #include "common.hpp"
 
 #include <algorithm>
