@@ -95,6 +95,10 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0,
                     help="budget for the cpu_baseline leg (rank 0, N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo + --device lets several ranks share one GPU (how the N>1 code "
+                         "path is exercised on a one-GPU box); the driver's runs use nccl (RCCL)")
+    ap.add_argument("--device", type=int, default=None, help="HIP device (default: LOCAL_RANK)")
     ap.add_argument("--shard", default="candidates", choices=["candidates", "sites"],
                     help="N>1: split candidate roots (no collective, weak scaling; default) or "
                          "split site blocks and all-reduce the per-block lnLs (strong scaling; "
@@ -114,11 +118,16 @@ def main():
 
     if not torch.cuda.is_available() or rd.device_count() < 1:
         raise SystemExit("bench.py needs a HIP device; there is no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    rd.set_device(local_rank)
+    device = local_rank if args.device is None else args.device
+    torch.cuda.set_device(device)
+    rd.set_device(device)           # (before the rendezvous: see root_digger_amd/cli.py)
+    host_collectives = args.dist_backend == "gloo"
     if world > 1:
         import torch.distributed as tdist
-        tdist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if host_collectives:
+            tdist.init_process_group("gloo")
+        else:
+            tdist.init_process_group("nccl", device_id=torch.device("cuda", device))
 
     cfg = CONFIGS[args.config]
     n, S, K, R = cfg["n"], cfg["S"], cfg["K"], cfg["R"]
@@ -142,6 +151,8 @@ def main():
     for label, seq in w["seqs"].items():
         part.set_tip_states(tree.tip_index(label), cmap, seq)
     freqs = part.empirical_frequencies()
+    if site_sharded and world > 1:   # the model is global: combine the blocks' counts
+        freqs = rdist.global_frequencies(freqs, S, device="cpu" if host_collectives else "cuda")
     part.set_frequencies(0, freqs)
     part.set_category_rates(w["rates"])
 
@@ -186,8 +197,12 @@ def main():
         if site_sharded:
             part.evaluate_batch_device([scheds[i] for i in idx], sub, freqs_b[idx],
                                        lnl_dev.data_ptr())
-            if world > 1:
+            if world > 1 and not host_collectives:
                 rdist.allreduce_lnl(lnl_dev)     # RCCL sum of the per-block lnLs
+            elif world > 1:                      # gloo test path: through the host
+                host = lnl_dev.cpu()
+                rdist.allreduce_lnl(host)
+                lnl_dev.copy_(host)
             return lnl_dev
         return float(part.evaluate_batch([scheds[i] for i in idx], sub, freqs_b[idx]).sum())
 
@@ -218,7 +233,8 @@ def main():
         raise SystemExit("non-finite lnL in the timed region")
 
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64,
+                         device="cpu" if host_collectives else "cuda")
         tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -297,6 +313,9 @@ def main():
                    "sharding": "site blocks + RCCL all-reduce" if site_sharded else "candidate roots",
                    "path": "fused batch" if use_fused else "per-operation"},
         "site_clv_updates_per_sec": round(value * (n - 1) * S_total, 1),
+        # sum of the lnLs rank 0 saw in the timed region: identical across world
+        # sizes when site-sharded (each job's lnL is the all-reduced total)
+        "lnl_check": check,
         "roofline": roofline,
     }
     result.update(extra)

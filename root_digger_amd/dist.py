@@ -53,3 +53,19 @@ def allreduce_lnl(values, group=None):
     import torch.distributed as dist
     dist.all_reduce(values, op=dist.ReduceOp.SUM, group=group)
     return values
+
+
+def global_frequencies(local_freqs, local_weight, group=None, device=None):
+    """Empirical base frequencies of the WHOLE alignment from each rank's
+    site-block figures (site-sharded runs: the model must be the same on every
+    rank).  rdamd_msa_empirical_frequencies normalises by (pattern-weight total
+    x tips), so the global vector is the weight-total-weighted mean of the
+    per-block vectors: one all-reduce of K+1 doubles."""
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor([f * local_weight for f in local_freqs] + [float(local_weight)],
+                     dtype=torch.float64, device=device or "cpu")
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    t = t.cpu()
+    return [float(v) / float(t[-1]) for v in t[:-1]]

@@ -68,13 +68,21 @@ def _worker(rank, world, port, out):
         subst = [.34, .42, .24, .74, .16, .88, .75, .54, .20, .06, .08, .41]
         rates = rd.compute_gamma_cats(1.0, 4)
 
-        def lnl_of(sub, roots):
+        def lnl_of(sub, roots, freqs=None):
             n = len(next(iter(sub.values())))
             p = OraclePartition.for_tree(tree, 4, n, 4)
             util.load_tips(p, tree, sub, ORC_MAP_NT)
             p.set_subst_params(0, subst)
             p.set_category_rates(rates)
+            if freqs is not None:
+                p.set_frequencies(0, freqs)
             return [util.compute_lh(p, tree, tree.root_location(i)) for i in roots]
+
+        def empirical(sub):
+            n = len(next(iter(sub.values())))
+            p = OraclePartition.for_tree(tree, 4, n, 4)
+            util.load_tips(p, tree, sub, ORC_MAP_NT)
+            return p.empirical_frequencies()
 
         # --- site-block sharding: every rank evaluates ALL jobs on its slice,
         # one all-reduce of the per-job partial lnLs (BASELINE config c4 pattern)
@@ -83,6 +91,12 @@ def _worker(rank, world, port, out):
         part = torch.tensor(lnl_of({k: v[lo:hi] for k, v in seqs.items()}, jobs),
                             dtype=torch.float64)
         rdist.allreduce_lnl(part)
+        # the model of a site-sharded run is global: empirical frequencies of the
+        # whole alignment from the blocks' own figures, then the same check again
+        block = {k: v[lo:hi] for k, v in seqs.items()}
+        gfreq = rdist.global_frequencies(empirical(block), hi - lo)
+        part_f = torch.tensor(lnl_of(block, jobs, gfreq), dtype=torch.float64)
+        rdist.allreduce_lnl(part_f)
         # --- candidate sharding: disjoint roots per rank, gathered at the end
         mine = rdist.assign_candidates(tree.root_count(), rank, world)
         vals = torch.full((tree.root_count(),), 0.0, dtype=torch.float64)
@@ -92,7 +106,9 @@ def _worker(rank, world, port, out):
         if rank == 0:
             whole = lnl_of(seqs, jobs)
             every = lnl_of(seqs, range(tree.root_count()))
-            out.put(("ok", part.tolist(), whole, vals.tolist(), every))
+            wfreq = empirical(seqs)
+            out.put(("ok", part.tolist(), whole, vals.tolist(), every,
+                     gfreq, wfreq, part_f.tolist(), lnl_of(seqs, jobs, wfreq)))
     except Exception as e:   # pragma: no cover
         if rank == 0:
             out.put(("err", repr(e)))
@@ -113,8 +129,11 @@ def test_world_size_2_gloo_site_and_candidate_sharding():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert res[0] == "ok", res
-    _, sharded, whole, gathered, every = res
+    _, sharded, whole, gathered, every, gfreq, wfreq, sharded_f, whole_f = res
     for a, b in zip(sharded, whole):
         assert util.rel_err(a, b) < 1e-13
     for a, b in zip(gathered, every):
         assert a == b
+    assert max(abs(a - b) for a, b in zip(gfreq, wfreq)) < 1e-15
+    for a, b in zip(sharded_f, whole_f):
+        assert util.rel_err(a, b) < 1e-12
