@@ -255,6 +255,11 @@ int rdamd_tree_root_location(const rdamd_tree_t *t, unsigned int index,
                              rdamd_root_location_t *out);        /* :74-82 */
 int rdamd_tree_root_location_by_label(const rdamd_tree_t *t, const char *label,
                                       rdamd_root_location_t *out); /* :84-91 */
+/* rank_midpoints (:863-901) / rank_modified_mad (:907-945): the root ids ordered
+ * best first by how well each branch balances the tree; root_ids holds
+ * root_count entries.  midpoint() is the first of rank_midpoints. */
+int rdamd_tree_rank_midpoints(const rdamd_tree_t *t, unsigned int *root_ids);
+int rdamd_tree_rank_modified_mad(const rdamd_tree_t *t, unsigned int *root_ids);
 /* label of a root location ("(null)" when unlabeled), src/tree.hpp:36-38 */
 const char *rdamd_tree_root_label(const rdamd_tree_t *t, unsigned int index);
 int rdamd_tree_root_is_internal(const rdamd_tree_t *t, unsigned int index);
@@ -465,6 +470,15 @@ int rdamd_model_set_checkpoint(rdamd_model_t *m, rdamd_checkpoint_t *c);
  * the roots already in the log are skipped */
 int rdamd_model_assign_by_rank_checkpoint(rdamd_model_t *m, unsigned int rank,
                                           unsigned int num_tasks, rdamd_checkpoint_t *c);
+/* assign_indicies_by_rank_search, :1809-1865: the heuristic search's starting
+ * roots = the first max(root_count*root_ratio, min_roots) of an ordering
+ * (0 random shuffle with the model's seed, 1 midpoint rank, 2 modified MAD
+ * rank), minus the roots already in `c` (may be NULL), chunked over the ranks */
+int rdamd_model_assign_by_rank_search(rdamd_model_t *m, unsigned int min_roots, double root_ratio,
+                                      unsigned int rank, unsigned int num_tasks,
+                                      int initial_root_strategy, rdamd_checkpoint_t *c);
+/* the root ids currently assigned to this model; returns how many there are */
+int rdamd_model_assigned(const rdamd_model_t *m, uint64_t *root_ids, unsigned int cap);
 
 /* character maps (replace corax_map_nt / corax_map_bin, src/main.cpp:484) */
 extern const uint64_t rdamd_map_nt[256];

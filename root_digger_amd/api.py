@@ -104,6 +104,8 @@ for _n in ("tip_count", "inner_count", "branch_count", "root_count", "root_clv_i
     _sig("rdamd_tree_" + _n, _u, _vp)
 _sig("rdamd_tree_root_scaler_index", C.c_int, _vp)
 _sig("rdamd_tree_root_location", C.c_int, _vp, _u, _prl)
+_sig("rdamd_tree_rank_midpoints", C.c_int, _vp, _pu)
+_sig("rdamd_tree_rank_modified_mad", C.c_int, _vp, _pu)
 _sig("rdamd_tree_root_location_by_label", C.c_int, _vp, C.c_char_p, _prl)
 _sig("rdamd_tree_root_label", C.c_char_p, _vp, _u)
 _sig("rdamd_tree_root_is_internal", C.c_int, _vp, _u)
@@ -179,6 +181,8 @@ _sig("rdamd_checkpoint_needs_cleaning", C.c_int, _vp)
 _sig("rdamd_checkpoint_clean", C.c_int, _vp)
 _sig("rdamd_checkpoint_checksum_result", C.c_uint32, C.c_uint64, C.c_double, C.c_double)
 _sig("rdamd_checkpoint_checksum_params", C.c_uint32, _u, _pu64, _pd)
+_sig("rdamd_model_assign_by_rank_search", C.c_int, _vp, _u, C.c_double, _u, _u, C.c_int, _vp)
+_sig("rdamd_model_assigned", C.c_int, _vp, _pu64, _u)
 _sig("rdamd_model_set_checkpoint", C.c_int, _vp, _vp)
 _sig("rdamd_model_assign_by_rank_checkpoint", C.c_int, _vp, _u, _u, _vp)
 _sig("rdamd_model_counters", None, C.c_void_p, C.POINTER(C.c_uint64))
@@ -294,6 +298,23 @@ class Tree:
         if ok != 1:
             _fail("root_location")
         return rl
+
+    def _ranked(self, fn):
+        ids = np.zeros(self.root_count(), dtype=np.uint32)
+        if fn(self._h, _uptr(ids)) != 1:
+            _fail("rank")
+        return [int(i) for i in ids]
+
+    def rank_midpoints(self):
+        """root ids, best midpoint balance first (src/tree.cpp:863-901)."""
+        return self._ranked(lib.rdamd_tree_rank_midpoints)
+
+    def rank_modified_mad(self):
+        """root ids ranked by the modified MAD score (src/tree.cpp:907-945)."""
+        return self._ranked(lib.rdamd_tree_rank_modified_mad)
+
+    def midpoint(self):
+        return self.root_location(self.rank_midpoints()[0])
 
     def roots(self):
         return [self.root_location(i) for i in range(self.root_count())]
@@ -892,6 +913,20 @@ class Model:
                                                                checkpoint.handle), "assign_by_rank")
         else:
             self._ok(lib.rdamd_model_assign_by_rank(self._h, rank, num_tasks), "assign_by_rank")
+
+    def assign_by_rank_search(self, min_roots, root_ratio, rank, num_tasks,
+                              initial_root_strategy="modified_mad", checkpoint=None):
+        """assign_indicies_by_rank_search (src/model.cpp:1809-1865)."""
+        strategy = {"random": 0, "midpoint": 1, "modified_mad": 2}[initial_root_strategy]
+        self._ok(lib.rdamd_model_assign_by_rank_search(
+            self._h, min_roots, root_ratio, rank, num_tasks, strategy,
+            checkpoint.handle if checkpoint else None), "assign_by_rank_search")
+
+    def assigned(self):
+        n = self._tree.root_count()
+        ids = (C.c_uint64 * n)()
+        k = lib.rdamd_model_assigned(self._h, ids, n)
+        return [int(ids[i]) for i in range(min(k, n))]
 
     def set_checkpoint(self, checkpoint):
         """searches append every finished candidate to this Checkpoint (None detaches)."""

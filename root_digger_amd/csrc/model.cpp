@@ -562,6 +562,57 @@ void model_t::assign_indicies() {
   std::iota(_assigned_idx.begin(), _assigned_idx.end(), 0);
 }
 
+std::vector<size_t> model_t::shuffle_root_indicies() {
+  std::vector<size_t> idx(_tree.root_count());
+  std::iota(idx.begin(), idx.end(), 0);
+  std::shuffle(idx.begin(), idx.end(), _random_engine);
+  return idx;
+}
+
+std::vector<size_t> model_t::suggest_root_indicies_midpoint() const {
+  std::vector<size_t> ids;
+  for (const auto &rl : _tree.rank_midpoints()) ids.push_back(rl.id);
+  return ids;
+}
+
+std::vector<size_t> model_t::suggest_root_indicies_modified_mad() const {
+  std::vector<size_t> ids;
+  for (const auto &rl : _tree.rank_modified_mad()) ids.push_back(rl.id);
+  return ids;
+}
+
+// src/model.cpp:1809-1865: the first max(root_count * root_ratio, min_roots)
+// roots of the chosen ordering are the search's starting points; the ones a
+// resumed run already holds are dropped, the rest is chunked over the ranks.
+void model_t::assign_indicies_by_rank_search(size_t min_roots, double root_ratio, size_t rank,
+                                             size_t num_tasks, initial_root_strategy init_root,
+                                             const std::vector<size_t> &completed) {
+  std::vector<size_t> order;
+  switch (init_root) {
+    case initial_root_strategy::random: order = shuffle_root_indicies(); break;
+    case initial_root_strategy::midpoint: order = suggest_root_indicies_midpoint(); break;
+    case initial_root_strategy::modified_mad: order = suggest_root_indicies_modified_mad(); break;
+  }
+  const size_t root_count = std::min(
+      std::max(static_cast<size_t>(_tree.root_count() * root_ratio), min_roots), _tree.root_count());
+  if (root_count < completed.size())
+    throw std::runtime_error("There are too many results in the checkpoint for this search. Is "
+                             "the checkpoint corrupted?");
+  std::vector<size_t> done(completed);
+  std::sort(done.begin(), done.end());
+  const size_t work_left = root_count - done.size();
+  std::vector<size_t> left;
+  for (size_t i : order)
+    if (!std::binary_search(done.begin(), done.end(), i)) left.push_back(i);
+  // (as in the reference, the chunk bounds come from work_left while the list
+  // still holds every unfinished root of the ordering)
+  const size_t chunk = work_left / num_tasks, mod = work_left % num_tasks;
+  const size_t beg = chunk * rank + std::min(mod, rank);
+  const size_t end = std::min(chunk * (rank + 1) + std::min(mod, rank + 1), left.size());
+  _assigned_idx.assign(left.begin() + (std::ptrdiff_t)std::min(beg, end),
+                       left.begin() + (std::ptrdiff_t)end);
+}
+
 void model_t::assign_indicies_by_rank_exhaustive(size_t rank, size_t num_tasks,
                                                  const std::vector<size_t> &completed) {
   if (_tree.root_count() < completed.size())

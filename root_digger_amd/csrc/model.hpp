@@ -182,6 +182,14 @@ public:
   // ---- work assignment (src/model.cpp:1761-1911) ------------------------------
   void assign_indicies();
   void assign_indicies(const std::vector<size_t> &idx) { _assigned_idx = idx; }
+  // starting roots of the heuristic search, src/model.cpp:941-962, :1809-1865
+  enum class initial_root_strategy { random, midpoint, modified_mad };
+  std::vector<size_t> shuffle_root_indicies();
+  std::vector<size_t> suggest_root_indicies_midpoint() const;
+  std::vector<size_t> suggest_root_indicies_modified_mad() const;
+  void assign_indicies_by_rank_search(size_t min_roots, double root_ratio, size_t rank,
+                                      size_t num_tasks, initial_root_strategy init_root,
+                                      const std::vector<size_t> &completed = {});
   void assign_indicies_by_rank_exhaustive(size_t rank, size_t num_tasks,
                                           const std::vector<size_t> &completed = {});
   std::vector<size_t> assigned_indicies() const { return _assigned_idx; }

@@ -341,6 +341,25 @@ int rdamd_model_assign_by_rank_checkpoint(rdamd_model_t *m, unsigned int rank,
     return RDAMD_SUCCESS;
   })
 }
+int rdamd_model_assign_by_rank_search(rdamd_model_t *m, unsigned int min_roots, double root_ratio,
+                                      unsigned int rank, unsigned int num_tasks,
+                                      int initial_root_strategy, rdamd_checkpoint_t *c) {
+  GUARD(RDAMD_FAILURE, {
+    if (initial_root_strategy < 0 || initial_root_strategy > 2)
+      throw std::runtime_error("The initial root strategy was not recognized");
+    std::vector<size_t> done;
+    if (c) done = rdamd_checkpoint_cpp(c)->completed_indicies();
+    m->model->assign_indicies_by_rank_search(
+        min_roots, root_ratio, rank, num_tasks,
+        (rdamd::model_t::initial_root_strategy)initial_root_strategy, done);
+    return RDAMD_SUCCESS;
+  })
+}
+int rdamd_model_assigned(const rdamd_model_t *m, uint64_t *root_ids, unsigned int cap) {
+  const auto &idx = m->model->assigned_indicies();
+  for (size_t i = 0; i < idx.size() && i < cap; ++i) root_ids[i] = idx[i];
+  return (int)idx.size();
+}
 int rdamd_model_assign_by_rank(rdamd_model_t *m, unsigned int rank, unsigned int num_tasks) {
   GUARD(RDAMD_FAILURE, {
     m->model->assign_indicies_by_rank_exhaustive(rank, num_tasks);

@@ -3,6 +3,8 @@
 // utree conventions it builds on.
 #include "tree.hpp"
 
+#include <cmath>
+
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -551,6 +553,91 @@ std::vector<std::string> rooted_tree_t::side_tips(const root_location_t &rl) con
   rec(rl.edge);
   std::sort(out.begin(), out.end());
   return out;
+}
+
+
+// ---- balance-based rankings (src/tree.cpp:795-945) ----------------------------------
+namespace {
+// distances from the far end of half-edge h to every tip behind it, depth first
+// in ring order; `depth` is the distance already walked before crossing h
+void collect_tip_distances(const std::vector<int> &next, const std::vector<int> &back,
+                           const std::vector<double> &length, int h, double depth,
+                           std::vector<double> &out) {
+  depth += length[h];
+  if (next[h] < 0) {
+    out.push_back(depth);
+    return;
+  }
+  for (int k = next[h]; k != h; k = next[k]) collect_tip_distances(next, back, length, back[k], depth, out);
+}
+}  // namespace
+
+template <typename Map, typename Reduce>
+std::vector<root_location_t> rooted_tree_t::rank_branches(Map &&pair_score, Reduce &&fold) const {
+  if (rooted()) {   // the rankings are a property of the unrooted tree
+    rooted_tree_t bare(*this);
+    bare.unroot();
+    return bare.rank_branches(pair_score, fold);
+  }
+  std::vector<std::pair<double, size_t>> scored;
+  std::vector<double> near, far, vals;
+  for (size_t i = 0; i < _roots.size(); ++i) {
+    const int e = _roots[i].edge;
+    near.clear();
+    far.clear();
+    if (_next[e] < 0) near.push_back(0.0);   // the branch hangs off a tip
+    else
+      for (int k = _next[e]; k != e; k = _next[k])
+        collect_tip_distances(_next, _back, _length, _back[k], 0.0, near);
+    collect_tip_distances(_next, _back, _length, _back[e], -_length[e], far);
+    vals.clear();
+    for (double a : near)
+      for (double b : far) vals.push_back(pair_score(a, b, _roots[i].saved_brlen));
+    scored.emplace_back(fold(vals), i);
+  }
+  std::sort(scored.begin(), scored.end(),
+            [](const std::pair<double, size_t> &a, const std::pair<double, size_t> &b) {
+              return a.first > b.first;
+            });
+  std::vector<root_location_t> out;
+  out.reserve(scored.size());
+  for (const auto &sc : scored) out.push_back(_roots[sc.second]);
+  return out;
+}
+
+std::vector<root_location_t> rooted_tree_t::rank_midpoints() const {
+  auto pair_score = [](double longer, double shorter, double brlen) {
+    if (longer < shorter) std::swap(longer, shorter);
+    const double gap = longer - shorter;
+    if (gap < brlen) {   // the branch can absorb the gap: what is left is shared
+      shorter += gap;
+      const double half = (brlen - gap) / 2.0;
+      shorter += half;
+      longer += half;
+    } else {
+      shorter += brlen;
+    }
+    const double span = shorter + longer;
+    return (1 - (gap * gap) / span) * span;
+  };
+  auto fold = [](const std::vector<double> &v) { return *std::max_element(v.begin(), v.end()); };
+  return rank_branches(pair_score, fold);
+}
+
+std::vector<root_location_t> rooted_tree_t::rank_modified_mad() const {
+  auto pair_score = [](double a, double b, double brlen) {
+    const double span = a + b + brlen;
+    const double rho = std::min(std::max((span - 2 * a) / (2 * brlen), 0.0), 1.0);
+    a = a + rho * brlen;
+    return a / span - 1;
+  };
+  auto fold = [](const std::vector<double> &v) {
+    double acc = 0.0;
+    for (double x : v) acc += x * x;
+    acc /= static_cast<double>(v.size());
+    return std::sqrt(acc);
+  };
+  return rank_branches(pair_score, fold);
 }
 
 }  // namespace rdamd

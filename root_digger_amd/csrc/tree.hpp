@@ -94,6 +94,15 @@ public:
   }
   void clear_newick_annotations() { _annotations.clear(); }
 
+  // Root placements ranked by how well they balance the tree, best first
+  // (src/tree.cpp:863-945): the starting points of the heuristic search.
+  // midpoint: score of a branch = max over (tip left, tip right) pairs of
+  // d·(1 − Δ²/d) with the root slid along the branch to balance the pair;
+  // modified MAD: root-mean-square relative deviation of the pairs' balance.
+  std::vector<root_location_t> rank_midpoints() const;
+  std::vector<root_location_t> rank_modified_mad() const;
+  root_location_t midpoint() const { return rank_midpoints().front(); }   // src/tree.cpp:903-905
+
   // tips below each side of a root edge (test/diagnostic helper, not in the
   // reference): labels reachable from rl.edge without crossing the branch.
   std::vector<std::string> side_tips(const root_location_t &rl) const;
@@ -102,6 +111,9 @@ private:
   std::vector<int> full_traverse() const;               // src/tree.cpp:256-269
   template <typename F> void traverse(int root, F &&visit, std::vector<int> &out) const;
   void tag_ring(int h, bool v);
+  // tip distances on both sides of every root branch, folded per branch
+  template <typename Map, typename Reduce>
+  std::vector<root_location_t> rank_branches(Map &&pair_score, Reduce &&fold) const;
   bool find_path_recurse(int n1, int n2);
   void find_path(int n1, int n2);
 

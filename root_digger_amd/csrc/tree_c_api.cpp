@@ -79,6 +79,21 @@ int rdamd_tree_root_location(const rdamd_tree_t *t, unsigned int index,
                              rdamd_root_location_t *out) {
   GUARD({ to_c(t->tree.root_location((size_t)index), out); return RDAMD_SUCCESS; })
 }
+// rank_midpoints / rank_modified_mad: root ids, best first (root_count of them)
+int rdamd_tree_rank_midpoints(const rdamd_tree_t *t, unsigned int *root_ids) {
+  GUARD({
+    const auto r = t->tree.rank_midpoints();
+    for (size_t i = 0; i < r.size(); ++i) root_ids[i] = (unsigned)r[i].id;
+    return RDAMD_SUCCESS;
+  })
+}
+int rdamd_tree_rank_modified_mad(const rdamd_tree_t *t, unsigned int *root_ids) {
+  GUARD({
+    const auto r = t->tree.rank_modified_mad();
+    for (size_t i = 0; i < r.size(); ++i) root_ids[i] = (unsigned)r[i].id;
+    return RDAMD_SUCCESS;
+  })
+}
 int rdamd_tree_root_location_by_label(const rdamd_tree_t *t, const char *label,
                                       rdamd_root_location_t *out) {
   GUARD({ to_c(t->tree.root_location(std::string(label)), out); return RDAMD_SUCCESS; })

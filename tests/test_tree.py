@@ -213,3 +213,82 @@ def test_msa_ingest_shapes():                  # test/src/msa.cpp:8-15 + SURVEY 
     assert (taxa, total) == (101, 1858) and patterns <= 1858
     with pytest.raises(rd.RdamdError):
         rd.msa_probe(os.path.join(util.DATA, "10.tree"))
+
+
+def test_midpoint_rooting_golden():
+    """test/src/tree.cpp:435-443 of the reference: 10.tree rooted at its midpoint."""
+    t = rd.Tree.from_file(os.path.join(util.DATA, "10.tree"))
+    t.root_by(t.midpoint())
+    assert t.newick(False) == (
+        "((j:0.854700,((h:0.983500,a:0.224900):0.416200,(c:0.540900,f:0.422200):"
+        "0.785300):0.614100):0.223050,(g:0.487400,(((i:0.569700,e:0.366600):0."
+        "602800,b:0.445900):0.099300,d:0.639600):0.825200):0.223050);")
+    # the ranking is a property of the unrooted tree: asking again while rooted
+    # gives the same order
+    assert t.rank_midpoints() == rd.Tree.from_file(os.path.join(util.DATA, "10.tree")).rank_midpoints()
+
+
+def test_balance_rankings_are_permutations_and_find_the_long_branch():
+    t = rd.Tree.from_newick("((a:1.0,b:1.0):0.5,c:1.0,d:9.0);")
+    n_roots = t.root_count()
+    for ranked in (t.rank_midpoints(), t.rank_modified_mad()):
+        assert sorted(ranked) == list(range(n_roots))
+    # the path a..d is 11.5 long, so its midpoint lies on d's 9.0 branch
+    assert t.side_tips(t.midpoint()) in (["d"], ["a", "b", "c"])
+    # brute force of the midpoint score on every branch (src/tree.cpp:864-885)
+    import itertools
+    best = None
+    for rid in range(n_roots):
+        rl = t.root_location(rid)
+        near, far = t.side_tips(rl), None
+        far = sorted(set("abcd") - set(near))
+        dist = _tip_distances("((a:1.0,b:1.0):0.5,c:1.0,d:9.0);")
+        score = -1.0
+        for x, y in itertools.product(near, far):
+            # distances from the two ends of the branch = path length minus the branch
+            path = dist[(x, y)]
+            # split the path at the branch: tip x to its end, tip y to the other end
+            lx = _to_branch_end(dist, x, near, far, rl.saved_brlen)
+            ly = path - rl.saved_brlen - lx
+            a, b = max(lx, ly), min(lx, ly)
+            gap = a - b
+            if gap < rl.saved_brlen:
+                b += gap + (rl.saved_brlen - gap) / 2
+                a += (rl.saved_brlen - gap) / 2
+            else:
+                b += rl.saved_brlen
+            span = a + b
+            score = max(score, (1 - gap * gap / span) * span)
+        if best is None or score > best[0] + 1e-12:
+            best = (score, rid)
+    assert t.rank_midpoints()[0] == best[1]
+
+
+def _tip_distances(newick):
+    """all tip-to-tip path lengths of the small test tree, by hand."""
+    length = {"a": 1.0, "b": 1.0, "c": 1.0, "d": 9.0}
+    inner = 0.5      # the (a,b) clade's stem
+    d = {}
+    for x in "abcd":
+        for y in "abcd":
+            if x == y:
+                d[(x, y)] = 0.0
+            elif {x, y} == {"a", "b"}:
+                d[(x, y)] = 2.0
+            elif x in "ab" or y in "ab":
+                d[(x, y)] = length[x] + length[y] + inner
+            else:
+                d[(x, y)] = length[x] + length[y]
+    return d
+
+
+def _to_branch_end(dist, x, near, far, brlen):
+    """distance from tip x to the near end of the root branch: for any far tip y
+    and any other near tip x2, tree additivity gives it; for a lone tip it is 0."""
+    if len(near) == 1:
+        return 0.0
+    y = far[0]
+    x2 = [t for t in near if t != x][0]
+    # d(x, end) = (d(x, y) + d(x, x2) - d(x2, y)) / 2 is the distance to the point
+    # where the paths part; with two near tips that point is the near end itself
+    return (dist[(x, y)] + dist[(x, x2)] - dist[(x2, y)]) / 2
