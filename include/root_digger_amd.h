@@ -480,6 +480,40 @@ int rdamd_model_assign_by_rank_search(rdamd_model_t *m, unsigned int min_roots, 
 /* the root ids currently assigned to this model; returns how many there are */
 int rdamd_model_assigned(const rdamd_model_t *m, uint64_t *root_ids, unsigned int cap);
 
+/* ------------------------------------------------------------------------
+ * Partition file / model string front end (src/msa.cpp:91-522): which columns
+ * form each partition and what its model string asks for.
+ * ---------------------------------------------------------------------- */
+typedef struct {   /* partition_info_t + model_info_t, src/util.hpp:86-100 */
+  char     model_name[256], partition_name[128], subst_str[64];
+  unsigned int n_ranges;
+  uint64_t ranges[64][2];          /* 1-based, inclusive */
+  int32_t  freq_type;              /* param_type: 0 emperical 1 estimate 2 equal 3 user */
+  int32_t  invar_present, invar_type;
+  float    invar_user_prop;
+  rdamd_ratehet_opts_t ratehet;    /* rate_cats == 0: the string has no +G / +R */
+  int32_t  asc_present, asc_type;  /* 0 lewis 1 fels 2 stam */
+  double   asc_fels_weight;
+  unsigned int n_stam_weights;
+  double   stam_weights[32];
+} rdamd_partition_info_t;
+/* parse_model_info, :364-415 / parse_partition_info, :417-506 */
+int rdamd_parse_model_info(const char *model_string, rdamd_partition_info_t *out);
+int rdamd_parse_partition_info(const char *line, rdamd_partition_info_t *out);
+/* msa_t::partition, :522-591: length (patterns when compress != 0) and total
+ * weight of each partition described by `lines` */
+int rdamd_msa_partition_probe(const char *msa_filename, const uint64_t *map,
+                              unsigned int n_lines, const char *const *lines, int compress,
+                              unsigned int *lengths, unsigned int *total_weights);
+/* the partitioned model of src/main.cpp:512-555: one partition per line of the
+ * partition file, rate categories from each line's model string */
+rdamd_model_t *rdamd_model_create_partitioned(const rdamd_tree_t *tree, const char *msa_filename,
+                                              const char *partition_filename,
+                                              unsigned int states, const uint64_t *map,
+                                              uint64_t seed, int early_stop,
+                                              unsigned int *n_partitions);
+int rdamd_model_partition_count(const rdamd_model_t *m);
+
 /* character maps (replace corax_map_nt / corax_map_bin, src/main.cpp:484) */
 extern const uint64_t rdamd_map_nt[256];
 extern const uint64_t rdamd_map_bin[256];

@@ -16,6 +16,9 @@ from .api import (  # noqa: F401
     Schedule,
     Model,
     Checkpoint,
+    parse_model_info,
+    parse_partition_info,
+    msa_partition_probe,
     checkpoint_checksum_result,
     checkpoint_checksum_params,
     MAP_NT,
@@ -29,7 +32,8 @@ from .api import (  # noqa: F401
 )
 
 __all__ = [
-    "lib", "lib_path", "RdamdError", "Operation", "RootLocation", "Tree", "Partition", "Schedule", "Model", "Checkpoint",
+    "lib", "lib_path", "RdamdError", "Operation", "RootLocation", "Tree", "Partition", "Schedule", "Model", "Checkpoint", "parse_model_info", "parse_partition_info",
+    "msa_partition_probe",
     "checkpoint_checksum_result", "checkpoint_checksum_params",
     "MAP_NT", "MAP_BIN", "compute_gamma_cats", "GAMMA_RATES_MEAN", "GAMMA_RATES_MEDIAN",
     "device_count", "set_device", "msa_probe",

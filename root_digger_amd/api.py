@@ -166,7 +166,26 @@ class CliOptions(C.Structure):
         ("initial_root_strategy", C.c_int32)])
 
 
+class PartitionInfo(C.Structure):
+    """rdamd_partition_info_t: partition_info_t + model_info_t (src/util.hpp:86-100)."""
+    _fields_ = [("model_name", C.c_char * 256), ("partition_name", C.c_char * 128),
+                ("subst_str", C.c_char * 64), ("n_ranges", C.c_uint),
+                ("ranges", (C.c_uint64 * 2) * 64), ("freq_type", C.c_int32),
+                ("invar_present", C.c_int32), ("invar_type", C.c_int32),
+                ("invar_user_prop", C.c_float), ("ratehet", RatehetOpts),
+                ("asc_present", C.c_int32), ("asc_type", C.c_int32),
+                ("asc_fels_weight", C.c_double), ("n_stam_weights", C.c_uint),
+                ("stam_weights", C.c_double * 32)]
+
+
 _pu64 = C.POINTER(C.c_uint64)
+_sig("rdamd_parse_model_info", C.c_int, C.c_char_p, C.POINTER(PartitionInfo))
+_sig("rdamd_parse_partition_info", C.c_int, C.c_char_p, C.POINTER(PartitionInfo))
+_sig("rdamd_msa_partition_probe", C.c_int, C.c_char_p, C.c_void_p, _u, C.POINTER(C.c_char_p),
+     C.c_int, _pu, _pu)
+_sig("rdamd_model_create_partitioned", _vp, _vp, C.c_char_p, C.c_char_p, _u, C.c_void_p,
+     C.c_uint64, C.c_int, _pu)
+_sig("rdamd_model_partition_count", C.c_int, _vp)
 _sig("rdamd_checkpoint_open", _vp, C.c_char_p)
 _sig("rdamd_checkpoint_close", None, _vp)
 _sig("rdamd_checkpoint_existing", C.c_int, _vp)
@@ -626,6 +645,56 @@ def _flatten_params(params):
     return counts, np.ascontiguousarray(values if values.size else np.zeros(1))
 
 
+PARAM_TYPES = ("emperical", "estimate", "equal", "user")          # src/util.hpp:37
+RATE_CATEGORIES = ("MEDIAN", "MEAN", "FREE")                       # :48
+ASC_TYPES = ("lewis", "fels", "stam")                              # :72
+
+
+def _info_dict(pi, with_ranges):
+    d = {"model_name": pi.model_name.decode(), "subst_str": pi.subst_str.decode(),
+         "freq_type": PARAM_TYPES[pi.freq_type],
+         "invar": ({"type": PARAM_TYPES[pi.invar_type], "user_prop": pi.invar_user_prop}
+                   if pi.invar_present else None),
+         "ratehet": {"type": PARAM_TYPES[pi.ratehet.type],
+                     "rate_category_type": RATE_CATEGORIES[pi.ratehet.rate_category_type],
+                     "rate_cats": int(pi.ratehet.rate_cats), "alpha_init": bool(pi.ratehet.alpha_init),
+                     "alpha": pi.ratehet.alpha},
+         "asc": ({"type": ASC_TYPES[pi.asc_type], "fels_weight": pi.asc_fels_weight,
+                  "stam_weights": [pi.stam_weights[i] for i in range(pi.n_stam_weights)]}
+                 if pi.asc_present else None)}
+    if with_ranges:
+        d["partition_name"] = pi.partition_name.decode()
+        d["parts"] = [(int(pi.ranges[i][0]), int(pi.ranges[i][1])) for i in range(pi.n_ranges)]
+    return d
+
+
+def parse_model_info(model_string):
+    """parse_model_info (src/msa.cpp:364-415) as a dict."""
+    pi = PartitionInfo()
+    if lib.rdamd_parse_model_info(model_string.encode(), C.byref(pi)) != 1:
+        _fail("parse_model_info")
+    return _info_dict(pi, False)
+
+
+def parse_partition_info(line):
+    """parse_partition_info (src/msa.cpp:417-506) as a dict."""
+    pi = PartitionInfo()
+    if lib.rdamd_parse_partition_info(line.encode(), C.byref(pi)) != 1:
+        _fail("parse_partition_info")
+    return _info_dict(pi, True)
+
+
+def msa_partition_probe(path, lines, cmap=None, compress=True):
+    """msa_t::partition on a file: [(length, total_weight)] per partition line."""
+    arr = (C.c_char_p * len(lines))(*[l.encode() for l in lines])
+    n = np.zeros(len(lines), dtype=np.uint32)
+    w = np.zeros(len(lines), dtype=np.uint32)
+    if lib.rdamd_msa_partition_probe(os.fsencode(path), cmap, len(lines), arr, int(compress),
+                                     _uptr(n), _uptr(w)) != 1:
+        _fail("msa_partition_probe")
+    return [(int(a), int(b)) for a, b in zip(n, w)]
+
+
 class Checkpoint:
     """checkpoint_t of the reference (src/checkpoint.hpp:231-300): the
     `<prefix>.ckp` result log, byte-compatible, shared between processes under
@@ -787,6 +856,26 @@ class Model:
             _fail("model_create_from_file")
         self.patterns = n.value
         return self
+
+    @classmethod
+    def from_partition_file(cls, tree, msa_path, partition_path, states=4, cmap=None, seed=1,
+                            early_stop=False):
+        """The reference's partitioned set-up (src/main.cpp:512-555): one model
+        partition per line of the partition file (column ranges + model string;
+        rate categories come from each line's +G / +R option)."""
+        self = cls.__new__(cls)
+        self._tree, self.states = tree, states
+        n = C.c_uint(0)
+        self._h = lib.rdamd_model_create_partitioned(
+            tree._h, os.fsencode(msa_path), os.fsencode(partition_path), states,
+            cmap if cmap is not None else MAP_NT, seed, 1 if early_stop else 0, C.byref(n))
+        if not self._h:
+            _fail("model_create_partitioned")
+        self.partitions = n.value
+        return self
+
+    def partition_count(self):
+        return int(lib.rdamd_model_partition_count(self._h))
 
     def destroy(self):
         if getattr(self, "_h", None):

@@ -31,7 +31,7 @@ import os
 import sys
 import time
 
-from . import Checkpoint, Model, Tree, set_device
+from . import Checkpoint, Model, Tree, parse_model_info, set_device
 
 STRATEGIES = ["random", "midpoint", "modified-mad"]   # initial_root_strategy_t, src/util.hpp:74-78
 
@@ -42,6 +42,12 @@ def main(argv=None):
     ap.add_argument("--tree", required=True)
     ap.add_argument("--prefix", default=None)
     ap.add_argument("--rate-cats", type=int, default=1)
+    ap.add_argument("--partition", default=None,
+                    help="partition file: <MODEL>, <NAME> = <BEGIN>-<END>[, ...] per line; rate "
+                         "categories then come from each line's model string")
+    ap.add_argument("--model", default=None,
+                    help="model string, e.g. UNREST+G4 (only its rate heterogeneity is used, "
+                         "src/main.cpp:491-510)")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--atol", type=float, default=1e-7)       # abs_tolerance
     ap.add_argument("--bfgstol", type=float, default=1e-7)
@@ -102,6 +108,7 @@ def main(argv=None):
             if stored is None:
                 ckp.save_options({
                     "msa_filename": args.msa, "tree_filename": args.tree, "prefix": prefix,
+                    "partition_filename": args.partition or "", "model_string": args.model or "",
                     "data_type": "nt", "rate_cats": [args.rate_cats], "seed": args.seed,
                     "threads": args.workers, "abs_tolerance": args.atol, "factor": args.factor,
                     "br_tolerance": args.brtol, "bfgs_tol": args.bfgstol,
@@ -123,6 +130,8 @@ def main(argv=None):
                       "If the program is not working, try deleting the checkpoint file",
                       file=sys.stderr)
             args.msa, args.tree = stored["msa_filename"], stored["tree_filename"]
+            args.partition = stored["partition_filename"] or None
+            args.model = stored["model_string"] or None
             args.rate_cats = int(stored["rate_cats"][0]["rate_cats"])
             args.seed, args.atol, args.factor = stored["seed"], stored["abs_tolerance"], stored["factor"]
             args.brtol, args.bfgstol = stored["br_tolerance"], stored["bfgs_tol"]
@@ -138,8 +147,18 @@ def main(argv=None):
         raise SystemExit("Min roots is larger than the number of roots on the tree")
     # early_stop.convert_with_default(!exhaustive), src/main.cpp:583
     early_stop = args.early_stop or not args.exhaustive
-    model = Model.from_file(tree, args.msa, rate_cats=args.rate_cats, seed=args.seed,
-                            early_stop=early_stop)
+    if args.model:
+        # (a string without +G / +R means one category here; the reference rejects it
+        # with "Rate categories cannot be zero", src/main.cpp:557-560)
+        args.rate_cats = parse_model_info(args.model)["ratehet"]["rate_cats"] or 1
+    if args.partition:
+        model = Model.from_partition_file(tree, args.msa, args.partition, seed=args.seed,
+                                          early_stop=early_stop)
+        if args.lockstep:
+            ap.error("--lockstep handles a single partition")
+    else:
+        model = Model.from_file(tree, args.msa, rate_cats=args.rate_cats, seed=args.seed,
+                                early_stop=early_stop)
     model.initialize_partitions()
     keep = None
     if args.lbfgsb:

@@ -1,6 +1,7 @@
 // C wrappers over model_t (declared in include/root_digger_amd.h).
 #include <atomic>
 #include <cmath>
+#include <cstdio>
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -12,13 +13,25 @@
 #include "batch_combiner.hpp"
 #include "checkpoint.hpp"
 #include "model.hpp"
+#include "partition_info.hpp"
 #include "tree_c_api.hpp"
 
 struct rdamd_model {
   rdamd::model_t *model = nullptr;
-  rdamd::msa_t    msa;
+  rdamd::msa_t    msa;                        // partition 0 (the only one unless partitioned)
+  std::vector<rdamd::msa_t> more_msas;        // partitions 1.. of a partitioned model
+  std::vector<rdamd::ratehet_opts_t> ratehets;   // per partition
   // what a replica needs (parallel exhaustive search)
   unsigned rate_cats = 1;
+  std::vector<rdamd::msa_t> all_msas() const {
+    std::vector<rdamd::msa_t> v{msa};
+    v.insert(v.end(), more_msas.begin(), more_msas.end());
+    return v;
+  }
+  std::vector<rdamd::ratehet_opts_t> all_ratehets() const {
+    return ratehets.empty() ? std::vector<rdamd::ratehet_opts_t>{rdamd::ratehet_opts_t(rate_cats)}
+                            : ratehets;
+  }
   uint64_t seed = 0;
   bool     early_stop = false;
   void    *setulb = nullptr;
@@ -103,6 +116,105 @@ rdamd_model_t *rdamd_model_create_from_file(const rdamd_tree_t *tree, const char
     return m;
   })
 }
+// The reference's partitioned set-up (src/main.cpp:512-555): the alignment is read
+// whole, cut into the partition file's column ranges, each partition compressed
+// on its own; rate categories come from each partition's model string.
+rdamd_model_t *rdamd_model_create_partitioned(const rdamd_tree_t *tree, const char *msa_filename,
+                                              const char *partition_filename,
+                                              unsigned int states, const uint64_t *map,
+                                              uint64_t seed, int early_stop,
+                                              unsigned int *n_partitions) {
+  GUARD(nullptr, {
+    auto *m = new rdamd_model();
+    m->seed = seed; m->early_stop = early_stop != 0;
+    try {
+      const rdamd::msa_t whole = rdamd::msa_t::from_file(msa_filename, map, states, false);
+      const auto infos = rdamd::parse_partition_file(partition_filename);
+      if (infos.empty()) throw std::runtime_error("The partition file holds no partitions");
+      auto msas = rdamd::partition_msa(whole, infos, true);
+      for (const auto &pi : infos) {
+        rdamd::ratehet_opts_t rc = pi.model.ratehet_opts;
+        if (rc.rate_cats == 0) rc.rate_cats = 1;
+        m->ratehets.push_back(rc);
+      }
+      for (const auto &x : msas)
+        if (!x.constiency_check(rdamd_tree_cpp(tree).label_set()))
+          throw std::invalid_argument("Taxa on the tree and in the MSA are inconsistient");
+      m->rate_cats = (unsigned)m->ratehets[0].rate_cats;
+      m->msa = msas[0];
+      m->more_msas.assign(msas.begin() + 1, msas.end());
+      m->model = new rdamd::model_t(rdamd_tree_cpp(tree), msas, m->ratehets, false, seed,
+                                    early_stop != 0);
+    } catch (...) {
+      delete m;
+      throw;
+    }
+    if (n_partitions) *n_partitions = (unsigned)(1 + m->more_msas.size());
+    return m;
+  })
+}
+
+namespace {
+void fill_model(const rdamd::model_info_t &mi, rdamd_partition_info_t *out) {
+  std::snprintf(out->subst_str, sizeof out->subst_str, "%s", mi.subst_str.c_str());
+  out->freq_type = (int)mi.freq_opts.type;
+  out->invar_present = mi.invar_opts.present;
+  out->invar_type = (int)mi.invar_opts.type;
+  out->invar_user_prop = mi.invar_opts.user_prop;
+  out->ratehet = {(int32_t)mi.ratehet_opts.type, (int32_t)mi.ratehet_opts.rate_category_type,
+                  mi.ratehet_opts.rate_cats, mi.ratehet_opts.alpha_init ? 1 : 0,
+                  mi.ratehet_opts.alpha};
+  out->asc_present = mi.asc_opts.present;
+  out->asc_type = (int)mi.asc_opts.type;
+  out->asc_fels_weight = mi.asc_opts.fels_weight;
+  out->n_stam_weights = (unsigned)std::min<size_t>(mi.asc_opts.stam_weights.size(), 32);
+  for (unsigned i = 0; i < out->n_stam_weights; ++i) out->stam_weights[i] = mi.asc_opts.stam_weights[i];
+}
+}  // namespace
+
+int rdamd_parse_model_info(const char *model_string, rdamd_partition_info_t *out) {
+  GUARD(RDAMD_FAILURE, {
+    std::memset(out, 0, sizeof *out);
+    fill_model(rdamd::parse_model_info(model_string), out);
+    std::snprintf(out->model_name, sizeof out->model_name, "%s", model_string);
+    return RDAMD_SUCCESS;
+  })
+}
+int rdamd_parse_partition_info(const char *line, rdamd_partition_info_t *out) {
+  GUARD(RDAMD_FAILURE, {
+    std::memset(out, 0, sizeof *out);
+    const auto pi = rdamd::parse_partition_info(line);
+    fill_model(pi.model, out);
+    std::snprintf(out->model_name, sizeof out->model_name, "%s", pi.model_name.c_str());
+    std::snprintf(out->partition_name, sizeof out->partition_name, "%s", pi.partition_name.c_str());
+    if (pi.parts.size() > 64) throw std::runtime_error("more than 64 ranges in one partition line");
+    out->n_ranges = (unsigned)pi.parts.size();
+    for (size_t i = 0; i < pi.parts.size(); ++i) {
+      out->ranges[i][0] = pi.parts[i].first;
+      out->ranges[i][1] = pi.parts[i].second;
+    }
+    return RDAMD_SUCCESS;
+  })
+}
+// msa_t::partition on a file: lengths (patterns if compress, columns otherwise) and
+// total weights of the partitions the given lines describe
+int rdamd_msa_partition_probe(const char *msa_filename, const uint64_t *map,
+                              unsigned int n_lines, const char *const *lines, int compress,
+                              unsigned int *lengths, unsigned int *total_weights) {
+  GUARD(RDAMD_FAILURE, {
+    const rdamd::msa_t whole = rdamd::msa_t::from_file(msa_filename, map, 4, false);
+    rdamd::msa_partitions_t infos;
+    for (unsigned i = 0; i < n_lines; ++i) infos.push_back(rdamd::parse_partition_info(lines[i]));
+    const auto msas = rdamd::partition_msa(whole, infos, compress != 0);
+    for (size_t i = 0; i < msas.size(); ++i) {
+      if (lengths) lengths[i] = (unsigned)msas[i].length();
+      if (total_weights) total_weights[i] = msas[i].total_weight();
+    }
+    return RDAMD_SUCCESS;
+  })
+}
+int rdamd_model_partition_count(const rdamd_model_t *m) { return (int)(1 + m->more_msas.size()); }
+
 int rdamd_msa_probe(const char *msa_filename, const uint64_t *map, int compress,
                     unsigned int *n_taxa, unsigned int *n_patterns,
                     unsigned int *total_weight) {
@@ -118,8 +230,8 @@ void rdamd_model_destroy(rdamd_model_t *m) { delete m; }
 
 int rdamd_model_initialize_partitions(rdamd_model_t *m, int uniform_freqs) {
   GUARD(RDAMD_FAILURE, {
-    if (uniform_freqs) m->model->initialize_partitions_uniform_freqs({m->msa});
-    else m->model->initialize_partitions({m->msa});
+    if (uniform_freqs) m->model->initialize_partitions_uniform_freqs(m->all_msas());
+    else m->model->initialize_partitions(m->all_msas());
     return RDAMD_SUCCESS;
   })
 }
@@ -241,9 +353,10 @@ static int search_with_replicas(rdamd_model_t *m, unsigned int workers, bool loc
     auto work = [&](unsigned wid) {
       try {
         if (hipSetDevice(device) != hipSuccess) throw std::runtime_error("hipSetDevice failed");
-        rdamd::model_t replica(m->model->tree(), {m->msa}, {rdamd::ratehet_opts_t(m->rate_cats)},
-                               false, m->seed + wid, m->early_stop);
-        replica.initialize_partitions({m->msa});
+        const auto msas = m->all_msas();
+        rdamd::model_t replica(m->model->tree(), msas, m->all_ratehets(), false, m->seed + wid,
+                               m->early_stop);
+        replica.initialize_partitions(msas);
         if (m->setulb) replica.set_lbfgsb(reinterpret_cast<rdamd::model_t::setulb_fn>(m->setulb));
         replica.set_checkpoint(m->checkpoint);
         replica.set_combiner(combiner.get());
