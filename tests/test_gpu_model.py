@@ -334,3 +334,36 @@ def test_partitioned_model_matches_the_sum_of_its_parts(tmp_path):
     recs = ck.read_results()
     assert len(recs) == 199 and all(len(p) == 2 for _, _, _, p in recs)
     assert ck.load_options()["partition_filename"] == str(pf)
+
+
+@pytest.mark.parametrize("dummy", [0, 1, 2, 4, 8])
+def test_assign_indicies_with_a_checkpoint(tmp_path, dummy):
+    """The reference's "assign indicies test" (test/src/model.cpp:448-549): roots
+    already in the checkpoint are never assigned again -- search mode with each
+    starting-root strategy and exhaustive mode."""
+    tree = rd.Tree.from_file(os.path.join(util.DATA, "10.tree"))
+    m = rd.Model.from_file(tree, os.path.join(util.DATA, "10.fasta"), rate_cats=1, seed=12345)
+    m.initialize_partitions_uniform_freqs()
+    ckp = rd.Checkpoint(str(tmp_path / "dummy"))
+    ckp.save_options({})
+    done = [int(i) for i in np.random.default_rng(dummy).permutation(17)[:dummy]]
+    for rid in done:
+        ckp.write(rid, 0.0, 0.0, [])
+    for strategy in ("random", "midpoint", "modified_mad"):
+        for want in (1, 2, 3, 4, 5):
+            if want - dummy >= 0:
+                m.assign_by_rank_search(want, 0.0, 0, 1, strategy, ckp)
+                got = m.assigned()
+                assert len(got) == want - dummy and not set(got) & set(done)
+        if 1 - dummy < 0:
+            with pytest.raises(rd.RdamdError):
+                m.assign_by_rank_search(1, 0.0, 0, 1, strategy, ckp)
+    m.assign_by_rank(0, 1, ckp)
+    got = m.assigned()
+    assert len(got) == 17 - dummy and not set(got) & set(done)
+    # several ranks: the unfinished roots are split without overlap or loss
+    pieces = []
+    for rank in range(3):
+        m.assign_by_rank(rank, 3, ckp)
+        pieces.append(m.assigned())
+    assert sorted(sum(pieces, [])) == sorted(set(range(17)) - set(done))
