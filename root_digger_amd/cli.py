@@ -31,7 +31,7 @@ import os
 import sys
 import time
 
-from . import Checkpoint, Model, Tree, parse_model_info, set_device
+from . import MAP_BIN, MAP_NT, Checkpoint, Model, Tree, parse_model_info, set_device
 
 STRATEGIES = ["random", "midpoint", "modified-mad"]   # initial_root_strategy_t, src/util.hpp:74-78
 
@@ -41,6 +41,9 @@ def main(argv=None):
     ap.add_argument("--msa", required=True)
     ap.add_argument("--tree", required=True)
     ap.add_argument("--prefix", default=None)
+    ap.add_argument("--states", type=int, default=4, choices=[2, 4],
+                    help="4: nucleotides; 2: binary characters (src/main.cpp:484-488; parameter "
+                         "optimisation is available for 4 states)")
     ap.add_argument("--rate-cats", type=int, default=1)
     ap.add_argument("--partition", default=None,
                     help="partition file: <MODEL>, <NAME> = <BEGIN>-<END>[, ...] per line; rate "
@@ -54,6 +57,11 @@ def main(argv=None):
     ap.add_argument("--brtol", type=float, default=1e-12)
     ap.add_argument("--factor", type=float, default=1e4)
     ap.add_argument("--early-stop", action="store_true")
+    ap.add_argument("--no-early-stop", action="store_true", help="force disable early stop")
+    ap.add_argument("--invariant-sites", action="store_true",
+                    help="accepted for compatibility; the proportion is pinned to 0 as in the "
+                         "reference (src/model.cpp:292-300)")
+    ap.add_argument("--verbose", action="count", default=0, help="accepted for compatibility")
     ap.add_argument("--exhaustive", action="store_true",
                     help="evaluate every branch as a root (default: heuristic search)")
     ap.add_argument("--min-roots", type=int, default=1)
@@ -62,7 +70,7 @@ def main(argv=None):
                     choices=["random", "midpoint", "modified-mad"])
     ap.add_argument("--lbfgsb", default=None,
                     help="shared library exporting the L-BFGS-B entry point `setulb`")
-    ap.add_argument("--workers", type=int, default=4,
+    ap.add_argument("--workers", "--threads", dest="workers", type=int, default=4,
                     help="host threads, each with its own model replica / HIP stream "
                          "(0 = the plain sequential loop)")
     ap.add_argument("--lockstep", type=int, default=0,
@@ -109,13 +117,14 @@ def main(argv=None):
                 ckp.save_options({
                     "msa_filename": args.msa, "tree_filename": args.tree, "prefix": prefix,
                     "partition_filename": args.partition or "", "model_string": args.model or "",
-                    "data_type": "nt", "rate_cats": [args.rate_cats], "seed": args.seed,
+                    "data_type": "bin" if args.states == 2 else "nt", "rate_cats": [args.rate_cats], "seed": args.seed,
                     "threads": args.workers, "abs_tolerance": args.atol, "factor": args.factor,
                     "br_tolerance": args.brtol, "bfgs_tol": args.bfgstol,
                     "silent": args.silent, "exhaustive": args.exhaustive,
                     "min_roots": args.min_roots, "root_ratio": args.root_ratio,
                     "initial_root_strategy": STRATEGIES.index(args.initial_root_strategy),
-                    "early_stop": 1 if args.early_stop else 0})
+                    "invariant_sites": args.invariant_sites,
+                    "early_stop": 2 if args.no_early_stop else 1 if args.early_stop else 0})
             if ckp.needs_cleaning():
                 ckp.clean()
         elif args.clean:
@@ -141,24 +150,26 @@ def main(argv=None):
             # initialized_flag_t: unset means "stop early unless exhaustive" (src/main.cpp:583)
             args.early_stop = (stored["early_stop"] == 1 or
                                (stored["early_stop"] == 0 and not args.exhaustive))
+            args.no_early_stop = stored["early_stop"] == 2
 
     tree = Tree.from_file(args.tree)
     if args.min_roots > tree.root_count():
         raise SystemExit("Min roots is larger than the number of roots on the tree")
     # early_stop.convert_with_default(!exhaustive), src/main.cpp:583
-    early_stop = args.early_stop or not args.exhaustive
+    early_stop = (args.early_stop or not args.exhaustive) and not args.no_early_stop
+    cmap = MAP_BIN if args.states == 2 else MAP_NT
     if args.model:
         # (a string without +G / +R means one category here; the reference rejects it
         # with "Rate categories cannot be zero", src/main.cpp:557-560)
         args.rate_cats = parse_model_info(args.model)["ratehet"]["rate_cats"] or 1
     if args.partition:
-        model = Model.from_partition_file(tree, args.msa, args.partition, seed=args.seed,
-                                          early_stop=early_stop)
+        model = Model.from_partition_file(tree, args.msa, args.partition, states=args.states,
+                                          cmap=cmap, seed=args.seed, early_stop=early_stop)
         if args.lockstep:
             ap.error("--lockstep handles a single partition")
     else:
-        model = Model.from_file(tree, args.msa, rate_cats=args.rate_cats, seed=args.seed,
-                                early_stop=early_stop)
+        model = Model.from_file(tree, args.msa, states=args.states, cmap=cmap,
+                                rate_cats=args.rate_cats, seed=args.seed, early_stop=early_stop)
     model.initialize_partitions()
     keep = None
     if args.lbfgsb:

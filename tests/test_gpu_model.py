@@ -367,3 +367,23 @@ def test_assign_indicies_with_a_checkpoint(tmp_path, dummy):
         m.assign_by_rank(rank, 3, ckp)
         pieces.append(m.assigned())
     assert sorted(sum(pieces, [])) == sorted(set(range(17)) - set(done))
+
+
+def test_cli_binary_characters(tmp_path):
+    """--states 2 (src/main.cpp:484-488): binary alignments go through the
+    generic K-state kernels; exhaustive root placement at fixed parameters."""
+    from root_digger_amd import cli
+    rng = np.random.default_rng(5)
+    tree_nwk = open(os.path.join(util.DATA, "10.tree")).read()
+    names = sorted(rd.Tree.from_newick(tree_nwk).label_map())
+    fa = tmp_path / "bin.fasta"
+    fa.write_text("".join(">%s\n%s\n" % (n, "".join(rng.choice(list("01-"), 200, p=[.45, .45, .1])))
+                          for n in names))
+    tr = tmp_path / "t.nwk"
+    tr.write_text(tree_nwk)
+    prefix = str(tmp_path / "b")
+    assert cli.main(["--msa", str(fa), "--tree", str(tr), "--prefix", prefix, "--states", "2",
+                     "--exhaustive", "--atol", "1e-3", "--brtol", "1e-3", "--silent"]) == 0
+    recs = rd.Checkpoint(prefix).read_results()
+    assert len(recs) == 17 and all(np.isfinite(l) and l < 0 for _, l, _, _ in recs)
+    assert all(len(p[0]["subst_rates"]) == 2 and len(p[0]["freqs"]) == 2 for _, _, _, p in recs)
