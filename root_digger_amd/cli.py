@@ -73,9 +73,10 @@ def main(argv=None):
     ap.add_argument("--workers", "--threads", dest="workers", type=int, default=4,
                     help="host threads, each with its own model replica / HIP stream "
                          "(0 = the plain sequential loop)")
-    ap.add_argument("--lockstep", type=int, default=0,
+    ap.add_argument("--lockstep", type=int, default=-1,
                     help="candidates advanced in lock step, their optimiser batches merged "
-                         "into one launch (overrides --workers)")
+                         "into one launch (overrides --workers; 0 = off; default: 16 when "
+                         "parameters are optimised on a single partition)")
     ap.add_argument("--device", type=int, default=None,
                     help="HIP device (default: LOCAL_RANK, else 0)")
     ap.add_argument("--silent", action="store_true")
@@ -165,7 +166,7 @@ def main(argv=None):
     if args.partition:
         model = Model.from_partition_file(tree, args.msa, args.partition, states=args.states,
                                           cmap=cmap, seed=args.seed, early_stop=early_stop)
-        if args.lockstep:
+        if args.lockstep > 0:
             ap.error("--lockstep handles a single partition")
     else:
         model = Model.from_file(tree, args.msa, states=args.states, cmap=cmap,
@@ -178,6 +179,8 @@ def main(argv=None):
     model.compute_lh(tree.root_location(0))                    # model.initialize()
     if ckp is not None:
         model.set_checkpoint(ckp)
+    if args.lockstep < 0:   # same results either way; lock step fills the GPU on small alignments
+        args.lockstep = 16 if (args.lbfgsb and not args.partition) else 0
     if args.exhaustive:
         model.assign_by_rank(rank, world, ckp)                 # src/main.cpp:612-615
         barrier()
