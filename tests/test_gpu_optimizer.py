@@ -205,3 +205,27 @@ def test_heuristic_search(lbfgsb):
     assert llh >= initial
     assert 0.0 <= best.brlen_ratio <= 1.0
     assert abs(m.compute_lh(best) - llh) < 1e-6 * abs(llh)
+
+
+def test_cli_exhaustive_with_parameter_optimisation(lbfgsb, tmp_path):
+    """`rd --exhaustive` end to end with the reference's L-BFGS-B: the command
+    line picks lock step by itself; its results equal the library's sequential
+    loop on the same options."""
+    from root_digger_amd import cli
+    msa, tre = os.path.join(util.DATA, "10.fasta"), os.path.join(util.DATA, "10.tree")
+    prefix = str(tmp_path / "opt")
+    assert cli.main(["--msa", msa, "--tree", tre, "--prefix", prefix, "--exhaustive", "--silent",
+                     "--lbfgsb", REF, "--rate-cats", "4", "--seed", "9", "--atol", "1e-3",
+                     "--bfgstol", "1e-3", "--brtol", "1e-3", "--factor", "1e12"]) == 0
+    got = {r: (l, a) for r, l, a, _ in rd.Checkpoint(prefix).read_results()}
+    tree = rd.Tree.from_file(tre)
+    m = rd.Model.from_file(tree, msa, rate_cats=4, seed=9)
+    m.initialize_partitions()
+    m.set_lbfgsb(lbfgsb.setulb)
+    m.compute_lh(tree.root_location(0))
+    seq = m.exhaustive_search(1e-3, 1e-3, 1e-3, 1e12)
+    assert sorted(got) == sorted(seq["root_id"])
+    for rid, llh, alpha in zip(seq["root_id"], seq["llh"], seq["alpha"]):
+        assert got[rid] == (llh, alpha)
+    lwr = open(prefix + ".lwr.tree").read()
+    assert lwr.count("LWR=") == 17
