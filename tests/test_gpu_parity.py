@@ -533,6 +533,37 @@ def test_thousand_taxon_tree_vs_oracle():
     compare_state(g, o, [ops[i] for i in (0, 500, 998)], tree)
 
 
+def test_many_sites_few_parking_slots_cross_check():
+    """300 taxa x 120 000 sites x 4 rates: 480 k (site, rate) lanes leave the
+    traversal kernel ONE LDS parking slot per lane, so most older siblings are
+    read back from HBM -- the route small cases never take.  Too big for the
+    oracle; the two independent HIP paths (materialised CLVs + root kernel vs
+    the fused evaluator) must agree, and so must a site slice."""
+    w = synth.workload(300, 120000, 4, 4, 91)
+    tree = rd.Tree.from_newick(w["newick"])
+    g = rd.Partition.for_tree(tree, 4, 120000, 4)
+    util.load_tips(g, tree, w["seqs"], rd.MAP_NT)
+    freqs = g.empirical_frequencies()
+    set_model((g,), w["subst"], freqs, w["rates"])
+    rls = [tree.root_location(i).with_ratio(a) for i, a in ((3, 0.2), (401, 0.7))]
+    full = [util.compute_lh(g, tree, rl) for rl in rls]
+    scheds = [g.schedule(*tree.generate_operations(rl)) for rl in rls]
+    fused = g.evaluate_batch(scheds, [w["subst"]] * 2, [freqs] * 2)
+    for a, b in zip(full, fused):
+        assert math.isfinite(a) and util.rel_err(a, b) < 1e-12
+    # a 3 000-site slice of the same alignment, small enough for every slot
+    sub = {k: v[50000:53000] for k, v in w["seqs"].items()}
+    h = rd.Partition.for_tree(tree, 4, 3000, 4)
+    util.load_tips(h, tree, sub, rd.MAP_NT)
+    set_model((h,), w["subst"], freqs, w["rates"])
+    _, persite = g.compute_root_loglikelihood(tree.root_clv_index(), tree.root_scaler_index(),
+                                              persite=True)      # state left by rls[1]
+    part = util.compute_lh(h, tree, rls[1])
+    assert util.rel_err(part, float(np.sum(persite[50000:53000]))) < 1e-12
+    g.destroy()
+    h.destroy()
+
+
 @pytest.mark.parametrize("n,S,R,seed", [(64, 700, 4, 71), (150, 300, 2, 72), (40, 9000, 4, 73)])
 def test_arbitrary_operation_orders(n, S, R, seed):
     """rdamd_update_clvs takes ANY valid list (corax_update_clvs contract), not
