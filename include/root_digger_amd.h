@@ -65,7 +65,11 @@ typedef struct rdamd_partition rdamd_partition_t;
  * --------------------------------------------------------------------- */
 
 /* replaces corax_partition_create, src/model.cpp:159-168.  Returns NULL and
- * sets rdamd_errmsg on failure (no GPU, out of memory, bad sizes). */
+ * sets rdamd_errmsg on failure (no GPU, out of memory, bad sizes).
+ * states == 2 (binary characters, `rd --states 2`, src/main.cpp:484-488) runs
+ * on the 4-state kernels with two inert states; every array that crosses this
+ * boundary keeps its 2-state shape (2 substitution rates, 2 frequencies,
+ * [S][R][2] CLVs, [R][2][2] P-matrices), including rdamd_evaluate_batch. */
 rdamd_partition_t *rdamd_partition_create(unsigned int tips,
                                           unsigned int clv_buffers,
                                           unsigned int states,

@@ -597,8 +597,9 @@ class Partition:
     def _batch_args(self, schedules, subst, freqs, rates, rate_weights):
         n = len(schedules)
         hs = (_vp * n)(*[s._h for s in schedules])
-        subst = np.ascontiguousarray(subst, dtype=np.float64).reshape(n, 12)
-        freqs = np.ascontiguousarray(freqs, dtype=np.float64).reshape(n, 4)
+        k = self.states                       # 4, or 2 (binary data on the 4-state kernels)
+        subst = np.ascontiguousarray(subst, dtype=np.float64).reshape(n, k * k - k)
+        freqs = np.ascontiguousarray(freqs, dtype=np.float64).reshape(n, k)
         if rates is not None:
             rates = np.ascontiguousarray(rates, dtype=np.float64).reshape(n, self.rate_cats)
         if rate_weights is not None:

@@ -59,7 +59,7 @@ public:
     rdamd_schedule_destroy(s);
   }
 
-  // n jobs of one candidate (same schedule): subst [n][12], freqs [n][4],
+  // n jobs of one candidate (same schedule): subst [n][K*K-K], freqs [n][K],
   // rates / weights [n][R].  Returns when the launch that carried them is done.
   void evaluate(unsigned n, const rdamd_schedule_t *sched, const double *subst,
                 const double *freqs, const double *rates, const double *weights, double *out) {
@@ -110,14 +110,15 @@ private:
   }
   std::string launch(const std::vector<request_t *> &batch) {
     const unsigned R = rdamd_partition_rate_cats(_part);
+    const unsigned K = rdamd_partition_states(_part), NP = K * K - K;
     const size_t total = count(batch);
     std::vector<const rdamd_schedule_t *> scheds;
     std::vector<double> subst, freqs, rates, weights, out(total);
     scheds.reserve(total);
     for (auto *r : batch) {
       scheds.insert(scheds.end(), r->n, r->sched);
-      subst.insert(subst.end(), r->subst, r->subst + (size_t)r->n * 12);
-      freqs.insert(freqs.end(), r->freqs, r->freqs + (size_t)r->n * 4);
+      subst.insert(subst.end(), r->subst, r->subst + (size_t)r->n * NP);
+      freqs.insert(freqs.end(), r->freqs, r->freqs + (size_t)r->n * K);
       rates.insert(rates.end(), r->rates, r->rates + (size_t)r->n * R);
       weights.insert(weights.end(), r->weights, r->weights + (size_t)r->n * R);
     }

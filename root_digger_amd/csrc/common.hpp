@@ -55,6 +55,12 @@ struct DeviceView {
 }  // namespace rdamd
 
 struct rdamd_partition {
+  // Binary (2-state) data runs on the 4-state machinery: states 2 and 3 are
+  // dummies with frequency 0, no substitutions and tip bit 0, so every kernel
+  // computes exactly the 2-state recursion in entries 0-1 and zeros in 2-3.
+  // `states` is what the kernels see (4 then), `api_states` what the caller set.
+  unsigned api_states = 0;
+  bool embedded() const { return api_states != states; }
   unsigned tips = 0, clv_buffers = 0, states = 0, sites = 0, rate_matrices = 0,
            prob_matrices = 0, rate_cats = 0, scale_buffers = 0, attributes = 0;
   int device = 0;
@@ -98,6 +104,7 @@ struct rdamd_partition {
   std::vector<std::vector<double>> subst, freqs;
   std::vector<double> rates, rate_weights, prop_invar;
   std::vector<unsigned> pattern_weights;
+  std::vector<std::vector<double>> api_subst, api_freqs;   // caller-shaped copies (embedded only)
   std::vector<uint8_t> tipcodes;     // [tips][sites]
   std::vector<uint64_t> codemask;    // code index -> state mask
   unsigned ncodes = 0, ncodes_cap = 0;

@@ -289,8 +289,17 @@ static int evaluate_batch_impl(rdamd_partition_t *p, unsigned int n_jobs,
     hj[j].prog = s->d_prog; hj[j].brlen = s->d_brlen; hj[j].n_ops = s->n_ops;
     hj[j].depth = 0;   // patched below: every block uses the launch-wide depth
     max_depth = std::max(max_depth, s->depth);
-    const double *fj = freqs + (size_t)j * 4;
-    build_q_host(4, subst + (size_t)j * NP, fj, hq + (size_t)j * 16);
+    double wide_s[12] = {0}, wide_f[4] = {0};
+    const double *sj = subst + (size_t)j * NP, *fj = freqs + (size_t)j * 4;
+    if (p->embedded()) {   // caller passes [n][2] / [n][2]: into the 4-state shapes
+      wide_s[0] = subst[(size_t)j * 2];
+      wide_s[3] = subst[(size_t)j * 2 + 1];
+      wide_f[0] = freqs[(size_t)j * 2];
+      wide_f[1] = freqs[(size_t)j * 2 + 1];
+      sj = wide_s;
+      fj = wide_f;
+    }
+    build_q_host(4, sj, fj, hq + (size_t)j * 16);
     for (unsigned k = 0; k < 4; ++k) hf[(size_t)j * 4 + k] = fj[k];
     for (unsigned r = 0; r < R; ++r) {
       hr[(size_t)j * R + r] = rates ? rates[(size_t)j * R + r] : p->rates[r];

@@ -337,13 +337,14 @@ std::vector<double> model_t::compute_all_root_lh_batched() {
   rooted_tree_t scratch(_tree);   // schedules are generated on a copy: _tree keeps its rooting
   for (size_t p = 0; p < _partitions.size(); ++p) {
     rdamd_partition_t *part = _partitions[p];
-    if (rdamd_partition_states(part) != 4)
-      throw std::runtime_error("compute_all_root_lh_batched: 4-state data only");
+    const unsigned K = rdamd_partition_states(part), NP = K * K - K;
+    if (K != 4 && K != 2)
+      throw std::runtime_error("compute_all_root_lh_batched: 4-state or binary data only");
     const unsigned R = rdamd_partition_rate_cats(part);
     const double *cs = rdamd_partition_subst_params(part, 0), *cf = rdamd_partition_frequencies(part, 0);
     std::vector<rdamd_schedule_t *> owned;
     std::vector<const rdamd_schedule_t *> scheds(n);
-    std::vector<double> subst(n * 12), freqs(n * 4), rates(n * R), weights(n * R), out(n);
+    std::vector<double> subst(n * NP), freqs(n * K), rates(n * R), weights(n * R), out(n);
     for (size_t j = 0; j < n; ++j) {
       auto sc = scratch.generate_operations(roots[j]);
       rdamd_schedule_t *s = rdamd_schedule_create(
@@ -355,8 +356,8 @@ std::vector<double> model_t::compute_all_root_lh_batched() {
       }
       owned.push_back(s);
       scheds[j] = s;
-      std::copy(cs, cs + 12, subst.begin() + j * 12);
-      std::copy(cf, cf + 4, freqs.begin() + j * 4);
+      std::copy(cs, cs + NP, subst.begin() + j * NP);
+      std::copy(cf, cf + K, freqs.begin() + j * K);
       std::copy(_rate_rates[p].begin(), _rate_rates[p].end(), rates.begin() + j * R);
       std::copy(_rate_weights[p].begin(), _rate_weights[p].end(), weights.begin() + j * R);
     }
@@ -378,9 +379,10 @@ std::vector<double> model_t::compute_lh_batch(
   // schedules are per (partition, distinct root): compile once per root
   for (size_t p = 0; p < _partitions.size(); ++p) {
     const unsigned R = rdamd_partition_rate_cats(_partitions[p]);
+    const unsigned K = rdamd_partition_states(_partitions[p]), NP = K * K - K;
     std::vector<rdamd_schedule_t *> owned;
     std::vector<const rdamd_schedule_t *> scheds(n);
-    std::vector<double> subst(n * 12), freqs(n * 4), rates(n * R), weights(n * R), out(n);
+    std::vector<double> subst(n * NP), freqs(n * K), rates(n * R), weights(n * R), out(n);
     for (size_t j = 0; j < n; ++j) {
       auto sc = _tree.generate_operations(roots[j]);
       rdamd_schedule_t *s = rdamd_schedule_create(
@@ -393,10 +395,10 @@ std::vector<double> model_t::compute_lh_batch(
       owned.push_back(s);
       scheds[j] = s;
       const partition_parameters_t &pp = params[j][p];
-      std::copy(pp.subst_rates.begin(), pp.subst_rates.end(), subst.begin() + j * 12);
+      std::copy(pp.subst_rates.begin(), pp.subst_rates.end(), subst.begin() + j * NP);
       double fs = 0.0;
       for (auto f : pp.freqs) fs += f;
-      for (size_t k = 0; k < 4; ++k) freqs[j * 4 + k] = pp.freqs[k] / fs;
+      for (size_t k = 0; k < K; ++k) freqs[j * K + k] = pp.freqs[k] / fs;
       std::vector<double> r(R, 1.0);
       if (_rate_category_types[p] != rate_category::FREE)
         rdamd_compute_gamma_cats(pp.gamma_alpha.empty() ? 1.0 : pp.gamma_alpha[0], R, r.data(),
@@ -643,7 +645,8 @@ double model_t::bfgs_params(model_params_t &initial, size_t pi, bfgs_target what
   // state of the partition that this optimiser does not vary
   const double *cur_subst = rdamd_partition_subst_params(part, 0);
   const double *cur_freqs = rdamd_partition_frequencies(part, 0);
-  const model_params_t base_subst(cur_subst, cur_subst + 12), base_freqs(cur_freqs, cur_freqs + 4);
+  const unsigned K = rdamd_partition_states(part), NP = K * K - K;
+  const model_params_t base_subst(cur_subst, cur_subst + NP), base_freqs(cur_freqs, cur_freqs + K);
   const model_params_t base_rates(_rate_rates[pi]);
 
   auto apply = [&](const model_params_t &x) {   // set_func of the reference
@@ -655,7 +658,7 @@ double model_t::bfgs_params(model_params_t &initial, size_t pi, bfgs_target what
   auto objective = [&](const std::vector<model_params_t> &xs) {
     const size_t m = xs.size();
     std::vector<const rdamd_schedule_t *> scheds(m, sched);
-    std::vector<double> subst(m * 12), freqs(m * 4), rates(m * R), weights(m * R), out(m);
+    std::vector<double> subst(m * NP), freqs(m * K), rates(m * R), weights(m * R), out(m);
     for (size_t j = 0; j < m; ++j) {
       model_params_t s = base_subst, f = base_freqs, r = base_rates;
       if (what == bfgs_target::rates) s = xs[j];
@@ -667,8 +670,8 @@ double model_t::bfgs_params(model_params_t &initial, size_t pi, bfgs_target what
       } else if (_rate_category_types[pi] != rate_category::FREE) {
         rdamd_compute_gamma_cats(xs[j][0], R, r.data(), RDAMD_GAMMA_RATES_MEDIAN);
       }
-      std::copy(s.begin(), s.end(), subst.begin() + j * 12);
-      std::copy(f.begin(), f.end(), freqs.begin() + j * 4);
+      std::copy(s.begin(), s.end(), subst.begin() + j * NP);
+      std::copy(f.begin(), f.end(), freqs.begin() + j * K);
       std::copy(r.begin(), r.end(), rates.begin() + j * R);
       std::copy(_rate_weights[pi].begin(), _rate_weights[pi].end(), weights.begin() + j * R);
     }
@@ -745,8 +748,8 @@ void model_t::optimize_params(std::vector<partition_parameters_t> &params,
     throw std::runtime_error("optimize_params: the batch combiner handles one partition");
   batch_combiner_t::scope_t in_lockstep(_combiner);
   for (size_t i = 0; i < _partitions.size(); ++i) {
-    if (rdamd_partition_states(_partitions[i]) != 4)
-      throw std::runtime_error("optimize_params: the batched objective handles 4-state data");
+    if (rdamd_partition_states(_partitions[i]) != 4 && rdamd_partition_states(_partitions[i]) != 2)
+      throw std::runtime_error("optimize_params: the batched objective handles 4-state and binary data");
     set_subst_rates(i, params[i].subst_rates);
     set_freqs_all_free(i, params[i].freqs);
     set_gamma_rates(i, params[i].gamma_alpha);

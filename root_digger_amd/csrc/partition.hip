@@ -161,6 +161,8 @@ rdamd_partition_t *rdamd_partition_create(unsigned int tips, unsigned int clv_bu
     return nullptr;
   }
   rdamd_partition *p = new rdamd_partition();
+  p->api_states = states;
+  if (states == 2) states = 4;   // embedded, see common.hpp
   p->tips = tips; p->clv_buffers = clv_buffers; p->states = states; p->sites = sites;
   p->rate_matrices = rate_matrices; p->prob_matrices = prob_matrices;
   p->rate_cats = rate_cats; p->scale_buffers = scale_buffers; p->attributes = attributes;
@@ -199,6 +201,15 @@ rdamd_partition_t *rdamd_partition_create(unsigned int tips, unsigned int clv_bu
   // defaults as corax_partition_create leaves them: weights 1, rates 1, 1/R
   p->subst.assign(rate_matrices, std::vector<double>((size_t)K * K - K, 1.0));
   p->freqs.assign(rate_matrices, std::vector<double>(K, 1.0 / K));
+  if (p->embedded()) {   // defaults of a 2-state partition, through the embedding setters
+    p->api_subst.assign(rate_matrices, std::vector<double>(2, 1.0));
+    p->api_freqs.assign(rate_matrices, std::vector<double>(2, 0.5));
+    for (unsigned i = 0; i < rate_matrices; ++i) {
+      p->subst[i].assign(12, 0.0);
+      p->subst[i][0] = p->subst[i][3] = 1.0;
+      p->freqs[i] = {0.5, 0.5, 0.0, 0.0};
+    }
+  }
   p->rates.assign(R, 1.0);
   p->rate_weights.assign(R, 1.0 / R);
   p->prop_invar.assign(rate_matrices, 0.0);
@@ -248,7 +259,7 @@ int rdamd_set_tip_states(rdamd_partition_t *p, unsigned int tip_index,
   }
   const size_t S = p->sites;
   uint8_t *row = p->tipcodes.data() + (size_t)tip_index * S;
-  const uint64_t full = p->states == 64 ? ~0ull : ((1ull << p->states) - 1);
+  const uint64_t full = p->api_states == 64 ? ~0ull : ((1ull << p->api_states) - 1);
   bool new_code = false;
   for (size_t s = 0; s < S; ++s) {
     uint64_t st = map[(unsigned char)sequence[s]];
@@ -291,13 +302,25 @@ void rdamd_set_pattern_weights(rdamd_partition_t *p, const unsigned int *w) {
 
 void rdamd_set_subst_params(rdamd_partition_t *p, unsigned int idx, const double *v) {
   if (idx >= p->rate_matrices) return;
-  p->subst[idx].assign(v, v + (size_t)p->states * p->states - p->states);
+  if (p->embedded()) {   // (q01, q10) into the row-major off-diagonals of the 4x4 matrix
+    p->api_subst[idx].assign(v, v + 2);
+    p->subst[idx].assign(12, 0.0);
+    p->subst[idx][0] = v[0];
+    p->subst[idx][3] = v[1];
+  } else {
+    p->subst[idx].assign(v, v + (size_t)p->states * p->states - p->states);
+  }
   p->q_dirty[idx] = 1;
 }
 
 void rdamd_set_frequencies(rdamd_partition_t *p, unsigned int idx, const double *f) {
   if (idx >= p->rate_matrices) return;
-  p->freqs[idx].assign(f, f + p->states);
+  if (p->embedded()) {
+    p->api_freqs[idx].assign(f, f + 2);
+    p->freqs[idx] = {f[0], f[1], 0.0, 0.0};
+  } else {
+    p->freqs[idx].assign(f, f + p->states);
+  }
   p->q_dirty[idx] = 1;
 }
 
@@ -324,7 +347,7 @@ int rdamd_update_invariant_sites_proportion(rdamd_partition_t *p, unsigned int i
 }
 
 double *rdamd_msa_empirical_frequencies(rdamd_partition_t *p) {
-  const unsigned K = p->states;
+  const unsigned K = p->api_states;
   double *f = (double *)calloc(K, sizeof(double));
   if (!f) return nullptr;
   double total = 0.0;
@@ -343,15 +366,17 @@ double *rdamd_msa_empirical_frequencies(rdamd_partition_t *p) {
   return f;
 }
 
-unsigned int rdamd_partition_states(const rdamd_partition_t *p) { return p->states; }
+unsigned int rdamd_partition_states(const rdamd_partition_t *p) { return p->api_states; }
 unsigned int rdamd_partition_rate_cats(const rdamd_partition_t *p) { return p->rate_cats; }
 unsigned int rdamd_partition_sites(const rdamd_partition_t *p) { return p->sites; }
 unsigned int rdamd_partition_tips(const rdamd_partition_t *p) { return p->tips; }
 const double *rdamd_partition_subst_params(const rdamd_partition_t *p, unsigned int i) {
-  return i < p->rate_matrices ? p->subst[i].data() : nullptr;
+  if (i >= p->rate_matrices) return nullptr;
+  return p->embedded() ? p->api_subst[i].data() : p->subst[i].data();
 }
 const double *rdamd_partition_frequencies(const rdamd_partition_t *p, unsigned int i) {
-  return i < p->rate_matrices ? p->freqs[i].data() : nullptr;
+  if (i >= p->rate_matrices) return nullptr;
+  return p->embedded() ? p->api_freqs[i].data() : p->freqs[i].data();
 }
 
 int rdamd_update_prob_matrices(rdamd_partition_t *p, const unsigned int *params_indices,
@@ -680,13 +705,13 @@ int rdamd_root_loglikelihood_fused(rdamd_partition_t *p, const rdamd_operation_t
 
 int rdamd_get_clv(rdamd_partition_t *p, unsigned int clv_index, double *out) {
   clear_error();
-  const size_t S = p->sites, R = p->rate_cats, K = p->states;
+  const size_t S = p->sites, R = p->rate_cats, K = p->states, KA = p->api_states;
   if (clv_index < p->tips) {  // tips live as codes; expand on the host
     const uint8_t *row = p->tipcodes.data() + (size_t)clv_index * S;
     for (size_t s = 0; s < S; ++s) {
       uint64_t mask = p->codemask[row[s]];
       for (size_t r = 0; r < R; ++r)
-        for (size_t j = 0; j < K; ++j) out[(s * R + r) * K + j] = (double)((mask >> j) & 1);
+        for (size_t j = 0; j < KA; ++j) out[(s * R + r) * KA + j] = (double)((mask >> j) & 1);
     }
     return RDAMD_SUCCESS;
   }
@@ -695,8 +720,16 @@ int rdamd_get_clv(rdamd_partition_t *p, unsigned int clv_index, double *out) {
     return RDAMD_FAILURE;
   }
   RDAMD_HIP_TRY(hipStreamSynchronize(p->stream), RDAMD_FAILURE);
-  RDAMD_HIP_TRY(hipMemcpy(out, p->d_clv + (size_t)(clv_index - p->tips) * S * R * K,
-                          sizeof(double) * S * R * K, hipMemcpyDeviceToHost), RDAMD_FAILURE);
+  const double *src = p->d_clv + (size_t)(clv_index - p->tips) * S * R * K;
+  if (!p->embedded()) {
+    RDAMD_HIP_TRY(hipMemcpy(out, src, sizeof(double) * S * R * K, hipMemcpyDeviceToHost), RDAMD_FAILURE);
+    return RDAMD_SUCCESS;
+  }
+  std::vector<double> wide(S * R * K);   // the caller's states are the first KA of every K
+  RDAMD_HIP_TRY(hipMemcpy(wide.data(), src, sizeof(double) * S * R * K, hipMemcpyDeviceToHost),
+                RDAMD_FAILURE);
+  for (size_t e = 0; e < S * R; ++e)
+    for (size_t j = 0; j < KA; ++j) out[e * KA + j] = wide[e * K + j];
   return RDAMD_SUCCESS;
 }
 
@@ -718,10 +751,19 @@ int rdamd_get_pmatrix(rdamd_partition_t *p, unsigned int matrix_index, double *o
     set_error(8, "rdamd_get_pmatrix: index out of range");
     return RDAMD_FAILURE;
   }
-  const size_t n = (size_t)p->rate_cats * p->states * p->states;
+  const size_t K = p->states, KA = p->api_states, n = (size_t)p->rate_cats * K * K;
   RDAMD_HIP_TRY(hipStreamSynchronize(p->stream), RDAMD_FAILURE);
-  RDAMD_HIP_TRY(hipMemcpy(out, p->d_pmat + (size_t)matrix_index * n, sizeof(double) * n,
+  if (!p->embedded()) {
+    RDAMD_HIP_TRY(hipMemcpy(out, p->d_pmat + (size_t)matrix_index * n, sizeof(double) * n,
+                            hipMemcpyDeviceToHost), RDAMD_FAILURE);
+    return RDAMD_SUCCESS;
+  }
+  std::vector<double> wide(n);
+  RDAMD_HIP_TRY(hipMemcpy(wide.data(), p->d_pmat + (size_t)matrix_index * n, sizeof(double) * n,
                           hipMemcpyDeviceToHost), RDAMD_FAILURE);
+  for (size_t r = 0; r < p->rate_cats; ++r)
+    for (size_t i = 0; i < KA; ++i)
+      for (size_t j = 0; j < KA; ++j) out[(r * KA + i) * KA + j] = wide[(r * K + i) * K + j];
   return RDAMD_SUCCESS;
 }
 

@@ -229,3 +229,35 @@ def test_cli_exhaustive_with_parameter_optimisation(lbfgsb, tmp_path):
         assert got[rid] == (llh, alpha)
     lwr = open(prefix + ".lwr.tree").read()
     assert lwr.count("LWR=") == 17
+
+
+def test_binary_characters_with_parameter_optimisation(lbfgsb, tmp_path):
+    """`rd --states 2` with the full per-candidate loop: two substitution rates
+    and two frequencies go through the same batched L-BFGS-B objective (the
+    partition runs on the 4-state kernels); optimising can only help."""
+    from root_digger_amd import synth
+    w = synth.workload(12, 1500, 2, 4, 5)
+    tree = rd.Tree.from_newick(w["newick"])
+    cmap = util.make_map(w["alphabet"])
+    m = rd.Model(tree, w["seqs"], states=2, cmap=cmap, rate_cats=4, seed=4, early_stop=True)
+    m.initialize_partitions()
+    m.compute_lh(tree.root_location(0))
+    plain = m.exhaustive_search(1e-3, 1e-3, 1e-3, 1e12)
+    m.set_lbfgsb(lbfgsb.setulb)
+    opt = m.exhaustive_search(1e-3, 1e-3, 1e-3, 1e12)
+    lock = m.exhaustive_search(1e-3, 1e-3, 1e-3, 1e12, lockstep=8)
+    by_id = dict(zip(plain["root_id"], plain["llh"]))
+    assert sorted(opt["root_id"]) == list(range(tree.root_count()))
+    for rid, llh in zip(opt["root_id"], opt["llh"]):
+        assert np.isfinite(llh) and llh >= by_id[rid] - 1e-6
+    assert opt["best_llh"] > plain["best_llh"]
+    order = np.argsort(opt["root_id"])
+    assert np.array_equal(lock["llh"], opt["llh"][order])
+    # the result log keeps the 2-state shapes
+    ck = rd.Checkpoint(str(tmp_path / "bin"))
+    ck.save_options({"data_type": "bin"})
+    m.set_checkpoint(ck)
+    m.assign_by_rank(0, tree.root_count())          # one candidate
+    m.exhaustive_search(1e-3, 1e-3, 1e-3, 1e12)
+    (rid, llh, alpha, params), = ck.read_results()
+    assert len(params[0]["subst_rates"]) == 2 and len(params[0]["freqs"]) == 2

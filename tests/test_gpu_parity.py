@@ -191,6 +191,8 @@ def test_protein20_generic_path():
     (25, 300, 20, 4, 15),       # c3 shape
     (12, 1, 4, 4, 16),          # a single site
     (9, 65, 3, 3, 17),          # odd K, odd R -> generic kernels
+    (30, 2100, 2, 4, 18),       # binary characters: embedded in the 4-state kernels
+    (17, 333, 2, 1, 19),
 ])
 def test_synthetic_vs_oracle(n, S, K, R, seed):
     w = synth.workload(n, S, K, R, seed)
@@ -531,6 +533,51 @@ def test_thousand_taxon_tree_vs_oracle():
     assert max(s.stack_depth() for s in scheds) <= 10
     ops, _, _ = tree.generate_operations(rls[2])
     compare_state(g, o, [ops[i] for i in (0, 500, 998)], tree)
+
+
+def test_binary_data_on_the_four_state_kernels():
+    """states == 2 (`rd --states 2`): the partition runs on the 4-state kernels
+    with two inert states.  Everything the caller sees keeps its 2-state shape
+    and agrees with the oracle's native 2-state arithmetic: P-matrices, CLVs,
+    scalers, lnL, the fused root step and the fused batch."""
+    w = synth.workload(40, 1500, 2, 4, 77)
+    tree = rd.Tree.from_newick(w["newick"])
+    cmap = util.make_map(w["alphabet"], {"-": 3, "?": 3})
+    seqs = {k: v[:700] + "-" * 5 + v[705:] for k, v in w["seqs"].items()}     # gaps = both states
+    g, o = pair(tree, seqs, 2, 4, cmap, cmap)
+    assert g.states == 2 and rd.lib.rdamd_partition_states(g.handle) == 2
+    freqs = g.empirical_frequencies()
+    assert len(freqs) == 2 and np.allclose(freqs, o.empirical_frequencies(), rtol=1e-13)
+    subst = [0.7, 1.9]
+    set_model((g, o), subst, freqs, w["rates"])
+    assert np.allclose(g.subst_params(0), subst)
+    rl = tree.root_location(21).with_ratio(0.35)
+    ops, pmi, brl = tree.generate_operations(rl)
+    for p in (g, o):
+        p.update_prob_matrices(pmi, brl)
+        p.update_clvs(ops)
+    for m in (0, 5, len(pmi) - 1):
+        a = g.get_pmatrix(int(pmi[m]))
+        assert a.shape == (4, 2, 2) and np.allclose(a, o.get_pmatrix(int(pmi[m])), atol=1e-13)
+        assert np.allclose(a.sum(axis=2), 1.0, atol=1e-13)
+    compare_state(g, o, ops, tree)
+    assert g.get_clv(ops[-1].parent_clv_index).shape == (1500, 4, 2)
+    a = g.compute_root_loglikelihood(tree.root_clv_index(), tree.root_scaler_index())
+    b = o.compute_root_loglikelihood(tree.root_clv_index(), tree.root_scaler_index())
+    assert util.rel_err(a, b) < LNL_TOL
+    assert util.rel_err(util.compute_lh_root(g, tree, rl), b) < LNL_TOL
+    # fused batch: [n][2] rates and [n][2] frequencies
+    rls = [tree.root_location(i).with_ratio(0.5) for i in (0, 33, 76)]
+    scheds = [g.schedule(*tree.generate_operations(r)) for r in rls]
+    subs = [[0.7, 1.9], [1.0, 1.0], [0.05, 3.0]]
+    frs = [freqs, [0.5, 0.5], [0.2, 0.8]]
+    got = g.evaluate_batch(scheds, subs, frs)
+    for r, s_, f_, val in zip(rls, subs, frs, got):
+        o.set_subst_params(0, s_)
+        o.set_frequencies(0, f_)
+        assert util.rel_err(val, util.compute_lh(o, tree, r)) < LNL_TOL
+    g.destroy()
+    o.destroy()
 
 
 def test_many_sites_few_parking_slots_cross_check():
