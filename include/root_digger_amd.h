@@ -517,6 +517,14 @@ rdamd_model_t *rdamd_model_create_partitioned(const rdamd_tree_t *tree, const ch
                                               uint64_t seed, int early_stop,
                                               unsigned int *n_partitions);
 int rdamd_model_partition_count(const rdamd_model_t *m);
+/* rdamd_model_create_from_file with the full rate-heterogeneity option
+ * (`rd --rate-cats N --rate-cats-type {mean,median,free}`, src/main.cpp:256-266) */
+rdamd_model_t *rdamd_model_create_from_file_ratehet(const rdamd_tree_t *tree,
+                                                    const char *msa_filename,
+                                                    unsigned int states, const uint64_t *map,
+                                                    const rdamd_ratehet_opts_t *ratehet,
+                                                    uint64_t seed, int early_stop, int compress,
+                                                    unsigned int *n_patterns);
 
 /* character maps (replace corax_map_nt / corax_map_bin, src/main.cpp:484) */
 extern const uint64_t rdamd_map_nt[256];

@@ -185,6 +185,8 @@ _sig("rdamd_msa_partition_probe", C.c_int, C.c_char_p, C.c_void_p, _u, C.POINTER
      C.c_int, _pu, _pu)
 _sig("rdamd_model_create_partitioned", _vp, _vp, C.c_char_p, C.c_char_p, _u, C.c_void_p,
      C.c_uint64, C.c_int, _pu)
+_sig("rdamd_model_create_from_file_ratehet", _vp, _vp, C.c_char_p, _u, C.c_void_p,
+     C.POINTER(RatehetOpts), C.c_uint64, C.c_int, C.c_int, _pu)
 _sig("rdamd_model_partition_count", C.c_int, _vp)
 _sig("rdamd_checkpoint_open", _vp, C.c_char_p)
 _sig("rdamd_checkpoint_close", None, _vp)
@@ -845,14 +847,20 @@ class Model:
 
     @classmethod
     def from_file(cls, tree, msa_path, states=4, cmap=None, rate_cats=1, seed=1,
-                  early_stop=False, compress=True):
+                  early_stop=False, compress=True, rate_category_type="mean"):
         """model_t over msa_t(filename): PHYLIP / FASTA ingest + pattern compression."""
         self = cls.__new__(cls)
         self._tree, self.states = tree, states
         n = C.c_uint(0)
-        self._h = lib.rdamd_model_create_from_file(
-            tree._h, str(msa_path).encode(), states, cmap if cmap is not None else MAP_NT,
-            rate_cats, seed, 1 if early_stop else 0, 1 if compress else 0, C.byref(n))
+        if rate_category_type != "mean":
+            rc = RatehetOpts(1, RATE_CATEGORIES.index(rate_category_type.upper()), rate_cats, 0, 1.0)
+            self._h = lib.rdamd_model_create_from_file_ratehet(
+                tree._h, str(msa_path).encode(), states, cmap if cmap is not None else MAP_NT,
+                C.byref(rc), seed, 1 if early_stop else 0, 1 if compress else 0, C.byref(n))
+        else:
+            self._h = lib.rdamd_model_create_from_file(
+                tree._h, str(msa_path).encode(), states, cmap if cmap is not None else MAP_NT,
+                rate_cats, seed, 1 if early_stop else 0, 1 if compress else 0, C.byref(n))
         if not self._h:
             _fail("model_create_from_file")
         self.patterns = n.value

@@ -33,6 +33,12 @@ import time
 
 from . import MAP_BIN, MAP_NT, Checkpoint, Model, Tree, parse_model_info, set_device
 
+def version_string():
+    from . import lib
+    lib.rdamd_version.restype = ctypes.c_char_p
+    return lib.rdamd_version().decode()
+
+
 STRATEGIES = ["random", "midpoint", "modified-mad"]   # initial_root_strategy_t, src/util.hpp:74-78
 
 
@@ -45,6 +51,7 @@ def main(argv=None):
                     help="4: nucleotides; 2: binary characters (src/main.cpp:484-488; parameter "
                          "optimisation is available for 4 states)")
     ap.add_argument("--rate-cats", type=int, default=1)
+    ap.add_argument("--rate-cats-type", default="mean", choices=["mean", "median", "free"])
     ap.add_argument("--partition", default=None,
                     help="partition file: <MODEL>, <NAME> = <BEGIN>-<END>[, ...] per line; rate "
                          "categories then come from each line's model string")
@@ -62,6 +69,10 @@ def main(argv=None):
                     help="accepted for compatibility; the proportion is pinned to 0 as in the "
                          "reference (src/model.cpp:292-300)")
     ap.add_argument("--verbose", action="count", default=0, help="accepted for compatibility")
+    ap.add_argument("--debug", action="store_true", help="accepted for compatibility")
+    ap.add_argument("--mpi-debug", action="store_true", help="accepted for compatibility")
+    ap.add_argument("--echo", action="store_true", help="print the tree as read")
+    ap.add_argument("--version", action="version", version=version_string())
     ap.add_argument("--exhaustive", action="store_true",
                     help="evaluate every branch as a root (default: heuristic search)")
     ap.add_argument("--min-roots", type=int, default=1)
@@ -170,7 +181,10 @@ def main(argv=None):
             ap.error("--lockstep handles a single partition")
     else:
         model = Model.from_file(tree, args.msa, states=args.states, cmap=cmap,
-                                rate_cats=args.rate_cats, seed=args.seed, early_stop=early_stop)
+                                rate_cats=args.rate_cats, seed=args.seed, early_stop=early_stop,
+                                rate_category_type=args.rate_cats_type)
+    if args.echo:
+        print(tree.newick(True))
     model.initialize_partitions()
     keep = None
     if args.lbfgsb:

@@ -93,20 +93,19 @@ rdamd_model_t *rdamd_model_create(const rdamd_tree_t *tree, unsigned int n_taxa,
     return m;
   })
 }
-rdamd_model_t *rdamd_model_create_from_file(const rdamd_tree_t *tree, const char *msa_filename,
-                                            unsigned int states, const uint64_t *map,
-                                            unsigned int rate_cats, uint64_t seed,
-                                            int early_stop, int compress,
-                                            unsigned int *n_patterns) {
+static rdamd_model_t *create_from_file(const rdamd_tree_t *tree, const char *msa_filename,
+                                       unsigned int states, const uint64_t *map,
+                                       const rdamd::ratehet_opts_t &rc, uint64_t seed,
+                                       int early_stop, int compress, unsigned int *n_patterns) {
   GUARD(nullptr, {
     auto *m = new rdamd_model();
-    m->rate_cats = rate_cats; m->seed = seed; m->early_stop = early_stop != 0;
+    m->rate_cats = (unsigned)rc.rate_cats; m->seed = seed; m->early_stop = early_stop != 0;
+    m->ratehets = {rc};
     try {
       m->msa = rdamd::msa_t::from_file(msa_filename, map, states, compress != 0);
       if (!m->msa.constiency_check(rdamd_tree_cpp(tree).label_set()))
         throw std::invalid_argument("Taxa on the tree and in the MSA are inconsistient");
-      m->model = new rdamd::model_t(rdamd_tree_cpp(tree), {m->msa},
-                                    {rdamd::ratehet_opts_t(rate_cats)}, false, seed,
+      m->model = new rdamd::model_t(rdamd_tree_cpp(tree), {m->msa}, {rc}, false, seed,
                                     early_stop != 0);
     } catch (...) {
       delete m;
@@ -115,6 +114,28 @@ rdamd_model_t *rdamd_model_create_from_file(const rdamd_tree_t *tree, const char
     if (n_patterns) *n_patterns = (unsigned)m->msa.length();
     return m;
   })
+}
+rdamd_model_t *rdamd_model_create_from_file(const rdamd_tree_t *tree, const char *msa_filename,
+                                            unsigned int states, const uint64_t *map,
+                                            unsigned int rate_cats, uint64_t seed,
+                                            int early_stop, int compress,
+                                            unsigned int *n_patterns) {
+  return create_from_file(tree, msa_filename, states, map, rdamd::ratehet_opts_t(rate_cats), seed,
+                          early_stop, compress, n_patterns);
+}
+rdamd_model_t *rdamd_model_create_from_file_ratehet(const rdamd_tree_t *tree,
+                                                    const char *msa_filename,
+                                                    unsigned int states, const uint64_t *map,
+                                                    const rdamd_ratehet_opts_t *ratehet,
+                                                    uint64_t seed, int early_stop, int compress,
+                                                    unsigned int *n_patterns) {
+  rdamd::ratehet_opts_t rc(ratehet->rate_cats ? ratehet->rate_cats : 1);
+  rc.type = (rdamd::param_type)ratehet->type;
+  rc.rate_category_type = (rdamd::rate_category)ratehet->rate_category_type;
+  rc.alpha_init = ratehet->alpha_init != 0;
+  rc.alpha = ratehet->alpha;
+  return create_from_file(tree, msa_filename, states, map, rc, seed, early_stop, compress,
+                          n_patterns);
 }
 // The reference's partitioned set-up (src/main.cpp:512-555): the alignment is read
 // whole, cut into the partition file's column ranges, each partition compressed

@@ -387,3 +387,31 @@ def test_cli_binary_characters(tmp_path):
     recs = rd.Checkpoint(prefix).read_results()
     assert len(recs) == 17 and all(np.isfinite(l) and l < 0 for _, l, _, _ in recs)
     assert all(len(p[0]["subst_rates"]) == 2 and len(p[0]["freqs"]) == 2 for _, _, _, p in recs)
+
+
+@pytest.mark.parametrize("kind", ["median", "free"])
+def test_rate_category_types(kind, tmp_path):
+    """`rd --rate-cats 4 --rate-cats-type {median,free}` (src/main.cpp:256-266):
+    the rate-heterogeneity option reaches the model; the run completes and the
+    likelihood responds to it."""
+    from root_digger_amd import cli
+    msa, tre = os.path.join(util.DATA, "10.fasta"), os.path.join(util.DATA, "10.tree")
+    tree = rd.Tree.from_file(tre)
+    base = rd.Model.from_file(tree, msa, rate_cats=4, seed=3)
+    base.initialize_partitions_uniform_freqs()
+    base.set_subst_rates_uniform()
+    other = rd.Model.from_file(tree, msa, rate_cats=4, seed=3, rate_category_type=kind)
+    other.initialize_partitions_uniform_freqs()
+    other.set_subst_rates_uniform()
+    rl = tree.root_location(4)
+    a, b = base.compute_lh(rl), other.compute_lh(rl)
+    assert np.isfinite(a) and np.isfinite(b)
+    prefix = str(tmp_path / kind)
+    assert cli.main(["--msa", msa, "--tree", tre, "--prefix", prefix, "--exhaustive", "--silent",
+                     "--rate-cats", "4", "--rate-cats-type", kind, "--atol", "1e-3",
+                     "--brtol", "1e-3", "--echo"]) == 0
+    recs = rd.Checkpoint(prefix).read_results()
+    assert len(recs) == 17
+    if kind == "free":
+        assert all(len(p[0]["gamma_weights"]) == 4 and len(p[0]["gamma_alpha"]) == 4
+                   for _, _, _, p in recs)
