@@ -536,6 +536,8 @@ int         rdamd_device_count(void);
 /* selects the HIP device later rdamd_partition_create calls of this thread use
  * (one process per GPU: call with LOCAL_RANK). */
 int         rdamd_set_device(int device);
+/* free / total memory of the current device in bytes (hipMemGetInfo) */
+int         rdamd_device_memory(uint64_t *free_bytes, uint64_t *total_bytes);
 
 #ifdef __cplusplus
 }

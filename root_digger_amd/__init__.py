@@ -28,6 +28,7 @@ from .api import (  # noqa: F401
     GAMMA_RATES_MEDIAN,
     device_count,
     set_device,
+    device_memory,
     msa_probe,
 )
 
@@ -36,5 +37,5 @@ __all__ = [
     "msa_partition_probe",
     "checkpoint_checksum_result", "checkpoint_checksum_params",
     "MAP_NT", "MAP_BIN", "compute_gamma_cats", "GAMMA_RATES_MEAN", "GAMMA_RATES_MEDIAN",
-    "device_count", "set_device", "msa_probe",
+    "device_count", "set_device", "device_memory", "msa_probe",
 ]

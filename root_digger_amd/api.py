@@ -62,6 +62,7 @@ _errno = _sig("rdamd_errno", C.c_int)
 _errmsg = _sig("rdamd_errmsg", C.c_char_p)
 _sig("rdamd_version", C.c_char_p)
 _sig("rdamd_device_count", C.c_int)
+_sig("rdamd_device_memory", C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64))
 _sig("rdamd_set_device", C.c_int, C.c_int)
 
 _sig("rdamd_partition_create", _vp, _u, _u, _u, _u, _u, _u, _u, _u, _u)
@@ -240,6 +241,14 @@ def _take_string(ptr):
 
 def device_count():
     return lib.rdamd_device_count()
+
+
+def device_memory():
+    """(free, total) bytes of the current HIP device."""
+    f, t = C.c_uint64(0), C.c_uint64(0)
+    if lib.rdamd_device_memory(C.byref(f), C.byref(t)) != 1:
+        _fail("device_memory")
+    return int(f.value), int(t.value)
 
 
 def set_device(device):

@@ -129,6 +129,15 @@ int rdamd_set_device(int device) {
   return RDAMD_SUCCESS;
 }
 
+int rdamd_device_memory(uint64_t *free_bytes, uint64_t *total_bytes) {
+  clear_error();
+  size_t f = 0, t = 0;
+  RDAMD_HIP_TRY(hipMemGetInfo(&f, &t), RDAMD_FAILURE);
+  if (free_bytes) *free_bytes = f;
+  if (total_bytes) *total_bytes = t;
+  return RDAMD_SUCCESS;
+}
+
 #define NT(ch, v) [ch] = v, [ch + 32] = v
 const uint64_t rdamd_map_nt[256] = {
     NT('A', 1),  NT('C', 2),  NT('G', 4),  NT('T', 8),  NT('U', 8),  NT('R', 5),

@@ -415,3 +415,29 @@ def test_rate_category_types(kind, tmp_path):
     if kind == "free":
         assert all(len(p[0]["gamma_weights"]) == 4 and len(p[0]["gamma_alpha"]) == 4
                    for _, _, _, p in recs)
+
+
+def test_no_device_memory_leak_over_object_lifetimes():
+    """partitions, schedules, models, replicas and checkpoints give back what they
+    took: free device memory is where it started after many create/destroy rounds."""
+    tree = rd.Tree.from_file(os.path.join(util.DATA, "10.tree"))
+    msa = os.path.join(util.DATA, "10.fasta")
+
+    def round_trip():
+        p = rd.Partition.for_tree(tree, 4, 20000, 4)
+        sc = p.schedule(*tree.generate_operations(tree.root_location(3)))
+        p.evaluate_batch([sc] * 8, np.ones((8, 12)), np.full((8, 4), 0.25))
+        sc.destroy()
+        p.destroy()
+        m = rd.Model.from_file(tree, msa, rate_cats=4, seed=2)
+        m.initialize_partitions()
+        m.compute_lh(tree.root_location(0))
+        m.exhaustive_search(1e-2, 1e-2, 1e-2, 1e12, workers=3)
+        m.destroy()
+
+    round_trip()                                   # warm allocator pools, code objects
+    free0, _ = rd.device_memory()
+    for _ in range(12):
+        round_trip()
+    free1, _ = rd.device_memory()
+    assert free0 - free1 < 32 << 20, (free0, free1)
