@@ -195,6 +195,8 @@ def main():
         jitter = 1.0 + 1e-3 * (((s % 97) + 1) + np.arange(nb)[:, None] / (4.0 * nb))
         sub = params[idx] * jitter * (1.0 + 0.05 * np.sin(np.arange(12) + s))
         if site_sharded:
+            row = s - args.warmup
+            lnl_dev = lnl_rows[row] if 0 <= row < args.steps else lnl_warm
             part.evaluate_batch_device([scheds[i] for i in idx], sub, freqs_b[idx],
                                        lnl_dev.data_ptr())
             if world > 1 and not host_collectives:
@@ -212,7 +214,11 @@ def main():
         torch.cuda.synchronize()
         part.sync()
 
-    lnl_dev = torch.zeros(nb, dtype=torch.float64, device="cuda") if site_sharded else None
+    # site-sharded: every timed step leaves its per-job lnLs in its own row (no
+    # torch work inside the timed region); warm-up steps share a scratch row
+    lnl_rows = (torch.zeros((args.steps, nb), dtype=torch.float64, device="cuda")
+                if site_sharded else None)
+    lnl_warm = torch.zeros(nb, dtype=torch.float64, device="cuda") if site_sharded else None
     for s in range(args.warmup):
         step(s)
     part.profile_enable(True)
@@ -226,7 +232,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if site_sharded:
-        check = float(lnl_dev.sum().item())
+        check = float(lnl_rows.sum().item())
     prof = part.profile_read()
     part.profile_enable(False)
     if not np.isfinite(check):

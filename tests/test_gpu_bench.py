@@ -1,0 +1,49 @@
+"""bench.py's contract on a small configuration: one JSON line with the fields
+the driver reads, the roofline and cpu_baseline objects, and the site-sharded
+variant (which hands rdamd_evaluate_batch_device a torch device pointer)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_bench(*extra):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "c1",
+                          "--steps", "3", "--warmup", "1", "--batch", "17"] + list(extra),
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    return json.loads(lines[0])
+
+
+def test_bench_line_has_the_contract_fields():
+    d = run_bench("--cpu-seconds", "2")
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
+                "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+                "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["metric"] == "candidate-root lnL evals/sec" and d["unit"] == "evals/s"
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1
+    assert d["dtype"] == "f64" and d["vs_baseline"] is None and d["scaling"] == "weak"
+    assert d["value"] > 0 and "workload" in d["config"]
+    r = d["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in r, key
+    assert r["bound"] in ("hbm", "mfma") and r["peak"] == 8000.0
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0
+    assert c["parity_max_rel_err"] < 1e-9
+
+
+def test_site_sharded_bench_matches_candidate_sharded_checksum():
+    a = run_bench("--no-cpu-baseline", "--shard", "sites")
+    b = run_bench("--no-cpu-baseline")
+    assert a["scaling"] == "strong" and a["config"]["sharding"].startswith("site blocks")
+    # same jobs, same parameters: the device-pointer path returns the same lnLs
+    assert abs(a["lnl_check"] - b["lnl_check"]) <= 1e-9 * abs(b["lnl_check"])
