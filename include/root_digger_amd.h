@@ -160,6 +160,13 @@ int rdamd_root_loglikelihood_fused(rdamd_partition_t       *p,
                                    unsigned int             n_alpha,
                                    double                  *lnl_out);
 
+/* corax_compute_root_loglikelihood for MANY root CLVs of the partition in one
+ * launch; every value is bit-identical to a separate call on that CLV.  Used by
+ * the all-directions sweep (rdamd_model_compute_all_root_lh_directional). */
+int rdamd_compute_root_loglikelihoods(rdamd_partition_t *p, unsigned int count,
+                                      const unsigned int *clv_indices, const int *scaler_indices,
+                                      const unsigned int *freqs_indices, double *lnl_out);
+
 /* ------------------------------------------------------------------------
  * Batched full-traversal evaluation (the exhaustive-search inner loop)
  *
@@ -352,6 +359,21 @@ int rdamd_model_move_root(rdamd_model_t *m, const rdamd_root_location_t *rl);  /
 int rdamd_model_compute_all_root_lh(rdamd_model_t *m, double *out);
 /* the same sweep as ONE fused launch (every root a job), partition untouched */
 int rdamd_model_compute_all_root_lh_batched(rdamd_model_t *m, double *out);
+/* the same sweep through an all-directions CLV cache: a
+ * partition of its own holds the 3(n-2) directed CLVs, so the 2n-3 likelihoods
+ * cost 3(n-2) + (2n-3) operations and one batched root reduction.  4-state /
+ * binary single-partition models; `ratios` (root_count values) overrides the
+ * stored alpha of every root when not NULL. */
+int rdamd_model_compute_all_root_lh_directional(rdamd_model_t *m, const double *ratios, double *out);
+/* generate_directional_operations of the tree (csrc/tree.hpp): ops holds
+ * 3(n-2) + (2n-3) entries, the matrix arrays (2n-3) + 2(2n-3); sizes[3] =
+ * {clv_buffers, scale_buffers, prob_matrices} the partition needs */
+int rdamd_tree_generate_directional_operations(const rdamd_tree_t *t, const double *ratios,
+                                               rdamd_operation_t *ops, unsigned int *n_ops,
+                                               unsigned int *matrix_indices,
+                                               double *branch_lengths, unsigned int *n_matrices,
+                                               unsigned int *root_clv, int *root_scaler,
+                                               unsigned int sizes[3]);
 /* heuristic search(min_roots, root_ratio, atol, pgtol, brtol, factor), :1008-1137
  * (needs rdamd_model_set_lbfgsb); best placement and its lnL are returned. */
 int rdamd_model_search(rdamd_model_t *m, unsigned int min_roots, double root_ratio, double atol,

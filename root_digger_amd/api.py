@@ -207,6 +207,10 @@ _sig("rdamd_model_assign_by_rank_search", C.c_int, _vp, _u, C.c_double, _u, _u, 
 _sig("rdamd_model_assigned", C.c_int, _vp, _pu64, _u)
 _sig("rdamd_model_set_checkpoint", C.c_int, _vp, _vp)
 _sig("rdamd_model_assign_by_rank_checkpoint", C.c_int, _vp, _u, _u, _vp)
+_sig("rdamd_model_compute_all_root_lh_directional", C.c_int, _vp, _pd, _pd)
+_sig("rdamd_compute_root_loglikelihoods", C.c_int, _vp, _u, _pu, C.POINTER(C.c_int), _pu, _pd)
+_sig("rdamd_tree_generate_directional_operations", C.c_int, _vp, _pd, _pop, _pu, _pu, _pd, _pu, _pu,
+     C.POINTER(C.c_int), _pu)
 _sig("rdamd_model_counters", None, C.c_void_p, C.POINTER(C.c_uint64))
 _sig("rdamd_model_assign_by_rank", C.c_int, _vp, _u, _u)
 _sig("rdamd_model_exhaustive_search_parallel", C.c_int, _vp, _u, C.c_double, C.c_double,
@@ -328,6 +332,34 @@ class Tree:
         if ok != 1:
             _fail("root_location")
         return rl
+
+    def generate_directional_operations(self, ratios=None):
+        """All-directions schedule (csrc/tree.hpp): dict with ops, matrix_indices,
+        branch_lengths, root_clv, root_scaler and the partition sizes it needs."""
+        n, roots = self.tip_count(), self.root_count()
+        cap_ops, cap_mat = 3 * n + roots + 8, 3 * roots + 8
+        ops = (Operation * cap_ops)()
+        pmi = np.zeros(cap_mat, dtype=np.uint32)
+        brl = np.zeros(cap_mat, dtype=np.float64)
+        rclv = np.zeros(roots, dtype=np.uint32)
+        rsc = np.zeros(roots, dtype=np.int32)
+        sizes = np.zeros(3, dtype=np.uint32)
+        nops, nmat = C.c_uint(0), C.c_uint(0)
+        r = None
+        if ratios is not None:
+            r = np.ascontiguousarray(ratios, dtype=np.float64)
+        if lib.rdamd_tree_generate_directional_operations(
+                self._h, _dptr(r) if r is not None else None, ops, C.byref(nops), _uptr(pmi),
+                _dptr(brl), C.byref(nmat), _uptr(rclv), rsc.ctypes.data_as(C.POINTER(C.c_int)),
+                _uptr(sizes)) != 1:
+            _fail("generate_directional_operations")
+        out = (Operation * nops.value)()
+        for i in range(nops.value):
+            out[i] = ops[i]
+        return {"ops": out, "matrix_indices": pmi[:nmat.value].copy(),
+                "branch_lengths": brl[:nmat.value].copy(), "root_clv": rclv, "root_scaler": rsc,
+                "clv_buffers": int(sizes[0]), "scale_buffers": int(sizes[1]),
+                "prob_matrices": int(sizes[2])}
 
     def _ranked(self, fn):
         ids = np.zeros(self.root_count(), dtype=np.uint32)
@@ -555,6 +587,19 @@ class Partition:
         if _errno():
             _fail("compute_root_loglikelihood")
         return (v, ps) if persite else v
+
+    def compute_root_loglikelihoods(self, clv_indices, scaler_indices, freqs_indices=None):
+        """corax_compute_root_loglikelihood for many root CLVs in one launch."""
+        ci = np.ascontiguousarray(clv_indices, dtype=np.uint32)
+        si = np.ascontiguousarray(scaler_indices, dtype=np.int32)
+        fi = (np.zeros(self.rate_cats, dtype=np.uint32) if freqs_indices is None
+              else np.ascontiguousarray(freqs_indices, dtype=np.uint32))
+        out = np.zeros(ci.size, dtype=np.float64)
+        if lib.rdamd_compute_root_loglikelihoods(self._h, ci.size, _uptr(ci),
+                                                 si.ctypes.data_as(C.POINTER(C.c_int)), _uptr(fi),
+                                                 _dptr(out)) != 1:
+            _fail("compute_root_loglikelihoods")
+        return out
 
     def root_loglikelihood_fused(self, root_op, lengths1, lengths2, params_indices=None):
         l1 = np.ascontiguousarray(lengths1, dtype=np.float64)
@@ -1003,6 +1048,15 @@ class Model:
                                                  C.byref(ne)), "optimize_params")
         return {"subst": subst, "freqs": freqs, "gamma_alpha": ga.value,
                 "batches": nb.value, "evaluations": ne.value}
+
+    def compute_all_root_lh_directional(self, ratios=None):
+        """every root's lnL at the current parameters through the all-directions
+        CLV cache (rdamd_model_compute_all_root_lh_directional)."""
+        out = np.zeros(self._tree.root_count(), dtype=np.float64)
+        r = None if ratios is None else np.ascontiguousarray(ratios, dtype=np.float64)
+        self._ok(lib.rdamd_model_compute_all_root_lh_directional(
+            self._h, _dptr(r) if r is not None else None, _dptr(out)), "compute_all_root_lh_directional")
+        return out
 
     def counters(self):
         """work counters since creation (rdamd_model_counters)."""

@@ -168,6 +168,11 @@ hipError_t launch_clv_k20_traversal(rdamd_partition *p, const LevelOp *d_ops, un
 hipError_t launch_root_lnl(rdamd_partition *p, unsigned clv_index, int scaler_index,
                            const unsigned *d_freqs_indices, double *d_persite,
                            double *d_out);
+// many root CLVs of one partition in one launch (bit-identical to launch_root_lnl each)
+unsigned root_lnl_blocks(const rdamd_partition *p);
+hipError_t launch_root_lnl_batch(rdamd_partition *p, unsigned count, const unsigned *d_clv_rel,
+                                 const int *d_scaler_idx, const unsigned *d_fidx,
+                                 double *d_partials, double *d_out);
 // one root operation + reduction for n_alpha (<= kExtraMatrices/2) positions;
 // d_mats = [n_alpha][2] matrix slots; the last position's root CLV is stored
 hipError_t launch_root_fused(rdamd_partition *p, const LevelOp &op, const unsigned *d_mats,

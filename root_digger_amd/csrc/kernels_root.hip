@@ -101,6 +101,79 @@ root_lnl_site_kernel(const double *__restrict__ clv, const unsigned *__restrict_
   if (threadIdx.x == 0) partials[blockIdx.x] = b;
 }
 
+// The same reduction for MANY root CLVs of one partition in one launch
+// (blockIdx.y = which): the grid shape in x, the per-lane order and the block
+// tree are those of the single-root kernels, so every value is bit-identical
+// to a separate rdamd_compute_root_loglikelihood call.
+template <int R>
+__global__ void __launch_bounds__(256)
+root_lnl_group_batch_kernel(const double *__restrict__ clv_base, const unsigned *__restrict__ scaler_base,
+                            const unsigned *__restrict__ clv_rel, const int *__restrict__ scaler_idx,
+                            const double *__restrict__ freqs, const unsigned *__restrict__ fidx,
+                            const double *__restrict__ rate_w, const unsigned *__restrict__ pw,
+                            unsigned S, unsigned K, double *__restrict__ partials) {
+  __shared__ double lds[4];
+  const unsigned which = blockIdx.y;
+  const double *clv = clv_base + (size_t)clv_rel[which] * S * R * K;
+  const int sci = scaler_idx[which];
+  const unsigned *scaler = sci >= 0 ? scaler_base + (size_t)sci * S : nullptr;
+  const size_t total = (size_t)S * R;
+  const size_t stride = (size_t)gridDim.x * 256;
+  double acc = 0.0;
+  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += stride) {
+    const unsigned s = (unsigned)(idx / R), r = (unsigned)(idx % R);
+    const double *c = clv + idx * K;
+    const double *f = freqs + (size_t)fidx[r] * K;
+    double tr = dot_freq(c, f, K) * rate_w[r];
+    double term = 0.0;
+    const int base = (int)(threadIdx.x & 63) & ~(R - 1);
+#pragma unroll
+    for (int q = 0; q < R; ++q) term += __shfl(tr, base + q);
+    if (r == 0) {
+      double l = log(term);
+      if (scaler) {
+        unsigned sc = scaler[s];
+        if (sc) l += (double)sc * kLogScaleThreshold;
+      }
+      l *= (double)pw[s];
+      acc += l;
+    }
+  }
+  double b = block_sum_256(acc, lds);
+  if (threadIdx.x == 0) partials[(size_t)which * gridDim.x + blockIdx.x] = b;
+}
+
+__global__ void __launch_bounds__(256)
+root_lnl_site_batch_kernel(const double *__restrict__ clv_base, const unsigned *__restrict__ scaler_base,
+                           const unsigned *__restrict__ clv_rel, const int *__restrict__ scaler_idx,
+                           const double *__restrict__ freqs, const unsigned *__restrict__ fidx,
+                           const double *__restrict__ rate_w, const unsigned *__restrict__ pw,
+                           unsigned S, unsigned R, unsigned K, double *__restrict__ partials) {
+  __shared__ double lds[4];
+  const unsigned which = blockIdx.y;
+  const double *clv = clv_base + (size_t)clv_rel[which] * S * R * K;
+  const int sci = scaler_idx[which];
+  const unsigned *scaler = sci >= 0 ? scaler_base + (size_t)sci * S : nullptr;
+  double acc = 0.0;
+  for (unsigned s = blockIdx.x * 256 + threadIdx.x; s < S; s += gridDim.x * 256) {
+    const double *c = clv + (size_t)s * R * K;
+    double term = 0.0;
+    for (unsigned r = 0; r < R; ++r) {
+      const double *f = freqs + (size_t)fidx[r] * K;
+      term += dot_freq(c + (size_t)r * K, f, K) * rate_w[r];
+    }
+    double l = log(term);
+    if (scaler) {
+      unsigned sc = scaler[s];
+      if (sc) l += (double)sc * kLogScaleThreshold;
+    }
+    l *= (double)pw[s];
+    acc += l;
+  }
+  double b = block_sum_256(acc, lds);
+  if (threadIdx.x == 0) partials[(size_t)which * gridDim.x + blockIdx.x] = b;
+}
+
 // fixed-order finish: 256 lanes stride over the partials, then the block tree
 __global__ void __launch_bounds__(256)
 finish_sum_kernel(const double *__restrict__ partials, unsigned n, double *__restrict__ out) {
@@ -259,6 +332,38 @@ hipError_t launch_root_lnl(rdamd_partition *p, unsigned clv_index, int scaler_in
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   finish_sum_kernel<<<1, 256, 0, p->stream>>>(p->d_partials, blocks, d_out);
+  return hipGetLastError();
+}
+
+unsigned root_lnl_blocks(const rdamd_partition *p) {
+  const unsigned S = p->sites, R = p->rate_cats;
+  const bool group = (R == 1 || R == 2 || R == 4 || R == 8 || R == 16);
+  unsigned blocks = group ? (unsigned)(((size_t)S * R + 255) / 256) : (S + 255) / 256;
+  if (blocks > kRootBlocks) blocks = kRootBlocks;
+  return blocks ? blocks : 1;
+}
+
+// d_clv_rel: CLV indices minus `tips`; d_partials: count * root_lnl_blocks(p) doubles
+hipError_t launch_root_lnl_batch(rdamd_partition *p, unsigned count, const unsigned *d_clv_rel,
+                                 const int *d_scaler_idx, const unsigned *d_fidx,
+                                 double *d_partials, double *d_out) {
+  if (!count) return hipSuccess;
+  const unsigned S = p->sites, R = p->rate_cats, K = p->states;
+  const unsigned blocks = root_lnl_blocks(p);
+  const dim3 grid(blocks, count);
+#define RDAMD_RB_ARGS p->d_clv, p->d_scaler, d_clv_rel, d_scaler_idx, p->d_freqs, d_fidx, p->d_rate_weights, p->d_pattern_weights
+  switch (R) {
+    case 1: root_lnl_group_batch_kernel<1><<<grid, 256, 0, p->stream>>>(RDAMD_RB_ARGS, S, K, d_partials); break;
+    case 2: root_lnl_group_batch_kernel<2><<<grid, 256, 0, p->stream>>>(RDAMD_RB_ARGS, S, K, d_partials); break;
+    case 4: root_lnl_group_batch_kernel<4><<<grid, 256, 0, p->stream>>>(RDAMD_RB_ARGS, S, K, d_partials); break;
+    case 8: root_lnl_group_batch_kernel<8><<<grid, 256, 0, p->stream>>>(RDAMD_RB_ARGS, S, K, d_partials); break;
+    case 16: root_lnl_group_batch_kernel<16><<<grid, 256, 0, p->stream>>>(RDAMD_RB_ARGS, S, K, d_partials); break;
+    default: root_lnl_site_batch_kernel<<<grid, 256, 0, p->stream>>>(RDAMD_RB_ARGS, S, R, K, d_partials); break;
+  }
+#undef RDAMD_RB_ARGS
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  finish_sum_kernel<<<count, 256, 0, p->stream>>>(d_partials, blocks, d_out);
   return hipGetLastError();
 }
 

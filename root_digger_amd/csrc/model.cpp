@@ -77,6 +77,7 @@ model_t::model_t(rooted_tree_t tree, const std::vector<msa_t> &msas,
 model_t::~model_t() {
   for (auto p : _partitions)
     if (p) rdamd_partition_destroy(p);
+  if (_sweep) rdamd_partition_destroy(_sweep);
 }
 
 // ---- setters ----------------------------------------------------------------
@@ -204,6 +205,7 @@ partition_parameters_t model_t::make_partition_parameters(size_t states, rate_ca
 }
 
 void model_t::initialize_partitions(const std::vector<msa_t> &msa) {
+  _sweep_msa = msa;   // the all-directions cache loads the same tips when it is first used
   for (size_t p = 0; p < _partitions.size(); ++p) {
     set_tip_states(p, msa[p]);
     update_invariant_sites(p);
@@ -214,6 +216,7 @@ void model_t::initialize_partitions(const std::vector<msa_t> &msa) {
 }
 
 void model_t::initialize_partitions_uniform_freqs(const std::vector<msa_t> &msa) {
+  _sweep_msa = msa;
   for (size_t p = 0; p < _partitions.size(); ++p) {
     set_tip_states(p, msa[p]);
     update_invariant_sites(p);
@@ -368,6 +371,45 @@ std::vector<double> model_t::compute_all_root_lh_batched() {
     for (size_t j = 0; j < n; ++j) total[j] += out[j];
   }
   return total;
+}
+
+// SURVEY.md 8f item 2.  The cache partition mirrors partition 0's data and
+// model; directed CLVs are recomputed on every call (they depend on the
+// parameters), which is still 3(n-2) operations instead of (2n-3)(n-1).
+std::vector<double> model_t::compute_all_root_lh_directional(const std::vector<double> *ratios) {
+  if (_partitions.size() != 1 || _sweep_msa.size() != 1)
+    throw std::runtime_error("compute_all_root_lh_directional: one initialised partition is required");
+  rdamd_partition_t *src = _partitions[0];
+  const auto d = _tree.generate_directional_operations(ratios);
+  const unsigned R = rdamd_partition_rate_cats(src), K = rdamd_partition_states(src);
+  if (!_sweep) {
+    const msa_t &msa = _sweep_msa[0];
+    _sweep = rdamd_partition_create(_tree.tip_count(), d.clv_buffers, K, (unsigned)msa.length(), 1,
+                                    d.prob_matrices, R, d.scale_buffers, RDAMD_ATTRIB_NONREV);
+    if (!_sweep) fail("partition_create (all-directions cache)");
+    auto labels = _tree.label_map();
+    for (int i = 0; i < msa.count(); ++i)
+      if (rdamd_set_tip_states(_sweep, labels.at(msa.labels[i]), msa.map, msa.sequences[i].c_str()) !=
+          RDAMD_SUCCESS)
+        fail("set_tip_states (all-directions cache)");
+    if (!msa.weights.empty()) rdamd_set_pattern_weights(_sweep, msa.weights.data());
+  }
+  rdamd_set_subst_params(_sweep, 0, rdamd_partition_subst_params(src, 0));
+  rdamd_set_frequencies(_sweep, 0, rdamd_partition_frequencies(src, 0));
+  rdamd_set_category_rates(_sweep, _rate_rates[0].data());
+  rdamd_set_category_weights(_sweep, _rate_weights[0].data());
+  if (rdamd_update_prob_matrices(_sweep, _param_indicies[0].data(), d.matrix_indices.data(),
+                                 d.branch_lengths.data(), (unsigned)d.matrix_indices.size()) !=
+      RDAMD_SUCCESS)
+    fail("update_prob_matrices (all-directions cache)");
+  rdamd_update_clvs(_sweep, d.ops.data(), (unsigned)d.ops.size());
+  if (rdamd_errno()) fail("update_clvs (all-directions cache)");
+  std::vector<double> out(d.root_clv.size());
+  if (rdamd_compute_root_loglikelihoods(_sweep, (unsigned)out.size(), d.root_clv.data(),
+                                        d.root_scaler.data(), _param_indicies[0].data(),
+                                        out.data()) != RDAMD_SUCCESS)
+    fail("compute_root_loglikelihoods");
+  return out;
 }
 
 std::vector<double> model_t::compute_lh_batch(
@@ -527,7 +569,12 @@ std::vector<root_location_t> model_t::suggest_roots_lh(size_t min, double ratio)
   std::vector<std::pair<root_location_t, double>> v;
   bool all_dna = true;
   for (auto p : _partitions) all_dna = all_dna && rdamd_partition_states(p) == 4;
-  if (all_dna) {   // every root in one fused launch; the partition state is not disturbed
+  if (_partitions.size() == 1 && _sweep_msa.size() == 1) {
+    // all-directions CLV cache: the values of the move_root sweep, bit for bit,
+    // for 3(n-2) + (2n-3) operations; the model's own partition is not disturbed
+    auto lh = compute_all_root_lh_directional();
+    for (size_t i = 0; i < lh.size(); ++i) v.emplace_back(_tree.roots()[i], lh[i]);
+  } else if (all_dna) {   // every root in one fused launch
     auto lh = compute_all_root_lh_batched();
     for (size_t i = 0; i < lh.size(); ++i) v.emplace_back(_tree.roots()[i], lh[i]);
   } else {

@@ -100,6 +100,11 @@ public:
   // job; 4-state data): what the all-directions CLV cache of SURVEY 8f item 2
   // was meant to buy, without storing any CLV.  Partition state is untouched.
   std::vector<double> compute_all_root_lh_batched();
+  // the same sweep through an all-directions CLV cache: a second partition holds
+  // the 3(n-2) directed CLVs (rooted_tree_t::generate_directional_operations),
+  // so every root costs one root operation.  ratios: alpha per root (nullptr =
+  // the stored ones).  One 4-state / binary partition.
+  std::vector<double> compute_all_root_lh_directional(const std::vector<double> *ratios = nullptr);
 
   // batched objective: lnL of (root, parameter set) pairs, all partitions,
   // through rdamd_evaluate_batch (one fused launch per partition)
@@ -214,6 +219,8 @@ private:
   std::vector<std::vector<unsigned int>> _param_indicies;
   std::vector<size_t>                    _assigned_idx;
   std::minstd_rand                       _random_engine;
+  rdamd_partition_t                     *_sweep = nullptr;   // all-directions cache (lazily built)
+  std::vector<msa_t>                     _sweep_msa;          // what it needs to load its tips
   checkpoint_t                          *_checkpoint = nullptr;
   batch_combiner_t                      *_combiner = nullptr;
   bool                                   _invariant_sites, _early_stop;   // +I is inert (:292-300)

@@ -308,6 +308,15 @@ int rdamd_model_compute_all_root_lh_batched(rdamd_model_t *m, double *out) {
     return RDAMD_SUCCESS;
   })
 }
+int rdamd_model_compute_all_root_lh_directional(rdamd_model_t *m, const double *ratios, double *out) {
+  GUARD(RDAMD_FAILURE, {
+    std::vector<double> r;
+    if (ratios) r.assign(ratios, ratios + m->model->tree().root_count());
+    const auto v = m->model->compute_all_root_lh_directional(ratios ? &r : nullptr);
+    std::copy(v.begin(), v.end(), out);
+    return RDAMD_SUCCESS;
+  })
+}
 int rdamd_model_search(rdamd_model_t *m, unsigned int min_roots, double root_ratio, double atol,
                        double pgtol, double brtol, double factor,
                        rdamd_root_location_t *best_rl, double *best_llh) {

@@ -611,6 +611,53 @@ double rdamd_compute_root_loglikelihood(rdamd_partition_t *p, unsigned int clv_i
   return p->h_result[0];
 }
 
+int rdamd_compute_root_loglikelihoods(rdamd_partition_t *p, unsigned int count,
+                                      const unsigned int *clv_indices, const int *scaler_indices,
+                                      const unsigned int *freqs_indices, double *lnl_out) {
+  clear_error();
+  if (count == 0) return RDAMD_SUCCESS;
+  std::vector<unsigned> rel(count);
+  for (unsigned i = 0; i < count; ++i) {
+    if (clv_indices[i] < p->tips || clv_indices[i] >= p->tips + p->clv_buffers ||
+        scaler_indices[i] >= (int)p->scale_buffers) {
+      set_error(11, "rdamd_compute_root_loglikelihoods: index out of range (entry %u)", i);
+      return RDAMD_FAILURE;
+    }
+    rel[i] = clv_indices[i] - p->tips;
+  }
+  for (unsigned r = 0; r < p->rate_cats; ++r)
+    if (freqs_indices[r] >= p->rate_matrices) {
+      set_error(7, "rdamd_compute_root_loglikelihoods: freqs index out of range");
+      return RDAMD_FAILURE;
+    }
+  if (p->sites == 0) {
+    std::fill(lnl_out, lnl_out + count, 0.0);
+    return RDAMD_SUCCESS;
+  }
+  RDAMD_HIP_TRY(flush_q(p), RDAMD_FAILURE);
+  const unsigned blocks = root_lnl_blocks(p);
+  const size_t need = 4096 + sizeof(unsigned) * p->rate_cats + (size_t)count * (8 + 8) +
+                      sizeof(double) * ((size_t)count * blocks + count);
+  RDAMD_HIP_TRY(ensure_scratch(p, need), RDAMD_FAILURE);
+  Scratch sc{p};
+  unsigned *d_fi = (unsigned *)sc.take(sizeof(unsigned) * p->rate_cats);
+  unsigned *d_rel = (unsigned *)sc.take(sizeof(unsigned) * count);
+  int *d_sci = (int *)sc.take(sizeof(int) * count);
+  double *d_partials = (double *)sc.take(sizeof(double) * (size_t)count * blocks);
+  double *d_out = (double *)sc.take(sizeof(double) * count);
+  RDAMD_HIP_TRY(upload(p, d_fi, freqs_indices, sizeof(unsigned) * p->rate_cats), RDAMD_FAILURE);
+  RDAMD_HIP_TRY(upload(p, d_rel, rel.data(), sizeof(unsigned) * count), RDAMD_FAILURE);
+  RDAMD_HIP_TRY(upload(p, d_sci, scaler_indices, sizeof(int) * count), RDAMD_FAILURE);
+  p->prof_begin(2);
+  hipError_t le = launch_root_lnl_batch(p, count, d_rel, d_sci, d_fi, d_partials, d_out);
+  p->prof_end();
+  RDAMD_HIP_TRY(le, RDAMD_FAILURE);
+  RDAMD_HIP_TRY(hipStreamSynchronize(p->stream), RDAMD_FAILURE);
+  RDAMD_HIP_TRY(hipMemcpy(lnl_out, d_out, sizeof(double) * count, hipMemcpyDeviceToHost),
+                RDAMD_FAILURE);
+  return RDAMD_SUCCESS;
+}
+
 int rdamd_root_loglikelihood_fused(rdamd_partition_t *p, const rdamd_operation_t *root_op,
                                    const unsigned int *params_indices,
                                    const double *lengths1, const double *lengths2,

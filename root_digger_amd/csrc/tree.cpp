@@ -640,4 +640,86 @@ std::vector<root_location_t> rooted_tree_t::rank_modified_mad() const {
   return rank_branches(pair_score, fold);
 }
 
+
+// ---- all-directions schedule ---------------------------------------------------------
+rooted_tree_t::directional_schedule_t
+rooted_tree_t::generate_directional_operations(const std::vector<double> *ratios) const {
+  if (rooted()) {
+    rooted_tree_t bare(*this);
+    bare.unroot();
+    return bare.generate_directional_operations(ratios);
+  }
+  if (ratios && ratios->size() != _roots.size())
+    throw std::invalid_argument("generate_directional_operations: one ratio per root location");
+  directional_schedule_t out;
+  const unsigned n = _tip_count, n_roots = (unsigned)_roots.size();
+  const size_t H = _next.size();
+  // number the directed inner half-edges and the undirected branches
+  std::vector<int> dir_id(H, -1), branch_id(H, -1);
+  unsigned n_dir = 0, n_branch = 0;
+  for (size_t h = 0; h < H; ++h) {
+    if ((int)h == _root_left || (int)h == _root_right || _back[h] < 0) continue;   // spare root slots
+    if (_next[h] >= 0) dir_id[h] = (int)n_dir++;
+    if (branch_id[h] < 0) branch_id[h] = branch_id[_back[h]] = (int)n_branch++;
+  }
+  auto clv_of = [&](int h) { return _next[h] < 0 ? _clv[h] : n + (unsigned)dir_id[h]; };
+  auto scaler_of = [&](int h) { return _next[h] < 0 ? -1 : dir_id[h]; };
+  out.matrix_indices.resize(n_branch);
+  out.branch_lengths.resize(n_branch);
+  for (size_t h = 0; h < H; ++h)
+    if (branch_id[h] >= 0) {
+      out.matrix_indices[branch_id[h]] = (unsigned)branch_id[h];
+      out.branch_lengths[branch_id[h]] = _length[h];
+    }
+  // D(h) needs D(back(k)) of the two other ring members k: depth-first, each once
+  std::vector<char> done(H, 0);
+  std::vector<std::pair<int, int>> stack;   // (half-edge, next ring member to look at: 0, 1, 2 = emit)
+  for (size_t h0 = 0; h0 < H; ++h0) {
+    if (dir_id[h0] < 0 || done[h0]) continue;
+    stack.emplace_back((int)h0, 0);
+    while (!stack.empty()) {
+      auto &[h, stage] = stack.back();
+      const int k1 = _next[h], k2 = _next[k1];
+      if (stage < 2) {
+        const int child = _back[stage == 0 ? k1 : k2];
+        ++stage;
+        if (_next[child] >= 0 && !done[child]) stack.emplace_back(child, 0);
+        continue;
+      }
+      rdamd_operation_t op;
+      op.parent_clv_index = clv_of(h); op.parent_scaler_index = scaler_of(h);
+      op.child1_clv_index = clv_of(_back[k1]); op.child1_matrix_index = (unsigned)branch_id[k1];
+      op.child1_scaler_index = scaler_of(_back[k1]);
+      op.child2_clv_index = clv_of(_back[k2]); op.child2_matrix_index = (unsigned)branch_id[k2];
+      op.child2_scaler_index = scaler_of(_back[k2]);
+      if (!done[h]) out.ops.push_back(op);
+      done[h] = 1;
+      stack.pop_back();
+    }
+  }
+  // one root operation per branch: the two directed CLVs that face each other
+  // across it, through the two halves of the branch (root_by's child order)
+  out.root_clv.resize(n_roots);
+  out.root_scaler.resize(n_roots);
+  for (unsigned rid = 0; rid < n_roots; ++rid) {
+    root_location_t rl = _roots[rid];
+    if (ratios) rl.brlen_ratio = (*ratios)[rid];
+    const int a = rl.edge, b = _back[rl.edge];
+    const unsigned m = n_branch + 2 * rid;
+    out.matrix_indices.push_back(m);     out.branch_lengths.push_back(rl.brlen());
+    out.matrix_indices.push_back(m + 1); out.branch_lengths.push_back(rl.brlen_compliment());
+    rdamd_operation_t op;
+    op.parent_clv_index = n + n_dir + rid; op.parent_scaler_index = (int)(n_dir + rid);
+    op.child1_clv_index = clv_of(a); op.child1_matrix_index = m;     op.child1_scaler_index = scaler_of(a);
+    op.child2_clv_index = clv_of(b); op.child2_matrix_index = m + 1; op.child2_scaler_index = scaler_of(b);
+    out.ops.push_back(op);
+    out.root_clv[rid] = op.parent_clv_index;
+    out.root_scaler[rid] = op.parent_scaler_index;
+  }
+  out.clv_buffers = n_dir + n_roots;
+  out.scale_buffers = n_dir + n_roots;
+  out.prob_matrices = n_branch + 2 * n_roots;
+  return out;
+}
+
 }  // namespace rdamd

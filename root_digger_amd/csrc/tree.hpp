@@ -94,6 +94,27 @@ public:
   }
   void clear_newick_annotations() { _annotations.clear(); }
 
+  // All-directions schedule for sweeps at FIXED parameters (SURVEY.md 8f item 2,
+  // the GPU analogue of move_root / compute_all_root_lh, src/model.cpp:823-889):
+  // one conditional likelihood vector per DIRECTED inner half-edge -- the subtree
+  // behind the node, looking away from the branch -- does not depend on where the
+  // root is, so 3(n-2) operations + one root operation per branch give every
+  // root's likelihood.  Indices refer to a partition of its own:
+  //   clv   tips .. tips+3(n-2)-1     directed inner half-edges
+  //         then one per root id      the root CLVs
+  //   scaler the same numbering minus `tips`
+  //   pmatrix 0 .. 2n-4 the branches; 2n-3+2*rid, +1 the two halves of root rid
+  struct directional_schedule_t {
+    std::vector<rdamd_operation_t> ops;          // directed ops in dependency order, then root ops by id
+    std::vector<unsigned int>      matrix_indices;
+    std::vector<double>            branch_lengths;
+    std::vector<unsigned int>      root_clv;     // per root id
+    std::vector<int>               root_scaler;
+    unsigned int clv_buffers = 0, scale_buffers = 0, prob_matrices = 0;
+  };
+  // the roots' alpha values are the ones stored in roots() unless `ratios` gives others
+  directional_schedule_t generate_directional_operations(const std::vector<double> *ratios = nullptr) const;
+
   // Root placements ranked by how well they balance the tree, best first
   // (src/tree.cpp:863-945): the starting points of the heuristic search.
   // midpoint: score of a branch = max over (tip left, tip right) pairs of

@@ -6,6 +6,8 @@
 #include "tree.hpp"
 #include "tree_c_api.hpp"
 
+#include <algorithm>
+
 struct rdamd_tree {
   rdamd::rooted_tree_t tree;
   mutable std::string  scratch;
@@ -78,6 +80,27 @@ int rdamd_tree_root_scaler_index(const rdamd_tree_t *t) { return t->tree.root_sc
 int rdamd_tree_root_location(const rdamd_tree_t *t, unsigned int index,
                              rdamd_root_location_t *out) {
   GUARD({ to_c(t->tree.root_location((size_t)index), out); return RDAMD_SUCCESS; })
+}
+int rdamd_tree_generate_directional_operations(const rdamd_tree_t *t, const double *ratios,
+                                               rdamd_operation_t *ops, unsigned int *n_ops,
+                                               unsigned int *matrix_indices,
+                                               double *branch_lengths, unsigned int *n_matrices,
+                                               unsigned int *root_clv, int *root_scaler,
+                                               unsigned int sizes[3]) {
+  GUARD({
+    std::vector<double> r;
+    if (ratios) r.assign(ratios, ratios + t->tree.root_count());
+    const auto d = t->tree.generate_directional_operations(ratios ? &r : nullptr);
+    std::copy(d.ops.begin(), d.ops.end(), ops);
+    *n_ops = (unsigned)d.ops.size();
+    std::copy(d.matrix_indices.begin(), d.matrix_indices.end(), matrix_indices);
+    std::copy(d.branch_lengths.begin(), d.branch_lengths.end(), branch_lengths);
+    *n_matrices = (unsigned)d.matrix_indices.size();
+    std::copy(d.root_clv.begin(), d.root_clv.end(), root_clv);
+    std::copy(d.root_scaler.begin(), d.root_scaler.end(), root_scaler);
+    sizes[0] = d.clv_buffers; sizes[1] = d.scale_buffers; sizes[2] = d.prob_matrices;
+    return RDAMD_SUCCESS;
+  })
 }
 // rank_midpoints / rank_modified_mad: root ids, best first (root_count of them)
 int rdamd_tree_rank_midpoints(const rdamd_tree_t *t, unsigned int *root_ids) {

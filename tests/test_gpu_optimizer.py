@@ -187,6 +187,41 @@ def test_batched_root_sweep_equals_move_root_sweep():
     # the batch leaves model state alone: the sweep state (last root) is still valid
     last = tree.root_location(198)
     assert util.rel_err(m.compute_lh_root(last), b[198]) < 1e-13
+    # the all-directions CLV cache: 3(n-2) directed operations +
+    # one root operation per branch on a partition of its own; same numbers
+    c = m.compute_all_root_lh_directional()
+    assert np.max(np.abs(c - b) / np.abs(b)) < 1e-12
+    assert util.rel_err(m.compute_lh_root(last), b[198]) < 1e-13      # the model's own state is untouched
+    # other root positions on every branch, and new parameters: the cache follows
+    ratios = np.linspace(0.05, 0.95, 199)
+    m.set_gamma_alpha(1.7)
+    d = m.compute_all_root_lh_directional(ratios)
+    want = np.array([m.compute_lh(tree.root_location(i).with_ratio(float(ratios[i]))) for i in (0, 57, 198)])
+    assert np.max(np.abs(d[[0, 57, 198]] - want) / np.abs(want)) < 1e-12
+
+
+def test_batched_root_reduction_is_bit_identical_to_single_calls():
+    """rdamd_compute_root_loglikelihoods: one launch for many root CLVs, each
+    value exactly what rdamd_compute_root_loglikelihood returns for that CLV."""
+    from root_digger_amd import synth
+    for R, S in ((4, 5000), (3, 777), (1, 64)):
+        w = synth.workload(20, S, 4, R, 31 + R)
+        tree = rd.Tree.from_newick(w["newick"])
+        d = tree.generate_directional_operations()
+        p = rd.Partition(tips=20, clv_buffers=d["clv_buffers"], states=4, sites=S, rate_matrices=1,
+                         prob_matrices=d["prob_matrices"], rate_cats=R,
+                         scale_buffers=d["scale_buffers"])
+        util.load_tips(p, tree, w["seqs"], rd.MAP_NT)
+        p.set_subst_params(0, w["subst"])
+        p.set_frequencies(0, p.empirical_frequencies())
+        p.set_category_rates(w["rates"])
+        p.update_prob_matrices(d["matrix_indices"], d["branch_lengths"])
+        p.update_clvs(d["ops"])
+        many = p.compute_root_loglikelihoods(d["root_clv"], d["root_scaler"])
+        for rid in range(tree.root_count()):
+            one = p.compute_root_loglikelihood(int(d["root_clv"][rid]), int(d["root_scaler"][rid]))
+            assert many[rid] == one
+        p.destroy()
 
 
 def test_heuristic_search(lbfgsb):

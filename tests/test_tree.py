@@ -292,3 +292,33 @@ def _to_branch_end(dist, x, near, far, brlen):
     # d(x, end) = (d(x, y) + d(x, x2) - d(x2, y)) / 2 is the distance to the point
     # where the paths part; with two near tips that point is the near end itself
     return (dist[(x, y)] + dist[(x, x2)] - dist[(x2, y)]) / 2
+
+
+@pytest.mark.parametrize("key", list(DATASETS))
+def test_directional_schedule_shape_and_order(key):
+    """generate_directional_operations: 3(n-2) directed operations in dependency
+    order, then one root operation per branch; index ranges as documented."""
+    t = tree_of(key)
+    n, roots = t.tip_count(), t.root_count()
+    d = t.generate_directional_operations()
+    ops = list(d["ops"])
+    assert len(ops) == 3 * (n - 2) + roots
+    assert d["clv_buffers"] == 3 * (n - 2) + roots and d["prob_matrices"] == 3 * roots
+    assert len(d["matrix_indices"]) == 3 * roots and sorted(d["matrix_indices"]) == list(range(3 * roots))
+    ready = set(range(n))
+    for op in ops[:3 * (n - 2)]:
+        assert op.child1_clv_index in ready and op.child2_clv_index in ready   # dependencies first
+        assert op.parent_clv_index not in ready and n <= op.parent_clv_index < n + 3 * (n - 2)
+        assert op.parent_scaler_index == op.parent_clv_index - n
+        ready.add(op.parent_clv_index)
+    for rid, op in enumerate(ops[3 * (n - 2):]):
+        assert op.parent_clv_index == d["root_clv"][rid] == n + 3 * (n - 2) + rid
+        assert op.child1_clv_index in ready and op.child2_clv_index in ready
+        assert (op.child1_matrix_index, op.child2_matrix_index) == (roots + 2 * rid, roots + 2 * rid + 1)
+        rl = t.root_location(rid)
+        i = list(d["matrix_indices"]).index(roots + 2 * rid)
+        assert abs(d["branch_lengths"][i] - rl.brlen()) < 1e-15
+        assert abs(d["branch_lengths"][i + 1] - rl.brlen_compliment()) < 1e-15
+    # explicit ratios override the stored ones
+    quarter = t.generate_directional_operations([0.25] * roots)["branch_lengths"]
+    assert quarter[roots] == t.root_location(0).saved_brlen * 0.25
