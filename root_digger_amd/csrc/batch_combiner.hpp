@@ -74,7 +74,12 @@ public:
         batch.swap(_pending);
         _launching = true;
         lk.unlock();
-        std::string err = launch(batch);
+        std::string err;
+        try {
+          err = launch(batch);
+        } catch (const std::exception &e) {   // nobody may be left waiting on this batch
+          err = std::string("combined evaluate_batch failed: ") + e.what();
+        }
         lk.lock();
         _launching = false;
         for (request_t *r : batch) {
