@@ -21,12 +21,6 @@ namespace {
 }
 }  // namespace
 
-unsigned int msa_t::total_weight() const {
-  if (weights.empty()) return (unsigned int)length();
-  unsigned int t = 0;
-  for (auto w : weights) t += w;
-  return t;
-}
 
 model_params_t random_params(size_t size, uint64_t seed) {
   model_params_t mp(size);

@@ -180,4 +180,11 @@ void msa_t::valid_data() const {
     }
 }
 
+unsigned int msa_t::total_weight() const {
+  if (weights.empty()) return (unsigned int)length();
+  unsigned int t = 0;
+  for (auto w : weights) t += w;
+  return t;
+}
+
 }  // namespace rdamd
