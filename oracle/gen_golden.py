@@ -406,6 +406,29 @@ def main():
     json.dump({"newick": nw, "seqs": seqs, "alphabet": aa, "subst": sp,
                "freqs": fr, "rates": rates, "roots": roots},
               open(os.path.join(GOLD, "protein20.json"), "w"))
+    # 8. binary characters (`rd --states 2`): 2 substitution rates, 2 frequencies ---
+    k = 2
+    names = ["b%02d" % i for i in range(14)]
+    clades = ["%s:%.4f" % (n, rng.uniform(0.02, 0.6)) for n in names[:3]]
+    for n in names[3:]:
+        i = rng.integers(len(clades))
+        clades[i] = "(%s,%s:%.4f):%.4f" % (clades[i], n, rng.uniform(0.02, 0.6),
+                                          rng.uniform(0.02, 0.6))
+    nw = "(" + ",".join(clades) + ");"
+    bmap = {"0": 1, "1": 2, "-": 3, "?": 3}
+    seqs = {n: "".join(rng.choice(list("0011-?"), 60)) for n in names}
+    tree = UTree(nw)
+    sp = [0.7, 1.9]
+    fr = [0.37, 0.63]
+    rates = gamma_cats(0.8, 4, "mean")
+    q = build_q(sp, fr)
+    roots = []
+    for (u, v) in tree.edges():
+        ps = prune(tree, seqs, bmap, q, rates, [0.25] * 4, fr, u, v, 0.6)
+        roots.append({"near_tips": tree.side_tips(u, v), "far_tips": tree.side_tips(v, u),
+                      "alpha": 0.6, "lnl": float(ps.sum())})
+    json.dump({"newick": nw, "seqs": seqs, "subst": sp, "freqs": fr, "rates": rates,
+               "roots": roots}, open(os.path.join(GOLD, "binary2.json"), "w"))
     print("goldens written to", os.path.normpath(GOLD))
 
 

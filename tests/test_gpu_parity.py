@@ -580,6 +580,27 @@ def test_binary_data_on_the_four_state_kernels():
     o.destroy()
 
 
+def test_binary2_goldens_on_the_gpu():
+    """the SciPy golden for 2-state data, through the embedded 4-state kernels:
+    materialising path, fused root step and fused batch."""
+    gd = util.golden("binary2.json")
+    tree = rd.Tree.from_newick(gd["newick"])
+    cmap = util.make_map("01", {"-": 3, "?": 3})
+    nsites = len(next(iter(gd["seqs"].values())))
+    g = rd.Partition.for_tree(tree, 2, nsites, 4)
+    util.load_tips(g, tree, gd["seqs"], cmap)
+    set_model((g,), gd["subst"], gd["freqs"], gd["rates"])
+    rls = [util.find_root(tree, r["near_tips"], r["far_tips"], r["alpha"]) for r in gd["roots"]]
+    for rl, root in zip(rls, gd["roots"]):
+        assert util.rel_err(util.compute_lh(g, tree, rl), root["lnl"]) < 1e-10
+        assert util.rel_err(util.compute_lh_root(g, tree, rl), root["lnl"]) < 1e-10
+    scheds = [g.schedule(*tree.generate_operations(rl)) for rl in rls]
+    fused = g.evaluate_batch(scheds, [gd["subst"]] * len(rls), [gd["freqs"]] * len(rls))
+    for val, root in zip(fused, gd["roots"]):
+        assert util.rel_err(val, root["lnl"]) < 1e-10
+    g.destroy()
+
+
 def test_many_sites_few_parking_slots_cross_check():
     """300 taxa x 120 000 sites x 4 rates: 480 k (site, rate) lanes leave the
     traversal kernel ONE LDS parking slot per lane, so most older siblings are

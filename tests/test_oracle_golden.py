@@ -217,6 +217,24 @@ def test_protein20_goldens():
         assert util.rel_err(got, root["lnl"]) < TOL
 
 
+def test_binary2_goldens():
+    """2-state characters with gaps (`rd --states 2`): the oracle's native
+    2-state arithmetic against the SciPy pruning, every rooting."""
+    g = util.golden("binary2.json")
+    tree = rd.Tree.from_newick(g["newick"])
+    cmap = util.make_map("01", {"-": 3, "?": 3})
+    nsites = len(next(iter(g["seqs"].values())))
+    part = OraclePartition.for_tree(tree, 2, nsites, 4)
+    util.load_tips(part, tree, g["seqs"], cmap)
+    part.set_subst_params(0, g["subst"])
+    part.set_frequencies(0, g["freqs"])
+    part.set_category_rates(g["rates"])
+    assert len(g["roots"]) == tree.root_count()
+    for root in g["roots"]:
+        rl = util.find_root(tree, root["near_tips"], root["far_tips"], root["alpha"])
+        assert util.rel_err(util.compute_lh(part, tree, rl), root["lnl"]) < TOL
+
+
 def test_determinism_and_negativity():
     """test/src/model.cpp:59-75: finite, negative, bit-identical on repeat."""
     tree = rd.Tree.from_file(os.path.join(util.DATA, "10.tree"))
