@@ -1,10 +1,12 @@
 #!/usr/bin/env python3
-"""End-to-end timing of the exhaustive per-candidate loop (src/model.cpp:1139-1272)
+"""(Lives under tests/: it borrows the reference's L-BFGS-B build, oracle/_ref,
+as the caller's optimiser -- nothing outside tests/ may touch oracle/.)
+End-to-end timing of the exhaustive per-candidate loop (src/model.cpp:1139-1272)
 on BASELINE config c2 with the reference's L-BFGS-B (oracle/_ref) driving the
 batched GPU objective.  Diagnostic, not the bench line."""
 import ctypes, os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import root_digger_amd as rd
 from root_digger_amd import synth

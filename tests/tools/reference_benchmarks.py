@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""The reference's own micro-benchmarks (benchmark/src/model.cpp:19-78:
+"""(Lives under tests/: it times the CPU oracle beside the GPU path -- nothing
+outside tests/ may touch oracle/.)
+The reference's own micro-benchmarks (benchmark/src/model.cpp:19-78:
 BM_LH_computation, BM_DLH_computation, BM_LH_root_computation, same datasets
 and root indices) timed on this implementation: latency of ONE model_t call,
 host wall clock, the GPU result synchronously returned each time.  Beside it
@@ -11,7 +13,7 @@ import os
 import sys
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import root_digger_amd as rd
