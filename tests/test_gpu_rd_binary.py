@@ -1,0 +1,67 @@
+"""root_digger_amd/bin/rd_amd: the native `rd` front end (csrc/tools/rd_main.cpp,
+built on include/root_digger_amd.h alone) against the Python command line on
+the same options -- same checkpoint records, same trees."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+import root_digger_amd as rd
+import util
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+RD = os.path.join(ROOT, "root_digger_amd", "bin", "rd_amd")
+REF = os.path.join(ROOT, "oracle", "_ref", "liblbfgsb_ref.so")
+MSA, TREE = os.path.join(util.DATA, "10.fasta"), os.path.join(util.DATA, "10.tree")
+
+
+def test_native_front_end_matches_the_python_one(tmp_path):
+    from root_digger_amd import cli
+    assert os.path.exists(RD), "make -C root_digger_amd/csrc builds it"
+    common = ["--msa", MSA, "--tree", TREE, "--exhaustive", "--silent", "--rate-cats", "4",
+              "--atol", "1e-3", "--brtol", "1e-3", "--bfgstol", "1e-3", "--factor", "1e12",
+              "--seed", "5"]
+    if os.path.exists(REF):
+        common += ["--lbfgsb", REF]
+    a, b = str(tmp_path / "native"), str(tmp_path / "python")
+    out = subprocess.run([RD] + common + ["--prefix", a], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert cli.main(common + ["--prefix", b]) == 0
+    ra = sorted(rd.Checkpoint(a).read_results())
+    rb = sorted(rd.Checkpoint(b).read_results())
+    assert [r[:3] for r in ra] == [r[:3] for r in rb] and len(ra) == 17
+    assert [r[3] for r in ra] == [r[3] for r in rb]
+    assert open(a + ".rooted.tree").read() == open(b + ".rooted.tree").read()
+    assert open(a + ".lwr.tree").read() == open(b + ".lwr.tree").read()
+    assert out.stdout.strip().splitlines()[-1] == open(a + ".lwr.tree").read().strip()
+    # a rerun finds everything in the log
+    again = subprocess.run([RD, "--msa", "x", "--tree", "y", "--prefix", a, "--silent"],
+                           capture_output=True, text=True, timeout=600)
+    assert again.returncode == 0 and len(rd.Checkpoint(a).read_results()) == 17
+
+
+def test_native_front_end_two_ranks_and_search_mode(tmp_path):
+    env = dict(os.environ, WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29547")
+    two = str(tmp_path / "two")
+    args = [RD, "--msa", MSA, "--tree", TREE, "--exhaustive", "--silent", "--atol", "1e-3",
+            "--brtol", "1e-3", "--prefix", two, "--device", "0", "--threads", "0"]
+    procs = [subprocess.Popen(args, env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for r in range(2)]
+    outs = [p.communicate(timeout=120)[0] for p in procs]
+    assert [p.returncode for p in procs] == [0, 0], outs
+    recs = sorted(rd.Checkpoint(two).read_results())
+    assert [r[0] for r in recs] == list(range(17))
+    assert outs[1].strip() == "" and outs[0].strip().startswith("(")      # only rank 0 prints the tree
+    if not os.path.exists(REF):
+        pytest.skip("oracle/_ref/liblbfgsb_ref.so not built")
+    s = str(tmp_path / "search")
+    out = subprocess.run([RD, "--msa", MSA, "--tree", TREE, "--prefix", s, "--silent", "--lbfgsb", REF,
+                          "--min-roots", "2", "--initial-root-strategy", "midpoint", "--atol", "1e-3",
+                          "--bfgstol", "1e-3", "--brtol", "1e-3", "--factor", "1e12"],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert len(rd.Checkpoint(s).read_results()) == 2 and not os.path.exists(s + ".lwr.tree")
+    assert rd.Tree.from_newick(open(s + ".rooted.tree").read()).tip_count() == 10
