@@ -489,6 +489,10 @@ int rdamd_checkpoint_clean(rdamd_checkpoint_t *c);
 uint32_t rdamd_checkpoint_checksum_result(uint64_t root_id, double llh, double alpha);
 uint32_t rdamd_checkpoint_checksum_params(unsigned int n_partitions, const uint64_t *counts,
                                           const double *values);
+/* on: the searches print the reference's progress lines ("Step i / n, ETC: h",
+ * src/model.cpp:1219-1223) to stdout, counting over the roots assigned at the
+ * time of the call; call it after the assign function.  off: silent. */
+int rdamd_model_set_progress(rdamd_model_t *m, int on);
 /* searches of this model append every finished candidate to `c` (NULL detaches),
  * src/model.cpp:1107 and :1215 */
 int rdamd_model_set_checkpoint(rdamd_model_t *m, rdamd_checkpoint_t *c);

@@ -205,6 +205,7 @@ _sig("rdamd_checkpoint_checksum_result", C.c_uint32, C.c_uint64, C.c_double, C.c
 _sig("rdamd_checkpoint_checksum_params", C.c_uint32, _u, _pu64, _pd)
 _sig("rdamd_model_assign_by_rank_search", C.c_int, _vp, _u, C.c_double, _u, _u, C.c_int, _vp)
 _sig("rdamd_model_assigned", C.c_int, _vp, _pu64, _u)
+_sig("rdamd_model_set_progress", C.c_int, _vp, C.c_int)
 _sig("rdamd_model_set_checkpoint", C.c_int, _vp, _vp)
 _sig("rdamd_model_assign_by_rank_checkpoint", C.c_int, _vp, _u, _u, _vp)
 _sig("rdamd_model_compute_all_root_lh_directional", C.c_int, _vp, _pd, _pd)
@@ -1088,6 +1089,10 @@ class Model:
         ids = (C.c_uint64 * n)()
         k = lib.rdamd_model_assigned(self._h, ids, n)
         return [int(ids[i]) for i in range(min(k, n))]
+
+    def set_progress(self, on=True):
+        """print the reference's "Step i / n, ETC" lines during searches (call after assign)."""
+        lib.rdamd_model_set_progress(self._h, 1 if on else 0)
 
     def set_checkpoint(self, checkpoint):
         """searches append every finished candidate to this Checkpoint (None detaches)."""

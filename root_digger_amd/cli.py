@@ -198,6 +198,9 @@ def main(argv=None):
     if args.exhaustive:
         model.assign_by_rank(rank, world, ckp)                 # src/main.cpp:612-615
         barrier()
+        if not args.silent and rank == 0:
+            print("Starting exhaustive search", flush=True)
+            model.set_progress(True)
         res = model.exhaustive_search(args.atol, args.bfgstol, args.brtol, args.factor,
                                       workers=args.workers, lockstep=args.lockstep)
     else:
@@ -207,6 +210,9 @@ def main(argv=None):
                                     args.initial_root_strategy.replace("-", "_"), ckp)
         barrier()
         starts = model.assigned()
+        if not args.silent and rank == 0:
+            print("Starting root search", flush=True)
+            model.set_progress(True)
         best, best_llh = model.search(args.min_roots, args.root_ratio, args.atol, args.bfgstol,
                                       args.brtol, args.factor)
         res = {"root_id": [int(best.id)] if starts else [], "llh": [best_llh], "alpha":

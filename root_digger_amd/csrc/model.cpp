@@ -1,6 +1,8 @@
 // model_t on the rdamd C ABI; behaviour follows /root/reference/src/model.cpp
 // (cited per function).
 #include "model.hpp"
+
+#include <cstdio>
 #include "batch_combiner.hpp"
 #include "checkpoint.hpp"
 
@@ -820,6 +822,14 @@ void model_t::optimize_params(std::vector<partition_parameters_t> &params,
   }
 }
 
+void model_t::progress_t::step(const char *what) {
+  const size_t i = ++done;
+  const double elapsed = std::chrono::duration<double>(std::chrono::steady_clock::now() - start).count();
+  const double etc_h = total > i ? elapsed / (double)i * (double)(total - i) / 3600.0 : 0.0;
+  std::printf("[%.2f] %s %zu / %zu, ETC: %0.2fh\n", elapsed, what, i, total, etc_h);
+  std::fflush(stdout);
+}
+
 // ---- heuristic search (src/model.cpp:1008-1137) ---------------------------------------
 std::pair<root_location_t, double> model_t::search(size_t min_roots, double root_ratio,
                                                    double atol, double pgtol, double brtol,
@@ -866,6 +876,7 @@ std::pair<root_location_t, double> model_t::search(size_t min_roots, double root
       rl = cur_best_rl;
     }
     if (_checkpoint) _checkpoint->write({cur_best_rl.id, cur_best_lh, cur_best_rl.brlen_ratio}, params);
+    if (_progress) _progress->step("Stage");
     local.push_back({cur_best_rl.id, cur_best_lh, cur_best_rl.brlen_ratio});
     local_params.push_back(params);
   }
@@ -921,6 +932,7 @@ std::pair<root_location_t, double> model_t::exhaustive_search(double atol, doubl
       rl = cur_rl;
     }
     if (_checkpoint) _checkpoint->write({cur_best_rl.id, cur_best_llh, cur_best_rl.brlen_ratio}, params);
+    if (_progress) _progress->step("Step");
     if (results) results->push_back({cur_best_rl.id, cur_best_llh, cur_best_rl.brlen_ratio});
     if (cur_best_llh > best_llh) { best_rl = cur_best_rl; best_llh = cur_best_llh; }
   }

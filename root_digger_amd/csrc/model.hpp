@@ -15,6 +15,8 @@
 #include <random>
 #include <stdexcept>
 #include <array>
+#include <atomic>
+#include <chrono>
 #include <string>
 #include <unordered_set>
 #include <utility>
@@ -138,6 +140,16 @@ public:
   // every finished candidate is appended to this result log (checkpoint.hpp), as
   // the reference's searches do (src/model.cpp:1107, :1215); not owned
   void set_checkpoint(checkpoint_t *c) { _checkpoint = c; }
+  // progress lines of the reference's searches ("Step i / n, ETC: h" at its
+  // default verbosity, src/model.cpp:1101-1105, :1219-1223) go to stdout when a
+  // tracker is attached; shared by the replicas of a parallel search; not owned
+  struct progress_t {
+    std::atomic<size_t> done{0};
+    size_t total = 0;
+    std::chrono::steady_clock::time_point start = std::chrono::steady_clock::now();
+    void step(const char *what);
+  };
+  void set_progress(progress_t *p) { _progress = p; }
   // the optimiser's objective batches go through this combiner (batch_combiner.hpp)
   // instead of being launched on this model's own partition; not owned
   void set_combiner(batch_combiner_t *c) { _combiner = c; }
@@ -221,6 +233,7 @@ private:
   std::minstd_rand                       _random_engine;
   rdamd_partition_t                     *_sweep = nullptr;   // all-directions cache (lazily built)
   std::vector<msa_t>                     _sweep_msa;          // what it needs to load its tips
+  progress_t                            *_progress = nullptr;
   checkpoint_t                          *_checkpoint = nullptr;
   batch_combiner_t                      *_combiner = nullptr;
   bool                                   _invariant_sites, _early_stop;   // +I is inert (:292-300)

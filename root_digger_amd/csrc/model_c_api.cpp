@@ -36,6 +36,7 @@ struct rdamd_model {
   bool     early_stop = false;
   void    *setulb = nullptr;
   rdamd::checkpoint_t *checkpoint = nullptr;
+  std::unique_ptr<rdamd::model_t::progress_t> progress;   // set by rdamd_model_set_progress
   ~rdamd_model() { delete model; }
 };
 
@@ -389,6 +390,7 @@ static int search_with_replicas(rdamd_model_t *m, unsigned int workers, bool loc
         replica.initialize_partitions(msas);
         if (m->setulb) replica.set_lbfgsb(reinterpret_cast<rdamd::model_t::setulb_fn>(m->setulb));
         replica.set_checkpoint(m->checkpoint);
+        replica.set_progress(m->progress.get());
         replica.set_combiner(combiner.get());
         replica.initialize();
         for (;;) {
@@ -470,6 +472,16 @@ void rdamd_model_counters(const rdamd_model_t *m, uint64_t out[6]) {
   for (int i = 0; i < 6; ++i) out[i] = c[i];
 }
 
+int rdamd_model_set_progress(rdamd_model_t *m, int on) {
+  if (on) {
+    m->progress.reset(new rdamd::model_t::progress_t());
+    m->progress->total = m->model->assigned_indicies().size();
+  } else {
+    m->progress.reset();
+  }
+  m->model->set_progress(m->progress.get());
+  return RDAMD_SUCCESS;
+}
 int rdamd_model_set_checkpoint(rdamd_model_t *m, rdamd_checkpoint_t *c) {
   m->checkpoint = rdamd_checkpoint_cpp(c);
   m->model->set_checkpoint(m->checkpoint);

@@ -315,6 +315,10 @@ int main(int argc, char **argv) {
   if (o.exhaustive) {
     need(rdamd_model_assign_by_rank_checkpoint(model, (unsigned)rank, (unsigned)world, ckp), "assign");
     ranks.barrier();
+    if (!o.silent && rank == 0) {
+      std::puts("Starting exhaustive search");
+      rdamd_model_set_progress(model, 1);
+    }
     if (o.lockstep > 0)
       need(rdamd_model_exhaustive_search_lockstep(model, (unsigned)o.lockstep, o.atol, o.bfgstol, o.brtol,
                                                   o.factor, ids.data(), llh.data(), alpha.data(),
@@ -334,6 +338,10 @@ int main(int argc, char **argv) {
     ranks.barrier();
     std::vector<uint64_t> mine(roots);
     const int assigned = rdamd_model_assigned(model, mine.data(), roots);
+    if (!o.silent && rank == 0) {
+      std::puts("Starting root search");
+      rdamd_model_set_progress(model, 1);
+    }
     need(rdamd_model_search(model, o.min_roots, o.root_ratio, o.atol, o.bfgstol, o.brtol, o.factor,
                             &best, &best_llh), "search");
     if (assigned > 0) {
