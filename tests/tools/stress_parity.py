@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Randomised parity soak (run by hand on a GPU box, not collected by pytest):
+random shapes, random valid operation orders, random root placements -- the
+materialising kernels and the fused evaluator against the CPU oracle.
+usage: stress_parity.py [seconds] [seed]"""
+import os
+import sys
+import time
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+sys.path.insert(0, os.path.dirname(HERE))
+import numpy as np
+import root_digger_amd as rd
+from root_digger_amd import synth
+from oracle_lib import OraclePartition, ORC_MAP_NT
+import util
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+t0, rounds, worst = time.time(), 0, 0.0
+while time.time() - t0 < budget:
+    n = int(rng.integers(4, 260))
+    R = int(rng.choice([1, 2, 4, 8]))
+    S = int(rng.choice([1, 7, 63, 64, 65, 255, 1000, 4097, 20000]))
+    if n * S * R > 6e6:
+        S = max(1, int(6e6 // (n * R)))
+    K = int(rng.choice([4, 4, 4, 2]))
+    w = synth.workload(n, S, K, R, int(rng.integers(1 << 30)))
+    tree = rd.Tree.from_newick(w["newick"])
+    cmap = rd.MAP_NT if K == 4 else util.make_map(w["alphabet"])
+    g = rd.Partition.for_tree(tree, K, S, R)
+    o = OraclePartition.for_tree(tree, K, S, R)
+    util.load_tips(g, tree, w["seqs"], cmap)
+    util.load_tips(o, tree, w["seqs"], ORC_MAP_NT if K == 4 else cmap)
+    freqs = g.empirical_frequencies()
+    if min(freqs) < 1e-3:        # a state that never occurs: the reference falls back to
+        freqs = [1.0 / K] * K    # uniform frequencies (src/main.cpp:577-581)
+    for p in (g, o):
+        p.set_subst_params(0, w["subst"])
+        p.set_frequencies(0, freqs)
+        p.set_category_rates(w["rates"])
+    rl = tree.root_location(int(rng.integers(tree.root_count()))).with_ratio(float(rng.uniform(0, 1)))
+    ops, pmi, brl = tree.generate_operations(rl)
+    ops = [rd.Operation(*op.astuple()) for op in ops]
+    # a random valid order
+    done, pending, order = set(range(n)), list(ops), []
+    while pending:
+        ready = [op for op in pending if op.child1_clv_index in done and op.child2_clv_index in done]
+        pick = ready[int(rng.integers(len(ready)))]
+        order.append(pick)
+        done.add(pick.parent_clv_index)
+        pending.remove(pick)
+    for p in (g, o):
+        p.update_prob_matrices(pmi, brl)
+        p.update_clvs(order if rng.random() < 0.5 else ops)
+    for op in (ops[0], ops[len(ops) // 2], ops[-1]):
+        a, b = g.get_clv(op.parent_clv_index), o.get_clv(op.parent_clv_index)
+        assert np.allclose(a, b, rtol=1e-12, atol=0.0), (n, S, R, K, op.parent_clv_index)
+        if op.parent_scaler_index >= 0:
+            assert np.array_equal(g.get_scaler(op.parent_scaler_index), o.get_scaler(op.parent_scaler_index))
+    la = g.compute_root_loglikelihood(tree.root_clv_index(), tree.root_scaler_index())
+    lb = o.compute_root_loglikelihood(tree.root_clv_index(), tree.root_scaler_index())
+    fused = g.evaluate_batch([g.schedule(ops, pmi, brl)], [w["subst"]], [freqs])[0]
+    err = max(abs(la - lb), abs(fused - lb)) / abs(lb)
+    assert err < 1e-11, (n, S, R, K, la, lb, fused)
+    worst = max(worst, err)
+    rounds += 1
+    g.destroy()
+    o.destroy()
+print("%d random cases in %.0f s, worst lnL rel. err %.2e" % (rounds, time.time() - t0, worst))
