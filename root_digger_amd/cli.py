@@ -31,7 +31,7 @@ import os
 import sys
 import time
 
-from . import MAP_BIN, MAP_NT, Checkpoint, Model, Tree, parse_model_info, set_device
+from . import MAP_BIN, MAP_NT, Checkpoint, Model, RdamdError, Tree, parse_model_info, set_device
 
 def version_string():
     from . import lib
@@ -185,7 +185,10 @@ def main(argv=None):
                                 rate_category_type=args.rate_cats_type)
     if args.echo:
         print(tree.newick(True))
-    model.initialize_partitions()
+    try:
+        model.initialize_partitions()
+    except RdamdError:      # a state that never occurs: uniform frequencies, src/main.cpp:577-581
+        model.initialize_partitions_uniform_freqs()
     keep = None
     if args.lbfgsb:
         keep = ctypes.CDLL(args.lbfgsb)
