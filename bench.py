@@ -99,7 +99,10 @@ def main():
                     help="gloo + --device lets several ranks share one GPU (how the N>1 code "
                          "path is exercised on a one-GPU box); the driver's runs use nccl (RCCL)")
     ap.add_argument("--device", type=int, default=None, help="HIP device (default: LOCAL_RANK)")
-    ap.add_argument("--shard", default="candidates", choices=["candidates", "sites"],
+    ap.add_argument("--site-groups", type=int, default=2,
+                    help="--shard grid: ranks per candidate group, i.e. site shards (BASELINE c5: "
+                         "candidate groups x site shards = N)")
+    ap.add_argument("--shard", default="candidates", choices=["candidates", "sites", "grid"],
                     help="N>1: split candidate roots (no collective, weak scaling; default) or "
                          "split site blocks and all-reduce the per-block lnLs (strong scaling; "
                          "BASELINE config c4 pattern)")
@@ -133,10 +136,24 @@ def main():
     n, S, K, R = cfg["n"], cfg["S"], cfg["K"], cfg["R"]
     seed = 0xD166E5 + sorted(CONFIGS).index(args.config)
     w = synth.workload(n, S, K, R, seed)
-    site_sharded = args.shard == "sites" and K == 4
+    # Three ways to use N GPUs: candidate roots only (default), site
+    # blocks only, or the 2-D grid of BASELINE config c5: `cgroups` groups of
+    # `sgroups` ranks; a group shares its candidates and splits the sites, and the
+    # all-reduce of the per-block lnLs stays inside the group (adjacent ranks).
+    grid = args.shard == "grid" and K == 4 and world > 1
+    cgroups, sgroups = (rdist.grid_2d(world, args.site_groups) if grid else
+                        (1, world) if args.shard == "sites" else (world, 1))
+    cgroup, srank = rdist.rank_coords(rank, sgroups)
+    site_sharded = args.shard in ("sites", "grid") and K == 4
+    site_group = None
+    if grid:
+        for c in range(cgroups):      # every rank creates every group, in the same order
+            g = tdist.new_group(list(range(c * sgroups, (c + 1) * sgroups)))
+            if c == cgroup:
+                site_group = g
     S_total = S
     if site_sharded:   # this rank's contiguous block of patterns (dist.site_block)
-        lo, hi = rdist.site_block(S, rank, world)
+        lo, hi = rdist.site_block(S, srank, sgroups)
         w["seqs"] = {k: v[lo:hi] for k, v in w["seqs"].items()}
         S = hi - lo
     tree = rd.Tree.from_newick(w["newick"])
@@ -151,16 +168,17 @@ def main():
     for label, seq in w["seqs"].items():
         part.set_tip_states(tree.tip_index(label), cmap, seq)
     freqs = part.empirical_frequencies()
-    if site_sharded and world > 1:   # the model is global: combine the blocks' counts
-        freqs = rdist.global_frequencies(freqs, S, device="cpu" if host_collectives else "cuda")
+    if site_sharded and sgroups > 1:   # the model is global: combine the blocks' counts
+        freqs = rdist.global_frequencies(freqs, S, group=site_group,
+                                         device="cpu" if host_collectives else "cuda")
     part.set_frequencies(0, freqs)
     part.set_category_rates(w["rates"])
 
     # this rank's candidate roots (src/model.cpp:1899-1907) and per-candidate
     # parameter sets (random_params, src/model.cpp:87-93)
-    if site_sharded:   # every rank sees every candidate, on its own sites
-        mine = list(range(tree.root_count()))
-        rng = np.random.default_rng(seed + 1000)
+    if site_sharded:   # a site group sees all candidates of its candidate group, on its own sites
+        mine = rdist.assign_candidates(tree.root_count(), cgroup, cgroups)
+        rng = np.random.default_rng(seed + 1000 + cgroup)
     else:
         mine = rdist.assign_candidates(tree.root_count(), rank, world)
         rng = np.random.default_rng(seed + 1000 + rank)
@@ -199,11 +217,11 @@ def main():
             lnl_dev = lnl_rows[row] if 0 <= row < args.steps else lnl_warm
             part.evaluate_batch_device([scheds[i] for i in idx], sub, freqs_b[idx],
                                        lnl_dev.data_ptr())
-            if world > 1 and not host_collectives:
-                rdist.allreduce_lnl(lnl_dev)     # RCCL sum of the per-block lnLs
-            elif world > 1:                      # gloo test path: through the host
+            if sgroups > 1 and not host_collectives:
+                rdist.allreduce_lnl(lnl_dev, site_group)     # RCCL sum of the per-block lnLs
+            elif sgroups > 1:                    # gloo test path: through the host
                 host = lnl_dev.cpu()
-                rdist.allreduce_lnl(host)
+                rdist.allreduce_lnl(host, site_group)
                 lnl_dev.copy_(host)
             return lnl_dev
         return float(part.evaluate_batch([scheds[i] for i in idx], sub, freqs_b[idx]).sum())
@@ -245,7 +263,7 @@ def main():
         elapsed = float(t.item())
 
     evals_per_rank = args.steps * nb
-    total_evals = evals_per_rank * (1 if site_sharded else world)
+    total_evals = evals_per_rank * cgroups      # one set of evaluations per candidate group
     value = total_evals / elapsed
 
     def clv_roofline(ms, launches, evals):
@@ -310,13 +328,16 @@ def main():
         "metric": "candidate-root lnL evals/sec", "value": round(value, 2),
         "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-        "higher_is_better": True, "scaling": "strong" if site_sharded else "weak",
+        "higher_is_better": True,
+        "scaling": "strong" if args.shard == "sites" and K == 4 else "weak",
         "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": "%s: %d-taxon %d-site %d-state UNREST+G%d full-traversal "
                                "root lnL" % (args.config, n, S, K, R),
                    "batch_per_gpu": nb,
-                   "sharding": "site blocks + RCCL all-reduce" if site_sharded else "candidate roots",
+                   "sharding": ("%d candidate groups x %d site shards, all-reduce inside a group"
+                                % (cgroups, sgroups) if grid else
+                                "site blocks + RCCL all-reduce" if site_sharded else "candidate roots"),
                    "path": "fused batch" if use_fused else "per-operation"},
         "site_clv_updates_per_sec": round(value * (n - 1) * S_total, 1),
         # sum of the lnLs rank 0 saw in the timed region: identical across world

@@ -137,3 +137,53 @@ def test_world_size_2_gloo_site_and_candidate_sharding():
     assert max(abs(a - b) for a, b in zip(gfreq, wfreq)) < 1e-15
     for a, b in zip(sharded_f, whole_f):
         assert util.rel_err(a, b) < 1e-12
+
+
+def _grid_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    tdist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        cgroups, sgroups = rdist.grid_2d(world, 2)
+        cgroup, srank = rdist.rank_coords(rank, sgroups)
+        mine = None
+        for c in range(cgroups):
+            g = tdist.new_group(list(range(c * sgroups, (c + 1) * sgroups)))
+            if c == cgroup:
+                mine = g
+        # per-block "lnLs" of this group's two jobs: group c, shard s contributes (c+1)*10^s
+        part = torch.tensor([(cgroup + 1) * 10.0 ** srank, (cgroup + 1) * 2 * 10.0 ** srank],
+                            dtype=torch.float64)
+        rdist.allreduce_lnl(part, mine)
+        freqs = rdist.global_frequencies([0.1 * (srank + 1), 1 - 0.1 * (srank + 1)],
+                                         100 * (srank + 1), group=mine)
+        gathered = [None] * world
+        tdist.all_gather_object(gathered, (cgroup, srank, part.tolist(), freqs))
+        if rank == 0:
+            out.put(("ok", gathered))
+    except Exception as e:   # pragma: no cover
+        if rank == 0:
+            out.put(("err", repr(e)))
+        raise
+    finally:
+        tdist.destroy_process_group()
+
+
+def test_world_size_4_grid_of_candidate_groups_and_site_shards():
+    """BASELINE config c5's layout: 2 candidate groups x 2 site shards; the
+    all-reduce and the global frequencies stay inside a candidate group."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_grid_worker, args=(r, 4, port, q)) for r in range(4)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0] == "ok", res
+    for cgroup, srank, part, freqs in res[1]:
+        assert part == [(cgroup + 1) * 11.0, (cgroup + 1) * 22.0]            # 10^0 + 10^1 per job
+        want0 = (0.1 * 100 + 0.2 * 200) / 300
+        assert abs(freqs[0] - want0) < 1e-15 and abs(sum(freqs) - 1.0) < 1e-15
