@@ -15,7 +15,8 @@
 // table (one row per ambiguity code, built next to the P-matrices) is exactly
 // 64 doubles, one per lane, dropped into LDS and read back by code.
 // HBM traffic per evaluation drops from ~(2n-2) CLVs to n bytes per site, so
-// the kernel is bound by FP64 FMA issue, not by HBM.
+// the kernel is bound by instruction issue (FP64 FMAs first), not by HBM --
+// DESIGN.md 4.1 has the counters and the ablations.
 //
 // Scaling: each (site, rate) lane keeps its own 2^256 rescale count (rescale
 // when all four entries drop below 2^-256) and the root sum aligns the rate

@@ -10,7 +10,9 @@
 //
 // The same launch also fills the tip lookup tables
 //   tiptab[m][r][code][i] = sum_j P[m][r][i][j] * bit_j(mask(code))
-// so CLV kernels never expand a tip into a 0/1 vector.
+// which the fused evaluator, the fused root step and the generic K-state kernel
+// read instead of expanding a tip into a 0/1 vector (the 4-state traversal
+// kernel expands in registers: it is bound by its store stream, not by FMAs).
 #include "common.hpp"
 
 namespace rdamd {
