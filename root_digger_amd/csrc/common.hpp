@@ -24,7 +24,6 @@ constexpr double kScaleThreshold = 1.0 / kScaleFactor;
 constexpr double kLogScaleThreshold = -177.44567822334599;
 // scratch P-matrix slots behind the caller's (root alpha variants)
 constexpr unsigned kTipcodePad = 256;   // bytes of slack after the tip-code rows
-constexpr unsigned kExtraMatrices = 8;
 
 void set_error(int code, const char *fmt, ...);
 void clear_error();
@@ -84,6 +83,7 @@ struct rdamd_partition {
   void     *d_scratch = nullptr;  // ops / matrix lists
   size_t    scratch_bytes = 0;
   double   *d_partials = nullptr; // per-block partial sums + result slots
+  unsigned *d_counter = nullptr;  // arrival counter of the single-launch root kernel (stays 0 between launches)
   double   *d_result = nullptr;
   double   *d_persite = nullptr;
   double   *h_result = nullptr;   // pinned
@@ -168,14 +168,13 @@ hipError_t launch_clv_k20_traversal(rdamd_partition *p, const LevelOp *d_ops, un
 hipError_t launch_root_lnl(rdamd_partition *p, unsigned clv_index, int scaler_index,
                            const unsigned *d_freqs_indices, double *d_persite,
                            double *d_out);
+// the whole root-only evaluation (P-matrices, root op, reduction) as one launch
+hipError_t launch_root_single(rdamd_partition *p, const LevelOp &op, const double *len1,
+                              const double *len2, unsigned n_positions,
+                              const unsigned *params_indices, unsigned *d_counter, double *result);
 // many root CLVs of one partition in one launch (bit-identical to launch_root_lnl each)
 unsigned root_lnl_blocks(const rdamd_partition *p);
 hipError_t launch_root_lnl_batch(rdamd_partition *p, unsigned count, const unsigned *d_clv_rel,
                                  const int *d_scaler_idx, const unsigned *d_fidx,
                                  double *d_partials, double *d_out);
-// one root operation + reduction for n_alpha (<= kExtraMatrices/2) positions;
-// d_mats = [n_alpha][2] matrix slots; the last position's root CLV is stored
-hipError_t launch_root_fused(rdamd_partition *p, const LevelOp &op, const unsigned *d_mats,
-                             unsigned n_alpha, const unsigned *d_freqs_indices, double *d_out);
-
 }  // namespace rdamd

@@ -14,6 +14,7 @@
 // read instead of expanding a tip into a 0/1 vector (the 4-state traversal
 // kernel expands in registers: it is bound by its store stream, not by FMAs).
 #include "common.hpp"
+#include "expm_k4.hpp"
 
 namespace rdamd {
 
@@ -35,7 +36,6 @@ void build_q_host(unsigned K, const double *subst, const double *freqs, double *
   for (unsigned i = 0; i < K * K; ++i) q[i] /= mean;
 }
 
-constexpr int kTaylorTerms = 16;
 
 // ---- K = 4: one thread per (matrix, rate), everything in registers ---------
 __global__ void __launch_bounds__(64)
@@ -50,53 +50,8 @@ pmatrix_k4_kernel(const double *__restrict__ q, const double *__restrict__ rates
   unsigned m = gid / R, r = gid % R;
   double t = brlen[m] * rates[r];
   const double *qq = q + (size_t)params_idx[r] * 16;
-  double x[16], term[16], out[16], tmp[16];
-  double norm = 0.0;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    double cs = 0.0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      x[i * 4 + j] = qq[i * 4 + j] * t;
-      cs += fabs(x[i * 4 + j]);
-    }
-    norm = fmax(norm, cs);
-  }
-  int s = 0;
-  double scale = 1.0;
-  while (norm * scale > 0.25 && s < 60) { scale *= 0.5; ++s; }
-#pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    x[i] *= scale;
-    term[i] = out[i] = (i % 5 == 0) ? 1.0 : 0.0;
-  }
-  for (int k = 1; k <= kTaylorTerms; ++k) {
-    double inv = 1.0 / (double)k;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        double a = 0.0;
-#pragma unroll
-        for (int l = 0; l < 4; ++l) a += term[i * 4 + l] * x[l * 4 + j];
-        tmp[i * 4 + j] = a * inv;
-      }
-#pragma unroll
-    for (int i = 0; i < 16; ++i) { term[i] = tmp[i]; out[i] += tmp[i]; }
-  }
-  for (int k = 0; k < s; ++k) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        double a = 0.0;
-#pragma unroll
-        for (int l = 0; l < 4; ++l) a += out[i * 4 + l] * out[l * 4 + j];
-        tmp[i * 4 + j] = a;
-      }
-#pragma unroll
-    for (int i = 0; i < 16; ++i) out[i] = tmp[i];
-  }
+  double out[16];
+  expm_k4(qq, t, out);
   size_t slot = (size_t)mat_idx[m] * R + r;
   double *pm = pmat + slot * 16;
 #pragma unroll

@@ -10,6 +10,7 @@
 // workgroup), so a repeated call returns the bit-identical value the
 // reference's test demands (test/src/model.cpp:73); no floating-point atomics.
 #include "common.hpp"
+#include "expm_k4.hpp"
 
 namespace rdamd {
 
@@ -186,31 +187,80 @@ finish_sum_kernel(const double *__restrict__ partials, unsigned n, double *__res
 }
 
 // ---------------------------------------------------------------------------
-// Fused root evaluation for 4-state data: the root operation (both child
-// CLVs read ONCE) and the log-likelihood reduction for NA root positions on
+// Root-only evaluation for 4-state data: the root operation (both child CLVs
+// read ONCE) and the log-likelihood reduction for up to four root positions on
 // the same branch -- the body of model_t::compute_lh_root / compute_dlh
 // (/root/reference/src/model.cpp:415-452, :481-519).  Grid shape, per-lane
-// accumulation order and reduction tree are those of root_lnl_group_kernel,
-// so each returned value is bit-identical to update_clvs + that kernel.
-// The last position's root CLV and scaler are stored.
+// accumulation order and reduction tree are those of root_lnl_group_kernel, so
+// each value is bit-identical to update_prob_matrices + update_clvs + that
+// kernel.  ONE launch, nothing else on the stream: the two
+// P-matrices per position are exponentiated inside the kernel (every block
+// repeats the few hundred flops; expm_k4 is the code of pmatrix_k4_kernel, so
+// the bits are the same), tip tables are built from them in LDS, the block
+// that finishes last folds the partial sums in finish_sum_kernel's order, and
+// the result lands in pinned host memory.  A root-only evaluation is
+// launch-latency, not bandwidth: one launch + one stream wait instead of three
+// copies, three launches and a copy back.
 // ---------------------------------------------------------------------------
+struct RootSingleArgs {
+  double len1[4], len2[4];      // child1 / child2 branch length per position
+  unsigned params_idx[8];       // rate -> rate matrix (also the frequency set)
+  unsigned n_positions;
+};
+
 template <int R, int NA>
 __global__ void __launch_bounds__(256)
-root_fused_dna_kernel(DeviceView v, LevelOp op, const unsigned *__restrict__ mats,
-                      const double *__restrict__ freqs, const unsigned *__restrict__ fidx,
-                      const double *__restrict__ rate_w, const unsigned *__restrict__ pw,
-                      double *__restrict__ partials) {
-  __shared__ double smat[NA][2][R * 64];
+root_single_dna_kernel(DeviceView v, LevelOp op, RootSingleArgs ra, const double *__restrict__ q,
+                       const double *__restrict__ rates, const double *__restrict__ freqs,
+                       const double *__restrict__ rate_w, const unsigned *__restrict__ pw,
+                       const uint64_t *__restrict__ codemask, double *__restrict__ partials,
+                       unsigned *__restrict__ counter, double *__restrict__ result) {
+  __shared__ double spm[NA][2][R][16];     // P-matrices
+  __shared__ double smat[NA][2][R * 64];   // what the site loop reads: P (inner child) or tip table
   __shared__ double lds[4];
+  __shared__ unsigned ticket;
   const unsigned tid = threadIdx.x, S = v.sites;
   const bool tip1 = op.child1_clv < v.tips, tip2 = op.child2_clv < v.tips;
-  for (int a = 0; a < NA; ++a) {
-    const unsigned m1 = mats[2 * a], m2 = mats[2 * a + 1];
-    const double *src1 = tip1 ? v.tiptab + (size_t)m1 * R * 64 : v.pmat + (size_t)m1 * R * 16;
-    const double *src2 = tip2 ? v.tiptab + (size_t)m2 * R * 64 : v.pmat + (size_t)m2 * R * 16;
-    const unsigned n1 = tip1 ? R * 64 : R * 16, n2 = tip2 ? R * 64 : R * 16;
-    for (unsigned e = tid; e < n1; e += 256) smat[a][0][e] = src1[e];
-    for (unsigned e = tid; e < n2; e += 256) smat[a][1][e] = src2[e];
+  if (tid < NA * 2 * R) {
+    const unsigned a = tid / (2 * R), c = (tid / R) & 1u, r = tid % R;
+    double out[16];
+    expm_k4(q + (size_t)ra.params_idx[r] * 16, (c ? ra.len2[a] : ra.len1[a]) * rates[r], out);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) spm[a][c][r][i] = out[i] < 0.0 ? 0.0 : out[i];
+  }
+  __syncthreads();
+  for (unsigned e = tid; e < NA * 2 * R * 64; e += 256) {
+    const unsigned a = e / (2 * R * 64), c = (e / (R * 64)) & 1u, w = e % (R * 64);
+    const bool tip = c ? tip2 : tip1;
+    if (tip) {   // tiptab[r][code][i] = sum_j P[r][i][j] * bit_j(code), pmatrix_k4_kernel's order
+      const unsigned r = w / 64, code = (w / 4) & 15u, i = w & 3u;
+      const uint64_t mask = codemask[code];
+      double acc = 0.0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc += ((mask >> j) & 1) ? spm[a][c][r][i * 4 + j] : 0.0;
+      smat[a][c][w] = acc;
+    } else if (w < R * 16) {
+      smat[a][c][w] = spm[a][c][w / 16][w % 16];
+    }
+  }
+  // the state contract: the LAST position's matrices (and their tip tables) are
+  // what rdamd_update_prob_matrices would have left in the partition
+  if (blockIdx.x == 0) {
+    for (unsigned e = tid; e < 2 * R * 16; e += 256) {
+      const unsigned c = e / (R * 16), w = e % (R * 16);
+      const unsigned m = c ? op.child2_mat : op.child1_mat;
+      v.pmat[(size_t)m * R * 16 + w] = spm[NA - 1][c][w / 16][w % 16];
+    }
+    for (unsigned e = tid; e < 2 * R * 64; e += 256) {
+      const unsigned c = e / (R * 64), w = e % (R * 64);
+      const unsigned m = c ? op.child2_mat : op.child1_mat;
+      const unsigned r = w / 64, code = (w / 4) & 15u, i = w & 3u;
+      const uint64_t mask = codemask[code];
+      double acc = 0.0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc += ((mask >> j) & 1) ? spm[NA - 1][c][r][i * 4 + j] : 0.0;
+      v.tiptab[(size_t)m * R * 64 + w] = acc;
+    }
   }
   __syncthreads();
 
@@ -238,7 +288,7 @@ root_fused_dna_kernel(DeviceView v, LevelOp op, const unsigned *__restrict__ mat
     if (tip2) cy = code2[s];
     else { const double2 a = c2[idx * 2], b = c2[idx * 2 + 1]; y[0] = a.x; y[1] = a.y; y[2] = b.x; y[3] = b.y; }
     const unsigned sc0 = (lsc ? lsc[s] : 0u) + (rsc ? rsc[s] : 0u);
-    const double *f = freqs + (size_t)fidx[r] * 4;
+    const double *f = freqs + (size_t)ra.params_idx[r] * 4;
     const double w = rate_w[r];
     const double weight = (double)pw[s];
     const int base = (int)(threadIdx.x & 63) & ~(R - 1);
@@ -280,7 +330,7 @@ root_fused_dna_kernel(DeviceView v, LevelOp op, const unsigned *__restrict__ mat
       const double tr = dot_freq(o, f, 4) * w;
       double term = 0.0;
 #pragma unroll
-      for (int q = 0; q < R; ++q) term += __shfl(tr, base + q);
+      for (int q2 = 0; q2 < R; ++q2) term += __shfl(tr, base + q2);
       if (r == 0) {
         double l = log(term);
         if (sc) l += (double)sc * kLogScaleThreshold;
@@ -299,6 +349,21 @@ root_fused_dna_kernel(DeviceView v, LevelOp op, const unsigned *__restrict__ mat
     if (threadIdx.x == 0) partials[(size_t)a * gridDim.x + blockIdx.x] = b;
     __syncthreads();
   }
+  // the block that arrives last folds the partials (finish_sum_kernel's order)
+  __threadfence();
+  if (tid == 0) ticket = atomicAdd(counter, 1u);
+  __syncthreads();
+  if (ticket != gridDim.x - 1) return;
+  __threadfence();
+  for (int a = 0; a < NA; ++a) {
+    const volatile double *p = partials + (size_t)a * gridDim.x;
+    double sum = 0.0;
+    for (unsigned i = tid; i < gridDim.x; i += 256) sum += p[i];
+    const double b = block_sum_256(sum, lds);
+    if (tid == 0) result[a] = b;
+    __syncthreads();
+  }
+  if (tid == 0) *counter = 0u;   // ready for the next launch on this stream
 }
 
 hipError_t launch_root_lnl(rdamd_partition *p, unsigned clv_index, int scaler_index,
@@ -368,42 +433,49 @@ hipError_t launch_root_lnl_batch(rdamd_partition *p, unsigned count, const unsig
 }
 
 template <int R>
-static hipError_t launch_root_fused_r(rdamd_partition *p, const DeviceView &v, const LevelOp &op,
-                                      const unsigned *d_mats, unsigned n_alpha,
-                                      const unsigned *d_fidx, unsigned blocks) {
-#define RDAMD_RF(NA)                                                                        \
-  root_fused_dna_kernel<R, NA><<<blocks, 256, 0, p->stream>>>(                              \
-      v, op, d_mats, p->d_freqs, d_fidx, p->d_rate_weights, p->d_pattern_weights, p->d_partials)
-  switch (n_alpha) {
-    case 1: RDAMD_RF(1); break;
-    case 2: RDAMD_RF(2); break;
-    case 3: RDAMD_RF(3); break;
-    default: RDAMD_RF(4); break;
+static hipError_t launch_root_single_r(rdamd_partition *p, const DeviceView &v, const LevelOp &op,
+                                       const RootSingleArgs &ra, unsigned blocks, unsigned *d_counter,
+                                       double *result) {
+#define RDAMD_RS(NA)                                                                         \
+  root_single_dna_kernel<R, NA><<<blocks, 256, 0, p->stream>>>(                               \
+      v, op, ra, p->d_q, p->d_rates, p->d_freqs, p->d_rate_weights, p->d_pattern_weights,      \
+      p->d_codemask, p->d_partials, d_counter, result)
+  switch (ra.n_positions) {
+    case 1: RDAMD_RS(1); break;
+    case 2: RDAMD_RS(2); break;
+    case 3: RDAMD_RS(3); break;
+    default: RDAMD_RS(4); break;
   }
-#undef RDAMD_RF
+#undef RDAMD_RS
   return hipGetLastError();
 }
 
-hipError_t launch_root_fused(rdamd_partition *p, const LevelOp &op, const unsigned *d_mats,
-                             unsigned n_alpha, const unsigned *d_fidx, double *d_out) {
+// lengths / parameter indices travel as kernel arguments; `result` must be
+// device-visible (the partition's pinned host block)
+hipError_t launch_root_single(rdamd_partition *p, const LevelOp &op, const double *len1,
+                              const double *len2, unsigned n_positions,
+                              const unsigned *params_indices, unsigned *d_counter, double *result) {
   const unsigned S = p->sites, R = p->rate_cats;
-  if (n_alpha == 0 || n_alpha > 4) return hipErrorInvalidValue;
+  if (n_positions == 0 || n_positions > 4 || R > 8) return hipErrorInvalidValue;
+  RootSingleArgs ra;
+  for (unsigned a = 0; a < 4; ++a) {
+    ra.len1[a] = a < n_positions ? len1[a] : 0.0;
+    ra.len2[a] = a < n_positions ? len2[a] : 0.0;
+  }
+  for (unsigned r = 0; r < 8; ++r) ra.params_idx[r] = r < R ? params_indices[r] : 0u;
+  ra.n_positions = n_positions;
   size_t total = (size_t)S * R;
   unsigned blocks = (unsigned)((total + 255) / 256);
   if (blocks > kRootBlocks) blocks = kRootBlocks;   // same shape as launch_root_lnl
   if (blocks == 0) blocks = 1;
-  DeviceView v = p->view();
-  hipError_t e;
+  const DeviceView v = p->view();
   switch (R) {
-    case 1: e = launch_root_fused_r<1>(p, v, op, d_mats, n_alpha, d_fidx, blocks); break;
-    case 2: e = launch_root_fused_r<2>(p, v, op, d_mats, n_alpha, d_fidx, blocks); break;
-    case 4: e = launch_root_fused_r<4>(p, v, op, d_mats, n_alpha, d_fidx, blocks); break;
-    case 8: e = launch_root_fused_r<8>(p, v, op, d_mats, n_alpha, d_fidx, blocks); break;
+    case 1: return launch_root_single_r<1>(p, v, op, ra, blocks, d_counter, result);
+    case 2: return launch_root_single_r<2>(p, v, op, ra, blocks, d_counter, result);
+    case 4: return launch_root_single_r<4>(p, v, op, ra, blocks, d_counter, result);
+    case 8: return launch_root_single_r<8>(p, v, op, ra, blocks, d_counter, result);
     default: return hipErrorInvalidValue;
   }
-  if (e != hipSuccess) return e;
-  finish_sum_kernel<<<n_alpha, 256, 0, p->stream>>>(p->d_partials, blocks, d_out);
-  return hipGetLastError();
 }
 
 }  // namespace rdamd

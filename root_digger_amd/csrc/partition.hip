@@ -187,11 +187,10 @@ rdamd_partition_t *rdamd_partition_create(unsigned int tips, unsigned int clv_bu
   TRY(hipMalloc(&p->d_tipcodes, (size_t)tips * p->tip_stride() + kTipcodePad));
   TRY(hipMalloc(&p->d_clv, std::max<size_t>(8, (size_t)clv_buffers * S * R * K * sizeof(double))));
   TRY(hipMalloc(&p->d_scaler, std::max<size_t>(4, (size_t)scale_buffers * S * sizeof(unsigned))));
-  // kExtraMatrices scratch slots behind the caller's: alpha variants of the fused root evaluation
-  TRY(hipMalloc(&p->d_pmat, (size_t)(prob_matrices + kExtraMatrices) * R * K * K * sizeof(double)));
-  TRY(hipMalloc(&p->d_tiptab, (size_t)(prob_matrices + kExtraMatrices) * R * p->ncodes_cap * K * sizeof(double)));
+  TRY(hipMalloc(&p->d_pmat, (size_t)prob_matrices * R * K * K * sizeof(double)));
+  TRY(hipMalloc(&p->d_tiptab, (size_t)prob_matrices * R * p->ncodes_cap * K * sizeof(double)));
   if (K == 20 && R <= 16)
-    TRY(hipMalloc(&p->d_pmat_mfma, (size_t)(prob_matrices + kExtraMatrices) * R * 640 * sizeof(double)));
+    TRY(hipMalloc(&p->d_pmat_mfma, (size_t)prob_matrices * R * 640 * sizeof(double)));
   TRY(hipMalloc(&p->d_codemask, 256 * sizeof(uint64_t)));
   TRY(hipMalloc(&p->d_q, (size_t)rate_matrices * K * K * sizeof(double)));
   TRY(hipMalloc(&p->d_freqs, (size_t)rate_matrices * K * sizeof(double)));
@@ -199,6 +198,8 @@ rdamd_partition_t *rdamd_partition_create(unsigned int tips, unsigned int clv_bu
   TRY(hipMalloc(&p->d_rate_weights, R * sizeof(double)));
   TRY(hipMalloc(&p->d_pattern_weights, std::max<size_t>(4, S * sizeof(unsigned))));
   TRY(hipMalloc(&p->d_partials, 8192 * sizeof(double)));
+  TRY(hipMalloc(&p->d_counter, sizeof(unsigned)));
+  TRY(hipMemsetAsync(p->d_counter, 0, sizeof(unsigned), p->stream));
   TRY(hipMalloc(&p->d_result, 64 * sizeof(double)));
   p->stage_bytes = (size_t)4 << 20;
   TRY(hipHostMalloc(&p->h_stage, p->stage_bytes, hipHostMallocDefault));
@@ -247,7 +248,7 @@ void rdamd_partition_destroy(rdamd_partition_t *p) {
   void *dev[] = {p->d_tipcodes, p->d_clv, p->d_scaler, p->d_pmat, p->d_tiptab, p->d_pmat_mfma,
                  p->d_codemask, p->d_q, p->d_freqs, p->d_rates, p->d_rate_weights,
                  p->d_pattern_weights, p->d_tipclv_scratch, p->d_scratch,
-                 p->d_partials, p->d_result, p->d_persite};
+                 p->d_partials, p->d_result, p->d_persite, p->d_counter};
   for (void *d : dev)
     if (d) (void)hipFree(d);
   rdamd::fused_workspace_free(p->fused);
@@ -708,51 +709,30 @@ int rdamd_root_loglikelihood_fused(rdamd_partition_t *p, const rdamd_operation_t
     RDAMD_HIP_TRY(launch_tiptab_all(p), RDAMD_FAILURE);
     p->tiptab_stale = false;
   }
-  // positions are processed in chunks of kExtraMatrices / 2; the LAST position of
-  // the call uses the caller's own matrix slots and leaves the root CLV / scaler
-  // in the partition, exactly as the unfused call sequence would.
-  const unsigned per_chunk = kExtraMatrices / 2;
-  for (unsigned base = 0; base < n_alpha; base += per_chunk) {
-    const unsigned n = std::min(per_chunk, n_alpha - base);
-    std::vector<unsigned> mi(2 * n);
-    std::vector<double> bl(2 * n);
-    for (unsigned a = 0; a < n; ++a) {
-      const bool last = base + a + 1 == n_alpha;
-      mi[2 * a] = last ? root_op->child1_matrix_index : p->prob_matrices + 2 * a;
-      mi[2 * a + 1] = last ? root_op->child2_matrix_index : p->prob_matrices + 2 * a + 1;
-      bl[2 * a] = lengths1[base + a];
-      bl[2 * a + 1] = lengths2[base + a];
-      if (!(bl[2 * a] >= 0.0) || !(bl[2 * a + 1] >= 0.0) || !std::isfinite(bl[2 * a]) ||
-          !std::isfinite(bl[2 * a + 1])) {
-        set_error(9, "rdamd_root_loglikelihood_fused: invalid branch length");
-        return RDAMD_FAILURE;
-      }
+  // One launch per chunk of up to four positions (root_single_dna_kernel): branch
+  // lengths and parameter indices travel as kernel arguments, the P-matrices are
+  // exponentiated inside the kernel, the result lands in the pinned host block.
+  // The LAST position of the call leaves its matrices, root CLV and scaler in the
+  // partition, exactly as the unfused call sequence would.
+  LevelOp op;
+  op.parent_clv = root_op->parent_clv_index; op.child1_clv = root_op->child1_clv_index;
+  op.child2_clv = root_op->child2_clv_index; op.child1_mat = root_op->child1_matrix_index;
+  op.child2_mat = root_op->child2_matrix_index; op.parent_sc = root_op->parent_scaler_index;
+  op.child1_sc = root_op->child1_scaler_index; op.child2_sc = root_op->child2_scaler_index;
+  op.src1 = op.src2 = 0;
+  for (unsigned a = 0; a < n_alpha; ++a)
+    if (!(lengths1[a] >= 0.0) || !(lengths2[a] >= 0.0) || !std::isfinite(lengths1[a]) ||
+        !std::isfinite(lengths2[a])) {
+      set_error(9, "rdamd_root_loglikelihood_fused: invalid branch length");
+      return RDAMD_FAILURE;
     }
-    RDAMD_HIP_TRY(ensure_scratch(p, 4096 + sizeof(unsigned) * (R + 2 * n) + sizeof(double) * 2 * n),
-                  RDAMD_FAILURE);
-    Scratch sc{p};
-    unsigned *d_pi = (unsigned *)sc.take(sizeof(unsigned) * R);
-    unsigned *d_mi = (unsigned *)sc.take(sizeof(unsigned) * 2 * n);
-    double *d_bl = (double *)sc.take(sizeof(double) * 2 * n);
-    RDAMD_HIP_TRY(upload(p, d_pi, params_indices, sizeof(unsigned) * R), RDAMD_FAILURE);
-    RDAMD_HIP_TRY(upload(p, d_mi, mi.data(), sizeof(unsigned) * 2 * n), RDAMD_FAILURE);
-    RDAMD_HIP_TRY(upload(p, d_bl, bl.data(), sizeof(double) * 2 * n), RDAMD_FAILURE);
-    p->prof_begin(1);
-    hipError_t e = launch_pmatrix(p, d_pi, d_mi, d_bl, 2 * n);
-    p->prof_end();
-    RDAMD_HIP_TRY(e, RDAMD_FAILURE);
-    LevelOp op;
-    op.parent_clv = root_op->parent_clv_index; op.child1_clv = root_op->child1_clv_index;
-    op.child2_clv = root_op->child2_clv_index; op.child1_mat = root_op->child1_matrix_index;
-    op.child2_mat = root_op->child2_matrix_index; op.parent_sc = root_op->parent_scaler_index;
-    op.child1_sc = root_op->child1_scaler_index; op.child2_sc = root_op->child2_scaler_index;
-    op.src1 = op.src2 = 0;
+  for (unsigned base = 0; base < n_alpha; base += 4) {
+    const unsigned n = std::min(4u, n_alpha - base);
     p->prof_begin(2);
-    e = launch_root_fused(p, op, d_mi, n, d_pi, p->d_result);
+    hipError_t e = launch_root_single(p, op, lengths1 + base, lengths2 + base, n, params_indices,
+                                      p->d_counter, p->h_result);
     p->prof_end();
     RDAMD_HIP_TRY(e, RDAMD_FAILURE);
-    RDAMD_HIP_TRY(hipMemcpyAsync(p->h_result, p->d_result, sizeof(double) * n,
-                                 hipMemcpyDeviceToHost, p->stream), RDAMD_FAILURE);
     RDAMD_HIP_TRY(hipStreamSynchronize(p->stream), RDAMD_FAILURE);
     for (unsigned a = 0; a < n; ++a) lnl_out[base + a] = p->h_result[a];
   }
