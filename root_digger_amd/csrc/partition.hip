@@ -414,15 +414,23 @@ int rdamd_update_prob_matrices(rdamd_partition_t *p, const unsigned int *params_
     }
   }
   RDAMD_HIP_TRY(flush_q(p), RDAMD_FAILURE);
-  size_t need = 256 * 3 + sizeof(unsigned) * (R + count) + sizeof(double) * count;
-  RDAMD_HIP_TRY(ensure_scratch(p, need), RDAMD_FAILURE);
+  // the three small input arrays travel as ONE host-to-device copy: lengths
+  // first (8-byte aligned), then the two index arrays
+  const size_t bl_bytes = sizeof(double) * count, mi_bytes = sizeof(unsigned) * count,
+               pi_bytes = sizeof(unsigned) * R, packed = bl_bytes + mi_bytes + pi_bytes;
+  RDAMD_HIP_TRY(ensure_scratch(p, packed + 512), RDAMD_FAILURE);
   Scratch sc{p};
-  unsigned *d_pi = (unsigned *)sc.take(sizeof(unsigned) * R);
-  unsigned *d_mi = (unsigned *)sc.take(sizeof(unsigned) * count);
-  double *d_bl = (double *)sc.take(sizeof(double) * count);
-  RDAMD_HIP_TRY(upload(p, d_pi, params_indices, sizeof(unsigned) * R), RDAMD_FAILURE);
-  RDAMD_HIP_TRY(upload(p, d_mi, matrix_indices, sizeof(unsigned) * count), RDAMD_FAILURE);
-  RDAMD_HIP_TRY(upload(p, d_bl, branch_lengths, sizeof(double) * count), RDAMD_FAILURE);
+  char *d_block = (char *)sc.take(packed);
+  double *d_bl = (double *)d_block;
+  unsigned *d_mi = (unsigned *)(d_block + bl_bytes);
+  unsigned *d_pi = (unsigned *)(d_block + bl_bytes + mi_bytes);
+  {
+    std::vector<char> host(packed);
+    memcpy(host.data(), branch_lengths, bl_bytes);
+    memcpy(host.data() + bl_bytes, matrix_indices, mi_bytes);
+    memcpy(host.data() + bl_bytes + mi_bytes, params_indices, pi_bytes);
+    RDAMD_HIP_TRY(upload(p, d_block, host.data(), packed), RDAMD_FAILURE);
+  }
   p->prof_begin(1);
   hipError_t le = launch_pmatrix(p, d_pi, d_mi, d_bl, count);
   if (le == hipSuccess && p->d_pmat_mfma) le = launch_pmat_to_mfma(p, d_mi, count);
@@ -599,12 +607,11 @@ double rdamd_compute_root_loglikelihood(rdamd_partition_t *p, unsigned int clv_i
   if (persite_lnl && !p->d_persite)
     RDAMD_HIP_TRY(hipMalloc(&p->d_persite, std::max<size_t>(8, sizeof(double) * p->sites)), nan);
   p->prof_begin(2);
+  // the finishing workgroup writes straight into the pinned host block
   hipError_t le = launch_root_lnl(p, clv_index, scaler_index, d_fi,
-                                  persite_lnl ? p->d_persite : nullptr, p->d_result);
+                                  persite_lnl ? p->d_persite : nullptr, p->h_result);
   p->prof_end();
   RDAMD_HIP_TRY(le, nan);
-  RDAMD_HIP_TRY(hipMemcpyAsync(p->h_result, p->d_result, sizeof(double),
-                               hipMemcpyDeviceToHost, p->stream), nan);
   RDAMD_HIP_TRY(hipStreamSynchronize(p->stream), nan);
   if (persite_lnl)
     RDAMD_HIP_TRY(hipMemcpy(persite_lnl, p->d_persite, sizeof(double) * p->sites,
