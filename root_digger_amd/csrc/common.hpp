@@ -163,6 +163,8 @@ hipError_t launch_clv_traversal(rdamd_partition *p, const LevelOp *d_ops, unsign
 // kernels_clv_mfma.hip (20 states)
 hipError_t launch_pmat_to_mfma(rdamd_partition *p, const unsigned *d_matrix_indices, unsigned count);
 hipError_t launch_clv_k20_traversal(rdamd_partition *p, const LevelOp *d_ops, unsigned nops);
+bool k20_mfma_ok(const rdamd_partition *p);   // can the 20-state MFMA kernel take this partition?
+size_t k20_mfma_copy_doubles();               // doubles per (matrix, rate) in d_pmat_mfma
 
 // kernels_root.hip
 hipError_t launch_root_lnl(rdamd_partition *p, unsigned clv_index, int scaler_index,

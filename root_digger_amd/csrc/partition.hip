@@ -189,8 +189,8 @@ rdamd_partition_t *rdamd_partition_create(unsigned int tips, unsigned int clv_bu
   TRY(hipMalloc(&p->d_scaler, std::max<size_t>(4, (size_t)scale_buffers * S * sizeof(unsigned))));
   TRY(hipMalloc(&p->d_pmat, (size_t)prob_matrices * R * K * K * sizeof(double)));
   TRY(hipMalloc(&p->d_tiptab, (size_t)prob_matrices * R * p->ncodes_cap * K * sizeof(double)));
-  if (K == 20 && R <= 16)
-    TRY(hipMalloc(&p->d_pmat_mfma, (size_t)prob_matrices * R * 640 * sizeof(double)));
+  if (K == 20 && R <= 8)
+    TRY(hipMalloc(&p->d_pmat_mfma, (size_t)prob_matrices * R * k20_mfma_copy_doubles() * sizeof(double)));
   TRY(hipMalloc(&p->d_codemask, 256 * sizeof(uint64_t)));
   TRY(hipMalloc(&p->d_q, (size_t)rate_matrices * K * K * sizeof(double)));
   TRY(hipMalloc(&p->d_freqs, (size_t)rate_matrices * K * sizeof(double)));
@@ -486,7 +486,28 @@ void rdamd_update_clvs(rdamd_partition_t *p, const rdamd_operation_t *ops,
   const unsigned nslots = clv_traversal_slots(p);
   // (`cuts` splits a list into separate launches; nothing needs that today:
   // memory children are read at use, after every earlier store of the lane.)
-  std::vector<unsigned> cuts{0u, count};
+  std::vector<unsigned> cuts{0u};
+  // The 20-state kernel fetches the operands of operation i+1 before the
+  // stores of operation i: where i+1 reads from memory what i wrote (possible
+  // only when the value cannot be forwarded: same CLV under another scaler
+  // index, or the other way round), the list is cut into two launches.
+  const bool use_k20 = k20_mfma_ok(p);
+  if (use_k20)
+    for (unsigned i = 1; i < count; ++i) {
+      const rdamd_operation_t &o = ops[i], &b = ops[i - 1];
+      const unsigned ch[2] = {o.child1_clv_index, o.child2_clv_index};
+      const int chsc[2] = {o.child1_scaler_index, o.child2_scaler_index};
+      bool hazard = false;
+      for (int c = 0; c < 2; ++c) {
+        if (ch[c] < p->tips) continue;
+        const bool forwarded = ch[c] == b.parent_clv_index && chsc[c] == b.parent_scaler_index;
+        const bool touches = ch[c] == b.parent_clv_index ||
+                             (chsc[c] >= 0 && chsc[c] == b.parent_scaler_index);
+        hazard = hazard || (touches && !forwarded);
+      }
+      if (hazard) cuts.push_back(i);
+    }
+  cuts.push_back(count);
   std::vector<int> producer(nclv), consumer(count), which(count);
   for (size_t seg = 0; seg + 1 < cuts.size(); ++seg) {
     const unsigned lo = cuts[seg], hi = cuts[seg + 1];
@@ -549,14 +570,14 @@ void rdamd_update_clvs(rdamd_partition_t *p, const rdamd_operation_t *ops,
   // Each segment (normally the whole list) runs as one launch in the caller's
   // order: every dependency is site-local, so the kernel needs no level
   // structure (kernels_clv.hip).
-  if (!p->d_pmat_mfma) {   // pad to whole chunks with no-ops (a copy of the last op, stores off)
+  if (!use_k20) {   // pad to whole chunks with no-ops (a copy of the last op, stores off)
     const unsigned chunk = clv_traversal_chunk(p);
     LevelOp pad = lops[count - 1];
     pad.src1 = pad.src2 = 2u;
     pad.park = 0;
     pad.noop = 1;
     while (lops.size() % chunk) lops.push_back(pad);
-    cuts.back() = (unsigned)lops.size();
+    cuts.back() = (unsigned)lops.size();   // (no cuts on this path: one segment)
     lops.push_back(pad);   // terminator: the kernel looks one operation ahead
   }
   const size_t padded = lops.size();
@@ -572,7 +593,7 @@ void rdamd_update_clvs(rdamd_partition_t *p, const rdamd_operation_t *ops,
     p->prof_begin(0);
     for (size_t seg = 0; e == hipSuccess && seg + 1 < cuts.size(); ++seg) {
       const unsigned lo = cuts[seg], n = cuts[seg + 1] - lo;
-      e = p->d_pmat_mfma ? launch_clv_k20_traversal(p, d_ops + lo, n)
+      e = use_k20 ? launch_clv_k20_traversal(p, d_ops + lo, n)
                          : launch_clv_traversal(p, d_ops + lo, n, nslots);
     }
     p->prof_end();

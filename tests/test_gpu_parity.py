@@ -632,18 +632,23 @@ def test_many_sites_few_parking_slots_cross_check():
     h.destroy()
 
 
-@pytest.mark.parametrize("n,S,R,seed", [(64, 700, 4, 71), (150, 300, 2, 72), (40, 9000, 4, 73)])
-def test_arbitrary_operation_orders(n, S, R, seed):
+@pytest.mark.parametrize("n,S,R,seed,K", [(64, 700, 4, 71, 4), (150, 300, 2, 72, 4), (40, 9000, 4, 73, 4),
+                                          (48, 333, 4, 74, 20), (30, 100, 3, 75, 20)])
+def test_arbitrary_operation_orders(n, S, R, seed, K):
     """rdamd_update_clvs takes ANY valid list (corax_update_clvs contract), not
     only the post-order the tree emits.  The 4-state kernel forwards children
     through registers and LDS parking slots depending on the order, so feed it
     orders that stress each route: level order (every sibling waits long ->
     slots overflow, values evicted to HBM), reversed-sibling order, the same
     CLV as both children, a child read with a different scaler index than it
-    was written with, and a partial list over CLVs left by an earlier call."""
-    w = synth.workload(n, S, 4, R, seed)
+    was written with, and a partial list over CLVs left by an earlier call.
+    The 20-state kernel forwards only the parent of the operation just before
+    and asks for the next operation's operands before it stores: the host
+    cuts the launch where that would read stale data (case 3)."""
+    w = synth.workload(n, S, K, R, seed)
     tree = rd.Tree.from_newick(w["newick"])
-    g, o = pair(tree, w["seqs"], 4, R)
+    cmap = rd.MAP_NT if K == 4 else util.make_map(w["alphabet"])
+    g, o = pair(tree, w["seqs"], K, R, cmap, cmap if K != 4 else ORC_MAP_NT)
     set_model((g, o), w["subst"], g.empirical_frequencies(), w["rates"])
     rl = tree.root_location(seed % tree.root_count())
     ops, pmi, brl = tree.generate_operations(rl)
