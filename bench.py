@@ -185,7 +185,10 @@ def main():
     params = [synth.random_params(K * K - K, rng) for _ in range(len(mine))]
     roots = [tree.root_location(i) for i in mine]
 
-    use_fused = (K == 4)
+    use_fused = K == 4 or (K == 20 and R <= 4)   # the shapes the fused evaluators take
+    fused_kernel = "fused_dna_eval_kernel" if K == 4 else "fused20_eval_kernel"
+    clv_kernel = ("clv_dna_traversal_kernel" if K == 4 else
+                  "clv_k20_traversal_kernel" if K == 20 else "clv_generic_traversal_kernel")
     nb = args.batch   # fixed per GPU whatever N is (weak scaling)
     params = np.array(params)
     freqs_b = np.tile(np.asarray(freqs), (len(mine), 1))
@@ -211,7 +214,7 @@ def main():
         idx = [(s * nb + b) % len(mine) for b in range(nb)]
         # every job of every step is a distinct (root, parameter set) pair
         jitter = 1.0 + 1e-3 * (((s % 97) + 1) + np.arange(nb)[:, None] / (4.0 * nb))
-        sub = params[idx] * jitter * (1.0 + 0.05 * np.sin(np.arange(12) + s))
+        sub = params[idx] * jitter * (1.0 + 0.05 * np.sin(np.arange(K * K - K) + s))
         if site_sharded:
             row = s - args.warmup
             lnl_dev = lnl_rows[row] if 0 <= row < args.steps else lnl_warm
@@ -269,8 +272,7 @@ def main():
     def clv_roofline(ms, launches, evals):
         bytes_clv = clv_kernel_bytes(n, S, R, K) * evals
         achieved = bytes_clv / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-        return {"kernel": ("clv_dna_traversal_kernel" if K == 4 else "clv_k20_traversal_kernel" if K == 20 else "clv_generic_traversal_kernel"),
-                "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+        return {"kernel": clv_kernel, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                 "bytes_per_launch": round(bytes_clv / max(launches, 1)),
                 "avg_launch_ms": round(ms / max(launches, 1), 5), "launches": launches}
@@ -287,24 +289,26 @@ def main():
         # The fused traversal never materialises a CLV, so frac > 1 by design;
         # what actually binds the kernel is FP64 FMA issue -> `fp64`.
         roofline = {
-            "kernel": "fused_dna_eval_kernel", "bound": "hbm",
+            "kernel": fused_kernel, "bound": "hbm",
             "achieved": round(hbm_equiv, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(hbm_equiv / HBM_PEAK_GBS, 3), "traffic": None,
             "algorithmic_bytes_per_launch": full_eval_bytes(n, S, R, K) * nb,
             "avg_launch_ms": round(ms / max(launches, 1), 4), "launches": launches,
             "share_of_step": round(ms * 1e-3 / elapsed, 3),
             "note": "fused traversal: CLVs never reach HBM, so the algorithmic-byte rate "
-                    "exceeds the HBM peak; the binding resource is FP64 FMA issue (see fp64)",
-            "fp64": {"bound": "fp64 fma issue", "achieved": round(tf, 2),
+                    "exceeds the HBM peak; the binding resource is FP64 %s (see fp64)"
+                    % ("FMA issue" if K == 4 else "matrix-core issue (v_mfma_f64_4x4x4_4b_f64)"),
+            "fp64": {"bound": "fp64 fma issue" if K == 4 else "fp64 mfma", "achieved": round(tf, 2),
                      "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(tf / FP64_PEAK_TFLOPS, 4),
                      "algorithmic_flops_per_launch": flops / max(launches, 1),
-                     "measured_dfma_ceiling_tflops": 68.4},
+                     ("measured_dfma_ceiling_tflops" if K == 4 else
+                      "measured_mfma_4x4x4_ceiling_tflops"): 68.4 if K == 4 else 73.2},
             "stack_depth": depth,
             "pmatrix_ms_per_launch": round(prof["fused_pmatrix"][0] / max(prof["fused_pmatrix"][1], 1), 4),
         }
         roofline["traffic"], roofline["traffic_source"] = profiled_traffic(
-            "fused_dna_eval_kernel", nb, args.config)
+            fused_kernel, nb, args.config)
         # second leg: the materialising CLV kernel (drop-in rdamd_update_clvs
         # path), HBM-bound.  The traversals are queued back to back without a
         # host sync in between, so the event-timed spans carry no launch gaps.
@@ -320,7 +324,7 @@ def main():
         part.profile_enable(False)
         extra["clv_kernel"] = clv_roofline(p2["clv"][0], p2["clv"][1], 6)
         extra["clv_kernel"]["traffic"], extra["clv_kernel"]["traffic_source"] = profiled_traffic(
-            "clv_dna_traversal_kernel", nb, args.config)
+            clv_kernel, nb, args.config)
     else:
         roofline = clv_roofline(prof["clv"][0], prof["clv"][1], evals_per_rank)
 

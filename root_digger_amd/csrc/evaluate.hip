@@ -59,27 +59,27 @@ static hipError_t ensure_workspace(rdamd_partition *p, unsigned n_jobs) {
   if (w->h_in) (void)hipHostFree(w->h_in);
   *w = FusedWorkspace();
   const unsigned cap = std::max(16u, n_jobs + n_jobs / 2);
-  const unsigned R = p->rate_cats;
-  // site blocks padded to a multiple of 8 so that blockIdx.x % 8 (the XCD a
-  // workgroup lands on) is the same for every job: each XCD's L2 then only
-  // ever sees 1/8 of the tip codes.
+  const unsigned R = p->rate_cats, K = p->states;
+  // 4 states: site blocks padded to a multiple of 8 so that blockIdx.x % 8 (the
+  // XCD a workgroup lands on) is the same for every job: each XCD's L2 then only
+  // ever sees 1/8 of the tip codes.  20 states: one partial per 16-site tile.
   const unsigned per_block = 64 * kFusedSitesPerLane;
-  w->blocks_x = ((p->sites + per_block - 1) / per_block + 7) / 8 * 8;
-  const size_t pm_per_job = (size_t)p->prob_matrices * R * 16;
+  w->blocks_x = K == 4 ? ((p->sites + per_block - 1) / per_block + 7) / 8 * 8 : (p->sites + 15) / 16;
+  const size_t pm_per_job = (size_t)p->prob_matrices * R * K * K;
 #define A(ptr, bytes) do { e = hipMalloc((void **)&(ptr), (bytes)); if (e != hipSuccess) return e; } while (0)
   A(w->d_jobs, sizeof(FusedJob) * cap);
-  A(w->d_q, sizeof(double) * 16 * cap);
+  A(w->d_q, sizeof(double) * K * K * cap);
   A(w->d_rates, sizeof(double) * R * cap);
-  A(w->d_freqs, sizeof(double) * 4 * cap);
+  A(w->d_freqs, sizeof(double) * K * cap);
   A(w->d_rw, sizeof(double) * R * cap);
   A(w->d_pmat, sizeof(double) * pm_per_job * cap);
-  A(w->d_tiptab, sizeof(double) * pm_per_job * 4 * cap);
+  if (K == 4) A(w->d_tiptab, sizeof(double) * pm_per_job * 4 * cap);
   A(w->d_partials, sizeof(double) * w->blocks_x * cap);
   A(w->d_out, sizeof(double) * cap);
 #undef A
   e = hipHostMalloc((void **)&w->h_out, sizeof(double) * cap, hipHostMallocDefault);
   if (e != hipSuccess) return e;
-  w->h_in_bytes = (size_t)cap * (sizeof(FusedJob) + sizeof(double) * (16 + 4 + 2 * R));
+  w->h_in_bytes = (size_t)cap * (sizeof(FusedJob) + sizeof(double) * (K * K + K + 2 * R));
   e = hipHostMalloc((void **)&w->h_in, w->h_in_bytes, hipHostMallocDefault);
   if (e != hipSuccess) return e;
   w->cap_jobs = cap;
@@ -94,6 +94,8 @@ static hipError_t ensure_workspace(rdamd_partition *p, unsigned n_jobs) {
 struct Compiler {
   const rdamd_operation_t *ops;
   unsigned n_ops, tips, sites, tip_stride, rate_cats;
+  unsigned unit = 0;         // bytes between the [rate 0] entries of consecutive matrices
+  bool split_park = false;   // 20-state programs: parking is a step of its own
   std::unordered_map<unsigned, unsigned> producer;   // clv -> op index
   std::vector<unsigned> need;                        // stack slots a subtree needs
   std::vector<FusedOp> out;
@@ -133,6 +135,15 @@ struct Compiler {
         if (depth == 0) spill |= 2;   // level 0 is a register slot in the kernel
         ++depth;
         max_depth = std::max(max_depth, depth);
+        if (split_park) {
+          FusedOp park;
+          memset(&park, 0, sizeof(park));
+          park.pM = matM * unit;
+          park.flags = kFusedPark;
+          out.push_back(park);
+          matM = 0;
+          spill = 0;
+        }
       }
     } else if (i1 != i2) {
       const bool first_inner = i1;
@@ -153,12 +164,12 @@ struct Compiler {
       --depth;
       if (depth == 0) spill |= 4;     // the popped sibling sits in the register slot
     }
-    f.pM = matM * rate_cats * 128u;
-    f.tX = matX * rate_cats * 128u;
-    f.tY = matY * rate_cats * 128u;
+    f.pM = matM * unit;
+    f.tX = matX * unit;
+    f.tY = matY * unit;
     f.cX = tipX_row * tip_stride;
     f.cY = tipY_row * tip_stride;
-    f.flags = kind | (spill << 8);
+    f.flags = kind | (split_park ? 0u : spill << 8);
     out.push_back(f);
   }
 };
@@ -175,19 +186,23 @@ rdamd_schedule_t *rdamd_schedule_create(rdamd_partition_t *p, const rdamd_operat
                                         const double *branch_lengths,
                                         unsigned int n_matrices) {
   clear_error();
-  if (p->states != 4) {
-    set_error(40, "rdamd_schedule_create: the fused evaluator handles 4-state data; use "
-                  "rdamd_update_clvs for %u states", p->states);
+  const bool k20 = p->states == 20 && p->rate_cats <= 4;
+  if (p->states != 4 && !k20) {
+    set_error(40, "rdamd_schedule_create: the fused evaluator handles 4-state data and 20-state "
+                  "data with up to 4 rate categories; use rdamd_update_clvs for %u states, %u "
+                  "categories", p->states, p->rate_cats);
     return nullptr;
   }
   if (n_ops == 0 || (size_t)p->tips * p->tip_stride() > 0xffffffffu ||
-      (size_t)p->prob_matrices * p->rate_cats * 512 > 0xffffffffu) {
+      (size_t)p->prob_matrices * p->rate_cats * (k20 ? 3200 : 512) > 0xffffffffu) {
     set_error(41, "rdamd_schedule_create: empty operation list, or partition too large for "
                   "32-bit offsets (tips*sites or matrices*rates*512 >= 4 GiB)");
     return nullptr;
   }
   Compiler c;
   c.ops = ops; c.n_ops = n_ops; c.tips = p->tips; c.sites = p->sites; c.tip_stride = p->tip_stride(); c.rate_cats = p->rate_cats;
+  c.unit = p->rate_cats * (k20 ? 3200u : 128u);
+  c.split_park = k20;
   const unsigned nclv = p->tips + p->clv_buffers;
   for (unsigned i = 0; i < n_ops; ++i) {
     const rdamd_operation_t &o = ops[i];
@@ -210,9 +225,12 @@ rdamd_schedule_t *rdamd_schedule_create(rdamd_partition_t *p, const rdamd_operat
   c.compute_need(n_ops - 1);
   c.out.reserve(n_ops);
   c.emit(n_ops - 1, false, 0);
-  if (c.out.size() != n_ops) {
+  size_t n_steps = c.out.size(), n_real = 0;
+  for (const FusedOp &f : c.out)
+    if (!c.split_park || (f.flags & 3u) != kFusedPark) ++n_real;
+  if (n_real != n_ops) {
     set_error(43, "rdamd_schedule_create: %u of %u operations are not reachable from the "
-                  "root operation", (unsigned)(n_ops - c.out.size()), n_ops);
+                  "root operation", (unsigned)(n_ops - n_real), n_ops);
     return nullptr;
   }
   std::vector<double> brlen(p->prob_matrices, 0.0);
@@ -227,7 +245,10 @@ rdamd_schedule_t *rdamd_schedule_create(rdamd_partition_t *p, const rdamd_operat
   }
   rdamd_schedule *s = new rdamd_schedule();
   // LDS levels = stack depth minus the register level (at least one is allocated)
-  s->part = p; s->n_ops = n_ops; s->depth = std::max(1u, c.max_depth > 0 ? c.max_depth - 1 : 0);
+  // (20 states: every level lives in LDS and parking steps count as steps)
+  s->part = p; s->n_ops = (unsigned)n_steps;
+  s->depth = k20 ? std::max(1u, c.max_depth) : std::max(1u, c.max_depth > 0 ? c.max_depth - 1 : 0);
+  n_ops = (unsigned)n_steps;
   s->prog = c.out;
   // harmless tail entries: the kernel prefetches descriptors up to i + 3
   for (int k = 0; k < 4; ++k) c.out.push_back(c.out.back());
@@ -257,11 +278,12 @@ static int evaluate_batch_impl(rdamd_partition_t *p, unsigned int n_jobs,
                                double *lnl_host, void *lnl_device) {
   clear_error();
   if (n_jobs == 0) return RDAMD_SUCCESS;
-  if (p->states != 4) {
-    set_error(40, "rdamd_evaluate_batch: 4-state data only");
+  const bool k20 = p->states == 20 && p->rate_cats <= 4;
+  if (p->states != 4 && !k20) {
+    set_error(40, "rdamd_evaluate_batch: 4-state data, or 20-state data with up to 4 rate categories");
     return RDAMD_FAILURE;
   }
-  const unsigned R = p->rate_cats, NP = 12;
+  const unsigned R = p->rate_cats, K = p->states, NP = K * K - K;
   if (p->sites == 0) {   // an empty alignment has likelihood 1
     if (lnl_host) std::fill(lnl_host, lnl_host + n_jobs, 0.0);
     if (lnl_device)
@@ -275,8 +297,8 @@ static int evaluate_batch_impl(rdamd_partition_t *p, unsigned int n_jobs,
   RDAMD_HIP_TRY(hipStreamSynchronize(p->stream), RDAMD_FAILURE);
   char *h = w->h_in;
   FusedJob *hj = (FusedJob *)h;          h += sizeof(FusedJob) * n_jobs;
-  double *hq = (double *)h;              h += sizeof(double) * 16 * n_jobs;
-  double *hf = (double *)h;              h += sizeof(double) * 4 * n_jobs;
+  double *hq = (double *)h;              h += sizeof(double) * K * K * n_jobs;
+  double *hf = (double *)h;              h += sizeof(double) * K * n_jobs;
   double *hr = (double *)h;              h += sizeof(double) * R * n_jobs;
   double *hw = (double *)h;
   unsigned max_depth = 1;
@@ -290,7 +312,7 @@ static int evaluate_batch_impl(rdamd_partition_t *p, unsigned int n_jobs,
     hj[j].depth = 0;   // patched below: every block uses the launch-wide depth
     max_depth = std::max(max_depth, s->depth);
     double wide_s[12] = {0}, wide_f[4] = {0};
-    const double *sj = subst + (size_t)j * NP, *fj = freqs + (size_t)j * 4;
+    const double *sj = subst + (size_t)j * NP, *fj = freqs + (size_t)j * K;
     if (p->embedded()) {   // caller passes [n][2] / [n][2]: into the 4-state shapes
       wide_s[0] = subst[(size_t)j * 2];
       wide_s[3] = subst[(size_t)j * 2 + 1];
@@ -299,8 +321,8 @@ static int evaluate_batch_impl(rdamd_partition_t *p, unsigned int n_jobs,
       sj = wide_s;
       fj = wide_f;
     }
-    build_q_host(4, sj, fj, hq + (size_t)j * 16);
-    for (unsigned k = 0; k < 4; ++k) hf[(size_t)j * 4 + k] = fj[k];
+    build_q_host(K, sj, fj, hq + (size_t)j * K * K);
+    for (unsigned k = 0; k < K; ++k) hf[(size_t)j * K + k] = fj[k];
     for (unsigned r = 0; r < R; ++r) {
       hr[(size_t)j * R + r] = rates ? rates[(size_t)j * R + r] : p->rates[r];
       hw[(size_t)j * R + r] = rate_weights ? rate_weights[(size_t)j * R + r] : p->rate_weights[r];
@@ -308,11 +330,29 @@ static int evaluate_batch_impl(rdamd_partition_t *p, unsigned int n_jobs,
   }
   for (unsigned j = 0; j < n_jobs; ++j) hj[j].depth = max_depth;
   RDAMD_HIP_TRY(hipMemcpyAsync(w->d_jobs, hj, sizeof(FusedJob) * n_jobs, hipMemcpyHostToDevice, p->stream), RDAMD_FAILURE);
-  RDAMD_HIP_TRY(hipMemcpyAsync(w->d_q, hq, sizeof(double) * 16 * n_jobs, hipMemcpyHostToDevice, p->stream), RDAMD_FAILURE);
-  RDAMD_HIP_TRY(hipMemcpyAsync(w->d_freqs, hf, sizeof(double) * 4 * n_jobs, hipMemcpyHostToDevice, p->stream), RDAMD_FAILURE);
+  RDAMD_HIP_TRY(hipMemcpyAsync(w->d_q, hq, sizeof(double) * K * K * n_jobs, hipMemcpyHostToDevice, p->stream), RDAMD_FAILURE);
+  RDAMD_HIP_TRY(hipMemcpyAsync(w->d_freqs, hf, sizeof(double) * K * n_jobs, hipMemcpyHostToDevice, p->stream), RDAMD_FAILURE);
   RDAMD_HIP_TRY(hipMemcpyAsync(w->d_rates, hr, sizeof(double) * R * n_jobs, hipMemcpyHostToDevice, p->stream), RDAMD_FAILURE);
   RDAMD_HIP_TRY(hipMemcpyAsync(w->d_rw, hw, sizeof(double) * R * n_jobs, hipMemcpyHostToDevice, p->stream), RDAMD_FAILURE);
 
+  double *d_out = lnl_device ? (double *)lnl_device : w->d_out;
+  hipError_t e;
+  if (k20) {
+    Fused20Args b;
+    b.jobs = w->d_jobs; b.tipcodes = p->d_tipcodes; b.tip_stride = p->tip_stride();
+    b.codemask = p->d_codemask; b.pattern_weights = p->d_pattern_weights;
+    b.pmat = w->d_pmat; b.freqs = w->d_freqs; b.rate_weights = w->d_rw; b.partials = w->d_partials;
+    b.pmat_job_stride = (size_t)p->prob_matrices * R * K * K;
+    b.sites = p->sites; b.rate_cats = R; b.tiles = w->blocks_x;
+    p->prof_begin(4);
+    e = launch_fused20_pmatrix(b, w->d_q, w->d_rates, n_jobs, p->prob_matrices, p->stream);
+    p->prof_end();
+    RDAMD_HIP_TRY(e, RDAMD_FAILURE);
+    p->prof_begin(3);
+    e = launch_fused20_eval(b, n_jobs, max_depth, d_out, p->stream);
+    p->prof_end();
+    RDAMD_HIP_TRY(e, RDAMD_FAILURE);
+  } else {
   FusedArgs a;
   a.jobs = w->d_jobs; a.tipcodes = p->d_tipcodes; a.pattern_weights = p->d_pattern_weights;
   a.pmat = w->d_pmat; a.tiptab = w->d_tiptab; a.freqs = w->d_freqs; a.rate_weights = w->d_rw;
@@ -321,14 +361,14 @@ static int evaluate_batch_impl(rdamd_partition_t *p, unsigned int n_jobs,
   a.sites = p->sites; a.rate_cats = R;
   a.tipcodes_bytes = (unsigned)std::min<size_t>((size_t)p->tips * p->tip_stride(), 0xffffffffu);
   p->prof_begin(4);
-  hipError_t e = launch_fused_pmatrix(a, w->d_q, w->d_rates, n_jobs, p->prob_matrices, p->stream);
+  e = launch_fused_pmatrix(a, w->d_q, w->d_rates, n_jobs, p->prob_matrices, p->stream);
   p->prof_end();
   RDAMD_HIP_TRY(e, RDAMD_FAILURE);
-  double *d_out = lnl_device ? (double *)lnl_device : w->d_out;
   p->prof_begin(3);
   e = launch_fused_eval(a, n_jobs, max_depth, w->blocks_x, d_out, p->stream);
   p->prof_end();
   RDAMD_HIP_TRY(e, RDAMD_FAILURE);
+  }
   if (lnl_host) {
     RDAMD_HIP_TRY(hipMemcpyAsync(w->h_out, d_out, sizeof(double) * n_jobs, hipMemcpyDeviceToHost, p->stream), RDAMD_FAILURE);
     RDAMD_HIP_TRY(hipStreamSynchronize(p->stream), RDAMD_FAILURE);

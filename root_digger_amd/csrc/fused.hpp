@@ -13,6 +13,7 @@ enum : uint32_t {
   kFusedTT = 0,   // both children are tips
   kFusedRT = 1,   // X = running CLV (register), Y = tip
   kFusedRP = 2,   // X = running CLV (register), Y = popped from the LDS stack
+  kFusedPark = 3, // 20-state programs only: push M . (running CLV) as a step of its own
 };
 
 // sites each lane of the fused kernel carries.  2 halves the scalar work per
@@ -55,6 +56,29 @@ struct FusedArgs {
   unsigned sites, rate_cats;
   unsigned tipcodes_bytes;           // tips * tip_stride
 };
+
+// ---- 20-state variant (kernels_fused_k20.hip) ---------------------------------
+// Same programs (pM / tX / tY are byte offsets of [matrix][rate 0] inside one
+// job's MFMA-ready P copies, 3200 bytes per (matrix, rate)); a TT step never
+// parks -- the compiler emits a kFusedPark step before it instead, so a step
+// multiplies by at most two matrices.
+struct Fused20Args {
+  const FusedJob *jobs;
+  const uint8_t  *tipcodes;          // [tips][tip_stride]
+  unsigned        tip_stride;
+  const uint64_t *codemask;          // [256] code -> state mask
+  const unsigned *pattern_weights;   // [sites]
+  const double   *pmat;              // [job][matrix][rate][400]  MFMA-ready (kernels_clv_mfma.hip)
+  const double   *freqs;             // [job][20]
+  const double   *rate_weights;      // [job][R]
+  double         *partials;          // [job][tiles]
+  size_t   pmat_job_stride;          // doubles per job
+  unsigned sites, rate_cats, tiles;
+};
+hipError_t launch_fused20_pmatrix(const Fused20Args &a, const double *d_q, const double *d_rates,
+                                  unsigned n_jobs, unsigned n_mat, hipStream_t stream);
+hipError_t launch_fused20_eval(const Fused20Args &a, unsigned n_jobs, unsigned max_depth,
+                               double *d_out, hipStream_t stream);
 
 hipError_t launch_fused_pmatrix(const FusedArgs &a, const double *d_q, const double *d_rates,
                                 unsigned n_jobs, unsigned n_mat, hipStream_t stream);

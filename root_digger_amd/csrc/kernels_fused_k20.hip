@@ -1,0 +1,361 @@
+// Fused full-traversal evaluator, 20-state data.
+//
+// The 20-state sibling of kernels_fused.hip: one launch evaluates a batch of
+// (schedule, parameter set) jobs -- the body of model_t::compute_lh_partition
+// (/root/reference/src/model.cpp:454-476: corax_update_clvs followed by
+// corax_compute_root_loglikelihood) -- without materialising any CLV in HBM,
+// so it has no store stream at all (the materialising 20-state kernel,
+// kernels_clv_mfma.hip, is held back by exactly that: DESIGN.md 4.2).
+//
+// Arithmetic: the same v_mfma_f64_4x4x4_4b_f64 tiling and lane layout as
+// kernels_clv_mfma.hip -- one wave = (16 sites, one rate), a lane holds states
+// {4 s + grp} of site `col` both as MFMA B operand and as MFMA result, a
+// matrix-vector product is 25 MFMAs in five independent chains.  A operands
+// come from the job's MFMA-ready P copies as contiguous 16-byte pieces,
+// requested one step ahead and redistributed through wave-private LDS.
+//
+// Control: a wave walks the job's compiled program (evaluate.hip) with the
+// running CLV in registers and pending siblings on a wave-private LDS stack
+// whose depth the host minimised.  Nothing is shared between waves until the
+// root, so there is no barrier in the loop: each (site, rate) keeps its own
+// 2^256 rescale count (decided by a ballot folded on the scalar unit) and the
+// root sum aligns the rate terms to the smallest count -- the per-rate-scaler
+// form of the reference rule, as in kernels_fused.hip.
+#include "common.hpp"
+#include "fused.hpp"
+
+namespace rdamd {
+
+namespace {
+
+constexpr int kK = 20;
+constexpr int kSteps = 5;            // k steps of 4 = states held per lane
+constexpr int kGroups = 5;           // row groups of 4
+constexpr int kBlocks = kGroups * kSteps;
+constexpr int kCopy = kBlocks * 16;  // doubles per (matrix, rate) copy
+constexpr int kCopyLds = 4 * 64 * 16;   // bytes one copy occupies in LDS (4 pieces per lane)
+constexpr int kLevelBytes = kSteps * 64 * 8 + 64 * 4;   // one stack level: 5 doubles + 1 count per lane
+
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(4))) unsigned *const_u32_ptr;
+
+__device__ __forceinline__ unsigned uni(unsigned x) {
+  return (unsigned)__builtin_amdgcn_readfirstlane((int)x);
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *p, unsigned bytes) {
+  const unsigned long long u = reinterpret_cast<unsigned long long>(p);
+  const unsigned lo = uni((unsigned)u), hi = uni((unsigned)(u >> 32));
+  void *q = reinterpret_cast<void *>(((unsigned long long)hi << 32) | lo);
+  return __builtin_amdgcn_make_buffer_rsrc(q, 0, (int)uni(bytes), 0x00020000);
+}
+__device__ __forceinline__ const_u32_ptr scalar_ptr(const void *p) {
+  const unsigned long long u = reinterpret_cast<unsigned long long>(p);
+  return (const_u32_ptr)(((unsigned long long)uni((unsigned)(u >> 32)) << 32) | uni((unsigned)u));
+}
+__device__ __forceinline__ double pow2_neg256(int d) {   // exact 2^(-256 d), 0 once it underflows
+  return d == 0 ? 1.0 : (d == 1 ? kScaleThreshold
+       : (d == 2 ? kScaleThreshold * kScaleThreshold
+       : (d == 3 ? kScaleThreshold * kScaleThreshold * kScaleThreshold : 0.0)));
+}
+
+struct Step {   // the six leading words of a FusedOp
+  unsigned pM, tX, tY, cX, cY, flags;
+};
+__device__ __forceinline__ Step load_step(const_u32_ptr prog, unsigned i) {
+  const const_u32_ptr w = prog + (size_t)i * (sizeof(FusedOp) / 4);
+  return Step{w[0], w[1], w[2], w[3], w[4], w[5]};
+}
+
+}  // namespace
+
+// ---- P-matrices of a batch, straight into the MFMA-ready layout ---------------
+// One workgroup per (job, matrix, rate); same scaling-and-squaring / 16-term
+// Taylor core as pmatrix_generic_kernel.
+__global__ void __launch_bounds__(256)
+fused20_pmatrix_kernel(const double *__restrict__ q, const double *__restrict__ rates,
+                       const FusedJob *__restrict__ jobs, unsigned n_mat, unsigned R,
+                       double *__restrict__ pmat, size_t pmat_job_stride) {
+  __shared__ double x[kK * kK], term[kK * kK], out[kK * kK], tmp[kK * kK], red[kK];
+  const unsigned per_job = n_mat * R;
+  const unsigned job = blockIdx.x / per_job, rem = blockIdx.x % per_job;
+  const unsigned m = rem / R, r = rem % R;
+  const unsigned tid = threadIdx.x, nt = blockDim.x;
+  const double t = jobs[job].brlen[m] * rates[(size_t)job * R + r];
+  const double *qq = q + (size_t)job * (kK * kK);
+  for (unsigned e = tid; e < kK * kK; e += nt) x[e] = qq[e] * t;
+  __syncthreads();
+  for (unsigned j = tid; j < kK; j += nt) {
+    double cs = 0.0;
+    for (unsigned i = 0; i < kK; ++i) cs += fabs(x[i * kK + j]);
+    red[j] = cs;
+  }
+  __syncthreads();
+  double norm = 0.0;
+  for (unsigned j = 0; j < kK; ++j) norm = fmax(norm, red[j]);
+  int s = 0;
+  double scale = 1.0;
+  while (norm * scale > 0.25 && s < 60) { scale *= 0.5; ++s; }
+  __syncthreads();
+  for (unsigned e = tid; e < kK * kK; e += nt) {
+    x[e] *= scale;
+    term[e] = out[e] = (e / kK == e % kK) ? 1.0 : 0.0;
+  }
+  __syncthreads();
+  for (int k = 1; k <= 16; ++k) {
+    const double inv = 1.0 / (double)k;
+    for (unsigned e = tid; e < kK * kK; e += nt) {
+      const unsigned i = e / kK, j = e % kK;
+      double acc = 0.0;
+      for (unsigned l = 0; l < kK; ++l) acc += term[i * kK + l] * x[l * kK + j];
+      tmp[e] = acc * inv;
+    }
+    __syncthreads();
+    for (unsigned e = tid; e < kK * kK; e += nt) { term[e] = tmp[e]; out[e] += tmp[e]; }
+    __syncthreads();
+  }
+  for (int k = 0; k < s; ++k) {
+    for (unsigned e = tid; e < kK * kK; e += nt) {
+      const unsigned i = e / kK, j = e % kK;
+      double acc = 0.0;
+      for (unsigned l = 0; l < kK; ++l) acc += out[i * kK + l] * out[l * kK + j];
+      tmp[e] = acc;
+    }
+    __syncthreads();
+    for (unsigned e = tid; e < kK * kK; e += nt) out[e] = tmp[e];
+    __syncthreads();
+  }
+  // element (rg, ks, k, i) of the copy = P[4 rg + i][4 ks + k]  (kernels_clv_mfma.hip)
+  double *o = pmat + (size_t)job * pmat_job_stride + ((size_t)m * R + r) * kCopy;
+  for (unsigned e = tid; e < (unsigned)kCopy; e += nt) {
+    const unsigned i = e & 3, k = (e >> 2) & 3, blk = e >> 4, ks = blk % kSteps, rg = blk / kSteps;
+    const double v = out[(4 * rg + i) * kK + 4 * ks + k];
+    o[e] = v < 0.0 ? 0.0 : v;
+  }
+}
+
+// ---- the evaluator ---------------------------------------------------------------
+// grid = (16-site tiles, jobs); workgroup = R waves, wave r = rate category r.
+// Dynamic LDS: [code masks 2 KB][root exchange R x 16 x (8 + 4) B][per wave:
+// two A copies (8 KB) + `depth` stack levels].
+__global__ void __launch_bounds__(256)
+fused20_eval_kernel(Fused20Args a, unsigned depth) {
+  extern __shared__ char lds_raw[];
+  const unsigned R = a.rate_cats, S = a.sites;
+  const unsigned lane = threadIdx.x & 63, r = uni(threadIdx.x >> 6);
+  const unsigned col = lane & 15, grp = lane >> 4;
+  const unsigned job = blockIdx.y;
+  const unsigned site = blockIdx.x * 16 + col;
+  const unsigned ls = site < S ? site : S - 1;   // clamped for loads
+
+  uint64_t *masks = reinterpret_cast<uint64_t *>(lds_raw);
+  double *root_f = reinterpret_cast<double *>(lds_raw + 2048);
+  int *root_sc = reinterpret_cast<int *>(lds_raw + 2048 + R * 16 * 8);
+  const unsigned wave_bytes = 2 * kCopyLds + depth * kLevelBytes;
+  char *mine = lds_raw + 2048 + R * 16 * 12 + r * wave_bytes;
+  char *a_lds = mine;                        // [2 products][4 pieces][64 lanes][16 B]
+  char *stack = mine + 2 * kCopyLds;         // [level][5][64] doubles, then [64] counts
+  for (unsigned e = threadIdx.x; e < 256; e += blockDim.x) masks[e] = a.codemask[e];
+  __syncthreads();
+
+  const FusedJob jb = a.jobs[job];
+  const const_u32_ptr prog = scalar_ptr(jb.prog);   // n_ops + 4 entries (tail padded)
+  const unsigned nops = jb.n_ops;
+  const char *pm_job = reinterpret_cast<const char *>(a.pmat + (size_t)job * a.pmat_job_stride);
+  const unsigned a_off = (grp * 4 + (col & 3)) * 8u;   // my element of every 4x4 block
+
+  // the loads one step needs, all unconditional (an unused one gets an empty descriptor)
+  u32x4 raw1[4], raw2[4];
+  unsigned code1, code2;
+  auto request = [&](const Step &st) {
+    const unsigned kind = st.flags & 3u;
+    const bool two = kind == kFusedTT || kind == kFusedRT;      // a second product (a tip's)
+    const unsigned off1 = kind == kFusedTT ? st.tX : st.pM;
+    const __amdgpu_buffer_rsrc_t rs1 = make_rsrc(pm_job + off1 + (size_t)r * (kCopy * 8), kCopy * 8);
+    const __amdgpu_buffer_rsrc_t rs2 = make_rsrc(pm_job + st.tY + (size_t)r * (kCopy * 8), two ? kCopy * 8 : 0);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      raw1[k] = __builtin_amdgcn_raw_buffer_load_b128(rs1, (int)(lane * 16u + 1024u * k), 0, 0);
+      raw2[k] = __builtin_amdgcn_raw_buffer_load_b128(rs2, (int)(lane * 16u + 1024u * k), 0, 0);
+    }
+    const __amdgpu_buffer_rsrc_t c1 = make_rsrc(a.tipcodes + st.cX, kind == kFusedTT ? a.tip_stride : 0u);
+    const __amdgpu_buffer_rsrc_t c2 = make_rsrc(a.tipcodes + st.cY, two ? a.tip_stride : 0u);
+    code1 = (unsigned)__builtin_amdgcn_raw_buffer_load_b8(c1, (int)ls, 0, 0);
+    code2 = (unsigned)__builtin_amdgcn_raw_buffer_load_b8(c2, (int)ls, 0, 0);
+  };
+  auto stage = [&]() {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      *reinterpret_cast<u32x4 *>(a_lds + lane * 16u + 1024u * k) = raw1[k];
+      *reinterpret_cast<u32x4 *>(a_lds + kCopyLds + lane * 16u + 1024u * k) = raw2[k];
+    }
+  };
+  // d = A(copy `which` in LDS) . b : five chains of five MFMAs
+  auto product = [&](int which, const double (&b)[kSteps], double (&d)[kGroups]) {
+    const char *ap = a_lds + which * kCopyLds + a_off;
+    double aa[kBlocks];
+#pragma unroll
+    for (int j = 0; j < kBlocks; ++j) aa[j] = *reinterpret_cast<const double *>(ap + 128 * j);
+#pragma unroll
+    for (int t = 0; t < kGroups; ++t) {
+      d[t] = 0.0;
+#pragma unroll
+      for (int s = 0; s < kSteps; ++s)
+        d[t] = __builtin_amdgcn_mfma_f64_4x4x4f64(aa[t * kSteps + s], b[s], d[t], 0, 0, 0);
+    }
+  };
+  auto tip_vector = [&](unsigned code, double (&b)[kSteps]) {
+    const uint64_t m = masks[code & 255u] >> grp;
+#pragma unroll
+    for (int s = 0; s < kSteps; ++s) b[s] = ((m >> (4 * s)) & 1) ? 1.0 : 0.0;
+  };
+
+  double v[kSteps];   // the running CLV: states 4 s + grp of site col
+  int sc = 0;         // its 2^256 rescale count
+#pragma unroll
+  for (int s = 0; s < kSteps; ++s) v[s] = 0.0;
+  unsigned sp = 0;
+
+  Step cur = load_step(prog, 0);
+  Step nxt = load_step(prog, 1);
+  request(cur);
+  stage();
+  unsigned ccode1 = code1, ccode2 = code2;   // tip codes of the current step
+
+  for (unsigned i = 0; i < nops; ++i) {
+    const Step nx2 = load_step(prog, i + 2);
+    const unsigned kind = cur.flags & 3u;
+    // B operands and the A copies of this step (staged at the end of the last one)
+    double b1[kSteps], b2[kSteps], d1[kGroups], d2[kGroups];
+    if (kind == kFusedTT) {
+      tip_vector(ccode1, b1);
+    } else {
+#pragma unroll
+      for (int s = 0; s < kSteps; ++s) b1[s] = v[s];
+    }
+    tip_vector(ccode2, b2);
+    // next step's operands are requested now, a whole step ahead
+    request(nxt);
+    product(0, b1, d1);
+    if (kind == kFusedTT || kind == kFusedRT) product(1, b2, d2);
+    if (kind == kFusedPark) {          // push M . (running CLV); the next step is a TT
+      double *lv = reinterpret_cast<double *>(stack + sp * kLevelBytes) + lane;
+#pragma unroll
+      for (int s = 0; s < kSteps; ++s) lv[s * 64] = d1[s];
+      reinterpret_cast<int *>(stack + sp * kLevelBytes + kSteps * 64 * 8)[lane] = sc;
+      ++sp;
+    } else {
+      if (kind == kFusedRP) {          // the sibling was multiplied by its matrix when parked
+        --sp;
+        const double *lv = reinterpret_cast<const double *>(stack + sp * kLevelBytes) + lane;
+#pragma unroll
+        for (int s = 0; s < kSteps; ++s) d2[s] = lv[s * 64];
+        sc += reinterpret_cast<const int *>(stack + sp * kLevelBytes + kSteps * 64 * 8)[lane];
+      } else if (kind == kFusedTT) {
+        sc = 0;
+      }
+      bool small = true;
+#pragma unroll
+      for (int s = 0; s < kSteps; ++s) {
+        v[s] = d1[s] * d2[s];
+        small = small && (v[s] < kScaleThreshold);
+      }
+      // all 20 entries of a (site, rate) sit in the four lanes col + 16 g
+      unsigned long long bm = __ballot(small);
+      bm &= bm >> 32;
+      bm &= bm >> 16;
+      if ((bm >> col) & 1ull) {
+#pragma unroll
+        for (int s = 0; s < kSteps; ++s) v[s] *= kScaleFactor;
+        sc += 1;
+      }
+    }
+    // the next step's A copies replace this one's in LDS
+    stage();
+    ccode1 = code1; ccode2 = code2;
+    cur = nxt;
+    nxt = nx2;
+  }
+
+  // root: f_r = sum_k pi_k v[k] for my site and rate, then the rate sum
+  const double *freqs = a.freqs + (size_t)job * kK;
+  double f = 0.0;
+#pragma unroll
+  for (int s = 0; s < kSteps; ++s) f += freqs[4 * s + grp] * v[s];
+  f += __shfl_xor(f, 16);
+  f += __shfl_xor(f, 32);
+  if (grp == 0) {
+    root_f[r * 16 + col] = f * a.rate_weights[(size_t)job * R + r];
+    root_sc[r * 16 + col] = sc;
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    double l = 0.0;
+    if (lane < 16) {
+      double term = root_f[lane];
+      int smin = root_sc[lane];
+      for (unsigned q = 1; q < R; ++q) {
+        const double fq = root_f[q * 16 + lane];
+        const int sq = root_sc[q * 16 + lane];
+        if (sq >= smin) {
+          term += fq * pow2_neg256(sq - smin);
+        } else {
+          term = term * pow2_neg256(smin - sq) + fq;
+          smin = sq;
+        }
+      }
+      l = log(term) + (double)smin * kLogScaleThreshold;
+      l *= (double)a.pattern_weights[ls];
+      if (site >= S) l = 0.0;
+    }
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) l += __shfl_down(l, off);
+    if (lane == 0) a.partials[(size_t)job * a.tiles + blockIdx.x] = l;
+  }
+}
+
+// fixed-order finish, one workgroup per job
+__global__ void __launch_bounds__(256)
+fused20_finish_kernel(const double *__restrict__ partials, unsigned per_job,
+                      double *__restrict__ out) {
+  __shared__ double lds[4];
+  const double *p = partials + (size_t)blockIdx.x * per_job;
+  double acc = 0.0;
+  for (unsigned i = threadIdx.x; i < per_job; i += 256) acc += p[i];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+  if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) out[blockIdx.x] = ((lds[0] + lds[1]) + lds[2]) + lds[3];
+}
+
+hipError_t launch_fused20_pmatrix(const Fused20Args &a, const double *d_q, const double *d_rates,
+                                  unsigned n_jobs, unsigned n_mat, hipStream_t stream) {
+  const size_t total = (size_t)n_jobs * n_mat * a.rate_cats;
+  if (!total) return hipSuccess;
+  fused20_pmatrix_kernel<<<(unsigned)total, 256, 0, stream>>>(
+      d_q, d_rates, a.jobs, n_mat, a.rate_cats, const_cast<double *>(a.pmat), a.pmat_job_stride);
+  return hipGetLastError();
+}
+
+size_t fused20_lds_bytes(unsigned R, unsigned depth) {
+  return 2048 + (size_t)R * 16 * 12 + (size_t)R * (2 * kCopyLds + (size_t)depth * kLevelBytes);
+}
+
+hipError_t launch_fused20_eval(const Fused20Args &a, unsigned n_jobs, unsigned max_depth,
+                               double *d_out, hipStream_t stream) {
+  if (!n_jobs) return hipSuccess;
+  const size_t lds = fused20_lds_bytes(a.rate_cats, max_depth);
+  if (lds > 64 * 1024) {   // more than 64 KB of LDS per workgroup has to be asked for
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fused20_eval_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
+  fused20_eval_kernel<<<dim3(a.tiles, n_jobs), 64 * a.rate_cats, lds, stream>>>(a, max_depth);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  fused20_finish_kernel<<<n_jobs, 256, 0, stream>>>(a.partials, a.tiles, d_out);
+  return hipGetLastError();
+}
+
+}  // namespace rdamd

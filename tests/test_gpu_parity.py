@@ -368,6 +368,36 @@ def test_fused_batch_vs_oracle(n, S, R, seed):
         assert util.rel_err(got2[j], want) < LNL_TOL
 
 
+@pytest.mark.parametrize("n,S,R,seed", [(40, 300, 4, 46), (25, 77, 2, 47), (12, 16, 1, 48), (70, 130, 3, 49)])
+def test_fused_batch_20_states_vs_oracle(n, S, R, seed):
+    """the 20-state fused evaluator (kernels_fused_k20.hip): batched jobs with
+    their own parameters, rates and category weights, ragged last tile."""
+    w = synth.workload(n, S, 20, R, seed)
+    tree = rd.Tree.from_newick(w["newick"])
+    rng = np.random.default_rng(seed)
+    weights = rng.integers(1, 4, size=S).astype(np.uint32)
+    cmap = util.make_map(w["alphabet"])
+    g, o = pair(tree, w["seqs"], 20, R, cmap, cmap, weights=weights)
+    g.set_category_rates(w["rates"])
+    picks = rng.choice(tree.root_count(), size=min(5, tree.root_count()), replace=False)
+    rls = [tree.root_location(int(i)).with_ratio(float(rng.uniform(0.02, 0.98))) for i in picks]
+    scheds = [g.schedule(*tree.generate_operations(rl)) for rl in rls]
+    subst = rng.uniform(1e-3, 1.0, (len(rls), 380))
+    freqs = rng.dirichlet(np.ones(20) * 5, len(rls))
+    rates = np.array([rd.compute_gamma_cats(a, R) for a in rng.uniform(0.3, 3.0, len(rls))])
+    cw = rng.dirichlet(np.ones(R) * 3, len(rls))
+    got = g.evaluate_batch(scheds, subst, freqs, rates, cw)
+    for j, rl in enumerate(rls):
+        want = _oracle_eval(o, tree, rl, subst[j], freqs[j], rates[j], cw[j])
+        assert util.rel_err(got[j], want) < LNL_TOL, (j, got[j], want)
+    assert np.array_equal(got, g.evaluate_batch(scheds, subst, freqs, rates, cw))
+    # and it agrees with the materialising path of the same partition
+    set_model((g,), subst[0], freqs[0], rates[0], cw[0])
+    assert util.rel_err(util.compute_lh(g, tree, rls[0]), got[0]) < 1e-11
+    g.destroy()
+    o.destroy()
+
+
 def test_fused_matches_unfused_and_leaves_partition_state_alone():
     w = synth.workload(50, 1500, 4, 4, 51)
     tree = rd.Tree.from_newick(w["newick"])
