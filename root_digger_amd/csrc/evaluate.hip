@@ -73,7 +73,8 @@ static hipError_t ensure_workspace(rdamd_partition *p, unsigned n_jobs) {
   A(w->d_freqs, sizeof(double) * K * cap);
   A(w->d_rw, sizeof(double) * R * cap);
   A(w->d_pmat, sizeof(double) * pm_per_job * cap);
-  if (K == 4) A(w->d_tiptab, sizeof(double) * pm_per_job * 4 * cap);
+  A(w->d_tiptab, sizeof(double) * (K == 4 ? pm_per_job * 4
+                                           : (size_t)p->prob_matrices * R * kFused20TabDoubles) * cap);
   A(w->d_partials, sizeof(double) * w->blocks_x * cap);
   A(w->d_out, sizeof(double) * cap);
 #undef A
@@ -341,7 +342,9 @@ static int evaluate_batch_impl(rdamd_partition_t *p, unsigned int n_jobs,
     Fused20Args b;
     b.jobs = w->d_jobs; b.tipcodes = p->d_tipcodes; b.tip_stride = p->tip_stride();
     b.codemask = p->d_codemask; b.pattern_weights = p->d_pattern_weights;
-    b.pmat = w->d_pmat; b.freqs = w->d_freqs; b.rate_weights = w->d_rw; b.partials = w->d_partials;
+    b.pmat = w->d_pmat; b.tiptab = w->d_tiptab; b.ncodes = p->ncodes;
+    b.tiptab_job_stride = (size_t)p->prob_matrices * R * kFused20TabDoubles;
+    b.freqs = w->d_freqs; b.rate_weights = w->d_rw; b.partials = w->d_partials;
     b.pmat_job_stride = (size_t)p->prob_matrices * R * K * K;
     b.sites = p->sites; b.rate_cats = R; b.tiles = w->blocks_x;
     p->prof_begin(4);

@@ -69,12 +69,18 @@ struct Fused20Args {
   const uint64_t *codemask;          // [256] code -> state mask
   const unsigned *pattern_weights;   // [sites]
   const double   *pmat;              // [job][matrix][rate][400]  MFMA-ready (kernels_clv_mfma.hip)
+  const double   *tiptab;            // [job][matrix][rate][64 codes][4 grp][6]: entry [g][s] = sum over
+                                     // the states j of the code of P[4 s + g][j] (s < 5; [5] pads to 48 B)
   const double   *freqs;             // [job][20]
   const double   *rate_weights;      // [job][R]
   double         *partials;          // [job][tiles]
   size_t   pmat_job_stride;          // doubles per job
-  unsigned sites, rate_cats, tiles;
+  size_t   tiptab_job_stride;        // doubles per job
+  unsigned sites, rate_cats, tiles, ncodes;
 };
+constexpr unsigned kFused20TabCodes = 64;                        // rows per (matrix, rate)
+constexpr unsigned kFused20TabRow = 4 * 6;                       // doubles per code
+constexpr unsigned kFused20TabDoubles = kFused20TabCodes * kFused20TabRow;   // per (matrix, rate)
 hipError_t launch_fused20_pmatrix(const Fused20Args &a, const double *d_q, const double *d_rates,
                                   unsigned n_jobs, unsigned n_mat, hipStream_t stream);
 hipError_t launch_fused20_eval(const Fused20Args &a, unsigned n_jobs, unsigned max_depth,

@@ -12,7 +12,12 @@
 // {4 s + grp} of site `col` both as MFMA B operand and as MFMA result, a
 // matrix-vector product is 25 MFMAs in five independent chains.  A operands
 // come from the job's MFMA-ready P copies as contiguous 16-byte pieces,
-// requested one step ahead and redistributed through wave-private LDS.
+// requested one step ahead and redistributed through wave-private LDS.  A tip
+// child costs no MFMA: its term is a row of the job's tip table (written next
+// to the P copies: per code the sums of P over the code's states, laid out so
+// that a lane's five entries are 48 contiguous bytes), looked up by the tip
+// code that was fetched two steps ahead.  So a step runs at most ONE product:
+// the running CLV times its branch matrix.
 //
 // Control: a wave walks the job's compiled program (evaluate.hip) with the
 // running CLV in registers and pending siblings on a wave-private LDS stack
@@ -75,7 +80,9 @@ __device__ __forceinline__ Step load_step(const_u32_ptr prog, unsigned i) {
 __global__ void __launch_bounds__(256)
 fused20_pmatrix_kernel(const double *__restrict__ q, const double *__restrict__ rates,
                        const FusedJob *__restrict__ jobs, unsigned n_mat, unsigned R,
-                       double *__restrict__ pmat, size_t pmat_job_stride) {
+                       double *__restrict__ pmat, size_t pmat_job_stride,
+                       double *__restrict__ tiptab, size_t tiptab_job_stride,
+                       const uint64_t *__restrict__ codemask, unsigned ncodes) {
   __shared__ double x[kK * kK], term[kK * kK], out[kK * kK], tmp[kK * kK], red[kK];
   const unsigned per_job = n_mat * R;
   const unsigned job = blockIdx.x / per_job, rem = blockIdx.x % per_job;
@@ -132,12 +139,27 @@ fused20_pmatrix_kernel(const double *__restrict__ q, const double *__restrict__ 
     const double v = out[(4 * rg + i) * kK + 4 * ks + k];
     o[e] = v < 0.0 ? 0.0 : v;
   }
+  // tip table: entry (code, g, s) = sum over the states j of the code of P[4 s + g][j]
+  double *tt = tiptab + (size_t)job * tiptab_job_stride + ((size_t)m * R + r) * kFused20TabDoubles;
+  for (unsigned e = tid; e < ncodes * kFused20TabRow; e += nt) {
+    const unsigned c = e / kFused20TabRow, w = e % kFused20TabRow, g = w / 6, sidx = w % 6;
+    double acc = 0.0;
+    if (sidx < (unsigned)kSteps) {
+      const uint64_t mask = codemask[c];
+      const double *row = out + (4 * sidx + g) * kK;
+      for (unsigned j = 0; j < kK; ++j) {
+        const double v = row[j] < 0.0 ? 0.0 : row[j];
+        acc += ((mask >> j) & 1) ? v : 0.0;
+      }
+    }
+    tt[e] = acc;
+  }
 }
 
 // ---- the evaluator ---------------------------------------------------------------
 // grid = (16-site tiles, jobs); workgroup = R waves, wave r = rate category r.
-// Dynamic LDS: [code masks 2 KB][root exchange R x 16 x (8 + 4) B][per wave:
-// two A copies (8 KB) + `depth` stack levels].
+// Dynamic LDS: [root exchange R x 16 x (8 + 4) B][per wave: one A copy (4 KB) +
+// `depth` stack levels].
 __global__ void __launch_bounds__(256)
 fused20_eval_kernel(Fused20Args a, unsigned depth) {
   extern __shared__ char lds_raw[];
@@ -148,51 +170,59 @@ fused20_eval_kernel(Fused20Args a, unsigned depth) {
   const unsigned site = blockIdx.x * 16 + col;
   const unsigned ls = site < S ? site : S - 1;   // clamped for loads
 
-  uint64_t *masks = reinterpret_cast<uint64_t *>(lds_raw);
-  double *root_f = reinterpret_cast<double *>(lds_raw + 2048);
-  int *root_sc = reinterpret_cast<int *>(lds_raw + 2048 + R * 16 * 8);
-  const unsigned wave_bytes = 2 * kCopyLds + depth * kLevelBytes;
-  char *mine = lds_raw + 2048 + R * 16 * 12 + r * wave_bytes;
-  char *a_lds = mine;                        // [2 products][4 pieces][64 lanes][16 B]
-  char *stack = mine + 2 * kCopyLds;         // [level][5][64] doubles, then [64] counts
-  for (unsigned e = threadIdx.x; e < 256; e += blockDim.x) masks[e] = a.codemask[e];
-  __syncthreads();
+  double *root_f = reinterpret_cast<double *>(lds_raw);
+  int *root_sc = reinterpret_cast<int *>(lds_raw + R * 16 * 8);
+  const unsigned wave_bytes = kCopyLds + depth * kLevelBytes;
+  char *a_lds = lds_raw + R * 16 * 12 + r * wave_bytes;   // [4 pieces][64 lanes][16 B]
+  char *stack = a_lds + kCopyLds;                          // [level][5][64] doubles, then [64] counts
 
   const FusedJob jb = a.jobs[job];
   const const_u32_ptr prog = scalar_ptr(jb.prog);   // n_ops + 4 entries (tail padded)
   const unsigned nops = jb.n_ops;
   const char *pm_job = reinterpret_cast<const char *>(a.pmat + (size_t)job * a.pmat_job_stride);
+  const char *tt_job = reinterpret_cast<const char *>(a.tiptab + (size_t)job * a.tiptab_job_stride);
   const unsigned a_off = (grp * 4 + (col & 3)) * 8u;   // my element of every 4x4 block
+  const unsigned tt_rate = r * (kFused20TabDoubles * 8u);
+  const unsigned tt_lane = grp * 48u;                  // + code * 192: my five entries of a table row
 
-  // the loads one step needs, all unconditional (an unused one gets an empty descriptor)
-  u32x4 raw1[4], raw2[4];
-  unsigned code1, code2;
-  auto request = [&](const Step &st) {
+  // Everything a step may need from memory, always the same instructions (an
+  // unneeded load gets an empty descriptor): the A copy of its product, the
+  // table rows of its tip children (by the codes fetched a step earlier), and
+  // the tip codes of the step after it.
+  u32x4 raw[4], tab1[3], tab2[3];
+  unsigned code1_next, code2_next;      // codes of the step after `nxt`
+  auto request = [&](const Step &st, unsigned c1, unsigned c2, const Step &after) {
     const unsigned kind = st.flags & 3u;
-    const bool two = kind == kFusedTT || kind == kFusedRT;      // a second product (a tip's)
-    const unsigned off1 = kind == kFusedTT ? st.tX : st.pM;
-    const __amdgpu_buffer_rsrc_t rs1 = make_rsrc(pm_job + off1 + (size_t)r * (kCopy * 8), kCopy * 8);
-    const __amdgpu_buffer_rsrc_t rs2 = make_rsrc(pm_job + st.tY + (size_t)r * (kCopy * 8), two ? kCopy * 8 : 0);
+    const bool tip1 = kind == kFusedTT, tip2 = kind == kFusedTT || kind == kFusedRT;
+    const __amdgpu_buffer_rsrc_t rs =
+        make_rsrc(pm_job + st.pM + (size_t)r * (kCopy * 8), tip1 ? 0 : kCopy * 8);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      raw1[k] = __builtin_amdgcn_raw_buffer_load_b128(rs1, (int)(lane * 16u + 1024u * k), 0, 0);
-      raw2[k] = __builtin_amdgcn_raw_buffer_load_b128(rs2, (int)(lane * 16u + 1024u * k), 0, 0);
+    for (int k = 0; k < 4; ++k)
+      raw[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(lane * 16u + 1024u * k), 0, 0);
+    // (matrix offsets of a 20-state program count 3200-byte copies; a table is 12288 bytes)
+    const __amdgpu_buffer_rsrc_t t1 = make_rsrc(
+        tt_job + (size_t)(st.tX / (kCopy * 8)) * (kFused20TabDoubles * 8) + tt_rate, tip1 ? kFused20TabDoubles * 8 : 0);
+    const __amdgpu_buffer_rsrc_t t2 = make_rsrc(
+        tt_job + (size_t)(st.tY / (kCopy * 8)) * (kFused20TabDoubles * 8) + tt_rate, tip2 ? kFused20TabDoubles * 8 : 0);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      tab1[k] = __builtin_amdgcn_raw_buffer_load_b128(t1, (int)(c1 * 192u + tt_lane + 16u * k), 0, 0);
+      tab2[k] = __builtin_amdgcn_raw_buffer_load_b128(t2, (int)(c2 * 192u + tt_lane + 16u * k), 0, 0);
     }
-    const __amdgpu_buffer_rsrc_t c1 = make_rsrc(a.tipcodes + st.cX, kind == kFusedTT ? a.tip_stride : 0u);
-    const __amdgpu_buffer_rsrc_t c2 = make_rsrc(a.tipcodes + st.cY, two ? a.tip_stride : 0u);
-    code1 = (unsigned)__builtin_amdgcn_raw_buffer_load_b8(c1, (int)ls, 0, 0);
-    code2 = (unsigned)__builtin_amdgcn_raw_buffer_load_b8(c2, (int)ls, 0, 0);
+    const unsigned akind = after.flags & 3u;
+    const __amdgpu_buffer_rsrc_t q1 = make_rsrc(a.tipcodes + after.cX, akind == kFusedTT ? a.tip_stride : 0u);
+    const __amdgpu_buffer_rsrc_t q2 = make_rsrc(
+        a.tipcodes + after.cY, (akind == kFusedTT || akind == kFusedRT) ? a.tip_stride : 0u);
+    code1_next = (unsigned)__builtin_amdgcn_raw_buffer_load_b8(q1, (int)ls, 0, 0);
+    code2_next = (unsigned)__builtin_amdgcn_raw_buffer_load_b8(q2, (int)ls, 0, 0);
   };
   auto stage = [&]() {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      *reinterpret_cast<u32x4 *>(a_lds + lane * 16u + 1024u * k) = raw1[k];
-      *reinterpret_cast<u32x4 *>(a_lds + kCopyLds + lane * 16u + 1024u * k) = raw2[k];
-    }
+    for (int k = 0; k < 4; ++k) *reinterpret_cast<u32x4 *>(a_lds + lane * 16u + 1024u * k) = raw[k];
   };
-  // d = A(copy `which` in LDS) . b : five chains of five MFMAs
-  auto product = [&](int which, const double (&b)[kSteps], double (&d)[kGroups]) {
-    const char *ap = a_lds + which * kCopyLds + a_off;
+  // d = A(the copy in LDS) . b : five chains of five MFMAs
+  auto product = [&](const double (&b)[kSteps], double (&d)[kGroups]) {
+    const char *ap = a_lds + a_off;
     double aa[kBlocks];
 #pragma unroll
     for (int j = 0; j < kBlocks; ++j) aa[j] = *reinterpret_cast<const double *>(ap + 128 * j);
@@ -204,10 +234,12 @@ fused20_eval_kernel(Fused20Args a, unsigned depth) {
         d[t] = __builtin_amdgcn_mfma_f64_4x4x4f64(aa[t * kSteps + s], b[s], d[t], 0, 0, 0);
     }
   };
-  auto tip_vector = [&](unsigned code, double (&b)[kSteps]) {
-    const uint64_t m = masks[code & 255u] >> grp;
-#pragma unroll
-    for (int s = 0; s < kSteps; ++s) b[s] = ((m >> (4 * s)) & 1) ? 1.0 : 0.0;
+  auto unpack = [&](const u32x4 (&t)[3], double (&d)[kSteps]) {
+    d[0] = __builtin_bit_cast(double, u32x2{t[0][0], t[0][1]});
+    d[1] = __builtin_bit_cast(double, u32x2{t[0][2], t[0][3]});
+    d[2] = __builtin_bit_cast(double, u32x2{t[1][0], t[1][1]});
+    d[3] = __builtin_bit_cast(double, u32x2{t[1][2], t[1][3]});
+    d[4] = __builtin_bit_cast(double, u32x2{t[2][0], t[2][1]});
   };
 
   double v[kSteps];   // the running CLV: states 4 s + grp of site col
@@ -216,28 +248,35 @@ fused20_eval_kernel(Fused20Args a, unsigned depth) {
   for (int s = 0; s < kSteps; ++s) v[s] = 0.0;
   unsigned sp = 0;
 
+  // prologue: codes of step 0 (an empty step stands in front of it), then
+  // step 0's operands and the codes of step 1
   Step cur = load_step(prog, 0);
   Step nxt = load_step(prog, 1);
-  request(cur);
+  {
+    Step none = cur;
+    none.flags = kFusedPark;     // no tips, A copy of step 0's matrix (harmless)
+    request(none, 0u, 0u, cur);
+  }
+  unsigned c1 = code1_next, c2 = code2_next;   // codes of `cur`
+  request(cur, c1, c2, nxt);
   stage();
-  unsigned ccode1 = code1, ccode2 = code2;   // tip codes of the current step
+  double t1[kSteps], t2[kSteps];               // table rows of `cur`
+  unpack(tab1, t1);
+  unpack(tab2, t2);
+  c1 = code1_next; c2 = code2_next;            // now: codes of `nxt`
 
   for (unsigned i = 0; i < nops; ++i) {
     const Step nx2 = load_step(prog, i + 2);
     const unsigned kind = cur.flags & 3u;
-    // B operands and the A copies of this step (staged at the end of the last one)
-    double b1[kSteps], b2[kSteps], d1[kGroups], d2[kGroups];
+    // next step's operands (and the codes of the one after) are requested now
+    request(nxt, c1, c2, nx2);
+    double d1[kGroups], d2[kGroups];
     if (kind == kFusedTT) {
-      tip_vector(ccode1, b1);
-    } else {
 #pragma unroll
-      for (int s = 0; s < kSteps; ++s) b1[s] = v[s];
+      for (int s = 0; s < kSteps; ++s) d1[s] = t1[s];
+    } else {
+      product(v, d1);
     }
-    tip_vector(ccode2, b2);
-    // next step's operands are requested now, a whole step ahead
-    request(nxt);
-    product(0, b1, d1);
-    if (kind == kFusedTT || kind == kFusedRT) product(1, b2, d2);
     if (kind == kFusedPark) {          // push M . (running CLV); the next step is a TT
       double *lv = reinterpret_cast<double *>(stack + sp * kLevelBytes) + lane;
 #pragma unroll
@@ -251,8 +290,10 @@ fused20_eval_kernel(Fused20Args a, unsigned depth) {
 #pragma unroll
         for (int s = 0; s < kSteps; ++s) d2[s] = lv[s * 64];
         sc += reinterpret_cast<const int *>(stack + sp * kLevelBytes + kSteps * 64 * 8)[lane];
-      } else if (kind == kFusedTT) {
-        sc = 0;
+      } else {
+#pragma unroll
+        for (int s = 0; s < kSteps; ++s) d2[s] = t2[s];
+        if (kind == kFusedTT) sc = 0;
       }
       bool small = true;
 #pragma unroll
@@ -270,9 +311,11 @@ fused20_eval_kernel(Fused20Args a, unsigned depth) {
         sc += 1;
       }
     }
-    // the next step's A copies replace this one's in LDS
+    // the next step's A copy replaces this one's in LDS; its table rows and codes move up
     stage();
-    ccode1 = code1; ccode2 = code2;
+    unpack(tab1, t1);
+    unpack(tab2, t2);
+    c1 = code1_next; c2 = code2_next;
     cur = nxt;
     nxt = nx2;
   }
@@ -334,12 +377,13 @@ hipError_t launch_fused20_pmatrix(const Fused20Args &a, const double *d_q, const
   const size_t total = (size_t)n_jobs * n_mat * a.rate_cats;
   if (!total) return hipSuccess;
   fused20_pmatrix_kernel<<<(unsigned)total, 256, 0, stream>>>(
-      d_q, d_rates, a.jobs, n_mat, a.rate_cats, const_cast<double *>(a.pmat), a.pmat_job_stride);
+      d_q, d_rates, a.jobs, n_mat, a.rate_cats, const_cast<double *>(a.pmat), a.pmat_job_stride,
+      const_cast<double *>(a.tiptab), a.tiptab_job_stride, a.codemask, a.ncodes);
   return hipGetLastError();
 }
 
 size_t fused20_lds_bytes(unsigned R, unsigned depth) {
-  return 2048 + (size_t)R * 16 * 12 + (size_t)R * (2 * kCopyLds + (size_t)depth * kLevelBytes);
+  return (size_t)R * 16 * 12 + (size_t)R * (kCopyLds + (size_t)depth * kLevelBytes);
 }
 
 hipError_t launch_fused20_eval(const Fused20Args &a, unsigned n_jobs, unsigned max_depth,
