@@ -75,79 +75,139 @@ __device__ __forceinline__ Step load_step(const_u32_ptr prog, unsigned i) {
 }  // namespace
 
 // ---- P-matrices of a batch, straight into the MFMA-ready layout ---------------
-// One workgroup per (job, matrix, rate); same scaling-and-squaring / 16-term
-// Taylor core as pmatrix_generic_kernel.
+// exp(Q t) by scaling and squaring around the same degree-16 Taylor polynomial
+// as pmatrix_generic_kernel (||A / 2^s||_1 <= 1/4), evaluated Paterson-
+// Stockmeyer style: X^2..X^4 (3 products), then Horner in X^4 over four cubic
+// blocks (3 products) -- 6 matrix products instead of 16.  A workgroup holds
+// two (job, matrix, rate) problems, 128 threads each; a thread owns a 2x2 tile
+// of every 20x20 product (3 LDS reads per 4 FMAs).
+namespace {
+
+constexpr int kMat = kK * kK;
+
+// C = A . B for this thread's 2x2 tile (rows 2 ti, 2 ti + 1; columns 2 tj, 2 tj + 1)
+__device__ __forceinline__ void tile_product(const double *A, const double *B, unsigned ti, unsigned tj,
+                                             double (&c)[4]) {
+  c[0] = c[1] = c[2] = c[3] = 0.0;
+  const double *a0 = A + (2 * ti) * kK, *a1 = a0 + kK;
+#pragma unroll 5
+  for (int l = 0; l < kK; ++l) {
+    const double2 b = *reinterpret_cast<const double2 *>(B + l * kK + 2 * tj);
+    const double x0 = a0[l], x1 = a1[l];
+    c[0] = fma(x0, b.x, c[0]); c[1] = fma(x0, b.y, c[1]);
+    c[2] = fma(x1, b.x, c[2]); c[3] = fma(x1, b.y, c[3]);
+  }
+}
+__device__ __forceinline__ void tile_store(double *C, unsigned ti, unsigned tj, const double (&c)[4]) {
+  *reinterpret_cast<double2 *>(C + (2 * ti) * kK + 2 * tj) = make_double2(c[0], c[1]);
+  *reinterpret_cast<double2 *>(C + (2 * ti + 1) * kK + 2 * tj) = make_double2(c[2], c[3]);
+}
+
+}  // namespace
+
 __global__ void __launch_bounds__(256)
 fused20_pmatrix_kernel(const double *__restrict__ q, const double *__restrict__ rates,
-                       const FusedJob *__restrict__ jobs, unsigned n_mat, unsigned R,
+                       const FusedJob *__restrict__ jobs, unsigned n_mat, unsigned R, unsigned total,
                        double *__restrict__ pmat, size_t pmat_job_stride,
                        double *__restrict__ tiptab, size_t tiptab_job_stride,
                        const uint64_t *__restrict__ codemask, unsigned ncodes) {
-  __shared__ double x[kK * kK], term[kK * kK], out[kK * kK], tmp[kK * kK], red[kK];
+  __shared__ __attribute__((aligned(16))) double lds[2][6][kMat];   // per problem: X, X^2, X^3, X^4, H, T
+  __shared__ double red[2][kK];
+  __shared__ int sq[2];
+  const unsigned half = threadIdx.x >> 7, tid = threadIdx.x & 127;
+  const unsigned prob = blockIdx.x * 2 + half;
+  const bool live = prob < total;
+  const unsigned pr = live ? prob : total - 1;
   const unsigned per_job = n_mat * R;
-  const unsigned job = blockIdx.x / per_job, rem = blockIdx.x % per_job;
+  const unsigned job = pr / per_job, rem = pr % per_job;
   const unsigned m = rem / R, r = rem % R;
-  const unsigned tid = threadIdx.x, nt = blockDim.x;
+  double *X = lds[half][0], *X2 = lds[half][1], *X3 = lds[half][2], *X4 = lds[half][3];
+  double *H = lds[half][4], *T = lds[half][5];
+  const bool worker = tid < 100;
+  const unsigned ti = tid / 10, tj = tid % 10;
+
   const double t = jobs[job].brlen[m] * rates[(size_t)job * R + r];
-  const double *qq = q + (size_t)job * (kK * kK);
-  for (unsigned e = tid; e < kK * kK; e += nt) x[e] = qq[e] * t;
+  const double *qq = q + (size_t)job * kMat;
+  for (unsigned e = tid; e < (unsigned)kMat; e += 128) X[e] = qq[e] * t;
   __syncthreads();
-  for (unsigned j = tid; j < kK; j += nt) {
+  if (tid < (unsigned)kK) {
     double cs = 0.0;
-    for (unsigned i = 0; i < kK; ++i) cs += fabs(x[i * kK + j]);
-    red[j] = cs;
+    for (unsigned i = 0; i < (unsigned)kK; ++i) cs += fabs(X[i * kK + tid]);
+    red[half][tid] = cs;
   }
   __syncthreads();
-  double norm = 0.0;
-  for (unsigned j = 0; j < kK; ++j) norm = fmax(norm, red[j]);
-  int s = 0;
-  double scale = 1.0;
-  while (norm * scale > 0.25 && s < 60) { scale *= 0.5; ++s; }
-  __syncthreads();
-  for (unsigned e = tid; e < kK * kK; e += nt) {
-    x[e] *= scale;
-    term[e] = out[e] = (e / kK == e % kK) ? 1.0 : 0.0;
+  if (tid == 0) {
+    double norm = 0.0;
+    for (unsigned j = 0; j < (unsigned)kK; ++j) norm = fmax(norm, red[half][j]);
+    int s = 0;
+    double scale = 1.0;
+    while (norm * scale > 0.25 && s < 60) { scale *= 0.5; ++s; }
+    sq[half] = s;
+    red[half][0] = scale;
   }
   __syncthreads();
-  for (int k = 1; k <= 16; ++k) {
-    const double inv = 1.0 / (double)k;
-    for (unsigned e = tid; e < kK * kK; e += nt) {
-      const unsigned i = e / kK, j = e % kK;
-      double acc = 0.0;
-      for (unsigned l = 0; l < kK; ++l) acc += term[i * kK + l] * x[l * kK + j];
-      tmp[e] = acc * inv;
+  const int s_mine = sq[half], s_max = max(sq[0], sq[1]);
+  const double scale = red[half][0];
+  for (unsigned e = tid; e < (unsigned)kMat; e += 128) X[e] *= scale;
+  __syncthreads();
+  double c[4];
+  if (worker) { tile_product(X, X, ti, tj, c); tile_store(X2, ti, tj, c); }
+  __syncthreads();
+  if (worker) { tile_product(X2, X, ti, tj, c); tile_store(X3, ti, tj, c); }
+  __syncthreads();
+  if (worker) { tile_product(X2, X2, ti, tj, c); tile_store(X4, ti, tj, c); }
+  __syncthreads();
+  // 1/k!, k = 0..16
+  constexpr double f[17] = {1.0, 1.0, 1.0 / 2, 1.0 / 6, 1.0 / 24, 1.0 / 120, 1.0 / 720, 1.0 / 5040,
+                            1.0 / 40320, 1.0 / 362880, 1.0 / 3628800, 1.0 / 39916800, 1.0 / 479001600,
+                            1.0 / 6227020800.0, 1.0 / 87178291200.0, 1.0 / 1307674368000.0,
+                            1.0 / 20922789888000.0};
+  // block q: B_q = f[4q] I + f[4q+1] X + f[4q+2] X^2 + f[4q+3] X^3 ; p = B0 + X^4 (B1 + X^4 (B2 + X^4 (B3 + f16 X^4)))
+  auto block_plus = [&](int qb, const double (&acc)[4], double *dst) {   // dst tile = B_qb tile + acc
+    double o[4];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const unsigned i = 2 * ti + (w >> 1), j = 2 * tj + (w & 1), e = i * kK + j;
+      o[w] = acc[w] + (i == j ? f[4 * qb] : 0.0) + f[4 * qb + 1] * X[e] + f[4 * qb + 2] * X2[e] +
+             f[4 * qb + 3] * X3[e];
     }
-    __syncthreads();
-    for (unsigned e = tid; e < kK * kK; e += nt) { term[e] = tmp[e]; out[e] += tmp[e]; }
-    __syncthreads();
+    tile_store(dst, ti, tj, o);
+  };
+  if (worker) {   // H = B3 + f16 X^4
+    double acc[4];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) acc[w] = f[16] * X4[(2 * ti + (w >> 1)) * kK + 2 * tj + (w & 1)];
+    block_plus(3, acc, H);
   }
-  for (int k = 0; k < s; ++k) {
-    for (unsigned e = tid; e < kK * kK; e += nt) {
-      const unsigned i = e / kK, j = e % kK;
-      double acc = 0.0;
-      for (unsigned l = 0; l < kK; ++l) acc += out[i * kK + l] * out[l * kK + j];
-      tmp[e] = acc;
-    }
+  __syncthreads();
+  for (int qb = 2; qb >= 0; --qb) {   // H <- B_qb + X^4 . H   (through T)
+    if (worker) { tile_product(X4, H, ti, tj, c); block_plus(qb, c, T); }
     __syncthreads();
-    for (unsigned e = tid; e < kK * kK; e += nt) out[e] = tmp[e];
-    __syncthreads();
+    double *swap = H; H = T; T = swap;
   }
+  for (int k = 0; k < s_max; ++k) {   // squarings
+    if (worker && k < s_mine) { tile_product(H, H, ti, tj, c); tile_store(T, ti, tj, c); }
+    __syncthreads();
+    if (k < s_mine) { double *swap = H; H = T; T = swap; }
+  }
+  if (!live) return;
+  const double *out = H;
   // element (rg, ks, k, i) of the copy = P[4 rg + i][4 ks + k]  (kernels_clv_mfma.hip)
   double *o = pmat + (size_t)job * pmat_job_stride + ((size_t)m * R + r) * kCopy;
-  for (unsigned e = tid; e < (unsigned)kCopy; e += nt) {
+  for (unsigned e = tid; e < (unsigned)kCopy; e += 128) {
     const unsigned i = e & 3, k = (e >> 2) & 3, blk = e >> 4, ks = blk % kSteps, rg = blk / kSteps;
     const double v = out[(4 * rg + i) * kK + 4 * ks + k];
     o[e] = v < 0.0 ? 0.0 : v;
   }
   // tip table: entry (code, g, s) = sum over the states j of the code of P[4 s + g][j]
   double *tt = tiptab + (size_t)job * tiptab_job_stride + ((size_t)m * R + r) * kFused20TabDoubles;
-  for (unsigned e = tid; e < ncodes * kFused20TabRow; e += nt) {
-    const unsigned c = e / kFused20TabRow, w = e % kFused20TabRow, g = w / 6, sidx = w % 6;
+  for (unsigned e = tid; e < ncodes * kFused20TabRow; e += 128) {
+    const unsigned cc = e / kFused20TabRow, w = e % kFused20TabRow, g = w / 6, sidx = w % 6;
     double acc = 0.0;
     if (sidx < (unsigned)kSteps) {
-      const uint64_t mask = codemask[c];
+      const uint64_t mask = codemask[cc];
       const double *row = out + (4 * sidx + g) * kK;
-      for (unsigned j = 0; j < kK; ++j) {
+      for (unsigned j = 0; j < (unsigned)kK; ++j) {
         const double v = row[j] < 0.0 ? 0.0 : row[j];
         acc += ((mask >> j) & 1) ? v : 0.0;
       }
@@ -376,8 +436,8 @@ hipError_t launch_fused20_pmatrix(const Fused20Args &a, const double *d_q, const
                                   unsigned n_jobs, unsigned n_mat, hipStream_t stream) {
   const size_t total = (size_t)n_jobs * n_mat * a.rate_cats;
   if (!total) return hipSuccess;
-  fused20_pmatrix_kernel<<<(unsigned)total, 256, 0, stream>>>(
-      d_q, d_rates, a.jobs, n_mat, a.rate_cats, const_cast<double *>(a.pmat), a.pmat_job_stride,
+  fused20_pmatrix_kernel<<<(unsigned)((total + 1) / 2), 256, 0, stream>>>(
+      d_q, d_rates, a.jobs, n_mat, a.rate_cats, (unsigned)total, const_cast<double *>(a.pmat), a.pmat_job_stride,
       const_cast<double *>(a.tiptab), a.tiptab_job_stride, a.codemask, a.ncodes);
   return hipGetLastError();
 }
