@@ -178,7 +178,8 @@ int rdamd_compute_root_loglikelihoods(rdamd_partition_t *p, unsigned int count,
  * parameter set -- in ONE fused launch that never writes a CLV to HBM.  They
  * are stateless with respect to the partition: its CLV / P-matrix / parameter
  * state is neither read nor changed (tip states and pattern weights are).
- * 4-state data only; other state counts use the three calls above.
+ * 4-state (and embedded binary) data, and 20-state data with up to 4 rate
+ * categories; other shapes use the three calls above.
  * --------------------------------------------------------------------- */
 typedef struct rdamd_schedule rdamd_schedule_t;
 
@@ -196,8 +197,9 @@ void         rdamd_schedule_destroy(rdamd_schedule_t *s);
 /* LDS stack slots per site the compiled traversal needs (diagnostic). */
 unsigned int rdamd_schedule_stack_depth(const rdamd_schedule_t *s);
 
-/* lnl_out[j] = log-likelihood of job j.  Row-major parameter blocks:
- * subst [n_jobs][12] (corax_set_subst_params order), freqs [n_jobs][4],
+/* lnl_out[j] = log-likelihood of job j.  Row-major parameter blocks, K = the
+ * partition's states: subst [n_jobs][K*K-K] (corax_set_subst_params order),
+ * freqs [n_jobs][K],
  * rates [n_jobs][rate_cats] and rate_weights [n_jobs][rate_cats] (either may be
  * NULL: the partition's current category rates / weights are used). */
 int rdamd_evaluate_batch(rdamd_partition_t *p, unsigned int n_jobs,
