@@ -337,8 +337,8 @@ std::vector<double> model_t::compute_all_root_lh_batched() {
   for (size_t p = 0; p < _partitions.size(); ++p) {
     rdamd_partition_t *part = _partitions[p];
     const unsigned K = rdamd_partition_states(part), NP = K * K - K;
-    if (K != 4 && K != 2)
-      throw std::runtime_error("compute_all_root_lh_batched: 4-state or binary data only");
+    if (K != 4 && K != 2 && K != 20)
+      throw std::runtime_error("compute_all_root_lh_batched: 4-state, binary or 20-state data only");
     const unsigned R = rdamd_partition_rate_cats(part);
     const double *cs = rdamd_partition_subst_params(part, 0), *cf = rdamd_partition_frequencies(part, 0);
     std::vector<rdamd_schedule_t *> owned;
