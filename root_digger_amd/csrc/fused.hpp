@@ -91,4 +91,5 @@ hipError_t launch_fused_pmatrix(const FusedArgs &a, const double *d_q, const dou
 hipError_t launch_fused_eval(const FusedArgs &a, unsigned n_jobs, unsigned max_depth,
                              unsigned blocks_x, double *d_out, hipStream_t stream);
 
+
 }  // namespace rdamd
