@@ -245,36 +245,48 @@ fused20_eval_kernel(Fused20Args a, unsigned depth) {
   const unsigned tt_rate = r * (kFused20TabDoubles * 8u);
   const unsigned tt_lane = grp * 48u;                  // + code * 192: my five entries of a table row
 
-  // Everything a step may need from memory, always the same instructions (an
-  // unneeded load gets an empty descriptor): the A copy of its product, the
-  // table rows of its tip children (by the codes fetched a step earlier), and
-  // the tip codes of the step after it.
-  u32x4 raw[4], tab1[3], tab2[3];
-  unsigned code1_next, code2_next;      // codes of the step after `nxt`
-  auto request = [&](const Step &st, unsigned c1, unsigned c2, const Step &after) {
-    const unsigned kind = st.flags & 3u;
-    const bool tip1 = kind == kFusedTT, tip2 = kind == kFusedTT || kind == kFusedRT;
+  // What a step needs from memory, always the same instructions (an unneeded
+  // load gets an empty descriptor), requested so that no loaded register has to
+  // be copied before it is used (a copy waits for the load and costs a VALU slot):
+  //   * the A copy of step i+1 at the top of step i (its registers were emptied
+  //     into LDS at the end of step i-1), staged into LDS at the end of step i;
+  //   * the table rows of step i+1's tip children and the tip codes of step i+2
+  //     right after step i has used its own rows, i.e. behind its MFMAs.
+  u32x4 raw[4], t1a, t1b, t2a, t2b;   // t?a/t?b: table entries 0-1, 2-3 of the X / Y tip child
+  u32x2 t1c, t2c;                     // ... entry 4
+  unsigned code1, code2;              // tip codes of the step after next (dword around my byte)
+  const unsigned code_shift = (ls & 3u) * 8u;
+  auto request_a = [&](const Step &st) {
+    const bool tip1 = (st.flags & 3u) == kFusedTT;
     const __amdgpu_buffer_rsrc_t rs =
         make_rsrc(pm_job + st.pM + (size_t)r * (kCopy * 8), tip1 ? 0 : kCopy * 8);
 #pragma unroll
     for (int k = 0; k < 4; ++k)
       raw[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(lane * 16u + 1024u * k), 0, 0);
+  };
+  auto request_tabs = [&](const Step &st, unsigned c1, unsigned c2, const Step &after) {
+    const unsigned kind = st.flags & 3u;
+    const bool tip1 = kind == kFusedTT, tip2 = kind == kFusedTT || kind == kFusedRT;
     // (matrix offsets of a 20-state program count 3200-byte copies; a table is 12288 bytes)
     const __amdgpu_buffer_rsrc_t t1 = make_rsrc(
         tt_job + (size_t)(st.tX / (kCopy * 8)) * (kFused20TabDoubles * 8) + tt_rate, tip1 ? kFused20TabDoubles * 8 : 0);
     const __amdgpu_buffer_rsrc_t t2 = make_rsrc(
         tt_job + (size_t)(st.tY / (kCopy * 8)) * (kFused20TabDoubles * 8) + tt_rate, tip2 ? kFused20TabDoubles * 8 : 0);
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      tab1[k] = __builtin_amdgcn_raw_buffer_load_b128(t1, (int)(c1 * 192u + tt_lane + 16u * k), 0, 0);
-      tab2[k] = __builtin_amdgcn_raw_buffer_load_b128(t2, (int)(c2 * 192u + tt_lane + 16u * k), 0, 0);
-    }
+    const int o1 = (int)(c1 * 192u + tt_lane), o2 = (int)(c2 * 192u + tt_lane);
+    t1a = __builtin_amdgcn_raw_buffer_load_b128(t1, o1, 0, 0);
+    t1b = __builtin_amdgcn_raw_buffer_load_b128(t1, o1 + 16, 0, 0);
+    t1c = __builtin_amdgcn_raw_buffer_load_b64(t1, o1 + 32, 0, 0);
+    t2a = __builtin_amdgcn_raw_buffer_load_b128(t2, o2, 0, 0);
+    t2b = __builtin_amdgcn_raw_buffer_load_b128(t2, o2 + 16, 0, 0);
+    t2c = __builtin_amdgcn_raw_buffer_load_b64(t2, o2 + 32, 0, 0);
     const unsigned akind = after.flags & 3u;
     const __amdgpu_buffer_rsrc_t q1 = make_rsrc(a.tipcodes + after.cX, akind == kFusedTT ? a.tip_stride : 0u);
     const __amdgpu_buffer_rsrc_t q2 = make_rsrc(
         a.tipcodes + after.cY, (akind == kFusedTT || akind == kFusedRT) ? a.tip_stride : 0u);
-    code1_next = (unsigned)__builtin_amdgcn_raw_buffer_load_b8(q1, (int)ls, 0, 0);
-    code2_next = (unsigned)__builtin_amdgcn_raw_buffer_load_b8(q2, (int)ls, 0, 0);
+    // (the dword around the code, unpacked where it is used: a byte load is
+    // widened right behind the load, i.e. the wave would wait for it there)
+    code1 = __builtin_amdgcn_raw_buffer_load_b32(q1, (int)(ls & ~3u), 0, 0);
+    code2 = __builtin_amdgcn_raw_buffer_load_b32(q2, (int)(ls & ~3u), 0, 0);
   };
   auto stage = [&]() {
 #pragma unroll
@@ -294,13 +306,7 @@ fused20_eval_kernel(Fused20Args a, unsigned depth) {
         d[t] = __builtin_amdgcn_mfma_f64_4x4x4f64(aa[t * kSteps + s], b[s], d[t], 0, 0, 0);
     }
   };
-  auto unpack = [&](const u32x4 (&t)[3], double (&d)[kSteps]) {
-    d[0] = __builtin_bit_cast(double, u32x2{t[0][0], t[0][1]});
-    d[1] = __builtin_bit_cast(double, u32x2{t[0][2], t[0][3]});
-    d[2] = __builtin_bit_cast(double, u32x2{t[1][0], t[1][1]});
-    d[3] = __builtin_bit_cast(double, u32x2{t[1][2], t[1][3]});
-    d[4] = __builtin_bit_cast(double, u32x2{t[2][0], t[2][1]});
-  };
+  auto f64 = [](unsigned lo, unsigned hi) { return __builtin_bit_cast(double, u32x2{lo, hi}); };
 
   double v[kSteps];   // the running CLV: states 4 s + grp of site col
   int sc = 0;         // its 2^256 rescale count
@@ -314,29 +320,24 @@ fused20_eval_kernel(Fused20Args a, unsigned depth) {
   Step nxt = load_step(prog, 1);
   {
     Step none = cur;
-    none.flags = kFusedPark;     // no tips, A copy of step 0's matrix (harmless)
-    request(none, 0u, 0u, cur);
+    none.flags = kFusedPark;     // no tips
+    request_tabs(none, 0u, 0u, cur);
   }
-  unsigned c1 = code1_next, c2 = code2_next;   // codes of `cur`
-  request(cur, c1, c2, nxt);
+  request_a(cur);
+  request_tabs(cur, (code1 >> code_shift) & 255u, (code2 >> code_shift) & 255u, nxt);
   stage();
-  double t1[kSteps], t2[kSteps];               // table rows of `cur`
-  unpack(tab1, t1);
-  unpack(tab2, t2);
-  c1 = code1_next; c2 = code2_next;            // now: codes of `nxt`
 
   for (unsigned i = 0; i < nops; ++i) {
     const Step nx2 = load_step(prog, i + 2);
     const unsigned kind = cur.flags & 3u;
-    // next step's operands (and the codes of the one after) are requested now
-    request(nxt, c1, c2, nx2);
-    double d1[kGroups], d2[kGroups];
-    if (kind == kFusedTT) {
-#pragma unroll
-      for (int s = 0; s < kSteps; ++s) d1[s] = t1[s];
-    } else {
-      product(v, d1);
-    }
+    request_a(nxt);                    // the A copy of the next step
+    double d1[kGroups];
+    if (kind != kFusedTT) product(v, d1);
+    // this step's table rows (requested behind the previous step's MFMAs), used in place
+    const double t1[kSteps] = {f64(t1a[0], t1a[1]), f64(t1a[2], t1a[3]), f64(t1b[0], t1b[1]),
+                               f64(t1b[2], t1b[3]), f64(t1c[0], t1c[1])};
+    const double t2[kSteps] = {f64(t2a[0], t2a[1]), f64(t2a[2], t2a[3]), f64(t2b[0], t2b[1]),
+                               f64(t2b[2], t2b[3]), f64(t2c[0], t2c[1])};
     if (kind == kFusedPark) {          // push M . (running CLV); the next step is a TT
       double *lv = reinterpret_cast<double *>(stack + sp * kLevelBytes) + lane;
 #pragma unroll
@@ -348,19 +349,19 @@ fused20_eval_kernel(Fused20Args a, unsigned depth) {
         --sp;
         const double *lv = reinterpret_cast<const double *>(stack + sp * kLevelBytes) + lane;
 #pragma unroll
-        for (int s = 0; s < kSteps; ++s) d2[s] = lv[s * 64];
+        for (int s = 0; s < kSteps; ++s) v[s] = d1[s] * lv[s * 64];
         sc += reinterpret_cast<const int *>(stack + sp * kLevelBytes + kSteps * 64 * 8)[lane];
+      } else if (kind == kFusedRT) {
+#pragma unroll
+        for (int s = 0; s < kSteps; ++s) v[s] = d1[s] * t2[s];
       } else {
 #pragma unroll
-        for (int s = 0; s < kSteps; ++s) d2[s] = t2[s];
-        if (kind == kFusedTT) sc = 0;
+        for (int s = 0; s < kSteps; ++s) v[s] = t1[s] * t2[s];
+        sc = 0;
       }
       bool small = true;
 #pragma unroll
-      for (int s = 0; s < kSteps; ++s) {
-        v[s] = d1[s] * d2[s];
-        small = small && (v[s] < kScaleThreshold);
-      }
+      for (int s = 0; s < kSteps; ++s) small = small && (v[s] < kScaleThreshold);
       // all 20 entries of a (site, rate) sit in the four lanes col + 16 g
       unsigned long long bm = __ballot(small);
       bm &= bm >> 32;
@@ -371,11 +372,10 @@ fused20_eval_kernel(Fused20Args a, unsigned depth) {
         sc += 1;
       }
     }
-    // the next step's A copy replaces this one's in LDS; its table rows and codes move up
+    // the next step's table rows (by the codes that arrived a step ago) and the
+    // codes of the step after it; then its A copy replaces this one's in LDS
+    request_tabs(nxt, (code1 >> code_shift) & 255u, (code2 >> code_shift) & 255u, nx2);
     stage();
-    unpack(tab1, t1);
-    unpack(tab2, t2);
-    c1 = code1_next; c2 = code2_next;
     cur = nxt;
     nxt = nx2;
   }
