@@ -140,7 +140,7 @@ struct Compiler {
           FusedOp park;
           memset(&park, 0, sizeof(park));
           park.pM = matM * unit;
-          park.flags = kFusedPark;
+          park.flags = kFusedPark | ((spill & 2) ? 0x200u : 0u);   // 0x200: into the register slot
           out.push_back(park);
           matM = 0;
           spill = 0;
@@ -170,7 +170,7 @@ struct Compiler {
     f.tY = matY * unit;
     f.cX = tipX_row * tip_stride;
     f.cY = tipY_row * tip_stride;
-    f.flags = kind | (split_park ? 0u : spill << 8);
+    f.flags = kind | (spill << 8);   // (a 20-state TT never parks: its spill bits were moved to the park step)
     out.push_back(f);
   }
 };
@@ -246,9 +246,9 @@ rdamd_schedule_t *rdamd_schedule_create(rdamd_partition_t *p, const rdamd_operat
   }
   rdamd_schedule *s = new rdamd_schedule();
   // LDS levels = stack depth minus the register level (at least one is allocated)
-  // (20 states: every level lives in LDS and parking steps count as steps)
+  // (20 states: parking steps count as steps)
   s->part = p; s->n_ops = (unsigned)n_steps;
-  s->depth = k20 ? std::max(1u, c.max_depth) : std::max(1u, c.max_depth > 0 ? c.max_depth - 1 : 0);
+  s->depth = std::max(1u, c.max_depth > 0 ? c.max_depth - 1 : 0);
   n_ops = (unsigned)n_steps;
   s->prog = c.out;
   // harmless tail entries: the kernel prefetches descriptors up to i + 3

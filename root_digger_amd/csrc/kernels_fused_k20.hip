@@ -21,7 +21,7 @@
 //
 // Control: a wave walks the job's compiled program (evaluate.hip) with the
 // running CLV in registers and pending siblings on a wave-private LDS stack
-// whose depth the host minimised.  Nothing is shared between waves until the
+// whose depth the host minimised (level 0 of it in registers).  Nothing is shared between waves until the
 // root, so there is no barrier in the loop: each (site, rate) keeps its own
 // 2^256 rescale count (decided by a ballot folded on the scalar unit) and the
 // root sum aligns the rate terms to the smallest count -- the per-rate-scaler
@@ -310,8 +310,10 @@ fused20_eval_kernel(Fused20Args a, unsigned depth) {
 
   double v[kSteps];   // the running CLV: states 4 s + grp of site col
   int sc = 0;         // its 2^256 rescale count
+  double s0[kSteps];  // stack level 0 (the most used) stays in registers
+  int s0sc = 0;
 #pragma unroll
-  for (int s = 0; s < kSteps; ++s) v[s] = 0.0;
+  for (int s = 0; s < kSteps; ++s) v[s] = s0[s] = 0.0;
   unsigned sp = 0;
 
   // prologue: codes of step 0 (an empty step stands in front of it), then
@@ -339,13 +341,23 @@ fused20_eval_kernel(Fused20Args a, unsigned depth) {
     const double t2[kSteps] = {f64(t2a[0], t2a[1]), f64(t2a[2], t2a[3]), f64(t2b[0], t2b[1]),
                                f64(t2b[2], t2b[3]), f64(t2c[0], t2c[1])};
     if (kind == kFusedPark) {          // push M . (running CLV); the next step is a TT
-      double *lv = reinterpret_cast<double *>(stack + sp * kLevelBytes) + lane;
+      if (cur.flags & 0x200u) {        // stack level 0 lives in registers
 #pragma unroll
-      for (int s = 0; s < kSteps; ++s) lv[s * 64] = d1[s];
-      reinterpret_cast<int *>(stack + sp * kLevelBytes + kSteps * 64 * 8)[lane] = sc;
-      ++sp;
+        for (int s = 0; s < kSteps; ++s) s0[s] = d1[s];
+        s0sc = sc;
+      } else {
+        double *lv = reinterpret_cast<double *>(stack + sp * kLevelBytes) + lane;
+#pragma unroll
+        for (int s = 0; s < kSteps; ++s) lv[s * 64] = d1[s];
+        reinterpret_cast<int *>(stack + sp * kLevelBytes + kSteps * 64 * 8)[lane] = sc;
+        ++sp;
+      }
     } else {
-      if (kind == kFusedRP) {          // the sibling was multiplied by its matrix when parked
+      if (kind == kFusedRP && (cur.flags & 0x400u)) {   // the sibling waits in the register slot
+#pragma unroll
+        for (int s = 0; s < kSteps; ++s) v[s] = d1[s] * s0[s];
+        sc += s0sc;
+      } else if (kind == kFusedRP) {   // ... or on the LDS stack (multiplied by its matrix when parked)
         --sp;
         const double *lv = reinterpret_cast<const double *>(stack + sp * kLevelBytes) + lane;
 #pragma unroll
