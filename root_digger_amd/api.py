@@ -654,7 +654,7 @@ class Partition:
     def _batch_args(self, schedules, subst, freqs, rates, rate_weights):
         n = len(schedules)
         hs = (_vp * n)(*[s._h for s in schedules])
-        k = self.states                       # 4, or 2 (binary data on the 4-state kernels)
+        k = self.states                       # 4, 2 (binary data on the 4-state kernels) or 20
         subst = np.ascontiguousarray(subst, dtype=np.float64).reshape(n, k * k - k)
         freqs = np.ascontiguousarray(freqs, dtype=np.float64).reshape(n, k)
         if rates is not None:
