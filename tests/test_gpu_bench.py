@@ -12,9 +12,9 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def run_bench(*extra):
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "c1",
-                          "--steps", "3", "--warmup", "1", "--batch", "17"] + list(extra),
+def run_bench(*extra, config="c1", steps="3", batch="17"):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", config,
+                          "--steps", steps, "--warmup", "1", "--batch", batch] + list(extra),
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
@@ -47,3 +47,12 @@ def test_site_sharded_bench_matches_candidate_sharded_checksum():
     assert a["scaling"] == "strong" and a["config"]["sharding"].startswith("site blocks")
     # same jobs, same parameters: the device-pointer path returns the same lnLs
     assert abs(a["lnl_check"] - b["lnl_check"]) <= 1e-9 * abs(b["lnl_check"])
+
+
+def test_protein_config_runs_through_the_20_state_fused_evaluator():
+    """c3 (200 taxa x 10 000 sites x 20 states): the batch goes through
+    kernels_fused_k20.hip and agrees with the CPU oracle on the sampled jobs."""
+    d = run_bench("--cpu-seconds", "3", config="c3", steps="1", batch="6")
+    assert d["config"]["path"] == "fused batch" and d["roofline"]["kernel"] == "fused20_eval_kernel"
+    assert d["value"] > 0
+    assert d["cpu_baseline"]["parity_max_rel_err"] < 1e-9
