@@ -189,6 +189,8 @@ def test_protein20_generic_path():
     (33, 777, 4, 2, 13),
     (40, 513, 4, 8, 14),
     (25, 300, 20, 4, 15),       # c3 shape
+    (14, 45, 20, 8, 20),        # 20 states, 8 categories: the wide-workgroup variant of the MFMA kernel
+    (9, 33, 20, 16, 21),        # 20 states, 16 categories: beyond the MFMA kernel -> generic kernel
     (12, 1, 4, 4, 16),          # a single site
     (9, 65, 3, 3, 17),          # odd K, odd R -> generic kernels
     (30, 2100, 2, 4, 18),       # binary characters: embedded in the 4-state kernels
