@@ -206,56 +206,84 @@ clv_k20_traversal_kernel(DeviceView v, const double *__restrict__ pmfma,
   for (int s = 0; s < kMfmaSteps; ++s) c1.b[s] = c2.b[s] = 0.0;
   c1.code = c2.code = 0u;
   c1.sc = c2.sc = 0u;
-  double res[kMfmaGroups];     // the CLV this wave produced last (D layout = B layout)
-  unsigned osc = 0;
+  // The results of the last two operations stay in registers (D layout = B
+  // layout): `res` belongs to operation oi - 1, `prev` to operation oi - 2.
+  // Stores are issued one operation LATE and behind the loads of the same
+  // iteration: a load then only ever queues behind stores that are a whole
+  // iteration old (vector memory operations return in order, and a store's
+  // acknowledgement takes as long as an operation).  The price is that an
+  // operation may not read from memory what the two operations before it
+  // produced: those children are forwarded from `res` (source 2) and `prev`
+  // (source 3), or the host cuts the list there.
+  double res[kMfmaGroups], prev[kMfmaGroups];
+  unsigned osc = 0, oscp = 0;
 #pragma unroll
-  for (int t = 0; t < kMfmaGroups; ++t) res[t] = 0.0;
+  for (int t = 0; t < kMfmaGroups; ++t) res[t] = prev[t] = 0.0;
   OpHead op = load_op(ops, 0);
   OpHead nx = op;              // operation oi + 1 (for oi = -1: operation 0)
+  OpHead pop = op;             // operation oi - 1: its stores are still due
+
+  auto store_result = [&](const OpHead &h, bool valid, const double (&val)[kMfmaGroups], unsigned sc) {
+    const bool scaled = valid && h.parent_sc >= 0;
+    const __amdgpu_buffer_rsrc_t psc_rs =
+        make_rsrc(sc_base + (size_t)(scaled ? h.parent_sc : 0) * sc_bytes, scaled ? sc_bytes : 0u);
+    __builtin_amdgcn_raw_buffer_store_b32(sc, psc_rs, (int)st_sc, 0, 0);
+    const __amdgpu_buffer_rsrc_t pclv_rs =
+        make_rsrc(clv_base + (size_t)(h.parent_clv - v.tips) * clv_bytes, valid ? clv_bytes : 0u);
+#pragma unroll
+    for (int t = 0; t < kMfmaGroups; ++t)
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, val[t]), pclv_rs,
+                                            (int)(st_clv + 32u * t), 0, 0);
+  };
 
   for (int oi = -1; oi < (int)nops; ++oi) {
     const bool live = oi >= 0;
     const unsigned nx2i = (unsigned)(oi + 2) < nops ? (unsigned)(oi + 2) : nops - 1;
     const OpHead nx2 = load_op(ops, nx2i);   // wanted one iteration from now
     // B operands without a branch: a tip's 0/1 vector from its state mask (the
-    // loads of a non-memory child returned zeros), then the D registers of the
-    // operation just before where the child is that parent
+    // loads of a non-memory child returned zeros), or the registers of one of
+    // the two operations before
     double b1[kMfmaSteps], b2[kMfmaSteps];
     {
       const unsigned tip1 = op.src1 == 0u ? ~0u : 0u, tip2 = op.src2 == 0u ? ~0u : 0u;
-      const unsigned reg1 = op.src1 == 2u ? ~0u : 0u, reg2 = op.src2 == 2u ? ~0u : 0u;
+      const unsigned ra1 = op.src1 == 2u ? ~0u : 0u, ra2 = op.src2 == 2u ? ~0u : 0u;
+      const unsigned rb1 = op.src1 == 3u ? ~0u : 0u, rb2 = op.src2 == 3u ? ~0u : 0u;
       const uint64_t m1 = masks[c1.code & 255u] >> grp, m2 = masks[c2.code & 255u] >> grp;
 #pragma unroll
       for (int s = 0; s < kMfmaSteps; ++s) {
         const u32x2 l1 = __builtin_bit_cast(u32x2, c1.b[s]), l2 = __builtin_bit_cast(u32x2, c2.b[s]);
-        const u32x2 p = __builtin_bit_cast(u32x2, res[s]);
+        const u32x2 p = __builtin_bit_cast(u32x2, res[s]), q = __builtin_bit_cast(u32x2, prev[s]);
         const unsigned t1 = (0u - ((unsigned)(m1 >> (4 * s)) & 1u)) & 0x3FF00000u & tip1;
         const unsigned t2 = (0u - ((unsigned)(m2 >> (4 * s)) & 1u)) & 0x3FF00000u & tip2;
-        const u32x2 w1 = {(l1[0] & ~reg1) | (p[0] & reg1), ((l1[1] | t1) & ~reg1) | (p[1] & reg1)};
-        const u32x2 w2 = {(l2[0] & ~reg2) | (p[0] & reg2), ((l2[1] | t2) & ~reg2) | (p[1] & reg2)};
+        // (a forwarded child loaded zeros and has no tip bits, so OR-ing is enough)
+        const u32x2 w1 = {l1[0] | (p[0] & ra1) | (q[0] & rb1), l1[1] | t1 | (p[1] & ra1) | (q[1] & rb1)};
+        const u32x2 w2 = {l2[0] | (p[0] & ra2) | (q[0] & rb2), l2[1] | t2 | (p[1] & ra2) | (q[1] & rb2)};
         b1[s] = as_f64(w1);
         b2[s] = as_f64(w2);
       }
     }
-    const unsigned sc1 = op.src1 == 2u ? osc : c1.sc;   // (an empty descriptor loaded 0)
-    const unsigned sc2 = op.src2 == 2u ? osc : c2.sc;
+    // (an empty descriptor loaded 0)
+    const unsigned sc1 = op.src1 == 2u ? osc : (op.src1 == 3u ? oscp : c1.sc);
+    const unsigned sc2 = op.src2 == 2u ? osc : (op.src2 == 3u ? oscp : c2.sc);
     // this operation's A copies, requested a whole iteration ago, go to LDS ...
     stage_child_a(0, c1);
     stage_child_a(1, c2);
-    // ... and everything the NEXT operation needs from memory is requested
+    // ... everything the NEXT operation needs from memory is requested ...
     load_child_b(nx.src1, nx.child1_clv, nx.child1_sc, c1);
     load_child_b(nx.src2, nx.child2_clv, nx.child2_sc, c2);
     load_child_a(nx.child1_mat, c1);
     load_child_a(nx.child2_mat, c2);
+    // ... and the PREVIOUS operation's result goes out behind those loads
+    store_result(pop, oi >= 1, res, osc);
     // the MFMAs of this operation
-    double d1[kMfmaGroups], d2[kMfmaGroups];
+    double d1[kMfmaGroups], d2[kMfmaGroups], out[kMfmaGroups];
     child_product(0, b1, d1);
     child_product(1, b2, d2);
     bool small = true;
 #pragma unroll
     for (int t = 0; t < kMfmaGroups; ++t) {
-      res[t] = d1[t] * d2[t];
-      small = small && (res[t] < kScaleThreshold);
+      out[t] = d1[t] * d2[t];
+      small = small && (out[t] < kScaleThreshold);
     }
     // across the 4 lane groups that hold the other rows of a site: fold the
     // ballot on the scalar unit (bit c of the result = site c of this wave)
@@ -269,21 +297,18 @@ clv_k20_traversal_kernel(DeviceView v, const double *__restrict__ pmfma,
     for (unsigned q = 0; q < R; ++q) all_bits &= flags[oi & 1][q];
     const bool all_small = (all_bits >> col) & 1u;
     const double f = all_small ? kScaleFactor : 1.0;
-#pragma unroll
-    for (int t = 0; t < kMfmaGroups; ++t) res[t] *= f;
+    oscp = osc;
     osc = scaled_buffer ? sc1 + sc2 + (all_small ? 1u : 0u) : 0u;
-    const __amdgpu_buffer_rsrc_t psc_rs =
-        make_rsrc(sc_base + (size_t)(scaled_buffer ? op.parent_sc : 0) * sc_bytes, scaled_buffer ? sc_bytes : 0u);
-    __builtin_amdgcn_raw_buffer_store_b32(osc, psc_rs, (int)st_sc, 0, 0);
-    const __amdgpu_buffer_rsrc_t pclv_rs =
-        make_rsrc(clv_base + (size_t)(op.parent_clv - v.tips) * clv_bytes, live ? clv_bytes : 0u);
 #pragma unroll
-    for (int t = 0; t < kMfmaGroups; ++t)
-      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, res[t]), pclv_rs,
-                                            (int)(st_clv + 32u * t), 0, 0);
+    for (int t = 0; t < kMfmaGroups; ++t) {
+      prev[t] = res[t];
+      res[t] = out[t] * f;
+    }
+    pop = op;
     op = nx;
     nx = nx2;
   }
+  store_result(pop, nops >= 1, res, osc);   // the last operation's result
 }
 
 hipError_t launch_pmat_to_mfma(rdamd_partition *p, const unsigned *d_matrix_indices,

@@ -487,23 +487,32 @@ void rdamd_update_clvs(rdamd_partition_t *p, const rdamd_operation_t *ops,
   // (`cuts` splits a list into separate launches; nothing needs that today:
   // memory children are read at use, after every earlier store of the lane.)
   std::vector<unsigned> cuts{0u};
-  // The 20-state kernel fetches the operands of operation i+1 before the
-  // stores of operation i: where i+1 reads from memory what i wrote (possible
-  // only when the value cannot be forwarded: same CLV under another scaler
-  // index, or the other way round), the list is cut into two launches.
+  // The 20-state kernel requests the operands of operation i+1 a whole
+  // operation ahead and stores the result of operation i one operation late:
+  // operation i may not read from memory what i-1 or i-2 wrote.  Their parents
+  // are forwarded in registers (sources 2 and 3 below) -- except where the
+  // value cannot be forwarded (same CLV under another scaler index, or the
+  // other way round, or both earlier operations wrote it): there the list is
+  // cut into two launches.
   const bool use_k20 = k20_mfma_ok(p);
   if (use_k20)
     for (unsigned i = 1; i < count; ++i) {
-      const rdamd_operation_t &o = ops[i], &b = ops[i - 1];
+      const rdamd_operation_t &o = ops[i];
       const unsigned ch[2] = {o.child1_clv_index, o.child2_clv_index};
       const int chsc[2] = {o.child1_scaler_index, o.child2_scaler_index};
       bool hazard = false;
       for (int c = 0; c < 2; ++c) {
         if (ch[c] < p->tips) continue;
-        const bool forwarded = ch[c] == b.parent_clv_index && chsc[c] == b.parent_scaler_index;
-        const bool touches = ch[c] == b.parent_clv_index ||
-                             (chsc[c] >= 0 && chsc[c] == b.parent_scaler_index);
-        hazard = hazard || (touches && !forwarded);
+        int hits = 0, clean = 0;
+        for (unsigned back = 1; back <= 2 && back <= i - cuts.back(); ++back) {
+          const rdamd_operation_t &b = ops[i - back];
+          const bool forwarded = ch[c] == b.parent_clv_index && chsc[c] == b.parent_scaler_index;
+          const bool touches = ch[c] == b.parent_clv_index ||
+                               (chsc[c] >= 0 && chsc[c] == b.parent_scaler_index);
+          hits += touches;
+          clean += forwarded;
+        }
+        hazard = hazard || hits != clean || hits > 1;
       }
       if (hazard) cuts.push_back(i);
     }
@@ -518,8 +527,16 @@ void rdamd_update_clvs(rdamd_partition_t *p, const rdamd_operation_t *ops,
       const unsigned ch[2] = {o.child1_clv_index, o.child2_clv_index};
       const int chsc[2] = {o.child1_scaler_index, o.child2_scaler_index};
       for (int c = 0; c < 2; ++c) {
-        if (ch[c] < p->tips || (c == 1 && ch[1] == ch[0])) continue;
+        if (ch[c] < p->tips || (!use_k20 && c == 1 && ch[1] == ch[0])) continue;
         const int j = producer[ch[c]];
+        if (use_k20) {
+          // the 20-state kernel keeps the results of the last TWO operations in
+          // registers and forwards them to every reader (source 2: the operation
+          // just before, 3: the one before that)
+          if (j >= 0 && (int)i - j <= 2 && ops[j].parent_scaler_index == chsc[c])
+            (c ? lops[i].src2 : lops[i].src1) = (int)i - j == 1 ? 2u : 3u;
+          continue;
+        }
         if (j >= 0 && consumer[j] < 0 && ops[j].parent_scaler_index == chsc[c]) {
           consumer[j] = (int)i;
           which[j] = c;
