@@ -69,10 +69,17 @@ __device__ __forceinline__ void matvec(const double *__restrict__ p, const doubl
     t[k] = p[k * 4 + 0] * x[0] + p[k * 4 + 1] * x[1] + p[k * 4 + 2] * x[2] + p[k * 4 + 3] * x[3];
 }
 
-__device__ __forceinline__ void read_row(const double *row, double (&t)[4]) {
-  const double2 lo = reinterpret_cast<const double2 *>(row)[0];
-  const double2 hi = reinterpret_cast<const double2 *>(row)[1];
-  t[0] = lo.x; t[1] = lo.y; t[2] = hi.x; t[3] = hi.y;
+// A tip-table row, addressed by its LDS byte offset: the table bases are
+// compile-time constants of the access (instruction offsets), so the only
+// vector instruction spent on the address is the shift that made `off`.
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) const f64x2 *lds_row_ptr;
+typedef __attribute__((address_space(3))) double *lds_f64_ptr;
+template <unsigned BASE>
+__device__ __forceinline__ void read_row(unsigned off, double (&t)[4]) {
+  const lds_row_ptr row = (lds_row_ptr)(size_t)(off + BASE);
+  const f64x2 lo = row[0], hi = row[1];
+  t[0] = lo[0]; t[1] = lo[1]; t[2] = hi[0]; t[3] = hi[1];
 }
 
 // v = tx * ty, then the 2^256 rescale when all four entries are < 2^-256
@@ -123,7 +130,7 @@ fused_dna_eval_kernel(FusedArgs a) {
   int site_off[NS];
 #pragma unroll
   for (int q = 0; q < NS; ++q) site_off[q] = (int)site[q];
-  double *tabx = lds, *taby = lds + 64;
+  // (the X / Y tip tables sit at LDS bytes 0 and 512: read_row / the writes below)
   double2 *stk = reinterpret_cast<double2 *>(lds + kTabDoubles) + lane;
   int *stk_sc = reinterpret_cast<int *>(lds + kTabDoubles + (size_t)jb.depth * NS * 256) + lane;
 
@@ -169,14 +176,14 @@ fused_dna_eval_kernel(FusedArgs a) {
   {                                                                                             \
     const unsigned kind = uni(cur.flags);                                                       \
     cur = prog[idx2];                                                                           \
-    const double *rowx[NS], *rowy[NS];                                                          \
-    _Pragma("unroll") for (int q = 0; q < NS; ++q) { rowx[q] = tabx + cx[q] * 4; rowy[q] = taby + cy[q] * 4; } \
+    unsigned rowx[NS], rowy[NS];   /* byte offsets of the rows inside the X / Y table */          \
+    _Pragma("unroll") for (int q = 0; q < NS; ++q) { rowx[q] = cx[q] << 5; rowy[q] = cy[q] << 5; } \
     double tx[NS][4], ty[NS][4];                                                                \
     const unsigned k3 = kind & 3u;                                                              \
     if (k3 == kFusedTT) {                                                                       \
-      tabx[lane] = ex;                                                                          \
-      taby[lane] = ey;                                                                          \
-      _Pragma("unroll") for (int q = 0; q < NS; ++q) { read_row(rowx[q], tx[q]); read_row(rowy[q], ty[q]); } \
+      ((lds_f64_ptr)(size_t)(unsigned)lane8)[0] = ex;                                                   \
+      ((lds_f64_ptr)(size_t)(unsigned)lane8)[64] = ey;                                                  \
+      _Pragma("unroll") for (int q = 0; q < NS; ++q) { read_row<0>(rowx[q], tx[q]); read_row<512>(rowy[q], ty[q]); } \
       RDAMD_LOAD_TIPS(nxt, ncx, ncy, nex, ney)                                                  \
       if (kind & 0x100u) { /* park M . (running CLV) for the later inner-inner node */          \
         double tp[NS][4];                                                                       \
@@ -199,8 +206,8 @@ fused_dna_eval_kernel(FusedArgs a) {
       RDAMD_LOAD_M(nxt, M)                                                                      \
       _Pragma("unroll") for (int q = 0; q < NS; ++q) { st.sc[q] = 0; combine(tx[q], ty[q], st.v[q], st.sc[q]); } \
     } else if (k3 == kFusedRT) {                                                                \
-      taby[lane] = ey;                                                                          \
-      _Pragma("unroll") for (int q = 0; q < NS; ++q) read_row(rowy[q], ty[q]);                  \
+      ((lds_f64_ptr)(size_t)(unsigned)lane8)[64] = ey;                                                  \
+      _Pragma("unroll") for (int q = 0; q < NS; ++q) read_row<512>(rowy[q], ty[q]);             \
       RDAMD_LOAD_TIPS(nxt, ncx, ncy, nex, ney)                                                  \
       _Pragma("unroll") for (int q = 0; q < NS; ++q) matvec(M, st.v[q], tx[q]);                 \
       RDAMD_LOAD_M(nxt, M)                                                                      \
