@@ -83,6 +83,63 @@ def profiled_traffic(kernel, batch, config):
     return None, None
 
 
+def spawn_ranks(n):
+    """One child process per GPU (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* in the
+    environment, rendezvous on 127.0.0.1), started from a parent that has not
+    initialised the GPU.  Rank 0's stdout is relayed; the exit code is the
+    first non-zero child code."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    children = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n),
+                   LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        children.append(subprocess.Popen(
+            [sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+            stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    import threading
+    lines = []
+    reader = threading.Thread(target=lambda: lines.extend(children[0].stdout), daemon=True)
+    reader.start()
+    failed = 0
+    while any(c.poll() is None for c in children):
+        failed = next((c.returncode for c in children if c.poll()), 0)
+        if failed:           # one rank died: the others would wait in a collective forever
+            for c in children:
+                if c.poll() is None:
+                    c.terminate()
+            break
+        time.sleep(0.2)
+    codes = [c.wait() for c in children]
+    reader.join(timeout=10)
+    sys.stdout.write("".join(lines))
+    sys.stdout.flush()
+    return failed or next((c for c in codes if c), 0)
+
+
+def profiled_issue(kernel, batch, config):
+    """Issue-slot figures of `kernel` derived by profiles/summarize.py from the
+    committed SQ counter passes of the default command (c2, batch 197): VALU
+    instructions per (operation, rate) step, the share of them that are the
+    algorithm's FP64 instructions, and VALU issue-slot utilisation."""
+    if config != "c2" or batch != 197:
+        return {}
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_summary.json")))
+    try:
+        d = json.load(open(files[-1]))
+        for k, v in d.items():
+            if k.startswith(kernel) and "derived" in v:
+                return {"issue": dict(v["derived"], source=os.path.relpath(files[-1], ROOT))}
+    except Exception:
+        pass
+    return {}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -108,10 +165,15 @@ def main():
                          "BASELINE config c4 pattern)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: this process becomes the
+        # launcher.  It starts N ranks as children BEFORE anything here touches
+        # HIP or torch, waits, relays rank 0's JSON line and nothing else.
+        raise SystemExit(spawn_ranks(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
 
     import numpy as np
@@ -283,30 +345,32 @@ def main():
         flops = full_eval_flops(n, S, R, K) * evals_per_rank
         tf = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         hbm_equiv = full_eval_bytes(n, S, R, K) * evals_per_rank / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-        # `roofline` follows the contract literally: ALGORITHMIC bytes (SURVEY 8d
-        # bytes_full per evaluation x evaluations per launch) / launch time
-        # against the HBM peak, `traffic` = HBM bytes the launch really moved (PMC).
-        # The fused traversal never materialises a CLV, so frac > 1 by design;
-        # what actually binds the kernel is FP64 FMA issue -> `fp64`.
+        # The fused traversal never materialises a CLV: its HBM traffic is tip codes
+        # + per-job tables (PMC: `traffic`), far below SURVEY 8d's bytes_full, so the
+        # resource that binds it is FP64 issue -- the vector FMA pipe for 4 states,
+        # the FP64 matrix core (v_mfma_f64_4x4x4_4b_f64) for 20.  `roofline` is that
+        # bound: SURVEY 8d's algorithmic flops per launch / the kernel's HIP-event
+        # launch time against the 78.6 TFLOP/s FP64 peak (vector = matrix on gfx950).
+        # `hbm_equiv` keeps the algorithmic-byte rate for comparison with the
+        # materialising path; it is a ratio to the HBM peak, not a roofline.
         roofline = {
-            "kernel": fused_kernel, "bound": "hbm",
-            "achieved": round(hbm_equiv, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(hbm_equiv / HBM_PEAK_GBS, 3), "traffic": None,
-            "algorithmic_bytes_per_launch": full_eval_bytes(n, S, R, K) * nb,
+            "kernel": fused_kernel, "bound": "fp64" if K == 4 else "mfma",
+            "achieved": round(tf, 2), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(tf / FP64_PEAK_TFLOPS, 4), "traffic": None,
+            "algorithmic_flops_per_launch": flops / max(launches, 1),
             "avg_launch_ms": round(ms / max(launches, 1), 4), "launches": launches,
             "share_of_step": round(ms * 1e-3 / elapsed, 3),
-            "note": "fused traversal: CLVs never reach HBM, so the algorithmic-byte rate "
-                    "exceeds the HBM peak; the binding resource is FP64 %s (see fp64)"
-                    % ("FMA issue" if K == 4 else "matrix-core issue (v_mfma_f64_4x4x4_4b_f64)"),
-            "fp64": {"bound": "fp64 fma issue" if K == 4 else "fp64 mfma", "achieved": round(tf, 2),
-                     "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": round(tf / FP64_PEAK_TFLOPS, 4),
-                     "algorithmic_flops_per_launch": flops / max(launches, 1),
-                     ("measured_dfma_ceiling_tflops" if K == 4 else
-                      "measured_mfma_4x4x4_ceiling_tflops"): 68.4 if K == 4 else 73.2},
+            ("measured_dfma_ceiling_tflops" if K == 4 else
+             "measured_mfma_4x4x4_ceiling_tflops"): 68.4 if K == 4 else 73.2,
             "stack_depth": depth,
             "pmatrix_ms_per_launch": round(prof["fused_pmatrix"][0] / max(prof["fused_pmatrix"][1], 1), 4),
+            "hbm_equiv": {"algorithmic_bytes_per_launch": full_eval_bytes(n, S, R, K) * nb,
+                          "rate_gbs": round(hbm_equiv, 1),
+                          "ratio_to_hbm_peak": round(hbm_equiv / HBM_PEAK_GBS, 3),
+                          "note": "SURVEY 8d bytes_full per evaluation / launch time; CLVs stay in "
+                                  "registers/LDS, so this exceeds the HBM peak by design"},
         }
+        roofline.update(profiled_issue(fused_kernel, nb, args.config))
         roofline["traffic"], roofline["traffic_source"] = profiled_traffic(
             fused_kernel, nb, args.config)
         # second leg: the materialising CLV kernel (drop-in rdamd_update_clvs

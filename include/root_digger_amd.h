@@ -117,6 +117,11 @@ unsigned int  rdamd_partition_states(const rdamd_partition_t *p);
 unsigned int  rdamd_partition_rate_cats(const rdamd_partition_t *p);
 unsigned int  rdamd_partition_sites(const rdamd_partition_t *p);
 unsigned int  rdamd_partition_tips(const rdamd_partition_t *p);
+/* sum of the pattern weights (= alignment columns the partition stands for) */
+double        rdamd_partition_weight_sum(const rdamd_partition_t *p);
+/* the HIP stream handle (opaque here; HIP's stream type) every launch of this partition is queued on:
+ * a collective queued on it runs after the batch that produced its input */
+void         *rdamd_partition_stream(const rdamd_partition_t *p);
 const double *rdamd_partition_subst_params(const rdamd_partition_t *p,
                                            unsigned int params_index);
 const double *rdamd_partition_frequencies(const rdamd_partition_t *p,
@@ -557,6 +562,53 @@ rdamd_model_t *rdamd_model_create_from_file_ratehet(const rdamd_tree_t *tree,
 /* character maps (replace corax_map_nt / corax_map_bin, src/main.cpp:484) */
 extern const uint64_t rdamd_map_nt[256];
 extern const uint64_t rdamd_map_bin[256];
+
+/* ---- site-sharded runs ------------------------------------------------------
+ * North star / SURVEY 8(e): "candidate edges and site blocks shard across the 8
+ * GPUs of one node with an RCCL all-reduce of per-block log-likelihoods".  The
+ * reference has no site sharding (its MPI ranks split candidates only,
+ * src/model.cpp:1867-1911); here each rank of a SITE GROUP builds its model on
+ * one contiguous block of alignment columns and every log-likelihood the model
+ * hands to its optimisers (compute_lh, compute_lh_root, compute_dlh, the
+ * L-BFGS-B objective batches of src/model.cpp:1488-1502, the root sweeps) is
+ * summed over the group through this hook before it is used, so all ranks of a
+ * group follow the same trajectory bit for bit.  Empirical frequencies are
+ * combined the same way (weighted by each block's column count).
+ *
+ * on_device = 0: `values` is a host array; sum it over the group in place.
+ * on_device = 1: `values` is DEVICE memory and `stream` the HIP stream handle the
+ *   producing launch was queued on: queue the collective on that stream
+ *   (ncclAllReduce(values, values, n, ncclDouble, ncclSum, comm, stream)).
+ * Return RDAMD_SUCCESS.  A site-sharded model runs its candidates sequentially
+ * (the replica / lock-step searches would reorder the collectives). */
+typedef int (*rdamd_lnl_reducer_t)(double *values, unsigned int n, void *stream, void *user);
+int rdamd_model_set_lnl_reducer(rdamd_model_t *m, rdamd_lnl_reducer_t reduce, void *user,
+                                int on_device);
+/* rdamd_model_create_from_file_ratehet on block `block` of `n_blocks` contiguous
+ * column blocks of the alignment (chunking of src/model.cpp:1899-1907 applied to
+ * columns; the block is cut BEFORE pattern compression).  n_columns: optional,
+ * the whole alignment's column count. */
+rdamd_model_t *rdamd_model_create_from_file_block(const rdamd_tree_t *tree, const char *msa_filename,
+                                                  unsigned int states, const uint64_t *map,
+                                                  const rdamd_ratehet_opts_t *ratehet,
+                                                  uint64_t seed, int early_stop, int compress,
+                                                  unsigned int block, unsigned int n_blocks,
+                                                  unsigned int *n_patterns,
+                                                  unsigned int *n_columns);
+
+/* RCCL communicator of one site group (librccl is loaded on first use; the
+ * library has no link-time dependency on it).  Rank 0 of the group calls
+ * rdamd_comm_unique_id and hands the 128 bytes to the others by any means
+ * (rd_amd: its TCP rendezvous); every rank then calls rdamd_comm_create on its
+ * own device.  rdamd_comm_reducer is a ready-made rdamd_lnl_reducer_t
+ * (on_device = 1) whose `user` is the communicator. */
+typedef struct rdamd_comm rdamd_comm_t;
+int           rdamd_comm_unique_id(char id[128]);
+rdamd_comm_t *rdamd_comm_create(const char id[128], int rank, int n_ranks);
+int           rdamd_comm_allreduce_sum(rdamd_comm_t *c, double *device_values, unsigned int n,
+                                       void *stream);
+int           rdamd_comm_reducer(double *values, unsigned int n, void *stream, void *user);
+void          rdamd_comm_destroy(rdamd_comm_t *c);
 
 /* library / device info */
 const char *rdamd_version(void);

@@ -16,6 +16,8 @@ from .api import (  # noqa: F401
     Schedule,
     Model,
     Checkpoint,
+    Comm,
+    LNL_REDUCER,
     parse_model_info,
     parse_partition_info,
     msa_partition_probe,
@@ -33,7 +35,7 @@ from .api import (  # noqa: F401
 )
 
 __all__ = [
-    "lib", "lib_path", "RdamdError", "Operation", "RootLocation", "Tree", "Partition", "Schedule", "Model", "Checkpoint", "parse_model_info", "parse_partition_info",
+    "lib", "lib_path", "RdamdError", "Operation", "RootLocation", "Tree", "Partition", "Schedule", "Model", "Checkpoint", "Comm", "LNL_REDUCER", "parse_model_info", "parse_partition_info",
     "msa_partition_probe",
     "checkpoint_checksum_result", "checkpoint_checksum_params",
     "MAP_NT", "MAP_BIN", "compute_gamma_cats", "GAMMA_RATES_MEAN", "GAMMA_RATES_MEDIAN",

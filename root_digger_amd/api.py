@@ -224,6 +224,18 @@ _sig("rdamd_model_optimize_params", C.c_int, _vp, _prl, C.c_double, C.c_double, 
 _sig("rdamd_model_exhaustive_search", C.c_int, _vp, C.c_double, C.c_double, C.c_double,
      C.c_double, C.POINTER(C.c_uint64), _pd, _pd, _pu, _prl, _pd)
 
+# site-sharded runs: reduction hook + RCCL communicator (include/root_digger_amd.h)
+LNL_REDUCER = C.CFUNCTYPE(C.c_int, _pd, _u, _vp, _vp)
+_sig("rdamd_model_set_lnl_reducer", C.c_int, _vp, _vp, _vp, C.c_int)
+_sig("rdamd_model_create_from_file_block", _vp, _vp, C.c_char_p, _u, C.c_void_p,
+     C.POINTER(RatehetOpts), C.c_uint64, C.c_int, C.c_int, _u, _u, _pu, _pu)
+_sig("rdamd_partition_weight_sum", C.c_double, _vp)
+_sig("rdamd_partition_stream", _vp, _vp)
+_sig("rdamd_comm_unique_id", C.c_int, C.c_char * 128)
+_sig("rdamd_comm_create", _vp, C.c_char * 128, C.c_int, C.c_int)
+_sig("rdamd_comm_allreduce_sum", C.c_int, _vp, _vp, _u, _vp)
+_sig("rdamd_comm_destroy", None, _vp)
+
 _libc = C.CDLL(None)
 _libc.free.argtypes = [_vp]
 _libc.free.restype = None
@@ -870,6 +882,44 @@ class Checkpoint:
             _fail("checkpoint_clean")
 
 
+class Comm:
+    """RCCL communicator of one site group (rdamd_comm_t)."""
+
+    @staticmethod
+    def unique_id():
+        buf = (C.c_char * 128)()
+        if lib.rdamd_comm_unique_id(buf) != 1:
+            _fail("comm_unique_id")
+        return bytes(buf)
+
+    def __init__(self, unique_id, rank, n_ranks):
+        buf = (C.c_char * 128).from_buffer_copy(unique_id)
+        self._h = lib.rdamd_comm_create(buf, rank, n_ranks)
+        if not self._h:
+            _fail("comm_create")
+
+    @property
+    def handle(self):
+        return self._h
+
+    @property
+    def reducer(self):
+        """the C reducer to hand to Model.set_lnl_reducer(..., on_device=True, user=comm.handle)"""
+        return C.cast(lib.rdamd_comm_reducer, _vp)
+
+    def allreduce_sum(self, device_ptr, n, stream=None):
+        if lib.rdamd_comm_allreduce_sum(self._h, device_ptr, n, stream) != 1:
+            _fail("comm_allreduce_sum")
+
+    def destroy(self):
+        if getattr(self, "_h", None):
+            lib.rdamd_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.destroy()
+
+
 def checkpoint_checksum_result(root_id, llh, alpha):
     return int(lib.rdamd_checkpoint_checksum_result(root_id, llh, alpha))
 
@@ -937,6 +987,48 @@ class Model:
             _fail("model_create_partitioned")
         self.partitions = n.value
         return self
+
+    @classmethod
+    def from_file_block(cls, tree, msa_path, block, n_blocks, states=4, cmap=None, rate_cats=1,
+                        seed=1, early_stop=False, compress=True):
+        """One rank's model of a site-sharded run: column block `block` of `n_blocks`
+        (rdamd_model_create_from_file_block); pair it with set_lnl_reducer."""
+        self = cls.__new__(cls)
+        self._tree, self.states = tree, states
+        n, cols = C.c_uint(0), C.c_uint(0)
+        rc = RatehetOpts(1, 1, rate_cats, 0, 1.0)
+        self._h = lib.rdamd_model_create_from_file_block(
+            tree._h, os.fsencode(msa_path), states, cmap if cmap is not None else MAP_NT,
+            C.byref(rc), seed, 1 if early_stop else 0, 1 if compress else 0, block, n_blocks,
+            C.byref(n), C.byref(cols))
+        if not self._h:
+            _fail("model_create_from_file_block")
+        self.patterns, self.columns = n.value, cols.value
+        return self
+
+    def set_lnl_reducer(self, fn, on_device=False, user=None):
+        """Site-group reduction hook (rdamd_model_set_lnl_reducer).  `fn` is either a
+        Python callable(values: float64 numpy view, n) -> None summing a HOST
+        array over the group in place, or a C function pointer (LNL_REDUCER /
+        address, e.g. the library's rdamd_comm_reducer with on_device=True and
+        `user` = the communicator handle)."""
+        if fn is None:
+            self._reducer = None
+            self._ok(lib.rdamd_model_set_lnl_reducer(self._h, None, None, 0), "set_lnl_reducer")
+            return
+        if callable(fn) and not isinstance(fn, C._CFuncPtr):
+            def trampoline(values, n, stream, user_, fn=fn):
+                try:
+                    fn(np.ctypeslib.as_array(values, shape=(n,)), n)
+                    return 1
+                except Exception:           # never let an exception cross the C frame
+                    import traceback
+                    traceback.print_exc()
+                    return 0
+            fn = LNL_REDUCER(trampoline)
+        self._reducer = fn                   # keep the callback alive
+        self._ok(lib.rdamd_model_set_lnl_reducer(self._h, C.cast(fn, _vp), user,
+                                                 1 if on_device else 0), "set_lnl_reducer")
 
     def partition_count(self):
         return int(lib.rdamd_model_partition_count(self._h))

@@ -3,6 +3,7 @@
 #include "model.hpp"
 
 #include <cstdio>
+#include <hip/hip_runtime.h>
 #include "batch_combiner.hpp"
 #include "checkpoint.hpp"
 
@@ -74,6 +75,38 @@ model_t::~model_t() {
   for (auto p : _partitions)
     if (p) rdamd_partition_destroy(p);
   if (_sweep) rdamd_partition_destroy(_sweep);
+  if (_d_reduce) (void)hipFree(_d_reduce);
+}
+
+// ---- site-group reduction ---------------------------------------------
+double *model_t::reduce_scratch(size_t n) {
+  if (n > _d_reduce_cap) {
+    if (_d_reduce) (void)hipFree(_d_reduce);
+    _d_reduce = nullptr;
+    _d_reduce_cap = std::max<size_t>(n, 256);
+    if (hipMalloc((void **)&_d_reduce, _d_reduce_cap * sizeof(double)) != hipSuccess) {
+      _d_reduce_cap = 0;
+      throw std::runtime_error("site-group reduction: hipMalloc failed");
+    }
+  }
+  return _d_reduce;
+}
+
+// host values in, their sums over the site group out (identical on every rank)
+void model_t::reduce_values(double *values, size_t n) {
+  if (!_reduce || n == 0) return;
+  if (!_reduce_device) {
+    if (_reduce(values, (unsigned)n, nullptr, _reduce_user) != RDAMD_SUCCESS)
+      throw std::runtime_error("site-group reduction failed");
+    return;
+  }
+  double *d = reduce_scratch(n);
+  hipStream_t st = (hipStream_t)rdamd_partition_stream(_partitions[0]);
+  if (hipMemcpyAsync(d, values, n * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess ||
+      _reduce(d, (unsigned)n, st, _reduce_user) != RDAMD_SUCCESS ||
+      hipMemcpyAsync(values, d, n * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess ||
+      hipStreamSynchronize(st) != hipSuccess)
+    throw std::runtime_error("site-group reduction failed");
 }
 
 // ---- setters ----------------------------------------------------------------
@@ -142,6 +175,14 @@ void model_t::set_tip_states(size_t p, const msa_t &msa) {
 void model_t::set_empirical_freqs(size_t p) {
   double *f = rdamd_msa_empirical_frequencies(_partitions[p]);
   unsigned states = rdamd_partition_states(_partitions[p]);
+  if (_reduce) {   // one model for the whole alignment: blocks weighted by their columns
+    const double w = rdamd_partition_weight_sum(_partitions[p]);
+    std::vector<double> acc(states + 1);
+    for (unsigned i = 0; i < states; ++i) acc[i] = f[i] * w;
+    acc[states] = w;
+    reduce_values(acc.data(), acc.size());
+    for (unsigned i = 0; i < states; ++i) f[i] = acc[i] / acc[states];
+  }
   for (unsigned i = 0; i < states; ++i)
     if (f[i] <= 0) {
       free(f);
@@ -247,7 +288,7 @@ double model_t::compute_lh(const root_location_t &root_location) {
                                            _tree.root_scaler_index(),
                                            _param_indicies[i].data(), nullptr);
   }
-  return lh;
+  return reduce_value(lh);
 }
 
 double model_t::compute_lh_root(const root_location_t &root) {
@@ -263,6 +304,7 @@ double model_t::compute_lh_root(const root_location_t &root) {
       fail("compute_lh_root");
     lh += v;
   }
+  lh = reduce_value(lh);
   if (std::isnan(lh)) throw std::runtime_error("lh at root is not a number: " + std::to_string(lh));
   return lh;
 }
@@ -293,6 +335,12 @@ dlh_t model_t::compute_dlh(const root_location_t &root) {
       fail("compute_dlh");
     fxh += v[0];
     fx += v[1];
+  }
+  if (_reduce) {
+    double both[2] = {fxh, fx};
+    reduce_values(both, 2);
+    fxh = both[0];
+    fx = both[1];
   }
   if (std::isnan(fx))
     throw std::runtime_error("fx is not finite when computing derivative: " +
@@ -366,6 +414,7 @@ std::vector<double> model_t::compute_all_root_lh_batched() {
     if (ok != RDAMD_SUCCESS) fail("evaluate_batch");
     for (size_t j = 0; j < n; ++j) total[j] += out[j];
   }
+  reduce_values(total.data(), total.size());
   return total;
 }
 
@@ -405,6 +454,7 @@ std::vector<double> model_t::compute_all_root_lh_directional(const std::vector<d
                                         d.root_scaler.data(), _param_indicies[0].data(),
                                         out.data()) != RDAMD_SUCCESS)
     fail("compute_root_loglikelihoods");
+  reduce_values(out.data(), out.size());
   return out;
 }
 
@@ -452,6 +502,7 @@ std::vector<double> model_t::compute_lh_batch(
     if (ok != RDAMD_SUCCESS) fail("evaluate_batch");
     for (size_t j = 0; j < n; ++j) total[j] += out[j];
   }
+  reduce_values(total.data(), total.size());
   return total;
 }
 
@@ -718,12 +769,27 @@ double model_t::bfgs_params(model_params_t &initial, size_t pi, bfgs_target what
       std::copy(r.begin(), r.end(), rates.begin() + j * R);
       std::copy(_rate_weights[pi].begin(), _rate_weights[pi].end(), weights.begin() + j * R);
     }
-    if (_combiner)   // meets the other candidates' requests in one launch
+    if (_combiner) {   // meets the other candidates' requests in one launch
       _combiner->evaluate((unsigned)m, sched, subst.data(), freqs.data(), rates.data(),
                           weights.data(), out.data());
-    else if (rdamd_evaluate_batch(part, (unsigned)m, scheds.data(), subst.data(), freqs.data(),
-                                  rates.data(), weights.data(), out.data()) != RDAMD_SUCCESS)
-      fail("evaluate_batch");
+    } else if (_reduce && _reduce_device) {
+      // site-sharded: the per-block lnLs stay on the device, the all-reduce is queued
+      // behind the batch on the partition's stream, one copy brings the sums back
+      double *d = reduce_scratch(m);
+      hipStream_t st = (hipStream_t)rdamd_partition_stream(part);
+      if (rdamd_evaluate_batch_device(part, (unsigned)m, scheds.data(), subst.data(), freqs.data(),
+                                      rates.data(), weights.data(), d) != RDAMD_SUCCESS)
+        fail("evaluate_batch");
+      if (_reduce(d, (unsigned)m, st, _reduce_user) != RDAMD_SUCCESS ||
+          hipMemcpyAsync(out.data(), d, m * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess ||
+          hipStreamSynchronize(st) != hipSuccess)
+        throw std::runtime_error("site-group reduction failed");
+    } else {
+      if (rdamd_evaluate_batch(part, (unsigned)m, scheds.data(), subst.data(), freqs.data(),
+                               rates.data(), weights.data(), out.data()) != RDAMD_SUCCESS)
+        fail("evaluate_batch");
+      reduce_values(out.data(), m);
+    }
     _objective_batches += 1;
     _objective_evals += m;
     for (auto &v : out) {
@@ -789,6 +855,9 @@ void model_t::optimize_params(std::vector<partition_parameters_t> &params,
   auto sc = _tree.generate_operations(rl);
   if (_combiner && _partitions.size() != 1)
     throw std::runtime_error("optimize_params: the batch combiner handles one partition");
+  if (_combiner && _reduce)
+    throw std::runtime_error("optimize_params: a site-sharded model runs its candidates "
+                             "sequentially (no batch combiner)");
   batch_combiner_t::scope_t in_lockstep(_combiner);
   for (size_t i = 0; i < _partitions.size(); ++i) {
     if (rdamd_partition_states(_partitions[i]) != 4 && rdamd_partition_states(_partitions[i]) != 2)

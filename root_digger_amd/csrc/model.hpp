@@ -77,6 +77,8 @@ struct msa_t {
   static msa_t from_file(const std::string &filename, const uint64_t *map = nullptr,
                          unsigned int states = 4, bool compress_patterns = true);
   void compress();                                                    // src/msa.cpp:621-633
+  // columns [lo, hi) of an UNCOMPRESSED alignment (a site block of a site-sharded run)
+  msa_t columns(size_t lo, size_t hi) const;
   bool constiency_check(const std::unordered_set<std::string> &tree_labels) const;   // :641-668
   void valid_data() const;                                            // :670-686
 };
@@ -153,6 +155,14 @@ public:
   // the optimiser's objective batches go through this combiner (batch_combiner.hpp)
   // instead of being launched on this model's own partition; not owned
   void set_combiner(batch_combiner_t *c) { _combiner = c; }
+  // Site-sharded runs: this model holds one block of the alignment's
+  // columns; every lnL it computes is summed over the ranks of its site group
+  // through `fn` before any optimiser sees it (include/root_digger_amd.h,
+  // rdamd_lnl_reducer_t).  device = true: fn takes device memory + the stream.
+  void set_lnl_reducer(rdamd_lnl_reducer_t fn, void *user, bool device) {
+    _reduce = fn; _reduce_user = user; _reduce_device = device;
+  }
+  bool site_sharded() const { return _reduce != nullptr; }
   // src/model.cpp:1925-1984
   void optimize_params(std::vector<partition_parameters_t> &params, const root_location_t &rl,
                        double pgtol, double factor, bool optimize_gamma);
@@ -223,6 +233,15 @@ private:
   void update_pmatrices(const std::vector<unsigned int> &pmatrix_indices,
                         const std::vector<double> &branch_lengths);   // :357-382 (one call per partition)
 
+  void   reduce_values(double *values, size_t n);   // no-op without a reducer
+  double reduce_value(double v) { reduce_values(&v, 1); return v; }
+  double *reduce_scratch(size_t n);                 // device buffer of >= n doubles
+
+  rdamd_lnl_reducer_t                    _reduce = nullptr;
+  void                                  *_reduce_user = nullptr;
+  bool                                   _reduce_device = false;
+  double                                *_d_reduce = nullptr;
+  size_t                                 _d_reduce_cap = 0;
   rooted_tree_t                          _tree;
   std::vector<rdamd_partition_t *>       _partitions;
   std::vector<rate_category>             _rate_category_types;

@@ -97,13 +97,28 @@ rdamd_model_t *rdamd_model_create(const rdamd_tree_t *tree, unsigned int n_taxa,
 static rdamd_model_t *create_from_file(const rdamd_tree_t *tree, const char *msa_filename,
                                        unsigned int states, const uint64_t *map,
                                        const rdamd::ratehet_opts_t &rc, uint64_t seed,
-                                       int early_stop, int compress, unsigned int *n_patterns) {
+                                       int early_stop, int compress, unsigned int *n_patterns,
+                                       unsigned int block = 0, unsigned int n_blocks = 1,
+                                       unsigned int *n_columns = nullptr) {
   GUARD(nullptr, {
     auto *m = new rdamd_model();
     m->rate_cats = (unsigned)rc.rate_cats; m->seed = seed; m->early_stop = early_stop != 0;
     m->ratehets = {rc};
     try {
-      m->msa = rdamd::msa_t::from_file(msa_filename, map, states, compress != 0);
+      if (n_blocks <= 1) {
+        m->msa = rdamd::msa_t::from_file(msa_filename, map, states, compress != 0);
+        if (n_columns) *n_columns = m->msa.total_weight();
+      } else {   // one site block of a site-sharded run: cut first, compress the block
+        if (block >= n_blocks) throw std::invalid_argument("site block index out of range");
+        const rdamd::msa_t whole = rdamd::msa_t::from_file(msa_filename, map, states, false);
+        const size_t len = whole.length(), size = len / n_blocks, mod = len % n_blocks;
+        const size_t lo = size * block + std::min<size_t>(mod, block);           // src/model.cpp:1899-1907
+        const size_t hi = size * (block + 1) + std::min<size_t>(mod, block + 1);
+        if (lo == hi) throw std::invalid_argument("more site blocks than alignment columns");
+        m->msa = whole.columns(lo, hi);
+        if (compress) m->msa.compress();
+        if (n_columns) *n_columns = (unsigned)len;
+      }
       if (!m->msa.constiency_check(rdamd_tree_cpp(tree).label_set()))
         throw std::invalid_argument("Taxa on the tree and in the MSA are inconsistient");
       m->model = new rdamd::model_t(rdamd_tree_cpp(tree), {m->msa}, {rc}, false, seed,
@@ -137,6 +152,28 @@ rdamd_model_t *rdamd_model_create_from_file_ratehet(const rdamd_tree_t *tree,
   rc.alpha = ratehet->alpha;
   return create_from_file(tree, msa_filename, states, map, rc, seed, early_stop, compress,
                           n_patterns);
+}
+rdamd_model_t *rdamd_model_create_from_file_block(const rdamd_tree_t *tree, const char *msa_filename,
+                                                  unsigned int states, const uint64_t *map,
+                                                  const rdamd_ratehet_opts_t *ratehet,
+                                                  uint64_t seed, int early_stop, int compress,
+                                                  unsigned int block, unsigned int n_blocks,
+                                                  unsigned int *n_patterns,
+                                                  unsigned int *n_columns) {
+  rdamd::ratehet_opts_t rc(ratehet->rate_cats ? ratehet->rate_cats : 1);
+  rc.type = (rdamd::param_type)ratehet->type;
+  rc.rate_category_type = (rdamd::rate_category)ratehet->rate_category_type;
+  rc.alpha_init = ratehet->alpha_init != 0;
+  rc.alpha = ratehet->alpha;
+  return create_from_file(tree, msa_filename, states, map, rc, seed, early_stop, compress,
+                          n_patterns, block, n_blocks, n_columns);
+}
+int rdamd_model_set_lnl_reducer(rdamd_model_t *m, rdamd_lnl_reducer_t reduce, void *user,
+                                int on_device) {
+  GUARD(RDAMD_FAILURE, {
+    m->model->set_lnl_reducer(reduce, user, on_device != 0);
+    return RDAMD_SUCCESS;
+  })
 }
 // The reference's partitioned set-up (src/main.cpp:512-555): the alignment is read
 // whole, cut into the partition file's column ranges, each partition compressed
@@ -370,6 +407,10 @@ static int search_with_replicas(rdamd_model_t *m, unsigned int workers, bool loc
   GUARD(RDAMD_FAILURE, {
     // lock-step: the replicas' objective batches meet in one launch on THIS
     // model's partition (batch_combiner.hpp); it does nothing else meanwhile
+    if (m->model->site_sharded())
+      throw std::runtime_error("a site-sharded model runs its candidates sequentially "
+                               "(rdamd_model_exhaustive_search): replicas would reorder the "
+                               "site group's collectives");
     std::unique_ptr<rdamd::batch_combiner_t> combiner;
     if (lockstep) combiner.reset(new rdamd::batch_combiner_t(m->model->partition(0)));
     const std::vector<size_t> todo = m->model->assigned_indicies();

@@ -157,6 +157,19 @@ void msa_t::compress() {
 }
 
 // src/msa.cpp:641-668
+msa_t msa_t::columns(size_t lo, size_t hi) const {
+  for (auto w : weights)
+    if (w != 1u) throw std::runtime_error("msa_t::columns: the alignment is already compressed");
+  if (lo > hi || hi > length()) throw std::out_of_range("msa_t::columns: block outside the alignment");
+  msa_t out;
+  out.labels = labels;
+  out.states = states;
+  out.map = map;
+  for (const auto &s : sequences) out.sequences.push_back(s.substr(lo, hi - lo));
+  if (!weights.empty()) out.weights.assign(hi - lo, 1u);
+  return out;
+}
+
 bool msa_t::constiency_check(const std::unordered_set<std::string> &tree_labels) const {
   std::unordered_set<std::string> taxa(labels.begin(), labels.end());
   for (const auto &k : tree_labels)

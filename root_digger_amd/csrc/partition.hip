@@ -380,6 +380,12 @@ unsigned int rdamd_partition_states(const rdamd_partition_t *p) { return p->api_
 unsigned int rdamd_partition_rate_cats(const rdamd_partition_t *p) { return p->rate_cats; }
 unsigned int rdamd_partition_sites(const rdamd_partition_t *p) { return p->sites; }
 unsigned int rdamd_partition_tips(const rdamd_partition_t *p) { return p->tips; }
+double rdamd_partition_weight_sum(const rdamd_partition_t *p) {
+  double total = 0.0;
+  for (unsigned s = 0; s < p->sites; ++s) total += p->pattern_weights[s];
+  return total;
+}
+void *rdamd_partition_stream(const rdamd_partition_t *p) { return (void *)p->stream; }
 const double *rdamd_partition_subst_params(const rdamd_partition_t *p, unsigned int i) {
   if (i >= p->rate_matrices) return nullptr;
   return p->embedded() ? p->api_subst[i].data() : p->subst[i].data();

@@ -9,6 +9,14 @@
 // ranks (src/model.cpp:1867-1911) and meet in the <prefix>.ckp file; they
 // synchronise over TCP at MASTER_ADDR:MASTER_PORT.
 //
+// --site-shards G (new here; north star / SURVEY 8e): the ranks form WORLD_SIZE/G
+// candidate groups of G adjacent ranks.  A group shares its candidates; each
+// member holds one contiguous block of the alignment's columns, and every
+// log-likelihood is summed over the group -- with an RCCL all-reduce on the
+// device (default), or through the host with --site-reduce host (ranks that
+// share one GPU).  G = WORLD_SIZE is BASELINE config c4's layout (site blocks
+// only), 1 < G < WORLD_SIZE config c5's 2-D grid.
+//
 //   rd_amd --msa aln.fasta --tree t.nwk --prefix out --exhaustive --lbfgsb liblbfgsb.so
 #include <chrono>
 #include <cmath>
@@ -21,21 +29,20 @@
 #include <iostream>
 #include <stdexcept>
 #include <string>
-#include <arpa/inet.h>
-#include <netinet/in.h>
-#include <sys/socket.h>
-#include <unistd.h>
+#include <memory>
 #include <thread>
 #include <vector>
 
 #include "root_digger_amd.h"
+#include "rendezvous.hpp"
 
 namespace {
 
 struct options_t {
   std::string msa, tree, prefix, partition, model, lbfgsb, rate_cats_type = "mean";
   unsigned states = 4, rate_cats = 1, min_roots = 1, workers = 4;
-  int lockstep = -1, device = -1;
+  int lockstep = -1, device = -1, site_shards = 1;
+  bool site_reduce_host = false;
   uint64_t seed = 1;
   double root_ratio = 0.01, atol = 1e-7, bfgstol = 1e-7, brtol = 1e-12, factor = 1e4;
   int early_stop = 0;   // initialized_flag_t: 0 unset, 1 true, 2 false
@@ -59,6 +66,7 @@ void usage() {
       "  --rate-cats-type {mean,median,free}  --seed <N>  --min-roots <N>  --root-ratio <X>\n"
       "  --atol <X>  --brtol <X>  --bfgstol <X>  --factor <X>  --early-stop  --no-early-stop\n"
       "  --initial-root-strategy {random,midpoint,modified-mad}  --threads <N>  --lockstep <N>\n"
+      "  --site-shards <G>  --site-reduce {rccl,host}\n"
       "  --lbfgsb <LIB>  --device <N>  --silent  --echo  --clean  --no-checkpoint  --version");
 }
 
@@ -80,7 +88,8 @@ options_t parse(int argc, char **argv) {
       {"clean", no_argument, 0, 0},              {"echo", no_argument, 0, 0},
       {"help", no_argument, 0, 0},               {"lbfgsb", required_argument, 0, 0},
       {"lockstep", required_argument, 0, 0},     {"device", required_argument, 0, 0},
-      {"no-checkpoint", no_argument, 0, 0},      {0, 0, 0, 0}};
+      {"no-checkpoint", no_argument, 0, 0},      {"site-shards", required_argument, 0, 0},
+      {"site-reduce", required_argument, 0, 0},  {0, 0, 0, 0}};
   options_t o;
   int index = 0;
   while (getopt_long_only(argc, argv, "", long_opts, &index) == 0) {
@@ -119,6 +128,12 @@ options_t parse(int argc, char **argv) {
     else if (name == "lockstep") o.lockstep = std::atoi(v);
     else if (name == "device") o.device = std::atoi(v);
     else if (name == "no-checkpoint") o.no_checkpoint = true;
+    else if (name == "site-shards") o.site_shards = std::atoi(v);
+    else if (name == "site-reduce") {
+      const std::string s = v;
+      if (s != "rccl" && s != "host") die("--site-reduce takes rccl or host");
+      o.site_reduce_host = s == "host";
+    }
   }
   return o;
 }
@@ -128,74 +143,21 @@ int env_int(const char *name, int fallback) {
   return v ? std::atoi(v) : fallback;
 }
 
-// The ranks of one run meet over TCP at MASTER_ADDR:MASTER_PORT (the variables
-// every torch-style launcher exports; rank 0 listens).  The reference uses
-// MPI_Barrier; this program carries no message-passing runtime.
-class rendezvous_t {
-public:
-  rendezvous_t(int rank, int world) : _rank(rank), _world(world) {
-    if (world <= 1) return;
-    const char *addr = std::getenv("MASTER_ADDR");
-    const int port = env_int("MASTER_PORT", 29400);
-    sockaddr_in sa;
-    std::memset(&sa, 0, sizeof sa);
-    sa.sin_family = AF_INET;
-    sa.sin_port = htons((uint16_t)port);
-    if (rank == 0) {
-      const int ls = socket(AF_INET, SOCK_STREAM, 0);
-      const int one = 1;
-      setsockopt(ls, SOL_SOCKET, SO_REUSEADDR, &one, sizeof one);
-      sa.sin_addr.s_addr = htonl(INADDR_ANY);
-      if (ls < 0 || bind(ls, (sockaddr *)&sa, sizeof sa) != 0 || listen(ls, world) != 0)
-        die("rank 0 cannot listen on MASTER_PORT " + std::to_string(port));
-      for (int i = 1; i < world; ++i) {
-        const int fd = accept(ls, nullptr, nullptr);
-        if (fd < 0) die("rendezvous: accept failed");
-        _peers.push_back(fd);
-      }
-      close(ls);
-    } else {
-      if (inet_pton(AF_INET, addr ? addr : "127.0.0.1", &sa.sin_addr) != 1)
-        die(std::string("MASTER_ADDR is not an IPv4 address: ") + (addr ? addr : ""));
-      const auto t0 = std::chrono::steady_clock::now();
-      for (;;) {   // rank 0 may not be listening yet
-        const int fd = socket(AF_INET, SOCK_STREAM, 0);
-        if (fd >= 0 && connect(fd, (sockaddr *)&sa, sizeof sa) == 0) {
-          _peers.push_back(fd);
-          break;
-        }
-        if (fd >= 0) close(fd);
-        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 600)
-          die("rank " + std::to_string(rank) + " could not reach rank 0 at MASTER_ADDR:MASTER_PORT");
-        std::this_thread::sleep_for(std::chrono::milliseconds(50));
-      }
-    }
-  }
-  ~rendezvous_t() {
-    for (int fd : _peers) close(fd);
-  }
-  void barrier() {
-    if (_world <= 1) return;
-    char byte = 1;
-    if (_rank == 0) {
-      for (int fd : _peers)
-        if (recv(fd, &byte, 1, MSG_WAITALL) != 1) die("rendezvous: a rank went away");
-      for (int fd : _peers)
-        if (send(fd, &byte, 1, MSG_NOSIGNAL) != 1) die("rendezvous: a rank went away");
-    } else {
-      if (send(_peers[0], &byte, 1, MSG_NOSIGNAL) != 1 || recv(_peers[0], &byte, 1, MSG_WAITALL) != 1)
-        die("rendezvous: rank 0 went away");
-    }
-  }
-
-private:
-  int _rank, _world;
-  std::vector<int> _peers;
-};
-
 }  // namespace
 
+static int run(int argc, char **argv);
+
 int main(int argc, char **argv) {
+  try {
+    return run(argc, argv);
+  } catch (const std::exception &e) {
+    die(e.what());
+  }
+}
+
+static int run(int argc, char **argv) {
+  using rdamd_tools::rendezvous_t;
+  using rdamd_tools::site_group_t;
   const auto start = std::chrono::steady_clock::now();
   options_t o = parse(argc, argv);
   const int rank = env_int("RANK", 0), world = env_int("WORLD_SIZE", 1);
@@ -203,6 +165,23 @@ int main(int argc, char **argv) {
   if (world > 1 && o.no_checkpoint) die("--no-checkpoint: the ranks of a run meet in the checkpoint file");
   need(rdamd_set_device(o.device >= 0 ? o.device : env_int("LOCAL_RANK", 0)), "set_device");
   rendezvous_t ranks(rank, world);
+  // candidate groups x site shards (see the header comment): rank = cgroup * G + srank
+  const int G = o.site_shards;
+  if (G < 1 || world % G) die("--site-shards must divide the number of ranks");
+  const int cgroups = world / G, cgroup = rank / G, srank = rank % G;
+  if (G > 1 && !o.partition.empty()) die("--site-shards: partition files are not supported");
+  std::unique_ptr<site_group_t> host_group;
+  rdamd_comm_t *comm = nullptr;
+  if (G > 1 && o.site_reduce_host) {
+    host_group.reset(new site_group_t(ranks, G));
+  } else if (G > 1) {   // the group leader's RCCL id reaches the members over the world star
+    char id[128] = {0};
+    if (srank == 0) need(rdamd_comm_unique_id(id), "RCCL unique id");
+    std::vector<char> all;
+    ranks.allgather(id, sizeof id, all);
+    comm = rdamd_comm_create(all.data() + sizeof id * (size_t)(cgroup * G), srank, G);
+    if (!comm) die(std::string("RCCL communicator: ") + rdamd_errmsg());
+  }
 
   // ---- checkpoint: mpi_create_checkpoint + merge_options_checkpoint, src/main.cpp:335-409
   rdamd_checkpoint_t *ckp = nullptr;
@@ -281,11 +260,22 @@ int main(int argc, char **argv) {
   } else {
     rdamd_ratehet_opts_t rc{1, o.rate_cats_type == "median" ? 0 : o.rate_cats_type == "free" ? 2 : 1,
                             o.rate_cats, 0, 1.0};
-    unsigned patterns = 0;
-    model = rdamd_model_create_from_file_ratehet(tree, o.msa.c_str(), o.states, map, &rc, o.seed,
-                                                 early_stop, 1, &patterns);
+    unsigned patterns = 0, columns = 0;
+    model = G > 1 ? rdamd_model_create_from_file_block(tree, o.msa.c_str(), o.states, map, &rc, o.seed,
+                                                       early_stop, 1, (unsigned)srank, (unsigned)G,
+                                                       &patterns, &columns)
+                  : rdamd_model_create_from_file_ratehet(tree, o.msa.c_str(), o.states, map, &rc,
+                                                         o.seed, early_stop, 1, &patterns);
+    if (model && G > 1 && !o.silent)
+      std::printf("[rank %d] candidate group %d/%d, site block %d/%d: %u patterns of %u columns\n",
+                  rank, cgroup, cgroups, srank, G, patterns, columns);
   }
   if (!model) die(rdamd_errmsg());
+  // before anything is evaluated: the empirical frequencies are reduced too
+  if (host_group)
+    need(rdamd_model_set_lnl_reducer(model, site_group_t::reducer, host_group.get(), 0), "reducer");
+  else if (comm)
+    need(rdamd_model_set_lnl_reducer(model, rdamd_comm_reducer, comm, 1), "reducer");
   if (o.echo) {
     char *nw = rdamd_tree_newick(tree, 1);
     std::cout << nw << std::endl;
@@ -302,8 +292,9 @@ int main(int argc, char **argv) {
   rdamd_root_location_t rl0;
   need(rdamd_tree_root_location(tree, 0, &rl0), "root_location");
   rdamd_model_compute_lh(model, &rl0);                                   // model.initialize()
-  if (ckp) rdamd_model_set_checkpoint(model, ckp);
+  if (ckp && srank == 0) rdamd_model_set_checkpoint(model, ckp);   // one record per candidate
   if (o.lockstep < 0) o.lockstep = (!o.lbfgsb.empty() && o.partition.empty()) ? 16 : 0;
+  if (G > 1) o.lockstep = o.workers = 0;   // a site group walks its candidates in step
 
   // ---- the search (src/main.cpp:586-635)
   std::vector<uint64_t> ids(roots);
@@ -313,7 +304,7 @@ int main(int argc, char **argv) {
   double best_llh = -INFINITY;
   std::memset(&best, 0, sizeof best);
   if (o.exhaustive) {
-    need(rdamd_model_assign_by_rank_checkpoint(model, (unsigned)rank, (unsigned)world, ckp), "assign");
+    need(rdamd_model_assign_by_rank_checkpoint(model, (unsigned)cgroup, (unsigned)cgroups, ckp), "assign");
     ranks.barrier();
     if (!o.silent && rank == 0) {
       std::puts("Starting exhaustive search");
@@ -333,8 +324,8 @@ int main(int argc, char **argv) {
            "exhaustive_search");
   } else {
     if (o.lbfgsb.empty()) die("the heuristic search optimises the model parameters: it needs --lbfgsb");
-    need(rdamd_model_assign_by_rank_search(model, o.min_roots, o.root_ratio, (unsigned)rank,
-                                           (unsigned)world, o.strategy, ckp), "assign");
+    need(rdamd_model_assign_by_rank_search(model, o.min_roots, o.root_ratio, (unsigned)cgroup,
+                                           (unsigned)cgroups, o.strategy, ckp), "assign");
     ranks.barrier();
     std::vector<uint64_t> mine(roots);
     const int assigned = rdamd_model_assigned(model, mine.data(), roots);
@@ -350,7 +341,11 @@ int main(int argc, char **argv) {
     }
   }
   ranks.barrier();
-  if (rank != 0) return 0;
+  if (rank != 0) {
+    rdamd_model_destroy(model);
+    if (comm) rdamd_comm_destroy(comm);
+    return 0;
+  }
 
   // ---- rank 0: everybody's results from the log (src/model.cpp:1237-1268), the trees
   if (ckp) {
@@ -415,6 +410,7 @@ int main(int argc, char **argv) {
   }
   rdamd_tree_destroy(out);
   rdamd_model_destroy(model);
+  if (comm) rdamd_comm_destroy(comm);
   rdamd_tree_destroy(tree);
   if (ckp) rdamd_checkpoint_close(ckp);
   return 0;

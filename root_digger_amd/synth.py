@@ -82,17 +82,12 @@ def simulate(root, n_sites, subst, freqs, rates, rng, alphabet=DNA):
 
     def down(node, states):
         if node is not root:
-            new = np.empty_like(states)
+            # one CDF table per (rate category, parent state); every site looks up
+            # its own row and counts the thresholds its uniform draw exceeds
+            cdf = np.stack([np.cumsum(_expm(q * rate * node.length), axis=1) for rate in rates])
+            cdf[:, :, -1] = 1.0
             u = rng.random(n_sites)
-            for r, rate in enumerate(rates):
-                sel = cat == r
-                if not sel.any():
-                    continue
-                cdf = np.cumsum(_expm(q * rate * node.length), axis=1)
-                cdf[:, -1] = 1.0
-                rows = cdf[states[sel]]
-                new[sel] = (u[sel][:, None] > rows).sum(axis=1)
-            states = np.minimum(new, k - 1)
+            states = np.minimum((u[:, None] > cdf[cat, states]).sum(axis=1), k - 1)
         if not node.children:
             seqs[node.name] = letters[states].tobytes().decode()
         for c in node.children:

@@ -187,3 +187,59 @@ def test_world_size_4_grid_of_candidate_groups_and_site_shards():
         assert part == [(cgroup + 1) * 11.0, (cgroup + 1) * 22.0]            # 10^0 + 10^1 per job
         want0 = (0.1 * 100 + 0.2 * 200) / 300
         assert abs(freqs[0] - want0) < 1e-15 and abs(sum(freqs) - 1.0) < 1e-15
+
+
+def test_bench_parent_spawns_one_child_per_gpu(tmp_path):
+    """`python bench.py --gpus 2` with no launcher must start two ranks itself
+    (it used to run one rank and print n_gpus 1).  Without a GPU the
+    children stop at bench.py's own "needs a HIP device" check: the parent must
+    pass that failure on instead of printing a 1-rank line."""
+    import subprocess
+    root = os.path.dirname(HERE)
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2",
+                          "--config", "c1", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=300, env=env)
+    if rd.device_count() > 0:
+        pytest.skip("GPU present: covered by tests/test_gpu_bench.py")
+    assert out.returncode != 0
+    assert '"n_gpus"' not in out.stdout
+    assert out.stderr.count("bench.py needs a HIP device") == 2     # one message per child rank
+
+
+def test_bench_refuses_a_world_size_that_contradicts_gpus():
+    import subprocess
+    root = os.path.dirname(HERE)
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"],
+                         capture_output=True, text=True, timeout=120, env=env)
+    assert out.returncode != 0 and "WORLD_SIZE (1) != --gpus (2)" in out.stderr
+
+
+@pytest.mark.parametrize("world,group", [(2, 2), (4, 2), (3, 1)])
+def test_rd_amd_rendezvous_and_host_site_group_sum(tmp_path, world, group):
+    """rd_amd's own channel (csrc/tools/rendezvous.hpp): TCP star allgather + the
+    host-side lnL sum inside a site group (`--site-reduce host`), as `world`
+    plain processes on CPU.  Sums are formed in rank order by the group leader and
+    are identical on every member."""
+    import subprocess
+    root = os.path.dirname(HERE)
+    exe = str(tmp_path / "rendezvous_check")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I",
+                           os.path.join(root, "root_digger_amd", "csrc", "tools"),
+                           os.path.join(HERE, "cpp", "rendezvous_check.cpp"), "-o", exe, "-lpthread"])
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    procs = [subprocess.Popen([exe, str(r), str(world), str(group)], env=env,
+                              stdout=subprocess.PIPE, text=True) for r in range(world)]
+    outs = [p.communicate(timeout=120)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs)
+    for r, out in enumerate(outs):
+        rank, gather, total = out.split()
+        assert int(rank) == r
+        assert gather == "gather=" + ",".join(str(100 + i) for i in range(world))
+        members = range(r - r % group, r - r % group + group)
+        want = [sum(1.0 + m for m in members), sum(0.5 * m for m in members), 1e-3 * group]
+        got = [float(x) for x in total[len("sum="):].split(",")]
+        assert got[:2] == want[:2] and abs(got[2] - want[2]) < 1e-18
+        assert total == outs[r - r % group].split()[2]        # same bits as the group leader

@@ -35,7 +35,14 @@ def test_bench_line_has_the_contract_fields():
     r = d["roofline"]
     for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert key in r, key
-    assert r["bound"] in ("hbm", "mfma") and r["peak"] == 8000.0
+    # the fused 4-state kernel is bound by FP64 FMA issue, not by HBM: the headline
+    # roofline is flops against the FP64 peak, and no fraction may exceed 1
+    assert r["kernel"] == "fused_dna_eval_kernel" and r["bound"] == "fp64"
+    assert r["unit"] == "TFLOP/s" and r["peak"] == 78.6 and 0 < r["frac"] <= 1.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert "frac" not in r["hbm_equiv"]
+    k = d["clv_kernel"]
+    assert k["bound"] == "hbm" and k["peak"] == 8000.0 and 0 < k["frac"] <= 1.0
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0
     assert c["parity_max_rel_err"] < 1e-9
@@ -54,5 +61,19 @@ def test_protein_config_runs_through_the_20_state_fused_evaluator():
     kernels_fused_k20.hip and agrees with the CPU oracle on the sampled jobs."""
     d = run_bench("--cpu-seconds", "3", config="c3", steps="1", batch="6")
     assert d["config"]["path"] == "fused batch" and d["roofline"]["kernel"] == "fused20_eval_kernel"
+    assert d["roofline"]["bound"] == "mfma" and 0 < d["roofline"]["frac"] <= 1.0
     assert d["value"] > 0
     assert d["cpu_baseline"]["parity_max_rel_err"] < 1e-9
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher: the parent spawns two ranks
+    (both on device 0 of this one-GPU box, gloo collectives) and relays rank 0's
+    line, which must say n_gpus 2 and carry the two ranks' aggregate rate."""
+    d = run_bench("--no-cpu-baseline", "--gpus", "2", "--dist-backend", "gloo", "--device", "0")
+    assert d["n_gpus"] == 2 and d["value"] > 0
+    s = run_bench("--no-cpu-baseline", "--gpus", "2", "--dist-backend", "gloo", "--device", "0",
+                  "--shard", "sites")
+    one = run_bench("--no-cpu-baseline", "--shard", "sites")
+    assert s["n_gpus"] == 2
+    assert abs(s["lnl_check"] - one["lnl_check"]) <= 1e-9 * abs(one["lnl_check"])

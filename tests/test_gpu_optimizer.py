@@ -12,12 +12,13 @@ import numpy as np
 import pytest
 
 import root_digger_amd as rd
-from oracle_lib import OraclePartition, ORC_MAP_NT
+from oracle_lib import OraclePartition, ORC_MAP_NT, orc_gamma_cats
 import util
 
 pytestmark = pytest.mark.gpu
 
 REF = os.path.join(util.ROOT, "oracle", "_ref", "liblbfgsb_ref.so")
+PARAMS3 = [.34, .42, .24, .74, .16, .88, .75, .54, .20, .06, .08, .41]
 
 
 @pytest.fixture(scope="module")
@@ -198,6 +199,39 @@ def test_batched_root_sweep_equals_move_root_sweep():
     d = m.compute_all_root_lh_directional(ratios)
     want = np.array([m.compute_lh(tree.root_location(i).with_ratio(float(ratios[i]))) for i in (0, 57, 198)])
     assert np.max(np.abs(d[[0, 57, 198]] - want) / np.abs(want)) < 1e-12
+
+
+def test_directional_cache_vs_oracle_all_199_roots():
+    """SURVEY 8(f)2, the all-directions CLV cache, against the CPU oracle directly
+    (not against this library's own move_root sweep): 101.phy (ambiguity codes,
+    zero-length branches), all 199 candidate branches, two root-position vectors
+    and two parameter sets; the oracle does a full traversal per root
+    (model_t::compute_lh, src/model.cpp:384-413)."""
+    tree = rd.Tree.from_file(os.path.join(util.DATA, "101.tree"))
+    seqs, w = util.compress(util.read_phylip(os.path.join(util.DATA, "101.phy")))
+    S = len(next(iter(seqs.values())))
+    m = rd.Model(tree, seqs, rate_cats=4, weights=w, seed=4)
+    m.initialize_partitions()
+    o = OraclePartition.for_tree(tree, 4, S, 4)
+    util.load_tips(o, tree, seqs, ORC_MAP_NT, w)
+    freqs = o.empirical_frequencies()
+    t2 = rd.Tree.from_file(os.path.join(util.DATA, "101.tree"))
+    rng = np.random.default_rng(1012)
+    cases = [(PARAMS3, 0.6, np.full(199, 0.5)),
+             (list(rng.uniform(1e-4, 1.0, 12)), 1.7, rng.uniform(0.02, 0.98, 199))]
+    for subst, alpha, ratios in cases:
+        m.set_subst_rates(subst)
+        m.set_empirical_freqs()
+        m.set_gamma_alpha(alpha)
+        o.set_subst_params(0, subst)
+        o.set_frequencies(0, freqs)
+        o.set_category_rates(orc_gamma_cats(alpha, 4, 1))   # model_t: MEDIAN mode after the first call
+        got = m.compute_all_root_lh_directional(ratios)
+        assert len(got) == 199
+        want = np.array([util.compute_lh(o, t2, t2.root_location(i).with_ratio(float(ratios[i])))
+                         for i in range(199)])
+        assert np.max(np.abs(got - want) / np.abs(want)) < 1e-11
+    o.destroy()
 
 
 def test_batched_root_reduction_is_bit_identical_to_single_calls():

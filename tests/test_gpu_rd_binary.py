@@ -65,3 +65,57 @@ def test_native_front_end_two_ranks_and_search_mode(tmp_path):
     assert out.returncode == 0, out.stdout + out.stderr
     assert len(rd.Checkpoint(s).read_results()) == 2 and not os.path.exists(s + ".lwr.tree")
     assert rd.Tree.from_newick(open(s + ".rooted.tree").read()).tip_count() == 10
+
+
+def _run_ranks(args, world, timeout=600):
+    s = __import__("socket").socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    procs = [subprocess.Popen(args, env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for r in range(world)]
+    outs = [p.communicate(timeout=timeout)[0] for p in procs]
+    assert [p.returncode for p in procs] == [0] * world, outs
+    return outs
+
+
+@pytest.mark.parametrize("world,shards", [(2, 2), (4, 2)])
+def test_site_sharded_exhaustive_search_writes_the_one_rank_records(tmp_path, world, shards):
+    """`rd_amd --site-shards G` (north star: site blocks + lnL all-reduce inside the
+    product): 2 ranks = one site group of two column blocks (BASELINE c4's layout),
+    4 ranks = 2 candidate groups x 2 site blocks (c5's 2-D grid).  All ranks share
+    device 0 of this box, so the sums go through `--site-reduce host`; the model
+    hook is the one RCCL uses.  The checkpoint must hold the one-rank run's
+    records: one per candidate, same root ids, lnL/alpha to optimiser tolerance."""
+    if not os.path.exists(REF):
+        pytest.skip("oracle/_ref/liblbfgsb_ref.so not built")
+    # (tight optimiser settings: the block sums differ from the one-rank sum in the
+    # last bit, and a loosely converged L-BFGS-B run would amplify that)
+    common = ["--msa", MSA, "--tree", TREE, "--exhaustive", "--silent", "--rate-cats", "4",
+              "--atol", "1e-7", "--brtol", "1e-9", "--bfgstol", "1e-7", "--factor", "1e4",
+              "--seed", "5", "--lbfgsb", REF, "--device", "0", "--threads", "0", "--lockstep", "0"]
+    one, many = str(tmp_path / "one"), str(tmp_path / "many")
+    out = subprocess.run([RD] + common + ["--prefix", one], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    outs = _run_ranks([RD] + common + ["--prefix", many, "--site-shards", str(shards),
+                                       "--site-reduce", "host"], world)
+    ra = sorted(rd.Checkpoint(one).read_results())
+    rb = sorted(rd.Checkpoint(many).read_results())
+    assert [r[0] for r in rb] == [r[0] for r in ra] == list(range(17))      # one record per candidate
+    for a, b in zip(ra, rb):
+        assert abs(a[1] - b[1]) <= 2e-6 * abs(a[1]), (a, b)                 # lnL
+        assert abs(a[2] - b[2]) <= 2e-2, (a, b)                             # alpha
+    assert all(o.strip() == "" for o in outs[1:]) and outs[0].strip().startswith("(")
+    ta = rd.Tree.from_newick(open(one + ".rooted.tree").read())
+    tb = rd.Tree.from_newick(open(many + ".rooted.tree").read())
+    assert ta.tip_count() == tb.tip_count() == 10
+    best_a, best_b = max(ra, key=lambda r: r[1]), max(rb, key=lambda r: r[1])
+    assert best_a[0] == best_b[0]                                           # same best root
+
+
+def test_site_shards_must_divide_the_world(tmp_path):
+    out = subprocess.run([RD, "--msa", MSA, "--tree", TREE, "--exhaustive", "--silent", "--no-checkpoint",
+                          "--site-shards", "2"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 1 and "--site-shards must divide" in out.stdout
