@@ -26,8 +26,14 @@
 // folded on the scalar unit plus one LDS exchange (one barrier per operation).
 // A operands come from an MFMA-ready permutation of the P-matrices that the
 // P-matrix step writes ([matrix][rate][rg][ks][k][i]: the 16 values of one MFMA
-// are one cache line).  Tips are expanded from their state masks in registers
-// (a 0/1 B operand), so no tip table and no tip CLV is read.
+// are one cache line).  A tip child costs no MFMA at all: P . (0/1 vector) is a
+// row of the partition's tip table (tiptab[matrix][rate][code][state], written by
+// the P-matrix step), and a lane's five entries {4 s + grp} of that row arrive
+// through the same five 8-byte loads an older sibling's CLV would use -- only the
+// descriptor and the per-lane offset differ.  Its A copy is not fetched (empty
+// descriptor), staged or multiplied (wave-uniform branch around LDS + MFMA work
+// only, so the vector-memory instruction stream stays fixed).  Tip codes are
+// requested two operations ahead so that the table row can be requested one ahead.
 //
 // Memory pipeline.  With ~2.4 waves per SIMD on the c3 shape nothing hides a
 // memory round trip, so everything operation i+1 needs (A operands, tip codes,
@@ -91,8 +97,9 @@ __device__ __forceinline__ OpHead load_op(const_u32_ptr ops, unsigned i) {
 // what one child of the next operation brings from memory
 struct ChildLoad {
   u32x4 raw[4];               // this lane's 16-byte pieces of the MFMA-ready copy (3200 B / 64 lanes)
-  double b[kMfmaSteps];       // B operands of an older sibling (0 when the descriptor is empty)
-  unsigned code, sc;          // tip code; scaler of an older sibling
+  double b[kMfmaSteps];       // B operands of an older sibling, or a tip's finished term (its
+                              // tip-table entries); 0 when the descriptor is empty
+  unsigned sc;                // scaler of an older sibling
 };
 constexpr int kMfmaLdsChild = 4 * 64 * 16;   // bytes of LDS one child's A copy occupies per wave
 
@@ -121,14 +128,11 @@ clv_k20_traversal_kernel(DeviceView v, const double *__restrict__ pmfma,
   // flags[parity][rate]: bit c = "this rate's 20 entries of site c are all < 2^-256";
   // double-buffered by operation parity so one barrier per operation suffices
   __shared__ unsigned flags[2][16];
-  __shared__ uint64_t masks[256];   // code -> state mask
   const unsigned R = v.rate_cats, S = v.sites;
   const unsigned lane = threadIdx.x & 63, r = uni(threadIdx.x >> 6);   // wave = rate
   const unsigned col = lane & 15, grp = lane >> 4;
   const unsigned site = blockIdx.x * 16 + col;
   const unsigned ls = site < S ? site : S - 1;   // clamped for loads
-  for (unsigned e = threadIdx.x; e < 256; e += blockDim.x) masks[e] = v.codemask[e];
-  __syncthreads();
 
   const bool sc_lane = r == 0 && grp == 0;       // the lanes that own the per-site scalers
   const unsigned clv_bytes = uni((unsigned)(v.clv_stride * sizeof(double)));
@@ -144,6 +148,9 @@ clv_k20_traversal_kernel(DeviceView v, const double *__restrict__ pmfma,
       (const_u32_ptr)(((unsigned long long)uni((unsigned)(ops_u >> 32)) << 32) | uni((unsigned)ops_u));
   const char *clv_base = reinterpret_cast<const char *>(v.clv);
   const char *sc_base = reinterpret_cast<const char *>(v.scaler);
+  const char *tab_base = reinterpret_cast<const char *>(v.tiptab);
+  const unsigned tab_row = kMfmaK * 8u;                              // bytes per code
+  const unsigned tab_slot = uni(v.ncodes_cap * tab_row);             // bytes per (matrix, rate)
 
   // Wave-private LDS: the A copies of both children of the NEXT operation,
   // written as loaded (contiguous), read back as [block][my role].
@@ -153,25 +160,33 @@ clv_k20_traversal_kernel(DeviceView v, const double *__restrict__ pmfma,
   // The loads a child of the next operation may need: the descriptors of the
   // ones it does not need are empty, so the instruction stream never changes.
   // (B side first, A pieces last: the B side is wanted first.)
-  auto load_child_b = [&](unsigned src, unsigned clv, int scb, ChildLoad &c) {
-    const bool tip = src == 0u, mem = src == 1u;
+  auto load_code = [&](unsigned src, unsigned clv) -> unsigned {
+    const bool tip = src == 0u;
     const __amdgpu_buffer_rsrc_t code_rs =
         make_rsrc(v.tipcodes + (size_t)(tip ? clv : 0u) * v.tip_stride, tip ? v.tip_stride : 0u);
-    c.code = (unsigned)__builtin_amdgcn_raw_buffer_load_b8(code_rs, (int)ls, 0, 0);
-    const __amdgpu_buffer_rsrc_t clv_rs =
-        make_rsrc(clv_base + (size_t)(mem ? clv - v.tips : 0u) * clv_bytes, mem ? clv_bytes : 0u);
+    return (unsigned)__builtin_amdgcn_raw_buffer_load_b8(code_rs, (int)ls, 0, 0);
+  };
+  auto load_child_b = [&](unsigned src, unsigned clv, unsigned mat, int scb, unsigned code, ChildLoad &c) {
+    const bool tip = src == 0u, mem = src == 1u;
+    // tip: row `code` of the (matrix, rate) tip table; memory: the CLV; else nothing
+    const char *base = tip ? tab_base + (size_t)(mat * R + r) * tab_slot
+                           : clv_base + (size_t)(mem ? clv - v.tips : 0u) * clv_bytes;
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(base, tip ? tab_slot : (mem ? clv_bytes : 0u));
+    const unsigned off = tip ? (code & 255u) * tab_row + grp * 8u : ld_clv;
 #pragma unroll
     for (int s = 0; s < kMfmaSteps; ++s)
-      c.b[s] = as_f64(__builtin_amdgcn_raw_buffer_load_b64(clv_rs, (int)(ld_clv + 32u * s), 0, 0));
+      c.b[s] = as_f64(__builtin_amdgcn_raw_buffer_load_b64(rs, (int)(off + 32u * s), 0, 0));
     const bool has_sc = mem && scb >= 0;
     const __amdgpu_buffer_rsrc_t sc_rs =
         make_rsrc(sc_base + (size_t)(has_sc ? scb : 0) * sc_bytes, has_sc ? sc_bytes : 0u);
     c.sc = __builtin_amdgcn_raw_buffer_load_b32(sc_rs, (int)ld_sc, 0, 0);
   };
-  auto load_child_a = [&](unsigned mat, ChildLoad &c) {
-    // one (matrix, rate) copy = 3200 contiguous bytes; pieces past its end are dropped
+  auto load_child_a = [&](unsigned src, unsigned mat, ChildLoad &c) {
+    // one (matrix, rate) copy = 3200 contiguous bytes; pieces past its end are dropped;
+    // a tip child needs none of it
     const __amdgpu_buffer_rsrc_t rs =
-        make_rsrc(reinterpret_cast<const char *>(pmfma) + (size_t)(mat * R + r) * (kMfmaCopy * 8), kMfmaCopy * 8);
+        make_rsrc(reinterpret_cast<const char *>(pmfma) + (size_t)(mat * R + r) * (kMfmaCopy * 8),
+                  src == 0u ? 0u : kMfmaCopy * 8);
 #pragma unroll
     for (int k = 0; k < 4; ++k)
       c.raw[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(lane * 16u + 1024u * k), 0, 0);
@@ -204,7 +219,6 @@ clv_k20_traversal_kernel(DeviceView v, const double *__restrict__ pmfma,
   for (int k = 0; k < 4; ++k) c1.raw[k] = c2.raw[k] = u32x4{0u, 0u, 0u, 0u};
 #pragma unroll
   for (int s = 0; s < kMfmaSteps; ++s) c1.b[s] = c2.b[s] = 0.0;
-  c1.code = c2.code = 0u;
   c1.sc = c2.sc = 0u;
   // The results of the last two operations stay in registers (D layout = B
   // layout): `res` belongs to operation oi - 1, `prev` to operation oi - 2.
@@ -222,6 +236,9 @@ clv_k20_traversal_kernel(DeviceView v, const double *__restrict__ pmfma,
   OpHead op = load_op(ops, 0);
   OpHead nx = op;              // operation oi + 1 (for oi = -1: operation 0)
   OpHead pop = op;             // operation oi - 1: its stores are still due
+  op.src1 = op.src2 = 2u;      // iteration -1 computes nothing: no tip term, no A copy
+  // tip codes of operation oi + 1 (requested an iteration ago; here: up front)
+  unsigned code1 = load_code(nx.src1, nx.child1_clv), code2 = load_code(nx.src2, nx.child2_clv);
 
   auto store_result = [&](const OpHead &h, bool valid, const double (&val)[kMfmaGroups], unsigned sc) {
     const bool scaled = valid && h.parent_sc >= 0;
@@ -240,24 +257,22 @@ clv_k20_traversal_kernel(DeviceView v, const double *__restrict__ pmfma,
     const bool live = oi >= 0;
     const unsigned nx2i = (unsigned)(oi + 2) < nops ? (unsigned)(oi + 2) : nops - 1;
     const OpHead nx2 = load_op(ops, nx2i);   // wanted one iteration from now
-    // B operands without a branch: a tip's 0/1 vector from its state mask (the
-    // loads of a non-memory child returned zeros), or the registers of one of
-    // the two operations before
+    // tip codes two operations ahead: they address next iteration's table loads
+    const unsigned ncode1 = load_code(nx2.src1, nx2.child1_clv);
+    const unsigned ncode2 = load_code(nx2.src2, nx2.child2_clv);
+    // B operands of an inner child without a branch: what the loads brought (zeros
+    // for a forwarded child), or the registers of one of the two operations before
+    const bool tip1 = op.src1 == 0u, tip2 = op.src2 == 0u;
     double b1[kMfmaSteps], b2[kMfmaSteps];
     {
-      const unsigned tip1 = op.src1 == 0u ? ~0u : 0u, tip2 = op.src2 == 0u ? ~0u : 0u;
       const unsigned ra1 = op.src1 == 2u ? ~0u : 0u, ra2 = op.src2 == 2u ? ~0u : 0u;
       const unsigned rb1 = op.src1 == 3u ? ~0u : 0u, rb2 = op.src2 == 3u ? ~0u : 0u;
-      const uint64_t m1 = masks[c1.code & 255u] >> grp, m2 = masks[c2.code & 255u] >> grp;
 #pragma unroll
       for (int s = 0; s < kMfmaSteps; ++s) {
         const u32x2 l1 = __builtin_bit_cast(u32x2, c1.b[s]), l2 = __builtin_bit_cast(u32x2, c2.b[s]);
         const u32x2 p = __builtin_bit_cast(u32x2, res[s]), q = __builtin_bit_cast(u32x2, prev[s]);
-        const unsigned t1 = (0u - ((unsigned)(m1 >> (4 * s)) & 1u)) & 0x3FF00000u & tip1;
-        const unsigned t2 = (0u - ((unsigned)(m2 >> (4 * s)) & 1u)) & 0x3FF00000u & tip2;
-        // (a forwarded child loaded zeros and has no tip bits, so OR-ing is enough)
-        const u32x2 w1 = {l1[0] | (p[0] & ra1) | (q[0] & rb1), l1[1] | t1 | (p[1] & ra1) | (q[1] & rb1)};
-        const u32x2 w2 = {l2[0] | (p[0] & ra2) | (q[0] & rb2), l2[1] | t2 | (p[1] & ra2) | (q[1] & rb2)};
+        const u32x2 w1 = {l1[0] | (p[0] & ra1) | (q[0] & rb1), l1[1] | (p[1] & ra1) | (q[1] & rb1)};
+        const u32x2 w2 = {l2[0] | (p[0] & ra2) | (q[0] & rb2), l2[1] | (p[1] & ra2) | (q[1] & rb2)};
         b1[s] = as_f64(w1);
         b2[s] = as_f64(w2);
       }
@@ -266,19 +281,30 @@ clv_k20_traversal_kernel(DeviceView v, const double *__restrict__ pmfma,
     const unsigned sc1 = op.src1 == 2u ? osc : (op.src1 == 3u ? oscp : c1.sc);
     const unsigned sc2 = op.src2 == 2u ? osc : (op.src2 == 3u ? oscp : c2.sc);
     // this operation's A copies, requested a whole iteration ago, go to LDS ...
-    stage_child_a(0, c1);
-    stage_child_a(1, c2);
+    if (!tip1) stage_child_a(0, c1);
+    if (!tip2) stage_child_a(1, c2);
     // ... everything the NEXT operation needs from memory is requested ...
-    load_child_b(nx.src1, nx.child1_clv, nx.child1_sc, c1);
-    load_child_b(nx.src2, nx.child2_clv, nx.child2_sc, c2);
-    load_child_a(nx.child1_mat, c1);
-    load_child_a(nx.child2_mat, c2);
+    load_child_b(nx.src1, nx.child1_clv, nx.child1_mat, nx.child1_sc, code1, c1);
+    load_child_b(nx.src2, nx.child2_clv, nx.child2_mat, nx.child2_sc, code2, c2);
+    load_child_a(nx.src1, nx.child1_mat, c1);
+    load_child_a(nx.src2, nx.child2_mat, c2);
     // ... and the PREVIOUS operation's result goes out behind those loads
     store_result(pop, oi >= 1, res, osc);
     // the MFMAs of this operation
+    // (a tip's loads brought its finished term: b = P . indicator, from the tip table)
     double d1[kMfmaGroups], d2[kMfmaGroups], out[kMfmaGroups];
-    child_product(0, b1, d1);
-    child_product(1, b2, d2);
+    if (tip1) {
+#pragma unroll
+      for (int t = 0; t < kMfmaGroups; ++t) d1[t] = b1[t];
+    } else {
+      child_product(0, b1, d1);
+    }
+    if (tip2) {
+#pragma unroll
+      for (int t = 0; t < kMfmaGroups; ++t) d2[t] = b2[t];
+    } else {
+      child_product(1, b2, d2);
+    }
     bool small = true;
 #pragma unroll
     for (int t = 0; t < kMfmaGroups; ++t) {
@@ -307,6 +333,8 @@ clv_k20_traversal_kernel(DeviceView v, const double *__restrict__ pmfma,
     pop = op;
     op = nx;
     nx = nx2;
+    code1 = ncode1;
+    code2 = ncode2;
   }
   store_result(pop, nops >= 1, res, osc);   // the last operation's result
 }

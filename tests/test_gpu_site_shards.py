@@ -39,7 +39,7 @@ def _free_port():
     return p
 
 
-def _measure(m, tree, search):
+def _measure(m, tree, search, tight=True):
     """the model-level quantities a site-sharded run must reproduce"""
     out = {}
     m.initialize_partitions()                      # empirical frequencies + random rates
@@ -54,12 +54,14 @@ def _measure(m, tree, search):
     out["sweep_directional"] = list(m.compute_all_root_lh_directional())
     if search:
         m.set_lbfgsb(C.CDLL(REF).setulb)
-        # (tight settings: a loosely converged run would amplify last-bit differences)
-        r = m.optimize_params(rls[0], SUBST, [.25] * 4, 1.0, 1e-7, 1e4)
+        # (tight settings where two different summation orders are compared: a loosely
+        # converged run would amplify last-bit differences)
+        pgtol, factor, atol, brtol = (1e-7, 1e4, 1e-7, 1e-9) if tight else (1e-3, 1e12, 1e-3, 1e-3)
+        r = m.optimize_params(rls[0], SUBST, [.25] * 4, 1.0, pgtol, factor)
         out["opt"] = list(r["subst"]) + list(r["freqs"]) + [r["gamma_alpha"], r["evaluations"]]
         out["opt_lh"] = m.compute_lh(rls[0])
-        m.assign_by_rank(0, 1)
-        res = m.exhaustive_search(1e-7, 1e-7, 1e-9, 1e4)
+        m.assign_by_rank(0, 1 if not tight else 3)       # all 17 candidates, or the first 6
+        res = m.exhaustive_search(atol, pgtol, brtol, factor)
         out["search"] = (res["root_id"], list(res["llh"]), list(res["alpha"]))
     return out
 
@@ -147,7 +149,7 @@ def test_two_site_blocks_search_like_one_rank():
     assert got[0]["opt"] == got[1]["opt"] and got[0]["search"] == got[1]["search"]
     assert _close(got[0]["opt_lh"], one["opt_lh"], 1e-7)
     ids, llh, alpha = got[0]["search"]
-    assert ids == one["search"][0] == list(range(17))
+    assert ids == one["search"][0] == list(range(6))
     assert _close(llh, one["search"][1], 2e-6)
     assert np.max(np.abs(np.array(alpha) - np.array(one["search"][2]))) < 2e-2
 
@@ -166,10 +168,10 @@ def test_rccl_communicator_as_device_side_reducer():
     assert t.tolist() == [0.0, 1.0, 2.0, 3.0, 4.0]
     tree = rd.Tree.from_file(os.path.join(util.DATA, "10.tree"))
     seqs, w = util.compress(util.read_fasta(os.path.join(util.DATA, "10.fasta")))
-    plain = _measure(rd.Model(tree, seqs, rate_cats=4, weights=w, seed=3), tree, True)
+    plain = _measure(rd.Model(tree, seqs, rate_cats=4, weights=w, seed=3), tree, True, tight=False)
     m = rd.Model(tree, seqs, rate_cats=4, weights=w, seed=3)
     m.set_lnl_reducer(comm.reducer, on_device=True, user=comm.handle)
-    sharded = _measure(m, tree, True)
+    sharded = _measure(m, tree, True, tight=False)
     for key in plain:
         assert sharded[key] == plain[key], key
     with pytest.raises(rd.RdamdError):       # replicas would reorder the collectives
