@@ -53,6 +53,7 @@
 // dependency is site-local and each wave owns its sites for the whole list
 // (the host cuts the list where an operation reads, from memory, what the
 // operation just before wrote -- partition.hip).
+#include <cstdlib>
 #include "common.hpp"
 
 namespace rdamd {
@@ -103,6 +104,17 @@ struct ChildLoad {
 };
 constexpr int kMfmaLdsChild = 4 * 64 * 16;   // bytes of LDS one child's A copy occupies per wave
 
+// Which state a lane group holds in row group / k-step t.  The MFMA only needs
+// the 20 states dealt out as 5 sets of 4 (one member per lane group), the same
+// dealing for rows (D), for the k dimension (B) and in the A copies; this one
+// gives lane group g the CONTIGUOUS states 5g .. 5g+4, so a lane's share of a
+// CLV record or tip-table row is 40 contiguous bytes (three memory
+// instructions instead of five 8-byte ones).  Odd groups start one state
+// later (rotation), which puts both 16-byte pieces on 16-byte boundaries.
+__host__ __device__ constexpr unsigned state_of(unsigned g, unsigned t) {
+  return 5u * g + (t + (g & 1u)) % 5u;
+}
+
 }  // namespace
 
 // MFMA-ready copy of one 20x20 P-matrix: element (rg, ks, k, i) = P[4 rg + i][4 ks + k], so
@@ -117,11 +129,11 @@ pmat_to_mfma_kernel(const double *__restrict__ pmat, double *__restrict__ out,
   double *o = out + slot * kMfmaCopy;
   for (unsigned e = threadIdx.x; e < (unsigned)kMfmaCopy; e += blockDim.x) {
     const unsigned i = e & 3, k = (e >> 2) & 3, blk = e >> 4, ks = blk % kMfmaSteps, rg = blk / kMfmaSteps;
-    o[e] = p[(4 * rg + i) * kMfmaK + 4 * ks + k];
+    o[e] = p[state_of(i, rg) * kMfmaK + state_of(k, ks)];
   }
 }
 
-template <int MAXT>   // 64 * rate categories, rounded up to 256 or 1024
+template <int MAXT, int VAR = 0>   // 64 * rate categories, rounded up to 256 or 1024
 __global__ void __launch_bounds__(MAXT)
 clv_k20_traversal_kernel(DeviceView v, const double *__restrict__ pmfma,
                          const LevelOp *__restrict__ ops_generic, unsigned nops) {
@@ -137,8 +149,13 @@ clv_k20_traversal_kernel(DeviceView v, const double *__restrict__ pmfma,
   const bool sc_lane = r == 0 && grp == 0;       // the lanes that own the per-site scalers
   const unsigned clv_bytes = uni((unsigned)(v.clv_stride * sizeof(double)));
   const unsigned sc_bytes = S * 4u;
-  // loop-invariant per-lane offsets
-  const unsigned ld_clv = ((ls * R + r) * kMfmaK + grp) * 8u;                 // + 32 s
+  // Loop-invariant per-lane offsets.  A lane's five states are 40 contiguous bytes of
+  // its (site, rate) record (or of a tip-table row), moved as 16 + 16 + 8 bytes with
+  // both 16-byte pieces aligned: even groups [x0 x1][x2 x3][x4], odd groups x4 first
+  // (state_of: their rotation starts one state later).
+  const unsigned in_row = 40u * grp;
+  const unsigned o1 = in_row + 8u * (grp & 1u), o3 = in_row + 32u * (1u - (grp & 1u));
+  const unsigned ld_clv = (ls * R + r) * (kMfmaK * 8u);
   const unsigned st_clv = site < S ? ld_clv : kOob;
   const unsigned ld_sc = sc_lane ? ls * 4u : kOob;
   const unsigned st_sc = (sc_lane && site < S) ? site * 4u : kOob;
@@ -151,42 +168,70 @@ clv_k20_traversal_kernel(DeviceView v, const double *__restrict__ pmfma,
   const char *tab_base = reinterpret_cast<const char *>(v.tiptab);
   const unsigned tab_row = kMfmaK * 8u;                              // bytes per code
   const unsigned tab_slot = uni(v.ncodes_cap * tab_row);             // bytes per (matrix, rate)
+  // the 16 tip codes of this wave's sites are 16 contiguous bytes of a tip row: they
+  // come through the scalar cache (no vector-memory instruction), two operations ahead
+  const unsigned long long codes_u = reinterpret_cast<unsigned long long>(v.tipcodes);
+  const unsigned long long codes_lo =
+      (((unsigned long long)uni((unsigned)(codes_u >> 32)) << 32) | uni((unsigned)codes_u)) +
+      (unsigned long long)blockIdx.x * 16u;
+  const bool w1 = (col >> 2) == 1u, w2 = (col >> 2) == 2u, w3 = (col >> 2) == 3u;
+  const unsigned code_shift = (col & 3u) * 8u;
+  struct Codes { unsigned w[4]; };
+  auto load_codes = [&](unsigned src, unsigned clv) -> Codes {
+    Codes c{{0u, 0u, 0u, 0u}};
+    if (src == 0u) {
+      const const_u32_ptr row = (const_u32_ptr)(codes_lo + (unsigned long long)clv * v.tip_stride);
+      c.w[0] = row[0]; c.w[1] = row[1]; c.w[2] = row[2]; c.w[3] = row[3];
+    }
+    return c;
+  };
+  auto my_code = [&](const Codes &c) -> unsigned {
+    unsigned w = c.w[0];
+    w = w1 ? c.w[1] : w;
+    w = w2 ? c.w[2] : w;
+    w = w3 ? c.w[3] : w;
+    return (w >> code_shift) & 255u;
+  };
 
   // Wave-private LDS: the A copies of both children of the NEXT operation,
   // written as loaded (contiguous), read back as [block][my role].
   extern __shared__ char a_lds_all[];
   char *a_lds = a_lds_all + (threadIdx.x >> 6) * (2 * kMfmaLdsChild);
 
-  // The loads a child of the next operation may need: the descriptors of the
-  // ones it does not need are empty, so the instruction stream never changes.
-  // (B side first, A pieces last: the B side is wanted first.)
-  auto load_code = [&](unsigned src, unsigned clv) -> unsigned {
-    const bool tip = src == 0u;
-    const __amdgpu_buffer_rsrc_t code_rs =
-        make_rsrc(v.tipcodes + (size_t)(tip ? clv : 0u) * v.tip_stride, tip ? v.tip_stride : 0u);
-    return (unsigned)__builtin_amdgcn_raw_buffer_load_b8(code_rs, (int)ls, 0, 0);
+  // What a child of the next operation needs from memory, by where it comes from
+  // (wave-uniform branches; the kernel is bound by the number of vector-memory
+  // instructions the CU's address unit has to process, so none is issued in vain):
+  //   tip      three pieces of its tip-table row: the child's finished term
+  //   memory   three pieces of its CLV, its scaler, the A copy of its matrix
+  //   register (result of one of the two operations before) only the A copy
+  auto load_five = [&](const __amdgpu_buffer_rsrc_t rs, unsigned base, ChildLoad &c) {
+    if (VAR & 16) return;   // VAR bit 4 (timing only): no CLV / tip-table loads
+    const u32x4 p = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(base + o1), 0, 0);
+    const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(base + o1 + 16u), 0, 0);
+    const u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)(base + o3), 0, 0);
+    c.b[0] = as_f64(u32x2{p[0], p[1]}); c.b[1] = as_f64(u32x2{p[2], p[3]});
+    c.b[2] = as_f64(u32x2{q[0], q[1]}); c.b[3] = as_f64(u32x2{q[2], q[3]});
+    c.b[4] = as_f64(t);
   };
-  auto load_child_b = [&](unsigned src, unsigned clv, unsigned mat, int scb, unsigned code, ChildLoad &c) {
-    const bool tip = src == 0u, mem = src == 1u;
-    // tip: row `code` of the (matrix, rate) tip table; memory: the CLV; else nothing
-    const char *base = tip ? tab_base + (size_t)(mat * R + r) * tab_slot
-                           : clv_base + (size_t)(mem ? clv - v.tips : 0u) * clv_bytes;
-    const __amdgpu_buffer_rsrc_t rs = make_rsrc(base, tip ? tab_slot : (mem ? clv_bytes : 0u));
-    const unsigned off = tip ? (code & 255u) * tab_row + grp * 8u : ld_clv;
-#pragma unroll
-    for (int s = 0; s < kMfmaSteps; ++s)
-      c.b[s] = as_f64(__builtin_amdgcn_raw_buffer_load_b64(rs, (int)(off + 32u * s), 0, 0));
-    const bool has_sc = mem && scb >= 0;
-    const __amdgpu_buffer_rsrc_t sc_rs =
-        make_rsrc(sc_base + (size_t)(has_sc ? scb : 0) * sc_bytes, has_sc ? sc_bytes : 0u);
-    c.sc = __builtin_amdgcn_raw_buffer_load_b32(sc_rs, (int)ld_sc, 0, 0);
-  };
-  auto load_child_a = [&](unsigned src, unsigned mat, ChildLoad &c) {
-    // one (matrix, rate) copy = 3200 contiguous bytes; pieces past its end are dropped;
-    // a tip child needs none of it
+  auto load_child = [&](unsigned src, unsigned clv, unsigned mat, int scb, const Codes &codes, ChildLoad &c) {
+    if (src == 0u) {
+      const __amdgpu_buffer_rsrc_t rs = make_rsrc(tab_base + (size_t)(mat * R + r) * tab_slot, tab_slot);
+      load_five(rs, my_code(codes) * tab_row, c);
+      return;
+    }
+    if (src == 1u) {
+      const __amdgpu_buffer_rsrc_t rs = make_rsrc(clv_base + (size_t)(clv - v.tips) * clv_bytes, clv_bytes);
+      load_five(rs, ld_clv, c);
+      c.sc = 0u;
+      if (scb >= 0) {
+        const __amdgpu_buffer_rsrc_t sc_rs = make_rsrc(sc_base + (size_t)scb * sc_bytes, sc_bytes);
+        c.sc = __builtin_amdgcn_raw_buffer_load_b32(sc_rs, (int)ld_sc, 0, 0);
+      }
+    }
+    if (VAR & 8) return;   // VAR bit 3 (timing only): no A loads
+    // one (matrix, rate) copy = 3200 contiguous bytes; pieces past its end are dropped
     const __amdgpu_buffer_rsrc_t rs =
-        make_rsrc(reinterpret_cast<const char *>(pmfma) + (size_t)(mat * R + r) * (kMfmaCopy * 8),
-                  src == 0u ? 0u : kMfmaCopy * 8);
+        make_rsrc(reinterpret_cast<const char *>(pmfma) + (size_t)(mat * R + r) * (kMfmaCopy * 8), kMfmaCopy * 8);
 #pragma unroll
     for (int k = 0; k < 4; ++k)
       c.raw[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(lane * 16u + 1024u * k), 0, 0);
@@ -211,9 +256,6 @@ clv_k20_traversal_kernel(DeviceView v, const double *__restrict__ pmfma,
     }
   };
 
-  // Iteration -1 only issues operation 0's loads (its arithmetic runs on zeros
-  // and its stores go to empty descriptors): the loop header then has a single
-  // memory-queue state, so the compiler's vmcnt waits are exact.
   ChildLoad c1, c2;
 #pragma unroll
   for (int k = 0; k < 4; ++k) c1.raw[k] = c2.raw[k] = u32x4{0u, 0u, 0u, 0u};
@@ -236,21 +278,21 @@ clv_k20_traversal_kernel(DeviceView v, const double *__restrict__ pmfma,
   OpHead op = load_op(ops, 0);
   OpHead nx = op;              // operation oi + 1 (for oi = -1: operation 0)
   OpHead pop = op;             // operation oi - 1: its stores are still due
-  op.src1 = op.src2 = 2u;      // iteration -1 computes nothing: no tip term, no A copy
+  op.src1 = op.src2 = 2u;      // iteration -1 computes nothing: it only issues operation 0's loads
   // tip codes of operation oi + 1 (requested an iteration ago; here: up front)
-  unsigned code1 = load_code(nx.src1, nx.child1_clv), code2 = load_code(nx.src2, nx.child2_clv);
+  Codes cw1 = load_codes(nx.src1, nx.child1_clv), cw2 = load_codes(nx.src2, nx.child2_clv);
 
-  auto store_result = [&](const OpHead &h, bool valid, const double (&val)[kMfmaGroups], unsigned sc) {
-    const bool scaled = valid && h.parent_sc >= 0;
-    const __amdgpu_buffer_rsrc_t psc_rs =
-        make_rsrc(sc_base + (size_t)(scaled ? h.parent_sc : 0) * sc_bytes, scaled ? sc_bytes : 0u);
-    __builtin_amdgcn_raw_buffer_store_b32(sc, psc_rs, (int)st_sc, 0, 0);
-    const __amdgpu_buffer_rsrc_t pclv_rs =
-        make_rsrc(clv_base + (size_t)(h.parent_clv - v.tips) * clv_bytes, valid ? clv_bytes : 0u);
-#pragma unroll
-    for (int t = 0; t < kMfmaGroups; ++t)
-      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, val[t]), pclv_rs,
-                                            (int)(st_clv + 32u * t), 0, 0);
+  auto store_result = [&](const OpHead &h, const double (&val)[kMfmaGroups], unsigned sc) {
+    if (h.parent_sc >= 0) {
+      const __amdgpu_buffer_rsrc_t psc_rs = make_rsrc(sc_base + (size_t)h.parent_sc * sc_bytes, sc_bytes);
+      __builtin_amdgcn_raw_buffer_store_b32(sc, psc_rs, (int)st_sc, 0, 0);
+    }
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(clv_base + (size_t)(h.parent_clv - v.tips) * clv_bytes, clv_bytes);
+    const u32x2 x0 = __builtin_bit_cast(u32x2, val[0]), x1 = __builtin_bit_cast(u32x2, val[1]);
+    const u32x2 x2 = __builtin_bit_cast(u32x2, val[2]), x3 = __builtin_bit_cast(u32x2, val[3]);
+    __builtin_amdgcn_raw_buffer_store_b128(u32x4{x0[0], x0[1], x1[0], x1[1]}, rs, (int)(st_clv + o1), 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(u32x4{x2[0], x2[1], x3[0], x3[1]}, rs, (int)(st_clv + o1 + 16u), 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, val[4]), rs, (int)(st_clv + o3), 0, 0);
   };
 
   for (int oi = -1; oi < (int)nops; ++oi) {
@@ -258,48 +300,56 @@ clv_k20_traversal_kernel(DeviceView v, const double *__restrict__ pmfma,
     const unsigned nx2i = (unsigned)(oi + 2) < nops ? (unsigned)(oi + 2) : nops - 1;
     const OpHead nx2 = load_op(ops, nx2i);   // wanted one iteration from now
     // tip codes two operations ahead: they address next iteration's table loads
-    const unsigned ncode1 = load_code(nx2.src1, nx2.child1_clv);
-    const unsigned ncode2 = load_code(nx2.src2, nx2.child2_clv);
-    // B operands of an inner child without a branch: what the loads brought (zeros
-    // for a forwarded child), or the registers of one of the two operations before
+    const Codes ncw1 = load_codes(nx2.src1, nx2.child1_clv), ncw2 = load_codes(nx2.src2, nx2.child2_clv);
+    // this operation's operands: what the loads brought, or the registers of one of
+    // the two operations before
     const bool tip1 = op.src1 == 0u, tip2 = op.src2 == 0u;
     double b1[kMfmaSteps], b2[kMfmaSteps];
-    {
-      const unsigned ra1 = op.src1 == 2u ? ~0u : 0u, ra2 = op.src2 == 2u ? ~0u : 0u;
-      const unsigned rb1 = op.src1 == 3u ? ~0u : 0u, rb2 = op.src2 == 3u ? ~0u : 0u;
+    unsigned sc1 = c1.sc, sc2 = c2.sc;
 #pragma unroll
-      for (int s = 0; s < kMfmaSteps; ++s) {
-        const u32x2 l1 = __builtin_bit_cast(u32x2, c1.b[s]), l2 = __builtin_bit_cast(u32x2, c2.b[s]);
-        const u32x2 p = __builtin_bit_cast(u32x2, res[s]), q = __builtin_bit_cast(u32x2, prev[s]);
-        const u32x2 w1 = {l1[0] | (p[0] & ra1) | (q[0] & rb1), l1[1] | (p[1] & ra1) | (q[1] & rb1)};
-        const u32x2 w2 = {l2[0] | (p[0] & ra2) | (q[0] & rb2), l2[1] | (p[1] & ra2) | (q[1] & rb2)};
-        b1[s] = as_f64(w1);
-        b2[s] = as_f64(w2);
-      }
+    for (int s = 0; s < kMfmaSteps; ++s) { b1[s] = c1.b[s]; b2[s] = c2.b[s]; }
+    if (op.src1 == 2u) {
+#pragma unroll
+      for (int s = 0; s < kMfmaSteps; ++s) b1[s] = res[s];
+      sc1 = osc;
+    } else if (op.src1 == 3u) {
+#pragma unroll
+      for (int s = 0; s < kMfmaSteps; ++s) b1[s] = prev[s];
+      sc1 = oscp;
+    } else if (tip1) {
+      sc1 = 0u;
     }
-    // (an empty descriptor loaded 0)
-    const unsigned sc1 = op.src1 == 2u ? osc : (op.src1 == 3u ? oscp : c1.sc);
-    const unsigned sc2 = op.src2 == 2u ? osc : (op.src2 == 3u ? oscp : c2.sc);
+    if (op.src2 == 2u) {
+#pragma unroll
+      for (int s = 0; s < kMfmaSteps; ++s) b2[s] = res[s];
+      sc2 = osc;
+    } else if (op.src2 == 3u) {
+#pragma unroll
+      for (int s = 0; s < kMfmaSteps; ++s) b2[s] = prev[s];
+      sc2 = oscp;
+    } else if (tip2) {
+      sc2 = 0u;
+    }
     // this operation's A copies, requested a whole iteration ago, go to LDS ...
-    if (!tip1) stage_child_a(0, c1);
-    if (!tip2) stage_child_a(1, c2);
+    if (!tip1 && !(VAR & 8)) stage_child_a(0, c1);
+    if (!tip2 && !(VAR & 8)) stage_child_a(1, c2);
     // ... everything the NEXT operation needs from memory is requested ...
-    load_child_b(nx.src1, nx.child1_clv, nx.child1_mat, nx.child1_sc, code1, c1);
-    load_child_b(nx.src2, nx.child2_clv, nx.child2_mat, nx.child2_sc, code2, c2);
-    load_child_a(nx.src1, nx.child1_mat, c1);
-    load_child_a(nx.src2, nx.child2_mat, c2);
+    if ((unsigned)(oi + 1) < nops) {
+      load_child(nx.src1, nx.child1_clv, nx.child1_mat, nx.child1_sc, cw1, c1);
+      load_child(nx.src2, nx.child2_clv, nx.child2_mat, nx.child2_sc, cw2, c2);
+    }
     // ... and the PREVIOUS operation's result goes out behind those loads
-    store_result(pop, oi >= 1, res, osc);
+    if (oi >= 1 && !(VAR & 1)) store_result(pop, res, osc);   // VAR bit 0 (timing only): no stores
     // the MFMAs of this operation
     // (a tip's loads brought its finished term: b = P . indicator, from the tip table)
     double d1[kMfmaGroups], d2[kMfmaGroups], out[kMfmaGroups];
-    if (tip1) {
+    if (tip1 || (VAR & 4)) {   // VAR bit 2 (timing only): no LDS reads, no MFMAs
 #pragma unroll
       for (int t = 0; t < kMfmaGroups; ++t) d1[t] = b1[t];
     } else {
       child_product(0, b1, d1);
     }
-    if (tip2) {
+    if (tip2 || (VAR & 4)) {
 #pragma unroll
       for (int t = 0; t < kMfmaGroups; ++t) d2[t] = b2[t];
     } else {
@@ -317,7 +367,7 @@ clv_k20_traversal_kernel(DeviceView v, const double *__restrict__ pmfma,
     bm &= bm >> 32;
     bm &= bm >> 16;
     if (lane == 0) flags[oi & 1][r] = (unsigned)bm & 0xFFFFu;
-    __syncthreads();
+    if (!(VAR & 2)) __syncthreads();   // VAR bit 1 (timing only): no barrier
     const bool scaled_buffer = live && op.parent_sc >= 0;
     unsigned all_bits = scaled_buffer ? 0xFFFFu : 0u;
     for (unsigned q = 0; q < R; ++q) all_bits &= flags[oi & 1][q];
@@ -333,10 +383,10 @@ clv_k20_traversal_kernel(DeviceView v, const double *__restrict__ pmfma,
     pop = op;
     op = nx;
     nx = nx2;
-    code1 = ncode1;
-    code2 = ncode2;
+    cw1 = ncw1;
+    cw2 = ncw2;
   }
-  store_result(pop, nops >= 1, res, osc);   // the last operation's result
+  if (nops >= 1 && !(VAR & 1)) store_result(pop, res, osc);   // the last operation's result
 }
 
 hipError_t launch_pmat_to_mfma(rdamd_partition *p, const unsigned *d_matrix_indices,
@@ -360,8 +410,14 @@ hipError_t launch_clv_k20_traversal(rdamd_partition *p, const LevelOp *d_ops, un
   DeviceView v = p->view();
   const unsigned gx = (p->sites + 15) / 16;
   const size_t lds = (size_t)p->rate_cats * 2 * kMfmaLdsChild;   // 8 KB per wave
+  static const int var = getenv("RDAMD_K20_VAR") ? atoi(getenv("RDAMD_K20_VAR")) : 0;
+#define RDAMD_K20_CASE(V) case V: clv_k20_traversal_kernel<256, V><<<gx, 64 * p->rate_cats, lds, p->stream>>>(v, p->d_pmat_mfma, d_ops, nops); break;
   if (p->rate_cats <= 4)
-    clv_k20_traversal_kernel<256><<<gx, 64 * p->rate_cats, lds, p->stream>>>(v, p->d_pmat_mfma, d_ops, nops);
+    switch (var) {
+      RDAMD_K20_CASE(1) RDAMD_K20_CASE(2) RDAMD_K20_CASE(4) RDAMD_K20_CASE(5) RDAMD_K20_CASE(8)
+      RDAMD_K20_CASE(13) RDAMD_K20_CASE(16) RDAMD_K20_CASE(17) RDAMD_K20_CASE(29) RDAMD_K20_CASE(31)
+      default: clv_k20_traversal_kernel<256><<<gx, 64 * p->rate_cats, lds, p->stream>>>(v, p->d_pmat_mfma, d_ops, nops);
+    }
   else
     clv_k20_traversal_kernel<1024><<<gx, 64 * p->rate_cats, lds, p->stream>>>(v, p->d_pmat_mfma, d_ops, nops);
   return hipGetLastError();
