@@ -103,6 +103,7 @@ struct ChildLoad {
   unsigned sc;                // scaler of an older sibling
 };
 constexpr int kMfmaLdsChild = 4 * 64 * 16;   // bytes of LDS one child's A copy occupies per wave
+constexpr int kMfmaLdsWave = 2 * kMfmaLdsChild + 4096;   // + the store transposition tile (2560 B, read as 3 x 1 KB)
 
 // Which state a lane group holds in row group / k-step t.  The MFMA only needs
 // the 20 states dealt out as 5 sets of 4 (one member per lane group), the same
@@ -156,7 +157,6 @@ clv_k20_traversal_kernel(DeviceView v, const double *__restrict__ pmfma,
   const unsigned in_row = 40u * grp;
   const unsigned o1 = in_row + 8u * (grp & 1u), o3 = in_row + 32u * (1u - (grp & 1u));
   const unsigned ld_clv = (ls * R + r) * (kMfmaK * 8u);
-  const unsigned st_clv = site < S ? ld_clv : kOob;
   const unsigned ld_sc = sc_lane ? ls * 4u : kOob;
   const unsigned st_sc = (sc_lane && site < S) ? site * 4u : kOob;
   const unsigned a_off = (grp * 4 + (col & 3)) * 8u;                          // my element of every 4x4 block
@@ -174,29 +174,40 @@ clv_k20_traversal_kernel(DeviceView v, const double *__restrict__ pmfma,
   const unsigned long long codes_lo =
       (((unsigned long long)uni((unsigned)(codes_u >> 32)) << 32) | uni((unsigned)codes_u)) +
       (unsigned long long)blockIdx.x * 16u;
-  const bool w1 = (col >> 2) == 1u, w2 = (col >> 2) == 2u, w3 = (col >> 2) == 3u;
-  const unsigned code_shift = (col & 3u) * 8u;
-  struct Codes { unsigned w[4]; };
+  const bool upper_half = (col & 8u) != 0u;
+  const unsigned code_shift = (col & 7u) * 8u;
+  struct Codes { unsigned w0, w1, w2, w3; };   // (named members: an array here ends up in scratch memory)
   auto load_codes = [&](unsigned src, unsigned clv) -> Codes {
-    Codes c{{0u, 0u, 0u, 0u}};
+    Codes c{0u, 0u, 0u, 0u};
     if (src == 0u) {
       const const_u32_ptr row = (const_u32_ptr)(codes_lo + (unsigned long long)clv * v.tip_stride);
-      c.w[0] = row[0]; c.w[1] = row[1]; c.w[2] = row[2]; c.w[3] = row[3];
+      c.w0 = row[0]; c.w1 = row[1]; c.w2 = row[2]; c.w3 = row[3];
     }
     return c;
   };
   auto my_code = [&](const Codes &c) -> unsigned {
-    unsigned w = c.w[0];
-    w = w1 ? c.w[1] : w;
-    w = w2 ? c.w[2] : w;
-    w = w3 ? c.w[3] : w;
-    return (w >> code_shift) & 255u;
+    // byte `col` of the 16: pick the 8-byte half, shift (a chain of selects over the
+    // four words is turned into an indexed load from scratch memory by the compiler)
+    const unsigned long long lo = ((unsigned long long)c.w1 << 32) | c.w0;
+    const unsigned long long hi = ((unsigned long long)c.w3 << 32) | c.w2;
+    return (unsigned)((upper_half ? hi : lo) >> code_shift) & 255u;
   };
 
   // Wave-private LDS: the A copies of both children of the NEXT operation,
   // written as loaded (contiguous), read back as [block][my role].
   extern __shared__ char a_lds_all[];
-  char *a_lds = a_lds_all + (threadIdx.x >> 6) * (2 * kMfmaLdsChild);
+  char *a_lds = a_lds_all + (threadIdx.x >> 6) * kMfmaLdsWave;
+  // ... and 2560 bytes in which a result tile (16 sites x 160 B) is turned from the
+  // lane layout into address order: the CLV stores then write 16 bytes per lane with
+  // consecutive lanes on consecutive addresses (160-byte runs, one per site),
+  // which costs the memory system a third less than 16-byte pieces 40 bytes apart
+  char *t_lds = a_lds + 2 * kMfmaLdsChild;
+  unsigned st_lin[3];      // where piece p = lane + 64 k of the tile goes (10 pieces per site)
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const unsigned pp = lane + 64u * k, psite = blockIdx.x * 16u + pp / 10u;
+    st_lin[k] = (pp < 160u && psite < S) ? (psite * R + r) * (kMfmaK * 8u) + (pp % 10u) * 16u : kOob;
+  }
 
   // What a child of the next operation needs from memory, by where it comes from
   // (wave-uniform branches; the kernel is bound by the number of vector-memory
@@ -290,9 +301,15 @@ clv_k20_traversal_kernel(DeviceView v, const double *__restrict__ pmfma,
     const __amdgpu_buffer_rsrc_t rs = make_rsrc(clv_base + (size_t)(h.parent_clv - v.tips) * clv_bytes, clv_bytes);
     const u32x2 x0 = __builtin_bit_cast(u32x2, val[0]), x1 = __builtin_bit_cast(u32x2, val[1]);
     const u32x2 x2 = __builtin_bit_cast(u32x2, val[2]), x3 = __builtin_bit_cast(u32x2, val[3]);
-    __builtin_amdgcn_raw_buffer_store_b128(u32x4{x0[0], x0[1], x1[0], x1[1]}, rs, (int)(st_clv + o1), 0, 0);
-    __builtin_amdgcn_raw_buffer_store_b128(u32x4{x2[0], x2[1], x3[0], x3[1]}, rs, (int)(st_clv + o1 + 16u), 0, 0);
-    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, val[4]), rs, (int)(st_clv + o3), 0, 0);
+    char *mine = t_lds + col * (kMfmaK * 8u);
+    *reinterpret_cast<u32x4 *>(mine + o1) = u32x4{x0[0], x0[1], x1[0], x1[1]};
+    *reinterpret_cast<u32x4 *>(mine + o1 + 16u) = u32x4{x2[0], x2[1], x3[0], x3[1]};
+    *reinterpret_cast<u32x2 *>(mine + o3) = __builtin_bit_cast(u32x2, val[4]);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {   // (the third instruction carries 32 lanes)
+      const u32x4 piece = *reinterpret_cast<const u32x4 *>(t_lds + ((lane + 64u * k) & 255u) * 16u);
+      __builtin_amdgcn_raw_buffer_store_b128(piece, rs, (int)st_lin[k], 0, (VAR & 2) ? 0 : 2);   // nt (streamed): VAR bit 1 = default policy
+    }
   };
 
   for (int oi = -1; oi < (int)nops; ++oi) {
@@ -367,7 +384,7 @@ clv_k20_traversal_kernel(DeviceView v, const double *__restrict__ pmfma,
     bm &= bm >> 32;
     bm &= bm >> 16;
     if (lane == 0) flags[oi & 1][r] = (unsigned)bm & 0xFFFFu;
-    if (!(VAR & 2)) __syncthreads();   // VAR bit 1 (timing only): no barrier
+    __syncthreads();
     const bool scaled_buffer = live && op.parent_sc >= 0;
     unsigned all_bits = scaled_buffer ? 0xFFFFu : 0u;
     for (unsigned q = 0; q < R; ++q) all_bits &= flags[oi & 1][q];
@@ -409,7 +426,7 @@ hipError_t launch_clv_k20_traversal(rdamd_partition *p, const LevelOp *d_ops, un
   if (nops == 0 || p->sites == 0) return hipSuccess;
   DeviceView v = p->view();
   const unsigned gx = (p->sites + 15) / 16;
-  const size_t lds = (size_t)p->rate_cats * 2 * kMfmaLdsChild;   // 8 KB per wave
+  const size_t lds = (size_t)p->rate_cats * kMfmaLdsWave;   // 12 KB per wave
   static const int var = getenv("RDAMD_K20_VAR") ? atoi(getenv("RDAMD_K20_VAR")) : 0;
 #define RDAMD_K20_CASE(V) case V: clv_k20_traversal_kernel<256, V><<<gx, 64 * p->rate_cats, lds, p->stream>>>(v, p->d_pmat_mfma, d_ops, nops); break;
   if (p->rate_cats <= 4)
