@@ -245,49 +245,68 @@ fused20_eval_kernel(Fused20Args a, unsigned depth) {
   const unsigned tt_rate = r * (kFused20TabDoubles * 8u);
   const unsigned tt_lane = grp * 48u;                  // + code * 192: my five entries of a table row
 
-  // What a step needs from memory, always the same instructions (an unneeded
-  // load gets an empty descriptor), requested so that no loaded register has to
-  // be copied before it is used (a copy waits for the load and costs a VALU slot):
-  //   * the A copy of step i+1 at the top of step i (its registers were emptied
-  //     into LDS at the end of step i-1), staged into LDS at the end of step i;
-  //   * the table rows of step i+1's tip children and the tip codes of step i+2
-  //     right after step i has used its own rows, i.e. behind its MFMAs.
+  // What a step needs from memory, by its kind (wave-uniform branches: the CU's one
+  // address unit serves ~12 waves here, so no vector-memory instruction is issued
+  // in vain -- an empty descriptor still costs it a slot), requested so that no
+  // loaded register has to be copied before it is used:
+  //   * the A copy of step i+1 (unless it is a tip-tip step) at the top of step i
+  //     (its registers were emptied into LDS at the end of step i-1), staged into
+  //     LDS at the end of step i;
+  //   * the table rows of step i+1's tip children right after step i has used its
+  //     own rows, i.e. behind its MFMAs;
+  //   * the 16 tip codes of a tile are 16 contiguous bytes of a tip row: they come
+  //     through the scalar cache, two steps ahead.
   u32x4 raw[4], t1a, t1b, t2a, t2b;   // t?a/t?b: table entries 0-1, 2-3 of the X / Y tip child
   u32x2 t1c, t2c;                     // ... entry 4
-  unsigned code1, code2;              // tip codes of the step after next (dword around my byte)
-  const unsigned code_shift = (ls & 3u) * 8u;
+  t1a = t1b = t2a = t2b = u32x4{0u, 0u, 0u, 0u};
+  t1c = t2c = u32x2{0u, 0u};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) raw[k] = u32x4{0u, 0u, 0u, 0u};
+  struct Codes { unsigned w0, w1, w2, w3; };
+  const unsigned long long codes_u = reinterpret_cast<unsigned long long>(a.tipcodes);
+  const unsigned long long codes_lo =
+      (((unsigned long long)uni((unsigned)(codes_u >> 32)) << 32) | uni((unsigned)codes_u)) +
+      (unsigned long long)blockIdx.x * 16u;
+  const bool upper_half = (col & 8u) != 0u;
+  const unsigned code_shift = (col & 7u) * 8u;
+  auto load_codes = [&](bool wanted, unsigned row_off) -> Codes {
+    Codes c{0u, 0u, 0u, 0u};
+    if (wanted) {
+      const const_u32_ptr row = (const_u32_ptr)(codes_lo + row_off);
+      c.w0 = row[0]; c.w1 = row[1]; c.w2 = row[2]; c.w3 = row[3];
+    }
+    return c;
+  };
+  auto my_code = [&](const Codes &c) -> unsigned {
+    const unsigned long long lo = ((unsigned long long)c.w1 << 32) | c.w0;
+    const unsigned long long hi = ((unsigned long long)c.w3 << 32) | c.w2;
+    return (unsigned)((upper_half ? hi : lo) >> code_shift) & 255u;
+  };
   auto request_a = [&](const Step &st) {
-    const bool tip1 = (st.flags & 3u) == kFusedTT;
-    const __amdgpu_buffer_rsrc_t rs =
-        make_rsrc(pm_job + st.pM + (size_t)r * (kCopy * 8), tip1 ? 0 : kCopy * 8);
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(pm_job + st.pM + (size_t)r * (kCopy * 8), kCopy * 8);
 #pragma unroll
     for (int k = 0; k < 4; ++k)
       raw[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(lane * 16u + 1024u * k), 0, 0);
   };
-  auto request_tabs = [&](const Step &st, unsigned c1, unsigned c2, const Step &after) {
-    const unsigned kind = st.flags & 3u;
-    const bool tip1 = kind == kFusedTT, tip2 = kind == kFusedTT || kind == kFusedRT;
-    // (matrix offsets of a 20-state program count 3200-byte copies; a table is 12288 bytes)
+  // (matrix offsets of a 20-state program count 3200-byte copies; a table is 12288 bytes)
+  auto request_tab1 = [&](const Step &st, unsigned c1) {
     const __amdgpu_buffer_rsrc_t t1 = make_rsrc(
-        tt_job + (size_t)(st.tX / (kCopy * 8)) * (kFused20TabDoubles * 8) + tt_rate, tip1 ? kFused20TabDoubles * 8 : 0);
-    const __amdgpu_buffer_rsrc_t t2 = make_rsrc(
-        tt_job + (size_t)(st.tY / (kCopy * 8)) * (kFused20TabDoubles * 8) + tt_rate, tip2 ? kFused20TabDoubles * 8 : 0);
-    const int o1 = (int)(c1 * 192u + tt_lane), o2 = (int)(c2 * 192u + tt_lane);
+        tt_job + (size_t)(st.tX / (kCopy * 8)) * (kFused20TabDoubles * 8) + tt_rate, kFused20TabDoubles * 8);
+    const int o1 = (int)(c1 * 192u + tt_lane);
     t1a = __builtin_amdgcn_raw_buffer_load_b128(t1, o1, 0, 0);
     t1b = __builtin_amdgcn_raw_buffer_load_b128(t1, o1 + 16, 0, 0);
     t1c = __builtin_amdgcn_raw_buffer_load_b64(t1, o1 + 32, 0, 0);
+  };
+  auto request_tab2 = [&](const Step &st, unsigned c2) {
+    const __amdgpu_buffer_rsrc_t t2 = make_rsrc(
+        tt_job + (size_t)(st.tY / (kCopy * 8)) * (kFused20TabDoubles * 8) + tt_rate, kFused20TabDoubles * 8);
+    const int o2 = (int)(c2 * 192u + tt_lane);
     t2a = __builtin_amdgcn_raw_buffer_load_b128(t2, o2, 0, 0);
     t2b = __builtin_amdgcn_raw_buffer_load_b128(t2, o2 + 16, 0, 0);
     t2c = __builtin_amdgcn_raw_buffer_load_b64(t2, o2 + 32, 0, 0);
-    const unsigned akind = after.flags & 3u;
-    const __amdgpu_buffer_rsrc_t q1 = make_rsrc(a.tipcodes + after.cX, akind == kFusedTT ? a.tip_stride : 0u);
-    const __amdgpu_buffer_rsrc_t q2 = make_rsrc(
-        a.tipcodes + after.cY, (akind == kFusedTT || akind == kFusedRT) ? a.tip_stride : 0u);
-    // (the dword around the code, unpacked where it is used: a byte load is
-    // widened right behind the load, i.e. the wave would wait for it there)
-    code1 = __builtin_amdgcn_raw_buffer_load_b32(q1, (int)(ls & ~3u), 0, 0);
-    code2 = __builtin_amdgcn_raw_buffer_load_b32(q2, (int)(ls & ~3u), 0, 0);
   };
+  auto has_tip1 = [](const Step &st) { return (st.flags & 3u) == kFusedTT; };
+  auto has_tip2 = [](const Step &st) { return (st.flags & 3u) == kFusedTT || (st.flags & 3u) == kFusedRT; };
   auto stage = [&]() {
 #pragma unroll
     for (int k = 0; k < 4; ++k) *reinterpret_cast<u32x4 *>(a_lds + lane * 16u + 1024u * k) = raw[k];
@@ -316,23 +335,25 @@ fused20_eval_kernel(Fused20Args a, unsigned depth) {
   for (int s = 0; s < kSteps; ++s) v[s] = s0[s] = 0.0;
   unsigned sp = 0;
 
-  // prologue: codes of step 0 (an empty step stands in front of it), then
-  // step 0's operands and the codes of step 1
+  // prologue: step 0's operands and the codes of step 1
   Step cur = load_step(prog, 0);
   Step nxt = load_step(prog, 1);
   {
-    Step none = cur;
-    none.flags = kFusedPark;     // no tips
-    request_tabs(none, 0u, 0u, cur);
+    const Codes k1 = load_codes(has_tip1(cur), cur.cX), k2 = load_codes(has_tip2(cur), cur.cY);
+    if (!has_tip1(cur)) request_a(cur);
+    if (has_tip1(cur)) request_tab1(cur, my_code(k1));
+    if (has_tip2(cur)) request_tab2(cur, my_code(k2));
+    if (!has_tip1(cur)) stage();
   }
-  request_a(cur);
-  request_tabs(cur, (code1 >> code_shift) & 255u, (code2 >> code_shift) & 255u, nxt);
-  stage();
+  Codes cw1 = load_codes(has_tip1(nxt), nxt.cX), cw2 = load_codes(has_tip2(nxt), nxt.cY);
 
   for (unsigned i = 0; i < nops; ++i) {
     const Step nx2 = load_step(prog, i + 2);
     const unsigned kind = cur.flags & 3u;
-    request_a(nxt);                    // the A copy of the next step
+    const bool next_product = !has_tip1(nxt) && i + 1 < nops;
+    // tip codes of the step after next (scalar loads)
+    const Codes ncw1 = load_codes(has_tip1(nx2), nx2.cX), ncw2 = load_codes(has_tip2(nx2), nx2.cY);
+    if (next_product) request_a(nxt);  // the A copy of the next step
     double d1[kGroups];
     if (kind != kFusedTT) product(v, d1);
     // this step's table rows (requested behind the previous step's MFMAs), used in place
@@ -384,12 +405,15 @@ fused20_eval_kernel(Fused20Args a, unsigned depth) {
         sc += 1;
       }
     }
-    // the next step's table rows (by the codes that arrived a step ago) and the
-    // codes of the step after it; then its A copy replaces this one's in LDS
-    request_tabs(nxt, (code1 >> code_shift) & 255u, (code2 >> code_shift) & 255u, nx2);
-    stage();
+    // the next step's table rows (by the codes that arrived a step ago); then its A
+    // copy replaces this one's in LDS
+    if (has_tip1(nxt)) request_tab1(nxt, my_code(cw1));
+    if (has_tip2(nxt)) request_tab2(nxt, my_code(cw2));
+    if (next_product) stage();
     cur = nxt;
     nxt = nx2;
+    cw1 = ncw1;
+    cw2 = ncw2;
   }
 
   // root: f_r = sum_k pi_k v[k] for my site and rate, then the rate sum
