@@ -168,6 +168,9 @@ struct Compiler {
     f.pM = matM * unit;
     f.tX = matX * unit;
     f.tY = matY * unit;
+    // 20 states: the tip tables' byte offsets ([matrix][rate 0], 12288 B per (matrix, rate))
+    f.pad[0] = matX * rate_cats * (kFused20TabDoubles * 8u);
+    f.pad[1] = matY * rate_cats * (kFused20TabDoubles * 8u);
     f.cX = tipX_row * tip_stride;
     f.cY = tipY_row * tip_stride;
     f.flags = kind | (spill << 8);   // (a 20-state TT never parks: its spill bits were moved to the park step)
@@ -195,7 +198,7 @@ rdamd_schedule_t *rdamd_schedule_create(rdamd_partition_t *p, const rdamd_operat
     return nullptr;
   }
   if (n_ops == 0 || (size_t)p->tips * p->tip_stride() > 0xffffffffu ||
-      (size_t)p->prob_matrices * p->rate_cats * (k20 ? 3200 : 512) > 0xffffffffu) {
+      (size_t)p->prob_matrices * p->rate_cats * (k20 ? 12288 : 512) > 0xffffffffu) {
     set_error(41, "rdamd_schedule_create: empty operation list, or partition too large for "
                   "32-bit offsets (tips*sites or matrices*rates*512 >= 4 GiB)");
     return nullptr;

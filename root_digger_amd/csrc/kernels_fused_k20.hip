@@ -64,12 +64,12 @@ __device__ __forceinline__ double pow2_neg256(int d) {   // exact 2^(-256 d), 0 
        : (d == 3 ? kScaleThreshold * kScaleThreshold * kScaleThreshold : 0.0)));
 }
 
-struct Step {   // the six leading words of a FusedOp
-  unsigned pM, tX, tY, cX, cY, flags;
+struct Step {   // a FusedOp: pM byte offset of the running child's A copy, cX / cY tip rows,
+  unsigned pM, tX, tY, cX, cY, flags, tabX, tabY;   // tabX / tabY the tip children's table offsets
 };
 __device__ __forceinline__ Step load_step(const_u32_ptr prog, unsigned i) {
   const const_u32_ptr w = prog + (size_t)i * (sizeof(FusedOp) / 4);
-  return Step{w[0], w[1], w[2], w[3], w[4], w[5]};
+  return Step{w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7]};
 }
 
 }  // namespace
@@ -217,9 +217,14 @@ fused20_pmatrix_kernel(const double *__restrict__ q, const double *__restrict__ 
 }
 
 // ---- the evaluator ---------------------------------------------------------------
-// grid = (16-site tiles, jobs); workgroup = R waves, wave r = rate category r.
-// Dynamic LDS: [root exchange R x 16 x (8 + 4) B][per wave: one A copy (4 KB) +
-// `depth` stack levels].
+// grid = (groups of NT 16-site tiles, jobs); workgroup = R waves, wave r = rate
+// category r.  A wave carries NT tiles: the A copy of a step is fetched, staged
+// and read from LDS once and multiplies NT running CLVs (2 NT x 5 independent MFMA
+// chains), so the per-step traffic through the CU's address unit, the LDS reads
+// and the scalar control flow are shared by NT x 16 sites.
+// Dynamic LDS: [root exchange R x NT x 16 x (8 + 4) B][per wave: one A copy (4 KB) +
+// `depth` stack levels of NT tiles].
+template <int NT>
 __global__ void __launch_bounds__(256)
 fused20_eval_kernel(Fused20Args a, unsigned depth) {
   extern __shared__ char lds_raw[];
@@ -227,14 +232,18 @@ fused20_eval_kernel(Fused20Args a, unsigned depth) {
   const unsigned lane = threadIdx.x & 63, r = uni(threadIdx.x >> 6);
   const unsigned col = lane & 15, grp = lane >> 4;
   const unsigned job = blockIdx.y;
-  const unsigned site = blockIdx.x * 16 + col;
-  const unsigned ls = site < S ? site : S - 1;   // clamped for loads
+  unsigned site[NT], ls[NT];
+#pragma unroll
+  for (int q = 0; q < NT; ++q) {
+    site[q] = (blockIdx.x * NT + q) * 16 + col;
+    ls[q] = site[q] < S ? site[q] : S - 1;   // clamped for loads
+  }
 
   double *root_f = reinterpret_cast<double *>(lds_raw);
-  int *root_sc = reinterpret_cast<int *>(lds_raw + R * 16 * 8);
-  const unsigned wave_bytes = kCopyLds + depth * kLevelBytes;
-  char *a_lds = lds_raw + R * 16 * 12 + r * wave_bytes;   // [4 pieces][64 lanes][16 B]
-  char *stack = a_lds + kCopyLds;                          // [level][5][64] doubles, then [64] counts
+  int *root_sc = reinterpret_cast<int *>(lds_raw + R * NT * 16 * 8);
+  const unsigned wave_bytes = kCopyLds + depth * NT * kLevelBytes;
+  char *a_lds = lds_raw + R * NT * 16 * 12 + r * wave_bytes;   // [4 pieces][64 lanes][16 B]
+  char *stack = a_lds + kCopyLds;                               // [level][tile][5][64] doubles + [64] counts
 
   const FusedJob jb = a.jobs[job];
   const const_u32_ptr prog = scalar_ptr(jb.prog);   // n_ops + 4 entries (tail padded)
@@ -246,9 +255,9 @@ fused20_eval_kernel(Fused20Args a, unsigned depth) {
   const unsigned tt_lane = grp * 48u;                  // + code * 192: my five entries of a table row
 
   // What a step needs from memory, by its kind (wave-uniform branches: the CU's one
-  // address unit serves ~12 waves here, so no vector-memory instruction is issued
-  // in vain -- an empty descriptor still costs it a slot), requested so that no
-  // loaded register has to be copied before it is used:
+  // address unit serves every wave of the CU, so no vector-memory instruction is
+  // issued in vain -- an empty descriptor still costs it a slot), requested so
+  // that no loaded register has to be copied before it is used:
   //   * the A copy of step i+1 (unless it is a tip-tip step) at the top of step i
   //     (its registers were emptied into LDS at the end of step i-1), staged into
   //     LDS at the end of step i;
@@ -256,24 +265,32 @@ fused20_eval_kernel(Fused20Args a, unsigned depth) {
   //     own rows, i.e. behind its MFMAs;
   //   * the 16 tip codes of a tile are 16 contiguous bytes of a tip row: they come
   //     through the scalar cache, two steps ahead.
-  u32x4 raw[4], t1a, t1b, t2a, t2b;   // t?a/t?b: table entries 0-1, 2-3 of the X / Y tip child
-  u32x2 t1c, t2c;                     // ... entry 4
-  t1a = t1b = t2a = t2b = u32x4{0u, 0u, 0u, 0u};
-  t1c = t2c = u32x2{0u, 0u};
+  struct Rows { u32x4 a, b; u32x2 c; };   // table entries 0-1, 2-3, 4 of one tip child of one tile
+  u32x4 raw[4];
+  Rows t1[NT], t2[NT];
+#pragma unroll
+  for (int q = 0; q < NT; ++q) {
+    t1[q].a = t1[q].b = t2[q].a = t2[q].b = u32x4{0u, 0u, 0u, 0u};
+    t1[q].c = t2[q].c = u32x2{0u, 0u};
+  }
 #pragma unroll
   for (int k = 0; k < 4; ++k) raw[k] = u32x4{0u, 0u, 0u, 0u};
   struct Codes { unsigned w0, w1, w2, w3; };
+  struct TileCodes { Codes t[NT]; };
   const unsigned long long codes_u = reinterpret_cast<unsigned long long>(a.tipcodes);
   const unsigned long long codes_lo =
       (((unsigned long long)uni((unsigned)(codes_u >> 32)) << 32) | uni((unsigned)codes_u)) +
-      (unsigned long long)blockIdx.x * 16u;
+      (unsigned long long)blockIdx.x * (16u * NT);
   const bool upper_half = (col & 8u) != 0u;
   const unsigned code_shift = (col & 7u) * 8u;
-  auto load_codes = [&](bool wanted, unsigned row_off) -> Codes {
-    Codes c{0u, 0u, 0u, 0u};
+  auto load_codes = [&](bool wanted, unsigned row_off) -> TileCodes {
+    TileCodes c;
+#pragma unroll
+    for (int q = 0; q < NT; ++q) c.t[q] = Codes{0u, 0u, 0u, 0u};
     if (wanted) {
       const const_u32_ptr row = (const_u32_ptr)(codes_lo + row_off);
-      c.w0 = row[0]; c.w1 = row[1]; c.w2 = row[2]; c.w3 = row[3];
+#pragma unroll
+      for (int q = 0; q < NT; ++q) c.t[q] = Codes{row[4 * q], row[4 * q + 1], row[4 * q + 2], row[4 * q + 3]};
     }
     return c;
   };
@@ -288,22 +305,15 @@ fused20_eval_kernel(Fused20Args a, unsigned depth) {
     for (int k = 0; k < 4; ++k)
       raw[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(lane * 16u + 1024u * k), 0, 0);
   };
-  // (matrix offsets of a 20-state program count 3200-byte copies; a table is 12288 bytes)
-  auto request_tab1 = [&](const Step &st, unsigned c1) {
-    const __amdgpu_buffer_rsrc_t t1 = make_rsrc(
-        tt_job + (size_t)(st.tX / (kCopy * 8)) * (kFused20TabDoubles * 8) + tt_rate, kFused20TabDoubles * 8);
-    const int o1 = (int)(c1 * 192u + tt_lane);
-    t1a = __builtin_amdgcn_raw_buffer_load_b128(t1, o1, 0, 0);
-    t1b = __builtin_amdgcn_raw_buffer_load_b128(t1, o1 + 16, 0, 0);
-    t1c = __builtin_amdgcn_raw_buffer_load_b64(t1, o1 + 32, 0, 0);
-  };
-  auto request_tab2 = [&](const Step &st, unsigned c2) {
-    const __amdgpu_buffer_rsrc_t t2 = make_rsrc(
-        tt_job + (size_t)(st.tY / (kCopy * 8)) * (kFused20TabDoubles * 8) + tt_rate, kFused20TabDoubles * 8);
-    const int o2 = (int)(c2 * 192u + tt_lane);
-    t2a = __builtin_amdgcn_raw_buffer_load_b128(t2, o2, 0, 0);
-    t2b = __builtin_amdgcn_raw_buffer_load_b128(t2, o2 + 16, 0, 0);
-    t2c = __builtin_amdgcn_raw_buffer_load_b64(t2, o2 + 32, 0, 0);
+  auto request_tab = [&](unsigned tab_off, const TileCodes &codes, Rows (&t)[NT]) {
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(tt_job + tab_off + tt_rate, kFused20TabDoubles * 8);
+#pragma unroll
+    for (int q = 0; q < NT; ++q) {
+      const int o = (int)(my_code(codes.t[q]) * 192u + tt_lane);
+      t[q].a = __builtin_amdgcn_raw_buffer_load_b128(rs, o, 0, 0);
+      t[q].b = __builtin_amdgcn_raw_buffer_load_b128(rs, o + 16, 0, 0);
+      t[q].c = __builtin_amdgcn_raw_buffer_load_b64(rs, o + 32, 0, 0);
+    }
   };
   auto has_tip1 = [](const Step &st) { return (st.flags & 3u) == kFusedTT; };
   auto has_tip2 = [](const Step &st) { return (st.flags & 3u) == kFusedTT || (st.flags & 3u) == kFusedRT; };
@@ -311,104 +321,123 @@ fused20_eval_kernel(Fused20Args a, unsigned depth) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) *reinterpret_cast<u32x4 *>(a_lds + lane * 16u + 1024u * k) = raw[k];
   };
-  // d = A(the copy in LDS) . b : five chains of five MFMAs
-  auto product = [&](const double (&b)[kSteps], double (&d)[kGroups]) {
+  // d[q] = A(the copy in LDS) . b[q] : NT x five chains of five MFMAs, each A operand read once
+  auto product = [&](const double (&b)[NT][kSteps], double (&d)[NT][kGroups]) {
     const char *ap = a_lds + a_off;
-    double aa[kBlocks];
 #pragma unroll
-    for (int j = 0; j < kBlocks; ++j) aa[j] = *reinterpret_cast<const double *>(ap + 128 * j);
+    for (int s = 0; s < kSteps; ++s)
 #pragma unroll
-    for (int t = 0; t < kGroups; ++t) {
-      d[t] = 0.0;
+      for (int t = 0; t < kGroups; ++t) {
+        const double aa = *reinterpret_cast<const double *>(ap + 128 * (t * kSteps + s));
 #pragma unroll
-      for (int s = 0; s < kSteps; ++s)
-        d[t] = __builtin_amdgcn_mfma_f64_4x4x4f64(aa[t * kSteps + s], b[s], d[t], 0, 0, 0);
-    }
+        for (int q = 0; q < NT; ++q)   // (first k step: the constant 0 as C, no register to clear)
+          d[q][t] = __builtin_amdgcn_mfma_f64_4x4x4f64(aa, b[q][s], s == 0 ? 0.0 : d[q][t], 0, 0, 0);
+      }
   };
   auto f64 = [](unsigned lo, unsigned hi) { return __builtin_bit_cast(double, u32x2{lo, hi}); };
+  auto row_of = [&](const Rows &t, double (&o)[kSteps]) {
+    o[0] = f64(t.a[0], t.a[1]); o[1] = f64(t.a[2], t.a[3]);
+    o[2] = f64(t.b[0], t.b[1]); o[3] = f64(t.b[2], t.b[3]);
+    o[4] = f64(t.c[0], t.c[1]);
+  };
 
-  double v[kSteps];   // the running CLV: states 4 s + grp of site col
-  int sc = 0;         // its 2^256 rescale count
-  double s0[kSteps];  // stack level 0 (the most used) stays in registers
-  int s0sc = 0;
+  double v[NT][kSteps];   // the running CLVs: states 4 s + grp of site col of each tile
+  int sc[NT];             // their 2^256 rescale counts
+  double s0[NT][kSteps];  // stack level 0 (the most used) stays in registers
+  int s0sc[NT];
 #pragma unroll
-  for (int s = 0; s < kSteps; ++s) v[s] = s0[s] = 0.0;
+  for (int q = 0; q < NT; ++q) {
+    sc[q] = s0sc[q] = 0;
+#pragma unroll
+    for (int s = 0; s < kSteps; ++s) v[q][s] = s0[q][s] = 0.0;
+  }
   unsigned sp = 0;
 
   // prologue: step 0's operands and the codes of step 1
   Step cur = load_step(prog, 0);
   Step nxt = load_step(prog, 1);
   {
-    const Codes k1 = load_codes(has_tip1(cur), cur.cX), k2 = load_codes(has_tip2(cur), cur.cY);
+    const TileCodes k1 = load_codes(has_tip1(cur), cur.cX), k2 = load_codes(has_tip2(cur), cur.cY);
     if (!has_tip1(cur)) request_a(cur);
-    if (has_tip1(cur)) request_tab1(cur, my_code(k1));
-    if (has_tip2(cur)) request_tab2(cur, my_code(k2));
+    if (has_tip1(cur)) request_tab(cur.tabX, k1, t1);
+    if (has_tip2(cur)) request_tab(cur.tabY, k2, t2);
     if (!has_tip1(cur)) stage();
   }
-  Codes cw1 = load_codes(has_tip1(nxt), nxt.cX), cw2 = load_codes(has_tip2(nxt), nxt.cY);
+  TileCodes cw1 = load_codes(has_tip1(nxt), nxt.cX), cw2 = load_codes(has_tip2(nxt), nxt.cY);
 
   for (unsigned i = 0; i < nops; ++i) {
     const Step nx2 = load_step(prog, i + 2);
     const unsigned kind = cur.flags & 3u;
     const bool next_product = !has_tip1(nxt) && i + 1 < nops;
     // tip codes of the step after next (scalar loads)
-    const Codes ncw1 = load_codes(has_tip1(nx2), nx2.cX), ncw2 = load_codes(has_tip2(nx2), nx2.cY);
+    const TileCodes ncw1 = load_codes(has_tip1(nx2), nx2.cX), ncw2 = load_codes(has_tip2(nx2), nx2.cY);
     if (next_product) request_a(nxt);  // the A copy of the next step
-    double d1[kGroups];
+    double d1[NT][kGroups];
     if (kind != kFusedTT) product(v, d1);
-    // this step's table rows (requested behind the previous step's MFMAs), used in place
-    const double t1[kSteps] = {f64(t1a[0], t1a[1]), f64(t1a[2], t1a[3]), f64(t1b[0], t1b[1]),
-                               f64(t1b[2], t1b[3]), f64(t1c[0], t1c[1])};
-    const double t2[kSteps] = {f64(t2a[0], t2a[1]), f64(t2a[2], t2a[3]), f64(t2b[0], t2b[1]),
-                               f64(t2b[2], t2b[3]), f64(t2c[0], t2c[1])};
     if (kind == kFusedPark) {          // push M . (running CLV); the next step is a TT
       if (cur.flags & 0x200u) {        // stack level 0 lives in registers
 #pragma unroll
-        for (int s = 0; s < kSteps; ++s) s0[s] = d1[s];
-        s0sc = sc;
-      } else {
-        double *lv = reinterpret_cast<double *>(stack + sp * kLevelBytes) + lane;
+        for (int q = 0; q < NT; ++q) {
 #pragma unroll
-        for (int s = 0; s < kSteps; ++s) lv[s * 64] = d1[s];
-        reinterpret_cast<int *>(stack + sp * kLevelBytes + kSteps * 64 * 8)[lane] = sc;
+          for (int s = 0; s < kSteps; ++s) s0[q][s] = d1[q][s];
+          s0sc[q] = sc[q];
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < NT; ++q) {
+          char *level = stack + (sp * NT + q) * kLevelBytes;
+          double *lv = reinterpret_cast<double *>(level) + lane;
+#pragma unroll
+          for (int s = 0; s < kSteps; ++s) lv[s * 64] = d1[q][s];
+          reinterpret_cast<int *>(level + kSteps * 64 * 8)[lane] = sc[q];
+        }
         ++sp;
       }
     } else {
-      if (kind == kFusedRP && (cur.flags & 0x400u)) {   // the sibling waits in the register slot
+      if (kind == kFusedRP && !(cur.flags & 0x400u)) --sp;
 #pragma unroll
-        for (int s = 0; s < kSteps; ++s) v[s] = d1[s] * s0[s];
-        sc += s0sc;
-      } else if (kind == kFusedRP) {   // ... or on the LDS stack (multiplied by its matrix when parked)
-        --sp;
-        const double *lv = reinterpret_cast<const double *>(stack + sp * kLevelBytes) + lane;
+      for (int q = 0; q < NT; ++q) {
+        if (kind == kFusedRP && (cur.flags & 0x400u)) {   // the sibling waits in the register slot
 #pragma unroll
-        for (int s = 0; s < kSteps; ++s) v[s] = d1[s] * lv[s * 64];
-        sc += reinterpret_cast<const int *>(stack + sp * kLevelBytes + kSteps * 64 * 8)[lane];
-      } else if (kind == kFusedRT) {
+          for (int s = 0; s < kSteps; ++s) v[q][s] = d1[q][s] * s0[q][s];
+          sc[q] += s0sc[q];
+        } else if (kind == kFusedRP) {   // ... or on the LDS stack (multiplied by its matrix when parked)
+          const char *level = stack + (sp * NT + q) * kLevelBytes;
+          const double *lv = reinterpret_cast<const double *>(level) + lane;
 #pragma unroll
-        for (int s = 0; s < kSteps; ++s) v[s] = d1[s] * t2[s];
-      } else {
+          for (int s = 0; s < kSteps; ++s) v[q][s] = d1[q][s] * lv[s * 64];
+          sc[q] += reinterpret_cast<const int *>(level + kSteps * 64 * 8)[lane];
+        } else if (kind == kFusedRT) {   // this step's table rows, used in place
+          double y[kSteps];
+          row_of(t2[q], y);
 #pragma unroll
-        for (int s = 0; s < kSteps; ++s) v[s] = t1[s] * t2[s];
-        sc = 0;
-      }
-      bool small = true;
+          for (int s = 0; s < kSteps; ++s) v[q][s] = d1[q][s] * y[s];
+        } else {
+          double x[kSteps], y[kSteps];
+          row_of(t1[q], x);
+          row_of(t2[q], y);
 #pragma unroll
-      for (int s = 0; s < kSteps; ++s) small = small && (v[s] < kScaleThreshold);
-      // all 20 entries of a (site, rate) sit in the four lanes col + 16 g
-      unsigned long long bm = __ballot(small);
-      bm &= bm >> 32;
-      bm &= bm >> 16;
-      if ((bm >> col) & 1ull) {
+          for (int s = 0; s < kSteps; ++s) v[q][s] = x[s] * y[s];
+          sc[q] = 0;
+        }
+        bool small = true;
 #pragma unroll
-        for (int s = 0; s < kSteps; ++s) v[s] *= kScaleFactor;
-        sc += 1;
+        for (int s = 0; s < kSteps; ++s) small = small && (v[q][s] < kScaleThreshold);
+        // all 20 entries of a (site, rate) sit in the four lanes col + 16 g
+        unsigned long long bm = __ballot(small);
+        bm &= bm >> 32;
+        bm &= bm >> 16;
+        if ((bm >> col) & 1ull) {
+#pragma unroll
+          for (int s = 0; s < kSteps; ++s) v[q][s] *= kScaleFactor;
+          sc[q] += 1;
+        }
       }
     }
     // the next step's table rows (by the codes that arrived a step ago); then its A
     // copy replaces this one's in LDS
-    if (has_tip1(nxt)) request_tab1(nxt, my_code(cw1));
-    if (has_tip2(nxt)) request_tab2(nxt, my_code(cw2));
+    if (has_tip1(nxt)) request_tab(nxt.tabX, cw1, t1);
+    if (has_tip2(nxt)) request_tab(nxt.tabY, cw2, t2);
     if (next_product) stage();
     cur = nxt;
     nxt = nx2;
@@ -418,38 +447,45 @@ fused20_eval_kernel(Fused20Args a, unsigned depth) {
 
   // root: f_r = sum_k pi_k v[k] for my site and rate, then the rate sum
   const double *freqs = a.freqs + (size_t)job * kK;
-  double f = 0.0;
 #pragma unroll
-  for (int s = 0; s < kSteps; ++s) f += freqs[4 * s + grp] * v[s];
-  f += __shfl_xor(f, 16);
-  f += __shfl_xor(f, 32);
-  if (grp == 0) {
-    root_f[r * 16 + col] = f * a.rate_weights[(size_t)job * R + r];
-    root_sc[r * 16 + col] = sc;
+  for (int q = 0; q < NT; ++q) {
+    double f = 0.0;
+#pragma unroll
+    for (int s = 0; s < kSteps; ++s) f += freqs[4 * s + grp] * v[q][s];
+    f += __shfl_xor(f, 16);
+    f += __shfl_xor(f, 32);
+    if (grp == 0) {
+      root_f[(r * NT + q) * 16 + col] = f * a.rate_weights[(size_t)job * R + r];
+      root_sc[(r * NT + q) * 16 + col] = sc[q];
+    }
   }
   __syncthreads();
   if (threadIdx.x < 64) {
-    double l = 0.0;
-    if (lane < 16) {
-      double term = root_f[lane];
-      int smin = root_sc[lane];
-      for (unsigned q = 1; q < R; ++q) {
-        const double fq = root_f[q * 16 + lane];
-        const int sq = root_sc[q * 16 + lane];
-        if (sq >= smin) {
-          term += fq * pow2_neg256(sq - smin);
-        } else {
-          term = term * pow2_neg256(smin - sq) + fq;
-          smin = sq;
-        }
-      }
-      l = log(term) + (double)smin * kLogScaleThreshold;
-      l *= (double)a.pattern_weights[ls];
-      if (site >= S) l = 0.0;
-    }
 #pragma unroll
-    for (int off = 8; off > 0; off >>= 1) l += __shfl_down(l, off);
-    if (lane == 0) a.partials[(size_t)job * a.tiles + blockIdx.x] = l;
+    for (int q = 0; q < NT; ++q) {
+      double l = 0.0;
+      if (lane < 16) {
+        double term = root_f[q * 16 + lane];
+        int smin = root_sc[q * 16 + lane];
+        for (unsigned w = 1; w < R; ++w) {
+          const double fq = root_f[(w * NT + q) * 16 + lane];
+          const int sq = root_sc[(w * NT + q) * 16 + lane];
+          if (sq >= smin) {
+            term += fq * pow2_neg256(sq - smin);
+          } else {
+            term = term * pow2_neg256(smin - sq) + fq;
+            smin = sq;
+          }
+        }
+        l = log(term) + (double)smin * kLogScaleThreshold;
+        l *= (double)a.pattern_weights[ls[q]];
+        if (site[q] >= S) l = 0.0;
+      }
+#pragma unroll
+      for (int off = 8; off > 0; off >>= 1) l += __shfl_down(l, off);
+      const unsigned tile = blockIdx.x * NT + q;
+      if (lane == 0 && tile < a.tiles) a.partials[(size_t)job * a.tiles + tile] = l;
+    }
   }
 }
 
@@ -478,8 +514,11 @@ hipError_t launch_fused20_pmatrix(const Fused20Args &a, const double *d_q, const
   return hipGetLastError();
 }
 
+constexpr int kFused20Tiles = 1;   // 16-site tiles per wave
+
 size_t fused20_lds_bytes(unsigned R, unsigned depth) {
-  return (size_t)R * 16 * 12 + (size_t)R * (kCopyLds + (size_t)depth * kLevelBytes);
+  return (size_t)R * kFused20Tiles * 16 * 12 +
+         (size_t)R * (kCopyLds + (size_t)depth * kFused20Tiles * kLevelBytes);
 }
 
 hipError_t launch_fused20_eval(const Fused20Args &a, unsigned n_jobs, unsigned max_depth,
@@ -487,11 +526,12 @@ hipError_t launch_fused20_eval(const Fused20Args &a, unsigned n_jobs, unsigned m
   if (!n_jobs) return hipSuccess;
   const size_t lds = fused20_lds_bytes(a.rate_cats, max_depth);
   if (lds > 64 * 1024) {   // more than 64 KB of LDS per workgroup has to be asked for
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fused20_eval_kernel),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fused20_eval_kernel<kFused20Tiles>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
   }
-  fused20_eval_kernel<<<dim3(a.tiles, n_jobs), 64 * a.rate_cats, lds, stream>>>(a, max_depth);
+  const unsigned groups = (a.tiles + kFused20Tiles - 1) / kFused20Tiles;
+  fused20_eval_kernel<kFused20Tiles><<<dim3(groups, n_jobs), 64 * a.rate_cats, lds, stream>>>(a, max_depth);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   fused20_finish_kernel<<<n_jobs, 256, 0, stream>>>(a.partials, a.tiles, d_out);
