@@ -11,6 +11,7 @@
 #include <functional>
 #include <unordered_map>
 
+#include <cstdlib>
 #include "common.hpp"
 #include "fused.hpp"
 
@@ -63,7 +64,7 @@ static hipError_t ensure_workspace(rdamd_partition *p, unsigned n_jobs) {
   // 4 states: site blocks padded to a multiple of 8 so that blockIdx.x % 8 (the
   // XCD a workgroup lands on) is the same for every job: each XCD's L2 then only
   // ever sees 1/8 of the tip codes.  20 states: one partial per 16-site tile.
-  const unsigned per_block = 64 * kFusedSitesPerLane;
+  const unsigned per_block = 64;
   w->blocks_x = K == 4 ? ((p->sites + per_block - 1) / per_block + 7) / 8 * 8 : (p->sites + 15) / 16;
   const size_t pm_per_job = (size_t)p->prob_matrices * R * K * K;
 #define A(ptr, bytes) do { e = hipMalloc((void **)&(ptr), (bytes)); if (e != hipSuccess) return e; } while (0)
@@ -371,7 +372,12 @@ static int evaluate_batch_impl(rdamd_partition_t *p, unsigned int n_jobs,
   p->prof_end();
   RDAMD_HIP_TRY(e, RDAMD_FAILURE);
   p->prof_begin(3);
-  e = launch_fused_eval(a, n_jobs, max_depth, w->blocks_x, d_out, p->stream);
+  // two sites per lane (kernels_fused.hip) when half the waves still fill the chip:
+  // >= 4 waves for each of the 1024 SIMDs.  RDAMD_FUSED_NS=1|2 overrides (A/B runs).
+  static const int force_ns = getenv("RDAMD_FUSED_NS") ? atoi(getenv("RDAMD_FUSED_NS")) : 0;
+  const unsigned ns = force_ns ? (unsigned)force_ns
+                               : ((size_t)n_jobs * w->blocks_x >= 8192 ? 2u : 1u);
+  e = launch_fused_eval(a, n_jobs, max_depth, w->blocks_x, ns, d_out, p->stream);
   p->prof_end();
   RDAMD_HIP_TRY(e, RDAMD_FAILURE);
   }

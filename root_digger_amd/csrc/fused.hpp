@@ -16,10 +16,8 @@ enum : uint32_t {
   kFusedPark = 3, // 20-state programs only: push M . (running CLV) as a step of its own
 };
 
-// sites each lane of the fused kernel carries.  2 halves the scalar work per
-// site but doubles the LDS stack per wave (half the waves per CU); measured
-// equal within 3 % on c2, so the simpler 1 is used.
-constexpr int kFusedSitesPerLane = 1;
+// 64-site blocks are the unit blocks_x counts; a lane of the fused kernel carries 1
+// or 2 sites (launch_fused_eval's sites_per_lane).
 
 // One step of a compiled traversal ("program"), 32 bytes, one scalar load.
 // All offsets are precomputed on the host so the kernel adds at most the rate.
@@ -89,7 +87,8 @@ hipError_t launch_fused20_eval(const Fused20Args &a, unsigned n_jobs, unsigned m
 hipError_t launch_fused_pmatrix(const FusedArgs &a, const double *d_q, const double *d_rates,
                                 unsigned n_jobs, unsigned n_mat, hipStream_t stream);
 hipError_t launch_fused_eval(const FusedArgs &a, unsigned n_jobs, unsigned max_depth,
-                             unsigned blocks_x, double *d_out, hipStream_t stream);
+                             unsigned blocks_x, unsigned sites_per_lane, double *d_out,
+                             hipStream_t stream);
 
 
 }  // namespace rdamd

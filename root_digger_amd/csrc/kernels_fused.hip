@@ -401,23 +401,37 @@ hipError_t launch_fused_pmatrix(const FusedArgs &a, const double *d_q, const dou
   return hipGetLastError();
 }
 
-hipError_t launch_fused_eval(const FusedArgs &a, unsigned n_jobs, unsigned max_depth,
-                             unsigned blocks_x, double *d_out, hipStream_t stream) {
-  if (!n_jobs) return hipSuccess;
+template <int NS>
+static hipError_t launch_fused_eval_ns(const FusedArgs &a, unsigned n_jobs, unsigned max_depth,
+                                       unsigned blocks_x, double *d_out, hipStream_t stream) {
   const size_t lds = kTabDoubles * sizeof(double) +
-                     (size_t)(max_depth ? max_depth : 1) * kFusedSitesPerLane * 64 *
-                         (4 * sizeof(double) + sizeof(int));
+                     (size_t)(max_depth ? max_depth : 1) * NS * 64 * (4 * sizeof(double) + sizeof(int));
   if (lds > 48 * 1024) {   // deep stacks (very unbalanced 10^3-taxon trees): raise the limit
-    hipError_t e = hipFuncSetAttribute((const void *)fused_dna_eval_kernel<kFusedSitesPerLane>,
+    hipError_t e = hipFuncSetAttribute((const void *)fused_dna_eval_kernel<NS>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
   }
-  dim3 grid(blocks_x, n_jobs);
-  fused_dna_eval_kernel<kFusedSitesPerLane><<<grid, 64, lds, stream>>>(a);
+  const unsigned gx = (blocks_x + NS - 1) / NS;   // blocks_x counts 64-site blocks
+  dim3 grid(gx, n_jobs);
+  fused_dna_eval_kernel<NS><<<grid, 64, lds, stream>>>(a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  fused_finish_kernel<<<n_jobs, 256, 0, stream>>>(a.partials, blocks_x, d_out);
+  fused_finish_kernel<<<n_jobs, 256, 0, stream>>>(a.partials, gx, d_out);
   return hipGetLastError();
+}
+
+// sites_per_lane: 1 or 2.  Two sites per lane share every scalar operand (P-matrix
+// SGPRs, descriptors, control flow) and every tip-table row fetch between two
+// sites: +10 % on c2 (197-job launches: 40.6k -> 44.8k evaluations/s, 124 VGPRs, four
+// waves per SIMD), +5 % on c5; three and four sites per lane lose (register
+// pressure: 31k and 22k).  One site per lane is kept for launches too small to
+// fill the chip with half the waves (evaluate.hip picks).
+hipError_t launch_fused_eval(const FusedArgs &a, unsigned n_jobs, unsigned max_depth,
+                             unsigned blocks_x, unsigned sites_per_lane, double *d_out,
+                             hipStream_t stream) {
+  if (!n_jobs) return hipSuccess;
+  return sites_per_lane == 2 ? launch_fused_eval_ns<2>(a, n_jobs, max_depth, blocks_x, d_out, stream)
+                             : launch_fused_eval_ns<1>(a, n_jobs, max_depth, blocks_x, d_out, stream);
 }
 
 }  // namespace rdamd
