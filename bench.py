@@ -430,14 +430,42 @@ def main():
         tdist.destroy_process_group()
 
 
+def host_topology():
+    """(sockets, physical cores per socket, logical cpus) from /proc/cpuinfo."""
+    cores = set()
+    phys = core = None
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                phys = int(line.split(":")[1])
+            elif line.startswith("core id"):
+                core = int(line.split(":")[1])
+            elif not line.strip() and phys is not None and core is not None:
+                cores.add((phys, core))
+                phys = core = None
+    except OSError:
+        pass
+    logical = os.cpu_count() or 1
+    if not cores:
+        return 1, logical, logical
+    sockets = len({p for p, _ in cores})
+    return sockets, max(1, len(cores) // sockets), logical
+
+
 def cpu_baseline(w, tree, cmap, freqs, n, S, K, R, params, roots, budget, gpu_eval):
-    """The CPU oracle (oracle/rd_oracle.c, single thread: what one reference rank
-    spends on CLV work with one partition) on the SAME workload,
-    bounded to `budget` seconds; also the in-run parity gate (<= 1e-9)."""
+    """The CPU oracle (oracle/rd_oracle.c) on the SAME workload, bounded to `budget`
+    seconds; also the in-run parity gate (<= 1e-9).  4-state data go through the
+    oracle's 256-bit-vector CLV loop (bit-identical to its scalar loop; the
+    reference selects coraxlib's AVX2 kernel for nucleotides,
+    /root/reference/src/model.cpp:145-155).  Two figures: one thread
+    -- what one reference rank spends on CLV work with one partition -- and one
+    candidate root per thread on the physical cores of ONE socket, what
+    `mpirun -np <cores> rd` does (src/model.cpp:1899-1907)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from oracle_lib import OraclePartition, ORC_MAP_NT
-    import ctypes
     ocmap = ORC_MAP_NT if K == 4 else cmap
+    vec = K == 4
+
     def make_partition():
         o = OraclePartition.for_tree(tree, K, S, R)
         for label, seq in w["seqs"].items():
@@ -446,14 +474,17 @@ def cpu_baseline(w, tree, cmap, freqs, n, S, K, R, params, roots, budget, gpu_ev
         o.set_category_rates(w["rates"])
         return o
 
-    def evaluate(o, j):
+    def evaluate(o, j, avx2=vec):
         o.set_subst_params(0, params[j])
         ops, pmi, brl = scheds[j]
         o.update_prob_matrices(pmi, brl)
-        o.update_clvs(ops)
+        o.update_clvs(ops, avx2=avx2)
         return o.compute_root_loglikelihood(tree.root_clv_index(), tree.root_scaler_index())
 
-    scheds = [tree.generate_operations(rl) for rl in roots[:64]]
+    scheds = []
+    for rl in roots[:64]:
+        ops, pmi, brl = tree.generate_operations(rl)
+        scheds.append((OraclePartition.pack_ops(ops), pmi, brl))
     o = make_partition()
     done, worst, dt = 0, 0.0, 0.0
     while True:
@@ -464,19 +495,27 @@ def cpu_baseline(w, tree, cmap, freqs, n, S, K, R, params, roots, budget, gpu_ev
         done += 1
         got = gpu_eval(j)                          # parity gate, not timed
         worst = max(worst, abs(got - ref) / abs(ref))
-        if dt >= 0.6 * budget or done >= 64:
+        if dt >= 0.5 * budget or done >= 64:
             break
     if worst > 1e-9:
         raise SystemExit("parity gate failed: GPU vs oracle rel.err %.3e" % worst)
+    loop = "256-bit-vector CLV loop (AVX2, no FMA), " if vec else "scalar CLV loop, "
+    sockets, per_socket, logical = host_topology()
     out = {"value": round(done / dt, 4), "unit": "evals/s", "cores": 1, "kind": "port",
-           "sample": "%d full-traversal evaluations of the same workload (oracle/rd_oracle.c, "
-                     "1 thread, -O3 x86-64-v3, no site repeats)" % done,
-           "host_cores": os.cpu_count(), "parity_max_rel_err": worst}
+           "sample": "%d full-traversal evaluations of the same workload (oracle/rd_oracle.c, 1 thread, "
+                     "%s-O3 x86-64-v3, no site repeats)" % (done, loop),
+           "host": {"sockets": sockets, "cores_per_socket": per_socket, "logical_cpus": logical},
+           "parity_max_rel_err": worst}
+    if vec:   # the scalar loop of the same oracle, for comparison with earlier rounds
+        t0 = time.perf_counter()
+        k = 0
+        while k < 2 or (time.perf_counter() - t0 < 0.1 * budget and k < 16):
+            evaluate(o, k % len(scheds), avx2=False)
+            k += 1
+        out["scalar_loop_1_thread"] = round(k / (time.perf_counter() - t0), 4)
 
-    # every host core, one candidate root per thread -- what
-    # `mpirun -np <cores> rd` does (src/model.cpp:1899-1907).  One oracle
-    # partition per thread (ctypes calls run without the GIL); the thread count
-    # is capped by host memory (each partition holds all 2n-2 CLVs).
+    # one socket: one candidate root per thread, one oracle partition per thread (ctypes
+    # calls run without the GIL); capped by host memory (a partition holds all 2n-2 CLVs)
     import threading
     try:
         import psutil
@@ -484,7 +523,8 @@ def cpu_baseline(w, tree, cmap, freqs, n, S, K, R, params, roots, budget, gpu_ev
     except Exception:
         avail = 16 << 30
     per_part = (2 * n - 2) * S * R * K * 8 * 1.15 + n * S * 8
-    threads = int(max(1, min(len(os.sched_getaffinity(0)), 0.4 * avail // per_part, 64, len(scheds))))
+    allowed = len(os.sched_getaffinity(0))
+    threads = int(max(1, min(per_socket, allowed, 0.4 * avail // per_part, len(scheds))))
     if threads > 1:
         parts = [o] + [make_partition() for _ in range(threads - 1)]
         counts = [0] * threads
@@ -506,10 +546,13 @@ def cpu_baseline(w, tree, cmap, freqs, n, S, K, R, params, roots, budget, gpu_ev
         for th in ths:
             th.join()
         wall = time.perf_counter() - t0
-        out["all_cores"] = {"value": round(sum(counts) / wall, 4), "unit": "evals/s",
-                            "cores": threads,
-                            "sample": "%d evaluations, one candidate root per thread, %d threads "
-                                      "for %.1f s" % (sum(counts), threads, wall)}
+        out["one_socket"] = {"value": round(sum(counts) / wall, 4), "unit": "evals/s",
+                             "cores": threads,
+                             "sample": "%d evaluations, one candidate root per thread, %d threads "
+                                       "(%d socket(s) x %d physical cores on this host%s) for %.1f s"
+                                       % (sum(counts), threads, sockets, per_socket,
+                                          "" if threads == per_socket else "; capped by memory/affinity",
+                                          wall)}
         for q in parts[1:]:
             q.destroy()
     o.destroy()

@@ -618,6 +618,19 @@ int         rdamd_device_count(void);
 int         rdamd_set_device(int device);
 /* free / total memory of the current device in bytes (hipMemGetInfo) */
 int         rdamd_device_memory(uint64_t *free_bytes, uint64_t *total_bytes);
+/* device bytes a partition of this shape takes (rdamd_partition_create's buffers) */
+uint64_t    rdamd_partition_footprint(unsigned int tips, unsigned int clv_buffers,
+                                      unsigned int states, unsigned int sites,
+                                      unsigned int prob_matrices, unsigned int rate_cats,
+                                      unsigned int scale_buffers);
+/* Replicas rdamd_model_exhaustive_search_parallel / _lockstep may hold for this
+ * model on the current device: `requested`, clamped so that the replicas'
+ * partitions (each a full copy: all CLV and scaler buffers) fit in 85 % of the
+ * device memory that is free now; at least 1.  replica_bytes (optional): what one
+ * replica takes.  The two searches apply this clamp themselves and say so on
+ * stderr when it bites. */
+unsigned int rdamd_model_max_replicas(const rdamd_model_t *m, unsigned int requested,
+                                      uint64_t *replica_bytes);
 
 #ifdef __cplusplus
 }

@@ -396,6 +396,79 @@ void orc_update_clvs(orc_partition_t *p, const orc_operation_t *ops,
   for (unsigned int i = 0; i < count; ++i) update_one(p, &ops[i]);
 }
 
+/* ---- the same update with 256-bit vectors, 4 states only ------------------
+ * What the reference links for nucleotide data is coraxlib's AVX2 kernel
+ * (src/model.cpp:145-155 selects CORAX_ATTRIB_ARCH_AVX2 at run time); bench.py's
+ * cpu_baseline leg times THIS loop so that the stated baseline is a vectorised
+ * one.  One vector = the four parent states; separate multiply and add in the
+ * scalar loop's order (no FMA: built with -ffp-contract=off), so every CLV entry
+ * and scaler is bit-identical to update_one's (tests/test_oracle_golden.py). */
+#if defined(__AVX2__)
+#include <immintrin.h>
+static void update_one_avx2(orc_partition_t *p, const orc_operation_t *op) {
+  unsigned int R = p->rate_cats, S = p->sites;
+  double *parent = p->clv[op->parent_clv_index];
+  const double *left = p->clv[op->child1_clv_index];
+  const double *right = p->clv[op->child2_clv_index];
+  const double *lm = p->pmatrix[op->child1_matrix_index];
+  const double *rm = p->pmatrix[op->child2_matrix_index];
+  unsigned int *psc = op->parent_scaler_index == ORC_SCALE_BUFFER_NONE
+                          ? NULL : p->scaler[op->parent_scaler_index];
+  const unsigned int *lsc = op->child1_scaler_index == ORC_SCALE_BUFFER_NONE
+                                ? NULL : p->scaler[op->child1_scaler_index];
+  const unsigned int *rsc = op->child2_scaler_index == ORC_SCALE_BUFFER_NONE
+                                ? NULL : p->scaler[op->child2_scaler_index];
+  /* columns of the P-matrices: lcol[r][j] = (P[0][j], P[1][j], P[2][j], P[3][j]) */
+  __m256d *lcol = (__m256d *)aligned_alloc(32, sizeof(__m256d) * 8 * R);
+  __m256d *rcol = lcol + 4 * R;
+  for (unsigned int r = 0; r < R; ++r)
+    for (unsigned int j = 0; j < 4; ++j) {
+      const double *a = lm + (size_t)r * 16, *b = rm + (size_t)r * 16;
+      lcol[r * 4 + j] = _mm256_set_pd(a[12 + j], a[8 + j], a[4 + j], a[j]);
+      rcol[r * 4 + j] = _mm256_set_pd(b[12 + j], b[8 + j], b[4 + j], b[j]);
+    }
+  const __m256d thr = _mm256_set1_pd(ORC_SCALE_THRESHOLD), fac = _mm256_set1_pd(ORC_SCALE_FACTOR);
+  size_t span = (size_t)R * 4;
+  for (unsigned int s = 0; s < S; ++s) {
+    double *pc = parent + s * span;
+    const double *lc = left + s * span, *rc = right + s * span;
+    int all_small = 0xF;
+    for (unsigned int r = 0; r < R; ++r) {
+      /* ((0 + m0 c0) + m1 c1) + m2 c2) + m3 c3, as the scalar loop adds them */
+      __m256d ta = _mm256_setzero_pd(), tb = _mm256_setzero_pd();
+      for (unsigned int j = 0; j < 4; ++j) {
+        ta = _mm256_add_pd(ta, _mm256_mul_pd(lcol[r * 4 + j], _mm256_broadcast_sd(lc + r * 4 + j)));
+        tb = _mm256_add_pd(tb, _mm256_mul_pd(rcol[r * 4 + j], _mm256_broadcast_sd(rc + r * 4 + j)));
+      }
+      const __m256d v = _mm256_mul_pd(ta, tb);
+      _mm256_storeu_pd(pc + r * 4, v);
+      all_small &= _mm256_movemask_pd(_mm256_cmp_pd(v, thr, _CMP_LT_OQ));
+    }
+    if (psc) {
+      unsigned int sc = (lsc ? lsc[s] : 0u) + (rsc ? rsc[s] : 0u);
+      if (all_small == 0xF) {
+        for (unsigned int r = 0; r < R; ++r)
+          _mm256_storeu_pd(pc + r * 4, _mm256_mul_pd(_mm256_loadu_pd(pc + r * 4), fac));
+        sc += 1;
+      }
+      psc[s] = sc;
+    }
+  }
+  free(lcol);
+}
+#endif
+
+int orc_update_clvs_avx2(orc_partition_t *p, const orc_operation_t *ops, unsigned int count) {
+#if defined(__AVX2__)
+  if (p->states != 4) return ORC_FAILURE;
+  for (unsigned int i = 0; i < count; ++i) update_one_avx2(p, &ops[i]);
+  return ORC_SUCCESS;
+#else
+  (void)p; (void)ops; (void)count;
+  return ORC_FAILURE;
+#endif
+}
+
 /* ---- root log-likelihood (row a3; Appendix A5) --------------------------- */
 
 double orc_compute_root_loglikelihood(orc_partition_t *p,

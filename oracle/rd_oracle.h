@@ -91,6 +91,10 @@ int orc_update_prob_matrices(orc_partition_t    *p,
 /* src/model.cpp:402,:440,:461,:851 */
 void orc_update_clvs(orc_partition_t *p, const orc_operation_t *ops,
                      unsigned int count);
+/* The same update through 256-bit vectors (4-state data; what the reference's
+ * coraxlib build selects for nucleotides, src/model.cpp:145-155), bit-identical
+ * to orc_update_clvs.  ORC_FAILURE for other state counts or without AVX2. */
+int orc_update_clvs_avx2(orc_partition_t *p, const orc_operation_t *ops, unsigned int count);
 /* src/model.cpp:406,:441,:466 */
 double orc_compute_root_loglikelihood(orc_partition_t    *p,
                                       unsigned int        clv_index,

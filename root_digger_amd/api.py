@@ -236,6 +236,9 @@ _sig("rdamd_comm_create", _vp, C.c_char * 128, C.c_int, C.c_int)
 _sig("rdamd_comm_allreduce_sum", C.c_int, _vp, _vp, _u, _vp)
 _sig("rdamd_comm_destroy", None, _vp)
 
+_sig("rdamd_partition_footprint", C.c_uint64, _u, _u, _u, _u, _u, _u, _u)
+_sig("rdamd_model_max_replicas", _u, _vp, _u, C.POINTER(C.c_uint64))
+
 _libc = C.CDLL(None)
 _libc.free.argtypes = [_vp]
 _libc.free.restype = None
@@ -1029,6 +1032,12 @@ class Model:
         self._reducer = fn                   # keep the callback alive
         self._ok(lib.rdamd_model_set_lnl_reducer(self._h, C.cast(fn, _vp), user,
                                                  1 if on_device else 0), "set_lnl_reducer")
+
+    def max_replicas(self, requested):
+        """-> (replicas that fit the free device memory, bytes per replica)"""
+        b = C.c_uint64(0)
+        n = lib.rdamd_model_max_replicas(self._h, requested, C.byref(b))
+        return int(n), int(b.value)
 
     def partition_count(self):
         return int(lib.rdamd_model_partition_count(self._h))

@@ -102,6 +102,10 @@ template <int NS>
 __global__ void __launch_bounds__(64)
 fused_dna_eval_kernel(FusedArgs a) {
   extern __shared__ double lds[];
+  // read_row<> and the tip-table writes address LDS bytes 0 and 512 absolutely: that
+  // is the dynamic block only while this kernel has no static __shared__ in front of
+  // it.  Should one ever appear, fail loudly instead of corrupting the tables.
+  if ((unsigned)(size_t)(__attribute__((address_space(3))) double *)lds != 0u) __builtin_trap();
   const unsigned lane = threadIdx.x;
   const unsigned job = blockIdx.y;
   const unsigned S = a.sites, R = a.rate_cats;

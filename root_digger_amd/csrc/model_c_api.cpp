@@ -400,6 +400,23 @@ void rdamd_model_set_lbfgsb(rdamd_model_t *m, void *fn) {
 // threads, each with its own model replica (own partition, own HIP stream),
 // pulling candidates from a shared counter -- their small launches (13-job
 // L-BFGS-B batches, root-only Brent steps) overlap on the device.
+unsigned int rdamd_model_max_replicas(const rdamd_model_t *m, unsigned int requested,
+                                      uint64_t *replica_bytes) {
+  const unsigned tips = m->model->tree().tip_count(), branches = m->model->tree().branch_count();
+  uint64_t per_replica = 0;
+  const auto ratehets = m->all_ratehets();
+  const auto msas = m->all_msas();
+  for (size_t i = 0; i < msas.size(); ++i)
+    per_replica += rdamd_partition_footprint(tips, branches, msas[i].states, (unsigned)msas[i].length(),
+                                             branches, (unsigned)ratehets[std::min(i, ratehets.size() - 1)].rate_cats,
+                                             branches);
+  if (replica_bytes) *replica_bytes = per_replica;
+  uint64_t free_b = 0, total_b = 0;
+  if (rdamd_device_memory(&free_b, &total_b) != RDAMD_SUCCESS || per_replica == 0) return requested ? requested : 1;
+  const uint64_t fit = (uint64_t)(0.85 * (double)free_b) / per_replica;
+  return (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(requested, fit));
+}
+
 static int search_with_replicas(rdamd_model_t *m, unsigned int workers, bool lockstep, double atol,
                                 double pgtol, double brtol, double factor, uint64_t *root_id,
                                 double *llh, double *alpha, unsigned int *n_results,
@@ -416,6 +433,15 @@ static int search_with_replicas(rdamd_model_t *m, unsigned int workers, bool loc
     const std::vector<size_t> todo = m->model->assigned_indicies();
     if (workers < 1) workers = 1;
     workers = (unsigned)std::min<size_t>(workers, std::max<size_t>(todo.size(), 1));
+    {   // every replica is a full model (all CLV buffers): keep them inside the device memory
+      uint64_t bytes = 0;
+      const unsigned fit = rdamd_model_max_replicas(m, workers, &bytes);
+      if (fit < workers) {
+        std::fprintf(stderr, "rdamd: %u replicas of %.1f GB each do not fit the free device memory; "
+                             "running %u\n", workers, (double)bytes / 1e9, fit);
+        workers = fit;
+      }
+    }
     int device = 0;
     if (hipGetDevice(&device) != hipSuccess) throw std::runtime_error("no HIP device");
     std::atomic<size_t> next{0};

@@ -138,6 +138,20 @@ int rdamd_device_memory(uint64_t *free_bytes, uint64_t *total_bytes) {
   return RDAMD_SUCCESS;
 }
 
+// device bytes rdamd_partition_create takes for a partition of this shape (the
+// large buffers; what a replica of a model costs)
+uint64_t rdamd_partition_footprint(unsigned int tips, unsigned int clv_buffers, unsigned int states,
+                                   unsigned int sites, unsigned int prob_matrices,
+                                   unsigned int rate_cats, unsigned int scale_buffers) {
+  const uint64_t K = states == 2 ? 4 : states, R = rate_cats, S = sites;
+  const uint64_t codes = K == 4 ? 16 : 64;
+  uint64_t b = (uint64_t)tips * ((S + 3) / 4 * 4) + (uint64_t)clv_buffers * S * R * K * 8 +
+               (uint64_t)scale_buffers * S * 4 + (uint64_t)prob_matrices * R * K * K * 8 +
+               (uint64_t)prob_matrices * R * codes * K * 8 + S * 4 + ((uint64_t)6 << 20);
+  if (K == 20 && R <= 8) b += (uint64_t)prob_matrices * R * k20_mfma_copy_doubles() * 8;
+  return b;
+}
+
 #define NT(ch, v) [ch] = v, [ch + 32] = v
 const uint64_t rdamd_map_nt[256] = {
     NT('A', 1),  NT('C', 2),  NT('G', 4),  NT('T', 8),  NT('U', 8),  NT('R', 5),

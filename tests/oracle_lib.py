@@ -41,6 +41,7 @@ _sig("orc_msa_empirical_frequencies", _pd, _vp)
 _sig("orc_compute_gamma_cats", C.c_int, C.c_double, _u, _pd, C.c_int)
 _sig("orc_update_prob_matrices", C.c_int, _vp, _pu, _pu, _pd, _u)
 _sig("orc_update_clvs", None, _vp, C.POINTER(OrcOperation), _u)
+_sig("orc_update_clvs_avx2", C.c_int, _vp, C.POINTER(OrcOperation), _u)
 _sig("orc_compute_root_loglikelihood", C.c_double, _vp, _u, C.c_int, _pu, _pd)
 _sig("orc_get_clv", _pd, _vp, _u)
 _sig("orc_get_scaler", _pu, _vp, _u)
@@ -135,13 +136,31 @@ class OraclePartition:
                                          mi.size) != 1:
             raise RuntimeError("oracle: update_prob_matrices failed")
 
-    def update_clvs(self, ops):
-        n = len(ops)
-        arr = (OrcOperation * n)()
+    def update_clvs(self, ops, avx2=False):
+        """avx2=True: the 256-bit-vector loop (4 states), bit-identical results; what
+        bench.py's cpu_baseline leg times."""
+        if isinstance(ops, C.Array) and ops._type_ is OrcOperation:
+            arr, n = ops, len(ops)
+        else:
+            n = len(ops)
+            arr = (OrcOperation * n)()
+            for i, o in enumerate(ops):
+                for f, _ in OrcOperation._fields_:
+                    setattr(arr[i], f, getattr(o, f))
+        if avx2:
+            if olib.orc_update_clvs_avx2(self._h, arr, n) != 1:
+                raise RuntimeError("oracle: the AVX2 loop takes 4-state data (and an AVX2 build)")
+        else:
+            olib.orc_update_clvs(self._h, arr, n)
+
+    @staticmethod
+    def pack_ops(ops):
+        """operations as the oracle's own array (build once, reuse in timed loops)"""
+        arr = (OrcOperation * len(ops))()
         for i, o in enumerate(ops):
             for f, _ in OrcOperation._fields_:
                 setattr(arr[i], f, getattr(o, f))
-        olib.orc_update_clvs(self._h, arr, n)
+        return arr
 
     def compute_root_loglikelihood(self, clv_index, scaler_index, freqs_indices=None,
                                    persite=False):

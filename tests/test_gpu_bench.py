@@ -46,6 +46,11 @@ def test_bench_line_has_the_contract_fields():
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0
     assert c["parity_max_rel_err"] < 1e-9
+    # the stated baseline is the oracle's AVX2 loop; host sockets x cores are stated
+    assert "AVX2" in c["sample"] and c["scalar_loop_1_thread"] > 0
+    assert c["host"]["sockets"] >= 1 and c["host"]["cores_per_socket"] >= 1
+    if "one_socket" in c:
+        assert 1 < c["one_socket"]["cores"] <= c["host"]["cores_per_socket"]
 
 
 def test_site_sharded_bench_matches_candidate_sharded_checksum():

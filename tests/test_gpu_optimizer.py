@@ -330,3 +330,25 @@ def test_binary_characters_with_parameter_optimisation(lbfgsb, tmp_path):
     m.exhaustive_search(1e-3, 1e-3, 1e-3, 1e12)
     (rid, llh, alpha, params), = ck.read_results()
     assert len(params[0]["subst_rates"]) == 2 and len(params[0]["freqs"]) == 2
+
+
+def test_replica_count_is_clamped_to_device_memory():
+    """every replica of the parallel / lock-step search is a full model
+    (all CLV buffers); asking for more than fit must be clamped, not die in
+    hipMalloc.  A 60-taxon x 400 000-site Γ4 model is 6.1 GB per replica."""
+    from root_digger_amd import synth
+    w = synth.workload(60, 400000, 4, 4, 77, simulate_seqs=False)
+    tree = rd.Tree.from_newick(w["newick"])
+    m = rd.Model(tree, w["seqs"], rate_cats=4, seed=1)
+    free, total = rd.device_memory()
+    fit, per = m.max_replicas(1000)
+    want = rd.lib.rdamd_partition_footprint(60, 118, 4, 400000, 118, 4, 118)
+    assert per == want and 5.9e9 < per < 6.6e9
+    assert 1 <= fit < 1000 and fit * per <= 0.85 * free + per
+    assert m.max_replicas(2) == (2, per)
+    # the search itself applies the clamp: 1000 workers requested, it runs (and says so)
+    m.initialize_partitions()
+    m.assign_by_rank(0, 60)                     # two candidates
+    res = m.exhaustive_search(1e-2, 1e-2, 1e-2, 1e12, workers=1000)
+    assert len(res["root_id"]) == 2 and np.all(np.isfinite(res["llh"]))
+    m.destroy()

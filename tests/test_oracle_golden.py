@@ -246,3 +246,42 @@ def test_determinism_and_negativity():
         a = util.compute_lh(part, tree, rl)
         b = util.compute_lh(part, tree, rl)
         assert math.isfinite(a) and a < 0.0 and a == b
+
+
+def test_avx2_clv_loop_is_bit_identical_to_the_scalar_one():
+    """bench.py's cpu_baseline times the oracle's 256-bit-vector 4-state loop
+    (orc_update_clvs_avx2; the reference selects coraxlib's AVX2 kernel for
+    nucleotides, src/model.cpp:145-155).  It must produce the scalar loop's
+    bits: every CLV entry, every scaler, the lnL -- on 101.phy (ambiguity codes,
+    zero-length branches) and on the deep tree where the rescaling fires."""
+    import root_digger_amd as rd
+    cases = []
+    tree = rd.Tree.from_file(os.path.join(util.DATA, "101.tree"))
+    seqs, w = util.compress(util.read_phylip(os.path.join(util.DATA, "101.phy")))
+    cases.append((tree, seqs, w, [.34, .42, .24, .74, .16, .88, .75, .54, .20, .06, .08, .41],
+                  [0.21, 0.29, 0.24, 0.26], orc_gamma_cats(0.7, 4)))
+    gd = util.golden("deep_scaling.json")
+    cases.append((rd.Tree.from_newick(gd["newick"]), gd["seqs"], None, gd["subst"], gd["freqs"], gd["rates"]))
+    for tree, seqs, w, subst, freqs, rates in cases:
+        S = len(next(iter(seqs.values())))
+        a = OraclePartition.for_tree(tree, 4, S, 4)
+        b = OraclePartition.for_tree(tree, 4, S, 4)
+        for p in (a, b):
+            util.load_tips(p, tree, seqs, ORC_MAP_NT, w)
+            p.set_subst_params(0, subst)
+            p.set_frequencies(0, freqs)
+            p.set_category_rates(rates)
+        rl = tree.root_location(7).with_ratio(0.3)
+        ops, pmi, brl = tree.generate_operations(rl)
+        for p, vec in ((a, False), (b, True)):
+            p.update_prob_matrices(pmi, brl)
+            p.update_clvs(ops, avx2=vec)
+        for op in ops:
+            assert np.array_equal(a.get_clv(op.parent_clv_index), b.get_clv(op.parent_clv_index))
+            if op.parent_scaler_index >= 0:
+                assert np.array_equal(a.get_scaler(op.parent_scaler_index), b.get_scaler(op.parent_scaler_index))
+        la = a.compute_root_loglikelihood(tree.root_clv_index(), tree.root_scaler_index())
+        assert la == b.compute_root_loglikelihood(tree.root_clv_index(), tree.root_scaler_index())
+    p20 = OraclePartition(4, 6, 20, 8, 1, 6, 1, 6)
+    with pytest.raises(RuntimeError):
+        p20.update_clvs([], avx2=True)
