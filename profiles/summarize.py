@@ -41,7 +41,7 @@ def pmc(sub):
     return agg
 
 
-for sub in ("fetch", "write", "sq1", "sq2"):
+for sub in ("fetch", "write", "sq1", "sq2", "sq3", "mem1"):
     for k, cs in pmc(sub).items():
         for c, vals in cs.items():
             out.setdefault(k, {})[c] = sum(vals) / len(vals)
@@ -52,6 +52,29 @@ for k, d in out.items():
         d["hbm_read_bytes_per_launch"] = fetch
         d["hbm_write_bytes_per_launch"] = write
         d["hbm_bytes_per_launch"] = fetch + write
+# Issue-slot figures of the FP64-bound kernels (bench.py publishes them under
+# roofline.issue).  A fused_dna_eval_kernel wave walks (n-1) operations x R rates
+# = 396 steps on the default command (c2); FP64 counters count wave instructions.
+STEPS_PER_WAVE = {"fused_dna_eval_kernel": 99 * 4}
+for k, d in out.items():
+    if "SQ_INSTS_VALU_FMA_F64" not in d or not d.get("SQ_WAVES"):
+        continue
+    fp64 = d["SQ_INSTS_VALU_FMA_F64"] + d["SQ_INSTS_VALU_MUL_F64"] + d["SQ_INSTS_VALU_ADD_F64"]
+    flops = (2 * d["SQ_INSTS_VALU_FMA_F64"] + d["SQ_INSTS_VALU_MUL_F64"] + d["SQ_INSTS_VALU_ADD_F64"]) * 64
+    der = {"valu_per_wave": round(d["SQ_INSTS_VALU"] / d["SQ_WAVES"], 1),
+           "fp64_valu_share": round(fp64 / d["SQ_INSTS_VALU"], 4)}
+    if d.get("avg_us"):
+        der["executed_fp64_tflops"] = round(flops / (d["avg_us"] * 1e-6) / 1e12, 2)
+        der["executed_fp64_frac_of_78.6"] = round(der["executed_fp64_tflops"] / 78.6, 4)
+    if d.get("GRBM_GUI_ACTIVE"):   # sum over the 8 XCDs; one VALU instruction holds a SIMD 4 cycles
+        cycles = d["GRBM_GUI_ACTIVE"] / 8.0
+        der["valu_issue_slot_util"] = round(d["SQ_INSTS_VALU"] * 4.0 / (1024 * cycles), 4)
+    for name, steps in STEPS_PER_WAVE.items():
+        if k.startswith(name):
+            der["valu_per_step"] = round(d["SQ_INSTS_VALU"] / d["SQ_WAVES"] / steps, 2)
+            der["fp64_valu_per_step"] = round(fp64 / d["SQ_WAVES"] / steps, 2)
+            der["sites_per_lane"] = 2
+    d["derived"] = der
 json.dump(out, open(os.path.join(root, "profiles", tag + "_summary.json"), "w"), indent=1,
           sort_keys=True)
 for k in sorted(out, key=lambda k: -out[k].get("pct", 0)):

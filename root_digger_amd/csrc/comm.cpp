@@ -11,8 +11,11 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <unistd.h>
+
 #include <cstring>
 #include <mutex>
+#include <string>
 
 #include "common.hpp"
 
@@ -31,8 +34,21 @@ rccl_api *rccl() {
   static rccl_api api;
   static std::once_flag once;
   std::call_once(once, [] {
-    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-      api.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+    // RCCL must sit on the SAME HIP/HSA runtime instance this library runs on.  A
+    // process may hold two ROCm installations (e.g. PyTorch's bundled one next to
+    // /opt/rocm): look next to the libamdhip64 that is actually serving us first.
+    std::string beside;
+    Dl_info info;
+    if (dladdr(reinterpret_cast<void *>(&hipGetDevice), &info) && info.dli_fname) {
+      beside = info.dli_fname;
+      const size_t slash = beside.rfind('/');
+      beside = slash == std::string::npos ? std::string() : beside.substr(0, slash + 1);
+    }
+    const std::string candidates[] = {beside + "librccl.so.1", beside + "librccl.so", "librccl.so.1",
+                                      "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const std::string &name : candidates) {
+      if (name.empty() || name[0] == 'l' ? false : access(name.c_str(), R_OK) != 0) continue;
+      api.lib = dlopen(name.c_str(), RTLD_NOW | RTLD_LOCAL);
       if (api.lib) break;
     }
     if (!api.lib) return;
