@@ -1,5 +1,6 @@
-# fused 4-state evaluator: bench lines for configs/variants:  CONFIGS="c2 c4" NSS="1 2" bash profiles/fd_ab.sh
-for c in ${CONFIGS:-c2}; do for ns in ${NSS:-1 2}; do
+# fused 4-state evaluator: bench lines for configs/variants:
+#   CONFIGS="c2 c4" NSS="0 1 2" bash profiles/fd_ab.sh     (NS 0 = the library's own choice)
+for c in ${CONFIGS:-c2}; do for ns in ${NSS:-0}; do
 RDAMD_FUSED_NS=$ns python bench.py --config $c --steps ${STEPS:-5} --warmup 1 --no-cpu-baseline | python -c "
 import json,sys
 d=json.loads(sys.stdin.read()); r=d['roofline']

@@ -61,11 +61,11 @@ static hipError_t ensure_workspace(rdamd_partition *p, unsigned n_jobs) {
   *w = FusedWorkspace();
   const unsigned cap = std::max(16u, n_jobs + n_jobs / 2);
   const unsigned R = p->rate_cats, K = p->states;
-  // 4 states: site blocks padded to a multiple of 8 so that blockIdx.x % 8 (the
+  // 4 states: site blocks padded to a multiple of 16 (8 at two sites per lane) so that blockIdx.x % 8 (the
   // XCD a workgroup lands on) is the same for every job: each XCD's L2 then only
   // ever sees 1/8 of the tip codes.  20 states: one partial per 16-site tile.
   const unsigned per_block = 64;
-  w->blocks_x = K == 4 ? ((p->sites + per_block - 1) / per_block + 7) / 8 * 8 : (p->sites + 15) / 16;
+  w->blocks_x = K == 4 ? ((p->sites + per_block - 1) / per_block + 15) / 16 * 16 : (p->sites + 15) / 16;
   const size_t pm_per_job = (size_t)p->prob_matrices * R * K * K;
 #define A(ptr, bytes) do { e = hipMalloc((void **)&(ptr), (bytes)); if (e != hipSuccess) return e; } while (0)
   A(w->d_jobs, sizeof(FusedJob) * cap);

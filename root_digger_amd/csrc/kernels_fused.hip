@@ -102,18 +102,22 @@ template <int NS>
 __global__ void __launch_bounds__(64)
 fused_dna_eval_kernel(FusedArgs a) {
   extern __shared__ double lds[];
-  // read_row<> and the tip-table writes address LDS bytes 0 and 512 absolutely: that
+  // (read_row<> and the tip-table writes address LDS bytes 0 and 512 absolutely: that
   // is the dynamic block only while this kernel has no static __shared__ in front of
-  // it.  Should one ever appear, fail loudly instead of corrupting the tables.
-  if ((unsigned)(size_t)(__attribute__((address_space(3))) double *)lds != 0u) __builtin_trap();
+  // it -- launch_fused_eval_ns checks the kernel's static LDS size on the host; a
+  // device-side test here cost a factor 2.6, its trap path changes the whole kernel)
   const unsigned lane = threadIdx.x;
-  const unsigned job = blockIdx.y;
+  // Workgroups are dealt round-robin over the 8 XCDs (each with its own L2); grid.x is
+  // a multiple of 8, so an XCD owns a fixed eighth of the sites and sees every job's
+  // tables.  (Measured alternative: every XCD walks whole jobs, so that its L2 holds one
+  // job's tables -- c2 -4 %, c4 +2 %, c5 +1 %: not worth a second mapping.)
+  const unsigned job = blockIdx.y, bx = blockIdx.x;
   const unsigned S = a.sites, R = a.rate_cats;
   unsigned site[NS];
   bool valid[NS];
 #pragma unroll
   for (int q = 0; q < NS; ++q) {
-    site[q] = (blockIdx.x * NS + q) * 64 + lane;
+    site[q] = (bx * NS + q) * 64 + lane;
     valid[q] = site[q] < S;
     if (!valid[q]) site[q] = S - 1;
   }
@@ -295,7 +299,7 @@ fused_dna_eval_kernel(FusedArgs a) {
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) total += __shfl_down(total, off);
-  if (lane == 0) a.partials[(size_t)job * gridDim.x + blockIdx.x] = total;
+  if (lane == 0) a.partials[(size_t)job * gridDim.x + bx] = total;
 }
 
 // fixed-order finish, one workgroup per job
@@ -415,6 +419,12 @@ static hipError_t launch_fused_eval_ns(const FusedArgs &a, unsigned n_jobs, unsi
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
   }
+  static const bool lds_starts_at_zero = [] {   // see the note at the top of the kernel
+    hipFuncAttributes attr;
+    return hipFuncGetAttributes(&attr, (const void *)fused_dna_eval_kernel<NS>) == hipSuccess &&
+           attr.sharedSizeBytes == 0;
+  }();
+  if (!lds_starts_at_zero) return hipErrorInvalidValue;
   const unsigned gx = (blocks_x + NS - 1) / NS;   // blocks_x counts 64-site blocks
   dim3 grid(gx, n_jobs);
   fused_dna_eval_kernel<NS><<<grid, 64, lds, stream>>>(a);
