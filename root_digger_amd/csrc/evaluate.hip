@@ -315,6 +315,7 @@ static int evaluate_batch_impl(rdamd_partition_t *p, unsigned int n_jobs,
     }
     hj[j].prog = s->d_prog; hj[j].brlen = s->d_brlen; hj[j].n_ops = s->n_ops;
     hj[j].depth = 0;   // patched below: every block uses the launch-wide depth
+    hj[j].tt_unsafe = 0; hj[j].pad = 0;   // (set again by the P-matrix step of this batch)
     max_depth = std::max(max_depth, s->depth);
     double wide_s[12] = {0}, wide_f[4] = {0};
     const double *sj = subst + (size_t)j * NP, *fj = freqs + (size_t)j * K;

@@ -98,7 +98,10 @@ __device__ __forceinline__ void combine(const double (&tx)[4], const double (&ty
   }
 }
 
-template <int NS>
+// TTCHECK: rescale test on tip-tip steps too.  Both variants of a launch are queued;
+// each looks at the launch-wide flag the P-matrix step left in jobs[0].pad (some
+// tip-table entry in (0, 2^-128)) and the one it does not belong to returns at once.
+template <int NS, bool TTCHECK>
 __global__ void __launch_bounds__(64)
 fused_dna_eval_kernel(FusedArgs a) {
   extern __shared__ double lds[];
@@ -122,6 +125,12 @@ fused_dna_eval_kernel(FusedArgs a) {
     if (!valid[q]) site[q] = S - 1;
   }
 
+  // a tip-tip step multiplies two tip-table rows: with every non-zero table entry of
+  // the launch >= 2^-128 (checked where the tables are built) the product is 0 or
+  // >= 2^-256 and the rescale test cannot fire on a non-zero vector: it is compiled
+  // out of the variant that runs then (+3.5 % on c2; a run-time branch gave nothing)
+  if ((uni(a.jobs[0].pad) != 0u) != TTCHECK) return;
+  constexpr bool tt_safe = !TTCHECK;
   const FusedJob jb = a.jobs[job];
   const FusedOp *__restrict__ prog = jb.prog;   // n_ops + 2 entries (tail padded)
   const unsigned nops = jb.n_ops;
@@ -212,7 +221,11 @@ fused_dna_eval_kernel(FusedArgs a) {
         }                                                                                       \
       }                                                                                         \
       RDAMD_LOAD_M(nxt, M)                                                                      \
-      _Pragma("unroll") for (int q = 0; q < NS; ++q) { st.sc[q] = 0; combine(tx[q], ty[q], st.v[q], st.sc[q]); } \
+      _Pragma("unroll") for (int q = 0; q < NS; ++q) {                                          \
+        st.sc[q] = 0;                                                                           \
+        if (tt_safe) { _Pragma("unroll") for (int k = 0; k < 4; ++k) st.v[q][k] = tx[q][k] * ty[q][k]; } \
+        else combine(tx[q], ty[q], st.v[q], st.sc[q]);                                          \
+      }                                                                                         \
     } else if (k3 == kFusedRT) {                                                                \
       ((lds_f64_ptr)(size_t)(unsigned)lane8)[64] = ey;                                                  \
       _Pragma("unroll") for (int q = 0; q < NS; ++q) read_row<512>(rowy[q], ty[q]);             \
@@ -321,7 +334,7 @@ fused_finish_kernel(const double *__restrict__ partials, unsigned per_job,
 // Same scaling-and-squaring / 16-term Taylor core as pmatrix_k4_kernel.
 __global__ void __launch_bounds__(64)
 fused_pmatrix_k4_kernel(const double *__restrict__ q, const double *__restrict__ rates,
-                        const FusedJob *__restrict__ jobs, unsigned n_jobs,
+                        FusedJob *__restrict__ jobs, unsigned n_jobs,
                         unsigned n_mat, unsigned R, double *__restrict__ pmat,
                         double *__restrict__ tiptab, size_t pmat_job_stride) {
   const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -397,6 +410,12 @@ fused_pmatrix_k4_kernel(const double *__restrict__ q, const double *__restrict__
         if ((c >> j) & 1) acc += out[i * 4 + j];
       tto[c * 4 + i] = acc;
     }
+  // every table entry is a sum of P entries, so the smallest non-zero P entry bounds
+  // them all from below (FusedJob::tt_unsafe; 2^-128 = 0x1p-128)
+  bool tiny = false;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) tiny = tiny || (out[i] > 0.0 && out[i] < 0x1p-128);
+  if (tiny) jobs[0].pad = 1u;   // launch-wide (every writer stores the same value)
 }
 
 hipError_t launch_fused_pmatrix(const FusedArgs &a, const double *d_q, const double *d_rates,
@@ -404,7 +423,7 @@ hipError_t launch_fused_pmatrix(const FusedArgs &a, const double *d_q, const dou
   const size_t total = (size_t)n_jobs * n_mat * a.rate_cats;
   if (!total) return hipSuccess;
   fused_pmatrix_k4_kernel<<<(unsigned)((total + 63) / 64), 64, 0, stream>>>(
-      d_q, d_rates, a.jobs, n_jobs, n_mat, a.rate_cats, const_cast<double *>(a.pmat),
+      d_q, d_rates, const_cast<FusedJob *>(a.jobs), n_jobs, n_mat, a.rate_cats, const_cast<double *>(a.pmat),
       const_cast<double *>(a.tiptab), a.pmat_job_stride);
   return hipGetLastError();
 }
@@ -415,19 +434,24 @@ static hipError_t launch_fused_eval_ns(const FusedArgs &a, unsigned n_jobs, unsi
   const size_t lds = kTabDoubles * sizeof(double) +
                      (size_t)(max_depth ? max_depth : 1) * NS * 64 * (4 * sizeof(double) + sizeof(int));
   if (lds > 48 * 1024) {   // deep stacks (very unbalanced 10^3-taxon trees): raise the limit
-    hipError_t e = hipFuncSetAttribute((const void *)fused_dna_eval_kernel<NS>,
+    hipError_t e = hipFuncSetAttribute((const void *)fused_dna_eval_kernel<NS, false>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute((const void *)fused_dna_eval_kernel<NS, true>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
   }
   static const bool lds_starts_at_zero = [] {   // see the note at the top of the kernel
-    hipFuncAttributes attr;
-    return hipFuncGetAttributes(&attr, (const void *)fused_dna_eval_kernel<NS>) == hipSuccess &&
-           attr.sharedSizeBytes == 0;
+    hipFuncAttributes attr, attr2;
+    return hipFuncGetAttributes(&attr, (const void *)fused_dna_eval_kernel<NS, false>) == hipSuccess &&
+           hipFuncGetAttributes(&attr2, (const void *)fused_dna_eval_kernel<NS, true>) == hipSuccess &&
+           attr.sharedSizeBytes == 0 && attr2.sharedSizeBytes == 0;
   }();
   if (!lds_starts_at_zero) return hipErrorInvalidValue;
   const unsigned gx = (blocks_x + NS - 1) / NS;   // blocks_x counts 64-site blocks
   dim3 grid(gx, n_jobs);
-  fused_dna_eval_kernel<NS><<<grid, 64, lds, stream>>>(a);
+  fused_dna_eval_kernel<NS, false><<<grid, 64, lds, stream>>>(a);
+  fused_dna_eval_kernel<NS, true><<<grid, 64, lds, stream>>>(a);   // (returns at once on ordinary data)
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   fused_finish_kernel<<<n_jobs, 256, 0, stream>>>(a.partials, gx, d_out);

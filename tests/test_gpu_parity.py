@@ -743,3 +743,30 @@ def test_zero_site_partition():
     assert util.compute_lh(g, tree, rl) == 0.0
     sched = g.schedule(*tree.generate_operations(rl))
     assert g.evaluate_batch([sched], [[1.0] * 12], [[0.25] * 4])[0] == 0.0
+
+
+def test_fused_tip_tip_steps_keep_the_rescale_test_when_tables_are_tiny():
+    """The fused 4-state evaluator skips the 2^256 rescale test on tip-tip steps only
+    while every non-zero tip-table entry of the job is >= 2^-128 (then a product of two
+    rows is 0 or >= 2^-256).  Branches of length 1e-60 make off-diagonal P entries
+    ~1e-61 < 2^-128: the job is flagged and must still agree with the oracle; an
+    ordinary tree goes through the unflagged path."""
+    rng = np.random.default_rng(321)
+    names = ["a", "b", "c", "d", "e", "f"]
+    seqs = {k: "".join(rng.choice(list("ACGT"), 300)) for k in names}
+    for t in (1e-60, 0.03):
+        tree = rd.Tree.from_newick("((a:%g,b:%g):0.1,(c:%g,d:%g):0.2,(e:0.05,f:0.07):0.1);" % (t, t, t, t))
+        g, o = pair(tree, seqs, 4, 4)
+        rates = rd.compute_gamma_cats(0.7, 4)
+        g.set_category_rates(rates)
+        freqs = [0.2, 0.3, 0.25, 0.25]
+        rls = [tree.root_location(i).with_ratio(0.4) for i in range(tree.root_count())]
+        scheds = [g.schedule(*tree.generate_operations(rl)) for rl in rls]
+        got = g.evaluate_batch(scheds, [PARAMS[1]] * len(rls), [freqs] * len(rls))
+        want = [_oracle_eval(o, tree, rl, PARAMS[1], freqs, rates) for rl in rls]
+        assert all(math.isfinite(x) for x in want)
+        for a, b in zip(got, want):
+            assert util.rel_err(a, b) < LNL_TOL
+        del scheds
+        g.destroy()
+        o.destroy()
