@@ -72,8 +72,8 @@ struct Fused20Args {
   const uint64_t *codemask;          // [256] code -> state mask
   const unsigned *pattern_weights;   // [sites]
   const double   *pmat;              // [job][matrix][rate][400]  MFMA-ready (kernels_clv_mfma.hip)
-  const double   *tiptab;            // [job][matrix][rate][64 codes][4 grp][6]: entry [g][s] = sum over
-                                     // the states j of the code of P[4 s + g][j] (s < 5; [5] pads to 48 B)
+  const double   *tiptab;            // [job][matrix][rate][64 codes][24]: a 192-byte row per code, laid out
+                                     // for the evaluator's loads (fused20_pmatrix_kernel)
   const double   *freqs;             // [job][20]
   const double   *rate_weights;      // [job][R]
   double         *partials;          // [job][tiles]

@@ -199,12 +199,17 @@ fused20_pmatrix_kernel(const double *__restrict__ q, const double *__restrict__ 
     const double v = out[(4 * rg + i) * kK + 4 * ks + k];
     o[e] = v < 0.0 ? 0.0 : v;
   }
-  // tip table: entry (code, g, s) = sum over the states j of the code of P[4 s + g][j]
+  // tip table, one 192-byte row per code: positions 0-7 = (s, g) for s = 0, 1 as pairs
+  // [g][s], 8-15 the same for s = 2, 3, 16-19 = s = 4 by g, 20-23 padding; entry (s, g) =
+  // sum over the states j of the code of P[4 s + g][j].  The four lanes of a site then
+  // read 64 + 64 + 32 CONTIGUOUS bytes with three instructions (one cache line per site
+  // and instruction instead of two).
   double *tt = tiptab + (size_t)job * tiptab_job_stride + ((size_t)m * R + r) * kFused20TabDoubles;
   for (unsigned e = tid; e < ncodes * kFused20TabRow; e += 128) {
-    const unsigned cc = e / kFused20TabRow, w = e % kFused20TabRow, g = w / 6, sidx = w % 6;
+    const unsigned cc = e / kFused20TabRow, w = e % kFused20TabRow;
+    const unsigned g = w < 16 ? (w & 7u) >> 1 : w - 16, sidx = w < 16 ? 2 * (w >> 3) + (w & 1u) : 4;
     double acc = 0.0;
-    if (sidx < (unsigned)kSteps) {
+    if (w < 20) {
       const uint64_t mask = codemask[cc];
       const double *row = out + (4 * sidx + g) * kK;
       for (unsigned j = 0; j < (unsigned)kK; ++j) {
@@ -252,7 +257,7 @@ fused20_eval_kernel(Fused20Args a, unsigned depth) {
   const char *tt_job = reinterpret_cast<const char *>(a.tiptab + (size_t)job * a.tiptab_job_stride);
   const unsigned a_off = (grp * 4 + (col & 3)) * 8u;   // my element of every 4x4 block
   const unsigned tt_rate = r * (kFused20TabDoubles * 8u);
-  const unsigned tt_lane = grp * 48u;                  // + code * 192: my five entries of a table row
+  const unsigned tt_lane = grp * 16u;                  // + code * 192: my share of a table row (see the P-matrix kernel)
 
   // What a step needs from memory, by its kind (wave-uniform branches: the CU's one
   // address unit serves every wave of the CU, so no vector-memory instruction is
@@ -310,9 +315,9 @@ fused20_eval_kernel(Fused20Args a, unsigned depth) {
 #pragma unroll
     for (int q = 0; q < NT; ++q) {
       const int o = (int)(my_code(codes.t[q]) * 192u + tt_lane);
-      t[q].a = __builtin_amdgcn_raw_buffer_load_b128(rs, o, 0, 0);
-      t[q].b = __builtin_amdgcn_raw_buffer_load_b128(rs, o + 16, 0, 0);
-      t[q].c = __builtin_amdgcn_raw_buffer_load_b64(rs, o + 32, 0, 0);
+      t[q].a = __builtin_amdgcn_raw_buffer_load_b128(rs, o, 0, 0);          // s = 0, 1
+      t[q].b = __builtin_amdgcn_raw_buffer_load_b128(rs, o + 64, 0, 0);     // s = 2, 3
+      t[q].c = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)(my_code(codes.t[q]) * 192u + 128u + grp * 8u), 0, 0);   // s = 4
     }
   };
   auto has_tip1 = [](const Step &st) { return (st.flags & 3u) == kFusedTT; };
@@ -371,6 +376,22 @@ fused20_eval_kernel(Fused20Args a, unsigned depth) {
     const bool next_product = !has_tip1(nxt) && i + 1 < nops;
     // tip codes of the step after next (scalar loads)
     const TileCodes ncw1 = load_codes(has_tip1(nx2), nx2.cX), ncw2 = load_codes(has_tip2(nx2), nx2.cY);
+    if (kind == kFusedTT) {   // both children are table rows: use them at once ...
+#pragma unroll
+      for (int q = 0; q < NT; ++q) {
+        double x[kSteps], y[kSteps];
+        row_of(t1[q], x);
+        row_of(t2[q], y);
+#pragma unroll
+        for (int s = 0; s < kSteps; ++s) v[q][s] = x[s] * y[s];
+        sc[q] = 0;
+      }
+    }
+    // ... so that, unless this step still needs its own row after its product (RT), the
+    // next step's rows are requested a whole step ahead (the codes arrived a step ago)
+    const bool rows_early = kind != kFusedRT;
+    if (rows_early && has_tip1(nxt)) request_tab(nxt.tabX, cw1, t1);
+    if (rows_early && has_tip2(nxt)) request_tab(nxt.tabY, cw2, t2);
     if (next_product) request_a(nxt);  // the A copy of the next step
     double d1[NT][kGroups];
     if (kind != kFusedTT) product(v, d1);
@@ -412,14 +433,7 @@ fused20_eval_kernel(Fused20Args a, unsigned depth) {
           row_of(t2[q], y);
 #pragma unroll
           for (int s = 0; s < kSteps; ++s) v[q][s] = d1[q][s] * y[s];
-        } else {
-          double x[kSteps], y[kSteps];
-          row_of(t1[q], x);
-          row_of(t2[q], y);
-#pragma unroll
-          for (int s = 0; s < kSteps; ++s) v[q][s] = x[s] * y[s];
-          sc[q] = 0;
-        }
+        }   // (tip-tip: v was formed at the top of the step)
         bool small = true;
 #pragma unroll
         for (int s = 0; s < kSteps; ++s) small = small && (v[q][s] < kScaleThreshold);
@@ -434,10 +448,10 @@ fused20_eval_kernel(Fused20Args a, unsigned depth) {
         }
       }
     }
-    // the next step's table rows (by the codes that arrived a step ago); then its A
-    // copy replaces this one's in LDS
-    if (has_tip1(nxt)) request_tab(nxt.tabX, cw1, t1);
-    if (has_tip2(nxt)) request_tab(nxt.tabY, cw2, t2);
+    // (an RT step: the next step's table rows only now;) then the next step's A copy
+    // replaces this one's in LDS
+    if (!rows_early && has_tip1(nxt)) request_tab(nxt.tabX, cw1, t1);
+    if (!rows_early && has_tip2(nxt)) request_tab(nxt.tabY, cw2, t2);
     if (next_product) stage();
     cur = nxt;
     nxt = nx2;
