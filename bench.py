@@ -75,9 +75,11 @@ def profiled_traffic(kernel, batch, config):
         return None, None
     try:
         d = json.load(open(files[-1]))
-        for k, v in d.items():
-            if k.startswith(kernel) and "hbm_bytes_per_launch" in v:
-                return int(v["hbm_bytes_per_launch"]), os.path.relpath(files[-1], ROOT)
+        # (template variants share the prefix: the one that did the work is the slowest)
+        hits = [v for k, v in d.items() if k.startswith(kernel) and "hbm_bytes_per_launch" in v]
+        if hits:
+            v = max(hits, key=lambda v: v.get("avg_us", 0.0))
+            return int(v["hbm_bytes_per_launch"]), os.path.relpath(files[-1], ROOT)
     except Exception:
         pass
     return None, None
@@ -132,9 +134,10 @@ def profiled_issue(kernel, batch, config):
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_summary.json")))
     try:
         d = json.load(open(files[-1]))
-        for k, v in d.items():
-            if k.startswith(kernel) and "derived" in v:
-                return {"issue": dict(v["derived"], source=os.path.relpath(files[-1], ROOT))}
+        hits = [v for k, v in d.items() if k.startswith(kernel) and "derived" in v]
+        if hits:
+            v = max(hits, key=lambda v: v.get("avg_us", 0.0))
+            return {"issue": dict(v["derived"], source=os.path.relpath(files[-1], ROOT))}
     except Exception:
         pass
     return {}

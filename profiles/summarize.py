@@ -57,7 +57,7 @@ for k, d in out.items():
 # = 396 steps on the default command (c2); FP64 counters count wave instructions.
 STEPS_PER_WAVE = {"fused_dna_eval_kernel": 99 * 4}
 for k, d in out.items():
-    if "SQ_INSTS_VALU_FMA_F64" not in d or not d.get("SQ_WAVES"):
+    if "SQ_INSTS_VALU_FMA_F64" not in d or not d.get("SQ_WAVES") or not d.get("SQ_INSTS_VALU"):
         continue
     fp64 = d["SQ_INSTS_VALU_FMA_F64"] + d["SQ_INSTS_VALU_MUL_F64"] + d["SQ_INSTS_VALU_ADD_F64"]
     flops = (2 * d["SQ_INSTS_VALU_FMA_F64"] + d["SQ_INSTS_VALU_MUL_F64"] + d["SQ_INSTS_VALU_ADD_F64"]) * 64
