@@ -6,7 +6,7 @@ import numpy as np
 import root_digger_amd as rd
 from root_digger_amd import synth
 
-shapes = [(10, 1000, 1), (10, 1000, 4), (100, 1000, 4), (100, 5000, 4), (100, 50000, 1),
+shapes = [tuple(int(x) for x in a.split("x")) for a in sys.argv[1:]] or [(10, 1000, 1), (10, 1000, 4), (100, 1000, 4), (100, 5000, 4), (100, 50000, 1),
           (100, 50000, 2), (100, 50000, 4), (100, 50000, 8), (1000, 5000, 4), (30, 200000, 4)]
 for n, S, R in shapes:
     w = synth.workload(n, S, 4, R, 11)

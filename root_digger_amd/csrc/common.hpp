@@ -67,6 +67,8 @@ struct rdamd_partition {
 
   // ---- HBM-resident state ------------------------------------------------
   uint8_t  *d_tipcodes = nullptr;
+  uint8_t  *d_tipcodes16 = nullptr;   // 4 states: code x 16 = the byte offset of the code's row in the fused
+                                      // evaluator's LDS tip tables (no shift per tip child and step)
   double   *d_clv = nullptr;
   unsigned *d_scaler = nullptr;
   double   *d_pmat = nullptr;

@@ -362,7 +362,7 @@ static int evaluate_batch_impl(rdamd_partition_t *p, unsigned int n_jobs,
     RDAMD_HIP_TRY(e, RDAMD_FAILURE);
   } else {
   FusedArgs a;
-  a.jobs = w->d_jobs; a.tipcodes = p->d_tipcodes; a.pattern_weights = p->d_pattern_weights;
+  a.jobs = w->d_jobs; a.tipcodes = p->d_tipcodes16; a.pattern_weights = p->d_pattern_weights;
   a.pmat = w->d_pmat; a.tiptab = w->d_tiptab; a.freqs = w->d_freqs; a.rate_weights = w->d_rw;
   a.partials = w->d_partials; a.persite = nullptr;
   a.pmat_job_stride = (size_t)p->prob_matrices * R * 16;

@@ -47,7 +47,7 @@ struct FusedJob {
 
 struct FusedArgs {
   const FusedJob *jobs;
-  const uint8_t  *tipcodes;          // [tips][tip_stride]
+  const uint8_t  *tipcodes;          // [tips][tip_stride], code x 16 (rdamd_partition::d_tipcodes16)
   const unsigned *pattern_weights;   // [sites]
   const double   *pmat;              // [job][matrix][rate][16]
   const double   *tiptab;            // [job][matrix][rate][16 codes][4]

@@ -69,16 +69,18 @@ __device__ __forceinline__ void matvec(const double *__restrict__ p, const doubl
     t[k] = p[k * 4 + 0] * x[0] + p[k * 4 + 1] * x[1] + p[k * 4 + 2] * x[2] + p[k * 4 + 3] * x[3];
 }
 
-// A tip-table row, addressed by its LDS byte offset: the table bases are
-// compile-time constants of the access (instruction offsets), so the only
-// vector instruction spent on the address is the shift that made `off`.
+// A tip-table row, addressed by its LDS byte offset.  A table (16 codes x 4 states)
+// sits in LDS as two half tables with 16-byte rows -- states 0-1 at BASE, states 2-3
+// at BASE + 256 -- so that the row offset is code x 16, which is what the tip-code
+// array of the fused evaluator stores: the loaded byte IS the address, the table
+// bases are instruction offsets, and no vector instruction is spent on addressing.
 typedef double f64x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) const f64x2 *lds_row_ptr;
 typedef __attribute__((address_space(3))) double *lds_f64_ptr;
 template <unsigned BASE>
 __device__ __forceinline__ void read_row(unsigned off, double (&t)[4]) {
   const lds_row_ptr row = (lds_row_ptr)(size_t)(off + BASE);
-  const f64x2 lo = row[0], hi = row[1];
+  const f64x2 lo = row[0], hi = row[16];   // + 256 bytes
   t[0] = lo[0]; t[1] = lo[1]; t[2] = hi[0]; t[3] = hi[1];
 }
 
@@ -144,10 +146,12 @@ fused_dna_eval_kernel(FusedArgs a) {
   const __amdgpu_buffer_rsrc_t tab_rs =
       make_rsrc(a.tiptab + (size_t)job * a.pmat_job_stride * 4, (unsigned)(a.pmat_job_stride * 32));
   const int lane8 = (int)lane * 8;
+  // where this lane's table entry (code lane / 4, state lane % 4) goes in LDS: see read_row
+  const unsigned tab_wr = ((lane & 2u) ? 256u : 0u) + (lane >> 2) * 16u + (lane & 1u) * 8u;
   int site_off[NS];
 #pragma unroll
   for (int q = 0; q < NS; ++q) site_off[q] = (int)site[q];
-  // (the X / Y tip tables sit at LDS bytes 0 and 512: read_row / the writes below)
+  // (the X / Y tip tables sit at LDS bytes 0 and 512, two half tables each: read_row)
   double2 *stk = reinterpret_cast<double2 *>(lds + kTabDoubles) + lane;
   int *stk_sc = reinterpret_cast<int *>(lds + kTabDoubles + (size_t)jb.depth * NS * 256) + lane;
 
@@ -193,13 +197,13 @@ fused_dna_eval_kernel(FusedArgs a) {
   {                                                                                             \
     const unsigned kind = uni(cur.flags);                                                       \
     cur = prog[idx2];                                                                           \
-    unsigned rowx[NS], rowy[NS];   /* byte offsets of the rows inside the X / Y table */          \
-    _Pragma("unroll") for (int q = 0; q < NS; ++q) { rowx[q] = cx[q] << 5; rowy[q] = cy[q] << 5; } \
+    unsigned rowx[NS], rowy[NS];   /* byte offsets of the rows inside the X / Y table = the codes */ \
+    _Pragma("unroll") for (int q = 0; q < NS; ++q) { rowx[q] = cx[q]; rowy[q] = cy[q]; }        \
     double tx[NS][4], ty[NS][4];                                                                \
     const unsigned k3 = kind & 3u;                                                              \
     if (k3 == kFusedTT) {                                                                       \
-      ((lds_f64_ptr)(size_t)(unsigned)lane8)[0] = ex;                                                   \
-      ((lds_f64_ptr)(size_t)(unsigned)lane8)[64] = ey;                                                  \
+      ((lds_f64_ptr)(size_t)tab_wr)[0] = ex;                                                    \
+      ((lds_f64_ptr)(size_t)tab_wr)[64] = ey;                                                   \
       _Pragma("unroll") for (int q = 0; q < NS; ++q) { read_row<0>(rowx[q], tx[q]); read_row<512>(rowy[q], ty[q]); } \
       RDAMD_LOAD_TIPS(nxt, ncx, ncy, nex, ney)                                                  \
       if (kind & 0x100u) { /* park M . (running CLV) for the later inner-inner node */          \
@@ -227,7 +231,7 @@ fused_dna_eval_kernel(FusedArgs a) {
         else combine(tx[q], ty[q], st.v[q], st.sc[q]);                                          \
       }                                                                                         \
     } else if (k3 == kFusedRT) {                                                                \
-      ((lds_f64_ptr)(size_t)(unsigned)lane8)[64] = ey;                                                  \
+      ((lds_f64_ptr)(size_t)tab_wr)[64] = ey;                                                   \
       _Pragma("unroll") for (int q = 0; q < NS; ++q) read_row<512>(rowy[q], ty[q]);             \
       RDAMD_LOAD_TIPS(nxt, ncx, ncy, nex, ney)                                                  \
       _Pragma("unroll") for (int q = 0; q < NS; ++q) matvec(M, st.v[q], tx[q]);                 \

@@ -199,6 +199,7 @@ rdamd_partition_t *rdamd_partition_create(unsigned int tips, unsigned int clv_bu
   // + kTipcodePad: the traversal kernel reads tip codes with dword-wide scalar
   // loads that may run a few bytes past the last row
   TRY(hipMalloc(&p->d_tipcodes, (size_t)tips * p->tip_stride() + kTipcodePad));
+  if (K == 4) TRY(hipMalloc(&p->d_tipcodes16, (size_t)tips * p->tip_stride() + kTipcodePad));
   TRY(hipMalloc(&p->d_clv, std::max<size_t>(8, (size_t)clv_buffers * S * R * K * sizeof(double))));
   TRY(hipMalloc(&p->d_scaler, std::max<size_t>(4, (size_t)scale_buffers * S * sizeof(unsigned))));
   TRY(hipMalloc(&p->d_pmat, (size_t)prob_matrices * R * K * K * sizeof(double)));
@@ -221,6 +222,7 @@ rdamd_partition_t *rdamd_partition_create(unsigned int tips, unsigned int clv_bu
   TRY(ensure_scratch(p, (size_t)1 << 20));
   TRY(hipMemsetAsync(p->d_scaler, 0, std::max<size_t>(4, (size_t)scale_buffers * S * sizeof(unsigned)), p->stream));
   TRY(hipMemsetAsync(p->d_tipcodes, 0, (size_t)tips * p->tip_stride() + kTipcodePad, p->stream));
+  if (K == 4) TRY(hipMemsetAsync(p->d_tipcodes16, 0, (size_t)tips * p->tip_stride() + kTipcodePad, p->stream));
 
   // defaults as corax_partition_create leaves them: weights 1, rates 1, 1/R
   p->subst.assign(rate_matrices, std::vector<double>((size_t)K * K - K, 1.0));
@@ -259,7 +261,7 @@ rdamd_partition_t *rdamd_partition_create(unsigned int tips, unsigned int clv_bu
 void rdamd_partition_destroy(rdamd_partition_t *p) {
   if (!p) return;
   if (p->stream) (void)hipStreamSynchronize(p->stream);
-  void *dev[] = {p->d_tipcodes, p->d_clv, p->d_scaler, p->d_pmat, p->d_tiptab, p->d_pmat_mfma,
+  void *dev[] = {p->d_tipcodes, p->d_tipcodes16, p->d_clv, p->d_scaler, p->d_pmat, p->d_tiptab, p->d_pmat_mfma,
                  p->d_codemask, p->d_q, p->d_freqs, p->d_rates, p->d_rate_weights,
                  p->d_pattern_weights, p->d_tipclv_scratch, p->d_scratch,
                  p->d_partials, p->d_result, p->d_persite, p->d_counter};
@@ -316,6 +318,11 @@ int rdamd_set_tip_states(rdamd_partition_t *p, unsigned int tip_index,
     p->tiptab_stale = true;
   }
   RDAMD_HIP_TRY(upload(p, p->d_tipcodes + (size_t)tip_index * p->tip_stride(), row, S), RDAMD_FAILURE);
+  if (p->d_tipcodes16) {   // the same row as LDS row offsets (kernels_fused.hip)
+    std::vector<uint8_t> row16(S);
+    for (size_t s = 0; s < S; ++s) row16[s] = (uint8_t)(row[s] << 4);
+    RDAMD_HIP_TRY(upload(p, p->d_tipcodes16 + (size_t)tip_index * p->tip_stride(), row16.data(), S), RDAMD_FAILURE);
+  }
   return RDAMD_SUCCESS;
 }
 
