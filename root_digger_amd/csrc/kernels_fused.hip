@@ -207,18 +207,18 @@ fused_dna_eval_kernel(FusedArgs a) {
       _Pragma("unroll") for (int q = 0; q < NS; ++q) { read_row<0>(rowx[q], tx[q]); read_row<512>(rowy[q], ty[q]); } \
       RDAMD_LOAD_TIPS(nxt, ncx, ncy, nex, ney)                                                  \
       if (kind & 0x100u) { /* park M . (running CLV) for the later inner-inner node */          \
-        double tp[NS][4];                                                                       \
-        _Pragma("unroll") for (int q = 0; q < NS; ++q) matvec(M, st.v[q], tp[q]);               \
-        if (kind & 0x200u) { /* stack level 0 lives in registers */                             \
+        if (kind & 0x200u) { /* stack level 0 lives in registers: the product lands there */    \
           _Pragma("unroll") for (int q = 0; q < NS; ++q) {                                      \
-            _Pragma("unroll") for (int k = 0; k < 4; ++k) s0[q][k] = tp[q][k];                  \
+            matvec(M, st.v[q], s0[q]);                                                          \
             s0sc[q] = st.sc[q];                                                                 \
           }                                                                                     \
         } else {                                                                                \
           _Pragma("unroll") for (int q = 0; q < NS; ++q) {                                      \
+            double tp[4];                                                                       \
+            matvec(M, st.v[q], tp);                                                             \
             double2 *d = stk + (size_t)(sp * NS + q) * 128;                                     \
-            d[0] = make_double2(tp[q][0], tp[q][1]);                                            \
-            d[64] = make_double2(tp[q][2], tp[q][3]);                                           \
+            d[0] = make_double2(tp[0], tp[1]);                                                  \
+            d[64] = make_double2(tp[2], tp[3]);                                                 \
             stk_sc[(sp * NS + q) * 64] = st.sc[q];                                              \
           }                                                                                     \
           ++sp;                                                                                 \
@@ -238,13 +238,13 @@ fused_dna_eval_kernel(FusedArgs a) {
       RDAMD_LOAD_M(nxt, M)                                                                      \
       _Pragma("unroll") for (int q = 0; q < NS; ++q) combine(tx[q], ty[q], st.v[q], st.sc[q]);  \
     } else { /* kFusedRP: running CLV times M, sibling already multiplied when parked */        \
-      int scy[NS];                                                                              \
-      if (kind & 0x400u) {                                                                      \
-        _Pragma("unroll") for (int q = 0; q < NS; ++q) {                                        \
-          _Pragma("unroll") for (int k = 0; k < 4; ++k) ty[q][k] = s0[q][k];                    \
-          scy[q] = s0sc[q];                                                                     \
-        }                                                                                       \
+      if (kind & 0x400u) { /* the sibling waits in the register slot: used in place */          \
+        RDAMD_LOAD_TIPS(nxt, ncx, ncy, nex, ney)                                                \
+        _Pragma("unroll") for (int q = 0; q < NS; ++q) matvec(M, st.v[q], tx[q]);               \
+        RDAMD_LOAD_M(nxt, M)                                                                    \
+        _Pragma("unroll") for (int q = 0; q < NS; ++q) { st.sc[q] += s0sc[q]; combine(tx[q], s0[q], st.v[q], st.sc[q]); } \
       } else {                                                                                  \
+        int scy[NS];                                                                            \
         --sp;                                                                                   \
         _Pragma("unroll") for (int q = 0; q < NS; ++q) {                                        \
           const double2 *d = stk + (size_t)(sp * NS + q) * 128;                                 \
@@ -252,11 +252,11 @@ fused_dna_eval_kernel(FusedArgs a) {
           ty[q][0] = lo.x; ty[q][1] = lo.y; ty[q][2] = hi.x; ty[q][3] = hi.y;                   \
           scy[q] = stk_sc[(sp * NS + q) * 64];                                                  \
         }                                                                                       \
+        RDAMD_LOAD_TIPS(nxt, ncx, ncy, nex, ney)                                                \
+        _Pragma("unroll") for (int q = 0; q < NS; ++q) matvec(M, st.v[q], tx[q]);               \
+        RDAMD_LOAD_M(nxt, M)                                                                    \
+        _Pragma("unroll") for (int q = 0; q < NS; ++q) { st.sc[q] += scy[q]; combine(tx[q], ty[q], st.v[q], st.sc[q]); } \
       }                                                                                         \
-      RDAMD_LOAD_TIPS(nxt, ncx, ncy, nex, ney)                                                  \
-      _Pragma("unroll") for (int q = 0; q < NS; ++q) matvec(M, st.v[q], tx[q]);                 \
-      RDAMD_LOAD_M(nxt, M)                                                                      \
-      _Pragma("unroll") for (int q = 0; q < NS; ++q) { st.sc[q] += scy[q]; combine(tx[q], ty[q], st.v[q], st.sc[q]); } \
     }                                                                                           \
   }
 
