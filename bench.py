@@ -14,14 +14,19 @@ every P-matrix and every CLV is recomputed inside the timed region.  Inputs
 the timed region.  A short second leg times the materialising per-operation
 CLV kernel (rdamd_update_clvs) for its HBM roofline.
 
-Multi-GPU (one process per GPU, launched by torch.distributed.run): candidate
-roots are sharded across ranks the way the reference shards them across MPI
-ranks (src/model.cpp:1867-1911) -- independent work, no data-path collective,
-weak scaling (per-GPU batch fixed).  `value` is the whole-job rate.
+Multi-GPU (one process per GPU): candidate roots are sharded across ranks the
+way the reference shards them across MPI ranks (src/model.cpp:1867-1911) --
+independent work, no data-path collective, weak scaling (per-GPU batch fixed);
+`--shard sites|grid` splits site blocks instead and all-reduces the per-block
+lnLs (RCCL).  `value` is the whole-job rate.  Without a launcher
+(`python bench.py --gpus N`, WORLD_SIZE unset) this process starts the N ranks
+itself, before anything touches the GPU, and relays rank 0's line.
 
-Rank 0 prints ONE JSON line with `roofline` (dominant kernel, HIP-event timed
-on the partition's own stream) and `cpu_baseline` (the CPU oracle timed on a
-bounded sample of the same workload on this box's host cores).
+Rank 0 prints ONE JSON line with `roofline` -- the dominant kernel's binding
+resource: FP64 flops against the 78.6 TFLOP/s peak for the fused evaluators,
+HIP-event timed on the partition's own stream -- `clv_kernel` (the materialising
+kernel against the HBM peak) and `cpu_baseline` (the CPU oracle's AVX2 loop timed
+on a bounded sample of the same workload on this box's host cores).
 """
 import argparse
 import json
