@@ -20,7 +20,7 @@ for n, S, R in shapes:
     rng = np.random.default_rng(5)
     roots = tree.root_count()
     scheds = [part.schedule(*tree.generate_operations(tree.root_location(i))) for i in range(min(roots, 64))]
-    nb = int(max(16, min(4096, 4e9 / ((n - 1) * S * R * 60))))    # ~ 4 GF of work per launch
+    nb = int(os.environ.get("BATCH", 0)) or int(max(16, min(4096, 4e9 / ((n - 1) * S * R * 60))))    # ~ 4 GF of work per launch
     sub = np.array([synth.random_params(12, rng) for _ in range(nb)])
     fr = np.tile(freqs, (nb, 1))
     sc = [scheds[i % len(scheds)] for i in range(nb)]
