@@ -19,7 +19,8 @@ struct rdamd_schedule {
   rdamd_partition *part = nullptr;
   rdamd::FusedOp *d_prog = nullptr;
   double *d_brlen = nullptr;
-  unsigned n_ops = 0, depth = 0;
+  unsigned n_ops = 0, depth = 0;      // depth: LDS stack levels the program needs
+  unsigned reg_levels = 1;            // register stack levels it was compiled for
   std::vector<rdamd::FusedOp> prog;   // host copy (tests / debugging)
 };
 
@@ -98,6 +99,7 @@ struct Compiler {
   unsigned n_ops, tips, sites, tip_stride, rate_cats;
   unsigned unit = 0;         // bytes between the [rate 0] entries of consecutive matrices
   bool split_park = false;   // 20-state programs: parking is a step of its own
+  unsigned reg_levels = 1;   // stack levels the kernel keeps in registers (4 states: 1 or 2)
   std::unordered_map<unsigned, unsigned> producer;   // clv -> op index
   std::vector<unsigned> need;                        // stack slots a subtree needs
   std::vector<FusedOp> out;
@@ -135,6 +137,7 @@ struct Compiler {
       if (live) {
         matM = park_mat;              // pre-multiply the parked CLV
         if (depth == 0) spill |= 2;   // level 0 is a register slot in the kernel
+        else if (depth == 1 && reg_levels >= 2) spill |= 8;   // ... and level 1 in programs compiled for two
         ++depth;
         max_depth = std::max(max_depth, depth);
         if (split_park) {
@@ -165,6 +168,7 @@ struct Compiler {
       matM = a_first ? o.child2_matrix_index : o.child1_matrix_index;
       --depth;
       if (depth == 0) spill |= 4;     // the popped sibling sits in the register slot
+      else if (depth == 1 && reg_levels >= 2) spill |= 16;
     }
     f.pM = matM * unit;
     f.tX = matX * unit;
@@ -230,6 +234,15 @@ rdamd_schedule_t *rdamd_schedule_create(rdamd_partition_t *p, const rdamd_operat
   c.compute_need(n_ops - 1);
   c.out.reserve(n_ops);
   c.emit(n_ops - 1, false, 0);
+  // 4 states: a program that would need three or more LDS stack levels is compiled for
+  // TWO register levels instead (kernels_fused.hip: the LDS saved buys more resident
+  // waves than the 18 extra registers cost)
+  if (!k20 && c.max_depth >= 4) {
+    c.out.clear();
+    c.depth = c.max_depth = 0;
+    c.reg_levels = 2;
+    c.emit(n_ops - 1, false, 0);
+  }
   size_t n_steps = c.out.size(), n_real = 0;
   for (const FusedOp &f : c.out)
     if (!c.split_park || (f.flags & 3u) != kFusedPark) ++n_real;
@@ -252,7 +265,8 @@ rdamd_schedule_t *rdamd_schedule_create(rdamd_partition_t *p, const rdamd_operat
   // LDS levels = stack depth minus the register level (at least one is allocated)
   // (20 states: parking steps count as steps)
   s->part = p; s->n_ops = (unsigned)n_steps;
-  s->depth = std::max(1u, c.max_depth > 0 ? c.max_depth - 1 : 0);
+  s->depth = std::max(1u, c.max_depth > c.reg_levels ? c.max_depth - c.reg_levels : 0);
+  s->reg_levels = c.reg_levels;
   n_ops = (unsigned)n_steps;
   s->prog = c.out;
   // harmless tail entries: the kernel prefetches descriptors up to i + 3
@@ -306,7 +320,7 @@ static int evaluate_batch_impl(rdamd_partition_t *p, unsigned int n_jobs,
   double *hf = (double *)h;              h += sizeof(double) * K * n_jobs;
   double *hr = (double *)h;              h += sizeof(double) * R * n_jobs;
   double *hw = (double *)h;
-  unsigned max_depth = 1;
+  unsigned max_depth = 1, reg_levels = 1;
   for (unsigned j = 0; j < n_jobs; ++j) {
     const rdamd_schedule_t *s = schedules[j];
     if (!s || s->part != p) {
@@ -317,6 +331,7 @@ static int evaluate_batch_impl(rdamd_partition_t *p, unsigned int n_jobs,
     hj[j].depth = 0;   // patched below: every block uses the launch-wide depth
     hj[j].tt_unsafe = 0; hj[j].pad = 0;   // (set again by the P-matrix step of this batch)
     max_depth = std::max(max_depth, s->depth);
+    reg_levels = std::max(reg_levels, s->reg_levels);
     double wide_s[12] = {0}, wide_f[4] = {0};
     const double *sj = subst + (size_t)j * NP, *fj = freqs + (size_t)j * K;
     if (p->embedded()) {   // caller passes [n][2] / [n][2]: into the 4-state shapes
@@ -378,7 +393,7 @@ static int evaluate_batch_impl(rdamd_partition_t *p, unsigned int n_jobs,
   static const int force_ns = getenv("RDAMD_FUSED_NS") ? atoi(getenv("RDAMD_FUSED_NS")) : 0;
   const unsigned ns = force_ns ? (unsigned)force_ns
                                : ((size_t)n_jobs * w->blocks_x >= 8192 ? 2u : 1u);
-  e = launch_fused_eval(a, n_jobs, max_depth, w->blocks_x, ns, d_out, p->stream);
+  e = launch_fused_eval(a, n_jobs, max_depth, w->blocks_x, ns, reg_levels, d_out, p->stream);
   p->prof_end();
   RDAMD_HIP_TRY(e, RDAMD_FAILURE);
   }

@@ -30,7 +30,8 @@ struct FusedOp {
   uint32_t pM;           // byte offset of [matrix][rate 0] for the running-CLV product
   uint32_t tX, tY;       // byte offsets (x4 = tip-table offsets) of the tip operands' matrices
   uint32_t cX, cY;       // byte offset of the tip rows inside tipcodes
-  uint32_t flags;        // kind | 0x100 park first | 0x200 park in registers | 0x400 pop registers
+  uint32_t flags;        // kind | 0x100 park first | 0x200 park in register level 0 | 0x400 pop it |
+                         // 0x800 park in register level 1 | 0x1000 pop it (4-state programs compiled for two)
   uint32_t pad[2];
 };
 
@@ -92,8 +93,8 @@ hipError_t launch_fused20_eval(const Fused20Args &a, unsigned n_jobs, unsigned m
 hipError_t launch_fused_pmatrix(const FusedArgs &a, const double *d_q, const double *d_rates,
                                 unsigned n_jobs, unsigned n_mat, hipStream_t stream);
 hipError_t launch_fused_eval(const FusedArgs &a, unsigned n_jobs, unsigned max_depth,
-                             unsigned blocks_x, unsigned sites_per_lane, double *d_out,
-                             hipStream_t stream);
+                             unsigned blocks_x, unsigned sites_per_lane, unsigned reg_levels,
+                             double *d_out, hipStream_t stream);
 
 
 }  // namespace rdamd

@@ -103,7 +103,11 @@ __device__ __forceinline__ void combine(const double (&tx)[4], const double (&ty
 // TTCHECK: rescale test on tip-tip steps too.  Both variants of a launch are queued;
 // each looks at the launch-wide flag the P-matrix step left in jobs[0].pad (some
 // tip-table entry in (0, 2^-128)) and the one it does not belong to returns at once.
-template <int NS, bool TTCHECK>
+// RL: stack levels that live in registers (1 or 2).  The second one costs 18 VGPRs per
+// lane at two sites per lane (142: three waves per SIMD) and is taken when it frees
+// enough LDS to more than pay for that (deep stacks of 500- and 1000-taxon trees:
+// three LDS levels allow 10 waves per CU, two LDS levels 15).
+template <int NS, bool TTCHECK, int RL>
 __global__ void __launch_bounds__(64)
 fused_dna_eval_kernel(FusedArgs a) {
   extern __shared__ double lds[];
@@ -212,6 +216,11 @@ fused_dna_eval_kernel(FusedArgs a) {
             matvec(M, st.v[q], s0[q]);                                                          \
             s0sc[q] = st.sc[q];                                                                 \
           }                                                                                     \
+        } else if (RL >= 2 && (kind & 0x800u)) { /* ... and so does level 1 */                  \
+          _Pragma("unroll") for (int q = 0; q < NS; ++q) {                                      \
+            matvec(M, st.v[q], s1[q]);                                                          \
+            s1sc[q] = st.sc[q];                                                                 \
+          }                                                                                     \
         } else {                                                                                \
           _Pragma("unroll") for (int q = 0; q < NS; ++q) {                                      \
             double tp[4];                                                                       \
@@ -243,6 +252,11 @@ fused_dna_eval_kernel(FusedArgs a) {
         _Pragma("unroll") for (int q = 0; q < NS; ++q) matvec(M, st.v[q], tx[q]);               \
         RDAMD_LOAD_M(nxt, M)                                                                    \
         _Pragma("unroll") for (int q = 0; q < NS; ++q) { st.sc[q] += s0sc[q]; combine(tx[q], s0[q], st.v[q], st.sc[q]); } \
+      } else if (RL >= 2 && (kind & 0x1000u)) {                                                 \
+        RDAMD_LOAD_TIPS(nxt, ncx, ncy, nex, ney)                                                \
+        _Pragma("unroll") for (int q = 0; q < NS; ++q) matvec(M, st.v[q], tx[q]);               \
+        RDAMD_LOAD_M(nxt, M)                                                                    \
+        _Pragma("unroll") for (int q = 0; q < NS; ++q) { st.sc[q] += s1sc[q]; combine(tx[q], s1[q], st.v[q], st.sc[q]); } \
       } else {                                                                                  \
         int scy[NS];                                                                            \
         --sp;                                                                                   \
@@ -262,11 +276,19 @@ fused_dna_eval_kernel(FusedArgs a) {
 
     double s0[NS][4];   // stack level 0 (the most frequently used) stays in registers
     int s0sc[NS];
+    double s1[RL >= 2 ? NS : 1][4];   // level 1 too when RL = 2
+    int s1sc[RL >= 2 ? NS : 1];
 #pragma unroll
     for (int q = 0; q < NS; ++q) {
       s0sc[q] = 0;
 #pragma unroll
       for (int k = 0; k < 4; ++k) s0[q][k] = 0.0;
+    }
+#pragma unroll
+    for (int q = 0; q < (RL >= 2 ? NS : 1); ++q) {
+      s1sc[q] = 0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) s1[q][k] = 0.0;
     }
     FusedOp dA = prog[0];
     FusedOp dB = prog[1];
@@ -432,30 +454,30 @@ hipError_t launch_fused_pmatrix(const FusedArgs &a, const double *d_q, const dou
   return hipGetLastError();
 }
 
-template <int NS>
+template <int NS, int RL>
 static hipError_t launch_fused_eval_ns(const FusedArgs &a, unsigned n_jobs, unsigned max_depth,
                                        unsigned blocks_x, double *d_out, hipStream_t stream) {
   const size_t lds = kTabDoubles * sizeof(double) +
                      (size_t)(max_depth ? max_depth : 1) * NS * 64 * (4 * sizeof(double) + sizeof(int));
   if (lds > 48 * 1024) {   // deep stacks (very unbalanced 10^3-taxon trees): raise the limit
-    hipError_t e = hipFuncSetAttribute((const void *)fused_dna_eval_kernel<NS, false>,
+    hipError_t e = hipFuncSetAttribute((const void *)fused_dna_eval_kernel<NS, false, RL>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e == hipSuccess)
-      e = hipFuncSetAttribute((const void *)fused_dna_eval_kernel<NS, true>,
+      e = hipFuncSetAttribute((const void *)fused_dna_eval_kernel<NS, true, RL>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
   }
   static const bool lds_starts_at_zero = [] {   // see the note at the top of the kernel
     hipFuncAttributes attr, attr2;
-    return hipFuncGetAttributes(&attr, (const void *)fused_dna_eval_kernel<NS, false>) == hipSuccess &&
-           hipFuncGetAttributes(&attr2, (const void *)fused_dna_eval_kernel<NS, true>) == hipSuccess &&
+    return hipFuncGetAttributes(&attr, (const void *)fused_dna_eval_kernel<NS, false, RL>) == hipSuccess &&
+           hipFuncGetAttributes(&attr2, (const void *)fused_dna_eval_kernel<NS, true, RL>) == hipSuccess &&
            attr.sharedSizeBytes == 0 && attr2.sharedSizeBytes == 0;
   }();
   if (!lds_starts_at_zero) return hipErrorInvalidValue;
   const unsigned gx = (blocks_x + NS - 1) / NS;   // blocks_x counts 64-site blocks
   dim3 grid(gx, n_jobs);
-  fused_dna_eval_kernel<NS, false><<<grid, 64, lds, stream>>>(a);
-  fused_dna_eval_kernel<NS, true><<<grid, 64, lds, stream>>>(a);   // (returns at once on ordinary data)
+  fused_dna_eval_kernel<NS, false, RL><<<grid, 64, lds, stream>>>(a);
+  fused_dna_eval_kernel<NS, true, RL><<<grid, 64, lds, stream>>>(a);   // (returns at once on ordinary data)
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   fused_finish_kernel<<<n_jobs, 256, 0, stream>>>(a.partials, gx, d_out);
@@ -469,11 +491,14 @@ static hipError_t launch_fused_eval_ns(const FusedArgs &a, unsigned n_jobs, unsi
 // pressure: 31k and 22k).  One site per lane is kept for launches too small to
 // fill the chip with half the waves (evaluate.hip picks).
 hipError_t launch_fused_eval(const FusedArgs &a, unsigned n_jobs, unsigned max_depth,
-                             unsigned blocks_x, unsigned sites_per_lane, double *d_out,
-                             hipStream_t stream) {
+                             unsigned blocks_x, unsigned sites_per_lane, unsigned reg_levels,
+                             double *d_out, hipStream_t stream) {
   if (!n_jobs) return hipSuccess;
-  return sites_per_lane == 2 ? launch_fused_eval_ns<2>(a, n_jobs, max_depth, blocks_x, d_out, stream)
-                             : launch_fused_eval_ns<1>(a, n_jobs, max_depth, blocks_x, d_out, stream);
+  if (reg_levels >= 2)
+    return sites_per_lane == 2 ? launch_fused_eval_ns<2, 2>(a, n_jobs, max_depth, blocks_x, d_out, stream)
+                               : launch_fused_eval_ns<1, 2>(a, n_jobs, max_depth, blocks_x, d_out, stream);
+  return sites_per_lane == 2 ? launch_fused_eval_ns<2, 1>(a, n_jobs, max_depth, blocks_x, d_out, stream)
+                             : launch_fused_eval_ns<1, 1>(a, n_jobs, max_depth, blocks_x, d_out, stream);
 }
 
 }  // namespace rdamd
