@@ -28,7 +28,8 @@ namespace rdamd {
 
 struct FusedWorkspace {
   unsigned cap_jobs = 0, blocks_x = 0;
-  FusedJob *d_jobs = nullptr;
+  char *d_in = nullptr;   // per-batch inputs (see ensure_workspace)
+  FusedJob *d_jobs = nullptr;   // ... and where this batch's pieces sit inside it
   double *d_q = nullptr, *d_rates = nullptr, *d_freqs = nullptr, *d_rw = nullptr;
   double *d_pmat = nullptr, *d_tiptab = nullptr, *d_partials = nullptr, *d_out = nullptr;
   double *h_out = nullptr;   // pinned
@@ -38,8 +39,7 @@ struct FusedWorkspace {
 
 void fused_workspace_free(FusedWorkspace *w) {
   if (!w) return;
-  void *dev[] = {w->d_jobs, w->d_q, w->d_rates, w->d_freqs, w->d_rw, w->d_pmat,
-                 w->d_tiptab, w->d_partials, w->d_out};
+  void *dev[] = {w->d_in, w->d_pmat, w->d_tiptab, w->d_partials, w->d_out};
   for (void *d : dev)
     if (d) (void)hipFree(d);
   if (w->h_out) (void)hipHostFree(w->h_out);
@@ -53,8 +53,7 @@ static hipError_t ensure_workspace(rdamd_partition *p, unsigned n_jobs) {
   if (n_jobs <= w->cap_jobs) return hipSuccess;
   hipError_t e = hipStreamSynchronize(p->stream);
   if (e != hipSuccess) return e;
-  void *dev[] = {w->d_jobs, w->d_q, w->d_rates, w->d_freqs, w->d_rw, w->d_pmat,
-                 w->d_tiptab, w->d_partials, w->d_out};
+  void *dev[] = {w->d_in, w->d_pmat, w->d_tiptab, w->d_partials, w->d_out};
   for (void *d : dev)
     if (d) (void)hipFree(d);
   if (w->h_out) (void)hipHostFree(w->h_out);
@@ -69,11 +68,9 @@ static hipError_t ensure_workspace(rdamd_partition *p, unsigned n_jobs) {
   w->blocks_x = K == 4 ? ((p->sites + per_block - 1) / per_block + 15) / 16 * 16 : (p->sites + 15) / 16;
   const size_t pm_per_job = (size_t)p->prob_matrices * R * K * K;
 #define A(ptr, bytes) do { e = hipMalloc((void **)&(ptr), (bytes)); if (e != hipSuccess) return e; } while (0)
-  A(w->d_jobs, sizeof(FusedJob) * cap);
-  A(w->d_q, sizeof(double) * K * K * cap);
-  A(w->d_rates, sizeof(double) * R * cap);
-  A(w->d_freqs, sizeof(double) * K * cap);
-  A(w->d_rw, sizeof(double) * R * cap);
+  // jobs + Q + frequencies + rates + rate weights of a batch live in ONE device block
+  // with the layout of the pinned staging block: one copy per batch instead of five
+  A(w->d_in, (size_t)cap * (sizeof(FusedJob) + sizeof(double) * (K * K + K + 2 * R)));
   A(w->d_pmat, sizeof(double) * pm_per_job * cap);
   A(w->d_tiptab, sizeof(double) * (K == 4 ? pm_per_job * 4
                                            : (size_t)p->prob_matrices * R * kFused20TabDoubles) * cap);
@@ -350,11 +347,15 @@ static int evaluate_batch_impl(rdamd_partition_t *p, unsigned int n_jobs,
     }
   }
   for (unsigned j = 0; j < n_jobs; ++j) hj[j].depth = max_depth;
-  RDAMD_HIP_TRY(hipMemcpyAsync(w->d_jobs, hj, sizeof(FusedJob) * n_jobs, hipMemcpyHostToDevice, p->stream), RDAMD_FAILURE);
-  RDAMD_HIP_TRY(hipMemcpyAsync(w->d_q, hq, sizeof(double) * K * K * n_jobs, hipMemcpyHostToDevice, p->stream), RDAMD_FAILURE);
-  RDAMD_HIP_TRY(hipMemcpyAsync(w->d_freqs, hf, sizeof(double) * K * n_jobs, hipMemcpyHostToDevice, p->stream), RDAMD_FAILURE);
-  RDAMD_HIP_TRY(hipMemcpyAsync(w->d_rates, hr, sizeof(double) * R * n_jobs, hipMemcpyHostToDevice, p->stream), RDAMD_FAILURE);
-  RDAMD_HIP_TRY(hipMemcpyAsync(w->d_rw, hw, sizeof(double) * R * n_jobs, hipMemcpyHostToDevice, p->stream), RDAMD_FAILURE);
+  {   // the device block mirrors the staging block: one copy
+    const size_t in_bytes = (size_t)n_jobs * (sizeof(FusedJob) + sizeof(double) * (K * K + K + 2 * R));
+    RDAMD_HIP_TRY(hipMemcpyAsync(w->d_in, w->h_in, in_bytes, hipMemcpyHostToDevice, p->stream), RDAMD_FAILURE);
+    w->d_jobs = (FusedJob *)(w->d_in + ((char *)hj - w->h_in));
+    w->d_q = (double *)(w->d_in + ((char *)hq - w->h_in));
+    w->d_freqs = (double *)(w->d_in + ((char *)hf - w->h_in));
+    w->d_rates = (double *)(w->d_in + ((char *)hr - w->h_in));
+    w->d_rw = (double *)(w->d_in + ((char *)hw - w->h_in));
+  }
 
   double *d_out = lnl_device ? (double *)lnl_device : w->d_out;
   hipError_t e;
