@@ -210,11 +210,11 @@ def main():
     # blocks only, or the 2-D grid of BASELINE config c5: `cgroups` groups of
     # `sgroups` ranks; a group shares its candidates and splits the sites, and the
     # all-reduce of the per-block lnLs stays inside the group (adjacent ranks).
-    grid = args.shard == "grid" and K == 4 and world > 1
+    grid = args.shard == "grid" and world > 1
     cgroups, sgroups = (rdist.grid_2d(world, args.site_groups) if grid else
                         (1, world) if args.shard == "sites" else (world, 1))
     cgroup, srank = rdist.rank_coords(rank, sgroups)
-    site_sharded = args.shard in ("sites", "grid") and K == 4
+    site_sharded = args.shard in ("sites", "grid")   # (both fused evaluators leave device-side lnLs)
     site_group = None
     if grid:
         for c in range(cgroups):      # every rank creates every group, in the same order
@@ -405,7 +405,7 @@ def main():
         "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4),
         "higher_is_better": True,
-        "scaling": "strong" if args.shard == "sites" and K == 4 else "weak",
+        "scaling": "strong" if args.shard == "sites" else "weak",
         "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": "%s: %d-taxon %d-site %d-state UNREST+G%d full-traversal "

@@ -82,3 +82,13 @@ def test_bench_launches_its_own_ranks():
     one = run_bench("--no-cpu-baseline", "--shard", "sites")
     assert s["n_gpus"] == 2
     assert abs(s["lnl_check"] - one["lnl_check"]) <= 1e-9 * abs(one["lnl_check"])
+
+
+def test_site_sharded_bench_on_the_20_state_evaluator():
+    """--shard sites is not a 4-state privilege: two ranks (one device, gloo) split c3's
+    sites and reproduce the one-rank checksum through fused20_eval_kernel."""
+    a = run_bench("--no-cpu-baseline", "--gpus", "2", "--dist-backend", "gloo", "--device", "0",
+                  "--shard", "sites", config="c3", steps="1", batch="4")
+    b = run_bench("--no-cpu-baseline", "--shard", "sites", config="c3", steps="1", batch="4")
+    assert a["n_gpus"] == 2 and a["scaling"] == "strong" and a["roofline"]["kernel"] == "fused20_eval_kernel"
+    assert abs(a["lnl_check"] - b["lnl_check"]) <= 1e-9 * abs(b["lnl_check"])
