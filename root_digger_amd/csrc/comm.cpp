@@ -44,10 +44,14 @@ rccl_api *rccl() {
       const size_t slash = beside.rfind('/');
       beside = slash == std::string::npos ? std::string() : beside.substr(0, slash + 1);
     }
-    const std::string candidates[] = {beside + "librccl.so.1", beside + "librccl.so", "librccl.so.1",
-                                      "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    // absolute candidates (beside the runtime, /opt/rocm) are tried only where the file
+    // exists; the bare sonames go through the loader's search path
+    const std::string candidates[] = {beside.empty() ? std::string() : beside + "librccl.so.1",
+                                      beside.empty() ? std::string() : beside + "librccl.so",
+                                      "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     for (const std::string &name : candidates) {
-      if (name.empty() || name[0] == 'l' ? false : access(name.c_str(), R_OK) != 0) continue;
+      if (name.empty()) continue;
+      if (name[0] == '/' && access(name.c_str(), R_OK) != 0) continue;
       api.lib = dlopen(name.c_str(), RTLD_NOW | RTLD_LOCAL);
       if (api.lib) break;
     }
