@@ -195,7 +195,11 @@ def main():
     torch.cuda.set_device(device)
     rd.set_device(device)           # (before the rendezvous: see root_digger_amd/cli.py)
     host_collectives = args.dist_backend == "gloo"
-    if world > 1:
+    # RDAMD_BENCH_PG=1: form the process group even for one rank, so that the RCCL calls
+    # of the N > 1 path (init, barrier, all-reduce on device tensors) can be exercised on
+    # a one-GPU box (tests/test_gpu_bench.py)
+    use_pg = world > 1 or os.environ.get("RDAMD_BENCH_PG") == "1"
+    if use_pg:
         import torch.distributed as tdist
         if host_collectives:
             tdist.init_process_group("gloo")
@@ -290,9 +294,9 @@ def main():
             lnl_dev = lnl_rows[row] if 0 <= row < args.steps else lnl_warm
             part.evaluate_batch_device([scheds[i] for i in idx], sub, freqs_b[idx],
                                        lnl_dev.data_ptr())
-            if sgroups > 1 and not host_collectives:
+            if use_pg and not host_collectives:
                 rdist.allreduce_lnl(lnl_dev, site_group)     # RCCL sum of the per-block lnLs
-            elif sgroups > 1:                    # gloo test path: through the host
+            elif use_pg:                         # gloo test path: through the host
                 host = lnl_dev.cpu()
                 rdist.allreduce_lnl(host, site_group)
                 lnl_dev.copy_(host)
@@ -300,7 +304,7 @@ def main():
         return float(part.evaluate_batch([scheds[i] for i in idx], sub, freqs_b[idx]).sum())
 
     def barrier():
-        if world > 1:
+        if use_pg:
             tdist.barrier()
         torch.cuda.synchronize()
         part.sync()
@@ -329,7 +333,7 @@ def main():
     if not np.isfinite(check):
         raise SystemExit("non-finite lnL in the timed region")
 
-    if world > 1:
+    if use_pg:
         t = torch.tensor([elapsed], dtype=torch.float64,
                          device="cpu" if host_collectives else "cuda")
         tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
@@ -434,7 +438,7 @@ def main():
                                               gpu_eval)
     if rank == 0:
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if use_pg:
         tdist.destroy_process_group()
 
 

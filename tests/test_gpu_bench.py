@@ -12,10 +12,10 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def run_bench(*extra, config="c1", steps="3", batch="17"):
+def run_bench(*extra, config="c1", steps="3", batch="17", env=None):
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", config,
                           "--steps", steps, "--warmup", "1", "--batch", batch] + list(extra),
-                         capture_output=True, text=True, timeout=600)
+                         capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
@@ -92,3 +92,21 @@ def test_site_sharded_bench_on_the_20_state_evaluator():
     b = run_bench("--no-cpu-baseline", "--shard", "sites", config="c3", steps="1", batch="4")
     assert a["n_gpus"] == 2 and a["scaling"] == "strong" and a["roofline"]["kernel"] == "fused20_eval_kernel"
     assert abs(a["lnl_check"] - b["lnl_check"]) <= 1e-9 * abs(b["lnl_check"])
+
+
+def test_rccl_calls_of_the_multi_gpu_path_with_one_rank():
+    """The N > 1 bench path on RCCL itself -- process group on `nccl` with a device id,
+    barrier, all-reduce of the per-block lnLs on a device tensor, MAX of the times -- as a
+    ONE-rank group (this box has one GPU; RCCL refuses two ranks on a device): the
+    all-reduced checksum must equal the plain run's."""
+    s = __import__("socket").socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, RDAMD_BENCH_PG="1", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0",
+               MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    a = run_bench("--no-cpu-baseline", "--shard", "sites", env=env)
+    b = run_bench("--no-cpu-baseline", "--shard", "sites")
+    assert a["n_gpus"] == 1 and a["lnl_check"] == b["lnl_check"]
+    c = run_bench("--no-cpu-baseline", env=env)          # candidate sharding: barrier + MAX only
+    assert c["value"] > 0
