@@ -199,7 +199,13 @@ def main():
     # of the N > 1 path (init, barrier, all-reduce on device tensors) can be exercised on
     # a one-GPU box (tests/test_gpu_bench.py)
     use_pg = world > 1 or os.environ.get("RDAMD_BENCH_PG") == "1"
+    real_stdout = None
     if use_pg:
+        # RCCL prints a version banner on the process's stdout when a communicator comes
+        # up: keep file descriptor 1 for the ONE JSON line, send everything else to stderr
+        sys.stdout.flush()
+        real_stdout = os.dup(1)
+        os.dup2(2, 1)
         import torch.distributed as tdist
         if host_collectives:
             tdist.init_process_group("gloo")
@@ -437,7 +443,12 @@ def main():
                                               params, roots, args.cpu_seconds,
                                               gpu_eval)
     if rank == 0:
-        print(json.dumps(result), flush=True)
+        line = json.dumps(result) + "\n"
+        if real_stdout is not None:
+            os.write(real_stdout, line.encode())
+        else:
+            sys.stdout.write(line)
+            sys.stdout.flush()
     if use_pg:
         tdist.destroy_process_group()
 
