@@ -43,14 +43,36 @@ struct DeviceView {
   unsigned tips, states, sites, rate_cats, ncodes_cap;
   const uint8_t *tipcodes;  // [tips][tip_stride] code index per tip character
   unsigned tip_stride;      // sites rounded up to a multiple of 4 (dword-aligned rows)
-  double        *clv;       // [clv_buffers][sites][rate_cats][states]
+  double        *clv;       // [clv_buffers][sites][rate_cats][states]; 20-state matrix-core partitions:
+                            // [clv_buffers][rate_cats][tiles][2560 B] (rdamd_partition::mfma_layout)
   unsigned      *scaler;    // [scale_buffers][sites]
   double        *pmat;      // [prob_matrices][rate_cats][states][states]
   double        *tiptab;    // [prob_matrices][rate_cats][ncodes_cap][states]
   const uint64_t *codemask; // [256]
-  size_t clv_stride;        // sites*rate_cats*states
+  size_t clv_stride;        // doubles per CLV buffer (rdamd_partition::clv_doubles)
 };
 
+
+// ---- 20-state matrix-core layouts (kernels_clv_mfma.hip, kernels_fused_k20.hip) ----------
+// Which state lane group g (= lane / 16) holds as its t-th operand (t = 0..4): the MFMA only
+// needs the 20 states dealt out as 5 sets of 4, one member per lane group; this dealing
+// gives group g the contiguous states 5g .. 5g+4, odd groups rotated by one.
+__host__ __device__ constexpr unsigned k20_state_of(unsigned g, unsigned t) {
+  return 5u * g + (t + (g & 1u)) % 5u;
+}
+// A CLV tile (16 sites of one rate, 320 doubles) as the wave holds it: piece 0 = operands
+// t = 0, 1 of every lane (64 x 16 B), piece 1 = t = 2, 3, piece 2 = t = 4 (64 x 8 B);
+// lane = 16 g + site % 16.  Index (in doubles) of (site in tile, state):
+__host__ __device__ constexpr unsigned k20_tile_index(unsigned site_in_tile, unsigned state) {
+  const unsigned g = state / 5u, t = (state % 5u + 5u - (g & 1u)) % 5u, lane = 16u * g + site_in_tile;
+  return t < 4u ? (t >> 1) * 128u + lane * 2u + (t & 1u) : 256u + lane;
+}
+// A tip-table row in the same spirit: positions 0-7 = operands t = 0, 1 of lane groups
+// 0..3, 8-15 = t = 2, 3, 16-19 = t = 4 -- the four lanes of a site read 64 + 64 + 32
+// contiguous bytes.  State at row position w:
+__host__ __device__ constexpr unsigned k20_row_state(unsigned w) {
+  return w < 16u ? k20_state_of((w & 7u) >> 1, 2u * (w >> 3) + (w & 1u)) : k20_state_of(w - 16u, 4u);
+}
 }  // namespace rdamd
 
 struct rdamd_partition {
@@ -70,6 +92,18 @@ struct rdamd_partition {
   uint8_t  *d_tipcodes16 = nullptr;   // 4 states: code x 16 = the byte offset of the code's row in the fused
                                       // evaluator's LDS tip tables (no shift per tip child and step)
   double   *d_clv = nullptr;
+  // CLV layout on the device.  The C ABI's layout ([site][rate][state], coraxlib's) is what
+  // rdamd_get_clv hands out.  Partitions that run on clv_k20_traversal_kernel keep a CLV in
+  // the matrix-core OPERAND layout instead (rdamd::k20_tile_index): [rate][tile of 16
+  // sites][2 560 B], a tile holding what each of the wave's 64 lanes keeps of it in
+  // registers -- loads and stores are 1 KB-contiguous instructions with no transposition.
+  // Fixed at creation; the readers of d_clv are that kernel, the root reductions
+  // (kernels_root.hip) and rdamd_get_clv.
+  bool mfma_layout = false;
+  unsigned clv_tiles() const { return (sites + 15u) / 16u; }
+  size_t clv_doubles() const {   // one CLV buffer
+    return mfma_layout ? (size_t)rate_cats * clv_tiles() * 16u * states : (size_t)sites * rate_cats * states;
+  }
   unsigned *d_scaler = nullptr;
   double   *d_pmat = nullptr;
   double   *d_tiptab = nullptr;
@@ -120,7 +154,7 @@ struct rdamd_partition {
     v.ncodes_cap = ncodes_cap;
     v.tipcodes = d_tipcodes; v.tip_stride = tip_stride(); v.clv = d_clv; v.scaler = d_scaler; v.pmat = d_pmat;
     v.tiptab = d_tiptab; v.codemask = d_codemask;
-    v.clv_stride = (size_t)sites * rate_cats * states;
+    v.clv_stride = clv_doubles();
     return v;
   }
 };
@@ -151,6 +185,11 @@ struct LevelOp {   // device-side op descriptor
   uint64_t parent_off, parent_sc_off;
   uint64_t child1_off, child1_sc_off;
   uint64_t child2_off, child2_sc_off;
+  // 20-state kernel only: the tip indices of the NEXT operation's children (0 where a child
+  // is no tip, or there is no next operation).  The kernel fetches tip codes through the
+  // scalar cache two operations ahead; taking the address from the operation in front
+  // means no scalar load has to wait for another one.
+  unsigned ahead1, ahead2;
 };
 constexpr uint64_t kNoOffset = ~0ull;
 // LDS parking slots per lane the 4-state traversal kernel will have for this
@@ -165,7 +204,6 @@ hipError_t launch_clv_traversal(rdamd_partition *p, const LevelOp *d_ops, unsign
 // kernels_clv_mfma.hip (20 states)
 hipError_t launch_pmat_to_mfma(rdamd_partition *p, const unsigned *d_matrix_indices, unsigned count);
 hipError_t launch_clv_k20_traversal(rdamd_partition *p, const LevelOp *d_ops, unsigned nops);
-bool k20_mfma_ok(const rdamd_partition *p);   // can the 20-state MFMA kernel take this partition?
 size_t k20_mfma_copy_doubles();               // doubles per (matrix, rate) in d_pmat_mfma
 
 // kernels_root.hip

@@ -24,31 +24,35 @@
 // One wave = (16 sites, one rate); the waves of a workgroup are the R rates of
 // the same 16 sites, so the per-site "all entries < 2^-256" rule is one ballot
 // folded on the scalar unit plus one LDS exchange (one barrier per operation).
-// A operands come from an MFMA-ready permutation of the P-matrices that the
-// P-matrix step writes ([matrix][rate][rg][ks][k][i]: the 16 values of one MFMA
-// are one cache line).  A tip child costs no MFMA at all: P . (0/1 vector) is a
-// row of the partition's tip table (tiptab[matrix][rate][code][state], written by
-// the P-matrix step), and a lane's five entries {4 s + grp} of that row arrive
-// through the same five 8-byte loads an older sibling's CLV would use -- only the
-// descriptor and the per-lane offset differ.  Its A copy is not fetched (empty
-// descriptor), staged or multiplied (wave-uniform branch around LDS + MFMA work
-// only, so the vector-memory instruction stream stays fixed).  Tip codes are
-// requested two operations ahead so that the table row can be requested one ahead.
+//
+// Data layouts (all private to this library; rdamd_get_clv hands out the ABI's
+// [site][rate][state]):
+//   * a CLV is kept in the OPERAND layout, [rate][tile of 16 sites][2 560 B]
+//     (common.hpp, k20_tile_index): a tile holds, lane by lane, exactly what the
+//     wave keeps of it in registers -- 16 + 16 + 8 bytes per lane in three pieces.
+//     Every CLV load and store instruction covers contiguous memory (1 KB, 1 KB,
+//     512 B) and needs no transposition; D layout = B layout, so a child produced
+//     by one of the two operations before is consumed straight from registers;
+//   * A operands come from an MFMA-ready permutation of the P-matrices that the
+//     P-matrix step writes ([matrix][rate][rg][ks][k][i]), fetched as four contiguous
+//     16-byte pieces per lane (3.2 KB per child instead of 25 scattered loads),
+//     parked in registers for one iteration and redistributed through a
+//     wave-private LDS area (no barrier) right before the MFMAs that use them;
+//   * a tip child costs no MFMA and no A copy: P . (0/1 vector) is a row of the
+//     partition's tip table (tiptab[matrix][rate][code][...], rows in operand order,
+//     k20_row_state: the four lanes of a site read 64 + 64 + 32 contiguous bytes).
 //
 // Memory pipeline.  With ~2.4 waves per SIMD on the c3 shape nothing hides a
-// memory round trip, so everything operation i+1 needs (A operands, tip codes,
-// older-sibling CLVs, scalers) is requested at the START of operation i, a
-// whole operation ahead.  The A operands (3.2 KB per child) are fetched as
-// contiguous 16-byte pieces (4 loads per child instead of 25), parked in
-// registers for one iteration and redistributed through a wave-private LDS
-// area (no barrier) right before the MFMAs that use them.  Vector memory
-// operations retire in issue order, so every one of them is issued
-// unconditionally through buffer descriptors -- a load that is not needed, or
-// a store of a lane past the last site, gets a zero-size descriptor or an
-// out-of-range offset and is dropped by the hardware.  The instruction stream
-// per operation is therefore fixed, the compiler's `s_waitcnt vmcnt(N)` are
-// exact (never below the six stores an iteration ends with), and no wave waits
-// for its own CLV stores.
+// memory round trip, so everything operation i+1 needs (A operands, table rows,
+// older-sibling CLVs, scalers) is requested at the START of operation i, and
+// the result of operation i-1 is stored behind those loads.  Only what a child
+// needs is requested (wave-uniform branches by its source: the CU's one address
+// unit serves every wave, an instruction dropped through an empty descriptor
+// still costs it a slot); the four stores of an iteration are always issued
+// (out-of-range offsets where there is nothing to keep).  Tip codes and operation
+// heads come through the scalar cache two operations ahead, the tip-code
+// address from the head in front (LevelOp::ahead*), so that no scalar load waits
+// for another one.
 // Like the 4-state kernel, a whole operation list is one launch: every
 // dependency is site-local and each wave owns its sites for the whole list
 // (the host cuts the list where an operation reads, from memory, what the
@@ -88,11 +92,16 @@ struct OpHead {
   unsigned parent_clv, child1_clv, child2_clv, child1_mat, child2_mat;
   int parent_sc, child1_sc, child2_sc;
   unsigned src1, src2;
+  unsigned ahead1, ahead2;   // tip indices of the next operation's children
 };
-static_assert(sizeof(LevelOp) % 4 == 0 && offsetof(LevelOp, src2) == 36, "OpHead mirrors LevelOp");
+constexpr unsigned kAheadWord = 24;
+static_assert(sizeof(LevelOp) % 4 == 0 && offsetof(LevelOp, src2) == 36 &&
+              offsetof(LevelOp, ahead1) == 4 * kAheadWord && offsetof(LevelOp, ahead2) == 4 * kAheadWord + 4,
+              "OpHead mirrors LevelOp");
 __device__ __forceinline__ OpHead load_op(const_u32_ptr ops, unsigned i) {
   const const_u32_ptr w = ops + (size_t)i * (sizeof(LevelOp) / 4);
-  return OpHead{w[0], w[1], w[2], w[3], w[4], (int)w[5], (int)w[6], (int)w[7], w[8], w[9]};
+  return OpHead{w[0], w[1], w[2], w[3], w[4], (int)w[5], (int)w[6], (int)w[7], w[8], w[9],
+                w[kAheadWord], w[kAheadWord + 1]};
 }
 
 // what one child of the next operation brings from memory
@@ -103,18 +112,10 @@ struct ChildLoad {
   unsigned sc;                // scaler of an older sibling
 };
 constexpr int kMfmaLdsChild = 4 * 64 * 16;   // bytes of LDS one child's A copy occupies per wave
-constexpr int kMfmaLdsWave = 2 * kMfmaLdsChild + 4096;   // + the store transposition tile (2560 B, read as 3 x 1 KB)
+constexpr int kMfmaLdsWave = 2 * kMfmaLdsChild;
 
-// Which state a lane group holds in row group / k-step t.  The MFMA only needs
-// the 20 states dealt out as 5 sets of 4 (one member per lane group), the same
-// dealing for rows (D), for the k dimension (B) and in the A copies; this one
-// gives lane group g the CONTIGUOUS states 5g .. 5g+4, so a lane's share of a
-// CLV record or tip-table row is 40 contiguous bytes (three memory
-// instructions instead of five 8-byte ones).  Odd groups start one state
-// later (rotation), which puts both 16-byte pieces on 16-byte boundaries.
-__host__ __device__ constexpr unsigned state_of(unsigned g, unsigned t) {
-  return 5u * g + (t + (g & 1u)) % 5u;
-}
+// (which state a lane group holds as operand t: k20_state_of, common.hpp)
+__host__ __device__ constexpr unsigned state_of(unsigned g, unsigned t) { return k20_state_of(g, t); }
 
 }  // namespace
 
@@ -150,13 +151,20 @@ clv_k20_traversal_kernel(DeviceView v, const double *__restrict__ pmfma,
   const bool sc_lane = r == 0 && grp == 0;       // the lanes that own the per-site scalers
   const unsigned clv_bytes = uni((unsigned)(v.clv_stride * sizeof(double)));
   const unsigned sc_bytes = S * 4u;
-  // Loop-invariant per-lane offsets.  A lane's five states are 40 contiguous bytes of
-  // its (site, rate) record (or of a tip-table row), moved as 16 + 16 + 8 bytes with
-  // both 16-byte pieces aligned: even groups [x0 x1][x2 x3][x4], odd groups x4 first
-  // (state_of: their rotation starts one state later).
-  const unsigned in_row = 40u * grp;
-  const unsigned o1 = in_row + 8u * (grp & 1u), o3 = in_row + 32u * (1u - (grp & 1u));
-  const unsigned ld_clv = (ls * R + r) * (kMfmaK * 8u);
+  // Loop-invariant per-lane offsets.  A CLV of these partitions is kept in the operand
+  // layout (common.hpp, k20_tile_index): [rate][tile][piece 0: 64 lanes x 16 B][piece 1:
+  // 64 x 16 B][piece 2: 64 x 8 B] -- a lane's five operands are its 16 + 16 + 8 bytes of
+  // the tile's three pieces, every load and store instruction covers contiguous memory.
+  // (A tip-table row has the same operands as [group][t = 0, 1] [group][t = 2, 3]
+  // [group][t = 4]: k20_row_state.)
+  const unsigned tiles = (S + 15u) / 16u;
+  const unsigned tile_off = (uni(r * tiles) + blockIdx.x) * (16u * kMfmaK * 8u);
+  const unsigned ll = grp * 16u + (ls & 15u);               // the lane whose data this lane loads (itself unless past S)
+  const unsigned ld_clv = tile_off + ll * 16u;              // piece 0; piece 1 at + 1024, piece 2 at tile_off + 2048 + ll * 8
+  const unsigned ld_clv4 = tile_off + 2048u + ll * 8u;
+  const unsigned st_clv = site < S ? tile_off + lane * 16u : kOob;
+  const unsigned st_clv4 = site < S ? tile_off + 2048u + lane * 8u : kOob;
+  const unsigned tab_g = grp * 16u;                         // a tip-table row: + code * 160
   const unsigned ld_sc = sc_lane ? ls * 4u : kOob;
   const unsigned st_sc = (sc_lane && site < S) ? site * 4u : kOob;
   const unsigned a_off = (grp * 4 + (col & 3)) * 8u;                          // my element of every 4x4 block
@@ -177,13 +185,21 @@ clv_k20_traversal_kernel(DeviceView v, const double *__restrict__ pmfma,
   const bool upper_half = (col & 8u) != 0u;
   const unsigned code_shift = (col & 7u) * 8u;
   struct Codes { unsigned w0, w1, w2, w3; };   // (named members: an array here ends up in scratch memory)
-  auto load_codes = [&](unsigned src, unsigned clv) -> Codes {
+  auto load_codes = [&](unsigned src, unsigned clv) -> Codes {   // (prologue only)
     Codes c{0u, 0u, 0u, 0u};
     if (src == 0u) {
       const const_u32_ptr row = (const_u32_ptr)(codes_lo + (unsigned long long)clv * v.tip_stride);
       c.w0 = row[0]; c.w1 = row[1]; c.w2 = row[2]; c.w3 = row[3];
     }
     return c;
+  };
+  // In the loop the 16 bytes are fetched unconditionally (row 0 for a child that is no
+  // tip) from an address the PREVIOUS operation's head supplies (LevelOp::ahead*): no
+  // branch, no scalar load waiting for another one -- nothing touches the result until
+  // the table loads of the next iteration need it.
+  auto load_codes_ahead = [&](unsigned tip) -> Codes {
+    const const_u32_ptr row = (const_u32_ptr)(codes_lo + (unsigned long long)tip * v.tip_stride);
+    return Codes{row[0], row[1], row[2], row[3]};
   };
   auto my_code = [&](const Codes &c) -> unsigned {
     // byte `col` of the 16: pick the 8-byte half, shift (a chain of selects over the
@@ -197,42 +213,35 @@ clv_k20_traversal_kernel(DeviceView v, const double *__restrict__ pmfma,
   // written as loaded (contiguous), read back as [block][my role].
   extern __shared__ char a_lds_all[];
   char *a_lds = a_lds_all + (threadIdx.x >> 6) * kMfmaLdsWave;
-  // ... and 2560 bytes in which a result tile (16 sites x 160 B) is turned from the
-  // lane layout into address order: the CLV stores then write 16 bytes per lane with
-  // consecutive lanes on consecutive addresses (160-byte runs, one per site),
-  // which costs the memory system a third less than 16-byte pieces 40 bytes apart
-  char *t_lds = a_lds + 2 * kMfmaLdsChild;
-  unsigned st_lin[3];      // where piece p = lane + 64 k of the tile goes (10 pieces per site)
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    const unsigned pp = lane + 64u * k, psite = blockIdx.x * 16u + pp / 10u;
-    st_lin[k] = (pp < 160u && psite < S) ? (psite * R + r) * (kMfmaK * 8u) + (pp % 10u) * 16u : kOob;
-  }
-
   // What a child of the next operation needs from memory, by where it comes from
   // (wave-uniform branches; the kernel is bound by the number of vector-memory
   // instructions the CU's address unit has to process, so none is issued in vain):
   //   tip      three pieces of its tip-table row: the child's finished term
   //   memory   three pieces of its CLV, its scaler, the A copy of its matrix
   //   register (result of one of the two operations before) only the A copy
-  auto load_five = [&](const __amdgpu_buffer_rsrc_t rs, unsigned base, ChildLoad &c) {
+  auto load_pieces = [&](const __amdgpu_buffer_rsrc_t rs, unsigned o01, unsigned o23, unsigned o4, ChildLoad &c) {
     if (VAR & 16) return;   // VAR bit 4 (timing only): no CLV / tip-table loads
-    const u32x4 p = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(base + o1), 0, 0);
-    const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(base + o1 + 16u), 0, 0);
-    const u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)(base + o3), 0, 0);
+    const u32x4 p = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)o01, 0, 0);
+    const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)o23, 0, 0);
+    const u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)o4, 0, 0);
     c.b[0] = as_f64(u32x2{p[0], p[1]}); c.b[1] = as_f64(u32x2{p[2], p[3]});
     c.b[2] = as_f64(u32x2{q[0], q[1]}); c.b[3] = as_f64(u32x2{q[2], q[3]});
     c.b[4] = as_f64(t);
   };
+  // (Measured alternative: the same eight load instructions for every child, descriptor and
+  // offsets chosen by its source, what is not needed dropped through a zero-size
+  // descriptor -- every wait becomes an exact count, 20 instead of 11.6 vector-memory
+  // instructions per operation: 4 - 7 % slower.)
   auto load_child = [&](unsigned src, unsigned clv, unsigned mat, int scb, const Codes &codes, ChildLoad &c) {
     if (src == 0u) {
       const __amdgpu_buffer_rsrc_t rs = make_rsrc(tab_base + (size_t)(mat * R + r) * tab_slot, tab_slot);
-      load_five(rs, my_code(codes) * tab_row, c);
+      const unsigned row = my_code(codes) * tab_row;
+      load_pieces(rs, row + tab_g, row + 64u + tab_g, row + 128u + grp * 8u, c);
       return;
     }
     if (src == 1u) {
       const __amdgpu_buffer_rsrc_t rs = make_rsrc(clv_base + (size_t)(clv - v.tips) * clv_bytes, clv_bytes);
-      load_five(rs, ld_clv, c);
+      load_pieces(rs, ld_clv, ld_clv + 1024u, ld_clv4, c);
       c.sc = 0u;
       if (scb >= 0) {
         const __amdgpu_buffer_rsrc_t sc_rs = make_rsrc(sc_base + (size_t)scb * sc_bytes, sc_bytes);
@@ -293,23 +302,23 @@ clv_k20_traversal_kernel(DeviceView v, const double *__restrict__ pmfma,
   // tip codes of operation oi + 1 (requested an iteration ago; here: up front)
   Codes cw1 = load_codes(nx.src1, nx.child1_clv), cw2 = load_codes(nx.src2, nx.child2_clv);
 
-  auto store_result = [&](const OpHead &h, const double (&val)[kMfmaGroups], unsigned sc) {
-    if (h.parent_sc >= 0) {
-      const __amdgpu_buffer_rsrc_t psc_rs = make_rsrc(sc_base + (size_t)h.parent_sc * sc_bytes, sc_bytes);
-      __builtin_amdgcn_raw_buffer_store_b32(sc, psc_rs, (int)st_sc, 0, 0);
-    }
+  // Always the same four instructions (a scaler that is not kept, or the iterations before
+  // there is a result, go to out-of-range offsets and are dropped by the hardware): with a
+  // fixed number of stores behind an iteration's loads the wait for those loads is a count
+  // (vmcnt(4)) and never a drain that would include the stores' acknowledgements.
+  auto store_result = [&](const OpHead &h, const double (&val)[kMfmaGroups], unsigned sc, bool wanted) {
+    const bool keep_sc = h.parent_sc >= 0;
+    const __amdgpu_buffer_rsrc_t psc_rs =
+        make_rsrc(sc_base + (size_t)(keep_sc ? (unsigned)h.parent_sc : 0u) * sc_bytes, sc_bytes);
+    __builtin_amdgcn_raw_buffer_store_b32(sc, psc_rs, (int)(wanted && keep_sc ? st_sc : kOob), 0, 0);
     const __amdgpu_buffer_rsrc_t rs = make_rsrc(clv_base + (size_t)(h.parent_clv - v.tips) * clv_bytes, clv_bytes);
     const u32x2 x0 = __builtin_bit_cast(u32x2, val[0]), x1 = __builtin_bit_cast(u32x2, val[1]);
     const u32x2 x2 = __builtin_bit_cast(u32x2, val[2]), x3 = __builtin_bit_cast(u32x2, val[3]);
-    char *mine = t_lds + col * (kMfmaK * 8u);
-    *reinterpret_cast<u32x4 *>(mine + o1) = u32x4{x0[0], x0[1], x1[0], x1[1]};
-    *reinterpret_cast<u32x4 *>(mine + o1 + 16u) = u32x4{x2[0], x2[1], x3[0], x3[1]};
-    *reinterpret_cast<u32x2 *>(mine + o3) = __builtin_bit_cast(u32x2, val[4]);
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {   // (the third instruction carries 32 lanes)
-      const u32x4 piece = *reinterpret_cast<const u32x4 *>(t_lds + ((lane + 64u * k) & 255u) * 16u);
-      __builtin_amdgcn_raw_buffer_store_b128(piece, rs, (int)st_lin[k], 0, (VAR & 2) ? 0 : 2);   // nt (streamed): VAR bit 1 = default policy
-    }
+    constexpr int aux = (VAR & 2) ? 0 : 2;   // nt (streamed): VAR bit 1 = default policy
+    const unsigned o = wanted ? st_clv : kOob, o4 = wanted ? st_clv4 : kOob;
+    __builtin_amdgcn_raw_buffer_store_b128(u32x4{x0[0], x0[1], x1[0], x1[1]}, rs, (int)o, 0, aux);
+    __builtin_amdgcn_raw_buffer_store_b128(u32x4{x2[0], x2[1], x3[0], x3[1]}, rs, (int)(o + 1024u), 0, aux);
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, val[4]), rs, (int)o4, 0, aux);
   };
 
   for (int oi = -1; oi < (int)nops; ++oi) {
@@ -317,7 +326,7 @@ clv_k20_traversal_kernel(DeviceView v, const double *__restrict__ pmfma,
     const unsigned nx2i = (unsigned)(oi + 2) < nops ? (unsigned)(oi + 2) : nops - 1;
     const OpHead nx2 = load_op(ops, nx2i);   // wanted one iteration from now
     // tip codes two operations ahead: they address next iteration's table loads
-    const Codes ncw1 = load_codes(nx2.src1, nx2.child1_clv), ncw2 = load_codes(nx2.src2, nx2.child2_clv);
+    const Codes ncw1 = load_codes_ahead(nx.ahead1), ncw2 = load_codes_ahead(nx.ahead2);
     // this operation's operands: what the loads brought, or the registers of one of
     // the two operations before
     const bool tip1 = op.src1 == 0u, tip2 = op.src2 == 0u;
@@ -356,7 +365,7 @@ clv_k20_traversal_kernel(DeviceView v, const double *__restrict__ pmfma,
       load_child(nx.src2, nx.child2_clv, nx.child2_mat, nx.child2_sc, cw2, c2);
     }
     // ... and the PREVIOUS operation's result goes out behind those loads
-    if (oi >= 1 && !(VAR & 1)) store_result(pop, res, osc);   // VAR bit 0 (timing only): no stores
+    if (!(VAR & 1)) store_result(pop, res, osc, oi >= 1);   // VAR bit 0 (timing only): no stores
     // the MFMAs of this operation
     // (a tip's loads brought its finished term: b = P . indicator, from the tip table)
     double d1[kMfmaGroups], d2[kMfmaGroups], out[kMfmaGroups];
@@ -403,7 +412,7 @@ clv_k20_traversal_kernel(DeviceView v, const double *__restrict__ pmfma,
     cw1 = ncw1;
     cw2 = ncw2;
   }
-  if (nops >= 1 && !(VAR & 1)) store_result(pop, res, osc);   // the last operation's result
+  if (nops >= 1 && !(VAR & 1)) store_result(pop, res, osc, true);   // the last operation's result
 }
 
 hipError_t launch_pmat_to_mfma(rdamd_partition *p, const unsigned *d_matrix_indices,
@@ -414,12 +423,6 @@ hipError_t launch_pmat_to_mfma(rdamd_partition *p, const unsigned *d_matrix_indi
   return hipGetLastError();
 }
 
-// one CLV must stay under 2 GB (32-bit buffer offsets, kOob above every offset)
-bool k20_mfma_ok(const rdamd_partition *p) {
-  return p->d_pmat_mfma != nullptr &&
-         (size_t)p->sites * p->rate_cats * kMfmaK * sizeof(double) < ((size_t)1 << 31) &&
-         (size_t)p->prob_matrices * p->rate_cats * kMfmaCopy * sizeof(double) < ((size_t)1 << 31);
-}
 size_t k20_mfma_copy_doubles() { return kMfmaCopy; }
 
 hipError_t launch_clv_k20_traversal(rdamd_partition *p, const LevelOp *d_ops, unsigned nops) {

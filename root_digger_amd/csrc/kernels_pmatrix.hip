@@ -79,7 +79,7 @@ pmatrix_generic_kernel(const double *__restrict__ q, const double *__restrict__ 
                        const unsigned *__restrict__ mat_idx,
                        const double *__restrict__ brlen, unsigned R, unsigned K,
                        double *__restrict__ pmat, double *__restrict__ tiptab,
-                       const uint64_t *__restrict__ codemask, unsigned ncodes_cap) {
+                       const uint64_t *__restrict__ codemask, unsigned ncodes_cap, unsigned operand_rows) {
   extern __shared__ double sm[];
   const unsigned KK = K * K;
   double *x = sm, *term = sm + KK, *out = sm + 2 * KK, *tmp = sm + 3 * KK;
@@ -140,7 +140,7 @@ pmatrix_generic_kernel(const double *__restrict__ q, const double *__restrict__ 
   __syncthreads();
   double *tt = tiptab + slot * ncodes_cap * K;
   for (unsigned e = tid; e < ncodes_cap * K; e += nt) {
-    unsigned c = e / K, i = e % K;
+    unsigned c = e / K, i = operand_rows ? k20_row_state(e % K) : e % K;   // (row order: common.hpp)
     uint64_t mask = codemask[c];
     double a = 0.0;
     for (unsigned j = 0; j < K; ++j) a += ((mask >> j) & 1) ? out[i * K + j] : 0.0;
@@ -153,10 +153,10 @@ pmatrix_generic_kernel(const double *__restrict__ q, const double *__restrict__ 
 __global__ void tiptab_all_kernel(const double *__restrict__ pmat,
                                   double *__restrict__ tiptab,
                                   const uint64_t *__restrict__ codemask,
-                                  unsigned K, unsigned ncodes_cap, size_t total) {
+                                  unsigned K, unsigned ncodes_cap, size_t total, unsigned operand_rows) {
   size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= total) return;
-  unsigned i = e % K;
+  unsigned i = operand_rows ? k20_row_state((unsigned)(e % K)) : (unsigned)(e % K);
   unsigned c = (e / K) % ncodes_cap;
   size_t slot = e / ((size_t)K * ncodes_cap);
   const double *pm = pmat + slot * K * K + (size_t)i * K;
@@ -180,7 +180,7 @@ hipError_t launch_pmatrix(rdamd_partition *p, const unsigned *d_params_indices,
     size_t lds = (4 * (size_t)K * K + K) * sizeof(double);
     pmatrix_generic_kernel<<<count * R, 256, lds, p->stream>>>(
         p->d_q, p->d_rates, d_params_indices, d_matrix_indices, d_branch_lengths,
-        R, K, p->d_pmat, p->d_tiptab, p->d_codemask, p->ncodes_cap);
+        R, K, p->d_pmat, p->d_tiptab, p->d_codemask, p->ncodes_cap, p->mfma_layout ? 1u : 0u);
   }
   return hipGetLastError();
 }
@@ -189,7 +189,7 @@ hipError_t launch_tiptab_all(rdamd_partition *p) {
   size_t total = (size_t)p->prob_matrices * p->rate_cats * p->ncodes_cap * p->states;
   if (!total) return hipSuccess;
   tiptab_all_kernel<<<(unsigned)((total + 255) / 256), 256, 0, p->stream>>>(
-      p->d_pmat, p->d_tiptab, p->d_codemask, p->states, p->ncodes_cap, total);
+      p->d_pmat, p->d_tiptab, p->d_codemask, p->states, p->ncodes_cap, total, p->mfma_layout ? 1u : 0u);
   return hipGetLastError();
 }
 

@@ -36,6 +36,14 @@ __device__ __forceinline__ double dot_freq(const double *c, const double *f, uns
   return tr;
 }
 
+// the same chain over a record kept in the 20-state operand layout (common.hpp:
+// k20_tile_index); `tile` = the 16-site tile of the record's rate, c = site % 16
+__device__ __forceinline__ double dot_freq_k20_tile(const double *tile, unsigned c, const double *f) {
+  double tr = 0.0;
+  for (unsigned k = 0; k < 20; ++k) tr = __builtin_fma(tile[k20_tile_index(c, k)], f[k], tr);
+  return tr;
+}
+
 // one lane per (site, rate); R in {1,2,4,8,16}
 template <int R>
 __global__ void __launch_bounds__(256)
@@ -78,7 +86,7 @@ __global__ void __launch_bounds__(256)
 root_lnl_site_kernel(const double *__restrict__ clv, const unsigned *__restrict__ scaler,
                      const double *__restrict__ freqs, const unsigned *__restrict__ fidx,
                      const double *__restrict__ rate_w, const unsigned *__restrict__ pw,
-                     unsigned S, unsigned R, unsigned K, double *__restrict__ persite,
+                     unsigned S, unsigned R, unsigned K, unsigned tiles, double *__restrict__ persite,
                      double *__restrict__ partials) {
   __shared__ double lds[4];
   double acc = 0.0;
@@ -87,7 +95,10 @@ root_lnl_site_kernel(const double *__restrict__ clv, const unsigned *__restrict_
     double term = 0.0;
     for (unsigned r = 0; r < R; ++r) {
       const double *f = freqs + (size_t)fidx[r] * K;
-      term += dot_freq(c + (size_t)r * K, f, K) * rate_w[r];
+      // tiles != 0: 20-state CLV in the operand layout, [rate][tile][320 doubles]
+      const double tr = tiles ? dot_freq_k20_tile(clv + ((size_t)r * tiles + (s >> 4)) * 320, s & 15u, f)
+                              : dot_freq(c + (size_t)r * K, f, K);
+      term += tr * rate_w[r];
     }
     double l = log(term);
     if (scaler) {
@@ -149,10 +160,11 @@ root_lnl_site_batch_kernel(const double *__restrict__ clv_base, const unsigned *
                            const unsigned *__restrict__ clv_rel, const int *__restrict__ scaler_idx,
                            const double *__restrict__ freqs, const unsigned *__restrict__ fidx,
                            const double *__restrict__ rate_w, const unsigned *__restrict__ pw,
-                           unsigned S, unsigned R, unsigned K, double *__restrict__ partials) {
+                           unsigned S, unsigned R, unsigned K, unsigned tiles, size_t clv_doubles,
+                           double *__restrict__ partials) {
   __shared__ double lds[4];
   const unsigned which = blockIdx.y;
-  const double *clv = clv_base + (size_t)clv_rel[which] * S * R * K;
+  const double *clv = clv_base + (size_t)clv_rel[which] * clv_doubles;
   const int sci = scaler_idx[which];
   const unsigned *scaler = sci >= 0 ? scaler_base + (size_t)sci * S : nullptr;
   double acc = 0.0;
@@ -161,7 +173,9 @@ root_lnl_site_batch_kernel(const double *__restrict__ clv_base, const unsigned *
     double term = 0.0;
     for (unsigned r = 0; r < R; ++r) {
       const double *f = freqs + (size_t)fidx[r] * K;
-      term += dot_freq(c + (size_t)r * K, f, K) * rate_w[r];
+      const double tr = tiles ? dot_freq_k20_tile(clv + ((size_t)r * tiles + (s >> 4)) * 320, s & 15u, f)
+                              : dot_freq(c + (size_t)r * K, f, K);
+      term += tr * rate_w[r];
     }
     double l = log(term);
     if (scaler) {
@@ -369,10 +383,12 @@ root_single_dna_kernel(DeviceView v, LevelOp op, RootSingleArgs ra, const double
 hipError_t launch_root_lnl(rdamd_partition *p, unsigned clv_index, int scaler_index,
                            const unsigned *d_fidx, double *d_persite, double *d_out) {
   const unsigned S = p->sites, R = p->rate_cats, K = p->states;
-  const double *clv = p->d_clv + (size_t)(clv_index - p->tips) * S * R * K;
+  const double *clv = p->d_clv + (size_t)(clv_index - p->tips) * p->clv_doubles();
   const unsigned *sc = scaler_index >= 0 ? p->d_scaler + (size_t)scaler_index * S : nullptr;
+  const unsigned tiles = p->mfma_layout ? p->clv_tiles() : 0u;
   unsigned blocks;
-  const bool group = (R == 1 || R == 2 || R == 4 || R == 8 || R == 16);
+  // (a CLV in the 20-state operand layout goes through the one-lane-per-site kernel)
+  const bool group = !p->mfma_layout && (R == 1 || R == 2 || R == 4 || R == 8 || R == 16);
   if (group) {
     size_t total = (size_t)S * R;
     blocks = (unsigned)((total + 255) / 256);
@@ -391,7 +407,7 @@ hipError_t launch_root_lnl(rdamd_partition *p, unsigned clv_index, int scaler_in
       default: root_lnl_group_kernel<16><<<blocks, 256, 0, p->stream>>>(RDAMD_ROOT_ARGS, S, K, d_persite, p->d_partials); break;
     }
   } else {
-    root_lnl_site_kernel<<<blocks, 256, 0, p->stream>>>(RDAMD_ROOT_ARGS, S, R, K, d_persite, p->d_partials);
+    root_lnl_site_kernel<<<blocks, 256, 0, p->stream>>>(RDAMD_ROOT_ARGS, S, R, K, tiles, d_persite, p->d_partials);
   }
 #undef RDAMD_ROOT_ARGS
   hipError_t e = hipGetLastError();
@@ -402,7 +418,7 @@ hipError_t launch_root_lnl(rdamd_partition *p, unsigned clv_index, int scaler_in
 
 unsigned root_lnl_blocks(const rdamd_partition *p) {
   const unsigned S = p->sites, R = p->rate_cats;
-  const bool group = (R == 1 || R == 2 || R == 4 || R == 8 || R == 16);
+  const bool group = !p->mfma_layout && (R == 1 || R == 2 || R == 4 || R == 8 || R == 16);
   unsigned blocks = group ? (unsigned)(((size_t)S * R + 255) / 256) : (S + 255) / 256;
   if (blocks > kRootBlocks) blocks = kRootBlocks;
   return blocks ? blocks : 1;
@@ -416,14 +432,15 @@ hipError_t launch_root_lnl_batch(rdamd_partition *p, unsigned count, const unsig
   const unsigned S = p->sites, R = p->rate_cats, K = p->states;
   const unsigned blocks = root_lnl_blocks(p);
   const dim3 grid(blocks, count);
+  const unsigned tiles = p->mfma_layout ? p->clv_tiles() : 0u;
 #define RDAMD_RB_ARGS p->d_clv, p->d_scaler, d_clv_rel, d_scaler_idx, p->d_freqs, d_fidx, p->d_rate_weights, p->d_pattern_weights
-  switch (R) {
+  switch (p->mfma_layout ? 0u : R) {
     case 1: root_lnl_group_batch_kernel<1><<<grid, 256, 0, p->stream>>>(RDAMD_RB_ARGS, S, K, d_partials); break;
     case 2: root_lnl_group_batch_kernel<2><<<grid, 256, 0, p->stream>>>(RDAMD_RB_ARGS, S, K, d_partials); break;
     case 4: root_lnl_group_batch_kernel<4><<<grid, 256, 0, p->stream>>>(RDAMD_RB_ARGS, S, K, d_partials); break;
     case 8: root_lnl_group_batch_kernel<8><<<grid, 256, 0, p->stream>>>(RDAMD_RB_ARGS, S, K, d_partials); break;
     case 16: root_lnl_group_batch_kernel<16><<<grid, 256, 0, p->stream>>>(RDAMD_RB_ARGS, S, K, d_partials); break;
-    default: root_lnl_site_batch_kernel<<<grid, 256, 0, p->stream>>>(RDAMD_RB_ARGS, S, R, K, d_partials); break;
+    default: root_lnl_site_batch_kernel<<<grid, 256, 0, p->stream>>>(RDAMD_RB_ARGS, S, R, K, tiles, p->clv_doubles(), d_partials); break;
   }
 #undef RDAMD_RB_ARGS
   hipError_t e = hipGetLastError();

@@ -145,7 +145,8 @@ uint64_t rdamd_partition_footprint(unsigned int tips, unsigned int clv_buffers, 
                                    unsigned int rate_cats, unsigned int scale_buffers) {
   const uint64_t K = states == 2 ? 4 : states, R = rate_cats, S = sites;
   const uint64_t codes = K == 4 ? 16 : 64;
-  uint64_t b = (uint64_t)tips * ((S + 3) / 4 * 4) + (uint64_t)clv_buffers * S * R * K * 8 +
+  const uint64_t Sclv = (K == 20 && R <= 8) ? (S + 15) / 16 * 16 : S;   // operand layout: whole 16-site tiles
+  uint64_t b = (uint64_t)tips * ((S + 3) / 4 * 4) + (uint64_t)clv_buffers * Sclv * R * K * 8 +
                (uint64_t)scale_buffers * S * 4 + (uint64_t)prob_matrices * R * K * K * 8 +
                (uint64_t)prob_matrices * R * codes * K * 8 + S * 4 + ((uint64_t)6 << 20);
   if (K == 20 && R <= 8) b += (uint64_t)prob_matrices * R * k20_mfma_copy_doubles() * 8;
@@ -200,11 +201,16 @@ rdamd_partition_t *rdamd_partition_create(unsigned int tips, unsigned int clv_bu
   // loads that may run a few bytes past the last row
   TRY(hipMalloc(&p->d_tipcodes, (size_t)tips * p->tip_stride() + kTipcodePad));
   if (K == 4) TRY(hipMalloc(&p->d_tipcodes16, (size_t)tips * p->tip_stride() + kTipcodePad));
-  TRY(hipMalloc(&p->d_clv, std::max<size_t>(8, (size_t)clv_buffers * S * R * K * sizeof(double))));
+  // (the 20-state matrix-core kernel keeps CLVs in its operand layout, whole 16-site tiles:
+  // decided here, before the CLV buffers are sized -- common.hpp)
+  p->mfma_layout = K == 20 && R <= 8 &&
+                   (size_t)p->clv_tiles() * 16u * R * K * sizeof(double) < ((size_t)1 << 31) &&
+                   (size_t)prob_matrices * R * k20_mfma_copy_doubles() * sizeof(double) < ((size_t)1 << 31);
+  TRY(hipMalloc(&p->d_clv, std::max<size_t>(8, (size_t)clv_buffers * p->clv_doubles() * sizeof(double))));
   TRY(hipMalloc(&p->d_scaler, std::max<size_t>(4, (size_t)scale_buffers * S * sizeof(unsigned))));
   TRY(hipMalloc(&p->d_pmat, (size_t)prob_matrices * R * K * K * sizeof(double)));
   TRY(hipMalloc(&p->d_tiptab, (size_t)prob_matrices * R * p->ncodes_cap * K * sizeof(double)));
-  if (K == 20 && R <= 8)
+  if (p->mfma_layout)
     TRY(hipMalloc(&p->d_pmat_mfma, (size_t)prob_matrices * R * k20_mfma_copy_doubles() * sizeof(double)));
   TRY(hipMalloc(&p->d_codemask, 256 * sizeof(uint64_t)));
   TRY(hipMalloc(&p->d_q, (size_t)rate_matrices * K * K * sizeof(double)));
@@ -492,7 +498,7 @@ void rdamd_update_clvs(rdamd_partition_t *p, const rdamd_operation_t *ops,
     d.src1 = o.child1_clv_index < p->tips ? 0u : 1u;
     d.src2 = o.child2_clv_index < p->tips ? 0u : 1u;
     d.park = d.noop = 0;
-    const uint64_t clv_bytes = (uint64_t)p->sites * p->rate_cats * p->states * sizeof(double);
+    const uint64_t clv_bytes = (uint64_t)p->clv_doubles() * sizeof(double);
     auto sc_off = [&](int scb) {
       return scb >= 0 ? (uint64_t)scb * p->sites * sizeof(unsigned) : kNoOffset;
     };
@@ -521,7 +527,7 @@ void rdamd_update_clvs(rdamd_partition_t *p, const rdamd_operation_t *ops,
   // value cannot be forwarded (same CLV under another scaler index, or the
   // other way round, or both earlier operations wrote it): there the list is
   // cut into two launches.
-  const bool use_k20 = k20_mfma_ok(p);
+  const bool use_k20 = p->mfma_layout;   // fixed at creation, with the CLV layout
   if (use_k20)
     for (unsigned i = 1; i < count; ++i) {
       const rdamd_operation_t &o = ops[i];
@@ -624,6 +630,12 @@ void rdamd_update_clvs(rdamd_partition_t *p, const rdamd_operation_t *ops,
     cuts.back() = (unsigned)lops.size();   // (no cuts on this path: one segment)
     lops.push_back(pad);   // terminator: the kernel looks one operation ahead
   }
+  if (use_k20)   // tip-code look-ahead of the 20-state kernel (LevelOp::ahead*)
+    for (unsigned i = 0; i < count; ++i) {
+      const bool more = i + 1 < count;
+      lops[i].ahead1 = more && lops[i + 1].src1 == 0u ? lops[i + 1].child1_clv : 0u;
+      lops[i].ahead2 = more && lops[i + 1].src2 == 0u ? lops[i + 1].child2_clv : 0u;
+    }
   const size_t padded = lops.size();
   hipError_t e = ensure_scratch(p, sizeof(LevelOp) * padded + 256);
   if (e == hipSuccess && p->tiptab_stale) {
@@ -828,7 +840,20 @@ int rdamd_get_clv(rdamd_partition_t *p, unsigned int clv_index, double *out) {
     return RDAMD_FAILURE;
   }
   RDAMD_HIP_TRY(hipStreamSynchronize(p->stream), RDAMD_FAILURE);
-  const double *src = p->d_clv + (size_t)(clv_index - p->tips) * S * R * K;
+  const double *src = p->d_clv + (size_t)(clv_index - p->tips) * p->clv_doubles();
+  if (p->mfma_layout) {   // device: [rate][tile][operand layout] -> the ABI's [site][rate][state]
+    std::vector<double> dev(p->clv_doubles());
+    RDAMD_HIP_TRY(hipMemcpy(dev.data(), src, sizeof(double) * dev.size(), hipMemcpyDeviceToHost),
+                  RDAMD_FAILURE);
+    const size_t tiles = p->clv_tiles();
+    for (size_t s = 0; s < S; ++s)
+      for (size_t r = 0; r < R; ++r) {
+        const double *tile = dev.data() + (r * tiles + s / 16) * (16 * K);
+        for (size_t j = 0; j < KA; ++j)
+          out[(s * R + r) * KA + j] = tile[k20_tile_index((unsigned)(s % 16), (unsigned)j)];
+      }
+    return RDAMD_SUCCESS;
+  }
   if (!p->embedded()) {
     RDAMD_HIP_TRY(hipMemcpy(out, src, sizeof(double) * S * R * K, hipMemcpyDeviceToHost), RDAMD_FAILURE);
     return RDAMD_SUCCESS;

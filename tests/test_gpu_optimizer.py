@@ -238,14 +238,15 @@ def test_batched_root_reduction_is_bit_identical_to_single_calls():
     """rdamd_compute_root_loglikelihoods: one launch for many root CLVs, each
     value exactly what rdamd_compute_root_loglikelihood returns for that CLV."""
     from root_digger_amd import synth
-    for R, S in ((4, 5000), (3, 777), (1, 64)):
-        w = synth.workload(20, S, 4, R, 31 + R)
+    # (20 states: CLVs in the matrix-core operand layout, ragged last tile, R = 3 and 4)
+    for R, S, K in ((4, 5000, 4), (3, 777, 4), (1, 64, 4), (4, 203, 20), (3, 45, 20)):
+        w = synth.workload(20, S, K, R, 31 + R)
         tree = rd.Tree.from_newick(w["newick"])
         d = tree.generate_directional_operations()
-        p = rd.Partition(tips=20, clv_buffers=d["clv_buffers"], states=4, sites=S, rate_matrices=1,
+        p = rd.Partition(tips=20, clv_buffers=d["clv_buffers"], states=K, sites=S, rate_matrices=1,
                          prob_matrices=d["prob_matrices"], rate_cats=R,
                          scale_buffers=d["scale_buffers"])
-        util.load_tips(p, tree, w["seqs"], rd.MAP_NT)
+        util.load_tips(p, tree, w["seqs"], rd.MAP_NT if K == 4 else util.make_map(w["alphabet"]))
         p.set_subst_params(0, w["subst"])
         p.set_frequencies(0, p.empirical_frequencies())
         p.set_category_rates(w["rates"])
