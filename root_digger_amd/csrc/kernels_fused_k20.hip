@@ -299,6 +299,17 @@ fused20_eval_kernel(Fused20Args a, unsigned depth) {
     }
     return c;
   };
+  // In the loop the codes are fetched unconditionally (a step without that tip child
+  // carries row offset 0: a valid row, the result is not used) from the offsets of a
+  // step head that arrived an iteration ago: no branch, no scalar load that waits for
+  // another one -- nothing touches the result before next iteration's table requests.
+  auto load_codes_ahead = [&](unsigned row_off) -> TileCodes {
+    TileCodes c;
+    const const_u32_ptr row = (const_u32_ptr)(codes_lo + row_off);
+#pragma unroll
+    for (int q = 0; q < NT; ++q) c.t[q] = Codes{row[4 * q], row[4 * q + 1], row[4 * q + 2], row[4 * q + 3]};
+    return c;
+  };
   auto my_code = [&](const Codes &c) -> unsigned {
     const unsigned long long lo = ((unsigned long long)c.w1 << 32) | c.w0;
     const unsigned long long hi = ((unsigned long long)c.w3 << 32) | c.w2;
@@ -361,6 +372,7 @@ fused20_eval_kernel(Fused20Args a, unsigned depth) {
   // prologue: step 0's operands and the codes of step 1
   Step cur = load_step(prog, 0);
   Step nxt = load_step(prog, 1);
+  Step nx2 = load_step(prog, 2);   // (the program is padded: heads up to n_ops + 3 exist)
   {
     const TileCodes k1 = load_codes(has_tip1(cur), cur.cX), k2 = load_codes(has_tip2(cur), cur.cY);
     if (!has_tip1(cur)) request_a(cur);
@@ -371,11 +383,11 @@ fused20_eval_kernel(Fused20Args a, unsigned depth) {
   TileCodes cw1 = load_codes(has_tip1(nxt), nxt.cX), cw2 = load_codes(has_tip2(nxt), nxt.cY);
 
   for (unsigned i = 0; i < nops; ++i) {
-    const Step nx2 = load_step(prog, i + 2);
+    const Step nx3 = load_step(prog, i + 3);   // first looked at an iteration from now
     const unsigned kind = cur.flags & 3u;
     const bool next_product = !has_tip1(nxt) && i + 1 < nops;
-    // tip codes of the step after next (scalar loads)
-    const TileCodes ncw1 = load_codes(has_tip1(nx2), nx2.cX), ncw2 = load_codes(has_tip2(nx2), nx2.cY);
+    // tip codes of the step after next (scalar loads; the offsets came with nx2 an iteration ago)
+    const TileCodes ncw1 = load_codes_ahead(nx2.cX), ncw2 = load_codes_ahead(nx2.cY);
     if (kind == kFusedTT) {   // both children are table rows: use them at once ...
 #pragma unroll
       for (int q = 0; q < NT; ++q) {
@@ -455,6 +467,7 @@ fused20_eval_kernel(Fused20Args a, unsigned depth) {
     if (next_product) stage();
     cur = nxt;
     nxt = nx2;
+    nx2 = nx3;
     cw1 = ncw1;
     cw2 = ncw2;
   }
