@@ -221,7 +221,9 @@ int rdamd_evaluate_batch_device(rdamd_partition_t *p, unsigned int n_jobs,
                                 const double *rates, const double *rate_weights,
                                 void *d_lnl_out);
 
-/* parity/debug views: copy device buffers to host. */
+/* parity/debug views: copy device buffers to host.  rdamd_get_clv returns coraxlib's
+ * layout, out[site][rate][state] (what partition->clv[i] holds in the reference),
+ * whatever layout the device keeps the CLV in. */
 int rdamd_get_clv(rdamd_partition_t *p, unsigned int clv_index, double *out);
 int rdamd_get_scaler(rdamd_partition_t *p, unsigned int scaler_index,
                      unsigned int *out);

@@ -177,20 +177,22 @@ struct LevelOp {   // device-side op descriptor
   // where each child comes from: 0 tip, 1 memory, 2 register (= parent of the
   // previous op), 3+s = LDS parking slot s (4-state kernel only)
   unsigned src1, src2;
-  unsigned park;         // 1+s: also park the parent in LDS slot s; 0: do not
-  unsigned noop;         // padding entry (4-state kernel: lists are padded to whole chunks)
+  // 4-state kernel: park = 1+s: also park the parent in LDS slot s (0: do not); noop = padding
+  // entry (lists are padded to whole chunks).  20-state kernel (which has neither): the tip
+  // indices of the NEXT operation's children (0 where a child is no tip, or there is no
+  // next operation) -- it fetches tip codes through the scalar cache two operations ahead,
+  // and taking the address from the operation in front means no scalar load has to wait
+  // for another one.
+  union { unsigned park; unsigned ahead1; };
+  union { unsigned noop; unsigned ahead2; };
   // 4-state kernel only: byte offsets worked out on the host, so the kernel's
   // scalar unit does no 64-bit index arithmetic.  *_off of a child: its row in
   // the tip codes (tip) or its CLV (memory); kNoOffset where there is none.
   uint64_t parent_off, parent_sc_off;
   uint64_t child1_off, child1_sc_off;
   uint64_t child2_off, child2_sc_off;
-  // 20-state kernel only: the tip indices of the NEXT operation's children (0 where a child
-  // is no tip, or there is no next operation).  The kernel fetches tip codes through the
-  // scalar cache two operations ahead; taking the address from the operation in front
-  // means no scalar load has to wait for another one.
-  unsigned ahead1, ahead2;
 };
+static_assert(sizeof(LevelOp) == 96, "LevelOp: 12 words + 6 offsets");
 constexpr uint64_t kNoOffset = ~0ull;
 // LDS parking slots per lane the 4-state traversal kernel will have for this
 // partition (0 for the other kernels): an older sibling waits there instead of

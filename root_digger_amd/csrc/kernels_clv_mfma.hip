@@ -94,7 +94,7 @@ struct OpHead {
   unsigned src1, src2;
   unsigned ahead1, ahead2;   // tip indices of the next operation's children
 };
-constexpr unsigned kAheadWord = 24;
+constexpr unsigned kAheadWord = 10;
 static_assert(sizeof(LevelOp) % 4 == 0 && offsetof(LevelOp, src2) == 36 &&
               offsetof(LevelOp, ahead1) == 4 * kAheadWord && offsetof(LevelOp, ahead2) == 4 * kAheadWord + 4,
               "OpHead mirrors LevelOp");
