@@ -68,3 +68,21 @@ def test_host_side_gamma_and_maps_work_without_gpu():
         got = rd.compute_gamma_cats(g["alpha"], g["cats"],
                                     rd.GAMMA_RATES_MEAN if g["mode"] == "mean" else rd.GAMMA_RATES_MEDIAN)
         assert max(abs(a - b) for a, b in zip(got, g["rates"])) < 2e-9
+
+
+def test_k20_operand_layouts_are_consistent(tmp_path):
+    """The 20-state CLV tile / tip-table row layouts of common.hpp (what keeps the
+    matrix-core traversal kernel's loads and stores contiguous): bijective, and every
+    lane's operands where the kernel's three instructions expect them.  Host code only."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    exe = str(tmp_path / "k20_layout_check")
+    subprocess.check_call([hipcc, "-std=c++17", "-O1", "--offload-arch=gfx950", "-Wno-c99-designator", "-w",
+                           "-I", os.path.join(util.ROOT, "root_digger_amd", "csrc"),
+                           "-I", os.path.join(util.ROOT, "include"),
+                           os.path.join(util.ROOT, "tests", "cpp", "k20_layout_check.cpp"), "-o", exe])
+    out = subprocess.run([exe], stdout=subprocess.PIPE, text=True)
+    assert out.returncode == 0 and "k20 layouts OK" in out.stdout, out.stdout
