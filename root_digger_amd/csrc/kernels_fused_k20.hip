@@ -446,9 +446,13 @@ fused20_eval_kernel(Fused20Args a, unsigned depth) {
 #pragma unroll
           for (int s = 0; s < kSteps; ++s) v[q][s] = d1[q][s] * y[s];
         }   // (tip-tip: v was formed at the top of the step)
-        bool small = true;
+        // all five entries < 2^-256: entries are non-negative, so the largest high word
+        // decides (two v_max3_u32 + one compare instead of five FP64 compares; a NaN
+        // compares as large and never rescales, as with `<`)
+        unsigned hmax = 0u;
 #pragma unroll
-        for (int s = 0; s < kSteps; ++s) small = small && (v[q][s] < kScaleThreshold);
+        for (int s = 0; s < kSteps; ++s) hmax = max(hmax, (unsigned)__double2hiint(v[q][s]));
+        const bool small = hmax < 0x2FF00000u;
         // all 20 entries of a (site, rate) sit in the four lanes col + 16 g
         unsigned long long bm = __ballot(small);
         bm &= bm >> 32;
