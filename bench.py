@@ -116,6 +116,11 @@ def spawn_ranks(n):
     while any(c.poll() is None for c in children):
         failed = next((c.returncode for c in children if c.poll()), 0)
         if failed:           # one rank died: the others would wait in a collective forever
+            # ... unless they are about to fail the same way: a short grace period lets
+            # them report their own error before they are stopped
+            deadline = time.monotonic() + 5.0
+            while time.monotonic() < deadline and any(c.poll() is None for c in children):
+                time.sleep(0.05)
             for c in children:
                 if c.poll() is None:
                     c.terminate()

@@ -603,13 +603,22 @@ rdamd_model_t *rdamd_model_create_from_file_block(const rdamd_tree_t *tree, cons
  * rdamd_comm_unique_id and hands the 128 bytes to the others by any means
  * (rd_amd: its TCP rendezvous); every rank then calls rdamd_comm_create on its
  * own device.  rdamd_comm_reducer is a ready-made rdamd_lnl_reducer_t
- * (on_device = 1) whose `user` is the communicator. */
+ * (on_device = 1) whose `user` is the communicator.
+ * A lost peer must not leave the other ranks of the group inside the collective:
+ * rdamd_comm_reducer waits for its all-reduce by polling the stream and FAILS (after
+ * ncclCommAbort; rdamd_errmsg says why) when RCCL reports an asynchronous error, when
+ * nothing has arrived within the time limit (rdamd_comm_set_timeout; default 600 s, or
+ * RDAMD_COMM_TIMEOUT seconds in the environment), or when another thread has called
+ * rdamd_comm_abort -- rd_amd does from the thread that watches its rendezvous
+ * connections.  An aborted communicator is unusable: exit and start a new process. */
 typedef struct rdamd_comm rdamd_comm_t;
 int           rdamd_comm_unique_id(char id[128]);
 rdamd_comm_t *rdamd_comm_create(const char id[128], int rank, int n_ranks);
 int           rdamd_comm_allreduce_sum(rdamd_comm_t *c, double *device_values, unsigned int n,
                                        void *stream);
 int           rdamd_comm_reducer(double *values, unsigned int n, void *stream, void *user);
+void          rdamd_comm_set_timeout(rdamd_comm_t *c, double seconds);
+void          rdamd_comm_abort(rdamd_comm_t *c);   /* any thread */
 void          rdamd_comm_destroy(rdamd_comm_t *c);
 
 /* library / device info */

@@ -1,5 +1,7 @@
 # fused 4-state evaluator: bench lines for configs/variants:
 #   CONFIGS="c2 c4" NSS="0 1 2" bash profiles/fd_ab.sh     (NS 0 = the library's own choice)
+# (the timing-only variants live in the ablation build only: csrc `make ablation`)
+make -s -C root_digger_amd/csrc ablation >/dev/null && export RDAMD_LIBRARY=$PWD/root_digger_amd/lib/librdamd_ablation.so
 for c in ${CONFIGS:-c2}; do for ns in ${NSS:-0}; do
 RDAMD_FUSED_NS=$ns python bench.py --config $c --steps ${STEPS:-5} --warmup 1 --no-cpu-baseline | python -c "
 import json,sys

@@ -5,6 +5,14 @@
 // message is 8 x jobs bytes, i.e. latency-bound: there is nothing to bucket or
 // overlap, the lever is the batch size of the launch in front of it.
 //
+// Failure handling: a collective whose peer never arrives would block for ever, so
+// rdamd_comm_reducer WAITS for its all-reduce by polling the stream -- with
+// ncclCommGetAsyncError, a time limit (rdamd_comm_set_timeout, default 600 s, or
+// RDAMD_COMM_TIMEOUT seconds) and an abort flag another thread may raise
+// (rdamd_comm_abort: rd_amd's rendezvous watcher, when a rank of the run has gone).  On
+// any of them the communicator is aborted (ncclCommAbort) and the call fails; the
+// caller must exit and start afresh -- a communicator is not reusable after that.
+//
 // librccl is opened on first use (dlopen) so that single-GPU users carry no
 // dependency on it; only the entry points used here are resolved.
 #include <dlfcn.h>
@@ -13,9 +21,13 @@
 
 #include <unistd.h>
 
+#include <atomic>
+#include <chrono>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <thread>
 
 #include "common.hpp"
 
@@ -27,7 +39,10 @@ struct rccl_api {
   ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t,
                             hipStream_t) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;                          // optional
+  ncclResult_t (*CommGetAsyncError)(ncclComm_t, ncclResult_t *) = nullptr;   // optional
   const char *(*GetErrorString)(ncclResult_t) = nullptr;
+  std::string load_error;   // dlerror() text of the failed load (dlerror() itself answers once)
 };
 
 rccl_api *rccl() {
@@ -54,20 +69,28 @@ rccl_api *rccl() {
       if (name[0] == '/' && access(name.c_str(), R_OK) != 0) continue;
       api.lib = dlopen(name.c_str(), RTLD_NOW | RTLD_LOCAL);
       if (api.lib) break;
+      const char *why = dlerror();
+      if (why) api.load_error = why;
     }
-    if (!api.lib) return;
+    if (!api.lib) {
+      if (api.load_error.empty()) api.load_error = "no librccl found";
+      return;
+    }
     api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(api.lib, "ncclGetUniqueId");
     api.CommInitRank = (decltype(api.CommInitRank))dlsym(api.lib, "ncclCommInitRank");
     api.AllReduce = (decltype(api.AllReduce))dlsym(api.lib, "ncclAllReduce");
     api.CommDestroy = (decltype(api.CommDestroy))dlsym(api.lib, "ncclCommDestroy");
     api.GetErrorString = (decltype(api.GetErrorString))dlsym(api.lib, "ncclGetErrorString");
+    api.CommAbort = (decltype(api.CommAbort))dlsym(api.lib, "ncclCommAbort");
+    api.CommGetAsyncError = (decltype(api.CommGetAsyncError))dlsym(api.lib, "ncclCommGetAsyncError");
     if (!api.GetUniqueId || !api.CommInitRank || !api.AllReduce || !api.CommDestroy) {
       dlclose(api.lib);
       api.lib = nullptr;
+      api.load_error = "the library lacks ncclGetUniqueId / ncclCommInitRank / ncclAllReduce / ncclCommDestroy";
     }
   });
   if (!api.lib) {
-    rdamd::set_error(60, "RCCL (librccl.so.1) could not be loaded: %s", dlerror());
+    rdamd::set_error(60, "RCCL (librccl.so.1) could not be loaded: %s", api.load_error.c_str());
     return nullptr;
   }
   return &api;
@@ -83,7 +106,56 @@ bool ok(rccl_api *a, ncclResult_t r, const char *what) {
 struct rdamd_comm {
   ncclComm_t comm = nullptr;
   int rank = 0, n_ranks = 1;
+  double timeout_s = 600.0;
+  std::atomic<bool> abort_requested{false};
+  std::atomic<bool> dead{false};   // aborted: no further collective may be queued
 };
+
+namespace {
+// ncclCommAbort once; afterwards the communicator only remembers that it is dead
+void abort_comm(rccl_api *a, rdamd_comm *c) {
+  if (c->dead.exchange(true)) return;
+  if (a->CommAbort && c->comm) (void)a->CommAbort(c->comm);
+  c->comm = nullptr;
+}
+
+// Wait for everything queued on `stream` (the all-reduce last) without blocking in the
+// runtime: see the header comment.
+bool wait_for_collective(rccl_api *a, rdamd_comm *c, hipStream_t stream) {
+  const auto t0 = std::chrono::steady_clock::now();
+  for (unsigned spin = 0;; ++spin) {
+    const hipError_t q = hipStreamQuery(stream);
+    if (q == hipSuccess) return true;
+    if (q != hipErrorNotReady) {
+      rdamd::set_error(63, "site-group all-reduce: %s", hipGetErrorString(q));
+      abort_comm(a, c);
+      return false;
+    }
+    if (c->abort_requested.load()) {
+      rdamd::set_error(64, "site-group all-reduce aborted: a rank of the run has gone");
+      abort_comm(a, c);
+      return false;
+    }
+    if (spin < 2000) continue;   // the usual case: the sum arrives within microseconds
+    ncclResult_t async = ncclSuccess;
+    if (a->CommGetAsyncError && c->comm && a->CommGetAsyncError(c->comm, &async) == ncclSuccess &&
+        async != ncclSuccess && async != ncclInProgress) {
+      rdamd::set_error(65, "site-group all-reduce: %s",
+                       a->GetErrorString ? a->GetErrorString(async) : "asynchronous RCCL error");
+      abort_comm(a, c);
+      return false;
+    }
+    const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (waited > c->timeout_s) {
+      rdamd::set_error(66, "site-group all-reduce: no answer from the other %d rank(s) within %.0f s",
+                       c->n_ranks - 1, c->timeout_s);
+      abort_comm(a, c);
+      return false;
+    }
+    std::this_thread::sleep_for(std::chrono::microseconds(waited < 0.01 ? 5 : 200));
+  }
+}
+}  // namespace
 
 static_assert(sizeof(ncclUniqueId) == 128, "rdamd_comm_unique_id hands out 128 bytes");
 
@@ -112,6 +184,8 @@ rdamd_comm_t *rdamd_comm_create(const char id[128], int rank, int n_ranks) {
   auto *c = new rdamd_comm();
   c->rank = rank;
   c->n_ranks = n_ranks;
+  if (const char *t = std::getenv("RDAMD_COMM_TIMEOUT"))
+    if (std::atof(t) > 0.0) c->timeout_s = std::atof(t);
   if (!ok(a, a->CommInitRank(&c->comm, n_ranks, u, rank), "ncclCommInitRank")) {
     delete c;
     return nullptr;
@@ -123,19 +197,37 @@ int rdamd_comm_allreduce_sum(rdamd_comm_t *c, double *device_values, unsigned in
   rccl_api *a = rccl();
   if (!a || !c) return RDAMD_FAILURE;
   if (n == 0) return RDAMD_SUCCESS;
+  if (c->dead.load() || c->abort_requested.load()) {
+    rdamd::set_error(64, "site-group all-reduce: the communicator was aborted");
+    return RDAMD_FAILURE;
+  }
   return ok(a, a->AllReduce(device_values, device_values, n, ncclDouble, ncclSum, c->comm,
                             (hipStream_t)stream), "ncclAllReduce")
              ? RDAMD_SUCCESS : RDAMD_FAILURE;
 }
 
+// the reducer model_t calls: queue the sum, then wait for it (a lost peer must not hang us)
 int rdamd_comm_reducer(double *values, unsigned int n, void *stream, void *user) {
-  return rdamd_comm_allreduce_sum((rdamd_comm_t *)user, values, n, stream);
+  rdamd_comm_t *c = (rdamd_comm_t *)user;
+  if (rdamd_comm_allreduce_sum(c, values, n, stream) != RDAMD_SUCCESS) return RDAMD_FAILURE;
+  rccl_api *a = rccl();
+  if (c->n_ranks <= 1 || !a) return RDAMD_SUCCESS;
+  return wait_for_collective(a, c, (hipStream_t)stream) ? RDAMD_SUCCESS : RDAMD_FAILURE;
+}
+
+void rdamd_comm_set_timeout(rdamd_comm_t *c, double seconds) {
+  if (c && seconds > 0.0) c->timeout_s = seconds;
+}
+
+// callable from any thread: the rank's next (or current) rdamd_comm_reducer call fails
+void rdamd_comm_abort(rdamd_comm_t *c) {
+  if (c) c->abort_requested = true;
 }
 
 void rdamd_comm_destroy(rdamd_comm_t *c) {
   if (!c) return;
   rccl_api *a = rccl();
-  if (a && c->comm) (void)a->CommDestroy(c->comm);
+  if (a && c->comm && !c->dead.load()) (void)a->CommDestroy(c->comm);
   delete c;
 }
 

@@ -390,10 +390,12 @@ static int evaluate_batch_impl(rdamd_partition_t *p, unsigned int n_jobs,
   RDAMD_HIP_TRY(e, RDAMD_FAILURE);
   p->prof_begin(3);
   // two sites per lane (kernels_fused.hip) when half the waves still fill the chip:
-  // >= 4 waves for each of the 1024 SIMDs.  RDAMD_FUSED_NS=1|2 overrides (A/B runs).
+  // >= 4 waves for each of the 1024 SIMDs.
+  unsigned ns = (size_t)n_jobs * w->blocks_x >= 8192 ? 2u : 1u;
+#ifdef RDAMD_ABLATION   // A/B runs only (`make ablation`): RDAMD_FUSED_NS=1|2 overrides
   static const int force_ns = getenv("RDAMD_FUSED_NS") ? atoi(getenv("RDAMD_FUSED_NS")) : 0;
-  const unsigned ns = force_ns ? (unsigned)force_ns
-                               : ((size_t)n_jobs * w->blocks_x >= 8192 ? 2u : 1u);
+  if (force_ns) ns = (unsigned)force_ns;
+#endif
   e = launch_fused_eval(a, n_jobs, max_depth, w->blocks_x, ns, reg_levels, d_out, p->stream);
   p->prof_end();
   RDAMD_HIP_TRY(e, RDAMD_FAILURE);

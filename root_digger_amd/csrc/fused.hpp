@@ -39,7 +39,7 @@ struct FusedJob {
   const FusedOp *prog;   // device
   const double  *brlen;  // device, indexed by P-matrix index
   uint32_t n_ops, depth;
-  // 4 states: jobs[0].pad is set by the P-matrix step when a tip-table entry of the
+  // 4 states: jobs[0].tt_unsafe is set by the P-matrix step when a tip-table entry of the
   // LAUNCH lies in (0, 2^-128).  While it is 0, the product of two tip rows is either 0
   // or >= 2^-256, a tip-tip step can never need a rescale, and the evaluator variant
   // without that test runs (kernels_fused.hip).

@@ -430,6 +430,10 @@ hipError_t launch_clv_k20_traversal(rdamd_partition *p, const LevelOp *d_ops, un
   DeviceView v = p->view();
   const unsigned gx = (p->sites + 15) / 16;
   const size_t lds = (size_t)p->rate_cats * kMfmaLdsWave;   // 12 KB per wave
+#ifdef RDAMD_ABLATION
+  // timing-only variants (stores / loads / arithmetic switched off: results are garbage).
+  // They exist only in the ablation build (`make ablation` -> ../lib/librdamd_ablation.so,
+  // used by profiles/k20_ab.sh); the product library ignores RDAMD_K20_VAR.
   static const int var = getenv("RDAMD_K20_VAR") ? atoi(getenv("RDAMD_K20_VAR")) : 0;
 #define RDAMD_K20_CASE(V) case V: clv_k20_traversal_kernel<256, V><<<gx, 64 * p->rate_cats, lds, p->stream>>>(v, p->d_pmat_mfma, d_ops, nops); break;
   if (p->rate_cats <= 4)
@@ -438,6 +442,10 @@ hipError_t launch_clv_k20_traversal(rdamd_partition *p, const LevelOp *d_ops, un
       RDAMD_K20_CASE(13) RDAMD_K20_CASE(16) RDAMD_K20_CASE(17) RDAMD_K20_CASE(29) RDAMD_K20_CASE(31)
       default: clv_k20_traversal_kernel<256><<<gx, 64 * p->rate_cats, lds, p->stream>>>(v, p->d_pmat_mfma, d_ops, nops);
     }
+#else
+  if (p->rate_cats <= 4)
+    clv_k20_traversal_kernel<256><<<gx, 64 * p->rate_cats, lds, p->stream>>>(v, p->d_pmat_mfma, d_ops, nops);
+#endif
   else
     clv_k20_traversal_kernel<1024><<<gx, 64 * p->rate_cats, lds, p->stream>>>(v, p->d_pmat_mfma, d_ops, nops);
   return hipGetLastError();

@@ -101,7 +101,7 @@ __device__ __forceinline__ void combine(const double (&tx)[4], const double (&ty
 }
 
 // TTCHECK: rescale test on tip-tip steps too.  Both variants of a launch are queued;
-// each looks at the launch-wide flag the P-matrix step left in jobs[0].pad (some
+// each looks at the launch-wide flag the P-matrix step left in jobs[0].tt_unsafe (some
 // tip-table entry in (0, 2^-128)) and the one it does not belong to returns at once.
 // RL: stack levels that live in registers (1 or 2).  The second one costs 18 VGPRs per
 // lane at two sites per lane (142: three waves per SIMD) and is taken when it frees
@@ -135,7 +135,7 @@ fused_dna_eval_kernel(FusedArgs a) {
   // the launch >= 2^-128 (checked where the tables are built) the product is 0 or
   // >= 2^-256 and the rescale test cannot fire on a non-zero vector: it is compiled
   // out of the variant that runs then (+3.5 % on c2; a run-time branch gave nothing)
-  if ((uni(a.jobs[0].pad) != 0u) != TTCHECK) return;
+  if ((uni(a.jobs[0].tt_unsafe) != 0u) != TTCHECK) return;
   constexpr bool tt_safe = !TTCHECK;
   const FusedJob jb = a.jobs[job];
   const FusedOp *__restrict__ prog = jb.prog;   // n_ops + 2 entries (tail padded)
@@ -421,7 +421,7 @@ fused_pmatrix_k4_kernel(const double *__restrict__ q, const double *__restrict__
   double *pmo = pmat + (size_t)job * pmat_job_stride + ((size_t)m * R + r) * 16;
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
-    out[i] = out[i] < 0.0 ? 0.0 : out[i];
+    out[i] = out[i] <= 0.0 ? 0.0 : out[i];   // (<=: a -0.0 becomes +0.0 -- the rescale tests read high words)
     pmo[i] = out[i];
   }
   // tip table of this (matrix, rate): row c = sum over the states in code c
@@ -441,7 +441,7 @@ fused_pmatrix_k4_kernel(const double *__restrict__ q, const double *__restrict__
   bool tiny = false;
 #pragma unroll
   for (int i = 0; i < 16; ++i) tiny = tiny || (out[i] > 0.0 && out[i] < 0x1p-128);
-  if (tiny) jobs[0].pad = 1u;   // launch-wide (every writer stores the same value)
+  if (tiny) jobs[0].tt_unsafe = 1u;   // launch-wide (every writer stores the same value)
 }
 
 hipError_t launch_fused_pmatrix(const FusedArgs &a, const double *d_q, const double *d_rates,

@@ -197,7 +197,7 @@ fused20_pmatrix_kernel(const double *__restrict__ q, const double *__restrict__ 
   for (unsigned e = tid; e < (unsigned)kCopy; e += 128) {
     const unsigned i = e & 3, k = (e >> 2) & 3, blk = e >> 4, ks = blk % kSteps, rg = blk / kSteps;
     const double v = out[(4 * rg + i) * kK + 4 * ks + k];
-    o[e] = v < 0.0 ? 0.0 : v;
+    o[e] = v <= 0.0 ? 0.0 : v;   // (<=: no -0.0 either -- the rescale test reads high words)
   }
   // tip table, one 192-byte row per code: positions 0-7 = (s, g) for s = 0, 1 as pairs
   // [g][s], 8-15 the same for s = 2, 3, 16-19 = s = 4 by g, 20-23 padding; entry (s, g) =
@@ -213,7 +213,7 @@ fused20_pmatrix_kernel(const double *__restrict__ q, const double *__restrict__ 
       const uint64_t mask = codemask[cc];
       const double *row = out + (4 * sidx + g) * kK;
       for (unsigned j = 0; j < (unsigned)kK; ++j) {
-        const double v = row[j] < 0.0 ? 0.0 : row[j];
+        const double v = row[j] <= 0.0 ? 0.0 : row[j];
         acc += ((mask >> j) & 1) ? v : 0.0;
       }
     }
@@ -446,8 +446,9 @@ fused20_eval_kernel(Fused20Args a, unsigned depth) {
 #pragma unroll
           for (int s = 0; s < kSteps; ++s) v[q][s] = d1[q][s] * y[s];
         }   // (tip-tip: v was formed at the top of the step)
-        // all five entries < 2^-256: entries are non-negative, so the largest high word
-        // decides (two v_max3_u32 + one compare instead of five FP64 compares; a NaN
+        // all five entries < 2^-256: entries are non-negative and never -0.0 (P-matrix and
+        // table entries are clamped with `<= 0 ? +0`, and sums / products of such values
+        // keep the sign bit clear), so the largest high word decides (two v_max3_u32 + one compare instead of five FP64 compares; a NaN
         // compares as large and never rescales, as with `<`)
         unsigned hmax = 0u;
 #pragma unroll

@@ -56,7 +56,7 @@ pmatrix_k4_kernel(const double *__restrict__ q, const double *__restrict__ rates
   double *pm = pmat + slot * 16;
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
-    out[i] = out[i] < 0.0 ? 0.0 : out[i];
+    out[i] = out[i] <= 0.0 ? 0.0 : out[i];   // (<=: a -0.0 becomes +0.0 -- the rescale tests read high words)
     pm[i] = out[i];
   }
   double *tt = tiptab + slot * ncodes_cap * 4;
@@ -133,7 +133,7 @@ pmatrix_generic_kernel(const double *__restrict__ q, const double *__restrict__ 
   size_t slot = (size_t)mat_idx[m] * R + r;
   double *pm = pmat + slot * KK;
   for (unsigned e = tid; e < KK; e += nt) {
-    double v = out[e] < 0.0 ? 0.0 : out[e];
+    double v = out[e] <= 0.0 ? 0.0 : out[e];   // (<=: no -0.0 -- the rescale tests read high words)
     out[e] = v;
     pm[e] = v;
   }

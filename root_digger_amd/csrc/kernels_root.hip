@@ -240,7 +240,7 @@ root_single_dna_kernel(DeviceView v, LevelOp op, RootSingleArgs ra, const double
     double out[16];
     expm_k4(q + (size_t)ra.params_idx[r] * 16, (c ? ra.len2[a] : ra.len1[a]) * rates[r], out);
 #pragma unroll
-    for (int i = 0; i < 16; ++i) spm[a][c][r][i] = out[i] < 0.0 ? 0.0 : out[i];
+    for (int i = 0; i < 16; ++i) spm[a][c][r][i] = out[i] <= 0.0 ? 0.0 : out[i];
   }
   __syncthreads();
   for (unsigned e = tid; e < NA * 2 * R * 64; e += 256) {

@@ -76,6 +76,7 @@ model_t::~model_t() {
     if (p) rdamd_partition_destroy(p);
   if (_sweep) rdamd_partition_destroy(_sweep);
   if (_d_reduce) (void)hipFree(_d_reduce);
+  if (_h_reduce) (void)hipHostFree(_h_reduce);
 }
 
 // ---- site-group reduction ---------------------------------------------
@@ -83,8 +84,12 @@ double *model_t::reduce_scratch(size_t n) {
   if (n > _d_reduce_cap) {
     if (_d_reduce) (void)hipFree(_d_reduce);
     _d_reduce = nullptr;
+    if (_h_reduce) (void)hipHostFree(_h_reduce);
+    _h_reduce = nullptr;
     _d_reduce_cap = std::max<size_t>(n, 256);
-    if (hipMalloc((void **)&_d_reduce, _d_reduce_cap * sizeof(double)) != hipSuccess) {
+    // (the pinned twin: scalar lnLs go up and come back without a pageable staging copy)
+    if (hipMalloc((void **)&_d_reduce, _d_reduce_cap * sizeof(double)) != hipSuccess ||
+        hipHostMalloc((void **)&_h_reduce, _d_reduce_cap * sizeof(double), hipHostMallocDefault) != hipSuccess) {
       _d_reduce_cap = 0;
       throw std::runtime_error("site-group reduction: hipMalloc failed");
     }
@@ -102,11 +107,13 @@ void model_t::reduce_values(double *values, size_t n) {
   }
   double *d = reduce_scratch(n);
   hipStream_t st = (hipStream_t)rdamd_partition_stream(_partitions[0]);
-  if (hipMemcpyAsync(d, values, n * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess ||
+  std::copy(values, values + n, _h_reduce);
+  if (hipMemcpyAsync(d, _h_reduce, n * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess ||
       _reduce(d, (unsigned)n, st, _reduce_user) != RDAMD_SUCCESS ||
-      hipMemcpyAsync(values, d, n * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess ||
+      hipMemcpyAsync(_h_reduce, d, n * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess ||
       hipStreamSynchronize(st) != hipSuccess)
-    throw std::runtime_error("site-group reduction failed");
+    throw std::runtime_error(std::string("site-group reduction failed: ") + rdamd_errmsg());
+  std::copy(_h_reduce, _h_reduce + n, values);
 }
 
 // ---- setters ----------------------------------------------------------------

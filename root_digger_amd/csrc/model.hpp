@@ -242,6 +242,7 @@ private:
   bool                                   _reduce_device = false;
   double                                *_d_reduce = nullptr;
   size_t                                 _d_reduce_cap = 0;
+  double                                *_h_reduce = nullptr;   // pinned twin of _d_reduce
   rooted_tree_t                          _tree;
   std::vector<rdamd_partition_t *>       _partitions;
   std::vector<rate_category>             _rate_category_types;

@@ -237,6 +237,11 @@ static int run(int argc, char **argv) {
       o.root_ratio = h.root_ratio; o.strategy = h.initial_root_strategy; o.early_stop = h.early_stop;
     }
   }
+  // (again, now that a resumed run's saved options are in: a partition file that comes from
+  // the checkpoint would build the whole partitioned model on every member of a site group
+  // while the group's reduction is installed, and every lnL would be counted G times)
+  if (G > 1 && !o.partition.empty())
+    die("--site-shards: the checkpoint belongs to a run with a partition file, which a site group does not support");
   if (o.msa.empty()) { std::puts("No MSA was given, please supply an MSA"); usage(); return 1; }
   if (o.tree.empty()) { std::puts("No tree was given, please supply an tree"); usage(); return 1; }
 
@@ -296,6 +301,19 @@ static int run(int argc, char **argv) {
   if (o.lockstep < 0) o.lockstep = (!o.lbfgsb.empty() && o.partition.empty()) ? 16 : 0;
   if (G > 1) o.lockstep = o.workers = 0;   // a site group walks its candidates in step
 
+  // While the ranks search they exchange nothing over the rendezvous: the end of a
+  // connection now means that a rank has died.  Nobody must stay behind inside a
+  // collective (or wait for the dead rank's checkpoint records): abort the site group's
+  // communicator and leave; closing our own connections passes the news on.
+  const auto watch_ranks = [&ranks, comm, rank] {
+    ranks.watch([comm, rank] {
+      std::fprintf(stderr, "[rank %d] another rank of this run has gone; giving up\n", rank);
+      if (comm) rdamd_comm_abort(comm);
+      std::this_thread::sleep_for(std::chrono::seconds(comm ? 2 : 0));   // let a blocked reducer fail first
+      std::_Exit(3);
+    });
+  };
+
   // ---- the search (src/main.cpp:586-635)
   std::vector<uint64_t> ids(roots);
   std::vector<double> llh(roots), alpha(roots);
@@ -306,6 +324,7 @@ static int run(int argc, char **argv) {
   if (o.exhaustive) {
     need(rdamd_model_assign_by_rank_checkpoint(model, (unsigned)cgroup, (unsigned)cgroups, ckp), "assign");
     ranks.barrier();
+    watch_ranks();
     if (!o.silent && rank == 0) {
       std::puts("Starting exhaustive search");
       rdamd_model_set_progress(model, 1);
@@ -327,6 +346,7 @@ static int run(int argc, char **argv) {
     need(rdamd_model_assign_by_rank_search(model, o.min_roots, o.root_ratio, (unsigned)cgroup,
                                            (unsigned)cgroups, o.strategy, ckp), "assign");
     ranks.barrier();
+    watch_ranks();
     std::vector<uint64_t> mine(roots);
     const int assigned = rdamd_model_assigned(model, mine.data(), roots);
     if (!o.silent && rank == 0) {

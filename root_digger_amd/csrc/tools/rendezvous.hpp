@@ -5,6 +5,12 @@
 //
 //  * barrier(), allgather(): over the world star (set-up traffic only: the
 //    checkpoint hand-shake, the RCCL unique ids of the site groups);
+//  * watch(): while the ranks search (no rendezvous traffic at all), a thread looks
+//    for the END of a peer's connection -- a rank that died, for whatever reason,
+//    closes its sockets -- and calls the program's handler, which aborts the RCCL
+//    communicator its own rank may be blocked in and exits.  Rank 0 sees every rank
+//    and goes down with any of them; the others see rank 0: one lost rank takes the
+//    whole run down in two hops instead of leaving G-1 ranks inside ncclAllReduce;
 //  * site_group_t: a second star inside one site group whose leader sums host
 //    arrays of doubles in rank order and sends the sums back -- the HOST
 //    fallback of the lnL all-reduce for runs whose ranks share one device (RCCL
@@ -15,10 +21,14 @@
 #include <arpa/inet.h>
 #include <netinet/in.h>
 #include <netinet/tcp.h>
+#include <poll.h>
 #include <sys/socket.h>
 #include <unistd.h>
 
+#include <atomic>
+#include <cerrno>
 #include <chrono>
+#include <functional>
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
@@ -121,7 +131,36 @@ public:
     }
   }
   ~rendezvous_t() {
+    unwatch();
     for (int fd : _peers) close(fd);
+  }
+  // From now until unwatch(): `on_loss` runs (once, on the watcher thread) when a peer's
+  // connection ends.  Bytes a peer sends meanwhile -- it has finished and waits in the
+  // next barrier -- are left alone and end the watch on that connection.
+  void watch(std::function<void()> on_loss) {
+    if (_world <= 1 || _watcher.joinable()) return;
+    _stop = false;
+    _watcher = std::thread([this, on_loss] {
+      std::vector<pollfd> fds;
+      for (int fd : _peers) fds.push_back(pollfd{fd, POLLIN, 0});
+      while (!_stop.load()) {
+        if (poll(fds.data(), fds.size(), 100) <= 0) continue;
+        for (pollfd &f : fds) {
+          if (f.fd < 0 || !(f.revents & (POLLIN | POLLHUP | POLLERR))) continue;
+          char byte;
+          const ssize_t k = recv(f.fd, &byte, 1, MSG_PEEK | MSG_DONTWAIT);
+          if (k > 0) { f.fd = -1; continue; }          // barrier traffic of a rank that is done
+          if (k < 0 && (errno == EAGAIN || errno == EWOULDBLOCK)) continue;
+          if (_stop.load()) return;
+          on_loss();                                     // EOF or a broken connection
+          return;
+        }
+      }
+    });
+  }
+  void unwatch() {
+    _stop = true;
+    if (_watcher.joinable()) _watcher.join();
   }
   rendezvous_t(const rendezvous_t &) = delete;
   rendezvous_t &operator=(const rendezvous_t &) = delete;
@@ -129,6 +168,7 @@ public:
   int world() const { return _world; }
 
   void barrier() {
+    unwatch();   // (from here on the connections carry data again)
     char byte = 1;
     std::vector<char> all;
     allgather(&byte, 1, all);
@@ -142,7 +182,22 @@ public:
     }
     if (_rank == 0) {
       std::memcpy(all.data(), mine, bytes);
-      for (int r = 1; r < _world; ++r) recv_all(_peers[(size_t)r - 1], all.data() + bytes * (size_t)r, bytes);
+      // whichever rank is ready first is read first, so that the end of ANY connection is
+      // seen at once (a rank that died while others are still searching)
+      std::vector<pollfd> fds;
+      for (int fd : _peers) fds.push_back(pollfd{fd, POLLIN, 0});
+      for (int pending = _world - 1; pending > 0;) {
+        if (poll(fds.data(), fds.size(), -1) < 0) {
+          if (errno == EINTR) continue;
+          throw std::runtime_error("rendezvous: poll failed");
+        }
+        for (size_t i = 0; i < fds.size(); ++i) {
+          if (fds[i].fd < 0 || !(fds[i].revents & (POLLIN | POLLHUP | POLLERR))) continue;
+          recv_all(fds[i].fd, all.data() + bytes * (i + 1), bytes);   // throws at the end of a connection
+          fds[i].fd = -1;
+          --pending;
+        }
+      }
       for (int fd : _peers) send_all(fd, all.data(), all.size());
     } else {
       send_all(_peers[0], mine, bytes);
@@ -153,6 +208,8 @@ public:
 private:
   int _rank, _world;
   std::vector<int> _peers;   // rank 0: peer of rank r at [r - 1]; others: rank 0
+  std::thread _watcher;
+  std::atomic<bool> _stop{false};
 };
 
 // Site group = ranks [leader, leader + size) of the world; host-side sum of

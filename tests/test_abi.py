@@ -60,6 +60,16 @@ def test_product_does_not_link_the_oracle():
                 assert "rd_oracle" not in src and "oracle_lib" not in src, f
 
 
+def test_product_library_has_no_timing_only_switches():
+    """the ablation variants (kernels with stores / loads removed, chosen by
+    RDAMD_K20_VAR / RDAMD_FUSED_NS) exist only behind -DRDAMD_ABLATION in a second library;
+    librdamd.so must not even know the variable names."""
+    blob = open(rd.lib_path, "rb").read()
+    assert os.path.basename(rd.lib_path) == "librdamd.so"
+    for name in (b"RDAMD_K20_VAR", b"RDAMD_FUSED_NS"):
+        assert name not in blob, name
+
+
 def test_host_side_gamma_and_maps_work_without_gpu():
     r = rd.compute_gamma_cats(1.0, 4)
     assert abs(sum(r) / 4 - 1.0) < 1e-12

@@ -217,6 +217,33 @@ def test_bench_refuses_a_world_size_that_contradicts_gpus():
     assert out.returncode != 0 and "WORLD_SIZE (1) != --gpus (2)" in out.stderr
 
 
+@pytest.mark.parametrize("world,victim", [(4, 2), (3, 0)])
+def test_rd_amd_ranks_notice_a_dead_rank(tmp_path, world, victim):
+    """a rank that dies mid-search must not leave the others inside a collective.
+    rd_amd's ranks watch their rendezvous connections while they search
+    (rendezvous_t::watch); the handler aborts the RCCL communicator and exits.  Here: the
+    victim dies silently, every survivor's handler must run within seconds -- through rank 0
+    when the victim is not rank 0 (two hops)."""
+    import subprocess
+    import time
+    root = os.path.dirname(HERE)
+    exe = str(tmp_path / "rendezvous_check")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I",
+                           os.path.join(root, "root_digger_amd", "csrc", "tools"),
+                           os.path.join(HERE, "cpp", "rendezvous_check.cpp"), "-o", exe, "-lpthread"])
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    t0 = time.monotonic()
+    procs = [subprocess.Popen([exe, str(r), str(world), "watch", str(victim)], env=env,
+                              stdout=subprocess.PIPE, text=True) for r in range(world)]
+    outs = [p.communicate(timeout=60)[0] for p in procs]
+    assert time.monotonic() - t0 < 15
+    for r, (p, out) in enumerate(zip(procs, outs)):
+        if r == victim:
+            assert p.returncode == 9
+        else:
+            assert p.returncode == 3 and out.strip() == "%d lost" % r, (r, p.returncode, out)
+
+
 @pytest.mark.parametrize("world,group", [(2, 2), (4, 2), (3, 1)])
 def test_rd_amd_rendezvous_and_host_site_group_sum(tmp_path, world, group):
     """rd_amd's own channel (csrc/tools/rendezvous.hpp): TCP star allgather + the
