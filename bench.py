@@ -165,6 +165,9 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0,
                     help="budget for the cpu_baseline leg (rank 0, N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-repeats", action="store_true",
+                    help="4-state partitions: without RDAMD_ATTRIB_SITE_REPEATS (the reference sets "
+                         "CORAX_ATTRIB_SITE_REPEATS for every 4-state run, src/model.cpp:145-149; A/B only)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + --device lets several ranks share one GPU (how the N>1 code "
                          "path is exercised on a one-GPU box); the driver's runs use nccl (RCCL)")
@@ -249,7 +252,8 @@ def main():
         for i, ch in enumerate(w["alphabet"]):
             cmap[ord(ch)] = 1 << i
 
-    part = rd.Partition.for_tree(tree, K, S, R)
+    repeats = K == 4 and not args.no_repeats
+    part = rd.Partition.for_tree(tree, K, S, R, attributes=rd.ATTRIB_SITE_REPEATS if repeats else 0)
     for label, seq in w["seqs"].items():
         part.set_tip_states(tree.tip_index(label), cmap, seq)
     freqs = part.empirical_frequencies()
@@ -290,6 +294,7 @@ def main():
     if use_fused:
         scheds = [part.schedule(*tree.generate_operations(rl)) for rl in roots]
         depth = max(sc.stack_depth() for sc in scheds)
+        sched_stats = [sc.stats() for sc in scheds]
 
     def step(s):
         """one batch: jobs rotate through this rank's candidates; parameters are

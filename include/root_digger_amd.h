@@ -202,6 +202,31 @@ void         rdamd_schedule_destroy(rdamd_schedule_t *s);
 /* LDS stack slots per site the compiled traversal needs (diagnostic). */
 unsigned int rdamd_schedule_stack_depth(const rdamd_schedule_t *s);
 
+/* Subtree site repeats (coraxlib's CORAX_ATTRIB_SITE_REPEATS, which the reference sets for
+ * every 4-state partition, src/model.cpp:145-149).  A partition created with
+ * RDAMD_ATTRIB_SITE_REPEATS compiles its schedules with them: a directed subtree below
+ * which the alignment's columns fall into at most `max_classes` distinct tip patterns is
+ * evaluated once per pattern class and job (a small table) instead of once per site, and the
+ * traversal meets it as one more tip.  Results are those of the plain traversal; 4-state
+ * (and embedded binary) partitions only, ignored otherwise.
+ * rdamd_partition_set_site_repeats changes the class limit for schedules compiled from then
+ * on (0 = off; the attribute's default and the largest accepted value is 16). */
+int rdamd_partition_set_site_repeats(rdamd_partition_t *p, unsigned int max_classes);
+/* What one (site, rate) executes per traversal of a compiled schedule, and what the
+ * repeats saved: the denominators of the roofline figures (bench.py). */
+typedef struct rdamd_schedule_stats {
+  unsigned int operations;     /* operations of the caller's list (n - 1) */
+  unsigned int steps;          /* operations left after folding clades into pseudo-tips */
+  unsigned int matvecs;        /* 4x4 matrix-vector products per (site, rate) in those steps */
+  unsigned int matvecs_plain;  /* ... in the plain program (= inner children of the list) */
+  unsigned int pseudo_tips;    /* clades folded */
+  unsigned int clade_nodes;    /* their nodes = operations evaluated per class instead of per site */
+  unsigned int clade_rows;     /* table rows (class x node) computed per job and rate category */
+  unsigned int stack_depth;    /* LDS stack levels of the program that runs */
+  unsigned int stack_depth_plain;
+} rdamd_schedule_stats_t;
+int rdamd_schedule_stats(const rdamd_schedule_t *s, rdamd_schedule_stats_t *out);
+
 /* lnl_out[j] = log-likelihood of job j.  Row-major parameter blocks, K = the
  * partition's states: subst [n_jobs][K*K-K] (corax_set_subst_params order),
  * freqs [n_jobs][K],

@@ -28,6 +28,8 @@ from .api import (  # noqa: F401
     compute_gamma_cats,
     GAMMA_RATES_MEAN,
     GAMMA_RATES_MEDIAN,
+    ATTRIB_SITE_REPEATS,
+    ATTRIB_NONREV,
     device_count,
     set_device,
     device_memory,
@@ -39,5 +41,6 @@ __all__ = [
     "msa_partition_probe",
     "checkpoint_checksum_result", "checkpoint_checksum_params",
     "MAP_NT", "MAP_BIN", "compute_gamma_cats", "GAMMA_RATES_MEAN", "GAMMA_RATES_MEDIAN",
+    "ATTRIB_SITE_REPEATS", "ATTRIB_NONREV",
     "device_count", "set_device", "device_memory", "msa_probe",
 ]

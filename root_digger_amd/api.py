@@ -8,6 +8,8 @@ from ._lib import lib, RdamdError
 
 GAMMA_RATES_MEAN = 0
 GAMMA_RATES_MEDIAN = 1
+ATTRIB_SITE_REPEATS = 1 << 10   # RDAMD_ATTRIB_SITE_REPEATS (CORAX_ATTRIB_SITE_REPEATS, src/model.cpp:145-149)
+ATTRIB_NONREV = 1 << 11
 SCALE_BUFFER_NONE = -1
 
 
@@ -89,6 +91,16 @@ _sig("rdamd_root_loglikelihood_fused", C.c_int, _vp, _pop, _pu, _pd, _pd, _u, _p
 _sig("rdamd_schedule_create", _vp, _vp, _pop, _u, _pu, _pd, _u)
 _sig("rdamd_schedule_destroy", None, _vp)
 _sig("rdamd_schedule_stack_depth", _u, _vp)
+
+
+class ScheduleStats(C.Structure):
+    """rdamd_schedule_stats_t"""
+    _fields_ = [(k, C.c_uint) for k in ("operations", "steps", "matvecs", "matvecs_plain", "pseudo_tips",
+                                        "clade_nodes", "clade_rows", "stack_depth", "stack_depth_plain")]
+
+
+_sig("rdamd_schedule_stats", C.c_int, _vp, C.POINTER(ScheduleStats))
+_sig("rdamd_partition_set_site_repeats", C.c_int, _vp, _u)
 _sig("rdamd_evaluate_batch", C.c_int, _vp, _u, C.POINTER(_vp), _pd, _pd, _pd, _pd, _pd)
 _sig("rdamd_evaluate_batch_device", C.c_int, _vp, _u, C.POINTER(_vp), _pd, _pd, _pd, _pd, _vp)
 _sig("rdamd_get_clv", C.c_int, _vp, _u, _pd)
@@ -487,6 +499,13 @@ class Schedule:
     def stack_depth(self):
         return lib.rdamd_schedule_stack_depth(self._h)
 
+    def stats(self):
+        """dict of rdamd_schedule_stats_t: what one (site, rate) executes per traversal."""
+        st = ScheduleStats()
+        if lib.rdamd_schedule_stats(self._h, C.byref(st)) != 1:
+            _fail("schedule_stats")
+        return {k: getattr(st, k) for k, _ in ScheduleStats._fields_}
+
     def destroy(self):
         if getattr(self, "_h", None) and getattr(self._part, "_h", None):
             lib.rdamd_schedule_destroy(self._h)
@@ -527,6 +546,11 @@ class Partition:
     @property
     def handle(self):
         return self._h
+
+    def set_site_repeats(self, max_classes):
+        """rdamd_partition_set_site_repeats: class limit of the pseudo-tips (0 = off)."""
+        if lib.rdamd_partition_set_site_repeats(self._h, max_classes) != 1:
+            _fail("partition_set_site_repeats")
 
     def set_tip_states(self, tip_index, cmap, sequence):
         if isinstance(sequence, str):

@@ -15,6 +15,8 @@ namespace rdamd {
 
 struct FusedWorkspace;
 void fused_workspace_free(FusedWorkspace *w);
+struct CladeCache;
+void clade_cache_free(CladeCache *c);
 
 // 2^256 and 2^-256: the per-site scaling constants.
 constexpr double kScaleFactor =
@@ -90,7 +92,12 @@ struct rdamd_partition {
   // ---- HBM-resident state ------------------------------------------------
   uint8_t  *d_tipcodes = nullptr;
   uint8_t  *d_tipcodes16 = nullptr;   // 4 states: code x 16 = the byte offset of the code's row in the fused
-                                      // evaluator's LDS tip tables (no shift per tip child and step)
+                                      // evaluator's LDS tip tables (no shift per tip child and step).
+                                      // An ARENA of rows: [0, tips) the tips, behind them the class codes of
+                                      // the pseudo-tips (clades.hpp), appended as schedules discover them
+  unsigned  code_rows = 0, code_rows_cap = 0;   // rows in use / allocated (tip_stride() bytes each)
+  rdamd::CladeCache *clades = nullptr;          // subtree site repeats (RDAMD_ATTRIB_SITE_REPEATS)
+  unsigned  tip_generation = 0;                 // bumped by rdamd_set_tip_states: schedules with pseudo-tips go stale
   double   *d_clv = nullptr;
   // CLV layout on the device.  The C ABI's layout ([site][rate][state], coraxlib's) is what
   // rdamd_get_clv hands out.  Partitions that run on clv_k20_traversal_kernel keep a CLV in

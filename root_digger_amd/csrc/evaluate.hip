@@ -12,6 +12,7 @@
 #include <unordered_map>
 
 #include <cstdlib>
+#include "clades.hpp"
 #include "common.hpp"
 #include "fused.hpp"
 
@@ -22,6 +23,17 @@ struct rdamd_schedule {
   unsigned n_ops = 0, depth = 0;      // depth: LDS stack levels the program needs
   unsigned reg_levels = 1;            // register stack levels it was compiled for
   std::vector<rdamd::FusedOp> prog;   // host copy (tests / debugging)
+  // subtree site repeats (clades.hpp): d_prog is then the program WITH pseudo-tips and the
+  // plain program of the caller's full operation list is kept beside it (it runs when a
+  // launch's tables make the pseudo-tips' missing rescale counts matter, fused.hpp)
+  rdamd::FusedOp *d_prog_plain = nullptr;     // == d_prog without pseudo-tips
+  unsigned n_ops_plain = 0, depth_plain = 0, reg_levels_plain = 1;
+  rdamd::CladeStep *d_steps = nullptr;
+  rdamd::CladeGroup *d_groups = nullptr;
+  unsigned n_steps = 0, n_groups = 0;
+  unsigned tip_generation = 0;
+  // what one (site, rate) executes: operations and matrix-vector products per traversal
+  unsigned matvecs = 0, matvecs_plain = 0, clade_rows = 0;
 };
 
 namespace rdamd {
@@ -32,6 +44,8 @@ struct FusedWorkspace {
   FusedJob *d_jobs = nullptr;   // ... and where this batch's pieces sit inside it
   double *d_q = nullptr, *d_rates = nullptr, *d_freqs = nullptr, *d_rw = nullptr;
   double *d_pmat = nullptr, *d_tiptab = nullptr, *d_partials = nullptr, *d_out = nullptr;
+  double *d_clade_scratch = nullptr;   // nested clade tables of a launch: [job][step][rate][16][4]
+  size_t clade_scratch_doubles = 0;
   double *h_out = nullptr;   // pinned
   char *h_in = nullptr;      // pinned parameter staging
   size_t h_in_bytes = 0;
@@ -39,7 +53,7 @@ struct FusedWorkspace {
 
 void fused_workspace_free(FusedWorkspace *w) {
   if (!w) return;
-  void *dev[] = {w->d_in, w->d_pmat, w->d_tiptab, w->d_partials, w->d_out};
+  void *dev[] = {w->d_in, w->d_pmat, w->d_tiptab, w->d_partials, w->d_out, w->d_clade_scratch};
   for (void *d : dev)
     if (d) (void)hipFree(d);
   if (w->h_out) (void)hipHostFree(w->h_out);
@@ -53,7 +67,7 @@ static hipError_t ensure_workspace(rdamd_partition *p, unsigned n_jobs) {
   if (n_jobs <= w->cap_jobs) return hipSuccess;
   hipError_t e = hipStreamSynchronize(p->stream);
   if (e != hipSuccess) return e;
-  void *dev[] = {w->d_in, w->d_pmat, w->d_tiptab, w->d_partials, w->d_out};
+  void *dev[] = {w->d_in, w->d_pmat, w->d_tiptab, w->d_partials, w->d_out, w->d_clade_scratch};
   for (void *d : dev)
     if (d) (void)hipFree(d);
   if (w->h_out) (void)hipHostFree(w->h_out);
@@ -98,12 +112,17 @@ struct Compiler {
   bool split_park = false;   // 20-state programs: parking is a step of its own
   unsigned reg_levels = 1;   // stack levels the kernel keeps in registers (4 states: 1 or 2)
   std::unordered_map<unsigned, unsigned> producer;   // clv -> op index
+  // pseudo-tips (clades.hpp): clv of a collapsed clade -> row of its class codes in the code
+  // arena; to the compiler such a child is a tip whose table sits in its branch's slot
+  std::unordered_map<unsigned, unsigned> pseudo_row;
+  unsigned matvecs = 0;                              // inner children = matrix-vector products per (site, rate)
   std::vector<unsigned> need;                        // stack slots a subtree needs
   std::vector<FusedOp> out;
   unsigned depth = 0, max_depth = 0;
   bool ok = true;
 
-  bool is_inner(unsigned clv) const { return clv >= tips; }
+  bool is_inner(unsigned clv) const { return clv >= tips && !pseudo_row.count(clv); }
+  unsigned row_of(unsigned clv) const { return clv < tips ? clv : pseudo_row.at(clv); }
 
   unsigned compute_need(unsigned i) {
     const rdamd_operation_t &o = ops[i];
@@ -129,8 +148,8 @@ struct Compiler {
     if (!i1 && !i2) {
       kind = kFusedTT;
       spill = live ? 1 : 0;
-      tipX_row = o.child1_clv_index; matX = o.child1_matrix_index;
-      tipY_row = o.child2_clv_index; matY = o.child2_matrix_index;
+      tipX_row = row_of(o.child1_clv_index); matX = o.child1_matrix_index;
+      tipY_row = row_of(o.child2_clv_index); matY = o.child2_matrix_index;
       if (live) {
         matM = park_mat;              // pre-multiply the parked CLV
         if (depth == 0) spill |= 2;   // level 0 is a register slot in the kernel
@@ -152,7 +171,7 @@ struct Compiler {
       emit(producer.at(first_inner ? o.child1_clv_index : o.child2_clv_index), live, park_mat);
       kind = kFusedRT;
       matM = first_inner ? o.child1_matrix_index : o.child2_matrix_index;
-      tipY_row = first_inner ? o.child2_clv_index : o.child1_clv_index;
+      tipY_row = row_of(first_inner ? o.child2_clv_index : o.child1_clv_index);
       matY = first_inner ? o.child2_matrix_index : o.child1_matrix_index;
     } else {
       const unsigned a = producer.at(o.child1_clv_index), b = producer.at(o.child2_clv_index);
@@ -167,6 +186,7 @@ struct Compiler {
       if (depth == 0) spill |= 4;     // the popped sibling sits in the register slot
       else if (depth == 1 && reg_levels >= 2) spill |= 16;
     }
+    matvecs += (i1 ? 1u : 0u) + (i2 ? 1u : 0u);
     f.pM = matM * unit;
     f.tX = matX * unit;
     f.tY = matY * unit;
@@ -205,48 +225,30 @@ rdamd_schedule_t *rdamd_schedule_create(rdamd_partition_t *p, const rdamd_operat
                   "32-bit offsets (tips*sites or matrices*rates*512 >= 4 GiB)");
     return nullptr;
   }
-  Compiler c;
-  c.ops = ops; c.n_ops = n_ops; c.tips = p->tips; c.sites = p->sites; c.tip_stride = p->tip_stride(); c.rate_cats = p->rate_cats;
-  c.unit = p->rate_cats * (k20 ? 3200u : 128u);
-  c.split_park = k20;
+  // ---- validation: a full post-order traversal ------------------------------------------
   const unsigned nclv = p->tips + p->clv_buffers;
+  std::unordered_map<unsigned, unsigned> producer;   // clv -> op index
+  std::vector<int> consumer(n_ops, -1);              // op -> the op that takes its result
   for (unsigned i = 0; i < n_ops; ++i) {
     const rdamd_operation_t &o = ops[i];
     bool bad = o.parent_clv_index < p->tips || o.parent_clv_index >= nclv ||
                o.child1_clv_index >= nclv || o.child2_clv_index >= nclv ||
                o.child1_matrix_index >= p->prob_matrices ||
                o.child2_matrix_index >= p->prob_matrices;
-    for (unsigned ch : {o.child1_clv_index, o.child2_clv_index})
-      if (ch >= p->tips && !c.producer.count(ch)) bad = true;   // not yet computed
-    if (c.producer.count(o.parent_clv_index)) bad = true;       // written twice
+    for (unsigned ch : {o.child1_clv_index, o.child2_clv_index}) {
+      if (ch < p->tips) continue;
+      auto it = producer.find(ch);
+      if (it == producer.end() || consumer[it->second] >= 0) bad = true;   // not yet computed / used twice
+      else consumer[it->second] = (int)i;
+    }
+    if (producer.count(o.parent_clv_index)) bad = true;       // written twice
     if (bad) {
       set_error(42, "rdamd_schedule_create: operation %u is not part of a valid post-order "
                     "traversal (the fused evaluator needs the full schedule of "
                     "generate_operations)", i);
       return nullptr;
     }
-    c.producer[o.parent_clv_index] = i;
-  }
-  c.need.assign(n_ops, 0);
-  c.compute_need(n_ops - 1);
-  c.out.reserve(n_ops);
-  c.emit(n_ops - 1, false, 0);
-  // 4 states: a program that would need three or more LDS stack levels is compiled for
-  // TWO register levels instead (kernels_fused.hip: the LDS saved buys more resident
-  // waves than the 18 extra registers cost)
-  if (!k20 && c.max_depth >= 4) {
-    c.out.clear();
-    c.depth = c.max_depth = 0;
-    c.reg_levels = 2;
-    c.emit(n_ops - 1, false, 0);
-  }
-  size_t n_steps = c.out.size(), n_real = 0;
-  for (const FusedOp &f : c.out)
-    if (!c.split_park || (f.flags & 3u) != kFusedPark) ++n_real;
-  if (n_real != n_ops) {
-    set_error(43, "rdamd_schedule_create: %u of %u operations are not reachable from the "
-                  "root operation", (unsigned)(n_ops - n_real), n_ops);
-    return nullptr;
+    producer[o.parent_clv_index] = i;
   }
   std::vector<double> brlen(p->prob_matrices, 0.0);
   for (unsigned m = 0; m < n_matrices; ++m) {
@@ -258,20 +260,152 @@ rdamd_schedule_t *rdamd_schedule_create(rdamd_partition_t *p, const rdamd_operat
     }
     brlen[matrix_indices[m]] = branch_lengths[m];
   }
+
+  // ---- one program from one operation list -------------------------------------------------
+  struct Program {
+    std::vector<FusedOp> steps;
+    unsigned depth = 1, reg_levels = 1, matvecs = 0;
+  };
+  auto compile = [&](const std::vector<rdamd_operation_t> &list,
+                     const std::unordered_map<unsigned, unsigned> &pseudo_row, Program &out) -> bool {
+    Compiler c;
+    c.ops = list.data(); c.n_ops = (unsigned)list.size(); c.tips = p->tips; c.sites = p->sites;
+    c.tip_stride = p->tip_stride(); c.rate_cats = p->rate_cats;
+    c.unit = p->rate_cats * (k20 ? 3200u : 128u);
+    c.split_park = k20;
+    c.pseudo_row = pseudo_row;
+    for (unsigned i = 0; i < c.n_ops; ++i) c.producer[list[i].parent_clv_index] = i;
+    c.need.assign(c.n_ops, 0);
+    c.compute_need(c.n_ops - 1);
+    c.out.reserve(c.n_ops);
+    c.emit(c.n_ops - 1, false, 0);
+    // 4 states: a program that would need three or more LDS stack levels is compiled for
+    // TWO register levels instead (kernels_fused.hip: the LDS saved buys more resident
+    // waves than the 18 extra registers cost)
+    if (!k20 && c.max_depth >= 4) {
+      c.out.clear();
+      c.depth = c.max_depth = 0;
+      c.matvecs = 0;
+      c.reg_levels = 2;
+      c.emit(c.n_ops - 1, false, 0);
+    }
+    size_t n_real = 0;
+    for (const FusedOp &f : c.out)
+      if (!c.split_park || (f.flags & 3u) != kFusedPark) ++n_real;
+    if (n_real != c.n_ops) {
+      set_error(43, "rdamd_schedule_create: %u of %u operations are not reachable from the "
+                    "root operation", (unsigned)(c.n_ops - n_real), c.n_ops);
+      return false;
+    }
+    // LDS levels = stack depth minus the register levels (at least one is allocated)
+    // (20 states: parking steps count as steps)
+    out.depth = std::max(1u, c.max_depth > c.reg_levels ? c.max_depth - c.reg_levels : 0);
+    out.reg_levels = c.reg_levels;
+    out.matvecs = c.matvecs;
+    out.steps = std::move(c.out);
+    return true;
+  };
+
+  const std::vector<rdamd_operation_t> all_ops(ops, ops + n_ops);
+  Program plain, folded;
+  if (!compile(all_ops, {}, plain)) return nullptr;
+
+  // ---- subtree site repeats: which clades become pseudo-tips (clades.hpp) -----------------
+  // A node is SMALL when the sites fall into at most max_classes classes below it; small is
+  // inherited downwards, so the small nodes form whole subtrees and the topmost small node
+  // of each is the pseudo-tip.  The root operation is never folded (a program has >= 1 step).
+  std::vector<char> small(n_ops, 0);
+  std::vector<unsigned> node_id(n_ops, 0);
+  std::vector<CladeStep> steps;
+  std::vector<CladeGroup> groups;
+  std::unordered_map<unsigned, unsigned> pseudo_row;
+  unsigned clade_rows = 0;
+  const bool repeats = !k20 && (p->attributes & RDAMD_ATTRIB_SITE_REPEATS) && p->sites > 0;
+  if (repeats) {
+    auto id_of = [&](unsigned clv) { return clv < p->tips ? clv : node_id[producer.at(clv)]; };
+    for (unsigned i = 0; i < n_ops; ++i) {
+      const rdamd_operation_t &o = ops[i];
+      node_id[i] = clade_intern(p, id_of(o.child1_clv_index), id_of(o.child2_clv_index),
+                                o.child1_matrix_index, o.child2_matrix_index);
+      small[i] = i + 1 < n_ops && clade_node(*p->clades, p->tips, node_id[i])->n_classes > 0;
+    }
+    // the branch above operation i: the matrix index its consumer uses for it
+    auto mat_above = [&](unsigned i) {
+      const rdamd_operation_t &c = ops[consumer[i]];
+      return c.child1_clv_index == ops[i].parent_clv_index ? c.child1_matrix_index : c.child2_matrix_index;
+    };
+    for (unsigned i = 0; i + 1 < n_ops; ++i) {
+      if (!small[i] || small[consumer[i]]) continue;     // not a pseudo-tip
+      CladeGroup g;
+      g.first = (unsigned)steps.size();
+      // post-order over the small subtree below i; local index = position inside the group
+      std::function<unsigned(unsigned)> walk = [&](unsigned j) -> unsigned {
+        const rdamd_operation_t &o = ops[j];
+        CladeStep st;
+        memset(&st, 0, sizeof st);
+        const unsigned ch[2] = {o.child1_clv_index, o.child2_clv_index};
+        const unsigned mt[2] = {o.child1_matrix_index, o.child2_matrix_index};
+        for (int k = 0; k < 2; ++k)
+          st.src[k] = ch[k] < p->tips ? mt[k] : (0x80000000u | walk(producer.at(ch[k])));
+        const CladeNode *node = clade_node(*p->clades, p->tips, node_id[j]);
+        st.n_classes = node->n_classes;
+        st.out_mat = mat_above(j);
+        st.last = j == i ? 1u : 0u;
+        st.pad[0] = node_id[j];   // (host only: the map offset is filled in below)
+        clade_rows += node->n_classes;
+        steps.push_back(st);
+        return (unsigned)steps.size() - 1 - g.first;
+      };
+      walk(i);
+      g.count = (unsigned)steps.size() - g.first;
+      groups.push_back(g);
+    }
+  }
   rdamd_schedule *s = new rdamd_schedule();
-  // LDS levels = stack depth minus the register level (at least one is allocated)
-  // (20 states: parking steps count as steps)
-  s->part = p; s->n_ops = (unsigned)n_steps;
-  s->depth = std::max(1u, c.max_depth > c.reg_levels ? c.max_depth - c.reg_levels : 0);
-  s->reg_levels = c.reg_levels;
-  n_ops = (unsigned)n_steps;
-  s->prog = c.out;
-  // harmless tail entries: the kernel prefetches descriptors up to i + 3
-  for (int k = 0; k < 4; ++k) c.out.push_back(c.out.back());
+  s->part = p;
+  s->tip_generation = p->tip_generation;
 #define TRY(expr) RDAMD_HIP_TRY(expr, (rdamd_schedule_destroy(s), nullptr))
-  TRY(hipMalloc((void **)&s->d_prog, sizeof(FusedOp) * (n_ops + 4)));
+  if (!groups.empty()) {
+    for (CladeStep &st : steps) {
+      TRY(clade_upload_map(p, st.pad[0]));
+      st.map_off = (uint32_t)clade_node(*p->clades, p->tips, st.pad[0])->map_off;
+      st.pad[0] = 0;
+    }
+    std::vector<rdamd_operation_t> kept;
+    for (unsigned i = 0; i < n_ops; ++i) {
+      if (!small[i]) { kept.push_back(ops[i]); continue; }
+      if (small[consumer[i]]) continue;
+      TRY(clade_upload_codes(p, node_id[i]));
+      pseudo_row[ops[i].parent_clv_index] = (unsigned)clade_node(*p->clades, p->tips, node_id[i])->code_row;
+    }
+    if (!compile(kept, pseudo_row, folded)) { rdamd_schedule_destroy(s); return nullptr; }
+  }
+  const Program &main_prog = groups.empty() ? plain : folded;
+  s->n_ops = (unsigned)main_prog.steps.size();
+  s->depth = main_prog.depth; s->reg_levels = main_prog.reg_levels; s->matvecs = main_prog.matvecs;
+  s->n_ops_plain = (unsigned)plain.steps.size();
+  s->depth_plain = plain.depth; s->reg_levels_plain = plain.reg_levels; s->matvecs_plain = plain.matvecs;
+  s->n_steps = (unsigned)steps.size(); s->n_groups = (unsigned)groups.size(); s->clade_rows = clade_rows;
+  s->prog = main_prog.steps;
+  auto upload_program = [&](const Program &pr, FusedOp **dst) -> hipError_t {
+    std::vector<FusedOp> padded = pr.steps;
+    // harmless tail entries: the kernel prefetches descriptors up to i + 3
+    for (int k = 0; k < 4; ++k) padded.push_back(padded.back());
+    hipError_t e = hipMalloc((void **)dst, sizeof(FusedOp) * padded.size());
+    if (e != hipSuccess) return e;
+    return hipMemcpy(*dst, padded.data(), sizeof(FusedOp) * padded.size(), hipMemcpyHostToDevice);
+  };
+  TRY(upload_program(main_prog, &s->d_prog));
+  if (groups.empty()) {
+    s->d_prog_plain = s->d_prog;
+  } else {
+    TRY(upload_program(plain, &s->d_prog_plain));
+    TRY(hipMalloc((void **)&s->d_steps, sizeof(CladeStep) * steps.size()));
+    TRY(hipMalloc((void **)&s->d_groups, sizeof(CladeGroup) * groups.size()));
+    TRY(hipMemcpy(s->d_steps, steps.data(), sizeof(CladeStep) * steps.size(), hipMemcpyHostToDevice));
+    TRY(hipMemcpy(s->d_groups, groups.data(), sizeof(CladeGroup) * groups.size(), hipMemcpyHostToDevice));
+  }
   TRY(hipMalloc((void **)&s->d_brlen, sizeof(double) * p->prob_matrices));
-  TRY(hipMemcpy(s->d_prog, c.out.data(), sizeof(FusedOp) * (n_ops + 4), hipMemcpyHostToDevice));
   TRY(hipMemcpy(s->d_brlen, brlen.data(), sizeof(double) * p->prob_matrices, hipMemcpyHostToDevice));
 #undef TRY
   return s;
@@ -280,12 +414,60 @@ rdamd_schedule_t *rdamd_schedule_create(rdamd_partition_t *p, const rdamd_operat
 void rdamd_schedule_destroy(rdamd_schedule_t *s) {
   if (!s) return;
   if (s->part && s->part->stream) (void)hipStreamSynchronize(s->part->stream);
+  if (s->d_prog_plain && s->d_prog_plain != s->d_prog) (void)hipFree(s->d_prog_plain);
   if (s->d_prog) (void)hipFree(s->d_prog);
   if (s->d_brlen) (void)hipFree(s->d_brlen);
+  if (s->d_steps) (void)hipFree(s->d_steps);
+  if (s->d_groups) (void)hipFree(s->d_groups);
   delete s;
 }
 
 unsigned int rdamd_schedule_stack_depth(const rdamd_schedule_t *s) { return s->depth; }
+
+int rdamd_schedule_stats(const rdamd_schedule_t *s, rdamd_schedule_stats_t *out) {
+  if (!s || !out) return RDAMD_FAILURE;
+  const bool k20 = s->part->states == 20;
+  unsigned parks = 0, parks_plain = 0;   // (20-state programs count parking as steps of their own)
+  if (k20)
+    for (const rdamd::FusedOp &f : s->prog) parks += (f.flags & 3u) == rdamd::kFusedPark;
+  parks_plain = parks;
+  out->operations = s->n_ops_plain - parks_plain;
+  out->steps = s->n_ops - parks;
+  out->matvecs = s->matvecs;
+  out->matvecs_plain = s->matvecs_plain;
+  out->pseudo_tips = s->n_groups;
+  out->clade_nodes = s->n_steps;
+  out->clade_rows = s->clade_rows;
+  out->stack_depth = s->depth;
+  out->stack_depth_plain = s->depth_plain;
+  return RDAMD_SUCCESS;
+}
+
+int rdamd_partition_set_site_repeats(rdamd_partition_t *p, unsigned int max_classes) {
+  clear_error();
+  if (max_classes > 16) {
+    set_error(46, "rdamd_partition_set_site_repeats: at most 16 classes per pseudo-tip (got %u)", max_classes);
+    return RDAMD_FAILURE;
+  }
+  if (p->states != 4) return RDAMD_SUCCESS;
+  if (max_classes == 0) {
+    p->attributes &= ~RDAMD_ATTRIB_SITE_REPEATS;
+    return RDAMD_SUCCESS;
+  }
+  p->attributes |= RDAMD_ATTRIB_SITE_REPEATS;
+  if (p->clades && p->clades->max_classes != max_classes) {
+    // classes were counted against the old limit: start the cache again (schedules keep
+    // their own device copies; code rows already handed out stay where they are)
+    RDAMD_HIP_TRY(hipStreamSynchronize(p->stream), RDAMD_FAILURE);
+    for (rdamd::CladeNode &n : p->clades->nodes) { n.cls.clear(); n.cmap.clear(); }
+    p->clades->intern.clear();
+    // (node ids of the old generation stay valid for the schedules that hold them: nodes are
+    // only appended, never re-used)
+  }
+  if (!p->clades) p->clades = new rdamd::CladeCache();
+  p->clades->max_classes = max_classes;
+  return RDAMD_SUCCESS;
+}
 
 static int evaluate_batch_impl(rdamd_partition_t *p, unsigned int n_jobs,
                                const rdamd_schedule_t *const *schedules,
@@ -317,18 +499,31 @@ static int evaluate_batch_impl(rdamd_partition_t *p, unsigned int n_jobs,
   double *hf = (double *)h;              h += sizeof(double) * K * n_jobs;
   double *hr = (double *)h;              h += sizeof(double) * R * n_jobs;
   double *hw = (double *)h;
-  unsigned max_depth = 1, reg_levels = 1;
+  unsigned max_depth[2] = {1, 1}, reg_levels[2] = {1, 1};   // [0] programs with pseudo-tips, [1] plain
+  unsigned max_groups = 0, max_steps = 0;
   for (unsigned j = 0; j < n_jobs; ++j) {
     const rdamd_schedule_t *s = schedules[j];
     if (!s || s->part != p) {
       set_error(44, "rdamd_evaluate_batch: job %u has no schedule of this partition", j);
       return RDAMD_FAILURE;
     }
+    if (s->n_groups && s->tip_generation != p->tip_generation) {
+      set_error(45, "rdamd_evaluate_batch: job %u: the tip states changed after its schedule was "
+                    "compiled (its site-repeat classes are stale); create the schedule again", j);
+      return RDAMD_FAILURE;
+    }
     hj[j].prog = s->d_prog; hj[j].brlen = s->d_brlen; hj[j].n_ops = s->n_ops;
-    hj[j].depth = 0;   // patched below: every block uses the launch-wide depth
-    hj[j].tt_unsafe = 0; hj[j].pad = 0;   // (set again by the P-matrix step of this batch)
-    max_depth = std::max(max_depth, s->depth);
-    reg_levels = std::max(reg_levels, s->reg_levels);
+    hj[j].prog_plain = s->d_prog_plain; hj[j].n_ops_plain = s->n_ops_plain;
+    hj[j].clade_steps = s->d_steps; hj[j].clade_groups = s->d_groups;
+    hj[j].n_groups = s->n_groups; hj[j].n_clade_steps = s->n_steps;
+    hj[j].depth = hj[j].depth_plain = 0;   // patched below: every block uses the launch-wide depth
+    hj[j].tt_unsafe = 0; hj[j].pad = 0;    // (set again by the P-matrix / clade-table steps of this batch)
+    max_depth[0] = std::max(max_depth[0], s->depth);
+    max_depth[1] = std::max(max_depth[1], s->depth_plain);
+    reg_levels[0] = std::max(reg_levels[0], s->reg_levels);
+    reg_levels[1] = std::max(reg_levels[1], s->reg_levels_plain);
+    max_groups = std::max(max_groups, s->n_groups);
+    max_steps = std::max(max_steps, s->n_steps);
     double wide_s[12] = {0}, wide_f[4] = {0};
     const double *sj = subst + (size_t)j * NP, *fj = freqs + (size_t)j * K;
     if (p->embedded()) {   // caller passes [n][2] / [n][2]: into the 4-state shapes
@@ -346,7 +541,17 @@ static int evaluate_batch_impl(rdamd_partition_t *p, unsigned int n_jobs,
       hw[(size_t)j * R + r] = rate_weights ? rate_weights[(size_t)j * R + r] : p->rate_weights[r];
     }
   }
-  for (unsigned j = 0; j < n_jobs; ++j) hj[j].depth = max_depth;
+  for (unsigned j = 0; j < n_jobs; ++j) {
+    hj[j].depth = max_depth[0];
+    hj[j].depth_plain = max_depth[1];
+  }
+  const size_t clade_scratch_job = (size_t)max_steps * R * 64;   // doubles: [step][rate][16 rows][4]
+  if (clade_scratch_job * n_jobs > w->clade_scratch_doubles) {
+    if (w->d_clade_scratch) (void)hipFree(w->d_clade_scratch);
+    w->d_clade_scratch = nullptr;
+    w->clade_scratch_doubles = clade_scratch_job * std::max(n_jobs, w->cap_jobs);
+    RDAMD_HIP_TRY(hipMalloc((void **)&w->d_clade_scratch, w->clade_scratch_doubles * sizeof(double)), RDAMD_FAILURE);
+  }
   {   // the device block mirrors the staging block: one copy
     const size_t in_bytes = (size_t)n_jobs * (sizeof(FusedJob) + sizeof(double) * (K * K + K + 2 * R));
     RDAMD_HIP_TRY(hipMemcpyAsync(w->d_in, w->h_in, in_bytes, hipMemcpyHostToDevice, p->stream), RDAMD_FAILURE);
@@ -373,7 +578,7 @@ static int evaluate_batch_impl(rdamd_partition_t *p, unsigned int n_jobs,
     p->prof_end();
     RDAMD_HIP_TRY(e, RDAMD_FAILURE);
     p->prof_begin(3);
-    e = launch_fused20_eval(b, n_jobs, max_depth, d_out, p->stream);
+    e = launch_fused20_eval(b, n_jobs, max_depth[0], d_out, p->stream);
     p->prof_end();
     RDAMD_HIP_TRY(e, RDAMD_FAILURE);
   } else {
@@ -383,9 +588,12 @@ static int evaluate_batch_impl(rdamd_partition_t *p, unsigned int n_jobs,
   a.partials = w->d_partials; a.persite = nullptr;
   a.pmat_job_stride = (size_t)p->prob_matrices * R * 16;
   a.sites = p->sites; a.rate_cats = R;
-  a.tipcodes_bytes = (unsigned)std::min<size_t>((size_t)p->tips * p->tip_stride(), 0xffffffffu);
+  a.tipcodes_bytes = (unsigned)std::min<size_t>((size_t)p->code_rows * p->tip_stride(), 0xffffffffu);
   p->prof_begin(4);
   e = launch_fused_pmatrix(a, w->d_q, w->d_rates, n_jobs, p->prob_matrices, p->stream);
+  if (e == hipSuccess && max_groups)   // the pseudo-tips' tables, from the P-matrices and tip tables just made
+    e = launch_clade_tables(a, p->clades->d_maps, w->d_clade_scratch, clade_scratch_job, n_jobs, max_groups,
+                            p->stream);
   p->prof_end();
   RDAMD_HIP_TRY(e, RDAMD_FAILURE);
   p->prof_begin(3);

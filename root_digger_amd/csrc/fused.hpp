@@ -35,20 +35,32 @@ struct FusedOp {
   uint32_t pad[2];
 };
 
+struct CladeStep;
+struct CladeGroup;
 struct FusedJob {
   const FusedOp *prog;   // device
   const double  *brlen;  // device, indexed by P-matrix index
   uint32_t n_ops, depth;
   // 4 states: jobs[0].tt_unsafe is set by the P-matrix step when a tip-table entry of the
-  // LAUNCH lies in (0, 2^-128).  While it is 0, the product of two tip rows is either 0
-  // or >= 2^-256, a tip-tip step can never need a rescale, and the evaluator variant
-  // without that test runs (kernels_fused.hip).
+  // LAUNCH lies in (0, 2^-128), and by the clade-table step when a pseudo-tip's table has
+  // such an entry or a class of a pseudo-tip would have been rescaled inside its clade.
+  // While it is 0, the product of two table rows is either 0 or >= 2^-256, a tip-tip step
+  // can never need a rescale, and the evaluator variant without that test runs
+  // (kernels_fused.hip) -- on `prog`, the program with the pseudo-tips.  When it is up, the
+  // variant with the test runs on `prog_plain`: every operation of the caller's list, tips
+  // only, every rescale exactly where the reference rule puts it.
   uint32_t tt_unsafe, pad;
+  // subtree site repeats (clades.hpp); without pseudo-tips prog_plain == prog, n_groups == 0
+  const FusedOp    *prog_plain;
+  const CladeStep  *clade_steps;
+  const CladeGroup *clade_groups;
+  uint32_t n_ops_plain, depth_plain, n_groups, n_clade_steps;
 };
+static_assert(sizeof(FusedJob) == 72, "FusedJob: scalar loads at fixed offsets");
 
 struct FusedArgs {
   const FusedJob *jobs;
-  const uint8_t  *tipcodes;          // [tips][tip_stride], code x 16 (rdamd_partition::d_tipcodes16)
+  const uint8_t  *tipcodes;          // [tips + pseudo-tips][tip_stride], code x 16 (rdamd_partition::d_tipcodes16)
   const unsigned *pattern_weights;   // [sites]
   const double   *pmat;              // [job][matrix][rate][16]
   const double   *tiptab;            // [job][matrix][rate][16 codes][4]
@@ -58,7 +70,7 @@ struct FusedArgs {
   double         *persite;           // [job][sites] or null
   size_t   pmat_job_stride;
   unsigned sites, rate_cats;
-  unsigned tipcodes_bytes;           // tips * tip_stride
+  unsigned tipcodes_bytes;           // rows in use * tip_stride
 };
 
 // ---- 20-state variant (kernels_fused_k20.hip) ---------------------------------
@@ -92,8 +104,10 @@ hipError_t launch_fused20_eval(const Fused20Args &a, unsigned n_jobs, unsigned m
 
 hipError_t launch_fused_pmatrix(const FusedArgs &a, const double *d_q, const double *d_rates,
                                 unsigned n_jobs, unsigned n_mat, hipStream_t stream);
-hipError_t launch_fused_eval(const FusedArgs &a, unsigned n_jobs, unsigned max_depth,
-                             unsigned blocks_x, unsigned sites_per_lane, unsigned reg_levels,
+// depth / reg_levels: [0] of the programs with pseudo-tips (FusedJob::prog), [1] of the plain
+// programs (prog_plain); the two evaluator variants are launched with their own LDS sizes
+hipError_t launch_fused_eval(const FusedArgs &a, unsigned n_jobs, const unsigned max_depth[2],
+                             unsigned blocks_x, unsigned sites_per_lane, const unsigned reg_levels[2],
                              double *d_out, hipStream_t stream);
 
 

@@ -1,0 +1,206 @@
+// Clade tables: the per-job look-up tables of the fused evaluator's pseudo-tips, and the
+// per-partition cache of directed subtrees behind them (clades.hpp has the idea).
+// Match: coraxlib's site repeats, switched on by the reference for every 4-state run
+// (/root/reference/src/model.cpp:145-149).
+#include <algorithm>
+#include <cstring>
+
+#include "clades.hpp"
+#include "common.hpp"
+#include "fused.hpp"
+
+namespace rdamd {
+
+CladeCache::~CladeCache() {
+  if (d_maps) (void)hipFree(d_maps);
+}
+void clade_cache_free(CladeCache *c) { delete c; }
+
+// ---- host: classes of a directed subtree ---------------------------------------------------
+// The classes of a node are the distinct pairs (class of child 0, class of child 1) over the
+// sites, numbered in order of first appearance -- the partition of the sites by the pattern
+// of the tips below the node, whichever way the subtree is split.  A tip's class is its code.
+unsigned clade_intern(rdamd_partition *p, unsigned child0, unsigned child1, unsigned mat0, unsigned mat1) {
+  if (!p->clades) p->clades = new CladeCache();
+  CladeCache &c = *p->clades;
+  const std::array<unsigned, 4> key = {child0, child1, mat0, mat1};
+  auto hit = c.intern.find(key);
+  if (hit != c.intern.end()) return hit->second;
+  const unsigned tips = p->tips;
+  CladeNode n;
+  n.child[0] = child0; n.child[1] = child1; n.mat[0] = mat0; n.mat[1] = mat1;
+  const size_t S = p->sites;
+  const uint8_t *cls[2];
+  unsigned cnt[2];
+  bool small = true;
+  for (int k = 0; k < 2; ++k) {
+    const unsigned ch = k ? child1 : child0;
+    if (ch < tips) {
+      cls[k] = p->tipcodes.data() + (size_t)ch * S;
+      cnt[k] = 16;   // (4-state codes are the state masks themselves)
+      n.n_tips += 1;
+    } else {
+      const CladeNode &cn = c.nodes[ch - tips];
+      n.n_tips += cn.n_tips;
+      if (cn.n_classes == 0) small = false;
+      cls[k] = cn.cls.data();
+      cnt[k] = cn.n_classes;
+    }
+  }
+  if (small) {
+    std::vector<int> seen((size_t)cnt[0] * cnt[1], -1);
+    n.cls.resize(S);
+    unsigned count = 0;
+    for (size_t s = 0; s < S; ++s) {
+      const unsigned a = cls[0][s], b = cls[1][s];
+      int &slot = seen[(size_t)a * cnt[1] + b];
+      if (slot < 0) {
+        if (count == c.max_classes) { small = false; break; }
+        slot = (int)count++;
+        n.cmap.push_back((uint8_t)a);
+        n.cmap.push_back((uint8_t)b);
+      }
+      n.cls[s] = (uint8_t)slot;
+    }
+    n.n_classes = small ? count : 0;
+  }
+  if (!small) {
+    n.n_classes = 0;
+    n.cls.clear(); n.cls.shrink_to_fit();
+    n.cmap.clear();
+  }
+  const unsigned id = tips + (unsigned)c.nodes.size();
+  c.nodes.push_back(std::move(n));
+  c.intern.emplace(key, id);
+  return id;
+}
+
+// the code arena: rows of tip_stride() bytes, grown geometrically (programs hold row OFFSETS)
+static hipError_t ensure_code_rows(rdamd_partition *p, unsigned rows) {
+  if (rows <= p->code_rows_cap) return hipSuccess;
+  const unsigned cap = std::max(rows, p->code_rows_cap + p->code_rows_cap / 2 + 16);
+  const size_t stride = p->tip_stride();
+  if ((size_t)cap * stride + kTipcodePad > 0xffffffffull) return hipErrorOutOfMemory;   // 32-bit offsets
+  hipError_t e = hipStreamSynchronize(p->stream);
+  if (e != hipSuccess) return e;
+  uint8_t *fresh = nullptr;
+  e = hipMalloc(&fresh, (size_t)cap * stride + kTipcodePad);
+  if (e != hipSuccess) return e;
+  e = hipMemcpy(fresh, p->d_tipcodes16, (size_t)p->code_rows * stride, hipMemcpyDeviceToDevice);
+  if (e == hipSuccess)
+    e = hipMemset(fresh + (size_t)p->code_rows * stride, 0, (size_t)(cap - p->code_rows) * stride + kTipcodePad);
+  if (e != hipSuccess) { (void)hipFree(fresh); return e; }
+  (void)hipFree(p->d_tipcodes16);
+  p->d_tipcodes16 = fresh;
+  p->code_rows_cap = cap;
+  return hipSuccess;
+}
+
+hipError_t clade_upload_codes(rdamd_partition *p, unsigned id) {
+  CladeNode &n = p->clades->nodes[id - p->tips];
+  if (n.code_row >= 0) return hipSuccess;
+  hipError_t e = ensure_code_rows(p, p->code_rows + 1);
+  if (e != hipSuccess) return e;
+  std::vector<uint8_t> row(p->tip_stride(), 0);
+  for (size_t s = 0; s < p->sites; ++s) row[s] = (uint8_t)(n.cls[s] << 4);   // the LDS row offset, as for tips
+  e = hipMemcpy(p->d_tipcodes16 + (size_t)p->code_rows * p->tip_stride(), row.data(), row.size(),
+                hipMemcpyHostToDevice);
+  if (e != hipSuccess) return e;
+  n.code_row = (int)p->code_rows++;
+  return hipSuccess;
+}
+
+hipError_t clade_upload_map(rdamd_partition *p, unsigned id) {
+  CladeCache &c = *p->clades;
+  CladeNode &n = c.nodes[id - p->tips];
+  if (n.map_off >= 0) return hipSuccess;
+  const size_t bytes = (n.cmap.size() + 3) & ~(size_t)3;
+  if (c.maps_used + bytes > c.maps_cap) {
+    const size_t cap = std::max<size_t>(c.maps_used + bytes, c.maps_cap * 2 + 4096);
+    hipError_t e = hipStreamSynchronize(p->stream);
+    if (e != hipSuccess) return e;
+    uint8_t *fresh = nullptr;
+    e = hipMalloc(&fresh, cap);
+    if (e != hipSuccess) return e;
+    if (c.maps_used) e = hipMemcpy(fresh, c.d_maps, c.maps_used, hipMemcpyDeviceToDevice);
+    if (e != hipSuccess) { (void)hipFree(fresh); return e; }
+    if (c.d_maps) (void)hipFree(c.d_maps);
+    c.d_maps = fresh;
+    c.maps_cap = cap;
+  }
+  hipError_t e = hipMemcpy(c.d_maps + c.maps_used, n.cmap.data(), n.cmap.size(), hipMemcpyHostToDevice);
+  if (e != hipSuccess) return e;
+  n.map_off = (long)c.maps_used;
+  c.maps_used += bytes;
+  return hipSuccess;
+}
+
+// ---- device: the tables of one launch -----------------------------------------------------
+// One workgroup per (pseudo-tip, job); a thread owns (class, rate) pairs.  The nodes of the
+// pseudo-tip's clade are walked in post-order (a barrier between nodes): the CLV of a class
+// is the product of the two child rows the class map points at -- rows of the job's tip
+// tables for tip children, rows this workgroup wrote a moment ago (global scratch) for nested
+// clades -- and the row that is kept is P(branch above the node) . CLV, which is what the
+// node's parent consumes.  The last node's rows go into the job's table slot of that branch
+// (the slot its tip table would occupy if the child were a tip: a branch has one child), in
+// the tip tables' layout, so the evaluator reads a pseudo-tip exactly as it reads a tip.
+//
+// Scaling: a pseudo-tip carries no rescale count.  That is exact as long as no class of any
+// node of the clade meets the rescale condition (all entries < 2^-256);
+// if one does -- or if a table entry is small enough for a later tip-tip product to meet it --
+// the launch-wide flag goes up and the evaluator runs the plain programs instead.
+__global__ void __launch_bounds__(64)
+clade_table_kernel(FusedJob *__restrict__ jobs, const uint8_t *__restrict__ maps,
+                   const double *__restrict__ pmat, double *__restrict__ tiptab, size_t pmat_job_stride,
+                   double *__restrict__ scratch, size_t scratch_job_stride, unsigned R) {
+  const unsigned job = blockIdx.y, grp = blockIdx.x;
+  const FusedJob jb = jobs[job];
+  if (grp >= jb.n_groups) return;
+  const CladeGroup g = jb.clade_groups[grp];
+  const double *__restrict__ pm = pmat + (size_t)job * pmat_job_stride;        // [matrix][rate][16]
+  double *__restrict__ tt = tiptab + (size_t)job * pmat_job_stride * 4;         // [matrix][rate][16 rows][4]
+  double *__restrict__ sc = scratch + (size_t)job * scratch_job_stride;         // [step][rate][16 rows][4]
+  bool unsafe = false;
+  for (unsigned k = 0; k < g.count; ++k) {
+    const CladeStep st = jb.clade_steps[g.first + k];
+    const uint8_t *__restrict__ map = maps + st.map_off;
+    for (unsigned idx = threadIdx.x; idx < st.n_classes * R; idx += blockDim.x) {
+      const unsigned c = idx / R, r = idx % R;
+      double v[4] = {1.0, 1.0, 1.0, 1.0};
+#pragma unroll
+      for (int ch = 0; ch < 2; ++ch) {
+        const unsigned cc = map[2 * c + ch];
+        const double *row = (st.src[ch] & 0x80000000u)
+                                ? sc + (((size_t)(g.first + (st.src[ch] & 0x7fffffffu)) * R + r) * 16 + cc) * 4
+                                : tt + (((size_t)st.src[ch] * R + r) * 16 + cc) * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] *= row[i];
+      }
+      const double vmax = fmax(fmax(v[0], v[1]), fmax(v[2], v[3]));
+      if (vmax > 0.0 && vmax < kScaleThreshold) unsafe = true;   // the reference rule would rescale here
+      const double *__restrict__ m = pm + ((size_t)st.out_mat * R + r) * 16;
+      double *out = st.last ? tt + (((size_t)st.out_mat * R + r) * 16 + c) * 4
+                            : sc + (((size_t)(g.first + k) * R + r) * 16 + c) * 4;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const double t = m[i * 4 + 0] * v[0] + m[i * 4 + 1] * v[1] + m[i * 4 + 2] * v[2] + m[i * 4 + 3] * v[3];
+        if (t > 0.0 && t < 0x1p-128) unsafe = true;
+        out[i] = t;
+      }
+    }
+    __syncthreads();   // (also orders this workgroup's scratch writes before the next node's reads)
+  }
+  if (unsafe) jobs[0].tt_unsafe = 1u;   // launch-wide (every writer stores the same value)
+}
+
+hipError_t launch_clade_tables(const FusedArgs &a, const uint8_t *d_maps, double *d_scratch,
+                               size_t scratch_job_stride, unsigned n_jobs, unsigned max_groups,
+                               hipStream_t stream) {
+  if (!n_jobs || !max_groups) return hipSuccess;
+  clade_table_kernel<<<dim3(max_groups, n_jobs), 64, 0, stream>>>(
+      const_cast<FusedJob *>(a.jobs), d_maps, a.pmat, const_cast<double *>(a.tiptab), a.pmat_job_stride,
+      d_scratch, scratch_job_stride, a.rate_cats);
+  return hipGetLastError();
+}
+
+}  // namespace rdamd

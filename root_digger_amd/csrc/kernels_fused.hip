@@ -137,9 +137,12 @@ fused_dna_eval_kernel(FusedArgs a) {
   // out of the variant that runs then (+3.5 % on c2; a run-time branch gave nothing)
   if ((uni(a.jobs[0].tt_unsafe) != 0u) != TTCHECK) return;
   constexpr bool tt_safe = !TTCHECK;
+  // (the variant with the test walks the PLAIN programs -- no pseudo-tips, every rescale
+  // where the reference rule has it; fused.hpp)
   const FusedJob jb = a.jobs[job];
-  const FusedOp *__restrict__ prog = jb.prog;   // n_ops + 2 entries (tail padded)
-  const unsigned nops = jb.n_ops;
+  const FusedOp *__restrict__ prog = TTCHECK ? jb.prog_plain : jb.prog;   // n_ops + 4 entries (tail padded)
+  const unsigned nops = TTCHECK ? jb.n_ops_plain : jb.n_ops;
+  const unsigned lds_levels = TTCHECK ? jb.depth_plain : jb.depth;
   const char *__restrict__ pm = reinterpret_cast<const char *>(a.pmat + (size_t)job * a.pmat_job_stride);
   const double *__restrict__ freqs = a.freqs + (size_t)job * 4;
   const double *__restrict__ rw = a.rate_weights + (size_t)job * R;
@@ -157,7 +160,7 @@ fused_dna_eval_kernel(FusedArgs a) {
   for (int q = 0; q < NS; ++q) site_off[q] = (int)site[q];
   // (the X / Y tip tables sit at LDS bytes 0 and 512, two half tables each: read_row)
   double2 *stk = reinterpret_cast<double2 *>(lds + kTabDoubles) + lane;
-  int *stk_sc = reinterpret_cast<int *>(lds + kTabDoubles + (size_t)jb.depth * NS * 256) + lane;
+  int *stk_sc = reinterpret_cast<int *>(lds + kTabDoubles + (size_t)lds_levels * NS * 256) + lane;
 
   double term[NS];   // sum_r w_r f_r 2^(-256 (s_r - smin))
   int smin[NS];
@@ -454,34 +457,33 @@ hipError_t launch_fused_pmatrix(const FusedArgs &a, const double *d_q, const dou
   return hipGetLastError();
 }
 
-template <int NS, int RL>
-static hipError_t launch_fused_eval_ns(const FusedArgs &a, unsigned n_jobs, unsigned max_depth,
-                                       unsigned blocks_x, double *d_out, hipStream_t stream) {
+template <int NS, bool TTCHECK, int RL>
+static hipError_t launch_fused_variant(const FusedArgs &a, unsigned n_jobs, unsigned max_depth, unsigned gx,
+                                       hipStream_t stream) {
   const size_t lds = kTabDoubles * sizeof(double) +
                      (size_t)(max_depth ? max_depth : 1) * NS * 64 * (4 * sizeof(double) + sizeof(int));
-  if (lds > 48 * 1024) {   // deep stacks (very unbalanced 10^3-taxon trees): raise the limit
-    hipError_t e = hipFuncSetAttribute((const void *)fused_dna_eval_kernel<NS, false, RL>,
+  static size_t lds_allowed = 48 * 1024;
+  if (lds > lds_allowed) {   // deep stacks (very unbalanced 10^3-taxon trees): raise the limit
+    hipError_t e = hipFuncSetAttribute((const void *)fused_dna_eval_kernel<NS, TTCHECK, RL>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e == hipSuccess)
-      e = hipFuncSetAttribute((const void *)fused_dna_eval_kernel<NS, true, RL>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
+    lds_allowed = lds;
   }
   static const bool lds_starts_at_zero = [] {   // see the note at the top of the kernel
-    hipFuncAttributes attr, attr2;
-    return hipFuncGetAttributes(&attr, (const void *)fused_dna_eval_kernel<NS, false, RL>) == hipSuccess &&
-           hipFuncGetAttributes(&attr2, (const void *)fused_dna_eval_kernel<NS, true, RL>) == hipSuccess &&
-           attr.sharedSizeBytes == 0 && attr2.sharedSizeBytes == 0;
+    hipFuncAttributes attr;
+    return hipFuncGetAttributes(&attr, (const void *)fused_dna_eval_kernel<NS, TTCHECK, RL>) == hipSuccess &&
+           attr.sharedSizeBytes == 0;
   }();
   if (!lds_starts_at_zero) return hipErrorInvalidValue;
-  const unsigned gx = (blocks_x + NS - 1) / NS;   // blocks_x counts 64-site blocks
-  dim3 grid(gx, n_jobs);
-  fused_dna_eval_kernel<NS, false, RL><<<grid, 64, lds, stream>>>(a);
-  fused_dna_eval_kernel<NS, true, RL><<<grid, 64, lds, stream>>>(a);   // (returns at once on ordinary data)
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return e;
-  fused_finish_kernel<<<n_jobs, 256, 0, stream>>>(a.partials, gx, d_out);
+  fused_dna_eval_kernel<NS, TTCHECK, RL><<<dim3(gx, n_jobs), 64, lds, stream>>>(a);
   return hipGetLastError();
+}
+
+template <int NS, bool TTCHECK>
+static hipError_t launch_fused_variant_rl(const FusedArgs &a, unsigned n_jobs, unsigned max_depth, unsigned gx,
+                                          unsigned reg_levels, hipStream_t stream) {
+  return reg_levels >= 2 ? launch_fused_variant<NS, TTCHECK, 2>(a, n_jobs, max_depth, gx, stream)
+                         : launch_fused_variant<NS, TTCHECK, 1>(a, n_jobs, max_depth, gx, stream);
 }
 
 // sites_per_lane: 1 or 2.  Two sites per lane share every scalar operand (P-matrix
@@ -490,15 +492,29 @@ static hipError_t launch_fused_eval_ns(const FusedArgs &a, unsigned n_jobs, unsi
 // waves per SIMD), +5 % on c5; three and four sites per lane lose (register
 // pressure: 31k and 22k).  One site per lane is kept for launches too small to
 // fill the chip with half the waves (evaluate.hip picks).
-hipError_t launch_fused_eval(const FusedArgs &a, unsigned n_jobs, unsigned max_depth,
-                             unsigned blocks_x, unsigned sites_per_lane, unsigned reg_levels,
+// Both variants are queued -- the one on the programs with pseudo-tips and no tip-tip
+// rescale test ([0]), the one on the plain programs with it ([1]) -- each with the LDS and
+// the register stack levels ITS programs need; the one the launch's flag rules out returns
+// at once.
+template <int NS>
+static hipError_t launch_fused_eval_ns(const FusedArgs &a, unsigned n_jobs, const unsigned max_depth[2],
+                                       unsigned blocks_x, const unsigned reg_levels[2], double *d_out,
+                                       hipStream_t stream) {
+  const unsigned gx = (blocks_x + NS - 1) / NS;   // blocks_x counts 64-site blocks
+  hipError_t e = launch_fused_variant_rl<NS, false>(a, n_jobs, max_depth[0], gx, reg_levels[0], stream);
+  if (e != hipSuccess) return e;
+  e = launch_fused_variant_rl<NS, true>(a, n_jobs, max_depth[1], gx, reg_levels[1], stream);   // (returns at once on ordinary data)
+  if (e != hipSuccess) return e;
+  fused_finish_kernel<<<n_jobs, 256, 0, stream>>>(a.partials, gx, d_out);
+  return hipGetLastError();
+}
+
+hipError_t launch_fused_eval(const FusedArgs &a, unsigned n_jobs, const unsigned max_depth[2],
+                             unsigned blocks_x, unsigned sites_per_lane, const unsigned reg_levels[2],
                              double *d_out, hipStream_t stream) {
   if (!n_jobs) return hipSuccess;
-  if (reg_levels >= 2)
-    return sites_per_lane == 2 ? launch_fused_eval_ns<2, 2>(a, n_jobs, max_depth, blocks_x, d_out, stream)
-                               : launch_fused_eval_ns<1, 2>(a, n_jobs, max_depth, blocks_x, d_out, stream);
-  return sites_per_lane == 2 ? launch_fused_eval_ns<2, 1>(a, n_jobs, max_depth, blocks_x, d_out, stream)
-                             : launch_fused_eval_ns<1, 1>(a, n_jobs, max_depth, blocks_x, d_out, stream);
+  return sites_per_lane == 2 ? launch_fused_eval_ns<2>(a, n_jobs, max_depth, blocks_x, reg_levels, d_out, stream)
+                             : launch_fused_eval_ns<1>(a, n_jobs, max_depth, blocks_x, reg_levels, d_out, stream);
 }
 
 }  // namespace rdamd

@@ -200,7 +200,10 @@ rdamd_partition_t *rdamd_partition_create(unsigned int tips, unsigned int clv_bu
   // + kTipcodePad: the traversal kernel reads tip codes with dword-wide scalar
   // loads that may run a few bytes past the last row
   TRY(hipMalloc(&p->d_tipcodes, (size_t)tips * p->tip_stride() + kTipcodePad));
-  if (K == 4) TRY(hipMalloc(&p->d_tipcodes16, (size_t)tips * p->tip_stride() + kTipcodePad));
+  if (K == 4) {
+    TRY(hipMalloc(&p->d_tipcodes16, (size_t)tips * p->tip_stride() + kTipcodePad));
+    p->code_rows = p->code_rows_cap = tips;
+  }
   // (the 20-state matrix-core kernel keeps CLVs in its operand layout, whole 16-site tiles:
   // decided here, before the CLV buffers are sized -- common.hpp)
   p->mfma_layout = K == 20 && R <= 8 &&
@@ -274,6 +277,7 @@ void rdamd_partition_destroy(rdamd_partition_t *p) {
   for (void *d : dev)
     if (d) (void)hipFree(d);
   rdamd::fused_workspace_free(p->fused);
+  rdamd::clade_cache_free(p->clades);
   for (auto &sp : p->prof_spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
   for (auto &e : p->prof_pool) (void)hipEventDestroy(e);
   if (p->h_stage) (void)hipHostFree(p->h_stage);
@@ -322,6 +326,15 @@ int rdamd_set_tip_states(rdamd_partition_t *p, unsigned int tip_index,
     RDAMD_HIP_TRY(upload(p, p->d_codemask, p->codemask.data(), 256 * sizeof(uint64_t)),
                   RDAMD_FAILURE);
     p->tiptab_stale = true;
+  }
+  // class codes of subtrees were worked out from the old characters: forget them (schedules
+  // compiled with pseudo-tips notice through the generation count)
+  p->tip_generation += 1;
+  if (p->clades) {
+    RDAMD_HIP_TRY(hipStreamSynchronize(p->stream), RDAMD_FAILURE);
+    rdamd::clade_cache_free(p->clades);
+    p->clades = nullptr;
+    p->code_rows = p->tips;
   }
   RDAMD_HIP_TRY(upload(p, p->d_tipcodes + (size_t)tip_index * p->tip_stride(), row, S), RDAMD_FAILURE);
   if (p->d_tipcodes16) {   // the same row as LDS row offsets (kernels_fused.hip)
