@@ -67,27 +67,44 @@ def full_eval_bytes(n, S, R, K):
     return (2 * n - 2) * W + n * S + (2 * n - 2) * 4 * S
 
 
-def profiled_traffic(kernel, batch, config):
-    """HBM bytes per launch of `kernel` from the committed PMC passes
-    (profiles/collect.sh + profiles/summarize.py: FETCH_SIZE/WRITE_SIZE in
-    separate rocprofv3 passes, corrected per MI355X_MICROARCH.md).  The passes
-    were taken on the default command (c2, batch 197); other shapes get null."""
+class StaleProfile(Exception):
+    pass
+
+
+def profiled_summary(kernel, batch, config, key):
+    """The committed counters of `kernel` (profiles/collect.sh + profiles/summarize.py:
+    separate rocprofv3 passes of the default command -- c2, batch 197; other shapes get
+    None).  They describe the kernel as it was when they were taken: the summary carries a
+    digest of the kernel's sources (profiles/sources.py), and counters of a kernel that has
+    changed since are REFUSED, not published."""
     if config != "c2" or batch != 197:
         return None, None
     import glob
+    sys.path.insert(0, os.path.join(ROOT, "profiles"))
+    from sources import source_digest
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_summary.json")))
     if not files:
         return None, None
-    try:
-        d = json.load(open(files[-1]))
-        # (template variants share the prefix: the one that did the work is the slowest)
-        hits = [v for k, v in d.items() if k.startswith(kernel) and "hbm_bytes_per_launch" in v]
-        if hits:
-            v = max(hits, key=lambda v: v.get("avg_us", 0.0))
-            return int(v["hbm_bytes_per_launch"]), os.path.relpath(files[-1], ROOT)
-    except Exception:
-        pass
-    return None, None
+    d = json.load(open(files[-1]))
+    # (template variants share the prefix: the one that did the work is the slowest)
+    hits = [v for k, v in d.items() if k.startswith(kernel) and key in v]
+    if not hits:
+        return None, None
+    v = max(hits, key=lambda v: v.get("avg_us", 0.0))
+    name = os.path.relpath(files[-1], ROOT)
+    if v.get("source_digest") != source_digest(kernel):
+        raise StaleProfile("%s holds counters of %s taken from sources %s, the sources are now %s: "
+                           "re-run profiles/collect.sh + profiles/summarize.py (or pass "
+                           "--allow-stale-profile to publish the line without counters)"
+                           % (name, kernel, v.get("source_digest"), source_digest(kernel)))
+    return v, name
+
+
+def profiled_traffic(kernel, batch, config):
+    """HBM bytes per launch from the FETCH_SIZE / WRITE_SIZE passes, corrected per
+    MI355X_MICROARCH.md."""
+    v, name = profiled_summary(kernel, batch, config, "hbm_bytes_per_launch")
+    return (int(v["hbm_bytes_per_launch"]), name) if v else (None, None)
 
 
 def spawn_ranks(n):
@@ -138,19 +155,8 @@ def profiled_issue(kernel, batch, config):
     committed SQ counter passes of the default command (c2, batch 197): VALU
     instructions per (operation, rate) step, the share of them that are the
     algorithm's FP64 instructions, and VALU issue-slot utilisation."""
-    if config != "c2" or batch != 197:
-        return {}
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_summary.json")))
-    try:
-        d = json.load(open(files[-1]))
-        hits = [v for k, v in d.items() if k.startswith(kernel) and "derived" in v]
-        if hits:
-            v = max(hits, key=lambda v: v.get("avg_us", 0.0))
-            return {"issue": dict(v["derived"], source=os.path.relpath(files[-1], ROOT))}
-    except Exception:
-        pass
-    return {}
+    v, name = profiled_summary(kernel, batch, config, "derived")
+    return {"issue": dict(v["derived"], source=name)} if v else {}
 
 
 def main():
@@ -168,6 +174,12 @@ def main():
     ap.add_argument("--no-repeats", action="store_true",
                     help="4-state partitions: without RDAMD_ATTRIB_SITE_REPEATS (the reference sets "
                          "CORAX_ATTRIB_SITE_REPEATS for every 4-state run, src/model.cpp:145-149; A/B only)")
+    ap.add_argument("--allow-stale-profile", action="store_true",
+                    help="publish the line without `traffic` / `issue` when the committed counter "
+                         "summary was taken from other kernel sources (default: fail)")
+    ap.add_argument("--sustain-seconds", type=float, default=2.0,
+                    help="after the K timed steps: the same step looped for this long, reported as "
+                         "`sustained` (0 = skip)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + --device lets several ranks share one GPU (how the N>1 code "
                          "path is exercised on a one-GPU box); the driver's runs use nccl (RCCL)")
@@ -291,6 +303,7 @@ def main():
         return part.compute_root_loglikelihood(tree.root_clv_index(),
                                                tree.root_scaler_index())
 
+    executed = {"steps": 0, "matvecs": 0, "clade_rows": 0, "evals": 0}
     if use_fused:
         scheds = [part.schedule(*tree.generate_operations(rl)) for rl in roots]
         depth = max(sc.stack_depth() for sc in scheds)
@@ -302,6 +315,10 @@ def main():
         if not use_fused:
             return sum(evaluate_unfused(s * nb + b) for b in range(nb))
         idx = [(s * nb + b) % len(mine) for b in range(nb)]
+        executed["steps"] += sum(sched_stats[i]["steps"] for i in idx)
+        executed["matvecs"] += sum(sched_stats[i]["matvecs"] for i in idx)
+        executed["clade_rows"] += sum(sched_stats[i]["clade_rows"] for i in idx)
+        executed["evals"] += len(idx)
         # every job of every step is a distinct (root, parameter set) pair
         jitter = 1.0 + 1e-3 * (((s % 97) + 1) + np.arange(nb)[:, None] / (4.0 * nb))
         sub = params[idx] * jitter * (1.0 + 0.05 * np.sin(np.arange(K * K - K) + s))
@@ -333,6 +350,7 @@ def main():
     for s in range(args.warmup):
         step(s)
     part.profile_enable(True)
+    executed = dict.fromkeys(executed, 0)
     barrier()
     t0 = time.perf_counter()
     check = 0.0
@@ -346,8 +364,30 @@ def main():
         check = float(lnl_rows.sum().item())
     prof = part.profile_read()
     part.profile_enable(False)
+    executed_timed = dict(executed)
     if not np.isfinite(check):
         raise SystemExit("non-finite lnL in the timed region")
+
+    # The K timed steps last tens of milliseconds: too short for the clocks to settle or for a
+    # sampling monitor to see the device busy.  `sustained`: the very same step, looped for
+    # --sustain-seconds, with its own rate and its own event-timed kernel figure.
+    sustained = None
+    if use_fused and not site_sharded and args.sustain_seconds > 0:
+        part.profile_enable(True)
+        executed = dict.fromkeys(executed, 0)
+        barrier()
+        t1 = time.perf_counter()
+        k = 0
+        while time.perf_counter() - t1 < args.sustain_seconds:
+            step(args.warmup + args.steps + k)
+            k += 1
+        barrier()
+        dt = time.perf_counter() - t1
+        sprof = part.profile_read()
+        part.profile_enable(False)
+        sustained = {"seconds": round(dt, 3), "steps": k, "evals_per_s": round(k * nb / dt, 2),
+                     "kernel_ms": sprof["fused"][0], "launches": sprof["fused"][1],
+                     "executed": dict(executed)}
 
     if use_pg:
         t = torch.tensor([elapsed], dtype=torch.float64,
@@ -370,22 +410,49 @@ def main():
     extra = {}
     if use_fused:
         ms, launches = prof["fused"]
-        flops = full_eval_flops(n, S, R, K) * evals_per_rank
+        # Flops (2K(2K-1)+K per (site, rate) and operation), counted two ways:
+        #  * `achieved` / `frac`: over the operations the evaluator actually RUNS -- with subtree
+        #    site repeats a schedule runs fewer than n-1 per site (clades folded into per-job
+        #    tables are evaluated once per pattern class; rdamd_schedule_stats), and work that
+        #    was skipped must not count as throughput: frac <= 1 stays a statement about the
+        #    kernel;
+        #  * `algorithmic_equiv`: SURVEY's formula on all n-1 operations per evaluation, i.e.
+        #    what a traversal without repeats would have had to execute for the same answers
+        #    (the figure earlier rounds published; it may exceed the peak).
+        per_op = (2 * K * (2 * K - 1) + K) * S * R
+        flops = per_op * executed_timed["steps"]
+        flops_equiv = full_eval_flops(n, S, R, K) * evals_per_rank
         tf = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        tf_equiv = flops_equiv / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        # matrix-vector products and element products the kernel really issues (tip and
+        # pseudo-tip children are table look-ups): 2K^2-K per product + K per operation
+        fp64_issued = ((2 * K * K - K) * executed_timed["matvecs"] + K * executed_timed["steps"]) * S * R
         hbm_equiv = full_eval_bytes(n, S, R, K) * evals_per_rank / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
         # The fused traversal never materialises a CLV: its HBM traffic is tip codes
         # + per-job tables (PMC: `traffic`), far below SURVEY 8d's bytes_full, so the
         # resource that binds it is FP64 issue -- the vector FMA pipe for 4 states,
         # the FP64 matrix core (v_mfma_f64_4x4x4_4b_f64) for 20.  `roofline` is that
-        # bound: SURVEY 8d's algorithmic flops per launch / the kernel's HIP-event
-        # launch time against the 78.6 TFLOP/s FP64 peak (vector = matrix on gfx950).
+        # bound against the 78.6 TFLOP/s FP64 peak (vector = matrix on gfx950), the launch
+        # time taken with HIP events on the partition's stream.
         # `hbm_equiv` keeps the algorithmic-byte rate for comparison with the
         # materialising path; it is a ratio to the HBM peak, not a roofline.
+        ev = max(executed_timed["evals"], 1)
         roofline = {
             "kernel": fused_kernel, "bound": "fp64" if K == 4 else "mfma",
             "achieved": round(tf, 2), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(tf / FP64_PEAK_TFLOPS, 4), "traffic": None,
-            "algorithmic_flops_per_launch": flops / max(launches, 1),
+            "executed_flops_per_launch": flops / max(launches, 1),
+            "algorithmic_equiv": {"flops_per_launch": flops_equiv / max(launches, 1),
+                                  "rate_tflops": round(tf_equiv, 2),
+                                  "ratio_to_peak": round(tf_equiv / FP64_PEAK_TFLOPS, 4),
+                                  "note": "SURVEY 8d flops of all n-1 operations per evaluation / launch "
+                                          "time: what a traversal without site repeats would execute"},
+            "schedule": {"operations_per_evaluation": n - 1,
+                         "steps_per_evaluation": round(executed_timed["steps"] / ev, 2),
+                         "matvecs_per_evaluation": round(executed_timed["matvecs"] / ev, 2),
+                         "clade_table_rows_per_evaluation_and_rate": round(executed_timed["clade_rows"] / ev, 1),
+                         "site_repeats": bool(repeats)},
+            "issued_fp64_tflops": round(fp64_issued / (ms * 1e-3) / 1e12, 2) if ms > 0 else 0.0,
             "avg_launch_ms": round(ms / max(launches, 1), 4), "launches": launches,
             "share_of_step": round(ms * 1e-3 / elapsed, 3),
             ("measured_dfma_ceiling_tflops" if K == 4 else
@@ -398,9 +465,23 @@ def main():
                           "note": "SURVEY 8d bytes_full per evaluation / launch time; CLVs stay in "
                                   "registers/LDS, so this exceeds the HBM peak by design"},
         }
-        roofline.update(profiled_issue(fused_kernel, nb, args.config))
-        roofline["traffic"], roofline["traffic_source"] = profiled_traffic(
-            fused_kernel, nb, args.config)
+        if sustained:
+            sms, sl = sustained.pop("kernel_ms"), sustained["launches"]
+            sx = sustained.pop("executed")
+            stf = per_op * sx["steps"] / (sms * 1e-3) / 1e12 if sms > 0 else 0.0
+            sustained.update(kernel_avg_launch_ms=round(sms / max(sl, 1), 4),
+                             achieved_tflops=round(stf, 2), frac=round(stf / FP64_PEAK_TFLOPS, 4))
+            roofline["sustained"] = sustained
+        default_cmd = args.config == "c2" and nb == 197 and (repeats or K != 4) and world == 1
+        try:
+            if default_cmd:
+                roofline.update(profiled_issue(fused_kernel, nb, args.config))
+                roofline["traffic"], roofline["traffic_source"] = profiled_traffic(
+                    fused_kernel, nb, args.config)
+        except StaleProfile as e:
+            if not args.allow_stale_profile:
+                raise SystemExit("bench.py: " + str(e))
+            roofline["traffic"], roofline["traffic_stale"] = None, str(e)
         # second leg: the materialising CLV kernel (drop-in rdamd_update_clvs
         # path), HBM-bound.  The traversals are queued back to back without a
         # host sync in between, so the event-timed spans carry no launch gaps.
@@ -415,8 +496,14 @@ def main():
         p2 = part.profile_read()
         part.profile_enable(False)
         extra["clv_kernel"] = clv_roofline(p2["clv"][0], p2["clv"][1], 6)
-        extra["clv_kernel"]["traffic"], extra["clv_kernel"]["traffic_source"] = profiled_traffic(
-            clv_kernel, nb, args.config)
+        try:
+            if default_cmd:
+                extra["clv_kernel"]["traffic"], extra["clv_kernel"]["traffic_source"] = profiled_traffic(
+                    clv_kernel, nb, args.config)
+        except StaleProfile as e:
+            if not args.allow_stale_profile:
+                raise SystemExit("bench.py: " + str(e))
+            extra["clv_kernel"]["traffic_stale"] = str(e)
     else:
         roofline = clv_roofline(prof["clv"][0], prof["clv"][1], evals_per_rank)
 
@@ -464,25 +551,55 @@ def main():
 
 
 def host_topology():
-    """(sockets, physical cores per socket, logical cpus) from /proc/cpuinfo."""
-    cores = set()
-    phys = core = None
+    """(sockets, physical cores per socket, logical cpus, {socket: [one logical cpu per
+    physical core]}) from /proc/cpuinfo."""
+    cores = {}
+    cpu = phys = core = None
     try:
         for line in open("/proc/cpuinfo"):
-            if line.startswith("physical id"):
+            if line.startswith("processor"):
+                cpu = int(line.split(":")[1])
+            elif line.startswith("physical id"):
                 phys = int(line.split(":")[1])
             elif line.startswith("core id"):
                 core = int(line.split(":")[1])
-            elif not line.strip() and phys is not None and core is not None:
-                cores.add((phys, core))
-                phys = core = None
+            elif not line.strip() and None not in (cpu, phys, core):
+                cores.setdefault((phys, core), cpu)     # first hardware thread of the core
+                cpu = phys = core = None
     except OSError:
         pass
     logical = os.cpu_count() or 1
     if not cores:
-        return 1, logical, logical
-    sockets = len({p for p, _ in cores})
-    return sockets, max(1, len(cores) // sockets), logical
+        return 1, logical, logical, {0: sorted(os.sched_getaffinity(0))}
+    by_socket = {}
+    for (p_, _), c in cores.items():
+        by_socket.setdefault(p_, []).append(c)
+    sockets = len(by_socket)
+    return sockets, max(1, len(cores) // sockets), logical, {k: sorted(v) for k, v in by_socket.items()}
+
+
+def site_repeats_class_ratio(tree, seqs, samples=3):
+    """Sum over inner nodes of (distinct tip patterns below the node) / (inner nodes x
+    patterns), averaged over a few rootings: the fraction of the CLV arithmetic a CPU run
+    WITH coraxlib's site repeats (the reference's configuration for 4-state data,
+    src/model.cpp:145-149) would still do.  The CPU baseline below has no repeats."""
+    import numpy as np
+    names = list(seqs)
+    S = len(seqs[names[0]])
+    tips = {tree.tip_index(k): np.frombuffer(seqs[k].upper().encode(), dtype=np.uint8).astype(np.int64)
+            for k in names}
+    nroots = tree.root_count()
+    ratios = []
+    for rid in range(0, nroots, max(1, nroots // samples))[:samples]:
+        ops, _, _ = tree.generate_operations(tree.root_location(rid))
+        cls, total = dict(tips), 0
+        for op in ops:
+            a, b = cls[op.child1_clv_index], cls[op.child2_clv_index]
+            uniq, inv = np.unique(a * (int(b.max()) + 1) + b, return_inverse=True)
+            cls[op.parent_clv_index] = inv.astype(np.int64)
+            total += len(uniq)
+        ratios.append(total / (len(ops) * S))
+    return round(float(np.mean(ratios)), 4)
 
 
 def cpu_baseline(w, tree, cmap, freqs, n, S, K, R, params, roots, budget, gpu_eval):
@@ -533,7 +650,7 @@ def cpu_baseline(w, tree, cmap, freqs, n, S, K, R, params, roots, budget, gpu_ev
     if worst > 1e-9:
         raise SystemExit("parity gate failed: GPU vs oracle rel.err %.3e" % worst)
     loop = "256-bit-vector CLV loop (AVX2, no FMA), " if vec else "scalar CLV loop, "
-    sockets, per_socket, logical = host_topology()
+    sockets, per_socket, logical, socket_cpus = host_topology()
     out = {"value": round(done / dt, 4), "unit": "evals/s", "cores": 1, "kind": "port",
            "sample": "%d full-traversal evaluations of the same workload (oracle/rd_oracle.c, 1 thread, "
                      "%s-O3 x86-64-v3, no site repeats)" % (done, loop),
@@ -547,8 +664,16 @@ def cpu_baseline(w, tree, cmap, freqs, n, S, K, R, params, roots, budget, gpu_ev
             k += 1
         out["scalar_loop_1_thread"] = round(k / (time.perf_counter() - t0), 4)
 
+    if K == 4:   # what the real `rd` would gain on this workload: it runs coraxlib WITH site repeats
+        out["site_repeats_class_ratio"] = site_repeats_class_ratio(tree, w["seqs"])
+        out["site_repeats_note"] = ("the reference sets CORAX_ATTRIB_SITE_REPEATS for 4-state data; this "
+                                    "restatement computes every site: a real rd rank would do about this "
+                                    "fraction of the CLV arithmetic timed here")
+
     # one socket: one candidate root per thread, one oracle partition per thread (ctypes
-    # calls run without the GIL); capped by host memory (a partition holds all 2n-2 CLVs)
+    # calls run without the GIL); capped by host memory (a partition holds all 2n-2 CLVs).
+    # Every thread is PINNED to its own physical core of socket 0 and builds (first-touches)
+    # its partition there, so the figure is one socket's cores on that socket's memory.
     import threading
     try:
         import psutil
@@ -556,24 +681,36 @@ def cpu_baseline(w, tree, cmap, freqs, n, S, K, R, params, roots, budget, gpu_ev
     except Exception:
         avail = 16 << 30
     per_part = (2 * n - 2) * S * R * K * 8 * 1.15 + n * S * 8
-    allowed = len(os.sched_getaffinity(0))
-    threads = int(max(1, min(per_socket, allowed, 0.4 * avail // per_part, len(scheds))))
+    allowed = os.sched_getaffinity(0)
+    socket0 = [c for c in socket_cpus[min(socket_cpus)] if c in allowed]
+    threads = int(max(1, min(len(socket0), 0.4 * avail // per_part, len(scheds))))
     if threads > 1:
-        parts = [o] + [make_partition() for _ in range(threads - 1)]
         counts = [0] * threads
         window = max(0.4 * budget, 2.0 / max(out["value"], 1e-9))
+        ready = threading.Barrier(threads + 1)
         start = threading.Barrier(threads + 1)
+        pinned = [False] * threads
 
         def work(t):
+            try:
+                os.sched_setaffinity(0, {socket0[t]})      # the calling thread only
+                pinned[t] = True
+            except OSError:
+                pass
+            q = make_partition()                            # first touch from this core
+            evaluate(q, t % len(scheds))                    # ... of the CLV buffers too
+            ready.wait()
             start.wait()
             t0 = time.perf_counter()
             while time.perf_counter() - t0 < window or counts[t] == 0:
-                evaluate(parts[t], (t + counts[t] * threads) % len(scheds))
+                evaluate(q, (t + counts[t] * threads) % len(scheds))
                 counts[t] += 1
+            q.destroy()
 
         ths = [threading.Thread(target=work, args=(t,)) for t in range(threads)]
         for th in ths:
             th.start()
+        ready.wait()
         start.wait()
         t0 = time.perf_counter()
         for th in ths:
@@ -581,13 +718,14 @@ def cpu_baseline(w, tree, cmap, freqs, n, S, K, R, params, roots, budget, gpu_ev
         wall = time.perf_counter() - t0
         out["one_socket"] = {"value": round(sum(counts) / wall, 4), "unit": "evals/s",
                              "cores": threads,
-                             "sample": "%d evaluations, one candidate root per thread, %d threads "
+                             "sample": "%d evaluations, one candidate root per thread, %d threads%s, each "
+                                       "with its own partition first-touched from its core "
                                        "(%d socket(s) x %d physical cores on this host%s) for %.1f s"
-                                       % (sum(counts), threads, sockets, per_socket,
+                                       % (sum(counts), threads,
+                                          " pinned one per physical core of socket 0" if all(pinned) else " (not pinned)",
+                                          sockets, per_socket,
                                           "" if threads == per_socket else "; capped by memory/affinity",
                                           wall)}
-        for q in parts[1:]:
-            q.destroy()
     o.destroy()
     return out
 

@@ -13,6 +13,9 @@ import os
 import shutil
 import sys
 
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from sources import source_digest   # noqa: E402
+
 tag = sys.argv[1] if len(sys.argv) > 1 else "r1"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", tag)
@@ -75,6 +78,9 @@ for k, d in out.items():
             der["fp64_valu_per_step"] = round(fp64 / d["SQ_WAVES"] / steps, 2)
             der["sites_per_lane"] = 2
     d["derived"] = der
+for k, d in out.items():   # what these counters describe (bench.py checks it before publishing them)
+    if source_digest(k):
+        d["source_digest"] = source_digest(k)
 json.dump(out, open(os.path.join(root, "profiles", tag + "_summary.json"), "w"), indent=1,
           sort_keys=True)
 for k in sorted(out, key=lambda k: -out[k].get("pct", 0)):

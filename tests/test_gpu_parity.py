@@ -434,6 +434,53 @@ def test_fused_deep_tree_per_rate_scaling():
         assert sched.stack_depth() <= 2      # a caterpillar needs (almost) no stack
 
 
+def test_fused_rate_categories_four_rescales_apart():
+    """VERDICT r2 item 9.  The fused evaluators rescale per (site, rate) and align the rate
+    terms at the root (kernels_fused.hip), the reference rule rescales per site:
+    the two can only differ where one category needs >= 4 more rescales than another -- there
+    the aligned term is 2^-1024 of the leading one and is dropped (pow2_neg256), while the
+    per-site rule has let the same category underflow to nothing.  Constructed case: the
+    161-taxon caterpillar, pi_A = 0.01, rate categories 1e-6 ... 1000.  On a constant column
+    of A the slow category keeps its CLV near 1 (never rescaled) while the fast ones shrink by
+    ~0.01 per tip (2^-1060 at the root: four rescales); on a column that alternates between
+    states the fast categories lead and the slow one pays ~1e-8 per tip.  Both rules must
+    lose the same category and agree on lnL."""
+    gd = util.golden("deep_scaling.json")
+    tree = rd.Tree.from_newick(gd["newick"])
+    names = sorted(gd["seqs"])
+    rng = np.random.default_rng(9)
+    cols = ["A" * len(names), "C" * len(names), "".join("ACGT"[i % 4] for i in range(len(names))),
+            "".join("AC"[i % 2] for i in range(len(names)))]
+    cols += ["".join(rng.choice(list("ACGT"), p=[0.7, 0.1, 0.1, 0.1]) for _ in names) for _ in range(60)]
+    seqs = {k: "".join(c[i] for c in cols) for i, k in enumerate(names)}
+    freqs = [0.01, 0.33, 0.33, 0.33]
+    rates = [1e-6, 0.01, 10.0, 1000.0]
+    g, o = pair(tree, seqs, 4, 4)
+    S = len(cols)
+    gr = rd.Partition.for_tree(tree, 4, S, 4, attributes=rd.ATTRIB_SITE_REPEATS)
+    util.load_tips(gr, tree, seqs, rd.MAP_NT)
+    for i in (0, 160, tree.root_count() - 1):
+        rl = tree.root_location(i).with_ratio(0.5)
+        ops = tree.generate_operations(rl)
+        want = _oracle_eval(o, tree, rl, gd["subst"], freqs, rates)
+        assert np.isfinite(want)
+        for part in (g, gr):
+            got = part.evaluate_batch([part.schedule(*ops)], [gd["subst"]], [freqs], [rates])[0]
+            assert util.rel_err(got, want) < LNL_TOL, (i, got, want)
+        # the per-site rule on the device (materialising path) as well
+        set_model((g,), gd["subst"], freqs, rates)
+        assert util.rel_err(util.compute_lh(g, tree, rl), want) < LNL_TOL
+    # the construction does what it says: on the constant column the categories' scaler
+    # needs are >= 4 apart (oracle CLV of the root, per rate: the slow category is O(1),
+    # the fast ones have underflowed to zero under the per-site rule)
+    rl = tree.root_location(160).with_ratio(0.5)
+    _oracle_eval(o, tree, rl, gd["subst"], freqs, rates)
+    root = o.get_clv(tree.root_clv_index())
+    assert root[0, 0].max() > 1e-3 and root[0, 3].max() < 2.0 ** -1000
+    for p in (g, gr, o):
+        p.destroy()
+
+
 def test_fused_schedule_validation():
     w = synth.workload(12, 64, 4, 1, 61)
     tree = rd.Tree.from_newick(w["newick"])
