@@ -43,6 +43,10 @@ CONFIGS = {
     "c3": dict(n=200, S=10000, K=20, R=4),
     "c4": dict(n=500, S=500000, K=4, R=4),
     "c5": dict(n=1000, S=100000, K=4, R=4),
+    # not a BASELINE config: the reference's largest DNA fixture (test/data/dna/125.phy +
+    # tree/125.tree; 29 149 columns = 19 436 patterns, a third of the characters gaps), for
+    # what subtree site repeats do on real, repeat-rich data.  n, S are filled in at load time.
+    "d125": dict(n=125, S=19436, K=4, R=4),
 }
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
 FP64_PEAK_TFLOPS = 78.6     # MI355X FP64 vector = matrix peak
@@ -105,6 +109,20 @@ def profiled_traffic(kernel, batch, config):
     MI355X_MICROARCH.md."""
     v, name = profiled_summary(kernel, batch, config, "hbm_bytes_per_launch")
     return (int(v["hbm_bytes_per_launch"]), name) if v else (None, None)
+
+
+def check_one_hip_runtime(rd):
+    """Before a torch tensor's device pointer goes to librdamd (rdamd_evaluate_batch_device):
+    both must sit on the SAME libamdhip64.  A process can hold two -- PyTorch bundles its own
+    ROCm, librdamd links /opt/rocm's; which one librdamd binds to depends on the import order
+    (this file imports torch first: one instance) -- and allocations of one are unknown to the
+    other (csrc/comm.cpp looks for its RCCL beside its own runtime for the same reason)."""
+    mapped = rd.mapped_hip_runtimes()
+    if len(mapped) > 1 or (mapped and rd.hip_runtime_path() not in mapped):
+        raise SystemExit("bench.py: two HIP runtime instances in this process (%s); librdamd runs on %s. "
+                         "Device pointers must not cross between them: import torch before "
+                         "root_digger_amd (or build librdamd against the same ROCm)"
+                         % (", ".join(mapped), rd.hip_runtime_path()))
 
 
 def spawn_ranks(n):
@@ -171,6 +189,9 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0,
                     help="budget for the cpu_baseline leg (rank 0, N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--repeat-classes", type=int, default=None,
+                    help="class limit of the pseudo-tips (rdamd_partition_set_site_repeats; "
+                         "default: the library's)")
     ap.add_argument("--no-repeats", action="store_true",
                     help="4-state partitions: without RDAMD_ATTRIB_SITE_REPEATS (the reference sets "
                          "CORAX_ATTRIB_SITE_REPEATS for every 4-state run, src/model.cpp:145-149; A/B only)")
@@ -180,6 +201,13 @@ def main():
     ap.add_argument("--sustain-seconds", type=float, default=2.0,
                     help="after the K timed steps: the same step looped for this long, reported as "
                          "`sustained` (0 = skip)")
+    ap.add_argument("--sites", type=int, default=None,
+                    help="override the config's site count (the multi-rank pre-flight runs c5's tree at "
+                         "an oracle-sized alignment)")
+    ap.add_argument("--as-candidate-group", default=None, metavar="I/N",
+                    help="one rank only: take the candidates (and parameter draws) of candidate group I "
+                         "of N, i.e. what rank 0 of that group of an N x G grid evaluates -- the "
+                         "reference value of the grid run's lnl_check")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + --device lets several ranks share one GPU (how the N>1 code "
                          "path is exercised on a one-GPU box); the driver's runs use nccl (RCCL)")
@@ -234,8 +262,23 @@ def main():
 
     cfg = CONFIGS[args.config]
     n, S, K, R = cfg["n"], cfg["S"], cfg["K"], cfg["R"]
+    if args.sites:
+        S = args.sites
     seed = 0xD166E5 + sorted(CONFIGS).index(args.config)
-    w = synth.workload(n, S, K, R, seed)
+    data_weights = None
+    if args.config == "d125":
+        import lzma
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import util
+        text = lzma.open(os.path.join(util.DATA, "125.phy.xz"), "rt").read()
+        toks = text.split()
+        seqs = {toks[2 + 2 * i]: toks[3 + 2 * i] for i in range(int(toks[0]))}
+        seqs, data_weights = util.compress(seqs)
+        w = {"newick": open(os.path.join(util.DATA, "125.tree")).read(), "seqs": seqs,
+             "rates": rd.compute_gamma_cats(1.0, R), "alphabet": "ACGT"}
+        n, S = len(seqs), len(next(iter(seqs.values())))
+    else:
+        w = synth.workload(n, S, K, R, seed)
     # Three ways to use N GPUs: candidate roots only (default), site
     # blocks only, or the 2-D grid of BASELINE config c5: `cgroups` groups of
     # `sgroups` ranks; a group shares its candidates and splits the sites, and the
@@ -266,8 +309,12 @@ def main():
 
     repeats = K == 4 and not args.no_repeats
     part = rd.Partition.for_tree(tree, K, S, R, attributes=rd.ATTRIB_SITE_REPEATS if repeats else 0)
+    if repeats and args.repeat_classes is not None:
+        part.set_site_repeats(args.repeat_classes)
     for label, seq in w["seqs"].items():
         part.set_tip_states(tree.tip_index(label), cmap, seq)
+    if data_weights is not None:
+        part.set_pattern_weights(data_weights)
     freqs = part.empirical_frequencies()
     if site_sharded and sgroups > 1:   # the model is global: combine the blocks' counts
         freqs = rdist.global_frequencies(freqs, S, group=site_group,
@@ -280,6 +327,10 @@ def main():
     if site_sharded:   # a site group sees all candidates of its candidate group, on its own sites
         mine = rdist.assign_candidates(tree.root_count(), cgroup, cgroups)
         rng = np.random.default_rng(seed + 1000 + cgroup)
+    elif args.as_candidate_group and world == 1:
+        gi, gn = (int(x) for x in args.as_candidate_group.split("/"))
+        mine = rdist.assign_candidates(tree.root_count(), gi, gn)
+        rng = np.random.default_rng(seed + 1000 + gi)
     else:
         mine = rdist.assign_candidates(tree.root_count(), rank, world)
         rng = np.random.default_rng(seed + 1000 + rank)
@@ -325,6 +376,8 @@ def main():
         if site_sharded:
             row = s - args.warmup
             lnl_dev = lnl_rows[row] if 0 <= row < args.steps else lnl_warm
+            # (the tensor's memory comes from torch's HIP runtime, the kernels that write it
+            # from librdamd's: check_one_hip_runtime() has made sure they are the same one)
             part.evaluate_batch_device([scheds[i] for i in idx], sub, freqs_b[idx],
                                        lnl_dev.data_ptr())
             if use_pg and not host_collectives:
@@ -342,6 +395,8 @@ def main():
         torch.cuda.synchronize()
         part.sync()
 
+    if site_sharded:
+        check_one_hip_runtime(rd)
     # site-sharded: every timed step leaves its per-job lnLs in its own row (no
     # torch work inside the timed region); warm-up steps share a scratch row
     lnl_rows = (torch.zeros((args.steps, nb), dtype=torch.float64, device="cuda")
@@ -451,7 +506,8 @@ def main():
                          "steps_per_evaluation": round(executed_timed["steps"] / ev, 2),
                          "matvecs_per_evaluation": round(executed_timed["matvecs"] / ev, 2),
                          "clade_table_rows_per_evaluation_and_rate": round(executed_timed["clade_rows"] / ev, 1),
-                         "site_repeats": bool(repeats)},
+                         "site_repeats": bool(repeats),
+                         "max_classes": (args.repeat_classes if repeats else 0)},
             "issued_fp64_tflops": round(fp64_issued / (ms * 1e-3) / 1e12, 2) if ms > 0 else 0.0,
             "avg_launch_ms": round(ms / max(launches, 1), 4), "launches": launches,
             "share_of_step": round(ms * 1e-3 / elapsed, 3),
@@ -514,7 +570,8 @@ def main():
         "higher_is_better": True,
         "scaling": "strong" if args.shard == "sites" else "weak",
         "vs_baseline": None,
-        "dtype": "f64", "data": "synthetic",
+        "dtype": "f64", "data": ("synthetic" if args.config != "d125" else
+                                 "reference fixture 125.phy / 125.tree (pattern-compressed)"),
         "config": {"workload": "%s: %d-taxon %d-site %d-state UNREST+G%d full-traversal "
                                "root lnL" % (args.config, n, S, K, R),
                    "batch_per_gpu": nb,
@@ -538,7 +595,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(w, tree, cmap, freqs, n, S, K, R,
                                               params, roots, args.cpu_seconds,
-                                              gpu_eval)
+                                              gpu_eval, data_weights)
     if rank == 0:
         line = json.dumps(result) + "\n"
         if real_stdout is not None:
@@ -602,7 +659,7 @@ def site_repeats_class_ratio(tree, seqs, samples=3):
     return round(float(np.mean(ratios)), 4)
 
 
-def cpu_baseline(w, tree, cmap, freqs, n, S, K, R, params, roots, budget, gpu_eval):
+def cpu_baseline(w, tree, cmap, freqs, n, S, K, R, params, roots, budget, gpu_eval, weights=None):
     """The CPU oracle (oracle/rd_oracle.c) on the SAME workload, bounded to `budget`
     seconds; also the in-run parity gate (<= 1e-9).  4-state data go through the
     oracle's 256-bit-vector CLV loop (bit-identical to its scalar loop; the
@@ -620,6 +677,8 @@ def cpu_baseline(w, tree, cmap, freqs, n, S, K, R, params, roots, budget, gpu_ev
         o = OraclePartition.for_tree(tree, K, S, R)
         for label, seq in w["seqs"].items():
             o.set_tip_states(tree.tip_index(label), ocmap, seq)
+        if weights is not None:
+            o.set_pattern_weights(weights)
         o.set_frequencies(0, freqs)
         o.set_category_rates(w["rates"])
         return o

@@ -210,7 +210,9 @@ unsigned int rdamd_schedule_stack_depth(const rdamd_schedule_t *s);
  * traversal meets it as one more tip.  Results are those of the plain traversal; 4-state
  * (and embedded binary) partitions only, ignored otherwise.
  * rdamd_partition_set_site_repeats changes the class limit for schedules compiled from then
- * on (0 = off; the attribute's default and the largest accepted value is 16). */
+ * on: 0 = off; up to 16 = pseudo-tips share the tips' 16-row tables and 8-bit codes; up to
+ * 64 (the attribute's default and the largest accepted value) = 64-row tables as well, 16-bit
+ * codes.  Schedules compiled under limits on different sides of 16 cannot share a batch. */
 int rdamd_partition_set_site_repeats(rdamd_partition_t *p, unsigned int max_classes);
 /* What one (site, rate) executes per traversal of a compiled schedule, and what the
  * repeats saved: the denominators of the roofline figures (bench.py). */
@@ -648,6 +650,11 @@ void          rdamd_comm_destroy(rdamd_comm_t *c);
 
 /* library / device info */
 const char *rdamd_version(void);
+/* Path of the HIP runtime (libamdhip64) this library runs on.  A caller that hands over
+ * DEVICE pointers it got elsewhere (rdamd_evaluate_batch_device, rdamd_comm_allreduce_sum)
+ * must have got them from the same runtime instance: a process can hold two (ML frameworks
+ * bundle their own ROCm next to /opt/rocm); bench.py checks before it passes a tensor. */
+const char *rdamd_hip_runtime_path(void);
 int         rdamd_device_count(void);
 /* selects the HIP device later rdamd_partition_create calls of this thread use
  * (one process per GPU: call with LOCAL_RANK). */

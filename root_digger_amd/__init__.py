@@ -31,6 +31,8 @@ from .api import (  # noqa: F401
     ATTRIB_SITE_REPEATS,
     ATTRIB_NONREV,
     device_count,
+    hip_runtime_path,
+    mapped_hip_runtimes,
     set_device,
     device_memory,
     msa_probe,
@@ -42,5 +44,5 @@ __all__ = [
     "checkpoint_checksum_result", "checkpoint_checksum_params",
     "MAP_NT", "MAP_BIN", "compute_gamma_cats", "GAMMA_RATES_MEAN", "GAMMA_RATES_MEDIAN",
     "ATTRIB_SITE_REPEATS", "ATTRIB_NONREV",
-    "device_count", "set_device", "device_memory", "msa_probe",
+    "device_count", "hip_runtime_path", "mapped_hip_runtimes", "set_device", "device_memory", "msa_probe",
 ]

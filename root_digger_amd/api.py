@@ -63,6 +63,7 @@ _prl = C.POINTER(RootLocation)
 _errno = _sig("rdamd_errno", C.c_int)
 _errmsg = _sig("rdamd_errmsg", C.c_char_p)
 _sig("rdamd_version", C.c_char_p)
+_sig("rdamd_hip_runtime_path", C.c_char_p)
 _sig("rdamd_device_count", C.c_int)
 _sig("rdamd_device_memory", C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64))
 _sig("rdamd_set_device", C.c_int, C.c_int)
@@ -269,6 +270,22 @@ def _take_string(ptr):
     s = C.string_at(ptr).decode()
     _libc.free(ptr)
     return s
+
+
+def hip_runtime_path():
+    """libamdhip64 behind librdamd (rdamd_hip_runtime_path)."""
+    return os.path.realpath(lib.rdamd_hip_runtime_path().decode())
+
+
+def mapped_hip_runtimes():
+    """every libamdhip64 mapped into this process (realpaths): more than one means two HIP
+    runtime instances, between which device pointers must not travel"""
+    found = set()
+    for line in open("/proc/self/maps"):
+        path = line.split()[-1] if "/" in line else ""
+        if os.path.basename(path).startswith("libamdhip64.so"):
+            found.add(os.path.realpath(path))
+    return sorted(found)
 
 
 def device_count():

@@ -38,12 +38,13 @@ struct CladeNode {
   unsigned n_classes = 0;          // 0: more than the cache's max_classes (never a pseudo-tip)
   std::vector<uint8_t> cls;        // [sites] class of every site (n_classes <= 256)
   std::vector<uint8_t> cmap;       // [n_classes][2]: class -> (class of child 0, class of child 1)
-  int code_row = -1;               // row in the fused evaluator's code arena (uploaded on first use)
+  int code_row[2] = {-1, -1};      // row in the fused evaluator's code arena ([0] 8-bit, [1] 16-bit entries;
+                                   // uploaded on first use)
   long map_off = -1;               // byte offset of cmap in the device map arena (uploaded on first use)
 };
 
 struct CladeCache {
-  unsigned max_classes = 16;
+  unsigned max_classes = 64;   // the attribute's default (rdamd_partition_set_site_repeats changes it)
   std::map<std::array<unsigned, 4>, unsigned> intern;   // (child0, child1, mat0, mat1) -> node id
   std::vector<CladeNode> nodes;
   // device: class -> child-class maps of every node a schedule has used
@@ -59,9 +60,11 @@ struct CladeStep {
   uint32_t src[2];         // child i: a tip -> its branch's matrix index (the job's tip table of
                            // that matrix); a nested clade -> 0x80000000 | step index inside the group
   uint32_t out_mat;        // the branch above this node: row = P[out_mat] . CLV
-  uint32_t last;           // 1: the pseudo-tip itself -> the row goes to the job's table of out_mat;
-                           // 0: nested -> scratch slot of this step
-  uint32_t pad[2];
+  uint32_t last;           // 1: the pseudo-tip itself -> the row goes to the job's table of out_mat
+                           // (<= 16 classes) or to its 64-row table `wide_slot`; 0: nested -> scratch
+                           // slot of this step
+  uint32_t wide_slot;      // 0xffffffff: none
+  uint32_t pad;
 };
 struct CladeGroup {        // one pseudo-tip = steps [first, first + count) of the schedule
   uint32_t first, count;
@@ -74,10 +77,12 @@ inline const CladeNode *clade_node(const CladeCache &c, unsigned tips, unsigned 
   return id < tips ? nullptr : &c.nodes[id - tips];
 }
 // make sure the node's class codes sit in the code arena / its map in the map arena
-hipError_t clade_upload_codes(rdamd_partition *p, unsigned id);
+hipError_t clade_upload_codes(rdamd_partition *p, unsigned id, bool wide);
+hipError_t ensure_wide_arena(rdamd_partition *p);   // the 16-bit arena with the tips' rows in place
 hipError_t clade_upload_map(rdamd_partition *p, unsigned id);
 
 struct FusedArgs;
+// scratch: [job][step][rate][rows][4] with rows = a.table_rows
 hipError_t launch_clade_tables(const FusedArgs &a, const uint8_t *d_maps, double *d_scratch,
                                size_t scratch_job_stride, unsigned n_jobs, unsigned max_groups,
                                hipStream_t stream);

@@ -96,6 +96,10 @@ struct rdamd_partition {
                                       // An ARENA of rows: [0, tips) the tips, behind them the class codes of
                                       // the pseudo-tips (clades.hpp), appended as schedules discover them
   unsigned  code_rows = 0, code_rows_cap = 0;   // rows in use / allocated (tip_stride() bytes each)
+  // the same arena with 16-bit entries (rows of 2 tip_stride() bytes), for schedules whose
+  // pseudo-tips have up to 64 classes (offsets up to 1008); built on first use
+  uint8_t  *d_codes_wide = nullptr;
+  unsigned  wide_rows = 0, wide_rows_cap = 0;
   rdamd::CladeCache *clades = nullptr;          // subtree site repeats (RDAMD_ATTRIB_SITE_REPEATS)
   unsigned  tip_generation = 0;                 // bumped by rdamd_set_tip_states: schedules with pseudo-tips go stale
   double   *d_clv = nullptr;

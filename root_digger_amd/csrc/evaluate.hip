@@ -32,11 +32,17 @@ struct rdamd_schedule {
   rdamd::CladeGroup *d_groups = nullptr;
   unsigned n_steps = 0, n_groups = 0;
   unsigned tip_generation = 0;
+  unsigned table_rows = 16;           // 16: 8-bit code arena, 16-row tables only; 64: 16-bit arena, 64-row tables too
+  unsigned n_wide = 0;                // 64-row tables per job
   // what one (site, rate) executes: operations and matrix-vector products per traversal
   unsigned matvecs = 0, matvecs_plain = 0, clade_rows = 0;
 };
 
 namespace rdamd {
+
+// doubles in front of the tables: the 64-row evaluator's buffer descriptor starts 1 KB
+// before a job's tables (kernels_fused.hip, RDAMD_LOAD_TAB)
+constexpr size_t kTiptabPad = 128;
 
 struct FusedWorkspace {
   unsigned cap_jobs = 0, blocks_x = 0;
@@ -44,8 +50,9 @@ struct FusedWorkspace {
   FusedJob *d_jobs = nullptr;   // ... and where this batch's pieces sit inside it
   double *d_q = nullptr, *d_rates = nullptr, *d_freqs = nullptr, *d_rw = nullptr;
   double *d_pmat = nullptr, *d_tiptab = nullptr, *d_partials = nullptr, *d_out = nullptr;
-  double *d_clade_scratch = nullptr;   // nested clade tables of a launch: [job][step][rate][16][4]
+  double *d_clade_scratch = nullptr;   // nested clade tables of a launch: [job][step][rate][rows][4]
   size_t clade_scratch_doubles = 0;
+  size_t tiptab_doubles = 0;           // allocated behind d_tiptab
   double *h_out = nullptr;   // pinned
   char *h_in = nullptr;      // pinned parameter staging
   size_t h_in_bytes = 0;
@@ -86,8 +93,8 @@ static hipError_t ensure_workspace(rdamd_partition *p, unsigned n_jobs) {
   // with the layout of the pinned staging block: one copy per batch instead of five
   A(w->d_in, (size_t)cap * (sizeof(FusedJob) + sizeof(double) * (K * K + K + 2 * R)));
   A(w->d_pmat, sizeof(double) * pm_per_job * cap);
-  A(w->d_tiptab, sizeof(double) * (K == 4 ? pm_per_job * 4
-                                           : (size_t)p->prob_matrices * R * kFused20TabDoubles) * cap);
+  w->tiptab_doubles = (K == 4 ? pm_per_job * 4 : (size_t)p->prob_matrices * R * kFused20TabDoubles) * cap;
+  A(w->d_tiptab, sizeof(double) * (w->tiptab_doubles + kTiptabPad));
   A(w->d_partials, sizeof(double) * w->blocks_x * cap);
   A(w->d_out, sizeof(double) * cap);
 #undef A
@@ -115,6 +122,8 @@ struct Compiler {
   // pseudo-tips (clades.hpp): clv of a collapsed clade -> row of its class codes in the code
   // arena; to the compiler such a child is a tip whose table sits in its branch's slot
   std::unordered_map<unsigned, unsigned> pseudo_row;
+  std::unordered_map<unsigned, unsigned> pseudo_wide;   // ... and, for a 64-row table, its slot among the job's
+  unsigned wide_base = 0;                               // tX of wide slot 0 (behind the 16-row tables)
   unsigned matvecs = 0;                              // inner children = matrix-vector products per (site, rate)
   std::vector<unsigned> need;                        // stack slots a subtree needs
   std::vector<FusedOp> out;
@@ -190,12 +199,26 @@ struct Compiler {
     f.pM = matM * unit;
     f.tX = matX * unit;
     f.tY = matY * unit;
+    // a leaf whose table has 64 rows: its own slot, flagged for the kernel (0x2000 X, 0x4000 Y)
+    unsigned wide_flags = 0;
+    if (kind == kFusedTT || kind == kFusedRT) {
+      const unsigned leafX = o.child1_clv_index;
+      const unsigned leafY = kind == kFusedTT ? o.child2_clv_index : (i1 ? o.child2_clv_index : o.child1_clv_index);
+      if (kind == kFusedTT && pseudo_wide.count(leafX)) {
+        f.tX = wide_base + pseudo_wide.at(leafX) * rate_cats * 512u;
+        wide_flags |= 0x2000u;
+      }
+      if (pseudo_wide.count(leafY)) {
+        f.tY = wide_base + pseudo_wide.at(leafY) * rate_cats * 512u;
+        wide_flags |= 0x4000u;
+      }
+    }
     // 20 states: the tip tables' byte offsets ([matrix][rate 0], 12288 B per (matrix, rate))
     f.pad[0] = matX * rate_cats * (kFused20TabDoubles * 8u);
     f.pad[1] = matY * rate_cats * (kFused20TabDoubles * 8u);
     f.cX = tipX_row * tip_stride;
     f.cY = tipY_row * tip_stride;
-    f.flags = kind | (spill << 8);   // (a 20-state TT never parks: its spill bits were moved to the park step)
+    f.flags = kind | (spill << 8) | wide_flags;   // (a 20-state TT never parks: its spill bits were moved to the park step)
     out.push_back(f);
   }
 };
@@ -266,14 +289,22 @@ rdamd_schedule_t *rdamd_schedule_create(rdamd_partition_t *p, const rdamd_operat
     std::vector<FusedOp> steps;
     unsigned depth = 1, reg_levels = 1, matvecs = 0;
   };
+  // 64-row tables (and the 16-bit code arena that goes with them) when the partition's class
+  // limit asks for them; every program of the schedule then addresses that arena
+  const bool repeats = !k20 && (p->attributes & RDAMD_ATTRIB_SITE_REPEATS) && p->sites > 0;
+  if (repeats && !p->clades) p->clades = new CladeCache();
+  const bool wide_mode = repeats && p->clades->max_classes > 16;
   auto compile = [&](const std::vector<rdamd_operation_t> &list,
-                     const std::unordered_map<unsigned, unsigned> &pseudo_row, Program &out) -> bool {
+                     const std::unordered_map<unsigned, unsigned> &pseudo_row,
+                     const std::unordered_map<unsigned, unsigned> &pseudo_wide, Program &out) -> bool {
     Compiler c;
     c.ops = list.data(); c.n_ops = (unsigned)list.size(); c.tips = p->tips; c.sites = p->sites;
-    c.tip_stride = p->tip_stride(); c.rate_cats = p->rate_cats;
+    c.tip_stride = p->tip_stride() * (wide_mode ? 2u : 1u); c.rate_cats = p->rate_cats;
     c.unit = p->rate_cats * (k20 ? 3200u : 128u);
     c.split_park = k20;
     c.pseudo_row = pseudo_row;
+    c.pseudo_wide = pseudo_wide;
+    c.wide_base = 8u * p->prob_matrices * p->rate_cats * 16u;
     for (unsigned i = 0; i < c.n_ops; ++i) c.producer[list[i].parent_clv_index] = i;
     c.need.assign(c.n_ops, 0);
     c.compute_need(c.n_ops - 1);
@@ -308,7 +339,7 @@ rdamd_schedule_t *rdamd_schedule_create(rdamd_partition_t *p, const rdamd_operat
 
   const std::vector<rdamd_operation_t> all_ops(ops, ops + n_ops);
   Program plain, folded;
-  if (!compile(all_ops, {}, plain)) return nullptr;
+  if (!compile(all_ops, {}, {}, plain)) return nullptr;
 
   // ---- subtree site repeats: which clades become pseudo-tips (clades.hpp) -----------------
   // A node is SMALL when the sites fall into at most max_classes classes below it; small is
@@ -318,9 +349,8 @@ rdamd_schedule_t *rdamd_schedule_create(rdamd_partition_t *p, const rdamd_operat
   std::vector<unsigned> node_id(n_ops, 0);
   std::vector<CladeStep> steps;
   std::vector<CladeGroup> groups;
-  std::unordered_map<unsigned, unsigned> pseudo_row;
-  unsigned clade_rows = 0;
-  const bool repeats = !k20 && (p->attributes & RDAMD_ATTRIB_SITE_REPEATS) && p->sites > 0;
+  std::unordered_map<unsigned, unsigned> pseudo_row, pseudo_wide;
+  unsigned clade_rows = 0, n_wide = 0;
   if (repeats) {
     auto id_of = [&](unsigned clv) { return clv < p->tips ? clv : node_id[producer.at(clv)]; };
     for (unsigned i = 0; i < n_ops; ++i) {
@@ -351,7 +381,12 @@ rdamd_schedule_t *rdamd_schedule_create(rdamd_partition_t *p, const rdamd_operat
         st.n_classes = node->n_classes;
         st.out_mat = mat_above(j);
         st.last = j == i ? 1u : 0u;
-        st.pad[0] = node_id[j];   // (host only: the map offset is filled in below)
+        st.wide_slot = 0xffffffffu;
+        if (j == i && node->n_classes > 16) {
+          st.wide_slot = n_wide;
+          pseudo_wide[o.parent_clv_index] = n_wide++;
+        }
+        st.pad = node_id[j];   // (host only: the map offset is filled in below)
         clade_rows += node->n_classes;
         steps.push_back(st);
         return (unsigned)steps.size() - 1 - g.first;
@@ -365,20 +400,23 @@ rdamd_schedule_t *rdamd_schedule_create(rdamd_partition_t *p, const rdamd_operat
   s->part = p;
   s->tip_generation = p->tip_generation;
 #define TRY(expr) RDAMD_HIP_TRY(expr, (rdamd_schedule_destroy(s), nullptr))
+  s->table_rows = wide_mode ? 64u : 16u;
+  s->n_wide = n_wide;
+  if (wide_mode) TRY(ensure_wide_arena(p));
   if (!groups.empty()) {
     for (CladeStep &st : steps) {
-      TRY(clade_upload_map(p, st.pad[0]));
-      st.map_off = (uint32_t)clade_node(*p->clades, p->tips, st.pad[0])->map_off;
-      st.pad[0] = 0;
+      TRY(clade_upload_map(p, st.pad));
+      st.map_off = (uint32_t)clade_node(*p->clades, p->tips, st.pad)->map_off;
+      st.pad = 0;
     }
     std::vector<rdamd_operation_t> kept;
     for (unsigned i = 0; i < n_ops; ++i) {
       if (!small[i]) { kept.push_back(ops[i]); continue; }
       if (small[consumer[i]]) continue;
-      TRY(clade_upload_codes(p, node_id[i]));
-      pseudo_row[ops[i].parent_clv_index] = (unsigned)clade_node(*p->clades, p->tips, node_id[i])->code_row;
+      TRY(clade_upload_codes(p, node_id[i], wide_mode));
+      pseudo_row[ops[i].parent_clv_index] = (unsigned)clade_node(*p->clades, p->tips, node_id[i])->code_row[wide_mode];
     }
-    if (!compile(kept, pseudo_row, folded)) { rdamd_schedule_destroy(s); return nullptr; }
+    if (!compile(kept, pseudo_row, pseudo_wide, folded)) { rdamd_schedule_destroy(s); return nullptr; }
   }
   const Program &main_prog = groups.empty() ? plain : folded;
   s->n_ops = (unsigned)main_prog.steps.size();
@@ -445,8 +483,8 @@ int rdamd_schedule_stats(const rdamd_schedule_t *s, rdamd_schedule_stats_t *out)
 
 int rdamd_partition_set_site_repeats(rdamd_partition_t *p, unsigned int max_classes) {
   clear_error();
-  if (max_classes > 16) {
-    set_error(46, "rdamd_partition_set_site_repeats: at most 16 classes per pseudo-tip (got %u)", max_classes);
+  if (max_classes > 64) {
+    set_error(46, "rdamd_partition_set_site_repeats: at most 64 classes per pseudo-tip (got %u)", max_classes);
     return RDAMD_FAILURE;
   }
   if (p->states != 4) return RDAMD_SUCCESS;
@@ -500,7 +538,7 @@ static int evaluate_batch_impl(rdamd_partition_t *p, unsigned int n_jobs,
   double *hr = (double *)h;              h += sizeof(double) * R * n_jobs;
   double *hw = (double *)h;
   unsigned max_depth[2] = {1, 1}, reg_levels[2] = {1, 1};   // [0] programs with pseudo-tips, [1] plain
-  unsigned max_groups = 0, max_steps = 0;
+  unsigned max_groups = 0, max_steps = 0, max_wide = 0, table_rows = 16;
   for (unsigned j = 0; j < n_jobs; ++j) {
     const rdamd_schedule_t *s = schedules[j];
     if (!s || s->part != p) {
@@ -524,6 +562,13 @@ static int evaluate_batch_impl(rdamd_partition_t *p, unsigned int n_jobs,
     reg_levels[1] = std::max(reg_levels[1], s->reg_levels_plain);
     max_groups = std::max(max_groups, s->n_groups);
     max_steps = std::max(max_steps, s->n_steps);
+    max_wide = std::max(max_wide, s->n_wide);
+    if (j && s->table_rows != table_rows) {
+      set_error(47, "rdamd_evaluate_batch: job %u was compiled for another site-repeat class limit "
+                    "than job 0 (16-row and 64-row schedules cannot share a launch)", j);
+      return RDAMD_FAILURE;
+    }
+    table_rows = s->table_rows;
     double wide_s[12] = {0}, wide_f[4] = {0};
     const double *sj = subst + (size_t)j * NP, *fj = freqs + (size_t)j * K;
     if (p->embedded()) {   // caller passes [n][2] / [n][2]: into the 4-state shapes
@@ -545,7 +590,17 @@ static int evaluate_batch_impl(rdamd_partition_t *p, unsigned int n_jobs,
     hj[j].depth = max_depth[0];
     hj[j].depth_plain = max_depth[1];
   }
-  const size_t clade_scratch_job = (size_t)max_steps * R * 64;   // doubles: [step][rate][16 rows][4]
+  const size_t clade_scratch_job = (size_t)max_steps * R * table_rows * 4;   // doubles: [step][rate][rows][4]
+  // the job's tables: one 16-row table per (matrix, rate), then its 64-row tables
+  const size_t tiptab_job = k20 ? (size_t)p->prob_matrices * R * kFused20TabDoubles
+                                : (size_t)p->prob_matrices * R * 64 + (size_t)max_wide * R * 256;
+  if (tiptab_job * n_jobs > w->tiptab_doubles) {
+    RDAMD_HIP_TRY(hipStreamSynchronize(p->stream), RDAMD_FAILURE);
+    if (w->d_tiptab) (void)hipFree(w->d_tiptab);
+    w->d_tiptab = nullptr;
+    w->tiptab_doubles = tiptab_job * std::max(n_jobs, w->cap_jobs);
+    RDAMD_HIP_TRY(hipMalloc((void **)&w->d_tiptab, (w->tiptab_doubles + kTiptabPad) * sizeof(double)), RDAMD_FAILURE);
+  }
   if (clade_scratch_job * n_jobs > w->clade_scratch_doubles) {
     if (w->d_clade_scratch) (void)hipFree(w->d_clade_scratch);
     w->d_clade_scratch = nullptr;
@@ -583,12 +638,17 @@ static int evaluate_batch_impl(rdamd_partition_t *p, unsigned int n_jobs,
     RDAMD_HIP_TRY(e, RDAMD_FAILURE);
   } else {
   FusedArgs a;
-  a.jobs = w->d_jobs; a.tipcodes = p->d_tipcodes16; a.pattern_weights = p->d_pattern_weights;
-  a.pmat = w->d_pmat; a.tiptab = w->d_tiptab; a.freqs = w->d_freqs; a.rate_weights = w->d_rw;
+  const bool wide_codes = table_rows > 16;
+  a.jobs = w->d_jobs; a.tipcodes = wide_codes ? p->d_codes_wide : p->d_tipcodes16;
+  a.pattern_weights = p->d_pattern_weights;
+  a.table_rows = table_rows;
+  a.tiptab_job_stride = tiptab_job;
+  a.pmat = w->d_pmat; a.tiptab = w->d_tiptab + kTiptabPad; a.freqs = w->d_freqs; a.rate_weights = w->d_rw;
   a.partials = w->d_partials; a.persite = nullptr;
   a.pmat_job_stride = (size_t)p->prob_matrices * R * 16;
   a.sites = p->sites; a.rate_cats = R;
-  a.tipcodes_bytes = (unsigned)std::min<size_t>((size_t)p->code_rows * p->tip_stride(), 0xffffffffu);
+  a.tipcodes_bytes = (unsigned)std::min<size_t>(wide_codes ? (size_t)p->wide_rows * p->tip_stride() * 2
+                                                           : (size_t)p->code_rows * p->tip_stride(), 0xffffffffu);
   p->prof_begin(4);
   e = launch_fused_pmatrix(a, w->d_q, w->d_rates, n_jobs, p->prob_matrices, p->stream);
   if (e == hipSuccess && max_groups)   // the pseudo-tips' tables, from the P-matrices and tip tables just made

@@ -60,7 +60,8 @@ static_assert(sizeof(FusedJob) == 72, "FusedJob: scalar loads at fixed offsets")
 
 struct FusedArgs {
   const FusedJob *jobs;
-  const uint8_t  *tipcodes;          // [tips + pseudo-tips][tip_stride], code x 16 (rdamd_partition::d_tipcodes16)
+  const uint8_t  *tipcodes;          // [tips + pseudo-tips][tip_stride], code x 16 (rdamd_partition::d_tipcodes16);
+                                     // table_rows = 64: 16-bit entries, rows of 2 tip_stride bytes (d_codes_wide)
   const unsigned *pattern_weights;   // [sites]
   const double   *pmat;              // [job][matrix][rate][16]
   const double   *tiptab;            // [job][matrix][rate][16 codes][4]
@@ -69,8 +70,11 @@ struct FusedArgs {
   double         *partials;          // [job][blocks_x]
   double         *persite;           // [job][sites] or null
   size_t   pmat_job_stride;
+  size_t   tiptab_job_stride;        // doubles per job: 4 pmat_job_stride (one 16-row table per matrix and rate)
+                                     // + the job's 64-row tables [wide pseudo-tip][rate][2 halves][64][2]
   unsigned sites, rate_cats;
-  unsigned tipcodes_bytes;           // rows in use * tip_stride
+  unsigned tipcodes_bytes;           // rows in use * row bytes
+  unsigned table_rows;               // 16 or 64: rows per LDS table slot (and the code arena's entry width)
 };
 
 // ---- 20-state variant (kernels_fused_k20.hip) ---------------------------------

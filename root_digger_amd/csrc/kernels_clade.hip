@@ -75,38 +75,65 @@ unsigned clade_intern(rdamd_partition *p, unsigned child0, unsigned child1, unsi
   return id;
 }
 
-// the code arena: rows of tip_stride() bytes, grown geometrically (programs hold row OFFSETS)
-static hipError_t ensure_code_rows(rdamd_partition *p, unsigned rows) {
-  if (rows <= p->code_rows_cap) return hipSuccess;
-  const unsigned cap = std::max(rows, p->code_rows_cap + p->code_rows_cap / 2 + 16);
-  const size_t stride = p->tip_stride();
+// the code arenas: rows of tip_stride() entries, grown geometrically (programs hold row
+// OFFSETS).  wide = false: the 8-bit arena every 4-state partition has (d_tipcodes16);
+// wide = true: its 16-bit twin for schedules with 64-row tables.
+static hipError_t ensure_code_rows(rdamd_partition *p, unsigned rows, bool wide) {
+  uint8_t *&arena = wide ? p->d_codes_wide : p->d_tipcodes16;
+  unsigned &used = wide ? p->wide_rows : p->code_rows;
+  unsigned &have = wide ? p->wide_rows_cap : p->code_rows_cap;
+  if (rows <= have) return hipSuccess;
+  const unsigned cap = std::max(rows, have + have / 2 + 16);
+  const size_t stride = (size_t)p->tip_stride() * (wide ? 2 : 1);
   if ((size_t)cap * stride + kTipcodePad > 0xffffffffull) return hipErrorOutOfMemory;   // 32-bit offsets
   hipError_t e = hipStreamSynchronize(p->stream);
   if (e != hipSuccess) return e;
   uint8_t *fresh = nullptr;
   e = hipMalloc(&fresh, (size_t)cap * stride + kTipcodePad);
   if (e != hipSuccess) return e;
-  e = hipMemcpy(fresh, p->d_tipcodes16, (size_t)p->code_rows * stride, hipMemcpyDeviceToDevice);
+  if (used) e = hipMemcpy(fresh, arena, (size_t)used * stride, hipMemcpyDeviceToDevice);
   if (e == hipSuccess)
-    e = hipMemset(fresh + (size_t)p->code_rows * stride, 0, (size_t)(cap - p->code_rows) * stride + kTipcodePad);
+    e = hipMemset(fresh + (size_t)used * stride, 0, (size_t)(cap - used) * stride + kTipcodePad);
   if (e != hipSuccess) { (void)hipFree(fresh); return e; }
-  (void)hipFree(p->d_tipcodes16);
-  p->d_tipcodes16 = fresh;
-  p->code_rows_cap = cap;
+  if (arena) (void)hipFree(arena);
+  arena = fresh;
+  have = cap;
   return hipSuccess;
 }
 
-hipError_t clade_upload_codes(rdamd_partition *p, unsigned id) {
+static hipError_t upload_wide_row(rdamd_partition *p, unsigned row, const uint8_t *classes) {
+  std::vector<uint16_t> wide(p->tip_stride(), 0);
+  for (size_t s = 0; s < p->sites; ++s) wide[s] = (uint16_t)(classes[s] << 4);
+  return hipMemcpy(p->d_codes_wide + (size_t)row * p->tip_stride() * 2, wide.data(), wide.size() * 2,
+                   hipMemcpyHostToDevice);
+}
+
+hipError_t ensure_wide_arena(rdamd_partition *p) {
+  if (p->d_codes_wide) return hipSuccess;
+  hipError_t e = ensure_code_rows(p, p->tips, true);
+  for (unsigned t = 0; t < p->tips && e == hipSuccess; ++t)
+    e = upload_wide_row(p, t, p->tipcodes.data() + (size_t)t * p->sites);
+  if (e == hipSuccess) p->wide_rows = p->tips;
+  return e;
+}
+
+hipError_t clade_upload_codes(rdamd_partition *p, unsigned id, bool wide) {
   CladeNode &n = p->clades->nodes[id - p->tips];
-  if (n.code_row >= 0) return hipSuccess;
-  hipError_t e = ensure_code_rows(p, p->code_rows + 1);
+  if (n.code_row[wide] >= 0) return hipSuccess;
+  hipError_t e = wide ? ensure_wide_arena(p) : hipSuccess;
   if (e != hipSuccess) return e;
-  std::vector<uint8_t> row(p->tip_stride(), 0);
-  for (size_t s = 0; s < p->sites; ++s) row[s] = (uint8_t)(n.cls[s] << 4);   // the LDS row offset, as for tips
-  e = hipMemcpy(p->d_tipcodes16 + (size_t)p->code_rows * p->tip_stride(), row.data(), row.size(),
-                hipMemcpyHostToDevice);
+  unsigned &used = wide ? p->wide_rows : p->code_rows;
+  e = ensure_code_rows(p, used + 1, wide);
   if (e != hipSuccess) return e;
-  n.code_row = (int)p->code_rows++;
+  if (wide) {
+    e = upload_wide_row(p, used, n.cls.data());
+  } else {
+    std::vector<uint8_t> row(p->tip_stride(), 0);
+    for (size_t s = 0; s < p->sites; ++s) row[s] = (uint8_t)(n.cls[s] << 4);   // the LDS row offset, as for tips
+    e = hipMemcpy(p->d_tipcodes16 + (size_t)used * p->tip_stride(), row.data(), row.size(), hipMemcpyHostToDevice);
+  }
+  if (e != hipSuccess) return e;
+  n.code_row[wide] = (int)used++;
   return hipSuccess;
 }
 
@@ -149,17 +176,23 @@ hipError_t clade_upload_map(rdamd_partition *p, unsigned id) {
 // node of the clade meets the rescale condition (all entries < 2^-256);
 // if one does -- or if a table entry is small enough for a later tip-tip product to meet it --
 // the launch-wide flag goes up and the evaluator runs the plain programs instead.
-__global__ void __launch_bounds__(64)
+// ROWS: rows per table slot of the launch (16 or 64) = the scratch tables' row count.  A
+// pseudo-tip of up to 16 classes lands in its branch's 16-row table, in the tip tables'
+// layout ([class][state]); one of up to 64 classes in its own 64-row table, stored as the
+// evaluator's LDS slot image ([half][class][2 states]: the table goes to LDS by DMA).
+template <int ROWS>
+__global__ void __launch_bounds__(ROWS == 16 ? 64 : 256)
 clade_table_kernel(FusedJob *__restrict__ jobs, const uint8_t *__restrict__ maps,
                    const double *__restrict__ pmat, double *__restrict__ tiptab, size_t pmat_job_stride,
-                   double *__restrict__ scratch, size_t scratch_job_stride, unsigned R) {
+                   size_t tiptab_job_stride, double *__restrict__ scratch, size_t scratch_job_stride, unsigned R) {
   const unsigned job = blockIdx.y, grp = blockIdx.x;
   const FusedJob jb = jobs[job];
   if (grp >= jb.n_groups) return;
   const CladeGroup g = jb.clade_groups[grp];
   const double *__restrict__ pm = pmat + (size_t)job * pmat_job_stride;        // [matrix][rate][16]
-  double *__restrict__ tt = tiptab + (size_t)job * pmat_job_stride * 4;         // [matrix][rate][16 rows][4]
-  double *__restrict__ sc = scratch + (size_t)job * scratch_job_stride;         // [step][rate][16 rows][4]
+  double *__restrict__ tt = tiptab + (size_t)job * tiptab_job_stride;           // [matrix][rate][16 rows][4]
+  double *__restrict__ wide = tt + pmat_job_stride * 4;                         // [slot][rate][2][64][2]
+  double *__restrict__ sc = scratch + (size_t)job * scratch_job_stride;         // [step][rate][ROWS][4]
   bool unsafe = false;
   for (unsigned k = 0; k < g.count; ++k) {
     const CladeStep st = jb.clade_steps[g.first + k];
@@ -170,22 +203,39 @@ clade_table_kernel(FusedJob *__restrict__ jobs, const uint8_t *__restrict__ maps
 #pragma unroll
       for (int ch = 0; ch < 2; ++ch) {
         const unsigned cc = map[2 * c + ch];
-        const double *row = (st.src[ch] & 0x80000000u)
-                                ? sc + (((size_t)(g.first + (st.src[ch] & 0x7fffffffu)) * R + r) * 16 + cc) * 4
-                                : tt + (((size_t)st.src[ch] * R + r) * 16 + cc) * 4;
+        if (st.src[ch] & 0x80000000u) {
+          const double *row = sc + (((size_t)(g.first + (st.src[ch] & 0x7fffffffu)) * R + r) * ROWS + cc) * 4;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] *= row[i];
+          for (int i = 0; i < 4; ++i) v[i] *= row[i];
+        } else {   // a tip's table (ROWS = 64: stored [half][code][2], kernels_fused.hip)
+          const double *tab = tt + ((size_t)st.src[ch] * R + r) * 64;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[i] *= tab[ROWS > 16 ? (i >> 1) * 32 + cc * 2 + (i & 1) : cc * 4 + i];
+        }
       }
       const double vmax = fmax(fmax(v[0], v[1]), fmax(v[2], v[3]));
       if (vmax > 0.0 && vmax < kScaleThreshold) unsafe = true;   // the reference rule would rescale here
       const double *__restrict__ m = pm + ((size_t)st.out_mat * R + r) * 16;
-      double *out = st.last ? tt + (((size_t)st.out_mat * R + r) * 16 + c) * 4
-                            : sc + (((size_t)(g.first + k) * R + r) * 16 + c) * 4;
+      double t[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const double t = m[i * 4 + 0] * v[0] + m[i * 4 + 1] * v[1] + m[i * 4 + 2] * v[2] + m[i * 4 + 3] * v[3];
-        if (t > 0.0 && t < 0x1p-128) unsafe = true;
-        out[i] = t;
+        t[i] = m[i * 4 + 0] * v[0] + m[i * 4 + 1] * v[1] + m[i * 4 + 2] * v[2] + m[i * 4 + 3] * v[3];
+        if (t[i] > 0.0 && t[i] < 0x1p-128) unsafe = true;
+      }
+      if (ROWS > 16 && st.last && st.wide_slot != 0xffffffffu) {
+        double *out = wide + ((size_t)st.wide_slot * R + r) * (4 * ROWS) + c * 2;
+        out[0] = t[0]; out[1] = t[1];
+        out[2 * ROWS] = t[2]; out[2 * ROWS + 1] = t[3];
+      } else {
+        if (st.last && ROWS > 16) {   // a 16-row table in the DMA layout
+          double *out = tt + ((size_t)st.out_mat * R + r) * 64 + c * 2;
+          out[0] = t[0]; out[1] = t[1]; out[32] = t[2]; out[33] = t[3];
+        } else {
+          double *out = st.last ? tt + (((size_t)st.out_mat * R + r) * 16 + c) * 4
+                                : sc + (((size_t)(g.first + k) * R + r) * ROWS + c) * 4;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) out[i] = t[i];
+        }
       }
     }
     __syncthreads();   // (also orders this workgroup's scratch writes before the next node's reads)
@@ -197,9 +247,14 @@ hipError_t launch_clade_tables(const FusedArgs &a, const uint8_t *d_maps, double
                                size_t scratch_job_stride, unsigned n_jobs, unsigned max_groups,
                                hipStream_t stream) {
   if (!n_jobs || !max_groups) return hipSuccess;
-  clade_table_kernel<<<dim3(max_groups, n_jobs), 64, 0, stream>>>(
-      const_cast<FusedJob *>(a.jobs), d_maps, a.pmat, const_cast<double *>(a.tiptab), a.pmat_job_stride,
-      d_scratch, scratch_job_stride, a.rate_cats);
+  if (a.table_rows > 16)
+    clade_table_kernel<64><<<dim3(max_groups, n_jobs), 256, 0, stream>>>(
+        const_cast<FusedJob *>(a.jobs), d_maps, a.pmat, const_cast<double *>(a.tiptab), a.pmat_job_stride,
+        a.tiptab_job_stride, d_scratch, scratch_job_stride, a.rate_cats);
+  else
+    clade_table_kernel<16><<<dim3(max_groups, n_jobs), 64, 0, stream>>>(
+        const_cast<FusedJob *>(a.jobs), d_maps, a.pmat, const_cast<double *>(a.tiptab), a.pmat_job_stride,
+        a.tiptab_job_stride, d_scratch, scratch_job_stride, a.rate_cats);
   return hipGetLastError();
 }
 

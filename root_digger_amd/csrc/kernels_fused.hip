@@ -40,10 +40,15 @@ __device__ __forceinline__ unsigned uni(unsigned x) {   // assert wave-uniformit
   return (unsigned)__builtin_amdgcn_readfirstlane((int)x);
 }
 
-// LDS per wave: [2][64] doubles of tip-table slots, then the CLV stack
-// [depth][site slot][2 halves][64 lanes] double2, then the rescale-count stack
-// [depth][site slot][64] ints.  NS = sites per lane.
-constexpr unsigned kTabDoubles = 128;
+// LDS per wave: two table slots (X and Y operand) of TR rows each -- a slot holds a table as
+// two half tables with 16-byte rows, states 0-1 then states 2-3, 32 TR bytes --, then the
+// CLV stack [depth][site slot][2 halves][64 lanes] double2, then the rescale-count stack
+// [depth][site slot][64] ints.  NS = sites per lane.  TR = 16: tips and pseudo-tips of up to
+// 16 classes (one double per lane fills a table); TR = 64: pseudo-tips of up to 64 classes as
+// well, whose 2 KB tables go from memory straight into their slot (LDS-DMA, two
+// `buffer_load_dwordx4 ... lds` per table: no VGPR holds them on the way).
+template <int TR>
+constexpr unsigned tab_doubles() { return 8u * TR; }
 
 typedef unsigned v2u __attribute__((ext_vector_type(2)));
 
@@ -77,11 +82,41 @@ __device__ __forceinline__ void matvec(const double *__restrict__ p, const doubl
 typedef double f64x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) const f64x2 *lds_row_ptr;
 typedef __attribute__((address_space(3))) double *lds_f64_ptr;
-template <unsigned BASE>
+typedef __attribute__((address_space(3))) void *lds_void_ptr;
+// Wave-uniform operands (step descriptors, P-matrices, frequencies) are read through the
+// CONSTANT address space: such loads stay scalar (s_load into SGPRs) whatever else the kernel
+// does.  Through plain global pointers the compiler demotes them to vector loads as soon as
+// the kernel contains a memory-writing intrinsic it cannot see through -- the LDS-DMA table
+// loads of the TR = 64 variants did exactly that (sgpr 106 -> 54, vgpr 127 -> 196).  The data
+// are written by earlier launches and constant for this one.
+template <typename T>
+using const_as = const __attribute__((address_space(4))) T *;
+template <typename T>
+__device__ __forceinline__ const_as<T> to_const(const T *p) {
+  return (const_as<T>)(unsigned long long)p;
+}
+template <typename T>   // a whole record (dword by dword: the compiler merges them into s_load_dwordx8 / x16)
+__device__ __forceinline__ T load_const(const T *p) {
+  static_assert(sizeof(T) % 4 == 0, "records of whole dwords");
+  T out;
+  const const_as<unsigned> src = to_const(reinterpret_cast<const unsigned *>(p));
+  unsigned *dst = reinterpret_cast<unsigned *>(&out);
+#pragma unroll
+  for (unsigned i = 0; i < sizeof(T) / 4; ++i) dst[i] = src[i];
+  return out;
+}
+template <unsigned BASE, int TR>
 __device__ __forceinline__ void read_row(unsigned off, double (&t)[4]) {
   const lds_row_ptr row = (lds_row_ptr)(size_t)(off + BASE);
-  const f64x2 lo = row[0], hi = row[16];   // + 256 bytes
+  const f64x2 lo = row[0], hi = row[TR];   // + 16 TR bytes: the other half table
   t[0] = lo[0]; t[1] = lo[1]; t[2] = hi[0]; t[3] = hi[1];
+}
+// the class / tip code of a site, stored as the LDS byte offset of its table row: a byte
+// (code x 16 <= 240) in the arena of 16-row launches, 16 bits where tables have 64 rows
+template <int TR>
+__device__ __forceinline__ unsigned load_code(__amdgpu_buffer_rsrc_t rs, int voff, int soff) {
+  if constexpr (TR == 16) return (unsigned)__builtin_amdgcn_raw_buffer_load_b8(rs, voff, soff, 0);
+  else return (unsigned)__builtin_amdgcn_raw_buffer_load_b16(rs, voff, soff, 0);
 }
 
 // v = tx * ty, then the 2^256 rescale when all four entries are < 2^-256
@@ -107,11 +142,11 @@ __device__ __forceinline__ void combine(const double (&tx)[4], const double (&ty
 // lane at two sites per lane (142: three waves per SIMD) and is taken when it frees
 // enough LDS to more than pay for that (deep stacks of 500- and 1000-taxon trees:
 // three LDS levels allow 10 waves per CU, two LDS levels 15).
-template <int NS, bool TTCHECK, int RL>
+template <int NS, bool TTCHECK, int RL, int TR>
 __global__ void __launch_bounds__(64)
 fused_dna_eval_kernel(FusedArgs a) {
   extern __shared__ double lds[];
-  // (read_row<> and the tip-table writes address LDS bytes 0 and 512 absolutely: that
+  // (read_row<> and the table writes address LDS bytes 0 and 32 TR absolutely: that
   // is the dynamic block only while this kernel has no static __shared__ in front of
   // it -- launch_fused_eval_ns checks the kernel's static LDS size on the host; a
   // device-side test here cost a factor 2.6, its trap path changes the whole kernel)
@@ -135,32 +170,37 @@ fused_dna_eval_kernel(FusedArgs a) {
   // the launch >= 2^-128 (checked where the tables are built) the product is 0 or
   // >= 2^-256 and the rescale test cannot fire on a non-zero vector: it is compiled
   // out of the variant that runs then (+3.5 % on c2; a run-time branch gave nothing)
-  if ((uni(a.jobs[0].tt_unsafe) != 0u) != TTCHECK) return;
+  if ((uni(to_const(&a.jobs[0].tt_unsafe)[0]) != 0u) != TTCHECK) return;
   constexpr bool tt_safe = !TTCHECK;
   // (the variant with the test walks the PLAIN programs -- no pseudo-tips, every rescale
   // where the reference rule has it; fused.hpp)
-  const FusedJob jb = a.jobs[job];
+  const FusedJob jb = load_const(a.jobs + job);
   const FusedOp *__restrict__ prog = TTCHECK ? jb.prog_plain : jb.prog;   // n_ops + 4 entries (tail padded)
   const unsigned nops = TTCHECK ? jb.n_ops_plain : jb.n_ops;
   const unsigned lds_levels = TTCHECK ? jb.depth_plain : jb.depth;
-  const char *__restrict__ pm = reinterpret_cast<const char *>(a.pmat + (size_t)job * a.pmat_job_stride);
-  const double *__restrict__ freqs = a.freqs + (size_t)job * 4;
-  const double *__restrict__ rw = a.rate_weights + (size_t)job * R;
+  const const_as<char> pm = to_const(reinterpret_cast<const char *>(a.pmat + (size_t)job * a.pmat_job_stride));
+  const const_as<double> freqs = to_const(a.freqs + (size_t)job * 4);
+  const const_as<double> rw = to_const(a.rate_weights + (size_t)job * R);
   // tip codes and this job's tip tables through buffer descriptors: the
   // per-operation part of every address is a scalar offset, the per-lane part
   // a loop-invariant VGPR, so address generation costs no vector instruction
   const __amdgpu_buffer_rsrc_t tips_rs = make_rsrc(a.tipcodes, a.tipcodes_bytes);
+  // (TR = 64: 1 KB in front of the job's tables, see RDAMD_LOAD_TAB; the workspace has that pad)
   const __amdgpu_buffer_rsrc_t tab_rs =
-      make_rsrc(a.tiptab + (size_t)job * a.pmat_job_stride * 4, (unsigned)(a.pmat_job_stride * 32));
-  const int lane8 = (int)lane * 8;
-  // where this lane's table entry (code lane / 4, state lane % 4) goes in LDS: see read_row
-  const unsigned tab_wr = ((lane & 2u) ? 256u : 0u) + (lane >> 2) * 16u + (lane & 1u) * 8u;
+      make_rsrc(reinterpret_cast<const char *>(a.tiptab + (size_t)job * a.tiptab_job_stride) - (TR == 16 ? 0 : 1024),
+                (unsigned)(a.tiptab_job_stride * 8) + (TR == 16 ? 0u : 1024u));
+  const int lane8 = (int)lane * 8, lane16 = (int)lane * 16;
+  // the lanes behind a 16-row half table carry nothing: an offset beyond the descriptor's range
+  // makes their loads no-ops (zeros into slot rows that a 16-row table never addresses)
+  const int lane16_narrow = lane < 16u ? lane16 : 0x40000000;
+  // where this lane's entry of a 16-row table (code lane / 4, state lane % 4) goes in LDS: see read_row
+  const unsigned tab_wr = ((lane & 2u) ? 16u * TR : 0u) + (lane >> 2) * 16u + (lane & 1u) * 8u;
+  constexpr unsigned kYSlot = 32u * TR;   // the X / Y table slots sit at LDS bytes 0 and 32 TR
   int site_off[NS];
 #pragma unroll
-  for (int q = 0; q < NS; ++q) site_off[q] = (int)site[q];
-  // (the X / Y tip tables sit at LDS bytes 0 and 512, two half tables each: read_row)
-  double2 *stk = reinterpret_cast<double2 *>(lds + kTabDoubles) + lane;
-  int *stk_sc = reinterpret_cast<int *>(lds + kTabDoubles + (size_t)lds_levels * NS * 256) + lane;
+  for (int q = 0; q < NS; ++q) site_off[q] = (int)site[q] * (TR == 16 ? 1 : 2);
+  double2 *stk = reinterpret_cast<double2 *>(lds + tab_doubles<TR>()) + lane;
+  int *stk_sc = reinterpret_cast<int *>(lds + tab_doubles<TR>() + (size_t)lds_levels * NS * 256) + lane;
 
   double term[NS];   // sum_r w_r f_r 2^(-256 (s_r - smin))
   int smin[NS];
@@ -180,19 +220,45 @@ fused_dna_eval_kernel(FusedArgs a) {
     // force the wait for the prefetch into the same iteration): while op i
     // computes, the tip codes / tip-table entries of op i+1 and the descriptor
     // of op i+2 are in flight.
+    // Operand tables of the NEXT operation.  TR = 16: a table is one double per lane,
+    // prefetched into a register and dropped into its slot when the operation starts.
+    // TR = 64: every table goes from memory straight into its slot (LDS-DMA, no register on
+    // the way, no branch on the table's size): two 16-byte-per-lane pieces, one per half
+    // table -- 64 lanes for a 64-row table (flags 0x2000 X / 0x4000 Y), lanes 0-15 for a
+    // 16-row one (the others get an out-of-range offset: no EXEC juggling, no branch; skipping
+    // the loads of an operand the next step does not have -- X unless it is tip-tip, Y if it
+    // pops -- with a branch measured c2 -9 %, 125.phy +4 %: not taken), whose
+    // second half sits 256 bytes behind the first in memory but 16 TR bytes behind it in the slot (the instruction offset moves source AND destination,
+    // profiles/micro/lds_dma_offset.hip; the scalar offset makes up the difference, which is
+    // why tab_rs starts 1 KB in front of the job's tables).  The wait in front: this
+    // operation's own rows must have left the slots before new tables land in them.
+#define RDAMD_LOAD_TAB(op, SLOT, WIDE, tOFF, e)                                                 \
+  if (TR == 16) {                                                                               \
+    e = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(                         \
+        tab_rs, lane8, (int)((uni(op.tOFF) + roff) * 4u), 0));                                  \
+  } else {                                                                                      \
+    const bool wide = (uni(op.flags) & WIDE) != 0u;                                             \
+    const int so = (int)((uni(op.tOFF) + (wide ? roff * 4u : roff)) * 4u) + 1024;               \
+    const int vo = wide ? lane16 : lane16_narrow;   /* (lanes 16.. of a 16-row table: out of range) */ \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(tab_rs, (lds_void_ptr)(size_t)(SLOT), 16, vo, so, 0, 0); \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(tab_rs, (lds_void_ptr)(size_t)(SLOT), 16, vo,       \
+                                             wide ? so : so - 768, 16 * TR, 0);                 \
+  }
 #define RDAMD_LOAD_TIPS(op, cx, cy, ex, ey)                                                     \
   _Pragma("unroll") for (int q = 0; q < NS; ++q) {                                              \
-    cx[q] = (unsigned)__builtin_amdgcn_raw_buffer_load_b8(tips_rs, site_off[q], (int)uni(op.cX), 0); \
-    cy[q] = (unsigned)__builtin_amdgcn_raw_buffer_load_b8(tips_rs, site_off[q], (int)uni(op.cY), 0); \
+    cx[q] = load_code<TR>(tips_rs, site_off[q], (int)uni(op.cX));                               \
+    cy[q] = load_code<TR>(tips_rs, site_off[q], (int)uni(op.cY));                               \
   }                                                                                             \
-  ex = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(                          \
-      tab_rs, lane8, (int)((uni(op.tX) + roff) * 4u), 0));                                      \
-  ey = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(                          \
-      tab_rs, lane8, (int)((uni(op.tY) + roff) * 4u), 0));
+  if (TR > 16) __builtin_amdgcn_s_waitcnt(0xc07f);   /* lgkmcnt(0) */                           \
+  RDAMD_LOAD_TAB(op, 0u, 0x2000u, tX, ex)                                                       \
+  RDAMD_LOAD_TAB(op, kYSlot, 0x4000u, tY, ey)
+    // (TR = 64: the descriptor of the operation after next only now -- fetched at the top of
+    // the step it would sit in front of the wait above)
+#define RDAMD_LATE_DESC(cur, idx2) if (TR > 16) cur = load_const(prog + (idx2));
     // the ONE matrix an operation applies to the running CLV, into SGPRs
 #define RDAMD_LOAD_M(op, M)                                                                     \
   {                                                                                             \
-    const double *__restrict__ pp = reinterpret_cast<const double *>(pm + uni(op.pM) + roff);   \
+    const const_as<double> pp = (const_as<double>)(pm + uni(op.pM) + roff);                     \
     _Pragma("unroll") for (int k = 0; k < 16; ++k) M[k] = pp[k];                                \
   }
 
@@ -203,16 +269,20 @@ fused_dna_eval_kernel(FusedArgs a) {
 #define RDAMD_STEP(cur, nxt, cx, cy, ex, ey, ncx, ncy, nex, ney, idx2)                          \
   {                                                                                             \
     const unsigned kind = uni(cur.flags);                                                       \
-    cur = prog[idx2];                                                                           \
+    if (TR == 16) cur = load_const(prog + (idx2));                                              \
     unsigned rowx[NS], rowy[NS];   /* byte offsets of the rows inside the X / Y table = the codes */ \
     _Pragma("unroll") for (int q = 0; q < NS; ++q) { rowx[q] = cx[q]; rowy[q] = cy[q]; }        \
     double tx[NS][4], ty[NS][4];                                                                \
     const unsigned k3 = kind & 3u;                                                              \
     if (k3 == kFusedTT) {                                                                       \
-      ((lds_f64_ptr)(size_t)tab_wr)[0] = ex;                                                    \
-      ((lds_f64_ptr)(size_t)tab_wr)[64] = ey;                                                   \
-      _Pragma("unroll") for (int q = 0; q < NS; ++q) { read_row<0>(rowx[q], tx[q]); read_row<512>(rowy[q], ty[q]); } \
-      RDAMD_LOAD_TIPS(nxt, ncx, ncy, nex, ney)                                                  \
+      if (TR == 16) {                                                                           \
+        ((lds_f64_ptr)(size_t)tab_wr)[0] = ex;                                                  \
+        ((lds_f64_ptr)(size_t)tab_wr)[4 * TR] = ey;                                             \
+      } else {   /* the tables came by DMA: the compiler does not order the reads below behind it */ \
+        __builtin_amdgcn_s_waitcnt(0x0f70);   /* vmcnt(0) */                                    \
+      }                                                                                         \
+      _Pragma("unroll") for (int q = 0; q < NS; ++q) { read_row<0, TR>(rowx[q], tx[q]); read_row<kYSlot, TR>(rowy[q], ty[q]); } \
+      RDAMD_LOAD_TIPS(nxt, ncx, ncy, nex, ney) RDAMD_LATE_DESC(cur, idx2)                       \
       if (kind & 0x100u) { /* park M . (running CLV) for the later inner-inner node */          \
         if (kind & 0x200u) { /* stack level 0 lives in registers: the product lands there */    \
           _Pragma("unroll") for (int q = 0; q < NS; ++q) {                                      \
@@ -243,20 +313,21 @@ fused_dna_eval_kernel(FusedArgs a) {
         else combine(tx[q], ty[q], st.v[q], st.sc[q]);                                          \
       }                                                                                         \
     } else if (k3 == kFusedRT) {                                                                \
-      ((lds_f64_ptr)(size_t)tab_wr)[64] = ey;                                                   \
-      _Pragma("unroll") for (int q = 0; q < NS; ++q) read_row<512>(rowy[q], ty[q]);             \
-      RDAMD_LOAD_TIPS(nxt, ncx, ncy, nex, ney)                                                  \
+      if (TR == 16) ((lds_f64_ptr)(size_t)tab_wr)[4 * TR] = ey;                                 \
+      else __builtin_amdgcn_s_waitcnt(0x0f70);   /* vmcnt(0): the table came by DMA */          \
+      _Pragma("unroll") for (int q = 0; q < NS; ++q) read_row<kYSlot, TR>(rowy[q], ty[q]);      \
+      RDAMD_LOAD_TIPS(nxt, ncx, ncy, nex, ney) RDAMD_LATE_DESC(cur, idx2)                       \
       _Pragma("unroll") for (int q = 0; q < NS; ++q) matvec(M, st.v[q], tx[q]);                 \
       RDAMD_LOAD_M(nxt, M)                                                                      \
       _Pragma("unroll") for (int q = 0; q < NS; ++q) combine(tx[q], ty[q], st.v[q], st.sc[q]);  \
     } else { /* kFusedRP: running CLV times M, sibling already multiplied when parked */        \
       if (kind & 0x400u) { /* the sibling waits in the register slot: used in place */          \
-        RDAMD_LOAD_TIPS(nxt, ncx, ncy, nex, ney)                                                \
+        RDAMD_LOAD_TIPS(nxt, ncx, ncy, nex, ney) RDAMD_LATE_DESC(cur, idx2)                     \
         _Pragma("unroll") for (int q = 0; q < NS; ++q) matvec(M, st.v[q], tx[q]);               \
         RDAMD_LOAD_M(nxt, M)                                                                    \
         _Pragma("unroll") for (int q = 0; q < NS; ++q) { st.sc[q] += s0sc[q]; combine(tx[q], s0[q], st.v[q], st.sc[q]); } \
       } else if (RL >= 2 && (kind & 0x1000u)) {                                                 \
-        RDAMD_LOAD_TIPS(nxt, ncx, ncy, nex, ney)                                                \
+        RDAMD_LOAD_TIPS(nxt, ncx, ncy, nex, ney) RDAMD_LATE_DESC(cur, idx2)                     \
         _Pragma("unroll") for (int q = 0; q < NS; ++q) matvec(M, st.v[q], tx[q]);               \
         RDAMD_LOAD_M(nxt, M)                                                                    \
         _Pragma("unroll") for (int q = 0; q < NS; ++q) { st.sc[q] += s1sc[q]; combine(tx[q], s1[q], st.v[q], st.sc[q]); } \
@@ -269,7 +340,7 @@ fused_dna_eval_kernel(FusedArgs a) {
           ty[q][0] = lo.x; ty[q][1] = lo.y; ty[q][2] = hi.x; ty[q][3] = hi.y;                   \
           scy[q] = stk_sc[(sp * NS + q) * 64];                                                  \
         }                                                                                       \
-        RDAMD_LOAD_TIPS(nxt, ncx, ncy, nex, ney)                                                \
+        RDAMD_LOAD_TIPS(nxt, ncx, ncy, nex, ney) RDAMD_LATE_DESC(cur, idx2)                     \
         _Pragma("unroll") for (int q = 0; q < NS; ++q) matvec(M, st.v[q], tx[q]);               \
         RDAMD_LOAD_M(nxt, M)                                                                    \
         _Pragma("unroll") for (int q = 0; q < NS; ++q) { st.sc[q] += scy[q]; combine(tx[q], ty[q], st.v[q], st.sc[q]); } \
@@ -293,8 +364,8 @@ fused_dna_eval_kernel(FusedArgs a) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) s1[q][k] = 0.0;
     }
-    FusedOp dA = prog[0];
-    FusedOp dB = prog[1];
+    FusedOp dA = load_const(prog);
+    FusedOp dB = load_const(prog + 1);
     unsigned cxA[NS], cyA[NS], cxB[NS], cyB[NS];
     double exA = 0.5, eyA = 0.25, exB = 0.5, eyB = 0.25;
 #pragma unroll
@@ -365,7 +436,8 @@ __global__ void __launch_bounds__(64)
 fused_pmatrix_k4_kernel(const double *__restrict__ q, const double *__restrict__ rates,
                         FusedJob *__restrict__ jobs, unsigned n_jobs,
                         unsigned n_mat, unsigned R, double *__restrict__ pmat,
-                        double *__restrict__ tiptab, size_t pmat_job_stride) {
+                        double *__restrict__ tiptab, size_t pmat_job_stride, size_t tiptab_job_stride,
+                        unsigned table_rows) {
   const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t per_job = (size_t)n_mat * R;
   if (gid >= per_job * n_jobs) return;
@@ -428,7 +500,8 @@ fused_pmatrix_k4_kernel(const double *__restrict__ q, const double *__restrict__
     pmo[i] = out[i];
   }
   // tip table of this (matrix, rate): row c = sum over the states in code c
-  double *tto = tiptab + ((size_t)job * pmat_job_stride + ((size_t)m * R + r) * 16) * 4;
+  // (64-row launches: as the evaluator's LDS image, [half][code][2 states] -- it goes there by DMA)
+  double *tto = tiptab + (size_t)job * tiptab_job_stride + ((size_t)m * R + r) * 64;
 #pragma unroll
   for (int c = 0; c < 16; ++c)
 #pragma unroll
@@ -437,7 +510,7 @@ fused_pmatrix_k4_kernel(const double *__restrict__ q, const double *__restrict__
 #pragma unroll
       for (int j = 0; j < 4; ++j)
         if ((c >> j) & 1) acc += out[i * 4 + j];
-      tto[c * 4 + i] = acc;
+      tto[table_rows > 16 ? (i >> 1) * 32 + c * 2 + (i & 1) : c * 4 + i] = acc;
     }
   // every table entry is a sum of P entries, so the smallest non-zero P entry bounds
   // them all from below (FusedJob::tt_unsafe; 2^-128 = 0x1p-128)
@@ -453,37 +526,37 @@ hipError_t launch_fused_pmatrix(const FusedArgs &a, const double *d_q, const dou
   if (!total) return hipSuccess;
   fused_pmatrix_k4_kernel<<<(unsigned)((total + 63) / 64), 64, 0, stream>>>(
       d_q, d_rates, const_cast<FusedJob *>(a.jobs), n_jobs, n_mat, a.rate_cats, const_cast<double *>(a.pmat),
-      const_cast<double *>(a.tiptab), a.pmat_job_stride);
+      const_cast<double *>(a.tiptab), a.pmat_job_stride, a.tiptab_job_stride, a.table_rows);
   return hipGetLastError();
 }
 
-template <int NS, bool TTCHECK, int RL>
+template <int NS, bool TTCHECK, int RL, int TR>
 static hipError_t launch_fused_variant(const FusedArgs &a, unsigned n_jobs, unsigned max_depth, unsigned gx,
                                        hipStream_t stream) {
-  const size_t lds = kTabDoubles * sizeof(double) +
+  const size_t lds = tab_doubles<TR>() * sizeof(double) +
                      (size_t)(max_depth ? max_depth : 1) * NS * 64 * (4 * sizeof(double) + sizeof(int));
   static size_t lds_allowed = 48 * 1024;
   if (lds > lds_allowed) {   // deep stacks (very unbalanced 10^3-taxon trees): raise the limit
-    hipError_t e = hipFuncSetAttribute((const void *)fused_dna_eval_kernel<NS, TTCHECK, RL>,
+    hipError_t e = hipFuncSetAttribute((const void *)fused_dna_eval_kernel<NS, TTCHECK, RL, TR>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     lds_allowed = lds;
   }
   static const bool lds_starts_at_zero = [] {   // see the note at the top of the kernel
     hipFuncAttributes attr;
-    return hipFuncGetAttributes(&attr, (const void *)fused_dna_eval_kernel<NS, TTCHECK, RL>) == hipSuccess &&
+    return hipFuncGetAttributes(&attr, (const void *)fused_dna_eval_kernel<NS, TTCHECK, RL, TR>) == hipSuccess &&
            attr.sharedSizeBytes == 0;
   }();
   if (!lds_starts_at_zero) return hipErrorInvalidValue;
-  fused_dna_eval_kernel<NS, TTCHECK, RL><<<dim3(gx, n_jobs), 64, lds, stream>>>(a);
+  fused_dna_eval_kernel<NS, TTCHECK, RL, TR><<<dim3(gx, n_jobs), 64, lds, stream>>>(a);
   return hipGetLastError();
 }
 
-template <int NS, bool TTCHECK>
+template <int NS, bool TTCHECK, int TR>
 static hipError_t launch_fused_variant_rl(const FusedArgs &a, unsigned n_jobs, unsigned max_depth, unsigned gx,
                                           unsigned reg_levels, hipStream_t stream) {
-  return reg_levels >= 2 ? launch_fused_variant<NS, TTCHECK, 2>(a, n_jobs, max_depth, gx, stream)
-                         : launch_fused_variant<NS, TTCHECK, 1>(a, n_jobs, max_depth, gx, stream);
+  return reg_levels >= 2 ? launch_fused_variant<NS, TTCHECK, 2, TR>(a, n_jobs, max_depth, gx, stream)
+                         : launch_fused_variant<NS, TTCHECK, 1, TR>(a, n_jobs, max_depth, gx, stream);
 }
 
 // sites_per_lane: 1 or 2.  Two sites per lane share every scalar operand (P-matrix
@@ -496,14 +569,14 @@ static hipError_t launch_fused_variant_rl(const FusedArgs &a, unsigned n_jobs, u
 // rescale test ([0]), the one on the plain programs with it ([1]) -- each with the LDS and
 // the register stack levels ITS programs need; the one the launch's flag rules out returns
 // at once.
-template <int NS>
+template <int NS, int TR>
 static hipError_t launch_fused_eval_ns(const FusedArgs &a, unsigned n_jobs, const unsigned max_depth[2],
                                        unsigned blocks_x, const unsigned reg_levels[2], double *d_out,
                                        hipStream_t stream) {
   const unsigned gx = (blocks_x + NS - 1) / NS;   // blocks_x counts 64-site blocks
-  hipError_t e = launch_fused_variant_rl<NS, false>(a, n_jobs, max_depth[0], gx, reg_levels[0], stream);
+  hipError_t e = launch_fused_variant_rl<NS, false, TR>(a, n_jobs, max_depth[0], gx, reg_levels[0], stream);
   if (e != hipSuccess) return e;
-  e = launch_fused_variant_rl<NS, true>(a, n_jobs, max_depth[1], gx, reg_levels[1], stream);   // (returns at once on ordinary data)
+  e = launch_fused_variant_rl<NS, true, TR>(a, n_jobs, max_depth[1], gx, reg_levels[1], stream);   // (returns at once on ordinary data)
   if (e != hipSuccess) return e;
   fused_finish_kernel<<<n_jobs, 256, 0, stream>>>(a.partials, gx, d_out);
   return hipGetLastError();
@@ -513,8 +586,11 @@ hipError_t launch_fused_eval(const FusedArgs &a, unsigned n_jobs, const unsigned
                              unsigned blocks_x, unsigned sites_per_lane, const unsigned reg_levels[2],
                              double *d_out, hipStream_t stream) {
   if (!n_jobs) return hipSuccess;
-  return sites_per_lane == 2 ? launch_fused_eval_ns<2>(a, n_jobs, max_depth, blocks_x, reg_levels, d_out, stream)
-                             : launch_fused_eval_ns<1>(a, n_jobs, max_depth, blocks_x, reg_levels, d_out, stream);
+  if (a.table_rows > 16)   // 16-bit code arena, 64-row table slots
+    return sites_per_lane == 2 ? launch_fused_eval_ns<2, 64>(a, n_jobs, max_depth, blocks_x, reg_levels, d_out, stream)
+                               : launch_fused_eval_ns<1, 64>(a, n_jobs, max_depth, blocks_x, reg_levels, d_out, stream);
+  return sites_per_lane == 2 ? launch_fused_eval_ns<2, 16>(a, n_jobs, max_depth, blocks_x, reg_levels, d_out, stream)
+                             : launch_fused_eval_ns<1, 16>(a, n_jobs, max_depth, blocks_x, reg_levels, d_out, stream);
 }
 
 }  // namespace rdamd

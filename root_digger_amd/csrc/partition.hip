@@ -8,6 +8,9 @@
 #include <cstring>
 #include <unordered_map>
 
+#include <dlfcn.h>
+
+#include "clades.hpp"
 #include "common.hpp"
 
 namespace rdamd {
@@ -116,6 +119,17 @@ extern "C" {
 int rdamd_errno(void) { return g_errno; }
 const char *rdamd_errmsg(void) { return g_errmsg; }
 const char *rdamd_version(void) { return "root_digger_amd 0.1 (gfx950)"; }
+
+// the libamdhip64 that serves this library (a process may hold a second one, e.g. the copy
+// PyTorch bundles): device pointers are only good between code on the SAME runtime
+const char *rdamd_hip_runtime_path(void) {
+  static std::string path = [] {
+    Dl_info info;
+    if (dladdr(reinterpret_cast<void *>(&hipGetDevice), &info) && info.dli_fname) return std::string(info.dli_fname);
+    return std::string();
+  }();
+  return path.c_str();
+}
 
 int rdamd_device_count(void) {
   int n = 0;
@@ -270,7 +284,7 @@ rdamd_partition_t *rdamd_partition_create(unsigned int tips, unsigned int clv_bu
 void rdamd_partition_destroy(rdamd_partition_t *p) {
   if (!p) return;
   if (p->stream) (void)hipStreamSynchronize(p->stream);
-  void *dev[] = {p->d_tipcodes, p->d_tipcodes16, p->d_clv, p->d_scaler, p->d_pmat, p->d_tiptab, p->d_pmat_mfma,
+  void *dev[] = {p->d_tipcodes, p->d_tipcodes16, p->d_codes_wide, p->d_clv, p->d_scaler, p->d_pmat, p->d_tiptab, p->d_pmat_mfma,
                  p->d_codemask, p->d_q, p->d_freqs, p->d_rates, p->d_rate_weights,
                  p->d_pattern_weights, p->d_tipclv_scratch, p->d_scratch,
                  p->d_partials, p->d_result, p->d_persite, p->d_counter};
@@ -332,9 +346,17 @@ int rdamd_set_tip_states(rdamd_partition_t *p, unsigned int tip_index,
   p->tip_generation += 1;
   if (p->clades) {
     RDAMD_HIP_TRY(hipStreamSynchronize(p->stream), RDAMD_FAILURE);
+    const unsigned keep = p->clades->max_classes;
     rdamd::clade_cache_free(p->clades);
-    p->clades = nullptr;
+    p->clades = new rdamd::CladeCache();
+    p->clades->max_classes = keep;
     p->code_rows = p->tips;
+  }
+  if (p->d_codes_wide) {   // (rebuilt from the host copy when the next wide schedule is compiled)
+    RDAMD_HIP_TRY(hipStreamSynchronize(p->stream), RDAMD_FAILURE);
+    (void)hipFree(p->d_codes_wide);
+    p->d_codes_wide = nullptr;
+    p->wide_rows = p->wide_rows_cap = 0;
   }
   RDAMD_HIP_TRY(upload(p, p->d_tipcodes + (size_t)tip_index * p->tip_stride(), row, S), RDAMD_FAILURE);
   if (p->d_tipcodes16) {   // the same row as LDS row offsets (kernels_fused.hip)

@@ -96,3 +96,25 @@ def test_k20_operand_layouts_are_consistent(tmp_path):
                            os.path.join(util.ROOT, "tests", "cpp", "k20_layout_check.cpp"), "-o", exe])
     out = subprocess.run([exe], stdout=subprocess.PIPE, text=True)
     assert out.returncode == 0 and "k20 layouts OK" in out.stdout, out.stdout
+
+
+def test_two_hip_runtimes_are_detected():
+    """bench.py hands torch device pointers to librdamd only when both sit on ONE libamdhip64
+    (check_one_hip_runtime).  The helpers behind that check, in both import orders: torch
+    first, librdamd binds to torch's bundled runtime (one instance); librdamd first, torch
+    brings a second one."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r)\n%s\n"
+            "print(len(rd.mapped_hip_runtimes()), rd.hip_runtime_path() in rd.mapped_hip_runtimes())")
+    first = subprocess.run([sys.executable, "-c", code % (util.ROOT, "import torch\nimport root_digger_amd as rd")],
+                           capture_output=True, text=True, timeout=300)
+    assert first.returncode == 0, first.stderr
+    n, inside = first.stdout.split()
+    assert inside == "True" and int(n) >= 1
+    if int(n) == 1:   # (an image whose torch uses the system ROCm has one runtime either way)
+        second = subprocess.run([sys.executable, "-c",
+                                 code % (util.ROOT, "import root_digger_amd as rd\nimport torch")],
+                                capture_output=True, text=True, timeout=300)
+        assert second.returncode == 0, second.stderr
+        assert second.stdout.split()[1] == "True"

@@ -17,10 +17,12 @@ pytestmark = pytest.mark.gpu
 LNL_TOL = 1e-11
 
 
-def trio(tree, seqs, R, weights=None):
-    """(partition with repeats, partition without, oracle) on the same data"""
+def trio(tree, seqs, R, weights=None, classes=16):
+    """(partition with repeats, partition without, oracle) on the same data; classes = the
+    pseudo-tips' class limit (16: 16-row tables only; 64: 64-row tables through LDS-DMA too)"""
     S = len(next(iter(seqs.values())))
     a = rd.Partition.for_tree(tree, 4, S, R, attributes=rd.ATTRIB_SITE_REPEATS)
+    a.set_site_repeats(classes)
     b = rd.Partition.for_tree(tree, 4, S, R)
     o = OraclePartition.for_tree(tree, 4, S, R)
     for p, m in ((a, rd.MAP_NT), (b, rd.MAP_NT), (o, ORC_MAP_NT)):
@@ -37,14 +39,26 @@ def oracle_eval(o, tree, rl, subst, freqs, rates, weights=None):
     return util.compute_lh(o, tree, rl)
 
 
+CLASSES = [16, 64]
+
+
+@pytest.mark.parametrize("classes", CLASSES)
 @pytest.mark.parametrize("n,S,R,seed", [(100, 2000, 4, 141), (37, 1000, 1, 142), (64, 333, 2, 143),
                                         (16, 65, 3, 144), (5, 7, 4, 145), (4, 1, 4, 146)])
-def test_repeats_vs_oracle_on_random_shapes(n, S, R, seed):
+def test_repeats_vs_oracle_on_random_shapes(n, S, R, seed, classes):
     w = synth.workload(n, S, 4, R, seed)
     tree = rd.Tree.from_newick(w["newick"])
     rng = np.random.default_rng(seed)
     weights = rng.integers(1, 4, size=S).astype(np.uint32)
-    a, b, o = trio(tree, w["seqs"], R, weights)
+    if classes > 16:   # gaps and ambiguity codes as in real alignments: cherries with 17-64 classes
+        seqs = {}
+        for k, v in w["seqs"].items():
+            v = np.frombuffer(v.encode(), dtype=np.uint8).copy()
+            v[rng.random(S) < 0.15] = ord("-")
+            v[rng.random(S) < 0.02] = ord("R")
+            seqs[k] = v.tobytes().decode()
+        w["seqs"] = seqs
+    a, b, o = trio(tree, w["seqs"], R, weights, classes)
     picks = rng.choice(tree.root_count(), size=min(6, tree.root_count()), replace=False)
     rls = [tree.root_location(int(i)).with_ratio(float(rng.uniform(0.02, 0.98))) for i in picks]
     sa = [a.schedule(*tree.generate_operations(rl)) for rl in rls]
@@ -74,14 +88,15 @@ def test_repeats_vs_oracle_on_random_shapes(n, S, R, seed):
         p.destroy()
 
 
-def test_repeats_on_the_reference_fixtures():
+@pytest.mark.parametrize("classes", CLASSES)
+def test_repeats_on_the_reference_fixtures(classes):
     """10.fasta (all 17 roots, the four parameter sets of test/src/model.cpp:12-17) and 101.phy
     (ambiguity codes, zero-length branches: most of its cherries have more than 16 classes and
     stay as they are -- the mixture of folded and unfolded clades is the point)."""
     gd = util.golden("ten_fasta.json")
     tree = rd.Tree.from_file(util.DATA + "/10.tree")
     seqs = util.read_fasta(util.DATA + "/10.fasta")
-    a, b, o = trio(tree, seqs, 4)
+    a, b, o = trio(tree, seqs, 4, None, classes)
     freqs = a.empirical_frequencies()
     rates = rd.compute_gamma_cats(1.0, 4)
     a.set_category_rates(rates)
@@ -96,12 +111,14 @@ def test_repeats_on_the_reference_fixtures():
 
     tree = rd.Tree.from_file(util.DATA + "/101.tree")
     seqs, weights = util.compress(util.read_phylip(util.DATA + "/101.phy"))
-    a, b, o = trio(tree, seqs, 4, weights)
+    a, b, o = trio(tree, seqs, 4, weights, classes)
     freqs = a.empirical_frequencies()
     rng = np.random.default_rng(7)
     picks = [0, 57, 101, 150, tree.root_count() - 1]
     rls = [tree.root_location(i).with_ratio(float(rng.uniform(0.1, 0.9))) for i in picks]
     scheds = [a.schedule(*tree.generate_operations(rl)) for rl in rls]
+    folded = [s_.stats()["clade_nodes"] for s_ in scheds]
+    assert min(folded) >= (25 if classes > 16 else 0)     # census: ~32 of 100 operations at 64 classes, ~0 at 16
     subst = rng.uniform(1e-3, 1.0, (len(rls), 12))
     got = a.evaluate_batch(scheds, subst, np.tile(freqs, (len(rls), 1)), np.tile(rates, (len(rls), 1)))
     for j, rl in enumerate(rls):
@@ -110,12 +127,13 @@ def test_repeats_on_the_reference_fixtures():
         p.destroy()
 
 
-def test_repeats_on_the_deep_scaling_caterpillar():
+@pytest.mark.parametrize("classes", CLASSES)
+def test_repeats_on_the_deep_scaling_caterpillar(classes):
     """161-taxon caterpillar whose CLVs are rescaled many times: the folded cherry at the far
     end carries no rescale count, everything above it does."""
     gd = util.golden("deep_scaling.json")
     tree = rd.Tree.from_newick(gd["newick"])
-    a, b, o = trio(tree, gd["seqs"], 4)
+    a, b, o = trio(tree, gd["seqs"], 4, None, classes)
     for i in (0, 100, 250, tree.root_count() - 1):
         rl = tree.root_location(i).with_ratio(0.31)
         sched = a.schedule(*tree.generate_operations(rl))
@@ -125,7 +143,8 @@ def test_repeats_on_the_deep_scaling_caterpillar():
         p.destroy()
 
 
-def test_tiny_table_entries_fall_back_to_the_plain_programs():
+@pytest.mark.parametrize("classes", CLASSES)
+def test_tiny_table_entries_fall_back_to_the_plain_programs(classes):
     """A pseudo-tip has no rescale count, so the launch must not use them when a clade's class
     could have been rescaled or a table entry is small enough for a tip-tip product to need
     it: with a rate category of 1e-42 the off-diagonal P entries are < 2^-128, the launch-wide
@@ -133,7 +152,7 @@ def test_tiny_table_entries_fall_back_to_the_plain_programs():
     a partition without repeats, hence the same bits."""
     w = synth.workload(30, 700, 4, 4, 151)
     tree = rd.Tree.from_newick(w["newick"])
-    a, b, o = trio(tree, w["seqs"], 4)
+    a, b, o = trio(tree, w["seqs"], 4, None, classes)
     rng = np.random.default_rng(151)
     rls = [tree.root_location(int(i)).with_ratio(0.4) for i in rng.choice(tree.root_count(), 4, replace=False)]
     sa = [a.schedule(*tree.generate_operations(rl)) for rl in rls]
@@ -175,8 +194,14 @@ def test_repeats_switch_and_stale_schedules():
     assert util.rel_err(a.evaluate_batch([s0], [w["subst"]], [[0.25] * 4])[0], base) < 1e-12
     assert a.evaluate_batch([s1], [w["subst"]], [[0.25] * 4])[0] == base   # the old one still runs
     with pytest.raises(rd.RdamdError):
-        a.set_site_repeats(17)
-    a.set_site_repeats(16)
+        a.set_site_repeats(65)
+    a.set_site_repeats(16)                                 # 8-bit codes, 16-row tables only
+    s16 = a.schedule(*ops)
+    assert 0 < s16.stats()["pseudo_tips"] and util.rel_err(
+        a.evaluate_batch([s16], [w["subst"]], [[0.25] * 4])[0], base) < 1e-12
+    with pytest.raises(rd.RdamdError):                     # 16-row and 64-row schedules in one launch
+        a.evaluate_batch([s16, s1], [w["subst"]] * 2, [[0.25] * 4] * 2)
+    a.set_site_repeats(64)
     # new characters at a tip: the class codes of s1 describe the old alignment
     label = next(iter(w["seqs"]))
     a.set_tip_states(tree.tip_index(label), rd.MAP_NT, w["seqs"][label][::-1])
