@@ -216,7 +216,13 @@ hipError_t launch_clv_traversal(rdamd_partition *p, const LevelOp *d_ops, unsign
 
 // kernels_clv_mfma.hip (20 states)
 hipError_t launch_pmat_to_mfma(rdamd_partition *p, const unsigned *d_matrix_indices, unsigned count);
-hipError_t launch_clv_k20_traversal(rdamd_partition *p, const LevelOp *d_ops, unsigned nops);
+// independent pieces of one operation list, run side by side (grid.y): [start, start + len) each
+constexpr unsigned kK20MaxPieces = 8;
+struct K20Pieces {
+  unsigned n = 0;
+  unsigned start[kK20MaxPieces] = {0}, len[kK20MaxPieces] = {0};
+};
+hipError_t launch_clv_k20_traversal(rdamd_partition *p, const LevelOp *d_ops, const K20Pieces &pieces);
 size_t k20_mfma_copy_doubles();               // doubles per (matrix, rate) in d_pmat_mfma
 
 // kernels_root.hip

@@ -138,7 +138,11 @@ pmat_to_mfma_kernel(const double *__restrict__ pmat, double *__restrict__ out,
 template <int MAXT, int VAR = 0>   // 64 * rate categories, rounded up to 256 or 1024
 __global__ void __launch_bounds__(MAXT)
 clv_k20_traversal_kernel(DeviceView v, const double *__restrict__ pmfma,
-                         const LevelOp *__restrict__ ops_generic, unsigned nops) {
+                         const LevelOp *__restrict__ ops_all, K20Pieces pieces) {
+  // blockIdx.y = an independent piece of the operation list (a subtree: rdamd_update_clvs cuts
+  // the list so that a shape with too few 16-site tiles for the chip still fills it)
+  const LevelOp *__restrict__ ops_generic = ops_all + pieces.start[blockIdx.y];
+  const unsigned nops = pieces.len[blockIdx.y];
   // flags[parity][rate]: bit c = "this rate's 20 entries of site c are all < 2^-256";
   // double-buffered by operation parity so one barrier per operation suffices
   __shared__ unsigned flags[2][16];
@@ -425,29 +429,29 @@ hipError_t launch_pmat_to_mfma(rdamd_partition *p, const unsigned *d_matrix_indi
 
 size_t k20_mfma_copy_doubles() { return kMfmaCopy; }
 
-hipError_t launch_clv_k20_traversal(rdamd_partition *p, const LevelOp *d_ops, unsigned nops) {
-  if (nops == 0 || p->sites == 0) return hipSuccess;
+hipError_t launch_clv_k20_traversal(rdamd_partition *p, const LevelOp *d_ops, const K20Pieces &pieces) {
+  if (pieces.n == 0 || p->sites == 0) return hipSuccess;
   DeviceView v = p->view();
-  const unsigned gx = (p->sites + 15) / 16;
+  const dim3 grid((p->sites + 15) / 16, pieces.n);
   const size_t lds = (size_t)p->rate_cats * kMfmaLdsWave;   // 12 KB per wave
 #ifdef RDAMD_ABLATION
   // timing-only variants (stores / loads / arithmetic switched off: results are garbage).
   // They exist only in the ablation build (`make ablation` -> ../lib/librdamd_ablation.so,
   // used by profiles/k20_ab.sh); the product library ignores RDAMD_K20_VAR.
   static const int var = getenv("RDAMD_K20_VAR") ? atoi(getenv("RDAMD_K20_VAR")) : 0;
-#define RDAMD_K20_CASE(V) case V: clv_k20_traversal_kernel<256, V><<<gx, 64 * p->rate_cats, lds, p->stream>>>(v, p->d_pmat_mfma, d_ops, nops); break;
+#define RDAMD_K20_CASE(V) case V: clv_k20_traversal_kernel<256, V><<<grid, 64 * p->rate_cats, lds, p->stream>>>(v, p->d_pmat_mfma, d_ops, pieces); break;
   if (p->rate_cats <= 4)
     switch (var) {
       RDAMD_K20_CASE(1) RDAMD_K20_CASE(2) RDAMD_K20_CASE(4) RDAMD_K20_CASE(5) RDAMD_K20_CASE(8)
       RDAMD_K20_CASE(13) RDAMD_K20_CASE(16) RDAMD_K20_CASE(17) RDAMD_K20_CASE(29) RDAMD_K20_CASE(31)
-      default: clv_k20_traversal_kernel<256><<<gx, 64 * p->rate_cats, lds, p->stream>>>(v, p->d_pmat_mfma, d_ops, nops);
+      default: clv_k20_traversal_kernel<256><<<grid, 64 * p->rate_cats, lds, p->stream>>>(v, p->d_pmat_mfma, d_ops, pieces);
     }
 #else
   if (p->rate_cats <= 4)
-    clv_k20_traversal_kernel<256><<<gx, 64 * p->rate_cats, lds, p->stream>>>(v, p->d_pmat_mfma, d_ops, nops);
+    clv_k20_traversal_kernel<256><<<grid, 64 * p->rate_cats, lds, p->stream>>>(v, p->d_pmat_mfma, d_ops, pieces);
 #endif
   else
-    clv_k20_traversal_kernel<1024><<<gx, 64 * p->rate_cats, lds, p->stream>>>(v, p->d_pmat_mfma, d_ops, nops);
+    clv_k20_traversal_kernel<1024><<<grid, 64 * p->rate_cats, lds, p->stream>>>(v, p->d_pmat_mfma, d_ops, pieces);
   return hipGetLastError();
 }
 
