@@ -164,6 +164,22 @@ int rdamd_root_loglikelihood_fused(rdamd_partition_t       *p,
                                    const double            *lengths2,
                                    unsigned int             n_alpha,
                                    double                  *lnl_out);
+/* The same for SEVERAL partitions of one device in ONE launch: item i = partition parts[i],
+ * its root operation ops[i], n_positions[i] <= 4 root positions with branch lengths
+ * lengths1[4 i + a] / lengths2[4 i + a]; lnl_out[4 i + a].  A lock-stepped search
+ * (rdamd_model_exhaustive_search_lockstep) serves the Brent / finite-difference steps
+ * (src/model.cpp:606-794) of all candidates in flight -- each on its own model replica --
+ * with it.  Every partition is left as rdamd_root_loglikelihood_fused leaves it and every
+ * value has that call's bits; the partitions must be idle (no call of another thread in
+ * progress on them). */
+int rdamd_root_loglikelihood_fused_multi(unsigned int              n_items,
+                                         rdamd_partition_t *const *parts,
+                                         const rdamd_operation_t  *ops,
+                                         const unsigned int *const *params_indices,
+                                         const double             *lengths1,
+                                         const double             *lengths2,
+                                         const unsigned int       *n_positions,
+                                         double                   *lnl_out);
 
 /* corax_compute_root_loglikelihood for MANY root CLVs of the partition in one
  * launch; every value is bit-identical to a separate call on that CLV.  Used by
@@ -440,6 +456,10 @@ int rdamd_model_optimize_params(rdamd_model_t *m, const rdamd_root_location_t *r
  * compute_lh, [3] root-only positions (compute_lh_root / compute_dlh),
  * [4] move_root calls, [5] setulb calls.  Diagnostic. */
 void rdamd_model_counters(const rdamd_model_t *m, uint64_t out[6]);
+/* the last rdamd_model_exhaustive_search_lockstep: out[0] combined objective launches,
+ * [1] the jobs they carried, [2] combined root-only launches
+ * (rdamd_root_loglikelihood_fused_multi), [3] the candidates' root-only steps they carried */
+void rdamd_model_lockstep_stats(const rdamd_model_t *m, uint64_t out[4]);
 /* assign_indicies_by_rank_exhaustive, :1867-1911 */
 int rdamd_model_assign_by_rank(rdamd_model_t *m, unsigned int rank, unsigned int num_tasks);
 /* exhaustive_search, :1139-1272, over the assigned roots.  root_id / llh /

@@ -226,6 +226,7 @@ _sig("rdamd_compute_root_loglikelihoods", C.c_int, _vp, _u, _pu, C.POINTER(C.c_i
 _sig("rdamd_tree_generate_directional_operations", C.c_int, _vp, _pd, _pop, _pu, _pu, _pd, _pu, _pu,
      C.POINTER(C.c_int), _pu)
 _sig("rdamd_model_counters", None, C.c_void_p, C.POINTER(C.c_uint64))
+_sig("rdamd_model_lockstep_stats", None, C.c_void_p, C.POINTER(C.c_uint64))
 _sig("rdamd_model_assign_by_rank", C.c_int, _vp, _u, _u)
 _sig("rdamd_model_exhaustive_search_parallel", C.c_int, _vp, _u, C.c_double, C.c_double,
      C.c_double, C.c_double, C.POINTER(C.c_uint64), _pd, _pd, _pu, _prl, _pd)
@@ -1208,6 +1209,13 @@ class Model:
         names = ("objective_batches", "objective_evaluations", "full_traversals",
                  "root_positions", "move_root_calls", "setulb_calls")
         return dict(zip(names, (int(v) for v in out)))
+
+    def lockstep_stats(self):
+        """combined launches of the last lock-stepped search (rdamd_model_lockstep_stats)."""
+        out = (C.c_uint64 * 4)()
+        lib.rdamd_model_lockstep_stats(self._h, out)
+        return dict(zip(("objective_launches", "objective_jobs", "root_launches", "root_steps"),
+                        (int(v) for v in out)))
 
     def assign_by_rank(self, rank, num_tasks, checkpoint=None):
         """assign_indicies_by_rank_exhaustive; with a Checkpoint, the roots it

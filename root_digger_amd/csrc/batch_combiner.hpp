@@ -10,6 +10,7 @@
 // with a single copy of the tip data for the objective.
 #pragma once
 
+#include <algorithm>
 #include <condition_variable>
 #include <mutex>
 #include <stdexcept>
@@ -148,6 +149,110 @@ private:
   int _active = 0;
   bool _launching = false;
   size_t _launches = 0, _jobs = 0;
+};
+
+// The same meeting point for the ROOT-ONLY steps (compute_lh_root / compute_dlh: Brent's
+// method on the root position, src/model.cpp:606-794, and optimize_alpha's scans).  Every
+// candidate in flight sits on its own model replica -- its own child CLVs, parameters and
+// stream --, so a combined step is one launch over several partitions
+// (rdamd_root_loglikelihood_fused_multi) instead of one per candidate: a c2 search issues
+// ~14 000 of them for 13 candidates.  A candidate enters when it starts to place the root on
+// its branch and leaves when it is done; when everyone inside has asked, the last one launches.
+class root_combiner_t {
+public:
+  void enter() {
+    std::lock_guard<std::mutex> g(_mu);
+    ++_active;
+  }
+  void leave() {
+    {
+      std::lock_guard<std::mutex> g(_mu);
+      --_active;
+    }
+    _cv.notify_all();
+  }
+  struct scope_t {
+    root_combiner_t *c;
+    explicit scope_t(root_combiner_t *c_) : c(c_) { if (c) c->enter(); }
+    ~scope_t() { if (c) c->leave(); }
+    scope_t(const scope_t &) = delete;
+    scope_t &operator=(const scope_t &) = delete;
+  };
+
+  // n <= 4 root positions of `op` on `part`: branch lengths l1 / l2, values to out
+  void evaluate(rdamd_partition_t *part, const rdamd_operation_t &op, const unsigned *params_idx,
+                const double *l1, const double *l2, unsigned n, double *out) {
+    request_t req{part, op, params_idx, {0, 0, 0, 0}, {0, 0, 0, 0}, n, out};
+    for (unsigned a = 0; a < n; ++a) { req.l1[a] = l1[a]; req.l2[a] = l2[a]; }
+    std::unique_lock<std::mutex> lk(_mu);
+    _pending.push_back(&req);
+    for (;;) {
+      if (req.done) break;
+      if (!_launching && !_pending.empty() && _pending.size() >= (size_t)std::max(_active, 1)) {
+        std::vector<request_t *> batch;
+        batch.swap(_pending);
+        _launching = true;
+        lk.unlock();
+        std::string err;
+        try {
+          err = launch(batch);
+        } catch (const std::exception &e) {
+          err = std::string("combined root step failed: ") + e.what();
+        }
+        lk.lock();
+        _launching = false;
+        for (request_t *r : batch) {
+          r->error = err;
+          r->done = true;
+        }
+        ++_launches;
+        _steps += batch.size();
+        _cv.notify_all();
+        continue;
+      }
+      _cv.wait(lk);
+    }
+    if (!req.error.empty()) throw std::runtime_error(req.error);
+  }
+  size_t launches() const { return _launches; }
+  size_t steps() const { return _steps; }
+
+private:
+  struct request_t {
+    rdamd_partition_t *part;
+    rdamd_operation_t op;
+    const unsigned *params_idx;
+    double l1[4], l2[4];
+    unsigned n;
+    double *out;
+    bool done = false;
+    std::string error;
+  };
+  static std::string launch(const std::vector<request_t *> &batch) {
+    const size_t m = batch.size();
+    std::vector<rdamd_partition_t *> parts(m);
+    std::vector<rdamd_operation_t> ops(m);
+    std::vector<const unsigned *> pidx(m);
+    std::vector<double> l1(4 * m), l2(4 * m), out(4 * m);
+    std::vector<unsigned> npos(m);
+    for (size_t i = 0; i < m; ++i) {
+      parts[i] = batch[i]->part; ops[i] = batch[i]->op; pidx[i] = batch[i]->params_idx;
+      npos[i] = batch[i]->n;
+      for (unsigned a = 0; a < 4; ++a) { l1[4 * i + a] = batch[i]->l1[a]; l2[4 * i + a] = batch[i]->l2[a]; }
+    }
+    if (rdamd_root_loglikelihood_fused_multi((unsigned)m, parts.data(), ops.data(), pidx.data(), l1.data(),
+                                             l2.data(), npos.data(), out.data()) != RDAMD_SUCCESS)
+      return std::string("combined root step failed: ") + rdamd_errmsg();
+    for (size_t i = 0; i < m; ++i)
+      for (unsigned a = 0; a < batch[i]->n; ++a) batch[i]->out[a] = out[4 * i + a];
+    return std::string();
+  }
+  std::mutex _mu;
+  std::condition_variable _cv;
+  std::vector<request_t *> _pending;
+  int _active = 0;
+  bool _launching = false;
+  size_t _launches = 0, _steps = 0;
 };
 
 }  // namespace rdamd

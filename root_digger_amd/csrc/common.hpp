@@ -138,6 +138,8 @@ struct rdamd_partition {
   size_t    stage_bytes = 0, stage_off = 0;
 
   rdamd::FusedWorkspace *fused = nullptr;   // evaluate.hip
+  void *d_root_items = nullptr, *h_root_items = nullptr;   // rdamd_root_loglikelihood_fused_multi (the leading partition's)
+  unsigned root_items_cap = 0;
 
   // ---- measurement (rdamd_profile_*) -----------------------------------------
   struct ProfSpan { hipEvent_t a, b; int kind; };
@@ -233,6 +235,27 @@ hipError_t launch_root_lnl(rdamd_partition *p, unsigned clv_index, int scaler_in
 hipError_t launch_root_single(rdamd_partition *p, const LevelOp &op, const double *len1,
                               const double *len2, unsigned n_positions,
                               const unsigned *params_indices, unsigned *d_counter, double *result);
+struct RootSingleArgs {
+  double len1[4], len2[4];      // child1 / child2 branch length per position
+  unsigned params_idx[8];       // rate -> rate matrix (also the frequency set)
+  unsigned n_positions;
+};
+// one row of root_multi_dna_kernel: everything root_single_dna_kernel takes as arguments
+struct RootItem {
+  DeviceView v;
+  LevelOp op;
+  RootSingleArgs ra;
+  const double *q, *rates, *freqs, *rate_w;
+  const unsigned *pw;
+  const uint64_t *codemask;
+  double *partials;
+  unsigned *counter;
+  double *result;      // [4]
+  unsigned blocks, pad;
+};
+unsigned root_single_blocks(const rdamd_partition *p);
+hipError_t launch_root_multi(const RootItem *d_items, unsigned n_items, unsigned R, unsigned max_positions,
+                             unsigned max_blocks, hipStream_t stream);
 // many root CLVs of one partition in one launch (bit-identical to launch_root_lnl each)
 unsigned root_lnl_blocks(const rdamd_partition *p);
 hipError_t launch_root_lnl_batch(rdamd_partition *p, unsigned count, const unsigned *d_clv_rel,

@@ -642,6 +642,7 @@ static int evaluate_batch_impl(rdamd_partition_t *p, unsigned int n_jobs,
   a.jobs = w->d_jobs; a.tipcodes = wide_codes ? p->d_codes_wide : p->d_tipcodes16;
   a.pattern_weights = p->d_pattern_weights;
   a.table_rows = table_rows;
+
   a.tiptab_job_stride = tiptab_job;
   a.pmat = w->d_pmat; a.tiptab = w->d_tiptab + kTiptabPad; a.freqs = w->d_freqs; a.rate_weights = w->d_rw;
   a.partials = w->d_partials; a.persite = nullptr;
@@ -663,6 +664,10 @@ static int evaluate_batch_impl(rdamd_partition_t *p, unsigned int n_jobs,
 #ifdef RDAMD_ABLATION   // A/B runs only (`make ablation`): RDAMD_FUSED_NS=1|2 overrides
   static const int force_ns = getenv("RDAMD_FUSED_NS") ? atoi(getenv("RDAMD_FUSED_NS")) : 0;
   if (force_ns) ns = (unsigned)force_ns;
+#endif
+#ifdef RDAMD_ABLATION   // timing only (results are garbage): what would fewer LDS stack levels / registers buy?
+  if (getenv("RDAMD_FUSED_DEPTH")) max_depth[0] = (unsigned)atoi(getenv("RDAMD_FUSED_DEPTH"));
+  if (getenv("RDAMD_FUSED_RL")) reg_levels[0] = (unsigned)atoi(getenv("RDAMD_FUSED_RL"));
 #endif
   e = launch_fused_eval(a, n_jobs, max_depth, w->blocks_x, ns, reg_levels, d_out, p->stream);
   p->prof_end();

@@ -216,19 +216,16 @@ finish_sum_kernel(const double *__restrict__ partials, unsigned n, double *__res
 // launch-latency, not bandwidth: one launch + one stream wait instead of three
 // copies, three launches and a copy back.
 // ---------------------------------------------------------------------------
-struct RootSingleArgs {
-  double len1[4], len2[4];      // child1 / child2 branch length per position
-  unsigned params_idx[8];       // rate -> rate matrix (also the frequency set)
-  unsigned n_positions;
-};
-
+// (the body: `bid` of `nblocks` workgroups work on one root operation -- the whole grid of
+// root_single_dna_kernel, one row of root_multi_dna_kernel's)
 template <int R, int NA>
-__global__ void __launch_bounds__(256)
-root_single_dna_kernel(DeviceView v, LevelOp op, RootSingleArgs ra, const double *__restrict__ q,
-                       const double *__restrict__ rates, const double *__restrict__ freqs,
-                       const double *__restrict__ rate_w, const unsigned *__restrict__ pw,
-                       const uint64_t *__restrict__ codemask, double *__restrict__ partials,
-                       unsigned *__restrict__ counter, double *__restrict__ result) {
+__device__ __forceinline__ void
+root_single_body(const DeviceView &v, const LevelOp &op, const RootSingleArgs &ra, const double *__restrict__ q,
+                 const double *__restrict__ rates, const double *__restrict__ freqs,
+                 const double *__restrict__ rate_w, const unsigned *__restrict__ pw,
+                 const uint64_t *__restrict__ codemask, double *__restrict__ partials,
+                 unsigned *__restrict__ counter, double *__restrict__ result, const unsigned bid,
+                 const unsigned nblocks) {
   __shared__ double spm[NA][2][R][16];     // P-matrices
   __shared__ double smat[NA][2][R * 64];   // what the site loop reads: P (inner child) or tip table
   __shared__ double lds[4];
@@ -259,7 +256,7 @@ root_single_dna_kernel(DeviceView v, LevelOp op, RootSingleArgs ra, const double
   }
   // the state contract: the LAST position's matrices (and their tip tables) are
   // what rdamd_update_prob_matrices would have left in the partition
-  if (blockIdx.x == 0) {
+  if (bid == 0) {
     for (unsigned e = tid; e < 2 * R * 16; e += 256) {
       const unsigned c = e / (R * 16), w = e % (R * 16);
       const unsigned m = c ? op.child2_mat : op.child1_mat;
@@ -278,7 +275,7 @@ root_single_dna_kernel(DeviceView v, LevelOp op, RootSingleArgs ra, const double
   }
   __syncthreads();
 
-  const size_t total = (size_t)S * R, stride = (size_t)gridDim.x * 256;
+  const size_t total = (size_t)S * R, stride = (size_t)nblocks * 256;
   const double2 *c1 = tip1 ? nullptr
       : reinterpret_cast<const double2 *>(v.clv + (size_t)(op.child1_clv - v.tips) * v.clv_stride);
   const double2 *c2 = tip2 ? nullptr
@@ -293,7 +290,7 @@ root_single_dna_kernel(DeviceView v, LevelOp op, RootSingleArgs ra, const double
   double acc[NA];
 #pragma unroll
   for (int a = 0; a < NA; ++a) acc[a] = 0.0;
-  for (size_t idx = (size_t)blockIdx.x * 256 + tid; idx < total; idx += stride) {
+  for (size_t idx = (size_t)bid * 256 + tid; idx < total; idx += stride) {
     const unsigned s = (unsigned)(idx / R), r = (unsigned)(idx % R);
     double x[4] = {0, 0, 0, 0}, y[4] = {0, 0, 0, 0};
     unsigned cx = 0, cy = 0;
@@ -360,24 +357,49 @@ root_single_dna_kernel(DeviceView v, LevelOp op, RootSingleArgs ra, const double
 #pragma unroll
   for (int a = 0; a < NA; ++a) {
     const double b = block_sum_256(acc[a], lds);
-    if (threadIdx.x == 0) partials[(size_t)a * gridDim.x + blockIdx.x] = b;
+    if (threadIdx.x == 0) partials[(size_t)a * nblocks + bid] = b;
     __syncthreads();
   }
   // the block that arrives last folds the partials (finish_sum_kernel's order)
   __threadfence();
   if (tid == 0) ticket = atomicAdd(counter, 1u);
   __syncthreads();
-  if (ticket != gridDim.x - 1) return;
+  if (ticket != nblocks - 1) return;
   __threadfence();
   for (int a = 0; a < NA; ++a) {
-    const volatile double *p = partials + (size_t)a * gridDim.x;
+    const volatile double *p = partials + (size_t)a * nblocks;
     double sum = 0.0;
-    for (unsigned i = tid; i < gridDim.x; i += 256) sum += p[i];
+    for (unsigned i = tid; i < nblocks; i += 256) sum += p[i];
     const double b = block_sum_256(sum, lds);
     if (tid == 0) result[a] = b;
     __syncthreads();
   }
   if (tid == 0) *counter = 0u;   // ready for the next launch on this stream
+}
+
+template <int R, int NA>
+__global__ void __launch_bounds__(256)
+root_single_dna_kernel(DeviceView v, LevelOp op, RootSingleArgs ra, const double *__restrict__ q,
+                       const double *__restrict__ rates, const double *__restrict__ freqs,
+                       const double *__restrict__ rate_w, const unsigned *__restrict__ pw,
+                       const uint64_t *__restrict__ codemask, double *__restrict__ partials,
+                       unsigned *__restrict__ counter, double *__restrict__ result) {
+  root_single_body<R, NA>(v, op, ra, q, rates, freqs, rate_w, pw, codemask, partials, counter, result,
+                          blockIdx.x, gridDim.x);
+}
+
+// The same for SEVERAL partitions at once (grid.y): the root-only steps of the candidates that
+// a lock-stepped search has in flight -- every one on its own model replica, hence its own
+// CLVs, parameters and scratch -- as one launch instead of one launch per candidate and step
+// (rdamd_root_loglikelihood_fused_multi).  Every row keeps the grid shape it would have had
+// alone, so each value has the bits of the single launch.
+template <int R, int NA>
+__global__ void __launch_bounds__(256)
+root_multi_dna_kernel(const RootItem *__restrict__ items) {
+  const RootItem &it = items[blockIdx.y];
+  if (blockIdx.x >= it.blocks) return;
+  root_single_body<R, NA>(it.v, it.op, it.ra, it.q, it.rates, it.freqs, it.rate_w, it.pw, it.codemask,
+                          it.partials, it.counter, it.result, blockIdx.x, it.blocks);
 }
 
 hipError_t launch_root_lnl(rdamd_partition *p, unsigned clv_index, int scaler_index,
@@ -493,6 +515,32 @@ hipError_t launch_root_single(rdamd_partition *p, const LevelOp &op, const doubl
     case 8: return launch_root_single_r<8>(p, v, op, ra, blocks, d_counter, result);
     default: return hipErrorInvalidValue;
   }
+}
+
+unsigned root_single_blocks(const rdamd_partition *p) {
+  size_t total = (size_t)p->sites * p->rate_cats;
+  unsigned blocks = (unsigned)((total + 255) / 256);
+  if (blocks > kRootBlocks) blocks = kRootBlocks;   // same shape as launch_root_lnl
+  return blocks ? blocks : 1u;
+}
+
+hipError_t launch_root_multi(const RootItem *d_items, unsigned n_items, unsigned R, unsigned max_positions,
+                             unsigned max_blocks, hipStream_t stream) {
+  if (!n_items) return hipSuccess;
+  const dim3 grid(max_blocks, n_items);
+#define RDAMD_RM(RR, NA) root_multi_dna_kernel<RR, NA><<<grid, 256, 0, stream>>>(d_items)
+#define RDAMD_RM_R(RR)                                                                        \
+  if (max_positions <= 1) RDAMD_RM(RR, 1); else if (max_positions == 2) RDAMD_RM(RR, 2); else RDAMD_RM(RR, 4)
+  switch (R) {
+    case 1: RDAMD_RM_R(1); break;
+    case 2: RDAMD_RM_R(2); break;
+    case 4: RDAMD_RM_R(4); break;
+    case 8: RDAMD_RM_R(8); break;
+    default: return hipErrorInvalidValue;
+  }
+#undef RDAMD_RM_R
+#undef RDAMD_RM
+  return hipGetLastError();
 }
 
 }  // namespace rdamd

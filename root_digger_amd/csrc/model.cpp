@@ -304,6 +304,9 @@ double model_t::compute_lh_root(const root_location_t &root) {
   const auto &brl = std::get<2>(res);
   ++_n_root_positions;
   double lh = 0.0;
+  if (_root_combiner && _partitions.size() == 1 && !_reduce) {   // meets the other candidates' steps
+    _root_combiner->evaluate(_partitions[0], op, _param_indicies[0].data(), &brl[0], &brl[1], 1, &lh);
+  } else
   for (size_t i = 0; i < _partitions.size(); ++i) {
     double v = 0.0;
     if (rdamd_root_loglikelihood_fused(_partitions[i], &op, _param_indicies[i].data(), &brl[0],
@@ -335,6 +338,12 @@ dlh_t model_t::compute_dlh(const root_location_t &root) {
   const double l2[2] = {root_prime.brlen_compliment(), root.brlen_compliment()};
   _n_root_positions += 2;
   double fx = 0.0, fxh = 0.0;
+  if (_root_combiner && _partitions.size() == 1 && !_reduce) {
+    double v[2];
+    _root_combiner->evaluate(_partitions[0], op, _param_indicies[0].data(), l1, l2, 2, v);
+    fxh = v[0];
+    fx = v[1];
+  } else
   for (size_t i = 0; i < _partitions.size(); ++i) {
     double v[2];
     if (rdamd_root_loglikelihood_fused(_partitions[i], &op, _param_indicies[i].data(), l1, l2, 2,
@@ -993,8 +1002,13 @@ std::pair<root_location_t, double> model_t::exhaustive_search(double atol, doubl
       if (_optimizer) _optimizer(*this, params, rl, pgtol, factor, iter % 10 == 0);
       else if (_setulb) optimize_params(params, rl, pgtol, factor, iter % 10 == 0);
       if (std::fabs(compute_lh(rl) - cur_best_llh) < atol) break;
-      root_location_t cur_rl = optimize_alpha(rl, brtol);
-      double cur_llh = compute_lh_root(cur_rl);
+      root_location_t cur_rl;
+      double cur_llh;
+      {   // (lock step: this candidate's root-only steps may now meet the others')
+        root_combiner_t::scope_t placing(_root_combiner);
+        cur_rl = optimize_alpha(rl, brtol);
+        cur_llh = compute_lh_root(cur_rl);
+      }
       if (_early_stop && std::fabs(rl.brlen_ratio - cur_rl.brlen_ratio) < brtol) {
         cur_best_rl = cur_rl;
         cur_best_llh = cur_llh;

@@ -29,6 +29,7 @@ namespace rdamd {
 
 class checkpoint_t;
 class batch_combiner_t;
+class root_combiner_t;
 
 typedef std::vector<double> model_params_t;
 
@@ -155,6 +156,8 @@ public:
   // the optimiser's objective batches go through this combiner (batch_combiner.hpp)
   // instead of being launched on this model's own partition; not owned
   void set_combiner(batch_combiner_t *c) { _combiner = c; }
+  // ... and the root-only steps (compute_lh_root / compute_dlh) through this one
+  void set_root_combiner(root_combiner_t *c) { _root_combiner = c; }
   // Site-sharded runs: this model holds one block of the alignment's
   // columns; every lnL it computes is summed over the ranks of its site group
   // through `fn` before any optimiser sees it (include/root_digger_amd.h,
@@ -256,6 +259,7 @@ private:
   progress_t                            *_progress = nullptr;
   checkpoint_t                          *_checkpoint = nullptr;
   batch_combiner_t                      *_combiner = nullptr;
+  root_combiner_t                       *_root_combiner = nullptr;
   bool                                   _invariant_sites, _early_stop;   // +I is inert (:292-300)
   uint64_t                               _seed;
   param_optimizer_t                      _optimizer;

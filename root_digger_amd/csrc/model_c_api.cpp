@@ -37,6 +37,7 @@ struct rdamd_model {
   void    *setulb = nullptr;
   rdamd::checkpoint_t *checkpoint = nullptr;
   std::unique_ptr<rdamd::model_t::progress_t> progress;   // set by rdamd_model_set_progress
+  uint64_t lockstep_stats[4] = {0, 0, 0, 0};   // of the last lock-stepped search (rdamd_model_lockstep_stats)
   ~rdamd_model() { delete model; }
 };
 
@@ -429,7 +430,11 @@ static int search_with_replicas(rdamd_model_t *m, unsigned int workers, bool loc
                                "(rdamd_model_exhaustive_search): replicas would reorder the "
                                "site group's collectives");
     std::unique_ptr<rdamd::batch_combiner_t> combiner;
-    if (lockstep) combiner.reset(new rdamd::batch_combiner_t(m->model->partition(0)));
+    std::unique_ptr<rdamd::root_combiner_t> root_combiner;
+    if (lockstep) {
+      combiner.reset(new rdamd::batch_combiner_t(m->model->partition(0)));
+      root_combiner.reset(new rdamd::root_combiner_t());
+    }
     const std::vector<size_t> todo = m->model->assigned_indicies();
     if (workers < 1) workers = 1;
     workers = (unsigned)std::min<size_t>(workers, std::max<size_t>(todo.size(), 1));
@@ -460,6 +465,7 @@ static int search_with_replicas(rdamd_model_t *m, unsigned int workers, bool loc
         replica.set_progress(m->progress.get());
         replica.set_combiner(combiner.get());
         replica.initialize();
+        replica.set_root_combiner(root_combiner.get());   // (after initialize(): that evaluates on its own)
         for (;;) {
           const size_t k = next.fetch_add(1);
           if (k >= todo.size()) break;
@@ -478,6 +484,10 @@ static int search_with_replicas(rdamd_model_t *m, unsigned int workers, bool loc
     std::vector<std::thread> pool;
     for (unsigned w = 0; w < workers; ++w) pool.emplace_back(work, w);
     for (auto &t : pool) t.join();
+    if (combiner) {
+      m->lockstep_stats[0] = combiner->launches(); m->lockstep_stats[1] = combiner->jobs();
+      m->lockstep_stats[2] = root_combiner->launches(); m->lockstep_stats[3] = root_combiner->steps();
+    }
     if (!first_error.empty()) throw std::runtime_error(first_error);
     std::sort(results.begin(), results.end(),
               [](const rdamd::rd_result_t &a, const rdamd::rd_result_t &b) { return a.root_id < b.root_id; });
@@ -533,6 +543,9 @@ int rdamd_model_optimize_params(rdamd_model_t *m, const rdamd_root_location_t *r
     if (n_evaluations) *n_evaluations = m->model->objective_evaluations() - e0;
     return RDAMD_SUCCESS;
   })
+}
+void rdamd_model_lockstep_stats(const rdamd_model_t *m, uint64_t out[4]) {
+  for (int i = 0; i < 4; ++i) out[i] = m->lockstep_stats[i];
 }
 void rdamd_model_counters(const rdamd_model_t *m, uint64_t out[6]) {
   const auto c = m->model->counters();

@@ -296,6 +296,8 @@ void rdamd_partition_destroy(rdamd_partition_t *p) {
   for (auto &e : p->prof_pool) (void)hipEventDestroy(e);
   if (p->h_stage) (void)hipHostFree(p->h_stage);
   if (p->h_result) (void)hipHostFree(p->h_result);
+  if (p->d_root_items) (void)hipFree(p->d_root_items);
+  if (p->h_root_items) (void)hipHostFree(p->h_root_items);
   if (p->stream) (void)hipStreamDestroy(p->stream);
   delete p;
 }
@@ -971,6 +973,114 @@ int rdamd_root_loglikelihood_fused(rdamd_partition_t *p, const rdamd_operation_t
     RDAMD_HIP_TRY(hipStreamSynchronize(p->stream), RDAMD_FAILURE);
     for (unsigned a = 0; a < n; ++a) lnl_out[base + a] = p->h_result[a];
   }
+  return RDAMD_SUCCESS;
+}
+
+// Root-only evaluations of SEVERAL partitions in one launch (root_multi_dna_kernel): the
+// Brent / finite-difference steps of the candidates a lock-stepped search has in flight, each
+// on its own replica.  Item i: partition parts[i], its root operation ops[i], n_positions[i]
+// <= 4 root positions with branch lengths len1[4 i + a], len2[4 i + a]; out[4 i + a] = lnL.
+// Every partition is left exactly as rdamd_root_loglikelihood_fused leaves it, and every value
+// has that call's bits.  Shapes the one-launch kernel does not take fall back to it item by item.
+int rdamd_root_loglikelihood_fused_multi(unsigned int n_items, rdamd_partition_t *const *parts,
+                                         const rdamd_operation_t *ops,
+                                         const unsigned int *const *params_indices,
+                                         const double *len1, const double *len2,
+                                         const unsigned int *n_positions, double *out) {
+  clear_error();
+  if (n_items == 0) return RDAMD_SUCCESS;
+  bool fast = true;
+  unsigned max_pos = 0, max_blocks = 0;
+  for (unsigned i = 0; i < n_items; ++i) {
+    const rdamd_partition *p = parts[i];
+    fast = fast && p->states == 4 && p->ncodes_cap == 16 && p->rate_cats == parts[0]->rate_cats &&
+           (p->rate_cats == 1 || p->rate_cats == 2 || p->rate_cats == 4 || p->rate_cats == 8) &&
+           ops[i].parent_scaler_index >= 0 && p->sites > 0 && p->device == parts[0]->device &&
+           n_positions[i] >= 1 && n_positions[i] <= 4;
+  }
+  if (!fast || n_items == 1) {
+    for (unsigned i = 0; i < n_items; ++i)
+      if (rdamd_root_loglikelihood_fused(parts[i], &ops[i], params_indices[i], len1 + 4 * i, len2 + 4 * i,
+                                         n_positions[i], out + 4 * i) != RDAMD_SUCCESS)
+        return RDAMD_FAILURE;
+    return RDAMD_SUCCESS;
+  }
+  rdamd_partition *lead = parts[0];
+  const unsigned R = lead->rate_cats;
+  if (lead->root_items_cap < n_items) {
+    if (lead->d_root_items) (void)hipFree(lead->d_root_items);
+    if (lead->h_root_items) (void)hipHostFree(lead->h_root_items);
+    lead->d_root_items = lead->h_root_items = nullptr;
+    lead->root_items_cap = std::max(64u, n_items * 2);
+    const size_t bytes = (size_t)lead->root_items_cap * (sizeof(RootItem) + 4 * sizeof(double));
+    RDAMD_HIP_TRY(hipMalloc(&lead->d_root_items, bytes), RDAMD_FAILURE);
+    RDAMD_HIP_TRY(hipHostMalloc(&lead->h_root_items, bytes, hipHostMallocDefault), RDAMD_FAILURE);
+  }
+  RootItem *h_items = (RootItem *)lead->h_root_items, *d_items = (RootItem *)lead->d_root_items;
+  double *h_res = (double *)(h_items + lead->root_items_cap), *d_res = (double *)(d_items + lead->root_items_cap);
+  for (unsigned i = 0; i < n_items; ++i) {
+    rdamd_partition *p = parts[i];
+    const rdamd_operation_t &o = ops[i];
+    const unsigned nclv = p->tips + p->clv_buffers;
+    if (o.parent_clv_index < p->tips || o.parent_clv_index >= nclv || o.child1_clv_index >= nclv ||
+        o.child2_clv_index >= nclv || o.child1_matrix_index >= p->prob_matrices ||
+        o.child2_matrix_index >= p->prob_matrices || o.parent_scaler_index >= (int)p->scale_buffers ||
+        o.child1_scaler_index >= (int)p->scale_buffers || o.child2_scaler_index >= (int)p->scale_buffers) {
+      set_error(10, "rdamd_root_loglikelihood_fused_multi: item %u: index out of range", i);
+      return RDAMD_FAILURE;
+    }
+    RootItem &it = h_items[i];
+    memset(&it, 0, sizeof it);
+    for (unsigned a = 0; a < 4; ++a) {   // (unused positions repeat the last one: same state left behind)
+      const unsigned src = std::min(a, n_positions[i] - 1);
+      it.ra.len1[a] = len1[4 * i + src];
+      it.ra.len2[a] = len2[4 * i + src];
+      if (!(it.ra.len1[a] >= 0.0) || !(it.ra.len2[a] >= 0.0) || !std::isfinite(it.ra.len1[a]) ||
+          !std::isfinite(it.ra.len2[a])) {
+        set_error(9, "rdamd_root_loglikelihood_fused_multi: item %u: invalid branch length", i);
+        return RDAMD_FAILURE;
+      }
+    }
+    for (unsigned r = 0; r < 8; ++r) {
+      it.ra.params_idx[r] = r < R ? params_indices[i][r] : 0u;
+      if (it.ra.params_idx[r] >= p->rate_matrices) {
+        set_error(7, "rdamd_root_loglikelihood_fused_multi: item %u: params index out of range", i);
+        return RDAMD_FAILURE;
+      }
+    }
+    RDAMD_HIP_TRY(flush_q(p), RDAMD_FAILURE);
+    if (p->tiptab_stale) {
+      RDAMD_HIP_TRY(launch_tiptab_all(p), RDAMD_FAILURE);
+      p->tiptab_stale = false;
+    }
+    // whatever this partition's own stream still has queued (parameter uploads just now) must
+    // be done before the leader's stream reads it
+    if (p != lead) RDAMD_HIP_TRY(hipStreamSynchronize(p->stream), RDAMD_FAILURE);
+    it.v = p->view();
+    it.op.parent_clv = o.parent_clv_index; it.op.child1_clv = o.child1_clv_index;
+    it.op.child2_clv = o.child2_clv_index; it.op.child1_mat = o.child1_matrix_index;
+    it.op.child2_mat = o.child2_matrix_index; it.op.parent_sc = o.parent_scaler_index;
+    it.op.child1_sc = o.child1_scaler_index; it.op.child2_sc = o.child2_scaler_index;
+    it.q = p->d_q; it.rates = p->d_rates; it.freqs = p->d_freqs; it.rate_w = p->d_rate_weights;
+    it.pw = p->d_pattern_weights; it.codemask = p->d_codemask;
+    it.partials = p->d_partials; it.counter = p->d_counter;
+    it.result = d_res + 4 * i;
+    it.blocks = root_single_blocks(p);
+    it.ra.n_positions = n_positions[i];
+    max_pos = std::max(max_pos, n_positions[i]);
+    max_blocks = std::max(max_blocks, it.blocks);
+  }
+  RDAMD_HIP_TRY(hipMemcpyAsync(d_items, h_items, sizeof(RootItem) * n_items, hipMemcpyHostToDevice, lead->stream),
+                RDAMD_FAILURE);
+  lead->prof_begin(2);
+  hipError_t e = launch_root_multi(d_items, n_items, R, max_pos, max_blocks, lead->stream);
+  lead->prof_end();
+  RDAMD_HIP_TRY(e, RDAMD_FAILURE);
+  RDAMD_HIP_TRY(hipMemcpyAsync(h_res, d_res, sizeof(double) * 4 * n_items, hipMemcpyDeviceToHost, lead->stream),
+                RDAMD_FAILURE);
+  RDAMD_HIP_TRY(hipStreamSynchronize(lead->stream), RDAMD_FAILURE);
+  for (unsigned i = 0; i < n_items; ++i)
+    for (unsigned a = 0; a < n_positions[i]; ++a) out[4 * i + a] = h_res[4 * i + a];
   return RDAMD_SUCCESS;
 }
 

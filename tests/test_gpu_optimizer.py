@@ -171,6 +171,15 @@ def test_parallel_exhaustive_search_equals_sequential(lbfgsb):
         assert np.array_equal(lock["llh"], seq["llh"][order])
         assert np.array_equal(lock["alpha"], seq["alpha"][order])
     assert m.counters()["objective_batches"] == before    # the replicas did the asking
+    # ... and so do their root-only steps (Brent on the root position, compute_dlh's two
+    # positions, optimize_alpha's scans): one launch over the replicas' partitions
+    # (rdamd_root_loglikelihood_fused_multi) serves every candidate that is placing its root.
+    # Same bits (asserted above).  How many steps share a launch depends on how many
+    # candidates are placing their root at the same moment -- a short phase between long
+    # parameter optimisations: ~3 of 17 here, 1.3 of 16 on c2.
+    st = m.lockstep_stats()
+    assert st["root_steps"] > 0 and st["objective_jobs"] > 0
+    assert st["root_steps"] >= 2 * st["root_launches"], st
 
 
 def test_batched_root_sweep_equals_move_root_sweep():

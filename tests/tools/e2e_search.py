@@ -36,6 +36,11 @@ if workers or lockstep:
     print("%d candidates, %s: %.2fs  (%.3fs per candidate)  sum llh %.6f" % (
         len(res["root_id"]), "%d in lock step" % lockstep if lockstep else "%d workers" % workers,
         dt, dt / len(res["root_id"]), float(sum(res["llh"]))))
+    if lockstep:
+        st = m.lockstep_stats()
+        print("  combined launches: %d objective (%.1f jobs each), %d root-only (%.1f steps each)" % (
+            st["objective_launches"], st["objective_jobs"] / max(st["objective_launches"], 1),
+            st["root_launches"], st["root_steps"] / max(st["root_launches"], 1)))
     sys.exit(0)
 t0 = time.time()
 tot = 0
