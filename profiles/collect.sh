@@ -7,7 +7,7 @@
 # profiles/<tag>_*.csv + profiles/<tag>_summary.json (committed).
 TAG=${1:-r1}
 export TMPDIR=/tmp; R=/root/repo; OUT=$R/gpurun_out/$TAG; mkdir -p $OUT; cd /tmp
-BENCH="python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline"
+BENCH="python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --allow-stale-profile --sustain-seconds 0"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH > $OUT/trace.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- $BENCH > $OUT/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- $BENCH > $OUT/write.log 2>&1

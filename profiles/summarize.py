@@ -58,7 +58,16 @@ for k, d in out.items():
 # Issue-slot figures of the FP64-bound kernels (bench.py publishes them under
 # roofline.issue).  A fused_dna_eval_kernel wave walks (n-1) operations x R rates
 # = 396 steps on the default command (c2); FP64 counters count wave instructions.
-STEPS_PER_WAVE = {"fused_dna_eval_kernel": 99 * 4}
+# (steps per evaluation: from the un-profiled bench line of the same collection -- with subtree
+# site repeats a schedule runs fewer than n-1 operations; 99 x 4 without that line)
+steps_per_eval = 99.0
+try:
+    for line in open(os.path.join(src, "bench_plain.log")):
+        if line.startswith("{"):
+            steps_per_eval = json.loads(line)["roofline"]["schedule"]["steps_per_evaluation"]
+except (OSError, KeyError, ValueError):
+    pass
+STEPS_PER_WAVE = {"fused_dna_eval_kernel": steps_per_eval * 4}
 for k, d in out.items():
     if "SQ_INSTS_VALU_FMA_F64" not in d or not d.get("SQ_WAVES") or not d.get("SQ_INSTS_VALU"):
         continue
@@ -77,6 +86,7 @@ for k, d in out.items():
             der["valu_per_step"] = round(d["SQ_INSTS_VALU"] / d["SQ_WAVES"] / steps, 2)
             der["fp64_valu_per_step"] = round(fp64 / d["SQ_WAVES"] / steps, 2)
             der["sites_per_lane"] = 2
+            der["steps_per_evaluation"] = steps_per_eval
     d["derived"] = der
 for k, d in out.items():   # what these counters describe (bench.py checks it before publishing them)
     if source_digest(k):
