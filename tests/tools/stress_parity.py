@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Randomised parity soak (run by hand on a GPU box, not collected by pytest):
 random shapes (4, 2 and 20 states), random valid operation orders, random root
-placements -- the materialising kernels and the fused evaluators against the
-CPU oracle.
+placements, subtree site repeats off / class limit 16 / 64, gaps and ambiguity
+codes, the occasional vanishing rate category -- the materialising kernels and
+the fused evaluators against the CPU oracle.
 usage: stress_parity.py [seconds] [seed]"""
 import os
 import sys
@@ -19,7 +20,7 @@ import util
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
-t0, rounds, worst = time.time(), 0, 0.0
+t0, rounds, worst, folded = time.time(), 0, 0.0, 0
 while time.time() - t0 < budget:
     n = int(rng.integers(4, 260))
     R = int(rng.choice([1, 2, 4, 8]))
@@ -32,7 +33,22 @@ while time.time() - t0 < budget:
     w = synth.workload(n, S, K, R, int(rng.integers(1 << 30)))
     tree = rd.Tree.from_newick(w["newick"])
     cmap = rd.MAP_NT if K == 4 else util.make_map(w["alphabet"])
-    g = rd.Partition.for_tree(tree, K, S, R)
+    # subtree site repeats (4 and 2 states): off / class limit 16 / 64; a third of the
+    # nucleotide cases get gaps and ambiguity codes (cherries with more than 16 classes),
+    # one in ten a rate category small enough to send the launch to the plain programs
+    repeats = int(rng.choice([0, 16, 64])) if K != 20 else 0
+    if K == 4 and rng.random() < 0.33:
+        for k, v in w["seqs"].items():
+            v = np.frombuffer(v.encode(), dtype=np.uint8).copy()
+            v[rng.random(S) < 0.2] = ord("-")
+            v[rng.random(S) < 0.03] = ord(str(rng.choice(list("RYKMSW"))))
+            w["seqs"][k] = v.tobytes().decode()
+    if K != 20 and rng.random() < 0.1:
+        w["rates"] = [1e-42] + list(w["rates"][1:])
+    g = rd.Partition.for_tree(tree, K, S, R, attributes=rd.ATTRIB_SITE_REPEATS if repeats else 0)
+    if repeats:
+        g.set_site_repeats(repeats)
+    folded += repeats > 0
     o = OraclePartition.for_tree(tree, K, S, R)
     util.load_tips(g, tree, w["seqs"], cmap)
     util.load_tips(o, tree, w["seqs"], ORC_MAP_NT if K == 4 else cmap)
@@ -73,4 +89,5 @@ while time.time() - t0 < budget:
     rounds += 1
     g.destroy()
     o.destroy()
-print("%d random cases in %.0f s, worst lnL rel. err %.2e" % (rounds, time.time() - t0, worst))
+print("%d random cases (%d with subtree site repeats) in %.0f s, worst lnL rel. err %.2e"
+      % (rounds, folded, time.time() - t0, worst))
