@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cstring>
 
+#include "clade_classes.hpp"
 #include "clades.hpp"
 #include "common.hpp"
 #include "fused.hpp"
@@ -16,10 +17,7 @@ CladeCache::~CladeCache() {
 }
 void clade_cache_free(CladeCache *c) { delete c; }
 
-// ---- host: classes of a directed subtree ---------------------------------------------------
-// The classes of a node are the distinct pairs (class of child 0, class of child 1) over the
-// sites, numbered in order of first appearance -- the partition of the sites by the pattern
-// of the tips below the node, whichever way the subtree is split.  A tip's class is its code.
+// ---- host: classes of a directed subtree (clade_classes.hpp) -------------------------------
 unsigned clade_intern(rdamd_partition *p, unsigned child0, unsigned child1, unsigned mat0, unsigned mat1) {
   if (!p->clades) p->clades = new CladeCache();
   CladeCache &c = *p->clades;
@@ -47,28 +45,8 @@ unsigned clade_intern(rdamd_partition *p, unsigned child0, unsigned child1, unsi
       cnt[k] = cn.n_classes;
     }
   }
-  if (small) {
-    std::vector<int> seen((size_t)cnt[0] * cnt[1], -1);
-    n.cls.resize(S);
-    unsigned count = 0;
-    for (size_t s = 0; s < S; ++s) {
-      const unsigned a = cls[0][s], b = cls[1][s];
-      int &slot = seen[(size_t)a * cnt[1] + b];
-      if (slot < 0) {
-        if (count == c.max_classes) { small = false; break; }
-        slot = (int)count++;
-        n.cmap.push_back((uint8_t)a);
-        n.cmap.push_back((uint8_t)b);
-      }
-      n.cls[s] = (uint8_t)slot;
-    }
-    n.n_classes = small ? count : 0;
-  }
-  if (!small) {
-    n.n_classes = 0;
-    n.cls.clear(); n.cls.shrink_to_fit();
-    n.cmap.clear();
-  }
+  if (small) n.n_classes = clade_classes(cls[0], cnt[0], cls[1], cnt[1], S, c.max_classes, n.cls, n.cmap);
+  else n.n_classes = 0;
   const unsigned id = tips + (unsigned)c.nodes.size();
   c.nodes.push_back(std::move(n));
   c.intern.emplace(key, id);

@@ -189,10 +189,16 @@ fused_dna_eval_kernel(FusedArgs a) {
   const __amdgpu_buffer_rsrc_t tab_rs =
       make_rsrc(reinterpret_cast<const char *>(a.tiptab + (size_t)job * a.tiptab_job_stride) - (TR == 16 ? 0 : 1024),
                 (unsigned)(a.tiptab_job_stride * 8) + (TR == 16 ? 0u : 1024u));
+  // (the tables' descriptor as four dwords, for the asm block in RDAMD_LOAD_TAB)
+  typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+  const unsigned long long tab_base = reinterpret_cast<unsigned long long>(
+      reinterpret_cast<const char *>(a.tiptab + (size_t)job * a.tiptab_job_stride) - (TR == 16 ? 0 : 1024));
+  const u32x4_t tab_desc = {uni((unsigned)tab_base), uni((unsigned)(tab_base >> 32)),
+                            uni((unsigned)(a.tiptab_job_stride * 8) + (TR == 16 ? 0u : 1024u)), 0x00020000u};
   const int lane8 = (int)lane * 8, lane16 = (int)lane * 16;
-  // the lanes behind a 16-row half table carry nothing: an offset beyond the descriptor's range
-  // makes their loads no-ops (zeros into slot rows that a 16-row table never addresses)
-  const int lane16_narrow = lane < 16u ? lane16 : 0x40000000;
+  const int lane4 = (int)lane * 4;
+  static_assert(TR == 16 || TR == 64, "RDAMD_LOAD_TAB's asm spells out the half-table offset of 64-row slots");
+  static_assert(kFusedTT == 0 && kFusedRP == 2, "... and the step kinds it skips an operand for");
   // where this lane's entry of a 16-row table (code lane / 4, state lane % 4) goes in LDS: see read_row
   const unsigned tab_wr = ((lane & 2u) ? 16u * TR : 0u) + (lane >> 2) * 16u + (lane & 1u) * 8u;
   constexpr unsigned kYSlot = 32u * TR;   // the X / Y table slots sit at LDS bytes 0 and 32 TR
@@ -223,26 +229,52 @@ fused_dna_eval_kernel(FusedArgs a) {
     // Operand tables of the NEXT operation.  TR = 16: a table is one double per lane,
     // prefetched into a register and dropped into its slot when the operation starts.
     // TR = 64: every table goes from memory straight into its slot (LDS-DMA, no register on
-    // the way, no branch on the table's size): two 16-byte-per-lane pieces, one per half
-    // table -- 64 lanes for a 64-row table (flags 0x2000 X / 0x4000 Y), lanes 0-15 for a
-    // 16-row one (the others get an out-of-range offset: no EXEC juggling, no branch; skipping
-    // the loads of an operand the next step does not have -- X unless it is tip-tip, Y if it
-    // pops -- with a branch measured c2 -9 %, 125.phy +4 %: not taken), whose
-    // second half sits 256 bytes behind the first in memory but 16 TR bytes behind it in the slot (the instruction offset moves source AND destination,
+    // the way): one piece per half table -- 64 lanes x 16 bytes for a 64-row table (flags
+    // 0x2000 X / 0x4000 Y), 64 lanes x 4 bytes for a 16-row one.  The choice is a scalar branch
+    // INSIDE one asm statement: as an `if` in the source it costs the two-sites-per-lane kernel
+    // 21 VGPRs and 90 register copies at the joins (145 against 124 VGPRs: three waves per
+    // SIMD instead of four), although neither side loads a register.  Measured alternatives on
+    // c2 with the 16-row kernel's schedules (class limit 17; that kernel: 2.98 ms per launch):
+    // 16-byte pieces for both sizes, the lanes behind a 16-row half table out of range -- they
+    // WRITE ZEROS, 4 x the bytes into LDS (profiles/micro/lds_dma_oob.hip) -- 3.44 ms; the extra
+    // pieces of a 64-row table issued with EXEC = 0 otherwise: 5.94 ms (an instruction without
+    // lanes still costs the address unit its ~10 cycles); this form 3.17 ms.  The same statement
+    // skips an operand the step does not have (X unless it is tip-tip, Y if it pops; as an
+    // `if` in the source that measured c2 -9 %).  The compiler does not count these loads: its own counted
+    // waits only get stricter by that, and the step that reads the tables waits for everything.
+    // A 16-row table's second half sits 256 bytes behind the first in memory but 16 TR bytes
+    // behind it in the slot (the instruction offset moves source AND destination,
     // profiles/micro/lds_dma_offset.hip; the scalar offset makes up the difference, which is
-    // why tab_rs starts 1 KB in front of the job's tables).  The wait in front: this
+    // why the descriptor starts 1 KB in front of the job's tables).  The wait in front: this
     // operation's own rows must have left the slots before new tables land in them.
-#define RDAMD_LOAD_TAB(op, SLOT, WIDE, tOFF, e)                                                 \
+#define RDAMD_LOAD_TAB(op, SLOT, WIDE, tOFF, e, SKIP_IF)                                        \
   if (TR == 16) {                                                                               \
     e = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(                         \
         tab_rs, lane8, (int)((uni(op.tOFF) + roff) * 4u), 0));                                  \
   } else {                                                                                      \
-    const bool wide = (uni(op.flags) & WIDE) != 0u;                                             \
+    const unsigned wide = uni(op.flags) & WIDE;                                                 \
     const int so = (int)((uni(op.tOFF) + (wide ? roff * 4u : roff)) * 4u) + 1024;               \
-    const int vo = wide ? lane16 : lane16_narrow;   /* (lanes 16.. of a 16-row table: out of range) */ \
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(tab_rs, (lds_void_ptr)(size_t)(SLOT), 16, vo, so, 0, 0); \
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(tab_rs, (lds_void_ptr)(size_t)(SLOT), 16, vo,       \
-                                             wide ? so : so - 768, 16 * TR, 0);                 \
+    unsigned m0_saved;                                                                          \
+    asm volatile(                                                                               \
+        SKIP_IF "\n\t"   /* an operand the step does not have: nothing to load */               \
+        "s_cbranch_scc1 3f\n\t"                                                               \
+        "s_mov_b32 %[sv], m0\n\t"                                                             \
+        "s_mov_b32 m0, %[m]\n\t"                                                              \
+        "s_cmp_lg_u32 %[w], 0\n\t"                                                            \
+        "s_cbranch_scc1 1f\n\t"                                                               \
+        "buffer_load_dword %[vo4], %[rs], %[so] offen lds\n\t"                                \
+        "buffer_load_dword %[vo4], %[rs], %[so2] offen offset:1024 lds\n\t"                   \
+        "s_branch 2f\n"                                                                        \
+        "1:\n\t"                                                                              \
+        "buffer_load_dwordx4 %[vo16], %[rs], %[so] offen lds\n\t"                             \
+        "buffer_load_dwordx4 %[vo16], %[rs], %[so] offen offset:1024 lds\n"                    \
+        "2:\n\t"                                                                              \
+        "s_mov_b32 m0, %[sv]\n"                                                                \
+        "3:"                                                                                    \
+        : [sv] "=&s"(m0_saved)                                                                  \
+        : [m] "s"((unsigned)(SLOT)), [w] "s"(wide), [vo4] "v"(lane4), [vo16] "v"(lane16), [rs] "s"(tab_desc), \
+          [so] "s"(so), [so2] "s"(so - 768), [kind] "s"(uni(op.flags) & 3u)                     \
+        : "memory", "scc");                                                                     \
   }
 #define RDAMD_LOAD_TIPS(op, cx, cy, ex, ey)                                                     \
   _Pragma("unroll") for (int q = 0; q < NS; ++q) {                                              \
@@ -250,8 +282,8 @@ fused_dna_eval_kernel(FusedArgs a) {
     cy[q] = load_code<TR>(tips_rs, site_off[q], (int)uni(op.cY));                               \
   }                                                                                             \
   if (TR > 16) __builtin_amdgcn_s_waitcnt(0xc07f);   /* lgkmcnt(0) */                           \
-  RDAMD_LOAD_TAB(op, 0u, 0x2000u, tX, ex)                                                       \
-  RDAMD_LOAD_TAB(op, kYSlot, 0x4000u, tY, ey)
+  RDAMD_LOAD_TAB(op, 0u, 0x2000u, tX, ex, "s_cmp_lg_u32 %[kind], 0")       /* X: tip-tip steps only */ \
+  RDAMD_LOAD_TAB(op, kYSlot, 0x4000u, tY, ey, "s_cmp_eq_u32 %[kind], 2")   /* Y: not when the step pops */
     // (TR = 64: the descriptor of the operation after next only now -- fetched at the top of
     // the step it would sit in front of the wait above)
 #define RDAMD_LATE_DESC(cur, idx2) if (TR > 16) cur = load_const(prog + (idx2));

@@ -11,6 +11,7 @@
 #include <dlfcn.h>
 
 #include "clades.hpp"
+#include "k20_split.hpp"
 #include "common.hpp"
 
 namespace rdamd {
@@ -509,111 +510,6 @@ int rdamd_update_prob_matrices(rdamd_partition_t *p, const unsigned int *params_
   return RDAMD_SUCCESS;
 }
 
-}  // extern "C"
-
-namespace {
-// does operation i read, from memory, something one of the two operations before it (inside
-// the same segment, which starts at `seg_start`) wrote and that cannot be forwarded in
-// registers?  (20-state kernel, see rdamd_update_clvs)
-bool k20_hazard(const rdamd_partition *p, const rdamd_operation_t *ops, unsigned i, unsigned seg_start) {
-  const rdamd_operation_t &o = ops[i];
-  const unsigned ch[2] = {o.child1_clv_index, o.child2_clv_index};
-  const int chsc[2] = {o.child1_scaler_index, o.child2_scaler_index};
-  bool hazard = false;
-  for (int c = 0; c < 2; ++c) {
-    if (ch[c] < p->tips) continue;
-    int hits = 0, clean = 0;
-    for (unsigned back = 1; back <= 2 && back <= i - seg_start; ++back) {
-      const rdamd_operation_t &b = ops[i - back];
-      const bool forwarded = ch[c] == b.parent_clv_index && chsc[c] == b.parent_scaler_index;
-      const bool touches = ch[c] == b.parent_clv_index ||
-                           (chsc[c] >= 0 && chsc[c] == b.parent_scaler_index);
-      hits += touches;
-      clean += forwarded;
-    }
-    hazard = hazard || hits != clean || hits > 1;
-  }
-  return hazard;
-}
-
-// The 20-state traversal kernel gives every 16-site tile ONE workgroup that walks the whole
-// operation list: BASELINE config c3 (10 000 sites) has 625 of them for 256 CUs that could
-// hold 768, and each is a 199-operation dependency chain.  A post-order list of a tree is a
-// nest of contiguous subtree ranges, so it can be cut into independent PIECES -- subtrees of
-// comparable size, longest first -- that run side by side (grid.y), followed by the few TOP
-// operations that join them.  Returns the re-ordered list (pieces, then top) and the piece
-// boundaries; leaves both empty when the list is no such nest (arbitrary operation orders,
-// partial traversals) or too short to be worth a second launch.
-void k20_split(const rdamd_partition *p, const rdamd_operation_t *ops, unsigned count,
-               std::vector<rdamd_operation_t> &order, std::vector<unsigned> &bounds) {
-  order.clear();
-  bounds.clear();
-  if (count < 24) return;
-  const unsigned nclv = p->tips + p->clv_buffers;
-  std::vector<int> producer(nclv, -1), parent(count, -1);
-  std::vector<unsigned> size(count, 1);
-  for (unsigned i = 0; i < count; ++i) {
-    const rdamd_operation_t &o = ops[i];
-    if (o.parent_clv_index < p->tips || o.parent_clv_index >= nclv || o.child1_clv_index >= nclv ||
-        o.child2_clv_index >= nclv || producer[o.parent_clv_index] >= 0)
-      return;
-    // post-order: the later inner child sits right in front, the earlier one right in front of
-    // the later one's whole subtree
-    int kids[2], nk = 0;
-    for (unsigned ch : {o.child1_clv_index, o.child2_clv_index})
-      if (ch >= p->tips) {
-        const int j = producer[ch];
-        if (j < 0 || parent[j] >= 0) return;   // not computed in this list / used twice
-        kids[nk++] = j;
-      }
-    if (nk == 2 && kids[0] > kids[1]) std::swap(kids[0], kids[1]);
-    if (nk >= 1 && kids[nk - 1] != (int)i - 1) return;
-    if (nk == 2 && kids[0] != (int)i - 1 - (int)size[kids[1]]) return;
-    for (int k = 0; k < nk; ++k) {
-      parent[kids[k]] = (int)i;
-      size[i] += size[kids[k]];
-    }
-    producer[o.parent_clv_index] = (int)i;
-  }
-  if (size[count - 1] != count) return;   // a forest
-  // split the largest piece into its child subtrees until the pieces are comparable
-  std::vector<unsigned> pieces{count - 1};   // by their last (root) operation
-  std::vector<char> top(count, 0);
-  for (;;) {
-    size_t big = 0;
-    for (size_t k = 1; k < pieces.size(); ++k)
-      if (size[pieces[k]] > size[pieces[big]]) big = k;
-    const unsigned r = pieces[big];
-    if (size[r] <= std::max(12u, count / 4) || pieces.size() + 1 > rdamd::kK20MaxPieces) break;
-    top[r] = 1;
-    pieces.erase(pieces.begin() + (std::ptrdiff_t)big);
-    for (unsigned j = 0; j < r; ++j)
-      if (parent[j] == (int)r) pieces.push_back(j);
-    if (pieces.empty()) return;   // (a root operation over two tips)
-  }
-  if (pieces.size() < 2) return;
-  std::sort(pieces.begin(), pieces.end(), [&](unsigned a, unsigned b) { return size[a] > size[b]; });
-  order.reserve(count);
-  for (unsigned r : pieces) {
-    bounds.push_back((unsigned)order.size());
-    for (unsigned j = r + 1 - size[r]; j <= r; ++j) order.push_back(ops[j]);
-  }
-  bounds.push_back((unsigned)order.size());   // = where the top operations start
-  for (unsigned j = 0; j < count; ++j)
-    if (top[j]) order.push_back(ops[j]);
-  // no piece may need a further cut of its own (then the plain order runs)
-  for (size_t k = 0; k + 1 < bounds.size(); ++k)
-    for (unsigned i = bounds[k] + 1; i < bounds[k + 1]; ++i)
-      if (k20_hazard(p, order.data(), i, bounds[k])) {
-        order.clear();
-        bounds.clear();
-        return;
-      }
-}
-}  // namespace
-
-extern "C" {
-
 void rdamd_update_clvs(rdamd_partition_t *p, const rdamd_operation_t *ops,
                        unsigned int count) {
   clear_error();
@@ -622,7 +518,7 @@ void rdamd_update_clvs(rdamd_partition_t *p, const rdamd_operation_t *ops,
   // (20 states: independent subtrees side by side, see k20_split)
   std::vector<rdamd_operation_t> k20_order;
   std::vector<unsigned> k20_bounds;
-  if (p->mfma_layout) k20_split(p, ops, count, k20_order, k20_bounds);
+  if (p->mfma_layout) k20_split(p->tips, p->clv_buffers, ops, count, kK20MaxPieces, k20_order, k20_bounds);
   if (!k20_order.empty()) ops = k20_order.data();
   std::vector<LevelOp> lops(count);
   for (unsigned i = 0; i < count; ++i) {
@@ -683,7 +579,7 @@ void rdamd_update_clvs(rdamd_partition_t *p, const rdamd_operation_t *ops,
         ++next_bound;
         continue;
       }
-      if (k20_hazard(p, ops, i, cuts.back())) cuts.push_back(i);
+      if (k20_hazard(p->tips, ops, i, cuts.back())) cuts.push_back(i);
     }
   }
   cuts.push_back(count);
