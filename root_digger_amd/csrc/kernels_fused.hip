@@ -433,6 +433,9 @@ fused_dna_eval_kernel(FusedArgs a) {
     }
   }
 
+  // (the last step of every rate pass has requested the tables of the padding entry behind
+  // the program: no LDS-DMA may still be on its way when the wave gives its LDS back)
+  if (TR > 16) __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0)
   double total = 0.0;
 #pragma unroll
   for (int q = 0; q < NS; ++q) {

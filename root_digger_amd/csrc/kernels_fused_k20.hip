@@ -315,20 +315,27 @@ fused20_eval_kernel(Fused20Args a, unsigned depth) {
     const unsigned long long hi = ((unsigned long long)c.w3 << 32) | c.w2;
     return (unsigned)((upper_half ? hi : lo) >> code_shift) & 255u;
   };
+  // ONE descriptor for the job's A copies and one for its tables, built once; a request adds
+  // its (matrix, rate) as the scalar offset of the load.  (Round 2 built a descriptor per
+  // request -- eight scalar instructions each, three requests per step.)  The last 16-byte piece
+  // of a 3 200-byte copy runs 896 bytes into the next copy: staged and never read.
+  const __amdgpu_buffer_rsrc_t pm_rs = make_rsrc(pm_job, (unsigned)(a.pmat_job_stride * 8));
+  const __amdgpu_buffer_rsrc_t tt_rs = make_rsrc(tt_job, (unsigned)(a.tiptab_job_stride * 8));
+  const unsigned pm_rate = r * (kCopy * 8u);
   auto request_a = [&](const Step &st) {
-    const __amdgpu_buffer_rsrc_t rs = make_rsrc(pm_job + st.pM + (size_t)r * (kCopy * 8), kCopy * 8);
+    const int so = (int)(st.pM + pm_rate);
 #pragma unroll
     for (int k = 0; k < 4; ++k)
-      raw[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(lane * 16u + 1024u * k), 0, 0);
+      raw[k] = __builtin_amdgcn_raw_buffer_load_b128(pm_rs, (int)(lane * 16u + 1024u * k), so, 0);
   };
   auto request_tab = [&](unsigned tab_off, const TileCodes &codes, Rows (&t)[NT]) {
-    const __amdgpu_buffer_rsrc_t rs = make_rsrc(tt_job + tab_off + tt_rate, kFused20TabDoubles * 8);
+    const int so = (int)(tab_off + tt_rate);
 #pragma unroll
     for (int q = 0; q < NT; ++q) {
       const int o = (int)(my_code(codes.t[q]) * 192u + tt_lane);
-      t[q].a = __builtin_amdgcn_raw_buffer_load_b128(rs, o, 0, 0);          // s = 0, 1
-      t[q].b = __builtin_amdgcn_raw_buffer_load_b128(rs, o + 64, 0, 0);     // s = 2, 3
-      t[q].c = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)(my_code(codes.t[q]) * 192u + 128u + grp * 8u), 0, 0);   // s = 4
+      t[q].a = __builtin_amdgcn_raw_buffer_load_b128(tt_rs, o, so, 0);          // s = 0, 1
+      t[q].b = __builtin_amdgcn_raw_buffer_load_b128(tt_rs, o + 64, so, 0);     // s = 2, 3
+      t[q].c = __builtin_amdgcn_raw_buffer_load_b64(tt_rs, (int)(my_code(codes.t[q]) * 192u + 128u + grp * 8u), so, 0);   // s = 4
     }
   };
   auto has_tip1 = [](const Step &st) { return (st.flags & 3u) == kFusedTT; };

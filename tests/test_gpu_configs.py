@@ -55,11 +55,21 @@ def test_c4_c5_tree_sizes_vs_oracle(n, S, seed):
     subst = rng.uniform(1e-4, 1.0, (4, 12))
     scheds = [g.schedule(*tree.generate_operations(rl)) for rl in rls]
     fused = g.evaluate_batch(scheds, subst, [freqs] * 4)
+    # ... and with subtree site repeats (clade tables) on a partition of its own
+    gr = rd.Partition.for_tree(tree, 4, S, 4, attributes=rd.ATTRIB_SITE_REPEATS)
+    util.load_tips(gr, tree, w["seqs"], rd.MAP_NT)
+    gr.set_category_rates(w["rates"])
+    sr = [gr.schedule(*tree.generate_operations(rl)) for rl in rls]
+    assert min(x.stats()["clade_nodes"] for x in sr) > n // 5
+    folded = gr.evaluate_batch(sr, subst, [freqs] * 4)
     for j, rl in enumerate(rls):
         _set((g, o), subst[j], freqs, w["rates"])
         want = util.compute_lh(o, tree, rl)
         assert util.rel_err(util.compute_lh(g, tree, rl), want) < LNL_TOL
         assert util.rel_err(fused[j], want) < LNL_TOL
+        assert util.rel_err(folded[j], want) < LNL_TOL
+    del sr
+    gr.destroy()
     ops, _, _ = tree.generate_operations(rls[-1])          # state left by the last job
     for op in ops[::7] + [ops[-1]]:
         a, b = g.get_clv(op.parent_clv_index), o.get_clv(op.parent_clv_index)
@@ -96,7 +106,10 @@ def c5_full():
 
 
 def _slice_partition(w, tree, lo, hi):
-    part = rd.Partition.for_tree(tree, 4, hi - lo, 4)
+    # (the site blocks run WITH subtree site repeats, the reference's configuration for
+    # 4-state data -- src/model.cpp:145-149 --, the whole-alignment partition they are summed
+    # against without: the additivity checks below are also repeats-vs-plain checks at full size)
+    part = rd.Partition.for_tree(tree, 4, hi - lo, 4, attributes=rd.ATTRIB_SITE_REPEATS)
     util.load_tips(part, tree, {k: v[lo:hi] for k, v in w["seqs"].items()}, rd.MAP_NT)
     part.set_category_rates(w["rates"])
     return part
