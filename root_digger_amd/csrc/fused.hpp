@@ -41,14 +41,15 @@ struct FusedJob {
   const FusedOp *prog;   // device
   const double  *brlen;  // device, indexed by P-matrix index
   uint32_t n_ops, depth;
-  // 4 states: jobs[0].tt_unsafe is set by the P-matrix step when a tip-table entry of the
-  // LAUNCH lies in (0, 2^-128), and by the clade-table step when a pseudo-tip's table has
-  // such an entry or a class of a pseudo-tip would have been rescaled inside its clade.
-  // While it is 0, the product of two table rows is either 0 or >= 2^-256, a tip-tip step
-  // can never need a rescale, and the evaluator variant without that test runs
-  // (kernels_fused.hip) -- on `prog`, the program with the pseudo-tips.  When it is up, the
-  // variant with the test runs on `prog_plain`: every operation of the caller's list, tips
-  // only, every rescale exactly where the reference rule puts it.
+  // 4 states: tt_unsafe is set by the P-matrix step when a tip-table entry of THIS JOB lies in
+  // (0, 2^-128), and by the clade-table step when one of its pseudo-tips' tables has such an
+  // entry or a class of a pseudo-tip would have been rescaled inside its clade.  While it is
+  // 0, the product of two table rows is either 0 or >= 2^-256, a tip-tip step can never need
+  // a rescale, and the evaluator variant without that test runs the job (kernels_fused.hip)
+  // -- on `prog`, the program with the pseudo-tips.  When it is up, the variant with the test
+  // runs it on `prog_plain`: every operation of the caller's list, tips only, every rescale
+  // exactly where the reference rule puts it.  (Both variants are launched over all jobs; a
+  // workgroup of the wrong variant returns at once.)
   uint32_t tt_unsafe, pad;
   // subtree site repeats (clades.hpp); without pseudo-tips prog_plain == prog, n_groups == 0
   const FusedOp    *prog_plain;

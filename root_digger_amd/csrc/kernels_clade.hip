@@ -153,7 +153,7 @@ hipError_t clade_upload_map(rdamd_partition *p, unsigned id) {
 // Scaling: a pseudo-tip carries no rescale count.  That is exact as long as no class of any
 // node of the clade meets the rescale condition (all entries < 2^-256);
 // if one does -- or if a table entry is small enough for a later tip-tip product to meet it --
-// the launch-wide flag goes up and the evaluator runs the plain programs instead.
+// the job's flag goes up and the evaluator runs the job's plain program instead.
 // ROWS: rows per table slot of the launch (16 or 64) = the scratch tables' row count.  A
 // pseudo-tip of up to 16 classes lands in its branch's 16-row table, in the tip tables'
 // layout ([class][state]); one of up to 64 classes in its own 64-row table, stored as the
@@ -218,7 +218,7 @@ clade_table_kernel(FusedJob *__restrict__ jobs, const uint8_t *__restrict__ maps
     }
     __syncthreads();   // (also orders this workgroup's scratch writes before the next node's reads)
   }
-  if (unsafe) jobs[0].tt_unsafe = 1u;   // launch-wide (every writer stores the same value)
+  if (unsafe) jobs[job].tt_unsafe = 1u;   // the job's flag (every writer stores the same value)
 }
 
 hipError_t launch_clade_tables(const FusedArgs &a, const uint8_t *d_maps, double *d_scratch,

@@ -135,9 +135,14 @@ __device__ __forceinline__ void combine(const double (&tx)[4], const double (&ty
   }
 }
 
-// TTCHECK: rescale test on tip-tip steps too.  Both variants of a launch are queued;
-// each looks at the launch-wide flag the P-matrix step left in jobs[0].tt_unsafe (some
-// tip-table entry in (0, 2^-128)) and the one it does not belong to returns at once.
+// TTCHECK: rescale test on tip-tip steps too.  Both variants of a launch are queued; a
+// workgroup looks at the flag the P-matrix / clade-table steps left in ITS job
+// (FusedJob::tt_unsafe: some table entry of the job in (0, 2^-128), or a pseudo-tip class
+// that would have been rescaled) and returns at once in the variant the job does not belong
+// to.  Per job, not per launch: a job's value then does not depend on what else shares its
+// launch -- the lock-stepped search combines the candidates' batches and must reproduce the
+// sequential trajectories bit for bit --, and one candidate on the edge of its parameter
+// range does not send the others to the slower plain programs.
 // RL: stack levels that live in registers (1 or 2).  The second one costs 18 VGPRs per
 // lane at two sites per lane (142: three waves per SIMD) and is taken when it frees
 // enough LDS to more than pay for that (deep stacks of 500- and 1000-taxon trees:
@@ -167,10 +172,10 @@ fused_dna_eval_kernel(FusedArgs a) {
   }
 
   // a tip-tip step multiplies two tip-table rows: with every non-zero table entry of
-  // the launch >= 2^-128 (checked where the tables are built) the product is 0 or
+  // the job >= 2^-128 (checked where the tables are built) the product is 0 or
   // >= 2^-256 and the rescale test cannot fire on a non-zero vector: it is compiled
   // out of the variant that runs then (+3.5 % on c2; a run-time branch gave nothing)
-  if ((uni(to_const(&a.jobs[0].tt_unsafe)[0]) != 0u) != TTCHECK) return;
+  if ((uni(to_const(&a.jobs[job].tt_unsafe)[0]) != 0u) != TTCHECK) return;
   constexpr bool tt_safe = !TTCHECK;
   // (the variant with the test walks the PLAIN programs -- no pseudo-tips, every rescale
   // where the reference rule has it; fused.hpp)
@@ -436,18 +441,20 @@ fused_dna_eval_kernel(FusedArgs a) {
   // (the last step of every rate pass has requested the tables of the padding entry behind
   // the program: no LDS-DMA may still be on its way when the wave gives its LDS back)
   if (TR > 16) __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0)
-  double total = 0.0;
+  // One partial sum per 64-SITE BLOCK, whatever the number of sites per lane: a job's value
+  // must not depend on the size of the launch it rides in (NS is chosen by that), so a wave
+  // with two blocks reduces them separately and the finishing kernel adds the same partials
+  // in the same order either way.
 #pragma unroll
   for (int q = 0; q < NS; ++q) {
     double l = log(term[q]) + (double)smin[q] * kLogScaleThreshold;
     l *= (double)a.pattern_weights[site[q]];
     if (!valid[q]) l = 0.0;
     if (a.persite && valid[q]) a.persite[(size_t)job * S + site[q]] = l;
-    total += l;
-  }
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) total += __shfl_down(total, off);
-  if (lane == 0) a.partials[(size_t)job * gridDim.x + bx] = total;
+    for (int off = 32; off > 0; off >>= 1) l += __shfl_down(l, off);
+    if (lane == 0) a.partials[(size_t)job * (gridDim.x * NS) + bx * NS + q] = l;
+  }
 }
 
 // fixed-order finish, one workgroup per job
@@ -552,7 +559,7 @@ fused_pmatrix_k4_kernel(const double *__restrict__ q, const double *__restrict__
   bool tiny = false;
 #pragma unroll
   for (int i = 0; i < 16; ++i) tiny = tiny || (out[i] > 0.0 && out[i] < 0x1p-128);
-  if (tiny) jobs[0].tt_unsafe = 1u;   // launch-wide (every writer stores the same value)
+  if (tiny) jobs[job].tt_unsafe = 1u;   // (every writer stores the same value)
 }
 
 hipError_t launch_fused_pmatrix(const FusedArgs &a, const double *d_q, const double *d_rates,
@@ -613,7 +620,7 @@ static hipError_t launch_fused_eval_ns(const FusedArgs &a, unsigned n_jobs, cons
   if (e != hipSuccess) return e;
   e = launch_fused_variant_rl<NS, true, TR>(a, n_jobs, max_depth[1], gx, reg_levels[1], stream);   // (returns at once on ordinary data)
   if (e != hipSuccess) return e;
-  fused_finish_kernel<<<n_jobs, 256, 0, stream>>>(a.partials, gx, d_out);
+  fused_finish_kernel<<<n_jobs, 256, 0, stream>>>(a.partials, gx * NS, d_out);   // 64-site blocks per job
   return hipGetLastError();
 }
 

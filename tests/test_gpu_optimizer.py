@@ -182,6 +182,34 @@ def test_parallel_exhaustive_search_equals_sequential(lbfgsb):
     assert st["root_steps"] >= 2 * st["root_launches"], st
 
 
+def test_lockstep_records_do_not_depend_on_the_launch_size(lbfgsb):
+    """A job's value must not depend on the launch it rides in -- else the lock-stepped search,
+    whose launches are as wide as the number of candidates in flight, would walk other
+    optimiser trajectories than the sequential one.  Two things could make it: the kernel takes
+    two sites per lane once a launch is big enough (here: from 26 jobs on; one candidate's
+    batches have 17), and the fall-back to the plain programs is decided by a flag.  Both are
+    per job now (one partial sum per 64-site block whatever the sites per lane;
+    FusedJob::tt_unsafe per job): same records with 1, 3 and 8 candidates in flight, bit for bit,
+    on an alignment long enough for the variants to differ."""
+    from root_digger_amd import synth
+    w = synth.workload(12, 20000, 4, 4, 977)
+    tree = rd.Tree.from_newick(w["newick"])
+    m = rd.Model(tree, w["seqs"], rate_cats=4, seed=5)
+    m.initialize_partitions()
+    m.set_lbfgsb(lbfgsb.setulb)
+    m.compute_lh(tree.root_location(0))
+    m._ok(rd.lib.rdamd_model_assign_by_rank(m._h, 0, 2), "assign")     # the first half of the 21 roots
+    seq = m.exhaustive_search(1e-4, 1e-4, 1e-6, 1e9)
+    order = np.argsort(seq["root_id"])
+    for in_flight in (3, 8):
+        lock = m.exhaustive_search(1e-4, 1e-4, 1e-6, 1e9, lockstep=in_flight)
+        assert lock["root_id"] == sorted(seq["root_id"])
+        assert np.array_equal(lock["llh"], seq["llh"][order])
+        assert np.array_equal(lock["alpha"], seq["alpha"][order])
+    st = m.lockstep_stats()
+    assert st["objective_jobs"] / st["objective_launches"] > 26     # wide launches were the rule
+
+
 def test_batched_root_sweep_equals_move_root_sweep():
     """all 2n-3 root lnLs at fixed parameters: one fused launch vs the reference's
     move_root sweep (src/model.cpp:865-889, :1737-1746)."""

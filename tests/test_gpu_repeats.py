@@ -147,9 +147,9 @@ def test_repeats_on_the_deep_scaling_caterpillar(classes):
 def test_tiny_table_entries_fall_back_to_the_plain_programs(classes):
     """A pseudo-tip has no rescale count, so the launch must not use them when a clade's class
     could have been rescaled or a table entry is small enough for a tip-tip product to need
-    it: with a rate category of 1e-42 the off-diagonal P entries are < 2^-128, the launch-wide
-    flag goes up and the evaluator walks the PLAIN programs -- the same kernel and program as
-    a partition without repeats, hence the same bits."""
+    it: with a rate category of 1e-42 the off-diagonal P entries are < 2^-128, the job's flag
+    goes up and the evaluator walks its PLAIN program -- the same kernel and program as a
+    partition without repeats, hence the same bits."""
     w = synth.workload(30, 700, 4, 4, 151)
     tree = rd.Tree.from_newick(w["newick"])
     a, b, o = trio(tree, w["seqs"], 4, None, classes)
@@ -165,15 +165,23 @@ def test_tiny_table_entries_fall_back_to_the_plain_programs(classes):
     assert np.array_equal(got, b.evaluate_batch(sb, subst, freqs, rates))
     for j, rl in enumerate(rls):
         assert util.rel_err(got[j], oracle_eval(o, tree, rl, subst[j], freqs[j], rates[j])) < LNL_TOL
-    # ... and one such job in a batch sends the whole launch there
+    # ... per JOB: one such job in a batch runs its plain program, the others keep their folded
+    # ones, and no job's value depends on what else shares its launch (the lock-stepped search
+    # combines candidates' batches and must reproduce the sequential trajectories bit for bit)
     rates[1:] = rd.compute_gamma_cats(1.0, 4)
-    got = a.evaluate_batch(sa, subst, freqs, rates)
-    assert np.array_equal(got, b.evaluate_batch(sb, subst, freqs, rates))
+    mixed = a.evaluate_batch(sa, subst, freqs, rates)
+    plain = b.evaluate_batch(sb, subst, freqs, rates)
+    assert mixed[0] == plain[0]
+    assert np.max(np.abs(mixed - plain) / np.abs(plain)) < 1e-12
+    for j in range(4):
+        alone = a.evaluate_batch([sa[j]], subst[j:j + 1], freqs[j:j + 1], rates[j:j + 1])[0]
+        assert alone == mixed[j], j
     # ordinary rates again: back on the folded programs, same values to rounding
     rates[0] = rd.compute_gamma_cats(1.0, 4)
     got = a.evaluate_batch(sa, subst, freqs, rates)
     ref = b.evaluate_batch(sb, subst, freqs, rates)
     assert np.max(np.abs(got - ref) / np.abs(ref)) < 1e-12
+    assert np.array_equal(got[1:], mixed[1:])
     for p in (a, b, o):
         p.destroy()
 
@@ -264,6 +272,10 @@ def test_c2_full_size_with_repeats():
     got = a.evaluate_batch([sa[i] for i in picks], subst, np.tile(freqs, (24, 1)))
     assert np.all(np.isfinite(got)) and np.all(got < 0)
     assert np.array_equal(got, a.evaluate_batch([sa[i] for i in picks], subst, np.tile(freqs, (24, 1))))
+    # a job's value does not depend on the launch it rides in: alone (one site per lane, a
+    # small launch) or among 24 (two sites per lane) -- the same bits
+    for j in (0, 13):
+        assert a.evaluate_batch([sa[picks[j]]], subst[j:j + 1], freqs[None, :])[0] == got[j]
     sb = [b.schedule(*tree.generate_operations(tree.root_location(int(i)))) for i in picks]
     ref = b.evaluate_batch(sb, subst, np.tile(freqs, (24, 1)))
     assert np.max(np.abs(got - ref) / np.abs(ref)) < 1e-12
