@@ -708,9 +708,15 @@ class Partition:
     def schedule(self, ops, matrix_indices, branch_lengths):
         return Schedule(self, ops, matrix_indices, branch_lengths)
 
+    @staticmethod
+    def schedule_handles(schedules):
+        """the handle array rdamd_evaluate_batch takes, for callers that evaluate the same list
+        of schedules repeatedly (evaluate_batch accepts it in place of the list)"""
+        return (_vp * len(schedules))(*[s._h for s in schedules])
+
     def _batch_args(self, schedules, subst, freqs, rates, rate_weights):
         n = len(schedules)
-        hs = (_vp * n)(*[s._h for s in schedules])
+        hs = schedules if isinstance(schedules, C.Array) else (_vp * n)(*[s._h for s in schedules])
         k = self.states                       # 4, 2 (binary data on the 4-state kernels) or 20
         subst = np.ascontiguousarray(subst, dtype=np.float64).reshape(n, k * k - k)
         freqs = np.ascontiguousarray(freqs, dtype=np.float64).reshape(n, k)
