@@ -642,6 +642,7 @@ static int evaluate_batch_impl(rdamd_partition_t *p, unsigned int n_jobs,
   a.jobs = w->d_jobs; a.tipcodes = wide_codes ? p->d_codes_wide : p->d_tipcodes16;
   a.pattern_weights = p->d_pattern_weights;
   a.table_rows = table_rows;
+  a.rates_across_waves = 0;   // (set below, once the size of the code arena is known)
 
   a.tiptab_job_stride = tiptab_job;
   a.pmat = w->d_pmat; a.tiptab = w->d_tiptab + kTiptabPad; a.freqs = w->d_freqs; a.rate_weights = w->d_rw;
@@ -650,6 +651,14 @@ static int evaluate_batch_impl(rdamd_partition_t *p, unsigned int n_jobs,
   a.sites = p->sites; a.rate_cats = R;
   a.tipcodes_bytes = (unsigned)std::min<size_t>(wide_codes ? (size_t)p->wide_rows * p->tip_stride() * 2
                                                            : (size_t)p->code_rows * p->tip_stride(), 0xffffffffu);
+  // One wave per rate category (kernels_fused.hip, RW) where re-reading the code arena once
+  // per rate pass is what hurts: when it is far beyond every cache level.  Measured (one
+  // box): c4 (850 MB of codes) 200.6 -> 181.1 ms per launch; c5 (340 MB) 77.9 -> 78.2; c2
+  // (16 MB) 2.88 -> 3.08; 125.phy 1.86 -> 1.80.
+  a.rates_across_waves = R >= 2 && R <= 8 && a.tipcodes_bytes >= (512u << 20);
+#ifdef RDAMD_ABLATION
+  if (getenv("RDAMD_FUSED_RW")) a.rates_across_waves = atoi(getenv("RDAMD_FUSED_RW")) != 0 && R >= 2 && R <= 8;
+#endif
   p->prof_begin(4);
   e = launch_fused_pmatrix(a, w->d_q, w->d_rates, n_jobs, p->prob_matrices, p->stream);
   if (e == hipSuccess && max_groups)   // the pseudo-tips' tables, from the P-matrices and tip tables just made

@@ -76,6 +76,7 @@ struct FusedArgs {
   unsigned sites, rate_cats;
   unsigned tipcodes_bytes;           // rows in use * row bytes
   unsigned table_rows;               // 16 or 64: rows per LDS table slot (and the code arena's entry width)
+  unsigned rates_across_waves;       // 1: a workgroup is R waves, one per rate category (kernels_fused.hip, RW)
 };
 
 // ---- 20-state variant (kernels_fused_k20.hip) ---------------------------------

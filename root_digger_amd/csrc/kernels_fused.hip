@@ -24,6 +24,8 @@
 // rule; every factor is an exact power of two, so the
 // result differs from the per-site rule only where that rule would already
 // have lost the category to underflow.
+#include <algorithm>
+
 #include "common.hpp"
 #include "fused.hpp"
 
@@ -147,15 +149,29 @@ __device__ __forceinline__ void combine(const double (&tx)[4], const double (&ty
 // lane at two sites per lane (142: three waves per SIMD) and is taken when it frees
 // enough LDS to more than pay for that (deep stacks of 500- and 1000-taxon trees:
 // three LDS levels allow 10 waves per CU, two LDS levels 15).
-template <int NS, bool TTCHECK, int RL, int TR>
-__global__ void __launch_bounds__(64)
+// RW ("rates across waves"): a workgroup is R waves, wave w walks rate category w of the same
+// 64 NS sites instead of one wave looping over the categories.  Nothing is shared between
+// them until the root -- each has its own table slots and stack in LDS, and they run without a
+// barrier --, but they start together and execute the same program, so the tip / class codes
+// of a site are fetched once per workgroup (the other waves hit L1 / L2) instead of once per
+// rate pass, a whole traversal apart: the 500- and 1000-taxon shapes, whose code arena
+// (850 MB / 340 MB) no longer fits any cache level, spend their time on exactly those
+// re-reads.  The rate terms meet in LDS and wave 0 folds them in rate order with
+// the loop's own arithmetic: the same bits as the one-wave form.
+template <int NS, bool TTCHECK, int RL, int TR, bool RW>
+__global__ void __launch_bounds__(RW ? 512 : 64)
 fused_dna_eval_kernel(FusedArgs a) {
   extern __shared__ double lds[];
   // (read_row<> and the table writes address LDS bytes 0 and 32 TR absolutely: that
   // is the dynamic block only while this kernel has no static __shared__ in front of
   // it -- launch_fused_eval_ns checks the kernel's static LDS size on the host; a
   // device-side test here cost a factor 2.6, its trap path changes the whole kernel)
-  const unsigned lane = threadIdx.x;
+  const unsigned lane = threadIdx.x & 63u;
+  const unsigned wave = RW ? uni(threadIdx.x >> 6) : 0u;
+  // (RW: the table slots of wave w sit at LDS bytes w x 64 TR: below every code -- a row offset
+  // < 16 TR -- so the wave's base is OR-ed into the codes as they arrive, one v_and_or instead
+  // of the v_and the compiler needs there anyway)
+  const unsigned wbase = wave * (64u * TR);
   // Workgroups are dealt round-robin over the 8 XCDs (each with its own L2); grid.x is
   // a multiple of 8, so an XCD owns a fixed eighth of the sites and sees every job's
   // tables.  (Measured alternative: every XCD walks whole jobs, so that its L2 holds one
@@ -205,18 +221,21 @@ fused_dna_eval_kernel(FusedArgs a) {
   static_assert(TR == 16 || TR == 64, "RDAMD_LOAD_TAB's asm spells out the half-table offset of 64-row slots");
   static_assert(kFusedTT == 0 && kFusedRP == 2, "... and the step kinds it skips an operand for");
   // where this lane's entry of a 16-row table (code lane / 4, state lane % 4) goes in LDS: see read_row
-  const unsigned tab_wr = ((lane & 2u) ? 16u * TR : 0u) + (lane >> 2) * 16u + (lane & 1u) * 8u;
+  const unsigned tab_wr = wbase + ((lane & 2u) ? 16u * TR : 0u) + (lane >> 2) * 16u + (lane & 1u) * 8u;
   constexpr unsigned kYSlot = 32u * TR;   // the X / Y table slots sit at LDS bytes 0 and 32 TR
   int site_off[NS];
 #pragma unroll
   for (int q = 0; q < NS; ++q) site_off[q] = (int)site[q] * (TR == 16 ? 1 : 2);
-  double2 *stk = reinterpret_cast<double2 *>(lds + tab_doubles<TR>()) + lane;
-  int *stk_sc = reinterpret_cast<int *>(lds + tab_doubles<TR>() + (size_t)lds_levels * NS * 256) + lane;
+  // LDS: the table slots of all waves first, then each wave's stack
+  const unsigned n_waves = RW ? R : 1u;
+  double *my_stack = lds + n_waves * tab_doubles<TR>() + (size_t)wave * lds_levels * NS * 288;
+  double2 *stk = reinterpret_cast<double2 *>(my_stack) + lane;
+  int *stk_sc = reinterpret_cast<int *>(my_stack + (size_t)lds_levels * NS * 256) + lane;
 
   double term[NS];   // sum_r w_r f_r 2^(-256 (s_r - smin))
   int smin[NS];
 
-  for (unsigned r = 0; r < R; ++r) {
+  for (unsigned r = RW ? wave : 0u; r < (RW ? wave + 1u : R); ++r) {
     LaneState<NS> st;
 #pragma unroll
     for (int q = 0; q < NS; ++q) {
@@ -277,14 +296,14 @@ fused_dna_eval_kernel(FusedArgs a) {
         "s_mov_b32 m0, %[sv]\n"                                                                \
         "3:"                                                                                    \
         : [sv] "=&s"(m0_saved)                                                                  \
-        : [m] "s"((unsigned)(SLOT)), [w] "s"(wide), [vo4] "v"(lane4), [vo16] "v"(lane16), [rs] "s"(tab_desc), \
+        : [m] "s"((unsigned)(SLOT) + wbase), [w] "s"(wide), [vo4] "v"(lane4), [vo16] "v"(lane16), [rs] "s"(tab_desc), \
           [so] "s"(so), [so2] "s"(so - 768), [kind] "s"(uni(op.flags) & 3u)                     \
         : "memory", "scc");                                                                     \
   }
 #define RDAMD_LOAD_TIPS(op, cx, cy, ex, ey)                                                     \
   _Pragma("unroll") for (int q = 0; q < NS; ++q) {                                              \
-    cx[q] = load_code<TR>(tips_rs, site_off[q], (int)uni(op.cX));                               \
-    cy[q] = load_code<TR>(tips_rs, site_off[q], (int)uni(op.cY));                               \
+    cx[q] = load_code<TR>(tips_rs, site_off[q], (int)uni(op.cX)) | wbase;                       \
+    cy[q] = load_code<TR>(tips_rs, site_off[q], (int)uni(op.cY)) | wbase;                       \
   }                                                                                             \
   if (TR > 16) __builtin_amdgcn_s_waitcnt(0xc07f);   /* lgkmcnt(0) */                           \
   RDAMD_LOAD_TAB(op, 0u, 0x2000u, tX, ex, "s_cmp_lg_u32 %[kind], 0")       /* X: tip-tip steps only */ \
@@ -426,7 +445,10 @@ fused_dna_eval_kernel(FusedArgs a) {
       double f = st.v[q][0] * freqs[0] + st.v[q][1] * freqs[1] + st.v[q][2] * freqs[2] +
                  st.v[q][3] * freqs[3];
       f *= w;
-      if (r == 0) {
+      if (RW) {   // (folded below, by wave 0, once all rates have arrived)
+        term[q] = f;
+        smin[q] = st.sc[q];
+      } else if (r == 0) {
         term[q] = f;
         smin[q] = st.sc[q];
       } else if (st.sc[q] >= smin[q]) {
@@ -441,6 +463,36 @@ fused_dna_eval_kernel(FusedArgs a) {
   // (the last step of every rate pass has requested the tables of the padding entry behind
   // the program: no LDS-DMA may still be on its way when the wave gives its LDS back)
   if (TR > 16) __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0)
+  if (RW) {
+    // the rate terms meet in LDS (every wave is done with its tables and stack: the space is
+    // free after the first barrier), then wave 0 alone folds them, rate 0 first, with the
+    // arithmetic of the loop above
+    __syncthreads();
+    double *xf = lds + (size_t)wave * NS * 64 + lane;
+    int *xs = reinterpret_cast<int *>(lds + (size_t)R * NS * 64) + (size_t)wave * NS * 64 + lane;
+#pragma unroll
+    for (int q = 0; q < NS; ++q) {
+      xf[q * 64] = term[q];
+      xs[q * 64] = smin[q];
+    }
+    __syncthreads();
+    if (wave != 0u) return;
+    for (unsigned r = 1; r < R; ++r) {
+      const double *yf = lds + (size_t)r * NS * 64 + lane;
+      const int *ys = reinterpret_cast<const int *>(lds + (size_t)R * NS * 64) + (size_t)r * NS * 64 + lane;
+#pragma unroll
+      for (int q = 0; q < NS; ++q) {
+        const double f = yf[q * 64];
+        const int sc = ys[q * 64];
+        if (sc >= smin[q]) {
+          term[q] += f * pow2_neg256(sc - smin[q]);
+        } else {
+          term[q] = term[q] * pow2_neg256(smin[q] - sc) + f;
+          smin[q] = sc;
+        }
+      }
+    }
+  }
   // One partial sum per 64-SITE BLOCK, whatever the number of sites per lane: a job's value
   // must not depend on the size of the launch it rides in (NS is chosen by that), so a wave
   // with two blocks reduces them separately and the finishing kernel adds the same partials
@@ -572,33 +624,39 @@ hipError_t launch_fused_pmatrix(const FusedArgs &a, const double *d_q, const dou
   return hipGetLastError();
 }
 
-template <int NS, bool TTCHECK, int RL, int TR>
+template <int NS, bool TTCHECK, int RL, int TR, bool RW>
 static hipError_t launch_fused_variant(const FusedArgs &a, unsigned n_jobs, unsigned max_depth, unsigned gx,
                                        hipStream_t stream) {
-  const size_t lds = tab_doubles<TR>() * sizeof(double) +
-                     (size_t)(max_depth ? max_depth : 1) * NS * 64 * (4 * sizeof(double) + sizeof(int));
+  const unsigned n_waves = RW ? a.rate_cats : 1u;
+  const size_t per_wave = tab_doubles<TR>() * sizeof(double) +
+                          (size_t)(max_depth ? max_depth : 1) * NS * 64 * (4 * sizeof(double) + sizeof(int));
+  // (RW: at least the room the rate terms need when they meet: R x NS x 64 x 12 bytes)
+  const size_t lds = std::max<size_t>(per_wave * n_waves, (size_t)n_waves * NS * 64 * 12);
   static size_t lds_allowed = 48 * 1024;
-  if (lds > lds_allowed) {   // deep stacks (very unbalanced 10^3-taxon trees): raise the limit
-    hipError_t e = hipFuncSetAttribute((const void *)fused_dna_eval_kernel<NS, TTCHECK, RL, TR>,
+  if (lds > lds_allowed) {   // deep stacks (very unbalanced 10^3-taxon trees), or R of them: raise the limit
+    hipError_t e = hipFuncSetAttribute((const void *)fused_dna_eval_kernel<NS, TTCHECK, RL, TR, RW>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     lds_allowed = lds;
   }
   static const bool lds_starts_at_zero = [] {   // see the note at the top of the kernel
     hipFuncAttributes attr;
-    return hipFuncGetAttributes(&attr, (const void *)fused_dna_eval_kernel<NS, TTCHECK, RL, TR>) == hipSuccess &&
+    return hipFuncGetAttributes(&attr, (const void *)fused_dna_eval_kernel<NS, TTCHECK, RL, TR, RW>) == hipSuccess &&
            attr.sharedSizeBytes == 0;
   }();
   if (!lds_starts_at_zero) return hipErrorInvalidValue;
-  fused_dna_eval_kernel<NS, TTCHECK, RL, TR><<<dim3(gx, n_jobs), 64, lds, stream>>>(a);
+  fused_dna_eval_kernel<NS, TTCHECK, RL, TR, RW><<<dim3(gx, n_jobs), 64 * n_waves, lds, stream>>>(a);
   return hipGetLastError();
 }
 
 template <int NS, bool TTCHECK, int TR>
 static hipError_t launch_fused_variant_rl(const FusedArgs &a, unsigned n_jobs, unsigned max_depth, unsigned gx,
                                           unsigned reg_levels, hipStream_t stream) {
-  return reg_levels >= 2 ? launch_fused_variant<NS, TTCHECK, 2, TR>(a, n_jobs, max_depth, gx, stream)
-                         : launch_fused_variant<NS, TTCHECK, 1, TR>(a, n_jobs, max_depth, gx, stream);
+  if (a.rates_across_waves)
+    return reg_levels >= 2 ? launch_fused_variant<NS, TTCHECK, 2, TR, true>(a, n_jobs, max_depth, gx, stream)
+                           : launch_fused_variant<NS, TTCHECK, 1, TR, true>(a, n_jobs, max_depth, gx, stream);
+  return reg_levels >= 2 ? launch_fused_variant<NS, TTCHECK, 2, TR, false>(a, n_jobs, max_depth, gx, stream)
+                         : launch_fused_variant<NS, TTCHECK, 1, TR, false>(a, n_jobs, max_depth, gx, stream);
 }
 
 // sites_per_lane: 1 or 2.  Two sites per lane share every scalar operand (P-matrix
@@ -609,8 +667,8 @@ static hipError_t launch_fused_variant_rl(const FusedArgs &a, unsigned n_jobs, u
 // fill the chip with half the waves (evaluate.hip picks).
 // Both variants are queued -- the one on the programs with pseudo-tips and no tip-tip
 // rescale test ([0]), the one on the plain programs with it ([1]) -- each with the LDS and
-// the register stack levels ITS programs need; the one the launch's flag rules out returns
-// at once.
+// the register stack levels ITS programs need; a workgroup of the variant its job does not
+// belong to returns at once.
 template <int NS, int TR>
 static hipError_t launch_fused_eval_ns(const FusedArgs &a, unsigned n_jobs, const unsigned max_depth[2],
                                        unsigned blocks_x, const unsigned reg_levels[2], double *d_out,

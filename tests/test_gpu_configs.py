@@ -165,6 +165,19 @@ def test_c4_full_size_properties_and_8_way_site_blocks(c4_full):
         part.destroy()
     assert np.allclose(fsum / wsum, freqs, rtol=1e-13, atol=0)
     assert np.max(np.abs(total - whole) / np.abs(whole)) < 1e-12
+    # The whole alignment WITH subtree site repeats: its code arena (16-bit entries, 500 tips +
+    # the pseudo-tips' rows, 1 MB each) passes 512 MB, so these launches run with one wave per
+    # rate category (kernels_fused.hip, RW) -- same values as the plain partition's
+    gr = rd.Partition.for_tree(tree, 4, g.sites, 4, attributes=rd.ATTRIB_SITE_REPEATS)
+    util.load_tips(gr, tree, w["seqs"], rd.MAP_NT)
+    gr.set_category_rates(w["rates"])
+    sr = [gr.schedule(*tree.generate_operations(rl)) for rl in rls]
+    assert min(x.stats()["pseudo_tips"] for x in sr) >= 100
+    folded = gr.evaluate_batch(sr, subst, np.tile(freqs, (len(rls), 1)))
+    assert np.max(np.abs(folded - whole) / np.abs(whole)) < 1e-12
+    assert np.array_equal(folded, gr.evaluate_batch(sr, subst, np.tile(freqs, (len(rls), 1))))
+    del sr
+    gr.destroy()
 
 
 def test_c5_full_size_properties_and_2d_grid(c5_full):
