@@ -15,6 +15,7 @@
 #include "clades.hpp"
 #include "common.hpp"
 #include "fused.hpp"
+#include "traversal_compiler.hpp"
 
 struct rdamd_schedule {
   rdamd_partition *part = nullptr;
@@ -28,6 +29,7 @@ struct rdamd_schedule {
   // launch's tables make the pseudo-tips' missing rescale counts matter, fused.hpp)
   rdamd::FusedOp *d_prog_plain = nullptr;     // == d_prog without pseudo-tips
   unsigned n_ops_plain = 0, depth_plain = 0, reg_levels_plain = 1;
+  unsigned lds_pos = 0, lds_pos_plain = 0;    // FusedJob::lds_pos of the two programs
   rdamd::CladeStep *d_steps = nullptr;
   rdamd::CladeGroup *d_groups = nullptr;
   unsigned n_steps = 0, n_groups = 0;
@@ -107,122 +109,6 @@ static hipError_t ensure_workspace(rdamd_partition *p, unsigned n_jobs) {
   return hipSuccess;
 }
 
-// ---- traversal compiler -----------------------------------------------------
-// Input: operations in dependency order, the last one being the root.  Output:
-// the same operations re-ordered so that, at every inner-inner node, the child
-// needing the deeper stack is evaluated first (its result is parked in LDS
-// while the other child runs), plus the flags the kernel interprets.
-struct Compiler {
-  const rdamd_operation_t *ops;
-  unsigned n_ops, tips, sites, tip_stride, rate_cats;
-  unsigned unit = 0;         // bytes between the [rate 0] entries of consecutive matrices
-  bool split_park = false;   // 20-state programs: parking is a step of its own
-  unsigned reg_levels = 1;   // stack levels the kernel keeps in registers (4 states: 1 or 2)
-  std::unordered_map<unsigned, unsigned> producer;   // clv -> op index
-  // pseudo-tips (clades.hpp): clv of a collapsed clade -> row of its class codes in the code
-  // arena; to the compiler such a child is a tip whose table sits in its branch's slot
-  std::unordered_map<unsigned, unsigned> pseudo_row;
-  std::unordered_map<unsigned, unsigned> pseudo_wide;   // ... and, for a 64-row table, its slot among the job's
-  unsigned wide_base = 0;                               // tX of wide slot 0 (behind the 16-row tables)
-  unsigned matvecs = 0;                              // inner children = matrix-vector products per (site, rate)
-  std::vector<unsigned> need;                        // stack slots a subtree needs
-  std::vector<FusedOp> out;
-  unsigned depth = 0, max_depth = 0;
-  bool ok = true;
-
-  bool is_inner(unsigned clv) const { return clv >= tips && !pseudo_row.count(clv); }
-  unsigned row_of(unsigned clv) const { return clv < tips ? clv : pseudo_row.at(clv); }
-
-  unsigned compute_need(unsigned i) {
-    const rdamd_operation_t &o = ops[i];
-    unsigned n1 = 0, n2 = 0;
-    const bool i1 = is_inner(o.child1_clv_index), i2 = is_inner(o.child2_clv_index);
-    if (i1) n1 = compute_need(producer.at(o.child1_clv_index));
-    if (i2) n2 = compute_need(producer.at(o.child2_clv_index));
-    unsigned r;
-    if (i1 && i2) r = std::max(std::max(n1, n2), std::min(n1, n2) + 1);
-    else r = i1 ? n1 : (i2 ? n2 : 0);
-    need[i] = r;
-    return r;
-  }
-
-  // park_mat: the matrix the CURRENTLY running CLV will meet at its parent if it
-  // has to be parked while this subtree is evaluated
-  void emit(unsigned i, bool live, unsigned park_mat) {
-    const rdamd_operation_t &o = ops[i];
-    const bool i1 = is_inner(o.child1_clv_index), i2 = is_inner(o.child2_clv_index);
-    FusedOp f;
-    memset(&f, 0, sizeof(f));
-    unsigned matM = 0, matX = 0, matY = 0, kind = 0, spill = 0, tipX_row = 0, tipY_row = 0;
-    if (!i1 && !i2) {
-      kind = kFusedTT;
-      spill = live ? 1 : 0;
-      tipX_row = row_of(o.child1_clv_index); matX = o.child1_matrix_index;
-      tipY_row = row_of(o.child2_clv_index); matY = o.child2_matrix_index;
-      if (live) {
-        matM = park_mat;              // pre-multiply the parked CLV
-        if (depth == 0) spill |= 2;   // level 0 is a register slot in the kernel
-        else if (depth == 1 && reg_levels >= 2) spill |= 8;   // ... and level 1 in programs compiled for two
-        ++depth;
-        max_depth = std::max(max_depth, depth);
-        if (split_park) {
-          FusedOp park;
-          memset(&park, 0, sizeof(park));
-          park.pM = matM * unit;
-          park.flags = kFusedPark | ((spill & 2) ? 0x200u : 0u);   // 0x200: into the register slot
-          out.push_back(park);
-          matM = 0;
-          spill = 0;
-        }
-      }
-    } else if (i1 != i2) {
-      const bool first_inner = i1;
-      emit(producer.at(first_inner ? o.child1_clv_index : o.child2_clv_index), live, park_mat);
-      kind = kFusedRT;
-      matM = first_inner ? o.child1_matrix_index : o.child2_matrix_index;
-      tipY_row = row_of(first_inner ? o.child2_clv_index : o.child1_clv_index);
-      matY = first_inner ? o.child2_matrix_index : o.child1_matrix_index;
-    } else {
-      const unsigned a = producer.at(o.child1_clv_index), b = producer.at(o.child2_clv_index);
-      const bool a_first = need[a] >= need[b];
-      const unsigned first = a_first ? a : b, second = a_first ? b : a;
-      const unsigned mat_first = a_first ? o.child1_matrix_index : o.child2_matrix_index;
-      emit(first, live, park_mat);    // parked (times mat_first) by the first TT op of `second`
-      emit(second, true, mat_first);
-      kind = kFusedRP;                // running CLV = second; popped = mat_first . first
-      matM = a_first ? o.child2_matrix_index : o.child1_matrix_index;
-      --depth;
-      if (depth == 0) spill |= 4;     // the popped sibling sits in the register slot
-      else if (depth == 1 && reg_levels >= 2) spill |= 16;
-    }
-    matvecs += (i1 ? 1u : 0u) + (i2 ? 1u : 0u);
-    f.pM = matM * unit;
-    f.tX = matX * unit;
-    f.tY = matY * unit;
-    // a leaf whose table has 64 rows: its own slot, flagged for the kernel (0x2000 X, 0x4000 Y)
-    unsigned wide_flags = 0;
-    if (kind == kFusedTT || kind == kFusedRT) {
-      const unsigned leafX = o.child1_clv_index;
-      const unsigned leafY = kind == kFusedTT ? o.child2_clv_index : (i1 ? o.child2_clv_index : o.child1_clv_index);
-      if (kind == kFusedTT && pseudo_wide.count(leafX)) {
-        f.tX = wide_base + pseudo_wide.at(leafX) * rate_cats * 512u;
-        wide_flags |= 0x2000u;
-      }
-      if (pseudo_wide.count(leafY)) {
-        f.tY = wide_base + pseudo_wide.at(leafY) * rate_cats * 512u;
-        wide_flags |= 0x4000u;
-      }
-    }
-    // 20 states: the tip tables' byte offsets ([matrix][rate 0], 12288 B per (matrix, rate))
-    f.pad[0] = matX * rate_cats * (kFused20TabDoubles * 8u);
-    f.pad[1] = matY * rate_cats * (kFused20TabDoubles * 8u);
-    f.cX = tipX_row * tip_stride;
-    f.cY = tipY_row * tip_stride;
-    f.flags = kind | (spill << 8) | wide_flags;   // (a 20-state TT never parks: its spill bits were moved to the park step)
-    out.push_back(f);
-  }
-};
-
 }  // namespace rdamd
 
 using namespace rdamd;
@@ -288,6 +174,7 @@ rdamd_schedule_t *rdamd_schedule_create(rdamd_partition_t *p, const rdamd_operat
   struct Program {
     std::vector<FusedOp> steps;
     unsigned depth = 1, reg_levels = 1, matvecs = 0;
+    unsigned lds_pos = 0;   // 4 states, stacks with private-segment levels: which in-memory entry sits in LDS
   };
   // 64-row tables (and the 16-bit code arena that goes with them) when the partition's class
   // limit asks for them; every program of the schedule then addresses that arena
@@ -310,16 +197,11 @@ rdamd_schedule_t *rdamd_schedule_create(rdamd_partition_t *p, const rdamd_operat
     c.compute_need(c.n_ops - 1);
     c.out.reserve(c.n_ops);
     c.emit(c.n_ops - 1, false, 0);
-    // 4 states: a program that would need three or more LDS stack levels is compiled for
-    // TWO register levels instead (kernels_fused.hip: the LDS saved buys more resident
-    // waves than the 18 extra registers cost)
-    if (!k20 && c.max_depth >= 4) {
-      c.out.clear();
-      c.depth = c.max_depth = 0;
-      c.matvecs = 0;
-      c.reg_levels = 2;
-      c.emit(c.n_ops - 1, false, 0);
-    }
+    // second pass: the register slot to the busiest stack level, the LDS slot to the runner-up
+    // (traversal_compiler.hpp)
+    // (two register levels: from 8 in-memory entries on where the kernel has private-segment
+    // levels, i.e. 64-row table slots; from 3 on an all-LDS stack -- kernels_fused.hip)
+    const unsigned lds_pos = c.place_levels(k20 ? 0u : (wide_mode ? 1u + kFusedSpillLevels : 3u));
     size_t n_real = 0;
     for (const FusedOp &f : c.out)
       if (!c.split_park || (f.flags & 3u) != kFusedPark) ++n_real;
@@ -332,6 +214,7 @@ rdamd_schedule_t *rdamd_schedule_create(rdamd_partition_t *p, const rdamd_operat
     // (20 states: parking steps count as steps)
     out.depth = std::max(1u, c.max_depth > c.reg_levels ? c.max_depth - c.reg_levels : 0);
     out.reg_levels = c.reg_levels;
+    out.lds_pos = lds_pos;
     out.matvecs = c.matvecs;
     out.steps = std::move(c.out);
     return true;
@@ -423,6 +306,7 @@ rdamd_schedule_t *rdamd_schedule_create(rdamd_partition_t *p, const rdamd_operat
   s->depth = main_prog.depth; s->reg_levels = main_prog.reg_levels; s->matvecs = main_prog.matvecs;
   s->n_ops_plain = (unsigned)plain.steps.size();
   s->depth_plain = plain.depth; s->reg_levels_plain = plain.reg_levels; s->matvecs_plain = plain.matvecs;
+  s->lds_pos = main_prog.lds_pos; s->lds_pos_plain = plain.lds_pos;
   s->n_steps = (unsigned)steps.size(); s->n_groups = (unsigned)groups.size(); s->clade_rows = clade_rows;
   s->prog = main_prog.steps;
   auto upload_program = [&](const Program &pr, FusedOp **dst) -> hipError_t {
@@ -555,7 +439,8 @@ static int evaluate_batch_impl(rdamd_partition_t *p, unsigned int n_jobs,
     hj[j].clade_steps = s->d_steps; hj[j].clade_groups = s->d_groups;
     hj[j].n_groups = s->n_groups; hj[j].n_clade_steps = s->n_steps;
     hj[j].depth = hj[j].depth_plain = 0;   // patched below: every block uses the launch-wide depth
-    hj[j].tt_unsafe = 0; hj[j].pad = 0;    // (set again by the P-matrix / clade-table steps of this batch)
+    hj[j].tt_unsafe = 0;                   // (set again by the P-matrix / clade-table steps of this batch)
+    hj[j].lds_pos = s->lds_pos | (s->lds_pos_plain << 16);
     max_depth[0] = std::max(max_depth[0], s->depth);
     max_depth[1] = std::max(max_depth[1], s->depth_plain);
     reg_levels[0] = std::max(reg_levels[0], s->reg_levels);

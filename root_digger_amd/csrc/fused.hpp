@@ -50,7 +50,11 @@ struct FusedJob {
   // runs it on `prog_plain`: every operation of the caller's list, tips only, every rescale
   // exactly where the reference rule puts it.  (Both variants are launched over all jobs; a
   // workgroup of the wrong variant returns at once.)
-  uint32_t tt_unsafe, pad;
+  uint32_t tt_unsafe;
+  // 4 states, stacks with private-segment levels (kernels_fused.hip, SP): which of a program's
+  // in-memory stack entries (counted from the bottom) sits in the one LDS slot -- the host
+  // picks the busiest; bits 0-15 `prog`, bits 16-31 `prog_plain`
+  uint32_t lds_pos;
   // subtree site repeats (clades.hpp); without pseudo-tips prog_plain == prog, n_groups == 0
   const FusedOp    *prog_plain;
   const CladeStep  *clade_steps;
@@ -100,6 +104,11 @@ struct Fused20Args {
   size_t   tiptab_job_stride;        // doubles per job
   unsigned sites, rate_cats, tiles, ncodes;
 };
+// 4 states: in-memory stack entries of a program whose stack lives in one register slot, one
+// LDS slot and the wave's private segment (kernels_fused.hip, SP; the private segment has a
+// slot for every in-memory entry, the LDS one's stays unused); deeper programs take two
+// register levels and all-LDS stacks
+constexpr unsigned kFusedSpillLevels = 7;
 constexpr unsigned kFused20TabCodes = 64;                        // rows per (matrix, rate)
 constexpr unsigned kFused20TabRow = 4 * 6;                       // doubles per code
 constexpr unsigned kFused20TabDoubles = kFused20TabCodes * kFused20TabRow;   // per (matrix, rate)

@@ -25,6 +25,7 @@
 // result differs from the per-site rule only where that rule would already
 // have lost the category to underflow.
 #include <algorithm>
+#include <cstdlib>
 
 #include "common.hpp"
 #include "fused.hpp"
@@ -158,7 +159,78 @@ __device__ __forceinline__ void combine(const double (&tx)[4], const double (&ty
 // (850 MB / 340 MB) no longer fits any cache level, spend their time on exactly those
 // re-reads.  The rate terms meet in LDS and wave 0 folds them in rate order with
 // the loop's own arithmetic: the same bits as the one-wave form.
-template <int NS, bool TTCHECK, int RL, int TR, bool RW>
+// Stack entries of the SP > 0 kernels: in-memory entry `sp` (counted from the bottom) lives in
+// the wave's one LDS slot if it is entry `lds_pos` (FusedJob::lds_pos), in the wave's private
+// segment otherwise.  The choice is a scalar branch INSIDE one asm
+// statement, both sides writing the same registers: as an `if` in the source the two-sites
+// kernel grows from 124 to 146-164 VGPRs (register copies where the paths join) and loses
+// the fourth wave per SIMD that the whole exercise is about.  The compiler does not count
+// these memory instructions: its own counted waits only get stricter by them, and the pop
+// waits for its data itself.
+typedef double f64x2_t __attribute__((ext_vector_type(2)));
+template <int NS>
+__device__ __forceinline__ void stack_push(unsigned sp, unsigned lds_pos, int q, unsigned stk_lds,
+                                           unsigned stksc_lds, unsigned spill_off, const double (&v)[4], int sc) {
+  const f64x2_t lo = {v[0], v[1]}, hi = {v[2], v[3]};
+  const unsigned la = stk_lds + q * 2048u, lsc = stksc_lds + q * 256u;
+  sp = uni(sp);   // (wave-uniform by construction; not every variant's compiler pass sees it)
+  const unsigned so = spill_off + (sp * NS + q) * 48u;
+  asm volatile(
+      "s_cmp_eq_u32 %[sp], %[cap]\n\t"
+      "s_cbranch_scc1 1f\n\t"
+      "scratch_store_dwordx4 off, %[lo], %[so]\n\t"
+      "scratch_store_dwordx4 off, %[hi], %[so] offset:16\n\t"
+      "scratch_store_dword off, %[sc], %[so] offset:32\n\t"
+      "s_branch 2f\n"
+      "1:\n\t"
+      "ds_write_b128 %[la], %[lo]\n\t"
+      "ds_write_b128 %[la], %[hi] offset:1024\n\t"
+      "ds_write_b32 %[lsc], %[sc]\n"
+      "2:\n\t"
+      "s_nop 0"   /* (a VALU write to 16-byte store data needs one wait state behind the store) */
+      :
+      : [sp] "s"(sp), [cap] "s"(lds_pos), [lo] "v"(lo), [hi] "v"(hi), [sc] "v"(sc), [so] "s"(so),
+        [la] "v"(la), [lsc] "v"(lsc)
+      : "memory", "scc");
+}
+template <int NS>
+__device__ __forceinline__ void stack_pop(unsigned sp, unsigned lds_pos, int q, unsigned stk_lds,
+                                          unsigned stksc_lds, unsigned spill_off, double (&v)[4], int &sc) {
+  f64x2_t lo, hi;
+  const unsigned la = stk_lds + q * 2048u, lsc = stksc_lds + q * 256u;
+  sp = uni(sp);   // (wave-uniform by construction; not every variant's compiler pass sees it)
+  const unsigned so = spill_off + (sp * NS + q) * 48u;
+  asm volatile(
+      "s_cmp_eq_u32 %[sp], %[cap]\n\t"
+      "s_cbranch_scc1 1f\n\t"
+      "scratch_load_dwordx4 %[lo], off, %[so]\n\t"
+      "scratch_load_dwordx4 %[hi], off, %[so] offset:16\n\t"
+      "scratch_load_dword %[sc], off, %[so] offset:32\n\t"
+      "s_waitcnt vmcnt(0)\n\t"
+      "s_branch 2f\n"
+      "1:\n\t"
+      "ds_read_b128 %[lo], %[la]\n\t"
+      "ds_read_b128 %[hi], %[la] offset:1024\n\t"
+      "ds_read_b32 %[sc], %[lsc]\n\t"
+      "s_waitcnt lgkmcnt(0)\n"
+      "2:"
+      : [lo] "=&v"(lo), [hi] "=&v"(hi), [sc] "=&v"(sc)
+      : [sp] "s"(sp), [cap] "s"(lds_pos), [so] "s"(so), [la] "v"(la), [lsc] "v"(lsc)
+      : "memory", "scc");
+  v[0] = lo.x; v[1] = lo.y; v[2] = hi.x; v[3] = hi.y;
+}
+
+// SP ("spill levels"): the LDS stack is what limits the resident waves once a program needs
+// two levels of it (13.2 KB per two-sites wave: 12 waves per CU instead of 16 -- and with
+// every wave waiting on its own dependent chain, throughput follows the wave count: c5 and
+// 125.phy measured +22 % with the second level simply taken away).  With SP > 0 a wave keeps
+// ONE stack entry in LDS and has a slot for each of its up to SP in-memory entries in its
+// PRIVATE segment (scratch: memory the hardware hands out per wave slot, so the same few MB
+// serve every wave that passes through and stay in L2): a park there is three stores, the pop
+// three loads whose latency the other waves cover.  Which entries are the busy ones the host
+// knows (evaluate.hip counts the parks per level): the busiest level gets the register slot,
+// the runner-up the LDS slot (FusedJob::lds_pos), the private segment the quiet rest.
+template <int NS, bool TTCHECK, int RL, int TR, bool RW, int SP>
 __global__ void __launch_bounds__(RW ? 512 : 64)
 fused_dna_eval_kernel(FusedArgs a) {
   extern __shared__ double lds[];
@@ -198,7 +270,9 @@ fused_dna_eval_kernel(FusedArgs a) {
   const FusedJob jb = load_const(a.jobs + job);
   const FusedOp *__restrict__ prog = TTCHECK ? jb.prog_plain : jb.prog;   // n_ops + 4 entries (tail padded)
   const unsigned nops = TTCHECK ? jb.n_ops_plain : jb.n_ops;
-  const unsigned lds_levels = TTCHECK ? jb.depth_plain : jb.depth;
+  const unsigned job_levels = TTCHECK ? jb.depth_plain : jb.depth;
+  const unsigned lds_levels = SP > 0 ? (job_levels < 1u ? job_levels : 1u) : job_levels;
+  const unsigned lds_pos = uni(TTCHECK ? jb.lds_pos >> 16 : jb.lds_pos & 0xffffu);
   const const_as<char> pm = to_const(reinterpret_cast<const char *>(a.pmat + (size_t)job * a.pmat_job_stride));
   const const_as<double> freqs = to_const(a.freqs + (size_t)job * 4);
   const const_as<double> rw = to_const(a.rate_weights + (size_t)job * R);
@@ -231,6 +305,12 @@ fused_dna_eval_kernel(FusedArgs a) {
   double *my_stack = lds + n_waves * tab_doubles<TR>() + (size_t)wave * lds_levels * NS * 288;
   double2 *stk = reinterpret_cast<double2 *>(my_stack) + lane;
   int *stk_sc = reinterpret_cast<int *>(my_stack + (size_t)lds_levels * NS * 256) + lane;
+  // SP > 0: LDS byte addresses of this lane's stack entries and the private-segment offset of
+  // the deep levels, for stack_push / stack_pop (the array is only ever touched by their
+  // scratch instructions; handing its address to them keeps it allocated)
+  const unsigned stk_lds = (unsigned)(size_t)stk, stksc_lds = (unsigned)(size_t)stk_sc;
+  char spill_mem[SP > 0 ? SP * NS * 48 : 4] __attribute__((aligned(16)));
+  const unsigned spill_off = SP > 0 ? uni((unsigned)(size_t)(__attribute__((address_space(5))) char *)spill_mem) : 0u;
 
   double term[NS];   // sum_r w_r f_r 2^(-256 (s_r - smin))
   int smin[NS];
@@ -354,10 +434,14 @@ fused_dna_eval_kernel(FusedArgs a) {
           _Pragma("unroll") for (int q = 0; q < NS; ++q) {                                      \
             double tp[4];                                                                       \
             matvec(M, st.v[q], tp);                                                             \
-            double2 *d = stk + (size_t)(sp * NS + q) * 128;                                     \
-            d[0] = make_double2(tp[0], tp[1]);                                                  \
-            d[64] = make_double2(tp[2], tp[3]);                                                 \
-            stk_sc[(sp * NS + q) * 64] = st.sc[q];                                              \
+            if (SP > 0) {                                                                       \
+              stack_push<NS>(sp, lds_pos, q, stk_lds, stksc_lds, spill_off, tp, st.sc[q]);      \
+            } else {                                                                            \
+              double2 *d = stk + (size_t)(sp * NS + q) * 128;                                   \
+              d[0] = make_double2(tp[0], tp[1]);                                                \
+              d[64] = make_double2(tp[2], tp[3]);                                               \
+              stk_sc[(sp * NS + q) * 64] = st.sc[q];                                            \
+            }                                                                                   \
           }                                                                                     \
           ++sp;                                                                                 \
         }                                                                                       \
@@ -391,10 +475,14 @@ fused_dna_eval_kernel(FusedArgs a) {
         int scy[NS];                                                                            \
         --sp;                                                                                   \
         _Pragma("unroll") for (int q = 0; q < NS; ++q) {                                        \
-          const double2 *d = stk + (size_t)(sp * NS + q) * 128;                                 \
-          const double2 lo = d[0], hi = d[64];                                                  \
-          ty[q][0] = lo.x; ty[q][1] = lo.y; ty[q][2] = hi.x; ty[q][3] = hi.y;                   \
-          scy[q] = stk_sc[(sp * NS + q) * 64];                                                  \
+          if (SP > 0) {                                                                         \
+            stack_pop<NS>(sp, lds_pos, q, stk_lds, stksc_lds, spill_off, ty[q], scy[q]);        \
+          } else {                                                                              \
+            const double2 *d = stk + (size_t)(sp * NS + q) * 128;                               \
+            const double2 lo = d[0], hi = d[64];                                                \
+            ty[q][0] = lo.x; ty[q][1] = lo.y; ty[q][2] = hi.x; ty[q][3] = hi.y;                 \
+            scy[q] = stk_sc[(sp * NS + q) * 64];                                                \
+          }                                                                                     \
         }                                                                                       \
         RDAMD_LOAD_TIPS(nxt, ncx, ncy, nex, ney) RDAMD_LATE_DESC(cur, idx2)                     \
         _Pragma("unroll") for (int q = 0; q < NS; ++q) matvec(M, st.v[q], tx[q]);               \
@@ -624,39 +712,53 @@ hipError_t launch_fused_pmatrix(const FusedArgs &a, const double *d_q, const dou
   return hipGetLastError();
 }
 
-template <int NS, bool TTCHECK, int RL, int TR, bool RW>
+template <int NS, bool TTCHECK, int RL, int TR, bool RW, int SP>
 static hipError_t launch_fused_variant(const FusedArgs &a, unsigned n_jobs, unsigned max_depth, unsigned gx,
                                        hipStream_t stream) {
   const unsigned n_waves = RW ? a.rate_cats : 1u;
   const size_t per_wave = tab_doubles<TR>() * sizeof(double) +
-                          (size_t)(max_depth ? max_depth : 1) * NS * 64 * (4 * sizeof(double) + sizeof(int));
+                          (size_t)(SP > 0 || !max_depth ? 1 : max_depth) * NS * 64 * (4 * sizeof(double) + sizeof(int));
   // (RW: at least the room the rate terms need when they meet: R x NS x 64 x 12 bytes)
   const size_t lds = std::max<size_t>(per_wave * n_waves, (size_t)n_waves * NS * 64 * 12);
   static size_t lds_allowed = 48 * 1024;
   if (lds > lds_allowed) {   // deep stacks (very unbalanced 10^3-taxon trees), or R of them: raise the limit
-    hipError_t e = hipFuncSetAttribute((const void *)fused_dna_eval_kernel<NS, TTCHECK, RL, TR, RW>,
+    hipError_t e = hipFuncSetAttribute((const void *)fused_dna_eval_kernel<NS, TTCHECK, RL, TR, RW, SP>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     lds_allowed = lds;
   }
   static const bool lds_starts_at_zero = [] {   // see the note at the top of the kernel
     hipFuncAttributes attr;
-    return hipFuncGetAttributes(&attr, (const void *)fused_dna_eval_kernel<NS, TTCHECK, RL, TR, RW>) == hipSuccess &&
+    return hipFuncGetAttributes(&attr, (const void *)fused_dna_eval_kernel<NS, TTCHECK, RL, TR, RW, SP>) == hipSuccess &&
            attr.sharedSizeBytes == 0;
   }();
   if (!lds_starts_at_zero) return hipErrorInvalidValue;
-  fused_dna_eval_kernel<NS, TTCHECK, RL, TR, RW><<<dim3(gx, n_jobs), 64 * n_waves, lds, stream>>>(a);
+  fused_dna_eval_kernel<NS, TTCHECK, RL, TR, RW, SP><<<dim3(gx, n_jobs), 64 * n_waves, lds, stream>>>(a);
   return hipGetLastError();
 }
 
 template <int NS, bool TTCHECK, int TR>
 static hipError_t launch_fused_variant_rl(const FusedArgs &a, unsigned n_jobs, unsigned max_depth, unsigned gx,
                                           unsigned reg_levels, hipStream_t stream) {
-  if (a.rates_across_waves)
-    return reg_levels >= 2 ? launch_fused_variant<NS, TTCHECK, 2, TR, true>(a, n_jobs, max_depth, gx, stream)
-                           : launch_fused_variant<NS, TTCHECK, 1, TR, true>(a, n_jobs, max_depth, gx, stream);
-  return reg_levels >= 2 ? launch_fused_variant<NS, TTCHECK, 2, TR, false>(a, n_jobs, max_depth, gx, stream)
-                         : launch_fused_variant<NS, TTCHECK, 1, TR, false>(a, n_jobs, max_depth, gx, stream);
+  // two or more stack levels behind the register one: one in LDS, the rest in the private segment
+  // -- for the kernels with 64-row table slots.  Their steps wait for table DMAs and want the
+  // waves; the 16-row kernels (partitions without site repeats) prefetch through registers, are
+  // bound by instruction issue at 12 waves per CU already and only pay for the asm-fenced stack
+  // accesses: c2 without repeats 47.5k evaluations/s on two LDS levels, 41.3k this way.
+#ifdef RDAMD_ABLATION   // A/B runs only: RDAMD_FUSED_SPILL_MIN = smallest in-memory depth that takes the SP kernels
+  static const unsigned spill_min = getenv("RDAMD_FUSED_SPILL_MIN") ? (unsigned)atoi(getenv("RDAMD_FUSED_SPILL_MIN")) : 2u;
+#else
+  constexpr unsigned spill_min = 2u;
+#endif
+  const bool spill = TR > 16 && reg_levels < 2 && max_depth >= spill_min && max_depth <= kFusedSpillLevels;
+  if (a.rates_across_waves) {
+    if (spill) return launch_fused_variant<NS, TTCHECK, 1, TR, true, kFusedSpillLevels>(a, n_jobs, max_depth, gx, stream);
+    return reg_levels >= 2 ? launch_fused_variant<NS, TTCHECK, 2, TR, true, 0>(a, n_jobs, max_depth, gx, stream)
+                           : launch_fused_variant<NS, TTCHECK, 1, TR, true, 0>(a, n_jobs, max_depth, gx, stream);
+  }
+  if (spill) return launch_fused_variant<NS, TTCHECK, 1, TR, false, kFusedSpillLevels>(a, n_jobs, max_depth, gx, stream);
+  return reg_levels >= 2 ? launch_fused_variant<NS, TTCHECK, 2, TR, false, 0>(a, n_jobs, max_depth, gx, stream)
+                         : launch_fused_variant<NS, TTCHECK, 1, TR, false, 0>(a, n_jobs, max_depth, gx, stream);
 }
 
 // sites_per_lane: 1 or 2.  Two sites per lane share every scalar operand (P-matrix

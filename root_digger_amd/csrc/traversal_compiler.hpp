@@ -1,0 +1,175 @@
+// The traversal compiler of the fused evaluators (pure host code: no HIP call, no device
+// memory -- tests/cpp/host_logic_check.cpp runs it on the CPU and replays its programs
+// symbolically).  rdamd_schedule_create (evaluate.hip) is its only caller in the library.
+#pragma once
+
+#include <algorithm>
+#include <cstring>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/root_digger_amd.h"
+#include "fused.hpp"
+
+namespace rdamd {
+
+// ---- traversal compiler -----------------------------------------------------
+// Input: operations in dependency order, the last one being the root.  Output:
+// the same operations re-ordered so that, at every inner-inner node, the child
+// needing the deeper stack is evaluated first (its result is parked in LDS
+// while the other child runs), plus the flags the kernel interprets.
+struct Compiler {
+  const rdamd_operation_t *ops;
+  unsigned n_ops, tips, sites, tip_stride, rate_cats;
+  unsigned unit = 0;         // bytes between the [rate 0] entries of consecutive matrices
+  bool split_park = false;   // 20-state programs: parking is a step of its own
+  unsigned reg_levels = 1;   // stack levels the kernel keeps in registers (4 states: 1 or 2)
+  unsigned reg_level = 0;    // reg_levels == 1: WHICH level that is (the busiest one, see the callers)
+  std::unordered_map<unsigned, unsigned> producer;   // clv -> op index
+  // pseudo-tips (clades.hpp): clv of a collapsed clade -> row of its class codes in the code
+  // arena; to the compiler such a child is a tip whose table sits in its branch's slot
+  std::unordered_map<unsigned, unsigned> pseudo_row;
+  std::unordered_map<unsigned, unsigned> pseudo_wide;   // ... and, for a 64-row table, its slot among the job's
+  unsigned wide_base = 0;                               // tX of wide slot 0 (behind the 16-row tables)
+  unsigned matvecs = 0;                              // inner children = matrix-vector products per (site, rate)
+  std::vector<unsigned> need;                        // stack slots a subtree needs
+  std::vector<FusedOp> out;
+  unsigned depth = 0, max_depth = 0;
+  unsigned parks_at[16] = {0};   // parks by stack level (0 = the first level, a register slot)
+  bool ok = true;
+
+  bool is_inner(unsigned clv) const { return clv >= tips && !pseudo_row.count(clv); }
+  unsigned row_of(unsigned clv) const { return clv < tips ? clv : pseudo_row.at(clv); }
+
+  unsigned compute_need(unsigned i) {
+    const rdamd_operation_t &o = ops[i];
+    unsigned n1 = 0, n2 = 0;
+    const bool i1 = is_inner(o.child1_clv_index), i2 = is_inner(o.child2_clv_index);
+    if (i1) n1 = compute_need(producer.at(o.child1_clv_index));
+    if (i2) n2 = compute_need(producer.at(o.child2_clv_index));
+    unsigned r;
+    if (i1 && i2) r = std::max(std::max(n1, n2), std::min(n1, n2) + 1);
+    else r = i1 ? n1 : (i2 ? n2 : 0);
+    need[i] = r;
+    return r;
+  }
+
+  // park_mat: the matrix the CURRENTLY running CLV will meet at its parent if it
+  // has to be parked while this subtree is evaluated
+  void emit(unsigned i, bool live, unsigned park_mat) {
+    const rdamd_operation_t &o = ops[i];
+    const bool i1 = is_inner(o.child1_clv_index), i2 = is_inner(o.child2_clv_index);
+    FusedOp f;
+    memset(&f, 0, sizeof(f));
+    unsigned matM = 0, matX = 0, matY = 0, kind = 0, spill = 0, tipX_row = 0, tipY_row = 0;
+    if (!i1 && !i2) {
+      kind = kFusedTT;
+      spill = live ? 1 : 0;
+      tipX_row = row_of(o.child1_clv_index); matX = o.child1_matrix_index;
+      tipY_row = row_of(o.child2_clv_index); matY = o.child2_matrix_index;
+      if (live) {
+        matM = park_mat;              // pre-multiply the parked CLV
+        if (reg_levels >= 2) {        // levels 0 and 1 are register slots in the kernel
+          if (depth == 0) spill |= 2;
+          else if (depth == 1) spill |= 8;
+        } else if (depth == reg_level) {
+          spill |= 2;                 // the one register slot
+        }
+        ++parks_at[depth < 15 ? depth : 15];
+        ++depth;
+        max_depth = std::max(max_depth, depth);
+        if (split_park) {
+          FusedOp park;
+          memset(&park, 0, sizeof(park));
+          park.pM = matM * unit;
+          park.flags = kFusedPark | ((spill & 2) ? 0x200u : 0u);   // 0x200: into the register slot
+          out.push_back(park);
+          matM = 0;
+          spill = 0;
+        }
+      }
+    } else if (i1 != i2) {
+      const bool first_inner = i1;
+      emit(producer.at(first_inner ? o.child1_clv_index : o.child2_clv_index), live, park_mat);
+      kind = kFusedRT;
+      matM = first_inner ? o.child1_matrix_index : o.child2_matrix_index;
+      tipY_row = row_of(first_inner ? o.child2_clv_index : o.child1_clv_index);
+      matY = first_inner ? o.child2_matrix_index : o.child1_matrix_index;
+    } else {
+      const unsigned a = producer.at(o.child1_clv_index), b = producer.at(o.child2_clv_index);
+      const bool a_first = need[a] >= need[b];
+      const unsigned first = a_first ? a : b, second = a_first ? b : a;
+      const unsigned mat_first = a_first ? o.child1_matrix_index : o.child2_matrix_index;
+      emit(first, live, park_mat);    // parked (times mat_first) by the first TT op of `second`
+      emit(second, true, mat_first);
+      kind = kFusedRP;                // running CLV = second; popped = mat_first . first
+      matM = a_first ? o.child2_matrix_index : o.child1_matrix_index;
+      --depth;
+      if (reg_levels >= 2) {
+        if (depth == 0) spill |= 4;   // the popped sibling sits in a register slot
+        else if (depth == 1) spill |= 16;
+      } else if (depth == reg_level) {
+        spill |= 4;
+      }
+    }
+    matvecs += (i1 ? 1u : 0u) + (i2 ? 1u : 0u);
+    f.pM = matM * unit;
+    f.tX = matX * unit;
+    f.tY = matY * unit;
+    // a leaf whose table has 64 rows: its own slot, flagged for the kernel (0x2000 X, 0x4000 Y)
+    unsigned wide_flags = 0;
+    if (kind == kFusedTT || kind == kFusedRT) {
+      const unsigned leafX = o.child1_clv_index;
+      const unsigned leafY = kind == kFusedTT ? o.child2_clv_index : (i1 ? o.child2_clv_index : o.child1_clv_index);
+      if (kind == kFusedTT && pseudo_wide.count(leafX)) {
+        f.tX = wide_base + pseudo_wide.at(leafX) * rate_cats * 512u;
+        wide_flags |= 0x2000u;
+      }
+      if (pseudo_wide.count(leafY)) {
+        f.tY = wide_base + pseudo_wide.at(leafY) * rate_cats * 512u;
+        wide_flags |= 0x4000u;
+      }
+    }
+    // 20 states: the tip tables' byte offsets ([matrix][rate 0], 12288 B per (matrix, rate))
+    f.pad[0] = matX * rate_cats * (kFused20TabDoubles * 8u);
+    f.pad[1] = matY * rate_cats * (kFused20TabDoubles * 8u);
+    f.cX = tipX_row * tip_stride;
+    f.cY = tipY_row * tip_stride;
+    f.flags = kind | (spill << 8) | wide_flags;   // (a 20-state TT never parks: its spill bits were moved to the park step)
+    out.push_back(f);
+  }
+  // Second pass: which level gets the register slot.  The first pass (emit) counted the parks
+  // per level, and in a big tree the BOTTOM of the stack is the quiet end (an entry parked near
+  // the root waits for half the traversal; the churn is two or three levels up: c5's plain
+  // programs park 24 / 79 / 112 / 36 times on levels 0 - 3), so the slot goes to the busiest
+  // level, and -- 4 states -- the one LDS slot of the kernels with private-segment levels
+  // (kernels_fused.hip, SP) to the runner-up.  What is parked in memory is a sub-sequence of a
+  // stack, i.e. a stack: the kernel's count of in-memory entries addresses it whichever level
+  // sits in the register.  4 states (`two_reg_beyond` > 0): a program with more levels than
+  // that is compiled for TWO register levels (0 and 1) and an all-LDS stack instead (the
+  // caller passes 1 + kFusedSpillLevels -- a balanced tree of more than 256 taxa -- for the
+  // kernels that have private-segment levels, 3 for those that do not).
+  // Returns the rank of the LDS level among the in-memory levels (FusedJob::lds_pos).
+  unsigned place_levels(unsigned two_reg_beyond) {
+    const bool two_reg = two_reg_beyond > 0 && max_depth > two_reg_beyond;
+    if (!two_reg && max_depth < 2) return 0;
+    unsigned busiest = 0;
+    for (unsigned l = 1; l < max_depth && l < 16; ++l)
+      if (parks_at[l] > parks_at[busiest]) busiest = l;
+    unsigned second = busiest == 0 ? 1 : 0;
+    for (unsigned l = 0; l < max_depth && l < 16; ++l)
+      if (l != busiest && parks_at[l] > parks_at[second]) second = l;
+    if (two_reg || busiest != 0) {
+      out.clear();
+      depth = max_depth = 0;
+      matvecs = 0;
+      memset(parks_at, 0, sizeof parks_at);
+      if (two_reg) reg_levels = 2;
+      else reg_level = busiest;
+      emit(n_ops - 1, false, 0);
+    }
+    return two_reg ? 0u : second - (second > busiest ? 1u : 0u);
+  }
+};
+
+}  // namespace rdamd

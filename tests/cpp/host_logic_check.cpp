@@ -1,8 +1,13 @@
-// CPU check of two pieces of pure host logic added in round 3 (no HIP, no GPU):
+// CPU check of three pieces of pure host logic added in round 3 (no HIP, no GPU):
 //   * clade_classes (csrc/clade_classes.hpp): the pattern classes of a subtree -- what decides
 //     which clades the fused evaluator folds into look-up tables -- against a brute-force count;
 //   * k20_split (csrc/k20_split.hpp): cutting a post-order operation list into independent
 //     subtree pieces -- against the properties the 20-state traversal kernel relies on.
+//   * the traversal compiler (csrc/traversal_compiler.hpp): its programs -- step order, which
+//     stack level sits in the register slot(s), which in-memory entry in the LDS slot -- replayed
+//     symbolically: the running value at the end must be the root's CLV expression, every pop
+//     must meet the sibling that was parked for it, for 4-state (one / two register levels,
+//     pseudo-tips) and 20-state (parking as a step of its own) programs.
 // prints "host logic OK <cases>" on success.
 #include <cstdio>
 #include <cstdlib>
@@ -13,6 +18,7 @@
 
 #include "clade_classes.hpp"
 #include "k20_split.hpp"
+#include "traversal_compiler.hpp"
 
 static int fail(const char *what, int a = 0, int b = 0) {
   std::printf("FAILED: %s (%d, %d)\n", what, a, b);
@@ -64,9 +70,148 @@ static std::vector<rdamd_operation_t> random_postorder(unsigned n, std::mt19937 
   return ops;
 }
 
+// ---- symbolic replay of a compiled program ---------------------------------------------------
+// A CLV expression is a 64-bit hash: tip(row, table) for a table look-up, mv(matrix, x) for a
+// matrix-vector product, x * y (commutative) for the element product.
+static uint64_t mix(uint64_t a, uint64_t b) {
+  a ^= b + 0x9e3779b97f4a7c15ull + (a << 6) + (a >> 2);
+  a *= 0xff51afd7ed558ccdull;
+  return a ^ (a >> 33);
+}
+static uint64_t h_tip(unsigned row, unsigned tab) { return mix(mix(1, row), tab); }
+static uint64_t h_mv(unsigned mat, uint64_t x) { return mix(mix(2, mat), x); }
+static uint64_t h_mul(uint64_t x, uint64_t y) { return mix(3, x < y ? mix(x, y) : mix(y, x)); }
+
+// what the operation list says the root CLV is, in the terms the program uses (byte offsets)
+static uint64_t expected(const rdamd::Compiler &c, const std::vector<rdamd_operation_t> &ops, unsigned i) {
+  const rdamd_operation_t &o = ops[i];
+  auto term = [&](unsigned clv, unsigned mat) -> uint64_t {
+    if (!c.is_inner(clv)) {
+      const unsigned tab = c.pseudo_wide.count(clv) ? c.wide_base + c.pseudo_wide.at(clv) * c.rate_cats * 512u
+                                                    : mat * c.unit;
+      return h_tip(c.row_of(clv) * c.tip_stride, tab);
+    }
+    return h_mv(mat * c.unit, expected(c, ops, c.producer.at(clv)));
+  };
+  return h_mul(term(o.child1_clv_index, o.child1_matrix_index), term(o.child2_clv_index, o.child2_matrix_index));
+}
+
+// runs the program the way the kernels do (kernels_fused.hip / kernels_fused_k20.hip): one or
+// two register slots, the other entries on a stack addressed by the count of entries in it
+static int replay(const rdamd::Compiler &c, unsigned lds_pos, uint64_t want, unsigned &mem_depth) {
+  using namespace rdamd;
+  uint64_t run = 0, s0 = 0, s1 = 0;
+  bool s0_full = false, s1_full = false;
+  std::vector<uint64_t> mem;
+  mem_depth = 0;
+  for (size_t i = 0; i < c.out.size(); ++i) {
+    const FusedOp &f = c.out[i];
+    const unsigned kind = f.flags & 3u;
+    auto park = [&](uint64_t v) -> int {
+      if (f.flags & 0x200u) { if (s0_full) return 1; s0 = v; s0_full = true; }
+      else if (f.flags & 0x800u) { if (s1_full || c.reg_levels < 2) return 1; s1 = v; s1_full = true; }
+      else { mem.push_back(v); mem_depth = std::max(mem_depth, (unsigned)mem.size()); }
+      return 0;
+    };
+    if (kind == kFusedPark) {
+      if (!c.split_park) return fail("a park step in a 4-state program", (int)i);
+      if (park(h_mv(f.pM, run))) return fail("park into an occupied register slot", (int)i);
+    } else if (kind == kFusedTT) {
+      if (f.flags & 0x100u) {
+        if (c.split_park) return fail("a 20-state tip-tip step must not park", (int)i);
+        if (park(h_mv(f.pM, run))) return fail("park into an occupied register slot", (int)i);
+      }
+      run = h_mul(h_tip(f.cX, f.tX), h_tip(f.cY, f.tY));
+    } else if (kind == kFusedRT) {
+      run = h_mul(h_mv(f.pM, run), h_tip(f.cY, f.tY));
+    } else {   // kFusedRP
+      uint64_t sib;
+      if (f.flags & 0x400u) { if (!s0_full) return fail("pop from an empty register slot", (int)i); sib = s0; s0_full = false; }
+      else if (f.flags & 0x1000u) { if (!s1_full) return fail("pop from an empty register slot 1", (int)i); sib = s1; s1_full = false; }
+      else { if (mem.empty()) return fail("pop from an empty stack", (int)i); sib = mem.back(); mem.pop_back(); }
+      run = h_mul(h_mv(f.pM, run), sib);
+    }
+  }
+  if (s0_full || s1_full || !mem.empty()) return fail("entries left on the stack");
+  if (run != want) return fail("the program does not compute the root CLV");
+  if (mem_depth >= 2 && c.reg_levels == 1 && lds_pos >= mem_depth) return fail("lds_pos out of range", (int)lds_pos, (int)mem_depth);
+  return 0;
+}
+
+static int check_compiler(std::mt19937 &rng, int &cases) {
+  for (int rep = 0; rep < 600; ++rep) {
+    const bool k20 = rep % 3 == 2;
+    // shapes: random joins (deep, unbalanced), balanced (deepest stacks), caterpillar (depth 1)
+    unsigned n = 3 + rng() % (rep % 10 == 0 ? 1500 : 300);
+    std::vector<rdamd_operation_t> ops = random_postorder(n, rng);
+    if (rep % 5 == 1) {   // perfectly balanced: pair up level by level
+      n = 1u << (2 + rng() % 9);
+      ops.clear();
+      std::vector<unsigned> level(n);
+      for (unsigned i = 0; i < n; ++i) level[i] = i;
+      unsigned next_clv = n, next_mat = 0;
+      while (level.size() > 1) {
+        std::vector<unsigned> up;
+        for (size_t i = 0; i + 1 < level.size(); i += 2) {
+          rdamd_operation_t o;
+          o.parent_clv_index = next_clv; o.parent_scaler_index = -1;
+          o.child1_clv_index = level[i]; o.child1_matrix_index = next_mat++; o.child1_scaler_index = -1;
+          o.child2_clv_index = level[i + 1]; o.child2_matrix_index = next_mat++; o.child2_scaler_index = -1;
+          ops.push_back(o);
+          up.push_back(next_clv++);
+        }
+        level.swap(up);
+      }
+    }
+    rdamd::Compiler c;
+    c.ops = ops.data(); c.n_ops = (unsigned)ops.size(); c.tips = n; c.sites = 1000;
+    c.tip_stride = k20 ? 1000 : 2000; c.rate_cats = 4;
+    c.unit = c.rate_cats * (k20 ? 3200u : 128u);
+    c.split_park = k20;
+    c.wide_base = 8u * (2 * n) * c.rate_cats * 16u;
+    for (unsigned i = 0; i < c.n_ops; ++i) c.producer[ops[i].parent_clv_index] = i;
+    if (!k20 && rep % 2 == 0) {   // some inner nodes become pseudo-tips (their subtrees leave the program)
+      unsigned rows = n, wide = 0;
+      for (unsigned i = 0; i + 1 < c.n_ops; ++i)
+        if (rng() % 6 == 0) {
+          c.pseudo_row[ops[i].parent_clv_index] = rows++;
+          if (rng() % 2) c.pseudo_wide[ops[i].parent_clv_index] = wide++;
+        }
+    }
+    c.need.assign(c.n_ops, 0);
+    c.compute_need(c.n_ops - 1);
+    c.emit(c.n_ops - 1, false, 0);
+    const unsigned first_pass_depth = c.max_depth;
+    unsigned parks = 0;
+    for (unsigned l = 0; l < 16; ++l) parks += c.parks_at[l];
+    // (the two thresholds rdamd_schedule_create uses: kernels with / without private-segment levels)
+    const unsigned beyond = k20 ? 0u : (rep % 4 < 2 ? 1u + rdamd::kFusedSpillLevels : 3u);
+    const unsigned lds_pos = c.place_levels(beyond);
+    if (c.max_depth != first_pass_depth) return fail("the second pass changed the stack depth");
+    unsigned parks2 = 0, busiest = 0;
+    for (unsigned l = 0; l < 16; ++l) { parks2 += c.parks_at[l]; busiest = std::max(busiest, c.parks_at[l]); }
+    if (parks2 != parks) return fail("the second pass changed the number of parks");
+    if (c.reg_levels == 1 && c.max_depth >= 1 && c.parks_at[c.reg_level] != busiest)
+      return fail("the register slot is not on the busiest level", (int)c.reg_level);
+    if (k20 && c.reg_levels != 1) return fail("20-state programs have one register level");
+    if (!k20 && (c.reg_levels == 2) != (c.max_depth > beyond)) return fail("two register levels", (int)c.max_depth);
+    unsigned mem_depth = 0;
+    if (replay(c, lds_pos, expected(c, ops, c.n_ops - 1), mem_depth)) return 1;
+    if (mem_depth != (c.max_depth > c.reg_levels ? c.max_depth - c.reg_levels : 0)) return fail("in-memory depth", (int)mem_depth, (int)c.max_depth);
+    if (c.reg_levels == 1 && !k20 && mem_depth + 1 > beyond) return fail("more in-memory entries than the kernel has places for");
+    // steps: one per operation left in the program (+ one per park for 20 states)
+    size_t real = 0;
+    for (const rdamd::FusedOp &f : c.out) real += (f.flags & 3u) != rdamd::kFusedPark || !k20;
+    if (c.pseudo_row.empty() && real != c.n_ops) return fail("operations lost", (int)real, (int)c.n_ops);
+    ++cases;
+  }
+  return 0;
+}
+
 int main() {
   std::mt19937 rng(20240603);
   int cases = 0;
+  if (check_compiler(rng, cases)) return 1;
   // ---- clade_classes ------------------------------------------------------------------------
   for (int rep = 0; rep < 400; ++rep) {
     const unsigned na = 1 + rng() % 64, nb = 1 + rng() % 64, limit = rep % 3 == 0 ? 16 : 64;

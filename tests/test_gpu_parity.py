@@ -614,6 +614,53 @@ def test_thousand_taxon_tree_vs_oracle():
     compare_state(g, o, [ops[i] for i in (0, 500, 998)], tree)
 
 
+def _balanced_newick(n_tips, rng):
+    nodes = ["t%d:%.5f" % (i, rng.uniform(0.02, 0.3)) for i in range(n_tips)]
+    while len(nodes) > 3:
+        nodes = ["(%s,%s):%.5f" % (nodes[i], nodes[i + 1], rng.uniform(0.02, 0.3))
+                 for i in range(0, len(nodes), 2)]
+    return "(" + ",".join(nodes) + ");"
+
+
+@pytest.mark.parametrize("n_tips,repeats,sites", [(48, 0, 700), (192, 0, 700), (192, 64, 700), (192, 16, 130),
+                                                 (768, 0, 300)])
+def test_balanced_trees_deep_stacks(n_tips, repeats, sites):
+    """Perfectly balanced trees need the deepest stacks a tree of their size can ask for: with
+    site repeats (64-row kernels) one register level, one LDS slot and the rest in the waves'
+    private segment up to eight levels in all (kernels_fused.hip, SP), two register levels and
+    an all-LDS stack beyond and without repeats.
+    Random (unrelated) sequences make the rescaling fire on the way up, so parked rescale
+    counts travel through every kind of level.  One and two sites per lane (launch size),
+    plain and folded programs."""
+    rng = np.random.default_rng(n_tips + repeats)
+    tree = rd.Tree.from_newick(_balanced_newick(n_tips, rng))
+    seqs = {"t%d" % i: "".join(rng.choice(list("ACGT"), sites)) for i in range(n_tips)}
+    w = synth.workload(8, 10, 4, 4, 5, simulate_seqs=False)
+    g = rd.Partition.for_tree(tree, 4, sites, 4, attributes=rd.ATTRIB_SITE_REPEATS if repeats else 0)
+    if repeats:
+        g.set_site_repeats(repeats)
+    o = OraclePartition.for_tree(tree, 4, sites, 4)
+    util.load_tips(g, tree, seqs, rd.MAP_NT)
+    util.load_tips(o, tree, seqs, ORC_MAP_NT)
+    freqs = [0.22, 0.31, 0.2, 0.27]
+    set_model((g, o), w["subst"], freqs, w["rates"])
+    picks = [int(i) for i in rng.choice(tree.root_count(), 3, replace=False)]
+    rls = [tree.root_location(i).with_ratio(float(rng.uniform(0.1, 0.9))) for i in picks]
+    want = [util.compute_lh(o, tree, rl) for rl in rls]
+    scheds = [g.schedule(*tree.generate_operations(rl)) for rl in rls]
+    depth = max(s.stack_depth() for s in scheds)
+    # (in-memory levels: behind one register level with repeats -- the 64-row kernels have
+    # private-segment levels --, behind two from four levels on without)
+    assert depth >= (3 if n_tips >= 192 and repeats != 16 else 2), depth
+    small = g.evaluate_batch(scheds, [w["subst"]] * 3, [freqs] * 3)                 # one site per lane
+    big = g.evaluate_batch(scheds * 20, [w["subst"]] * 60, [freqs] * 60)            # two
+    for a, b in zip(small, want):
+        assert util.rel_err(a, b) < LNL_TOL
+    assert np.array_equal(big, np.tile(small, 20))
+    g.destroy()
+    o.destroy()
+
+
 def test_binary_data_on_the_four_state_kernels():
     """states == 2 (`rd --states 2`): the partition runs on the 4-state kernels
     with two inert states.  Everything the caller sees keeps its 2-state shape
