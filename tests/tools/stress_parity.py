@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Randomised parity soak (run by hand on a GPU box, not collected by pytest):
-random shapes (4, 2 and 20 states), random valid operation orders, random root
+random shapes (4, 2 and 20 states; one tree in eight perfectly balanced: the deepest
+traversal stacks), random valid operation orders, random root
 placements, subtree site repeats off / class limit 16 / 64, gaps and ambiguity
 codes, the occasional vanishing rate category -- the materialising kernels and
 the fused evaluators against the CPU oracle.
@@ -31,6 +32,13 @@ while time.time() - t0 < budget:
     if K == 20:                  # the oracle is slow there: smaller cases
         n, S = min(n, 90), min(S, 1000)
     w = synth.workload(n, S, K, R, int(rng.integers(1 << 30)))
+    if rng.random() < 0.125:     # a balanced tree over the same tips (branch lengths random)
+        nodes = ["%s:%.5f" % (name, rng.uniform(0.01, 0.4)) for name in sorted(w["seqs"])]
+        while len(nodes) > 3:    # (pair up level by level; the top keeps three children)
+            stop = 2 if len(nodes) == 4 else len(nodes)
+            nodes = ["(%s,%s):%.5f" % (nodes[i], nodes[i + 1], rng.uniform(0.01, 0.4)) if i + 1 < len(nodes)
+                     else nodes[i] for i in range(0, stop, 2)] + nodes[stop:]
+        w["newick"] = "(" + ",".join(nodes) + ");"
     tree = rd.Tree.from_newick(w["newick"])
     cmap = rd.MAP_NT if K == 4 else util.make_map(w["alphabet"])
     # subtree site repeats (4 and 2 states): off / class limit 16 / 64; a third of the
