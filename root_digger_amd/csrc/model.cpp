@@ -161,7 +161,9 @@ void model_t::set_gamma_rates(size_t p, const model_params_t &alpha) {
 }
 
 void model_t::update_invariant_sites(size_t p) {
-  // src/model.cpp:292-300: the proportion is only ever 0.0 (+I is inert)
+  // src/model.cpp:292-300: the proportion is only ever 0.0 (+I is inert) -- with the flag the
+  // reference re-derives which sites are invariant, which a proportion of 0 never reads
+  (void)_invariant_sites;
   if (rdamd_update_invariant_sites_proportion(_partitions[p], 0, 0.0) != RDAMD_SUCCESS)
     fail("update_invariant_sites");
 }
