@@ -49,6 +49,7 @@ constexpr size_t kTiptabPad = 128;
 struct FusedWorkspace {
   unsigned cap_jobs = 0, blocks_x = 0;
   char *d_in = nullptr;   // per-batch inputs (see ensure_workspace)
+  unsigned *d_any_unsafe = nullptr;   // inside d_in, behind the batch's inputs
   FusedJob *d_jobs = nullptr;   // ... and where this batch's pieces sit inside it
   double *d_q = nullptr, *d_rates = nullptr, *d_freqs = nullptr, *d_rw = nullptr;
   double *d_pmat = nullptr, *d_tiptab = nullptr, *d_partials = nullptr, *d_out = nullptr;
@@ -93,16 +94,17 @@ static hipError_t ensure_workspace(rdamd_partition *p, unsigned n_jobs) {
 #define A(ptr, bytes) do { e = hipMalloc((void **)&(ptr), (bytes)); if (e != hipSuccess) return e; } while (0)
   // jobs + Q + frequencies + rates + rate weights of a batch live in ONE device block
   // with the layout of the pinned staging block: one copy per batch instead of five
-  A(w->d_in, (size_t)cap * (sizeof(FusedJob) + sizeof(double) * (K * K + K + 2 * R)));
+  // (+ 8 bytes: the batch's any-unsafe word, zeroed by the same copy, FusedArgs::any_unsafe)
+  A(w->d_in, (size_t)cap * (sizeof(FusedJob) + sizeof(double) * (K * K + K + 2 * R)) + 8);
   A(w->d_pmat, sizeof(double) * pm_per_job * cap);
   w->tiptab_doubles = (K == 4 ? pm_per_job * 4 : (size_t)p->prob_matrices * R * kFused20TabDoubles) * cap;
   A(w->d_tiptab, sizeof(double) * (w->tiptab_doubles + kTiptabPad));
   A(w->d_partials, sizeof(double) * w->blocks_x * cap);
   A(w->d_out, sizeof(double) * cap);
 #undef A
-  e = hipHostMalloc((void **)&w->h_out, sizeof(double) * cap, hipHostMallocDefault);
+  e = hipHostMalloc((void **)&w->h_out, sizeof(double) * (cap + 1), hipHostMallocDefault);   // (+ the any-unsafe word)
   if (e != hipSuccess) return e;
-  w->h_in_bytes = (size_t)cap * (sizeof(FusedJob) + sizeof(double) * (K * K + K + 2 * R));
+  w->h_in_bytes = (size_t)cap * (sizeof(FusedJob) + sizeof(double) * (K * K + K + 2 * R)) + 8;
   e = hipHostMalloc((void **)&w->h_in, w->h_in_bytes, hipHostMallocDefault);
   if (e != hipSuccess) return e;
   w->cap_jobs = cap;
@@ -494,7 +496,9 @@ static int evaluate_batch_impl(rdamd_partition_t *p, unsigned int n_jobs,
   }
   {   // the device block mirrors the staging block: one copy
     const size_t in_bytes = (size_t)n_jobs * (sizeof(FusedJob) + sizeof(double) * (K * K + K + 2 * R));
-    RDAMD_HIP_TRY(hipMemcpyAsync(w->d_in, w->h_in, in_bytes, hipMemcpyHostToDevice, p->stream), RDAMD_FAILURE);
+    memset(w->h_in + in_bytes, 0, 8);   // the any-unsafe word behind the block
+    w->d_any_unsafe = (unsigned *)(w->d_in + in_bytes);
+    RDAMD_HIP_TRY(hipMemcpyAsync(w->d_in, w->h_in, in_bytes + 8, hipMemcpyHostToDevice, p->stream), RDAMD_FAILURE);
     w->d_jobs = (FusedJob *)(w->d_in + ((char *)hj - w->h_in));
     w->d_q = (double *)(w->d_in + ((char *)hq - w->h_in));
     w->d_freqs = (double *)(w->d_in + ((char *)hf - w->h_in));
@@ -532,6 +536,7 @@ static int evaluate_batch_impl(rdamd_partition_t *p, unsigned int n_jobs,
   a.tiptab_job_stride = tiptab_job;
   a.pmat = w->d_pmat; a.tiptab = w->d_tiptab + kTiptabPad; a.freqs = w->d_freqs; a.rate_weights = w->d_rw;
   a.partials = w->d_partials; a.persite = nullptr;
+  a.any_unsafe = w->d_any_unsafe;
   a.pmat_job_stride = (size_t)p->prob_matrices * R * 16;
   a.sites = p->sites; a.rate_cats = R;
   a.tipcodes_bytes = (unsigned)std::min<size_t>(wide_codes ? (size_t)p->wide_rows * p->tip_stride() * 2
@@ -563,9 +568,29 @@ static int evaluate_batch_impl(rdamd_partition_t *p, unsigned int n_jobs,
   if (getenv("RDAMD_FUSED_DEPTH")) max_depth[0] = (unsigned)atoi(getenv("RDAMD_FUSED_DEPTH"));
   if (getenv("RDAMD_FUSED_RL")) reg_levels[0] = (unsigned)atoi(getenv("RDAMD_FUSED_RL"));
 #endif
-  e = launch_fused_eval(a, n_jobs, max_depth, w->blocks_x, ns, reg_levels, d_out, p->stream);
+  e = launch_fused_eval(a, n_jobs, max_depth, w->blocks_x, ns, reg_levels, false, d_out, p->stream);
   p->prof_end();
   RDAMD_HIP_TRY(e, RDAMD_FAILURE);
+  // The jobs whose tt_unsafe flag went up in this batch (a table entry in (0, 2^-128), a
+  // pseudo-tip class that would have been rescaled: fused.hpp) were skipped by that pass;
+  // the word that says whether there are any comes back with the results, and only then is
+  // the second pass -- plain programs, tip-tip rescale test -- queued over the batch.
+  unsigned *h_flag = (unsigned *)(w->h_out + w->cap_jobs);
+  if (lnl_host)
+    RDAMD_HIP_TRY(hipMemcpyAsync(w->h_out, d_out, sizeof(double) * n_jobs, hipMemcpyDeviceToHost, p->stream), RDAMD_FAILURE);
+  RDAMD_HIP_TRY(hipMemcpyAsync(h_flag, w->d_any_unsafe, sizeof(unsigned), hipMemcpyDeviceToHost, p->stream), RDAMD_FAILURE);
+  RDAMD_HIP_TRY(hipStreamSynchronize(p->stream), RDAMD_FAILURE);
+  if (*h_flag) {
+    p->prof_begin(3);
+    e = launch_fused_eval(a, n_jobs, max_depth, w->blocks_x, ns, reg_levels, true, d_out, p->stream);
+    p->prof_end();
+    RDAMD_HIP_TRY(e, RDAMD_FAILURE);
+    if (lnl_host)
+      RDAMD_HIP_TRY(hipMemcpyAsync(w->h_out, d_out, sizeof(double) * n_jobs, hipMemcpyDeviceToHost, p->stream), RDAMD_FAILURE);
+    RDAMD_HIP_TRY(hipStreamSynchronize(p->stream), RDAMD_FAILURE);
+  }
+  if (lnl_host) memcpy(lnl_host, w->h_out, sizeof(double) * n_jobs);
+  return RDAMD_SUCCESS;
   }
   if (lnl_host) {
     RDAMD_HIP_TRY(hipMemcpyAsync(w->h_out, d_out, sizeof(double) * n_jobs, hipMemcpyDeviceToHost, p->stream), RDAMD_FAILURE);

@@ -48,8 +48,9 @@ struct FusedJob {
   // a rescale, and the evaluator variant without that test runs the job (kernels_fused.hip)
   // -- on `prog`, the program with the pseudo-tips.  When it is up, the variant with the test
   // runs it on `prog_plain`: every operation of the caller's list, tips only, every rescale
-  // exactly where the reference rule puts it.  (Both variants are launched over all jobs; a
-  // workgroup of the wrong variant returns at once.)
+  // exactly where the reference rule puts it.  (A variant is launched over all jobs, a
+  // workgroup whose job belongs to the other one returns at once; the second variant's pass
+  // is only queued when the batch raised a flag at all, FusedArgs::any_unsafe.)
   uint32_t tt_unsafe;
   // 4 states, stacks with private-segment levels (kernels_fused.hip, SP): which of a program's
   // in-memory stack entries (counted from the bottom) sits in the one LDS slot -- the host
@@ -81,6 +82,7 @@ struct FusedArgs {
   unsigned tipcodes_bytes;           // rows in use * row bytes
   unsigned table_rows;               // 16 or 64: rows per LDS table slot (and the code arena's entry width)
   unsigned rates_across_waves;       // 1: a workgroup is R waves, one per rate category (kernels_fused.hip, RW)
+  unsigned *any_unsafe;              // device word, 0 when the batch starts: set with the first FusedJob::tt_unsafe
 };
 
 // ---- 20-state variant (kernels_fused_k20.hip) ---------------------------------
@@ -121,9 +123,12 @@ hipError_t launch_fused_pmatrix(const FusedArgs &a, const double *d_q, const dou
                                 unsigned n_jobs, unsigned n_mat, hipStream_t stream);
 // depth / reg_levels: [0] of the programs with pseudo-tips (FusedJob::prog), [1] of the plain
 // programs (prog_plain); the two evaluator variants are launched with their own LDS sizes
+// unsafe_pass: false = the jobs whose tt_unsafe flag is down (programs with pseudo-tips, no
+// tip-tip rescale test), true = the others (plain programs, with the test).  The caller runs
+// the second pass only when FusedArgs::any_unsafe came back set.
 hipError_t launch_fused_eval(const FusedArgs &a, unsigned n_jobs, const unsigned max_depth[2],
                              unsigned blocks_x, unsigned sites_per_lane, const unsigned reg_levels[2],
-                             double *d_out, hipStream_t stream);
+                             bool unsafe_pass, double *d_out, hipStream_t stream);
 
 
 }  // namespace rdamd

@@ -162,7 +162,8 @@ template <int ROWS>
 __global__ void __launch_bounds__(ROWS == 16 ? 64 : 256)
 clade_table_kernel(FusedJob *__restrict__ jobs, const uint8_t *__restrict__ maps,
                    const double *__restrict__ pmat, double *__restrict__ tiptab, size_t pmat_job_stride,
-                   size_t tiptab_job_stride, double *__restrict__ scratch, size_t scratch_job_stride, unsigned R) {
+                   size_t tiptab_job_stride, double *__restrict__ scratch, size_t scratch_job_stride, unsigned R,
+                   unsigned *__restrict__ any_unsafe) {
   const unsigned job = blockIdx.y, grp = blockIdx.x;
   const FusedJob jb = jobs[job];
   if (grp >= jb.n_groups) return;
@@ -218,7 +219,10 @@ clade_table_kernel(FusedJob *__restrict__ jobs, const uint8_t *__restrict__ maps
     }
     __syncthreads();   // (also orders this workgroup's scratch writes before the next node's reads)
   }
-  if (unsafe) jobs[job].tt_unsafe = 1u;   // the job's flag (every writer stores the same value)
+  if (unsafe) {
+    jobs[job].tt_unsafe = 1u;   // the job's flag (every writer stores the same value)
+    *any_unsafe = 1u;           // ... and the batch's: the evaluator's second pass is needed
+  }
 }
 
 hipError_t launch_clade_tables(const FusedArgs &a, const uint8_t *d_maps, double *d_scratch,
@@ -228,11 +232,11 @@ hipError_t launch_clade_tables(const FusedArgs &a, const uint8_t *d_maps, double
   if (a.table_rows > 16)
     clade_table_kernel<64><<<dim3(max_groups, n_jobs), 256, 0, stream>>>(
         const_cast<FusedJob *>(a.jobs), d_maps, a.pmat, const_cast<double *>(a.tiptab), a.pmat_job_stride,
-        a.tiptab_job_stride, d_scratch, scratch_job_stride, a.rate_cats);
+        a.tiptab_job_stride, d_scratch, scratch_job_stride, a.rate_cats, a.any_unsafe);
   else
     clade_table_kernel<16><<<dim3(max_groups, n_jobs), 64, 0, stream>>>(
         const_cast<FusedJob *>(a.jobs), d_maps, a.pmat, const_cast<double *>(a.tiptab), a.pmat_job_stride,
-        a.tiptab_job_stride, d_scratch, scratch_job_stride, a.rate_cats);
+        a.tiptab_job_stride, d_scratch, scratch_job_stride, a.rate_cats, a.any_unsafe);
   return hipGetLastError();
 }
 

@@ -138,7 +138,8 @@ __device__ __forceinline__ void combine(const double (&tx)[4], const double (&ty
   }
 }
 
-// TTCHECK: rescale test on tip-tip steps too.  Both variants of a launch are queued; a
+// TTCHECK: rescale test on tip-tip steps too.  A variant is queued over all jobs of a batch
+// (the one with the test only if the batch raised a flag at all, launch_fused_eval_ns); a
 // workgroup looks at the flag the P-matrix / clade-table steps left in ITS job
 // (FusedJob::tt_unsafe: some table entry of the job in (0, 2^-128), or a pseudo-tip class
 // that would have been rescaled) and returns at once in the variant the job does not belong
@@ -619,10 +620,17 @@ fused_pmatrix_k4_kernel(const double *__restrict__ q, const double *__restrict__
                         FusedJob *__restrict__ jobs, unsigned n_jobs,
                         unsigned n_mat, unsigned R, double *__restrict__ pmat,
                         double *__restrict__ tiptab, size_t pmat_job_stride, size_t tiptab_job_stride,
-                        unsigned table_rows) {
-  const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+                        unsigned table_rows, unsigned *__restrict__ any_unsafe) {
+  // the wave's 64 results, for the cooperative stores below ([problem][17]: no bank conflict
+  // when every lane reads its own row)
+  __shared__ double sh[64 * 17];
+  __shared__ unsigned long long base_pm[64], base_tt[64];
+  const unsigned lane = threadIdx.x;
   const size_t per_job = (size_t)n_mat * R;
-  if (gid >= per_job * n_jobs) return;
+  const size_t total = per_job * n_jobs;
+  const size_t gid_raw = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = gid_raw < total;
+  const size_t gid = live ? gid_raw : total - 1;   // (idle lanes of the last wave repeat its last problem)
   const unsigned job = (unsigned)(gid / per_job);
   const unsigned rem = (unsigned)(gid % per_job);
   const unsigned m = rem / R, r = rem % R;
@@ -675,31 +683,46 @@ fused_pmatrix_k4_kernel(const double *__restrict__ q, const double *__restrict__
 #pragma unroll
     for (int i = 0; i < 16; ++i) out[i] = tmp[i];
   }
-  double *pmo = pmat + (size_t)job * pmat_job_stride + ((size_t)m * R + r) * 16;
+  // Stores: a thread's own 16 + 64 doubles would go out as 80 instructions of 64 lanes x 8
+  // bytes, 512 bytes apart -- 64 cache lines each (235 MB of HBM traffic for 100 MB of data
+  // on c2).  Instead the wave parks its results in LDS and writes problem by problem, a lane
+  // per element: 512 contiguous bytes per instruction.
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     out[i] = out[i] <= 0.0 ? 0.0 : out[i];   // (<=: a -0.0 becomes +0.0 -- the rescale tests read high words)
-    pmo[i] = out[i];
+    sh[lane * 17 + i] = out[i];
   }
-  // tip table of this (matrix, rate): row c = sum over the states in code c
-  // (64-row launches: as the evaluator's LDS image, [half][code][2 states] -- it goes there by DMA)
-  double *tto = tiptab + (size_t)job * tiptab_job_stride + ((size_t)m * R + r) * 64;
+  base_pm[lane] = (unsigned long long)job * pmat_job_stride + ((size_t)m * R + r) * 16;
+  base_tt[lane] = (unsigned long long)job * tiptab_job_stride + ((size_t)m * R + r) * 64;
+  __syncthreads();
+  const unsigned n_live = (unsigned)(total - (size_t)blockIdx.x * 64 < 64 ? total - (size_t)blockIdx.x * 64 : 64);
+#pragma unroll 4
+  for (unsigned it = 0; it < 16; ++it) {   // P: four problems per instruction
+    const unsigned e = it * 64 + lane, pr = e >> 4, k = e & 15u;
+    if (pr < n_live) pmat[base_pm[pr] + k] = sh[pr * 17 + k];
+  }
+  // tip table of a (matrix, rate): row c = sum over the states in code c; my element of every
+  // problem's table (64-row launches: the evaluator's LDS image, [half][code][2 states] -- it
+  // goes there by DMA; 16-row launches: [code][state])
+  const unsigned c = table_rows > 16 ? (lane >> 1) & 15u : lane >> 2;
+  const unsigned i = table_rows > 16 ? (lane >> 5) * 2 + (lane & 1u) : lane & 3u;
+  for (unsigned pr = 0; pr < n_live; ++pr) {
+    const double *o = sh + pr * 17 + i * 4;
+    double acc = 0.0;
 #pragma unroll
-  for (int c = 0; c < 16; ++c)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      double acc = 0.0;
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if ((c >> j) & 1) acc += out[i * 4 + j];
-      tto[table_rows > 16 ? (i >> 1) * 32 + c * 2 + (i & 1) : c * 4 + i] = acc;
-    }
+    for (int j = 0; j < 4; ++j)
+      if ((c >> j) & 1) acc += o[j];
+    tiptab[base_tt[pr] + lane] = acc;
+  }
   // every table entry is a sum of P entries, so the smallest non-zero P entry bounds
   // them all from below (FusedJob::tt_unsafe; 2^-128 = 0x1p-128)
   bool tiny = false;
 #pragma unroll
-  for (int i = 0; i < 16; ++i) tiny = tiny || (out[i] > 0.0 && out[i] < 0x1p-128);
-  if (tiny) jobs[job].tt_unsafe = 1u;   // (every writer stores the same value)
+  for (int k = 0; k < 16; ++k) tiny = tiny || (out[k] > 0.0 && out[k] < 0x1p-128);
+  if (tiny) {
+    jobs[job].tt_unsafe = 1u;   // (every writer stores the same value)
+    *any_unsafe = 1u;
+  }
 }
 
 hipError_t launch_fused_pmatrix(const FusedArgs &a, const double *d_q, const double *d_rates,
@@ -708,7 +731,7 @@ hipError_t launch_fused_pmatrix(const FusedArgs &a, const double *d_q, const dou
   if (!total) return hipSuccess;
   fused_pmatrix_k4_kernel<<<(unsigned)((total + 63) / 64), 64, 0, stream>>>(
       d_q, d_rates, const_cast<FusedJob *>(a.jobs), n_jobs, n_mat, a.rate_cats, const_cast<double *>(a.pmat),
-      const_cast<double *>(a.tiptab), a.pmat_job_stride, a.tiptab_job_stride, a.table_rows);
+      const_cast<double *>(a.tiptab), a.pmat_job_stride, a.tiptab_job_stride, a.table_rows, a.any_unsafe);
   return hipGetLastError();
 }
 
@@ -767,18 +790,20 @@ static hipError_t launch_fused_variant_rl(const FusedArgs &a, unsigned n_jobs, u
 // waves per SIMD), +5 % on c5; three and four sites per lane lose (register
 // pressure: 31k and 22k).  One site per lane is kept for launches too small to
 // fill the chip with half the waves (evaluate.hip picks).
-// Both variants are queued -- the one on the programs with pseudo-tips and no tip-tip
-// rescale test ([0]), the one on the plain programs with it ([1]) -- each with the LDS and
-// the register stack levels ITS programs need; a workgroup of the variant its job does not
-// belong to returns at once.
+// Two variants -- the one on the programs with pseudo-tips and no tip-tip rescale test
+// ([0]), the one on the plain programs with it ([1]) --, each with the LDS and the register
+// stack levels ITS programs need; a workgroup of the variant its job does not belong to
+// returns at once.  A pass queues one of them over all jobs and the finishing kernel; the
+// second pass is only queued when a flag went up in the batch (evaluate.hip reads
+// FusedArgs::any_unsafe with the results: on ordinary data it never does, and a launch of
+// 77 000 workgroups that all return at once still costs 20 us).
 template <int NS, int TR>
 static hipError_t launch_fused_eval_ns(const FusedArgs &a, unsigned n_jobs, const unsigned max_depth[2],
-                                       unsigned blocks_x, const unsigned reg_levels[2], double *d_out,
-                                       hipStream_t stream) {
+                                       unsigned blocks_x, const unsigned reg_levels[2], bool unsafe_pass,
+                                       double *d_out, hipStream_t stream) {
   const unsigned gx = (blocks_x + NS - 1) / NS;   // blocks_x counts 64-site blocks
-  hipError_t e = launch_fused_variant_rl<NS, false, TR>(a, n_jobs, max_depth[0], gx, reg_levels[0], stream);
-  if (e != hipSuccess) return e;
-  e = launch_fused_variant_rl<NS, true, TR>(a, n_jobs, max_depth[1], gx, reg_levels[1], stream);   // (returns at once on ordinary data)
+  hipError_t e = unsafe_pass ? launch_fused_variant_rl<NS, true, TR>(a, n_jobs, max_depth[1], gx, reg_levels[1], stream)
+                             : launch_fused_variant_rl<NS, false, TR>(a, n_jobs, max_depth[0], gx, reg_levels[0], stream);
   if (e != hipSuccess) return e;
   fused_finish_kernel<<<n_jobs, 256, 0, stream>>>(a.partials, gx * NS, d_out);   // 64-site blocks per job
   return hipGetLastError();
@@ -786,13 +811,13 @@ static hipError_t launch_fused_eval_ns(const FusedArgs &a, unsigned n_jobs, cons
 
 hipError_t launch_fused_eval(const FusedArgs &a, unsigned n_jobs, const unsigned max_depth[2],
                              unsigned blocks_x, unsigned sites_per_lane, const unsigned reg_levels[2],
-                             double *d_out, hipStream_t stream) {
+                             bool unsafe_pass, double *d_out, hipStream_t stream) {
   if (!n_jobs) return hipSuccess;
   if (a.table_rows > 16)   // 16-bit code arena, 64-row table slots
-    return sites_per_lane == 2 ? launch_fused_eval_ns<2, 64>(a, n_jobs, max_depth, blocks_x, reg_levels, d_out, stream)
-                               : launch_fused_eval_ns<1, 64>(a, n_jobs, max_depth, blocks_x, reg_levels, d_out, stream);
-  return sites_per_lane == 2 ? launch_fused_eval_ns<2, 16>(a, n_jobs, max_depth, blocks_x, reg_levels, d_out, stream)
-                             : launch_fused_eval_ns<1, 16>(a, n_jobs, max_depth, blocks_x, reg_levels, d_out, stream);
+    return sites_per_lane == 2 ? launch_fused_eval_ns<2, 64>(a, n_jobs, max_depth, blocks_x, reg_levels, unsafe_pass, d_out, stream)
+                               : launch_fused_eval_ns<1, 64>(a, n_jobs, max_depth, blocks_x, reg_levels, unsafe_pass, d_out, stream);
+  return sites_per_lane == 2 ? launch_fused_eval_ns<2, 16>(a, n_jobs, max_depth, blocks_x, reg_levels, unsafe_pass, d_out, stream)
+                             : launch_fused_eval_ns<1, 16>(a, n_jobs, max_depth, blocks_x, reg_levels, unsafe_pass, d_out, stream);
 }
 
 }  // namespace rdamd
