@@ -78,110 +78,130 @@ __device__ __forceinline__ Step load_step(const_u32_ptr prog, unsigned i) {
 // exp(Q t) by scaling and squaring around the same degree-16 Taylor polynomial
 // as pmatrix_generic_kernel (||A / 2^s||_1 <= 1/4), evaluated Paterson-
 // Stockmeyer style: X^2..X^4 (3 products), then Horner in X^4 over four cubic
-// blocks (3 products) -- 6 matrix products instead of 16.  A workgroup holds
-// two (job, matrix, rate) problems, 128 threads each; a thread owns a 2x2 tile
-// of every 20x20 product (3 LDS reads per 4 FMAs).
+// blocks (3 products) -- 6 matrix products instead of 16.  The products are bound by LDS
+// bandwidth, so a thread owns a 4x4 tile of every 20x20 product: per inner step four 8-byte
+// reads of A (a row each, shared by the five threads of a tile row) and two 16-byte reads of
+// B feed 16 FMAs -- 4 bytes per FMA (round 2: 2x2 tiles, 8 bytes per FMA, 3.6 ms per c3
+// batch).  25 threads of a 32-lane half wave work on a (job, matrix, rate) problem, a
+// 128-thread workgroup holds four; a problem needs three matrices in LDS at any time
+// (X, X^2, X^4, then X^4 and two Horner / squaring buffers), its own tiles of X, X^2 and X^3
+// for the cubic blocks stay in registers.
 namespace {
 
-constexpr int kMat = kK * kK;
+constexpr int kLd = 20;             // row stride in LDS (doubles).  Unpadded: the tile rows of A collide on banks (stride 22 avoids
+                                    // that), but 38.9 instead of 42.9 KB per workgroup is a fourth workgroup per CU: 2.65 against 2.82 ms
+constexpr int kMatLds = kK * kLd;   // doubles per matrix in LDS
 
-// C = A . B for this thread's 2x2 tile (rows 2 ti, 2 ti + 1; columns 2 tj, 2 tj + 1)
+// c = A . B for this thread's 4x4 tile (rows 4 ti .., columns 4 tj ..)
 __device__ __forceinline__ void tile_product(const double *A, const double *B, unsigned ti, unsigned tj,
-                                             double (&c)[4]) {
-  c[0] = c[1] = c[2] = c[3] = 0.0;
-  const double *a0 = A + (2 * ti) * kK, *a1 = a0 + kK;
-#pragma unroll 5
+                                             double (&c)[16]) {
+#pragma unroll
+  for (int e = 0; e < 16; ++e) c[e] = 0.0;
+  const double *a = A + (4 * ti) * kLd, *b = B + 4 * tj;
+#pragma unroll 4
   for (int l = 0; l < kK; ++l) {
-    const double2 b = *reinterpret_cast<const double2 *>(B + l * kK + 2 * tj);
-    const double x0 = a0[l], x1 = a1[l];
-    c[0] = fma(x0, b.x, c[0]); c[1] = fma(x0, b.y, c[1]);
-    c[2] = fma(x1, b.x, c[2]); c[3] = fma(x1, b.y, c[3]);
+    const double2 b0 = *reinterpret_cast<const double2 *>(b + l * kLd);
+    const double2 b1 = *reinterpret_cast<const double2 *>(b + l * kLd + 2);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const double x = a[r * kLd + l];
+      c[4 * r + 0] = fma(x, b0.x, c[4 * r + 0]); c[4 * r + 1] = fma(x, b0.y, c[4 * r + 1]);
+      c[4 * r + 2] = fma(x, b1.x, c[4 * r + 2]); c[4 * r + 3] = fma(x, b1.y, c[4 * r + 3]);
+    }
   }
 }
-__device__ __forceinline__ void tile_store(double *C, unsigned ti, unsigned tj, const double (&c)[4]) {
-  *reinterpret_cast<double2 *>(C + (2 * ti) * kK + 2 * tj) = make_double2(c[0], c[1]);
-  *reinterpret_cast<double2 *>(C + (2 * ti + 1) * kK + 2 * tj) = make_double2(c[2], c[3]);
+__device__ __forceinline__ void tile_store(double *C, unsigned ti, unsigned tj, const double (&c)[16]) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    double *row = C + (4 * ti + r) * kLd + 4 * tj;
+    *reinterpret_cast<double2 *>(row) = make_double2(c[4 * r], c[4 * r + 1]);
+    *reinterpret_cast<double2 *>(row + 2) = make_double2(c[4 * r + 2], c[4 * r + 3]);
+  }
 }
 
 }  // namespace
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(128)
 fused20_pmatrix_kernel(const double *__restrict__ q, const double *__restrict__ rates,
                        const FusedJob *__restrict__ jobs, unsigned n_mat, unsigned R, unsigned total,
                        double *__restrict__ pmat, size_t pmat_job_stride,
                        double *__restrict__ tiptab, size_t tiptab_job_stride,
                        const uint64_t *__restrict__ codemask, unsigned ncodes) {
-  __shared__ __attribute__((aligned(16))) double lds[2][6][kMat];   // per problem: X, X^2, X^3, X^4, H, T
-  __shared__ double red[2][kK];
-  __shared__ int sq[2];
-  const unsigned half = threadIdx.x >> 7, tid = threadIdx.x & 127;
-  const unsigned prob = blockIdx.x * 2 + half;
+  __shared__ __attribute__((aligned(16))) double lds[4][3][kMatLds];
+  __shared__ double red[4][kK];
+  __shared__ int sq[4];
+  const unsigned sub = threadIdx.x >> 5, w = threadIdx.x & 31u;
+  const unsigned prob = blockIdx.x * 4 + sub;
   const bool live = prob < total;
   const unsigned pr = live ? prob : total - 1;
   const unsigned per_job = n_mat * R;
   const unsigned job = pr / per_job, rem = pr % per_job;
   const unsigned m = rem / R, r = rem % R;
-  double *X = lds[half][0], *X2 = lds[half][1], *X3 = lds[half][2], *X4 = lds[half][3];
-  double *H = lds[half][4], *T = lds[half][5];
-  const bool worker = tid < 100;
-  const unsigned ti = tid / 10, tj = tid % 10;
+  double *M0 = lds[sub][0], *M1 = lds[sub][1], *M2 = lds[sub][2];
+  const bool worker = w < 25;
+  const unsigned ti = worker ? w / 5 : 0, tj = worker ? w % 5 : 0;
 
   const double t = jobs[job].brlen[m] * rates[(size_t)job * R + r];
-  const double *qq = q + (size_t)job * kMat;
-  for (unsigned e = tid; e < (unsigned)kMat; e += 128) X[e] = qq[e] * t;
+  const double *qq = q + (size_t)job * (kK * kK);
+  for (unsigned e = w; e < (unsigned)(kK * kK); e += 32) M0[(e / kK) * kLd + e % kK] = qq[e] * t;
   __syncthreads();
-  if (tid < (unsigned)kK) {
+  if (w < (unsigned)kK) {
     double cs = 0.0;
-    for (unsigned i = 0; i < (unsigned)kK; ++i) cs += fabs(X[i * kK + tid]);
-    red[half][tid] = cs;
+    for (unsigned i = 0; i < (unsigned)kK; ++i) cs += fabs(M0[i * kLd + w]);
+    red[sub][w] = cs;
   }
   __syncthreads();
-  if (tid == 0) {
+  if (w == 0) {
     double norm = 0.0;
-    for (unsigned j = 0; j < (unsigned)kK; ++j) norm = fmax(norm, red[half][j]);
+    for (unsigned j = 0; j < (unsigned)kK; ++j) norm = fmax(norm, red[sub][j]);
     int s = 0;
     double scale = 1.0;
     while (norm * scale > 0.25 && s < 60) { scale *= 0.5; ++s; }
-    sq[half] = s;
-    red[half][0] = scale;
+    sq[sub] = s;
+    red[sub][0] = scale;
   }
   __syncthreads();
-  const int s_mine = sq[half], s_max = max(sq[0], sq[1]);
-  const double scale = red[half][0];
-  for (unsigned e = tid; e < (unsigned)kMat; e += 128) X[e] *= scale;
-  __syncthreads();
-  double c[4];
-  if (worker) { tile_product(X, X, ti, tj, c); tile_store(X2, ti, tj, c); }
-  __syncthreads();
-  if (worker) { tile_product(X2, X, ti, tj, c); tile_store(X3, ti, tj, c); }
-  __syncthreads();
-  if (worker) { tile_product(X2, X2, ti, tj, c); tile_store(X4, ti, tj, c); }
+  const int s_mine = sq[sub], s_max = max(max(sq[0], sq[1]), max(sq[2], sq[3]));
+  const double scale = red[sub][0];
+  for (unsigned e = w; e < (unsigned)(kK * kK); e += 32) M0[(e / kK) * kLd + e % kK] *= scale;
   __syncthreads();
   // 1/k!, k = 0..16
   constexpr double f[17] = {1.0, 1.0, 1.0 / 2, 1.0 / 6, 1.0 / 24, 1.0 / 120, 1.0 / 720, 1.0 / 5040,
                             1.0 / 40320, 1.0 / 362880, 1.0 / 3628800, 1.0 / 39916800, 1.0 / 479001600,
                             1.0 / 6227020800.0, 1.0 / 87178291200.0, 1.0 / 1307674368000.0,
                             1.0 / 20922789888000.0};
-  // block q: B_q = f[4q] I + f[4q+1] X + f[4q+2] X^2 + f[4q+3] X^3 ; p = B0 + X^4 (B1 + X^4 (B2 + X^4 (B3 + f16 X^4)))
-  auto block_plus = [&](int qb, const double (&acc)[4], double *dst) {   // dst tile = B_qb tile + acc
-    double o[4];
+  double x1[16], x2[16], x3[16], c[16];   // my tiles of X, X^2, X^3; the product in hand
 #pragma unroll
-    for (int w = 0; w < 4; ++w) {
-      const unsigned i = 2 * ti + (w >> 1), j = 2 * tj + (w & 1), e = i * kK + j;
-      o[w] = acc[w] + (i == j ? f[4 * qb] : 0.0) + f[4 * qb + 1] * X[e] + f[4 * qb + 2] * X2[e] +
-             f[4 * qb + 3] * X3[e];
+  for (int e = 0; e < 16; ++e) x1[e] = M0[(4 * ti + (e >> 2)) * kLd + 4 * tj + (e & 3)];
+  if (worker) { tile_product(M0, M0, ti, tj, x2); tile_store(M1, ti, tj, x2); }   // X^2
+  __syncthreads();
+  if (worker) {
+    tile_product(M1, M0, ti, tj, x3);                                              // X^3 (registers only)
+    tile_product(M1, M1, ti, tj, c); tile_store(M2, ti, tj, c);                    // X^4
+  }
+  __syncthreads();   // (X and X^2 are not read again: M0 / M1 become the Horner buffers)
+  // block qb: B_qb = f[4qb] I + f[4qb+1] X + f[4qb+2] X^2 + f[4qb+3] X^3 ;
+  // p = B0 + X^4 (B1 + X^4 (B2 + X^4 (B3 + f16 X^4)))
+  auto block_plus = [&](int qb, const double (&acc)[16], double *dst) {   // dst tile = B_qb tile + acc
+    double o[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const unsigned i = 4 * ti + (e >> 2), j = 4 * tj + (e & 3);
+      o[e] = acc[e] + (i == j ? f[4 * qb] : 0.0) + f[4 * qb + 1] * x1[e] + f[4 * qb + 2] * x2[e] +
+             f[4 * qb + 3] * x3[e];
     }
     tile_store(dst, ti, tj, o);
   };
+  double *H = M0, *T = M1;
   if (worker) {   // H = B3 + f16 X^4
-    double acc[4];
+    double acc[16];
 #pragma unroll
-    for (int w = 0; w < 4; ++w) acc[w] = f[16] * X4[(2 * ti + (w >> 1)) * kK + 2 * tj + (w & 1)];
+    for (int e = 0; e < 16; ++e) acc[e] = f[16] * c[e];
     block_plus(3, acc, H);
   }
   __syncthreads();
   for (int qb = 2; qb >= 0; --qb) {   // H <- B_qb + X^4 . H   (through T)
-    if (worker) { tile_product(X4, H, ti, tj, c); block_plus(qb, c, T); }
+    if (worker) { tile_product(M2, H, ti, tj, c); block_plus(qb, c, T); }
     __syncthreads();
     double *swap = H; H = T; T = swap;
   }
@@ -194,9 +214,9 @@ fused20_pmatrix_kernel(const double *__restrict__ q, const double *__restrict__ 
   const double *out = H;
   // element (rg, ks, k, i) of the copy = P[4 rg + i][4 ks + k]  (kernels_clv_mfma.hip)
   double *o = pmat + (size_t)job * pmat_job_stride + ((size_t)m * R + r) * kCopy;
-  for (unsigned e = tid; e < (unsigned)kCopy; e += 128) {
+  for (unsigned e = w; e < (unsigned)kCopy; e += 32) {
     const unsigned i = e & 3, k = (e >> 2) & 3, blk = e >> 4, ks = blk % kSteps, rg = blk / kSteps;
-    const double v = out[(4 * rg + i) * kK + 4 * ks + k];
+    const double v = out[(4 * rg + i) * kLd + 4 * ks + k];
     o[e] = v <= 0.0 ? 0.0 : v;   // (<=: no -0.0 either -- the rescale test reads high words)
   }
   // tip table, one 192-byte row per code: positions 0-7 = (s, g) for s = 0, 1 as pairs
@@ -205,13 +225,13 @@ fused20_pmatrix_kernel(const double *__restrict__ q, const double *__restrict__ 
   // read 64 + 64 + 32 CONTIGUOUS bytes with three instructions (one cache line per site
   // and instruction instead of two).
   double *tt = tiptab + (size_t)job * tiptab_job_stride + ((size_t)m * R + r) * kFused20TabDoubles;
-  for (unsigned e = tid; e < ncodes * kFused20TabRow; e += 128) {
-    const unsigned cc = e / kFused20TabRow, w = e % kFused20TabRow;
-    const unsigned g = w < 16 ? (w & 7u) >> 1 : w - 16, sidx = w < 16 ? 2 * (w >> 3) + (w & 1u) : 4;
+  for (unsigned e = w; e < ncodes * kFused20TabRow; e += 32) {
+    const unsigned cc = e / kFused20TabRow, ww = e % kFused20TabRow;
+    const unsigned g = ww < 16 ? (ww & 7u) >> 1 : ww - 16, sidx = ww < 16 ? 2 * (ww >> 3) + (ww & 1u) : 4;
     double acc = 0.0;
-    if (w < 20) {
+    if (ww < 20) {
       const uint64_t mask = codemask[cc];
-      const double *row = out + (4 * sidx + g) * kK;
+      const double *row = out + (4 * sidx + g) * kLd;
       for (unsigned j = 0; j < (unsigned)kK; ++j) {
         const double v = row[j] <= 0.0 ? 0.0 : row[j];
         acc += ((mask >> j) & 1) ? v : 0.0;
@@ -547,7 +567,7 @@ hipError_t launch_fused20_pmatrix(const Fused20Args &a, const double *d_q, const
                                   unsigned n_jobs, unsigned n_mat, hipStream_t stream) {
   const size_t total = (size_t)n_jobs * n_mat * a.rate_cats;
   if (!total) return hipSuccess;
-  fused20_pmatrix_kernel<<<(unsigned)((total + 1) / 2), 256, 0, stream>>>(
+  fused20_pmatrix_kernel<<<(unsigned)((total + 3) / 4), 128, 0, stream>>>(
       d_q, d_rates, a.jobs, n_mat, a.rate_cats, (unsigned)total, const_cast<double *>(a.pmat), a.pmat_job_stride,
       const_cast<double *>(a.tiptab), a.tiptab_job_stride, a.codemask, a.ncodes);
   return hipGetLastError();
