@@ -66,7 +66,8 @@ def test_product_library_has_no_timing_only_switches():
     librdamd.so must not even know the variable names."""
     blob = open(rd.lib_path, "rb").read()
     assert os.path.basename(rd.lib_path) == "librdamd.so"
-    for name in (b"RDAMD_K20_VAR", b"RDAMD_FUSED_NS"):
+    for name in (b"RDAMD_K20_VAR", b"RDAMD_FUSED_NS", b"RDAMD_FUSED_DEPTH", b"RDAMD_FUSED_RL", b"RDAMD_FUSED_RW",
+                 b"RDAMD_FUSED_SPILL_MIN"):
         assert name not in blob, name
 
 
