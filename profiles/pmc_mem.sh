@@ -24,7 +24,7 @@ import csv, glob, sys, collections
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(sys.argv[1] + "/p*/*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
-        agg[r["Kernel_Name"].split("(")[0][-44:]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        agg[r["Kernel_Name"].split("(")[0][-64:]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, v in agg.items():
     if sys.argv[2] in k:
         print(k)
