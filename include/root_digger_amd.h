@@ -122,6 +122,14 @@ double        rdamd_partition_weight_sum(const rdamd_partition_t *p);
 /* the HIP stream handle (opaque here; HIP's stream type) every launch of this partition is queued on:
  * a collective queued on it runs after the batch that produced its input */
 void         *rdamd_partition_stream(const rdamd_partition_t *p);
+/* Dispatch priority of the partition's stream: -1 high, 0 normal (default), +1 low.  When
+ * several partitions' kernels compete for the device, workgroups of a higher-priority stream
+ * take the wave slots that become free first.  The lock-stepped search puts the shared
+ * objective partition -- long launches that fill every CU -- on LOW priority, so that the
+ * short kernels beside it (the other group's P-matrices and clade tables, the candidates'
+ * root-only steps) start when a slot frees up instead of when the launch ends.  The stream is
+ * re-created: call it while nothing is queued on the partition (it waits for that). */
+int           rdamd_partition_set_stream_priority(rdamd_partition_t *p, int level);
 const double *rdamd_partition_subst_params(const rdamd_partition_t *p,
                                            unsigned int params_index);
 const double *rdamd_partition_frequencies(const rdamd_partition_t *p,
@@ -165,13 +173,15 @@ int rdamd_root_loglikelihood_fused(rdamd_partition_t       *p,
                                    unsigned int             n_alpha,
                                    double                  *lnl_out);
 /* The same for SEVERAL partitions of one device in ONE launch: item i = partition parts[i],
- * its root operation ops[i], n_positions[i] <= 4 root positions with branch lengths
- * lengths1[4 i + a] / lengths2[4 i + a]; lnl_out[4 i + a].  A lock-stepped search
+ * its root operation ops[i], n_positions[i] <= 8 root positions (RDAMD_ROOT_MAX_POSITIONS;
+ * <= 4 at 8 rate categories) with branch lengths lengths1[8 i + a] / lengths2[8 i + a];
+ * lnl_out[8 i + a].  A lock-stepped search
  * (rdamd_model_exhaustive_search_lockstep) serves the Brent / finite-difference steps
  * (src/model.cpp:606-794) of all candidates in flight -- each on its own model replica --
  * with it.  Every partition is left as rdamd_root_loglikelihood_fused leaves it and every
  * value has that call's bits; the partitions must be idle (no call of another thread in
  * progress on them). */
+#define RDAMD_ROOT_MAX_POSITIONS 8
 int rdamd_root_loglikelihood_fused_multi(unsigned int              n_items,
                                          rdamd_partition_t *const *parts,
                                          const rdamd_operation_t  *ops,
@@ -256,13 +266,32 @@ int rdamd_evaluate_batch(rdamd_partition_t *p, unsigned int n_jobs,
                          const double *rates, const double *rate_weights,
                          double *lnl_out);
 /* Same, but the n_jobs results are left in DEVICE memory at d_lnl_out (e.g. a
- * tensor that an RCCL all-reduce sums over site-sharded ranks next); the call
- * returns after the partition's stream has finished writing them. */
+ * tensor that an RCCL all-reduce sums over site-sharded ranks next).  The call BLOCKS like
+ * rdamd_evaluate_batch: it returns after the partition's stream has finished writing the
+ * results (the batch's second evaluator pass, needed when a job's tables hold entries small
+ * enough for the per-site rescaling rule to matter, is decided on the host from a word that
+ * comes back with the batch).  Until it returns, d_lnl_out[j] of such a job is unspecified. */
 int rdamd_evaluate_batch_device(rdamd_partition_t *p, unsigned int n_jobs,
                                 const rdamd_schedule_t *const *schedules,
                                 const double *subst, const double *freqs,
                                 const double *rates, const double *rate_weights,
                                 void *d_lnl_out);
+
+/* The same batch in two halves, for callers that keep TWO batches of one partition in flight
+ * (the lock-stepped exhaustive search, src/model.cpp:1139-1272 run for several candidates at
+ * once: while one group's batch is on the device the other group's hosts take their L-BFGS-B
+ * steps).  _submit queues the batch on `slot` (0 or 1) and returns; _wait blocks until that
+ * batch is done and hands out its results.  The part of a batch in front of the evaluator
+ * (parameter upload, P-matrices, clade tables) runs beside the evaluator of the batch
+ * submitted before it; the evaluators follow each other in submission order.  A slot takes a
+ * new batch only after its last one has been waited for.  Both calls may be made from
+ * different host threads (one per slot); results are those of rdamd_evaluate_batch, bit for bit. */
+int rdamd_evaluate_batch_submit(rdamd_partition_t *p, unsigned int slot, unsigned int n_jobs,
+                                const rdamd_schedule_t *const *schedules,
+                                const double *subst, const double *freqs,
+                                const double *rates, const double *rate_weights);
+int rdamd_evaluate_batch_wait(rdamd_partition_t *p, unsigned int slot, double *lnl_out);
+
 
 /* parity/debug views: copy device buffers to host.  rdamd_get_clv returns coraxlib's
  * layout, out[site][rate][state] (what partition->clv[i] holds in the reference),
@@ -460,6 +489,15 @@ void rdamd_model_counters(const rdamd_model_t *m, uint64_t out[6]);
  * [1] the jobs they carried, [2] combined root-only launches
  * (rdamd_root_loglikelihood_fused_multi), [3] the candidates' root-only steps they carried */
 void rdamd_model_lockstep_stats(const rdamd_model_t *m, uint64_t out[4]);
+/* How the candidates in flight of a lock-stepped search meet: 0 (default) = the library's
+ * choice -- from four candidates on, TWO groups whose objective batches alternate on the
+ * shared partition (rdamd_evaluate_batch_submit / _wait: one group's hosts take their
+ * L-BFGS-B steps while the other group's batch runs); 1 = one group, blocking launches.
+ * The records are the same either way (a job's value does not depend on its launch). */
+void rdamd_model_set_lockstep_groups(rdamd_model_t *m, unsigned int groups);
+/* stream priority (rdamd_partition_set_stream_priority) of the shared objective partition
+ * during a lock-stepped search: +1 low (default), 0 leave it as it is */
+void rdamd_model_set_lockstep_priority(rdamd_model_t *m, int level);
 /* assign_indicies_by_rank_exhaustive, :1867-1911 */
 int rdamd_model_assign_by_rank(rdamd_model_t *m, unsigned int rank, unsigned int num_tasks);
 /* exhaustive_search, :1139-1272, over the assigned roots.  root_id / llh /

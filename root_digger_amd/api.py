@@ -104,6 +104,8 @@ _sig("rdamd_schedule_stats", C.c_int, _vp, C.POINTER(ScheduleStats))
 _sig("rdamd_partition_set_site_repeats", C.c_int, _vp, _u)
 _sig("rdamd_evaluate_batch", C.c_int, _vp, _u, C.POINTER(_vp), _pd, _pd, _pd, _pd, _pd)
 _sig("rdamd_evaluate_batch_device", C.c_int, _vp, _u, C.POINTER(_vp), _pd, _pd, _pd, _pd, _vp)
+_sig("rdamd_evaluate_batch_submit", C.c_int, _vp, _u, _u, C.POINTER(_vp), _pd, _pd, _pd, _pd)
+_sig("rdamd_evaluate_batch_wait", C.c_int, _vp, _u, _pd)
 _sig("rdamd_get_clv", C.c_int, _vp, _u, _pd)
 _sig("rdamd_get_scaler", C.c_int, _vp, _u, _pu)
 _sig("rdamd_get_pmatrix", C.c_int, _vp, _u, _pd)
@@ -227,6 +229,9 @@ _sig("rdamd_tree_generate_directional_operations", C.c_int, _vp, _pd, _pop, _pu,
      C.POINTER(C.c_int), _pu)
 _sig("rdamd_model_counters", None, C.c_void_p, C.POINTER(C.c_uint64))
 _sig("rdamd_model_lockstep_stats", None, C.c_void_p, C.POINTER(C.c_uint64))
+_sig("rdamd_model_set_lockstep_groups", None, C.c_void_p, _u)
+_sig("rdamd_model_set_lockstep_priority", None, C.c_void_p, C.c_int)
+_sig("rdamd_partition_set_stream_priority", C.c_int, _vp, C.c_int)
 _sig("rdamd_model_assign_by_rank", C.c_int, _vp, _u, _u)
 _sig("rdamd_model_exhaustive_search_parallel", C.c_int, _vp, _u, C.c_double, C.c_double,
      C.c_double, C.c_double, C.POINTER(C.c_uint64), _pd, _pd, _pu, _prl, _pd)
@@ -738,6 +743,24 @@ class Partition:
             _fail("evaluate_batch")
         return out
 
+    def evaluate_batch_submit(self, slot, schedules, subst, freqs, rates=None, rate_weights=None):
+        """Queue the batch on `slot` (0 or 1) and return (rdamd_evaluate_batch_submit); returns the
+        number of jobs, which evaluate_batch_wait needs."""
+        n, hs, subst, freqs, rates, rw = self._batch_args(schedules, subst, freqs, rates,
+                                                          rate_weights)
+        if lib.rdamd_evaluate_batch_submit(self._h, slot, n, hs, _dptr(subst), _dptr(freqs),
+                                           _dptr(rates) if rates is not None else None,
+                                           _dptr(rw) if rw is not None else None) != 1:
+            _fail("evaluate_batch_submit")
+        return n
+
+    def evaluate_batch_wait(self, slot, n):
+        """Results of the batch last submitted on `slot`."""
+        out = np.zeros(n, dtype=np.float64)
+        if lib.rdamd_evaluate_batch_wait(self._h, slot, _dptr(out)) != 1:
+            _fail("evaluate_batch_wait")
+        return out
+
     def evaluate_batch_device(self, schedules, subst, freqs, device_ptr, rates=None,
                               rate_weights=None):
         """Same, results left in device memory at `device_ptr` (n float64)."""
@@ -1215,6 +1238,16 @@ class Model:
         names = ("objective_batches", "objective_evaluations", "full_traversals",
                  "root_positions", "move_root_calls", "setulb_calls")
         return dict(zip(names, (int(v) for v in out)))
+
+    def set_lockstep_groups(self, groups):
+        """0: the library's choice (two pipelined groups from four candidates in flight on);
+        1: one group, blocking launches (rdamd_model_set_lockstep_groups)."""
+        lib.rdamd_model_set_lockstep_groups(self._h, groups)
+
+    def set_lockstep_priority(self, level):
+        """stream priority of the shared objective partition during a lock-stepped search
+        (+1 low, the default; 0 unchanged)."""
+        lib.rdamd_model_set_lockstep_priority(self._h, level)
 
     def lockstep_stats(self):
         """combined launches of the last lock-stepped search (rdamd_model_lockstep_stats)."""

@@ -21,10 +21,18 @@
 
 namespace rdamd {
 
+//
+// Two combiners on ONE shared partition form a pipeline (rdamd_evaluate_batch_submit / _wait,
+// slots 0 and 1): the candidates in flight are split into two groups, and while one group's
+// batch is on the device the other group's host threads take their L-BFGS-B steps and queue
+// the next batch behind it -- the evaluator launches follow each other without the gap a
+// single group leaves between its launches (results back, n setulb calls, parameters up,
+// P-matrices, clade tables: ~250 us on c2 against 1.25 ms of evaluator per launch).
 class batch_combiner_t {
 public:
-  // `shared`: the partition every combined launch runs on (not owned)
-  explicit batch_combiner_t(rdamd_partition_t *shared) : _part(shared) {}
+  // `shared`: the partition every combined launch runs on (not owned); slot < 0: blocking
+  // launches (one group), 0 / 1: this group's slot of the pipeline
+  explicit batch_combiner_t(rdamd_partition_t *shared, int slot = -1) : _part(shared), _slot(slot) {}
 
   rdamd_partition_t *partition() const { return _part; }
 
@@ -48,17 +56,13 @@ public:
     scope_t &operator=(const scope_t &) = delete;
   };
 
-  // schedules live on the shared partition; its stream is used by one thread at a time
+  // schedules live on the shared partition (the library serialises what touches it)
   rdamd_schedule_t *schedule_create(const rdamd_operation_t *ops, unsigned n_ops,
                                     const unsigned *matrix_indices, const double *branch_lengths,
                                     unsigned n_matrices) {
-    std::lock_guard<std::mutex> g(_launch_mu);
     return rdamd_schedule_create(_part, ops, n_ops, matrix_indices, branch_lengths, n_matrices);
   }
-  void schedule_destroy(rdamd_schedule_t *s) {
-    std::lock_guard<std::mutex> g(_launch_mu);
-    rdamd_schedule_destroy(s);
-  }
+  void schedule_destroy(rdamd_schedule_t *s) { rdamd_schedule_destroy(s); }
 
   // n jobs of one candidate (same schedule): subst [n][K*K-K], freqs [n][K],
   // rates / weights [n][R].  Returns when the launch that carried them is done.
@@ -128,10 +132,14 @@ private:
       rates.insert(rates.end(), r->rates, r->rates + (size_t)r->n * R);
       weights.insert(weights.end(), r->weights, r->weights + (size_t)r->n * R);
     }
-    {
-      std::lock_guard<std::mutex> g(_launch_mu);
+    if (_slot < 0) {
       if (rdamd_evaluate_batch(_part, (unsigned)total, scheds.data(), subst.data(), freqs.data(),
                                rates.data(), weights.data(), out.data()) != RDAMD_SUCCESS)
+        return std::string("combined evaluate_batch failed: ") + rdamd_errmsg();
+    } else {
+      if (rdamd_evaluate_batch_submit(_part, (unsigned)_slot, (unsigned)total, scheds.data(), subst.data(),
+                                      freqs.data(), rates.data(), weights.data()) != RDAMD_SUCCESS ||
+          rdamd_evaluate_batch_wait(_part, (unsigned)_slot, out.data()) != RDAMD_SUCCESS)
         return std::string("combined evaluate_batch failed: ") + rdamd_errmsg();
     }
     size_t at = 0;
@@ -143,7 +151,8 @@ private:
   }
 
   rdamd_partition_t *_part;
-  std::mutex _mu, _launch_mu;
+  int _slot;
+  std::mutex _mu;
   std::condition_variable _cv;
   std::vector<request_t *> _pending;
   int _active = 0;
@@ -179,10 +188,11 @@ public:
     scope_t &operator=(const scope_t &) = delete;
   };
 
-  // n <= 4 root positions of `op` on `part`: branch lengths l1 / l2, values to out
+  // n <= 8 root positions (4 at 8 rate categories) of `op` on `part`: branch lengths l1 / l2,
+  // values to out
   void evaluate(rdamd_partition_t *part, const rdamd_operation_t &op, const unsigned *params_idx,
                 const double *l1, const double *l2, unsigned n, double *out) {
-    request_t req{part, op, params_idx, {0, 0, 0, 0}, {0, 0, 0, 0}, n, out};
+    request_t req{part, op, params_idx, {0}, {0}, n, out};
     for (unsigned a = 0; a < n; ++a) { req.l1[a] = l1[a]; req.l2[a] = l2[a]; }
     std::unique_lock<std::mutex> lk(_mu);
     _pending.push_back(&req);
@@ -222,7 +232,7 @@ private:
     rdamd_partition_t *part;
     rdamd_operation_t op;
     const unsigned *params_idx;
-    double l1[4], l2[4];
+    double l1[RDAMD_ROOT_MAX_POSITIONS], l2[RDAMD_ROOT_MAX_POSITIONS];
     unsigned n;
     double *out;
     bool done = false;
@@ -233,18 +243,19 @@ private:
     std::vector<rdamd_partition_t *> parts(m);
     std::vector<rdamd_operation_t> ops(m);
     std::vector<const unsigned *> pidx(m);
-    std::vector<double> l1(4 * m), l2(4 * m), out(4 * m);
+    constexpr unsigned P = RDAMD_ROOT_MAX_POSITIONS;
+    std::vector<double> l1(P * m), l2(P * m), out(P * m);
     std::vector<unsigned> npos(m);
     for (size_t i = 0; i < m; ++i) {
       parts[i] = batch[i]->part; ops[i] = batch[i]->op; pidx[i] = batch[i]->params_idx;
       npos[i] = batch[i]->n;
-      for (unsigned a = 0; a < 4; ++a) { l1[4 * i + a] = batch[i]->l1[a]; l2[4 * i + a] = batch[i]->l2[a]; }
+      for (unsigned a = 0; a < P; ++a) { l1[P * i + a] = batch[i]->l1[a]; l2[P * i + a] = batch[i]->l2[a]; }
     }
     if (rdamd_root_loglikelihood_fused_multi((unsigned)m, parts.data(), ops.data(), pidx.data(), l1.data(),
                                              l2.data(), npos.data(), out.data()) != RDAMD_SUCCESS)
       return std::string("combined root step failed: ") + rdamd_errmsg();
     for (size_t i = 0; i < m; ++i)
-      for (unsigned a = 0; a < batch[i]->n; ++a) batch[i]->out[a] = out[4 * i + a];
+      for (unsigned a = 0; a < batch[i]->n; ++a) batch[i]->out[a] = out[P * i + a];
     return std::string();
   }
   std::mutex _mu;

@@ -4,6 +4,9 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+#include <mutex>
+
 #include <cstdint>
 #include <cstdio>
 #include <string>
@@ -100,6 +103,7 @@ struct rdamd_partition {
   // pseudo-tips have up to 64 classes (offsets up to 1008); built on first use
   uint8_t  *d_codes_wide = nullptr;
   unsigned  wide_rows = 0, wide_rows_cap = 0;
+  bool      code_arena_full = false;            // a code arena hit the 32-bit offset limit: no more pseudo-tip rows
   rdamd::CladeCache *clades = nullptr;          // subtree site repeats (RDAMD_ATTRIB_SITE_REPEATS)
   unsigned  tip_generation = 0;                 // bumped by rdamd_set_tip_states: schedules with pseudo-tips go stale
   double   *d_clv = nullptr;
@@ -137,7 +141,20 @@ struct rdamd_partition {
   char     *h_stage = nullptr;    // pinned staging ring for small H2D copies
   size_t    stage_bytes = 0, stage_off = 0;
 
-  rdamd::FusedWorkspace *fused = nullptr;   // evaluate.hip
+  // evaluate.hip: the batch workspaces.  Slot 0 serves rdamd_evaluate_batch; slots 0 and 1
+  // alternate under rdamd_evaluate_batch_submit / _wait (two batches in flight: the second one's
+  // inputs, P-matrices and clade tables are made on stream_pre while the first one's evaluator
+  // runs on `stream`, and the evaluators follow each other on `stream` without a gap)
+  rdamd::FusedWorkspace *fused = nullptr, *fused1 = nullptr;
+  hipStream_t stream_pre = nullptr;                 // created with the first pipelined batch (high priority)
+  int stream_priority = 0;                          // of `stream` (rdamd_partition_set_stream_priority)
+  std::mutex launch_mu;                             // queueing on `stream` / stream_pre from several host threads
+  uint64_t batch_submitted = 0;                     // batches queued so far (under launch_mu)
+  std::atomic<uint64_t> batch_completed{0};         // ... and known to have finished (a stream is FIFO)
+  // device blocks of destroyed schedules: reused by the next schedule once no batch in flight
+  // can still read them (no hipFree -- it waits for the whole device -- in the steady state)
+  struct PoolBlock { char *ptr; size_t bytes; uint64_t seq; };
+  std::vector<PoolBlock> sched_pool, sched_retired;
   void *d_root_items = nullptr, *h_root_items = nullptr;   // rdamd_root_loglikelihood_fused_multi (the leading partition's)
   unsigned root_items_cap = 0;
 
@@ -173,6 +190,13 @@ struct rdamd_partition {
 };
 
 namespace rdamd {
+
+// everything queued for the partition, pipelined batches' front halves included
+inline hipError_t sync_streams(rdamd_partition *p) {
+  hipError_t e = hipStreamSynchronize(p->stream);
+  if (e == hipSuccess && p->stream_pre) e = hipStreamSynchronize(p->stream_pre);
+  return e;
+}
 
 // kernels_pmatrix.hip
 // Rebuild Q for one rate matrix on the host into q[K*K].
@@ -235,8 +259,12 @@ hipError_t launch_root_lnl(rdamd_partition *p, unsigned clv_index, int scaler_in
 hipError_t launch_root_single(rdamd_partition *p, const LevelOp &op, const double *len1,
                               const double *len2, unsigned n_positions,
                               const unsigned *params_indices, unsigned *d_counter, double *result);
+// root positions one launch of the fused root kernels takes: 8 for up to 4 rate categories,
+// 4 for 8 (one lane of a wave exponentiates one of the 2 R matrices of a position)
+constexpr unsigned kRootMaxPositions = 8;
+inline unsigned root_single_max_positions(unsigned R) { return R <= 4 ? 8u : 4u; }
 struct RootSingleArgs {
-  double len1[4], len2[4];      // child1 / child2 branch length per position
+  double len1[kRootMaxPositions], len2[kRootMaxPositions];      // child1 / child2 branch length per position
   unsigned params_idx[8];       // rate -> rate matrix (also the frequency set)
   unsigned n_positions;
 };
@@ -250,7 +278,7 @@ struct RootItem {
   const uint64_t *codemask;
   double *partials;
   unsigned *counter;
-  double *result;      // [4]
+  double *result;      // [kRootMaxPositions]
   unsigned blocks, pad;
 };
 unsigned root_single_blocks(const rdamd_partition *p);

@@ -19,6 +19,10 @@
 
 struct rdamd_schedule {
   rdamd_partition *part = nullptr;
+  // everything of the schedule that lives on the device is ONE block out of the partition's
+  // pool (schedule_block_alloc): [program | plain program | clade steps | clade groups | lengths]
+  char *d_block = nullptr;
+  size_t block_bytes = 0;
   rdamd::FusedOp *d_prog = nullptr;
   double *d_brlen = nullptr;
   unsigned n_ops = 0, depth = 0;      // depth: LDS stack levels the program needs
@@ -59,6 +63,16 @@ struct FusedWorkspace {
   double *h_out = nullptr;   // pinned
   char *h_in = nullptr;      // pinned parameter staging
   size_t h_in_bytes = 0;
+  hipEvent_t ev_ready = nullptr, ev_done = nullptr;   // pipelined batches (batch_submit / batch_wait)
+  // the batch this slot has in flight: what batch_wait needs for the results and, should the
+  // batch have raised a flag, for the second pass
+  struct Pending {
+    bool active = false, k20 = false, host_out = false;
+    unsigned n_jobs = 0, ns = 1, max_depth[2] = {1, 1}, reg_levels[2] = {1, 1};
+    FusedArgs a;
+    double *d_out = nullptr;
+    uint64_t seq = 0;
+  } pend;
 };
 
 void fused_workspace_free(FusedWorkspace *w) {
@@ -68,21 +82,69 @@ void fused_workspace_free(FusedWorkspace *w) {
     if (d) (void)hipFree(d);
   if (w->h_out) (void)hipHostFree(w->h_out);
   if (w->h_in) (void)hipHostFree(w->h_in);
+  if (w->ev_ready) (void)hipEventDestroy(w->ev_ready);
+  if (w->ev_done) (void)hipEventDestroy(w->ev_done);
   delete w;
 }
 
-static hipError_t ensure_workspace(rdamd_partition *p, unsigned n_jobs) {
-  if (!p->fused) p->fused = new FusedWorkspace();
-  FusedWorkspace *w = p->fused;
+// ---- device blocks of schedules -------------------------------------------------------------
+// A lock-stepped search compiles and drops a schedule per candidate and round while batches
+// are in flight; hipMalloc / hipFree there would wait for the whole device.  Blocks of dropped
+// schedules are parked until the batches that may still read them have finished
+// (rdamd_partition::batch_completed) and handed to the next schedule that fits.
+static char *schedule_block_alloc(rdamd_partition *p, size_t bytes, size_t *got) {
+  const uint64_t done = p->batch_completed.load(std::memory_order_acquire);
+  for (size_t i = 0; i < p->sched_retired.size();) {
+    if (p->sched_retired[i].seq <= done) {
+      p->sched_pool.push_back(p->sched_retired[i]);
+      p->sched_retired[i] = p->sched_retired.back();
+      p->sched_retired.pop_back();
+    } else {
+      ++i;
+    }
+  }
+  size_t best = p->sched_pool.size();
+  for (size_t i = 0; i < p->sched_pool.size(); ++i)
+    if (p->sched_pool[i].bytes >= bytes && p->sched_pool[i].bytes <= 2 * bytes + 4096 &&
+        (best == p->sched_pool.size() || p->sched_pool[i].bytes < p->sched_pool[best].bytes))
+      best = i;
+  if (best < p->sched_pool.size()) {
+    char *ptr = p->sched_pool[best].ptr;
+    *got = p->sched_pool[best].bytes;
+    p->sched_pool[best] = p->sched_pool.back();
+    p->sched_pool.pop_back();
+    return ptr;
+  }
+  const size_t rounded = (bytes + 4095) & ~(size_t)4095;
+  char *ptr = nullptr;
+  if (hipMalloc((void **)&ptr, rounded) != hipSuccess) return nullptr;
+  *got = rounded;
+  return ptr;
+}
+static void schedule_block_release(rdamd_partition *p, char *ptr, size_t bytes) {
+  if (!ptr) return;
+  // (batches in flight when the schedule is dropped may hold its programs)
+  const uint64_t seq = p->batch_submitted;
+  if (p->batch_completed.load(std::memory_order_acquire) >= seq) p->sched_pool.push_back({ptr, bytes, 0});
+  else p->sched_retired.push_back({ptr, bytes, seq});
+}
+
+static hipError_t ensure_workspace(rdamd_partition *p, FusedWorkspace *&slot, unsigned n_jobs) {
+  if (!slot) slot = new FusedWorkspace();
+  FusedWorkspace *w = slot;
   if (n_jobs <= w->cap_jobs) return hipSuccess;
-  hipError_t e = hipStreamSynchronize(p->stream);
+  hipError_t e = sync_streams(p);
   if (e != hipSuccess) return e;
   void *dev[] = {w->d_in, w->d_pmat, w->d_tiptab, w->d_partials, w->d_out, w->d_clade_scratch};
   for (void *d : dev)
     if (d) (void)hipFree(d);
   if (w->h_out) (void)hipHostFree(w->h_out);
   if (w->h_in) (void)hipHostFree(w->h_in);
-  *w = FusedWorkspace();
+  {
+    hipEvent_t r = w->ev_ready, d = w->ev_done;   // (the events survive a larger workspace)
+    *w = FusedWorkspace();
+    w->ev_ready = r; w->ev_done = d;
+  }
   const unsigned cap = std::max(16u, n_jobs + n_jobs / 2);
   const unsigned R = p->rate_cats, K = p->states;
   // 4 states: site blocks padded to a multiple of 16 (8 at two sites per lane) so that blockIdx.x % 8 (the
@@ -115,6 +177,13 @@ static hipError_t ensure_workspace(rdamd_partition *p, unsigned n_jobs) {
 
 using namespace rdamd;
 
+// (the partition's launch_mu is held: the block goes back to the pool, nothing waits)
+static void rdamd_schedule_destroy_locked(rdamd_schedule *s) {
+  if (!s) return;
+  if (s->part) schedule_block_release(s->part, s->d_block, s->block_bytes);
+  delete s;
+}
+
 extern "C" {
 
 rdamd_schedule_t *rdamd_schedule_create(rdamd_partition_t *p, const rdamd_operation_t *ops,
@@ -123,6 +192,8 @@ rdamd_schedule_t *rdamd_schedule_create(rdamd_partition_t *p, const rdamd_operat
                                         const double *branch_lengths,
                                         unsigned int n_matrices) {
   clear_error();
+  // (clade cache, code arenas and the block pool belong to the partition: one thread at a time)
+  std::lock_guard<std::mutex> guard(p->launch_mu);
   const bool k20 = p->states == 20 && p->rate_cats <= 4;
   if (p->states != 4 && !k20) {
     set_error(40, "rdamd_schedule_create: the fused evaluator handles 4-state data and 20-state "
@@ -180,9 +251,25 @@ rdamd_schedule_t *rdamd_schedule_create(rdamd_partition_t *p, const rdamd_operat
   };
   // 64-row tables (and the 16-bit code arena that goes with them) when the partition's class
   // limit asks for them; every program of the schedule then addresses that arena
+  // A pseudo-tip's table is written into the tip-table slot of the branch above it
+  // (kernels_clade.hip): that slot is only free when the branch's matrix index is used by this
+  // one child.  The C ABI (like coraxlib's) lets a caller share a matrix index between
+  // branches; such a list is evaluated without folding -- its tip tables are all code-indexed.
+  bool matrix_shared = false;
+  {
+    std::vector<unsigned char> uses(p->prob_matrices, 0);
+    for (unsigned i = 0; i < n_ops; ++i)
+      for (unsigned m : {ops[i].child1_matrix_index, ops[i].child2_matrix_index})
+        if (uses[m]++) matrix_shared = true;
+  }
   const bool repeats = !k20 && (p->attributes & RDAMD_ATTRIB_SITE_REPEATS) && p->sites > 0;
   if (repeats && !p->clades) p->clades = new CladeCache();
-  const bool wide_mode = repeats && p->clades->max_classes > 16;
+  // (the 16-bit arena needs twice the bytes per row: a partition whose tip rows alone would not
+  // fit 32-bit offsets there keeps the 8-bit arena and 16-row tables -- for every schedule, so
+  // that all of them can share a launch)
+  const bool wide_fits = ((size_t)p->tips + 16) * p->tip_stride() * 2 + kTipcodePad <= 0xffffffffull;
+  const bool wide_mode = repeats && p->clades->max_classes > 16 && wide_fits;
+  const unsigned class_limit = wide_mode ? 64u : 16u;   // what this schedule's table slots hold
   auto compile = [&](const std::vector<rdamd_operation_t> &list,
                      const std::unordered_map<unsigned, unsigned> &pseudo_row,
                      const std::unordered_map<unsigned, unsigned> &pseudo_wide, Program &out) -> bool {
@@ -242,7 +329,10 @@ rdamd_schedule_t *rdamd_schedule_create(rdamd_partition_t *p, const rdamd_operat
       const rdamd_operation_t &o = ops[i];
       node_id[i] = clade_intern(p, id_of(o.child1_clv_index), id_of(o.child2_clv_index),
                                 o.child1_matrix_index, o.child2_matrix_index);
-      small[i] = i + 1 < n_ops && clade_node(*p->clades, p->tips, node_id[i])->n_classes > 0;
+      const unsigned nc = clade_node(*p->clades, p->tips, node_id[i])->n_classes;
+      // (a parent has at least as many classes as either child: small is inherited downwards
+      // under any limit)
+      small[i] = i + 1 < n_ops && !matrix_shared && nc > 0 && nc <= class_limit;
     }
     // the branch above operation i: the matrix index its consumer uses for it
     auto mat_above = [&](unsigned i) {
@@ -284,7 +374,7 @@ rdamd_schedule_t *rdamd_schedule_create(rdamd_partition_t *p, const rdamd_operat
   rdamd_schedule *s = new rdamd_schedule();
   s->part = p;
   s->tip_generation = p->tip_generation;
-#define TRY(expr) RDAMD_HIP_TRY(expr, (rdamd_schedule_destroy(s), nullptr))
+#define TRY(expr) RDAMD_HIP_TRY(expr, (rdamd_schedule_destroy_locked(s), nullptr))
   s->table_rows = wide_mode ? 64u : 16u;
   s->n_wide = n_wide;
   if (wide_mode) TRY(ensure_wide_arena(p));
@@ -298,11 +388,20 @@ rdamd_schedule_t *rdamd_schedule_create(rdamd_partition_t *p, const rdamd_operat
     for (unsigned i = 0; i < n_ops; ++i) {
       if (!small[i]) { kept.push_back(ops[i]); continue; }
       if (small[consumer[i]]) continue;
-      TRY(clade_upload_codes(p, node_id[i], wide_mode));
+      const hipError_t ce = clade_upload_codes(p, node_id[i], wide_mode);
+      if (ce != hipSuccess && p->code_arena_full) {
+        // no room for another row of class codes within 32-bit offsets: this schedule runs its
+        // plain program (rows handed out earlier stay valid for the schedules that hold them)
+        groups.clear(); steps.clear(); pseudo_row.clear(); pseudo_wide.clear();
+        n_wide = 0; clade_rows = 0;
+        break;
+      }
+      TRY(ce);
       pseudo_row[ops[i].parent_clv_index] = (unsigned)clade_node(*p->clades, p->tips, node_id[i])->code_row[wide_mode];
     }
-    if (!compile(kept, pseudo_row, pseudo_wide, folded)) { rdamd_schedule_destroy(s); return nullptr; }
+    if (!groups.empty() && !compile(kept, pseudo_row, pseudo_wide, folded)) { rdamd_schedule_destroy_locked(s); return nullptr; }
   }
+  s->n_wide = n_wide;
   const Program &main_prog = groups.empty() ? plain : folded;
   s->n_ops = (unsigned)main_prog.steps.size();
   s->depth = main_prog.depth; s->reg_levels = main_prog.reg_levels; s->matvecs = main_prog.matvecs;
@@ -311,39 +410,52 @@ rdamd_schedule_t *rdamd_schedule_create(rdamd_partition_t *p, const rdamd_operat
   s->lds_pos = main_prog.lds_pos; s->lds_pos_plain = plain.lds_pos;
   s->n_steps = (unsigned)steps.size(); s->n_groups = (unsigned)groups.size(); s->clade_rows = clade_rows;
   s->prog = main_prog.steps;
-  auto upload_program = [&](const Program &pr, FusedOp **dst) -> hipError_t {
-    std::vector<FusedOp> padded = pr.steps;
-    // harmless tail entries: the kernel prefetches descriptors up to i + 3
-    for (int k = 0; k < 4; ++k) padded.push_back(padded.back());
-    hipError_t e = hipMalloc((void **)dst, sizeof(FusedOp) * padded.size());
-    if (e != hipSuccess) return e;
-    return hipMemcpy(*dst, padded.data(), sizeof(FusedOp) * padded.size(), hipMemcpyHostToDevice);
-  };
-  TRY(upload_program(main_prog, &s->d_prog));
-  if (groups.empty()) {
-    s->d_prog_plain = s->d_prog;
-  } else {
-    TRY(upload_program(plain, &s->d_prog_plain));
-    TRY(hipMalloc((void **)&s->d_steps, sizeof(CladeStep) * steps.size()));
-    TRY(hipMalloc((void **)&s->d_groups, sizeof(CladeGroup) * groups.size()));
-    TRY(hipMemcpy(s->d_steps, steps.data(), sizeof(CladeStep) * steps.size(), hipMemcpyHostToDevice));
-    TRY(hipMemcpy(s->d_groups, groups.data(), sizeof(CladeGroup) * groups.size(), hipMemcpyHostToDevice));
+  // ---- the device block: [program | plain program | clade steps | clade groups | lengths] ----
+  {
+    auto padded = [](const Program &pr) {
+      std::vector<FusedOp> v = pr.steps;
+      // harmless tail entries: the kernel prefetches descriptors up to i + 3
+      for (int k = 0; k < 4; ++k) v.push_back(v.back());
+      return v;
+    };
+    const std::vector<FusedOp> pm = padded(main_prog), pp = groups.empty() ? std::vector<FusedOp>() : padded(plain);
+    auto up = [](size_t b) { return (b + 63) & ~(size_t)63; };
+    const size_t o_prog = 0, o_plain = up(o_prog + sizeof(FusedOp) * pm.size()),
+                 o_steps = up(o_plain + sizeof(FusedOp) * pp.size()),
+                 o_groups = up(o_steps + sizeof(CladeStep) * steps.size()),
+                 o_brlen = up(o_groups + sizeof(CladeGroup) * groups.size()),
+                 total = up(o_brlen + sizeof(double) * p->prob_matrices);
+    std::vector<char> host(total, 0);
+    memcpy(host.data() + o_prog, pm.data(), sizeof(FusedOp) * pm.size());
+    if (!pp.empty()) memcpy(host.data() + o_plain, pp.data(), sizeof(FusedOp) * pp.size());
+    if (!steps.empty()) memcpy(host.data() + o_steps, steps.data(), sizeof(CladeStep) * steps.size());
+    if (!groups.empty()) memcpy(host.data() + o_groups, groups.data(), sizeof(CladeGroup) * groups.size());
+    memcpy(host.data() + o_brlen, brlen.data(), sizeof(double) * p->prob_matrices);
+    s->d_block = schedule_block_alloc(p, total, &s->block_bytes);
+    if (!s->d_block) {
+      set_error(100 + (int)hipErrorOutOfMemory, "rdamd_schedule_create: no device memory for a %zu-byte schedule", total);
+      rdamd_schedule_destroy_locked(s);
+      return nullptr;
+    }
+    TRY(hipMemcpy(s->d_block, host.data(), total, hipMemcpyHostToDevice));
+    s->d_prog = (FusedOp *)(s->d_block + o_prog);
+    s->d_prog_plain = groups.empty() ? s->d_prog : (FusedOp *)(s->d_block + o_plain);
+    s->d_steps = groups.empty() ? nullptr : (CladeStep *)(s->d_block + o_steps);
+    s->d_groups = groups.empty() ? nullptr : (CladeGroup *)(s->d_block + o_groups);
+    s->d_brlen = (double *)(s->d_block + o_brlen);
   }
-  TRY(hipMalloc((void **)&s->d_brlen, sizeof(double) * p->prob_matrices));
-  TRY(hipMemcpy(s->d_brlen, brlen.data(), sizeof(double) * p->prob_matrices, hipMemcpyHostToDevice));
 #undef TRY
   return s;
 }
 
 void rdamd_schedule_destroy(rdamd_schedule_t *s) {
   if (!s) return;
-  if (s->part && s->part->stream) (void)hipStreamSynchronize(s->part->stream);
-  if (s->d_prog_plain && s->d_prog_plain != s->d_prog) (void)hipFree(s->d_prog_plain);
-  if (s->d_prog) (void)hipFree(s->d_prog);
-  if (s->d_brlen) (void)hipFree(s->d_brlen);
-  if (s->d_steps) (void)hipFree(s->d_steps);
-  if (s->d_groups) (void)hipFree(s->d_groups);
-  delete s;
+  if (s->part) {
+    std::lock_guard<std::mutex> g(s->part->launch_mu);
+    rdamd_schedule_destroy_locked(s);
+  } else {
+    delete s;
+  }
 }
 
 unsigned int rdamd_schedule_stack_depth(const rdamd_schedule_t *s) { return s->depth; }
@@ -369,6 +481,7 @@ int rdamd_schedule_stats(const rdamd_schedule_t *s, rdamd_schedule_stats_t *out)
 
 int rdamd_partition_set_site_repeats(rdamd_partition_t *p, unsigned int max_classes) {
   clear_error();
+  std::lock_guard<std::mutex> guard(p->launch_mu);
   if (max_classes > 64) {
     set_error(46, "rdamd_partition_set_site_repeats: at most 64 classes per pseudo-tip (got %u)", max_classes);
     return RDAMD_FAILURE;
@@ -382,7 +495,7 @@ int rdamd_partition_set_site_repeats(rdamd_partition_t *p, unsigned int max_clas
   if (p->clades && p->clades->max_classes != max_classes) {
     // classes were counted against the old limit: start the cache again (schedules keep
     // their own device copies; code rows already handed out stay where they are)
-    RDAMD_HIP_TRY(hipStreamSynchronize(p->stream), RDAMD_FAILURE);
+    RDAMD_HIP_TRY(sync_streams(p), RDAMD_FAILURE);
     for (rdamd::CladeNode &n : p->clades->nodes) { n.cls.clear(); n.cmap.clear(); }
     p->clades->intern.clear();
     // (node ids of the old generation stay valid for the schedules that hold them: nodes are
@@ -393,30 +506,61 @@ int rdamd_partition_set_site_repeats(rdamd_partition_t *p, unsigned int max_clas
   return RDAMD_SUCCESS;
 }
 
-static int evaluate_batch_impl(rdamd_partition_t *p, unsigned int n_jobs,
-                               const rdamd_schedule_t *const *schedules,
-                               const double *subst, const double *freqs,
-                               const double *rates, const double *rate_weights,
-                               double *lnl_host, void *lnl_device) {
-  clear_error();
-  if (n_jobs == 0) return RDAMD_SUCCESS;
+// A batch in two halves.  batch_submit queues everything a batch needs -- inputs, P-matrices,
+// clade tables, the evaluator, the copies of the results and of the batch's any-unsafe word --
+// and returns; batch_wait blocks until that work is done, runs the second evaluator pass if the
+// word came back set, and hands out the results.  rdamd_evaluate_batch is one after the other
+// on slot 0, everything on the partition's stream.  `pipelined`: the slot form
+// (rdamd_evaluate_batch_submit): the part in front of the evaluator goes to stream_pre, so that
+// it runs beside the evaluator of the batch submitted before, and the evaluators follow each
+// other on the partition's stream (a stream is a FIFO: batches finish in submission order).
+static int batch_submit(rdamd_partition_t *p, FusedWorkspace *&slot, bool pipelined, unsigned int n_jobs,
+                        const rdamd_schedule_t *const *schedules,
+                        const double *subst, const double *freqs,
+                        const double *rates, const double *rate_weights,
+                        bool host_out, void *lnl_device) {
   const bool k20 = p->states == 20 && p->rate_cats <= 4;
   if (p->states != 4 && !k20) {
     set_error(40, "rdamd_evaluate_batch: 4-state data, or 20-state data with up to 4 rate categories");
     return RDAMD_FAILURE;
   }
   const unsigned R = p->rate_cats, K = p->states, NP = K * K - K;
-  if (p->sites == 0) {   // an empty alignment has likelihood 1
-    if (lnl_host) std::fill(lnl_host, lnl_host + n_jobs, 0.0);
-    if (lnl_device)
+  std::lock_guard<std::mutex> guard(p->launch_mu);
+  if (slot && slot->pend.active) {
+    set_error(49, "rdamd_evaluate_batch_submit: the slot's last batch has not been waited for");
+    return RDAMD_FAILURE;
+  }
+  RDAMD_HIP_TRY(ensure_workspace(p, slot, std::max(n_jobs, 1u)), RDAMD_FAILURE);
+  FusedWorkspace *w = slot;
+  w->pend = FusedWorkspace::Pending();
+  w->pend.n_jobs = n_jobs; w->pend.k20 = k20; w->pend.host_out = host_out;
+  w->pend.d_out = lnl_device ? (double *)lnl_device : w->d_out;
+  if (n_jobs == 0 || p->sites == 0) {   // an empty alignment has likelihood 1
+    w->pend.active = true;
+    w->pend.n_jobs = p->sites == 0 ? n_jobs : 0;
+    w->pend.seq = 0;
+    if (p->sites == 0 && lnl_device && n_jobs)
       RDAMD_HIP_TRY(hipMemset(lnl_device, 0, sizeof(double) * n_jobs), RDAMD_FAILURE);
     return RDAMD_SUCCESS;
   }
-  RDAMD_HIP_TRY(ensure_workspace(p, n_jobs), RDAMD_FAILURE);
-  FusedWorkspace *w = p->fused;
-  // the pinned input block must not be rewritten while an earlier batch's
-  // copies are still in flight
-  RDAMD_HIP_TRY(hipStreamSynchronize(p->stream), RDAMD_FAILURE);
+  hipStream_t pre = p->stream;
+  if (pipelined) {
+    if (!p->stream_pre) {
+      // high priority: its short kernels must find wave slots WHILE the other slot's evaluator
+      // fills the device (at equal priority they start when that launch ends: measured, the
+      // front half of every batch then sits in the gap between two evaluators)
+      int least = 0, greatest = 0;
+      RDAMD_HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest), RDAMD_FAILURE);
+      RDAMD_HIP_TRY(hipStreamCreateWithPriority(&p->stream_pre, hipStreamNonBlocking, greatest), RDAMD_FAILURE);
+    }
+    if (!w->ev_ready) RDAMD_HIP_TRY(hipEventCreateWithFlags(&w->ev_ready, hipEventDisableTiming), RDAMD_FAILURE);
+    if (!w->ev_done) RDAMD_HIP_TRY(hipEventCreateWithFlags(&w->ev_done, hipEventDisableTiming), RDAMD_FAILURE);
+    pre = p->stream_pre;
+  } else {
+    // the pinned input block must not be rewritten while an earlier batch's
+    // copies are still in flight
+    RDAMD_HIP_TRY(hipStreamSynchronize(p->stream), RDAMD_FAILURE);
+  }
   char *h = w->h_in;
   FusedJob *hj = (FusedJob *)h;          h += sizeof(FusedJob) * n_jobs;
   double *hq = (double *)h;              h += sizeof(double) * K * K * n_jobs;
@@ -482,13 +626,14 @@ static int evaluate_batch_impl(rdamd_partition_t *p, unsigned int n_jobs,
   const size_t tiptab_job = k20 ? (size_t)p->prob_matrices * R * kFused20TabDoubles
                                 : (size_t)p->prob_matrices * R * 64 + (size_t)max_wide * R * 256;
   if (tiptab_job * n_jobs > w->tiptab_doubles) {
-    RDAMD_HIP_TRY(hipStreamSynchronize(p->stream), RDAMD_FAILURE);
+    RDAMD_HIP_TRY(sync_streams(p), RDAMD_FAILURE);
     if (w->d_tiptab) (void)hipFree(w->d_tiptab);
     w->d_tiptab = nullptr;
     w->tiptab_doubles = tiptab_job * std::max(n_jobs, w->cap_jobs);
     RDAMD_HIP_TRY(hipMalloc((void **)&w->d_tiptab, (w->tiptab_doubles + kTiptabPad) * sizeof(double)), RDAMD_FAILURE);
   }
   if (clade_scratch_job * n_jobs > w->clade_scratch_doubles) {
+    RDAMD_HIP_TRY(sync_streams(p), RDAMD_FAILURE);
     if (w->d_clade_scratch) (void)hipFree(w->d_clade_scratch);
     w->d_clade_scratch = nullptr;
     w->clade_scratch_doubles = clade_scratch_job * std::max(n_jobs, w->cap_jobs);
@@ -498,7 +643,7 @@ static int evaluate_batch_impl(rdamd_partition_t *p, unsigned int n_jobs,
     const size_t in_bytes = (size_t)n_jobs * (sizeof(FusedJob) + sizeof(double) * (K * K + K + 2 * R));
     memset(w->h_in + in_bytes, 0, 8);   // the any-unsafe word behind the block
     w->d_any_unsafe = (unsigned *)(w->d_in + in_bytes);
-    RDAMD_HIP_TRY(hipMemcpyAsync(w->d_in, w->h_in, in_bytes + 8, hipMemcpyHostToDevice, p->stream), RDAMD_FAILURE);
+    RDAMD_HIP_TRY(hipMemcpyAsync(w->d_in, w->h_in, in_bytes + 8, hipMemcpyHostToDevice, pre), RDAMD_FAILURE);
     w->d_jobs = (FusedJob *)(w->d_in + ((char *)hj - w->h_in));
     w->d_q = (double *)(w->d_in + ((char *)hq - w->h_in));
     w->d_freqs = (double *)(w->d_in + ((char *)hf - w->h_in));
@@ -506,8 +651,10 @@ static int evaluate_batch_impl(rdamd_partition_t *p, unsigned int n_jobs,
     w->d_rw = (double *)(w->d_in + ((char *)hw - w->h_in));
   }
 
-  double *d_out = lnl_device ? (double *)lnl_device : w->d_out;
+  double *d_out = w->pend.d_out;
   hipError_t e;
+  // (the profiling spans are events on the partition's stream: a pipelined batch keeps the one
+  // around its evaluator)
   if (k20) {
     Fused20Args b;
     b.jobs = w->d_jobs; b.tipcodes = p->d_tipcodes; b.tip_stride = p->tip_stride();
@@ -517,88 +664,125 @@ static int evaluate_batch_impl(rdamd_partition_t *p, unsigned int n_jobs,
     b.freqs = w->d_freqs; b.rate_weights = w->d_rw; b.partials = w->d_partials;
     b.pmat_job_stride = (size_t)p->prob_matrices * R * K * K;
     b.sites = p->sites; b.rate_cats = R; b.tiles = w->blocks_x;
-    p->prof_begin(4);
-    e = launch_fused20_pmatrix(b, w->d_q, w->d_rates, n_jobs, p->prob_matrices, p->stream);
-    p->prof_end();
+    if (!pipelined) p->prof_begin(4);
+    e = launch_fused20_pmatrix(b, w->d_q, w->d_rates, n_jobs, p->prob_matrices, pre);
+    if (!pipelined) p->prof_end();
     RDAMD_HIP_TRY(e, RDAMD_FAILURE);
+    if (pipelined) {
+      RDAMD_HIP_TRY(hipEventRecord(w->ev_ready, pre), RDAMD_FAILURE);
+      RDAMD_HIP_TRY(hipStreamWaitEvent(p->stream, w->ev_ready, 0), RDAMD_FAILURE);
+    }
     p->prof_begin(3);
     e = launch_fused20_eval(b, n_jobs, max_depth[0], d_out, p->stream);
     p->prof_end();
     RDAMD_HIP_TRY(e, RDAMD_FAILURE);
+    if (host_out)
+      RDAMD_HIP_TRY(hipMemcpyAsync(w->h_out, d_out, sizeof(double) * n_jobs, hipMemcpyDeviceToHost, p->stream), RDAMD_FAILURE);
   } else {
-  FusedArgs a;
-  const bool wide_codes = table_rows > 16;
-  a.jobs = w->d_jobs; a.tipcodes = wide_codes ? p->d_codes_wide : p->d_tipcodes16;
-  a.pattern_weights = p->d_pattern_weights;
-  a.table_rows = table_rows;
-  a.rates_across_waves = 0;   // (set below, once the size of the code arena is known)
+    FusedArgs a;
+    const bool wide_codes = table_rows > 16;
+    // (rdamd_set_tip_states drops the 16-bit arena; a 64-row schedule WITHOUT pseudo-tips
+    // survives that call -- its programs only address tip rows -- and finds the arena rebuilt here)
+    if (wide_codes) RDAMD_HIP_TRY(ensure_wide_arena(p), RDAMD_FAILURE);
+    a.jobs = w->d_jobs; a.tipcodes = wide_codes ? p->d_codes_wide : p->d_tipcodes16;
+    a.pattern_weights = p->d_pattern_weights;
+    a.table_rows = table_rows;
+    a.rates_across_waves = 0;   // (set below, once the size of the code arena is known)
 
-  a.tiptab_job_stride = tiptab_job;
-  a.pmat = w->d_pmat; a.tiptab = w->d_tiptab + kTiptabPad; a.freqs = w->d_freqs; a.rate_weights = w->d_rw;
-  a.partials = w->d_partials; a.persite = nullptr;
-  a.any_unsafe = w->d_any_unsafe;
-  a.pmat_job_stride = (size_t)p->prob_matrices * R * 16;
-  a.sites = p->sites; a.rate_cats = R;
-  a.tipcodes_bytes = (unsigned)std::min<size_t>(wide_codes ? (size_t)p->wide_rows * p->tip_stride() * 2
-                                                           : (size_t)p->code_rows * p->tip_stride(), 0xffffffffu);
-  // One wave per rate category (kernels_fused.hip, RW) where re-reading the code arena once
-  // per rate pass is what hurts: when it is far beyond every cache level.  Measured (one
-  // box): c4 (850 MB of codes) 200.6 -> 181.1 ms per launch; c5 (340 MB) 77.9 -> 78.2; c2
-  // (16 MB) 2.88 -> 3.08; 125.phy 1.86 -> 1.80.
-  a.rates_across_waves = R >= 2 && R <= 8 && a.tipcodes_bytes >= (512u << 20);
+    a.tiptab_job_stride = tiptab_job;
+    a.pmat = w->d_pmat; a.tiptab = w->d_tiptab + kTiptabPad; a.freqs = w->d_freqs; a.rate_weights = w->d_rw;
+    a.partials = w->d_partials; a.persite = nullptr;
+    a.any_unsafe = w->d_any_unsafe;
+    a.pmat_job_stride = (size_t)p->prob_matrices * R * 16;
+    a.sites = p->sites; a.rate_cats = R;
+    a.tipcodes_bytes = (unsigned)std::min<size_t>(wide_codes ? (size_t)p->wide_rows * p->tip_stride() * 2
+                                                             : (size_t)p->code_rows * p->tip_stride(), 0xffffffffu);
+    // One wave per rate category (kernels_fused.hip, RW) where re-reading the code arena once
+    // per rate pass is what hurts: when it is far beyond every cache level.  Measured (one
+    // box): c4 (850 MB of codes) 200.6 -> 181.1 ms per launch; c5 (340 MB) 77.9 -> 78.2; c2
+    // (16 MB) 2.88 -> 3.08; 125.phy 1.86 -> 1.80.
+    a.rates_across_waves = R >= 2 && R <= 8 && a.tipcodes_bytes >= (512u << 20);
 #ifdef RDAMD_ABLATION
-  if (getenv("RDAMD_FUSED_RW")) a.rates_across_waves = atoi(getenv("RDAMD_FUSED_RW")) != 0 && R >= 2 && R <= 8;
+    if (getenv("RDAMD_FUSED_RW")) a.rates_across_waves = atoi(getenv("RDAMD_FUSED_RW")) != 0 && R >= 2 && R <= 8;
 #endif
-  p->prof_begin(4);
-  e = launch_fused_pmatrix(a, w->d_q, w->d_rates, n_jobs, p->prob_matrices, p->stream);
-  if (e == hipSuccess && max_groups)   // the pseudo-tips' tables, from the P-matrices and tip tables just made
-    e = launch_clade_tables(a, p->clades->d_maps, w->d_clade_scratch, clade_scratch_job, n_jobs, max_groups,
-                            p->stream);
-  p->prof_end();
-  RDAMD_HIP_TRY(e, RDAMD_FAILURE);
-  p->prof_begin(3);
-  // two sites per lane (kernels_fused.hip) when half the waves still fill the chip:
-  // >= 4 waves for each of the 1024 SIMDs.
-  unsigned ns = (size_t)n_jobs * w->blocks_x >= 8192 ? 2u : 1u;
+    if (!pipelined) p->prof_begin(4);
+    e = launch_fused_pmatrix(a, w->d_q, w->d_rates, n_jobs, p->prob_matrices, pre);
+    if (e == hipSuccess && max_groups)   // the pseudo-tips' tables, from the P-matrices and tip tables just made
+      e = launch_clade_tables(a, p->clades->d_maps, w->d_clade_scratch, clade_scratch_job, n_jobs, max_groups, pre);
+    if (!pipelined) p->prof_end();
+    RDAMD_HIP_TRY(e, RDAMD_FAILURE);
+    if (pipelined) {
+      RDAMD_HIP_TRY(hipEventRecord(w->ev_ready, pre), RDAMD_FAILURE);
+      RDAMD_HIP_TRY(hipStreamWaitEvent(p->stream, w->ev_ready, 0), RDAMD_FAILURE);
+    }
+    p->prof_begin(3);
+    // two sites per lane (kernels_fused.hip) when half the waves still fill the chip:
+    // >= 4 waves for each of the 1024 SIMDs.
+    unsigned ns = (size_t)n_jobs * w->blocks_x >= 8192 ? 2u : 1u;
 #ifdef RDAMD_ABLATION   // A/B runs only (`make ablation`): RDAMD_FUSED_NS=1|2 overrides
-  static const int force_ns = getenv("RDAMD_FUSED_NS") ? atoi(getenv("RDAMD_FUSED_NS")) : 0;
-  if (force_ns) ns = (unsigned)force_ns;
+    static const int force_ns = getenv("RDAMD_FUSED_NS") ? atoi(getenv("RDAMD_FUSED_NS")) : 0;
+    if (force_ns) ns = (unsigned)force_ns;
 #endif
 #ifdef RDAMD_ABLATION   // timing only (results are garbage): what would fewer LDS stack levels / registers buy?
-  if (getenv("RDAMD_FUSED_DEPTH")) max_depth[0] = (unsigned)atoi(getenv("RDAMD_FUSED_DEPTH"));
-  if (getenv("RDAMD_FUSED_RL")) reg_levels[0] = (unsigned)atoi(getenv("RDAMD_FUSED_RL"));
+    if (getenv("RDAMD_FUSED_DEPTH")) max_depth[0] = (unsigned)atoi(getenv("RDAMD_FUSED_DEPTH"));
+    if (getenv("RDAMD_FUSED_RL")) reg_levels[0] = (unsigned)atoi(getenv("RDAMD_FUSED_RL"));
 #endif
-  e = launch_fused_eval(a, n_jobs, max_depth, w->blocks_x, ns, reg_levels, false, d_out, p->stream);
-  p->prof_end();
-  RDAMD_HIP_TRY(e, RDAMD_FAILURE);
-  // The jobs whose tt_unsafe flag went up in this batch (a table entry in (0, 2^-128), a
-  // pseudo-tip class that would have been rescaled: fused.hpp) were skipped by that pass;
-  // the word that says whether there are any comes back with the results, and only then is
-  // the second pass -- plain programs, tip-tip rescale test -- queued over the batch.
-  unsigned *h_flag = (unsigned *)(w->h_out + w->cap_jobs);
-  if (lnl_host)
-    RDAMD_HIP_TRY(hipMemcpyAsync(w->h_out, d_out, sizeof(double) * n_jobs, hipMemcpyDeviceToHost, p->stream), RDAMD_FAILURE);
-  RDAMD_HIP_TRY(hipMemcpyAsync(h_flag, w->d_any_unsafe, sizeof(unsigned), hipMemcpyDeviceToHost, p->stream), RDAMD_FAILURE);
-  RDAMD_HIP_TRY(hipStreamSynchronize(p->stream), RDAMD_FAILURE);
-  if (*h_flag) {
-    p->prof_begin(3);
-    e = launch_fused_eval(a, n_jobs, max_depth, w->blocks_x, ns, reg_levels, true, d_out, p->stream);
+    unsigned *h_flag = (unsigned *)(w->h_out + w->cap_jobs);
+    e = launch_fused_eval(a, n_jobs, max_depth, w->blocks_x, ns, reg_levels, false, d_out,
+                          host_out ? w->h_out : nullptr, h_flag, p->stream);
     p->prof_end();
     RDAMD_HIP_TRY(e, RDAMD_FAILURE);
-    if (lnl_host)
-      RDAMD_HIP_TRY(hipMemcpyAsync(w->h_out, d_out, sizeof(double) * n_jobs, hipMemcpyDeviceToHost, p->stream), RDAMD_FAILURE);
-    RDAMD_HIP_TRY(hipStreamSynchronize(p->stream), RDAMD_FAILURE);
+    // The jobs whose tt_unsafe flag went up in this batch (a table entry in (0, 2^-128), a
+    // pseudo-tip class that would have been rescaled: fused.hpp) were skipped by that pass;
+    // the word that says whether there are any comes back with the results, and only then is
+    // the second pass -- plain programs, tip-tip rescale test -- queued over the batch
+    // (batch_wait).
+    // (results and word are written into the pinned block by the finishing kernel itself)
+    w->pend.a = a; w->pend.ns = ns;
+    for (int k = 0; k < 2; ++k) { w->pend.max_depth[k] = max_depth[k]; w->pend.reg_levels[k] = reg_levels[k]; }
   }
-  if (lnl_host) memcpy(lnl_host, w->h_out, sizeof(double) * n_jobs);
+  if (pipelined) RDAMD_HIP_TRY(hipEventRecord(w->ev_done, p->stream), RDAMD_FAILURE);
+  w->pend.seq = ++p->batch_submitted;
+  w->pend.active = true;
   return RDAMD_SUCCESS;
+}
+
+static int batch_wait(rdamd_partition_t *p, FusedWorkspace *w, bool pipelined, double *lnl_host) {
+  if (!w || !w->pend.active) {
+    set_error(49, "rdamd_evaluate_batch_wait: no batch was submitted on this slot");
+    return RDAMD_FAILURE;
   }
-  if (lnl_host) {
-    RDAMD_HIP_TRY(hipMemcpyAsync(w->h_out, d_out, sizeof(double) * n_jobs, hipMemcpyDeviceToHost, p->stream), RDAMD_FAILURE);
-    RDAMD_HIP_TRY(hipStreamSynchronize(p->stream), RDAMD_FAILURE);
-    memcpy(lnl_host, w->h_out, sizeof(double) * n_jobs);
-  } else {
-    RDAMD_HIP_TRY(hipStreamSynchronize(p->stream), RDAMD_FAILURE);
+  FusedWorkspace::Pending &pd = w->pend;
+  struct done_t {   // whatever happens, the slot is free again afterwards
+    FusedWorkspace::Pending &pd;
+    ~done_t() { pd.active = false; }
+  } done{pd};
+  if (pd.seq == 0) {   // nothing was queued (no jobs / no sites)
+    if (lnl_host && pd.host_out) std::fill(lnl_host, lnl_host + pd.n_jobs, 0.0);
+    return RDAMD_SUCCESS;
   }
+  if (pipelined) RDAMD_HIP_TRY(hipEventSynchronize(w->ev_done), RDAMD_FAILURE);
+  else RDAMD_HIP_TRY(hipStreamSynchronize(p->stream), RDAMD_FAILURE);
+  auto completed = [&] {   // (batches of one stream finish in submission order)
+    uint64_t cur = p->batch_completed.load(std::memory_order_relaxed);
+    while (cur < pd.seq && !p->batch_completed.compare_exchange_weak(cur, pd.seq, std::memory_order_release)) {}
+  };
+  const unsigned *h_flag = (const unsigned *)(w->h_out + w->cap_jobs);
+  if (!pd.k20 && *h_flag) {
+    {
+      std::lock_guard<std::mutex> guard(p->launch_mu);
+      p->prof_begin(3);
+      hipError_t e = launch_fused_eval(pd.a, pd.n_jobs, pd.max_depth, w->blocks_x, pd.ns, pd.reg_levels, true, pd.d_out,
+                                       pd.host_out ? w->h_out : nullptr, nullptr, p->stream);
+      p->prof_end();
+      RDAMD_HIP_TRY(e, RDAMD_FAILURE);
+      if (pipelined) RDAMD_HIP_TRY(hipEventRecord(w->ev_done, p->stream), RDAMD_FAILURE);
+    }
+    if (pipelined) RDAMD_HIP_TRY(hipEventSynchronize(w->ev_done), RDAMD_FAILURE);
+    else RDAMD_HIP_TRY(hipStreamSynchronize(p->stream), RDAMD_FAILURE);
+  }
+  completed();
+  if (lnl_host && pd.host_out) memcpy(lnl_host, w->h_out, sizeof(double) * pd.n_jobs);
   return RDAMD_SUCCESS;
 }
 
@@ -606,7 +790,10 @@ int rdamd_evaluate_batch(rdamd_partition_t *p, unsigned int n_jobs,
                          const rdamd_schedule_t *const *schedules, const double *subst,
                          const double *freqs, const double *rates,
                          const double *rate_weights, double *lnl_out) {
-  return evaluate_batch_impl(p, n_jobs, schedules, subst, freqs, rates, rate_weights, lnl_out, nullptr);
+  clear_error();
+  if (batch_submit(p, p->fused, false, n_jobs, schedules, subst, freqs, rates, rate_weights, true, nullptr) != RDAMD_SUCCESS)
+    return RDAMD_FAILURE;
+  return batch_wait(p, p->fused, false, lnl_out);
 }
 
 int rdamd_evaluate_batch_device(rdamd_partition_t *p, unsigned int n_jobs,
@@ -614,7 +801,31 @@ int rdamd_evaluate_batch_device(rdamd_partition_t *p, unsigned int n_jobs,
                                 const double *subst, const double *freqs,
                                 const double *rates, const double *rate_weights,
                                 void *d_lnl_out) {
-  return evaluate_batch_impl(p, n_jobs, schedules, subst, freqs, rates, rate_weights, nullptr, d_lnl_out);
+  clear_error();
+  if (batch_submit(p, p->fused, false, n_jobs, schedules, subst, freqs, rates, rate_weights, false, d_lnl_out) != RDAMD_SUCCESS)
+    return RDAMD_FAILURE;
+  return batch_wait(p, p->fused, false, nullptr);
+}
+
+int rdamd_evaluate_batch_submit(rdamd_partition_t *p, unsigned int slot, unsigned int n_jobs,
+                                const rdamd_schedule_t *const *schedules,
+                                const double *subst, const double *freqs,
+                                const double *rates, const double *rate_weights) {
+  clear_error();
+  if (slot > 1) {
+    set_error(49, "rdamd_evaluate_batch_submit: slot %u (a partition has slots 0 and 1)", slot);
+    return RDAMD_FAILURE;
+  }
+  return batch_submit(p, slot ? p->fused1 : p->fused, true, n_jobs, schedules, subst, freqs, rates, rate_weights, true, nullptr);
+}
+
+int rdamd_evaluate_batch_wait(rdamd_partition_t *p, unsigned int slot, double *lnl_out) {
+  clear_error();
+  if (slot > 1) {
+    set_error(49, "rdamd_evaluate_batch_wait: slot %u (a partition has slots 0 and 1)", slot);
+    return RDAMD_FAILURE;
+  }
+  return batch_wait(p, slot ? p->fused1 : p->fused, true, lnl_out);
 }
 
 }  // extern "C"

@@ -126,9 +126,12 @@ hipError_t launch_fused_pmatrix(const FusedArgs &a, const double *d_q, const dou
 // unsafe_pass: false = the jobs whose tt_unsafe flag is down (programs with pseudo-tips, no
 // tip-tip rescale test), true = the others (plain programs, with the test).  The caller runs
 // the second pass only when FusedArgs::any_unsafe came back set.
+// h_out / h_flag (pinned host memory, or null): the finishing kernel writes the results and the
+// batch's any-unsafe word there as well -- no copy launches behind the batch.
 hipError_t launch_fused_eval(const FusedArgs &a, unsigned n_jobs, const unsigned max_depth[2],
                              unsigned blocks_x, unsigned sites_per_lane, const unsigned reg_levels[2],
-                             bool unsafe_pass, double *d_out, hipStream_t stream);
+                             bool unsafe_pass, double *d_out, double *h_out, unsigned *h_flag,
+                             hipStream_t stream);
 
 
 }  // namespace rdamd

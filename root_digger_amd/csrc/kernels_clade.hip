@@ -56,15 +56,22 @@ unsigned clade_intern(rdamd_partition *p, unsigned child0, unsigned child1, unsi
 // the code arenas: rows of tip_stride() entries, grown geometrically (programs hold row
 // OFFSETS).  wide = false: the 8-bit arena every 4-state partition has (d_tipcodes16);
 // wide = true: its 16-bit twin for schedules with 64-row tables.
+// Returns hipErrorOutOfMemory with p->code_arena_full set when `rows` rows cannot be addressed
+// with 32-bit byte offsets (the caller then compiles without pseudo-tips); growth is geometric
+// but never asks for more than the offsets can reach.
 static hipError_t ensure_code_rows(rdamd_partition *p, unsigned rows, bool wide) {
   uint8_t *&arena = wide ? p->d_codes_wide : p->d_tipcodes16;
   unsigned &used = wide ? p->wide_rows : p->code_rows;
   unsigned &have = wide ? p->wide_rows_cap : p->code_rows_cap;
   if (rows <= have) return hipSuccess;
-  const unsigned cap = std::max(rows, have + have / 2 + 16);
   const size_t stride = (size_t)p->tip_stride() * (wide ? 2 : 1);
-  if ((size_t)cap * stride + kTipcodePad > 0xffffffffull) return hipErrorOutOfMemory;   // 32-bit offsets
-  hipError_t e = hipStreamSynchronize(p->stream);
+  const size_t max_rows = (0xffffffffull - kTipcodePad) / stride;   // 32-bit offsets
+  if (rows > max_rows) {
+    p->code_arena_full = true;
+    return hipErrorOutOfMemory;
+  }
+  const unsigned cap = (unsigned)std::min<size_t>(std::max<size_t>(rows, (size_t)have + have / 2 + 16), max_rows);
+  hipError_t e = sync_streams(p);
   if (e != hipSuccess) return e;
   uint8_t *fresh = nullptr;
   e = hipMalloc(&fresh, (size_t)cap * stride + kTipcodePad);
@@ -86,12 +93,21 @@ static hipError_t upload_wide_row(rdamd_partition *p, unsigned row, const uint8_
                    hipMemcpyHostToDevice);
 }
 
+// The 16-bit arena with every tip's row in place.  rdamd_set_tip_states drops the arena; it is
+// rebuilt from the host copy here, by the next schedule that is compiled or the next batch that
+// runs a 64-row schedule.  A failure half way leaves NO arena (never one with missing tip rows).
 hipError_t ensure_wide_arena(rdamd_partition *p) {
-  if (p->d_codes_wide) return hipSuccess;
+  if (p->d_codes_wide && p->wide_rows >= p->tips) return hipSuccess;
   hipError_t e = ensure_code_rows(p, p->tips, true);
   for (unsigned t = 0; t < p->tips && e == hipSuccess; ++t)
     e = upload_wide_row(p, t, p->tipcodes.data() + (size_t)t * p->sites);
-  if (e == hipSuccess) p->wide_rows = p->tips;
+  if (e == hipSuccess) {
+    p->wide_rows = p->tips;
+  } else {
+    if (p->d_codes_wide) (void)hipFree(p->d_codes_wide);
+    p->d_codes_wide = nullptr;
+    p->wide_rows = p->wide_rows_cap = 0;
+  }
   return e;
 }
 
@@ -122,7 +138,7 @@ hipError_t clade_upload_map(rdamd_partition *p, unsigned id) {
   const size_t bytes = (n.cmap.size() + 3) & ~(size_t)3;
   if (c.maps_used + bytes > c.maps_cap) {
     const size_t cap = std::max<size_t>(c.maps_used + bytes, c.maps_cap * 2 + 4096);
-    hipError_t e = hipStreamSynchronize(p->stream);
+    hipError_t e = sync_streams(p);
     if (e != hipSuccess) return e;
     uint8_t *fresh = nullptr;
     e = hipMalloc(&fresh, cap);
@@ -158,8 +174,11 @@ hipError_t clade_upload_map(rdamd_partition *p, unsigned id) {
 // pseudo-tip of up to 16 classes lands in its branch's 16-row table, in the tip tables'
 // layout ([class][state]); one of up to 64 classes in its own 64-row table, stored as the
 // evaluator's LDS slot image ([half][class][2 states]: the table goes to LDS by DMA).
+// (One wave per workgroup whatever the table size: the launch runs beside the evaluator of the
+// batch in front of it, whose one-wave workgroups fill the device -- a four-wave workgroup
+// waits until four slots of one CU are free at once, a wave takes the first that opens.)
 template <int ROWS>
-__global__ void __launch_bounds__(ROWS == 16 ? 64 : 256)
+__global__ void __launch_bounds__(64)
 clade_table_kernel(FusedJob *__restrict__ jobs, const uint8_t *__restrict__ maps,
                    const double *__restrict__ pmat, double *__restrict__ tiptab, size_t pmat_job_stride,
                    size_t tiptab_job_stride, double *__restrict__ scratch, size_t scratch_job_stride, unsigned R,
@@ -230,7 +249,7 @@ hipError_t launch_clade_tables(const FusedArgs &a, const uint8_t *d_maps, double
                                hipStream_t stream) {
   if (!n_jobs || !max_groups) return hipSuccess;
   if (a.table_rows > 16)
-    clade_table_kernel<64><<<dim3(max_groups, n_jobs), 256, 0, stream>>>(
+    clade_table_kernel<64><<<dim3(max_groups, n_jobs), 64, 0, stream>>>(
         const_cast<FusedJob *>(a.jobs), d_maps, a.pmat, const_cast<double *>(a.tiptab), a.pmat_job_stride,
         a.tiptab_job_stride, d_scratch, scratch_job_stride, a.rate_cats, a.any_unsafe);
   else

@@ -28,9 +28,21 @@
 #include <cstdlib>
 
 #include "common.hpp"
+#include "expm_k4.hpp"
 #include "fused.hpp"
 
 namespace rdamd {
+
+// A job's value must not depend on the kernel variant that happens to run it -- the sites per
+// lane follow the launch size, the stack form the deepest program of the launch, and the
+// lock-stepped search (batch_combiner.hpp) must walk the sequential search's trajectories bit
+// for bit whatever its launches look like.  Left to itself the compiler contracts a * b + c
+// into fused multiply-adds per instantiation, and not always the same pairs (round 3: six of
+// them in the variant with the tip-tip rescale test; round 4: one job in 160 between one and
+// two sites per lane).  So the evaluator's arithmetic is spelled out -- every fused
+// multiply-add is an explicit fma() -- and contraction is off from here to the end of the
+// evaluator kernel.
+#pragma clang fp contract(off)
 
 // exact 2^(-256 * d) for d >= 0 (0 once it underflows)
 __device__ __forceinline__ double pow2_neg256(int d) {
@@ -74,7 +86,8 @@ __device__ __forceinline__ void matvec(const double *__restrict__ p, const doubl
                                        double (&t)[4]) {
 #pragma unroll
   for (int k = 0; k < 4; ++k)
-    t[k] = p[k * 4 + 0] * x[0] + p[k * 4 + 1] * x[1] + p[k * 4 + 2] * x[2] + p[k * 4 + 3] * x[3];
+    t[k] = __builtin_fma(p[k * 4 + 3], x[3],
+                         __builtin_fma(p[k * 4 + 2], x[2], __builtin_fma(p[k * 4 + 1], x[1], p[k * 4 + 0] * x[0])));
 }
 
 // A tip-table row, addressed by its LDS byte offset.  A table (16 codes x 4 states)
@@ -549,8 +562,8 @@ fused_dna_eval_kernel(FusedArgs a) {
     const double w = rw[r];
 #pragma unroll
     for (int q = 0; q < NS; ++q) {
-      double f = st.v[q][0] * freqs[0] + st.v[q][1] * freqs[1] + st.v[q][2] * freqs[2] +
-                 st.v[q][3] * freqs[3];
+      double f = __builtin_fma(st.v[q][3], freqs[3],
+                               __builtin_fma(st.v[q][2], freqs[2], __builtin_fma(st.v[q][1], freqs[1], st.v[q][0] * freqs[0])));
       f *= w;
       if (RW) {   // (folded below, by wave 0, once all rates have arrived)
         term[q] = f;
@@ -559,9 +572,9 @@ fused_dna_eval_kernel(FusedArgs a) {
         term[q] = f;
         smin[q] = st.sc[q];
       } else if (st.sc[q] >= smin[q]) {
-        term[q] += f * pow2_neg256(st.sc[q] - smin[q]);
+        term[q] = __builtin_fma(f, pow2_neg256(st.sc[q] - smin[q]), term[q]);
       } else {
-        term[q] = term[q] * pow2_neg256(smin[q] - st.sc[q]) + f;
+        term[q] = __builtin_fma(term[q], pow2_neg256(smin[q] - st.sc[q]), f);
         smin[q] = st.sc[q];
       }
     }
@@ -592,9 +605,9 @@ fused_dna_eval_kernel(FusedArgs a) {
         const double f = yf[q * 64];
         const int sc = ys[q * 64];
         if (sc >= smin[q]) {
-          term[q] += f * pow2_neg256(sc - smin[q]);
+          term[q] = __builtin_fma(f, pow2_neg256(sc - smin[q]), term[q]);
         } else {
-          term[q] = term[q] * pow2_neg256(smin[q] - sc) + f;
+          term[q] = __builtin_fma(term[q], pow2_neg256(smin[q] - sc), f);
           smin[q] = sc;
         }
       }
@@ -606,7 +619,7 @@ fused_dna_eval_kernel(FusedArgs a) {
   // in the same order either way.
 #pragma unroll
   for (int q = 0; q < NS; ++q) {
-    double l = log(term[q]) + (double)smin[q] * kLogScaleThreshold;
+    double l = __builtin_fma((double)smin[q], kLogScaleThreshold, log(term[q]));
     l *= (double)a.pattern_weights[site[q]];
     if (!valid[q]) l = 0.0;
     if (a.persite && valid[q]) a.persite[(size_t)job * S + site[q]] = l;
@@ -616,11 +629,21 @@ fused_dna_eval_kernel(FusedArgs a) {
   }
 }
 
-// fixed-order finish, one workgroup per job
+#pragma clang fp contract(fast)   // (the kernels below keep the compiler's default)
+
+// fixed-order finish, one workgroup per job.  A job belongs to exactly one of the two passes
+// (FusedJob::tt_unsafe): the other pass's workgroups returned at once and left no partials, so
+// its result is not touched -- `out` never holds a value made from stale partials.
 __global__ void __launch_bounds__(256)
 fused_finish_kernel(const double *__restrict__ partials, unsigned per_job,
-                    double *__restrict__ out) {
+                    const FusedJob *__restrict__ jobs, unsigned unsafe_pass,
+                    double *__restrict__ out, double *__restrict__ host_out,
+                    const unsigned *__restrict__ any_unsafe, unsigned *__restrict__ host_flag) {
   __shared__ double lds[4];
+  // (host_out / host_flag: pinned host memory, written from here -- the results and the word
+  // that says whether the second pass is needed arrive with the kernel's end, no copy launches)
+  if (host_flag && blockIdx.x == 0 && threadIdx.x == 0) *host_flag = *any_unsafe;
+  if ((jobs[blockIdx.x].tt_unsafe != 0u) != (unsafe_pass != 0u)) return;
   const double *p = partials + (size_t)blockIdx.x * per_job;
   double acc = 0.0;
   for (unsigned i = threadIdx.x; i < per_job; i += 256) acc += p[i];
@@ -628,118 +651,68 @@ fused_finish_kernel(const double *__restrict__ partials, unsigned per_job,
   for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
   if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = acc;
   __syncthreads();
-  if (threadIdx.x == 0) out[blockIdx.x] = ((lds[0] + lds[1]) + lds[2]) + lds[3];
+  if (threadIdx.x == 0) {
+    const double v = ((lds[0] + lds[1]) + lds[2]) + lds[3];
+    out[blockIdx.x] = v;
+    if (host_out) host_out[blockIdx.x] = v;
+  }
 }
 
-// P-matrices for a batch of jobs: one thread per (job, matrix, rate).
-// Same scaling-and-squaring / 16-term Taylor core as pmatrix_k4_kernel.
+// P-matrices and tip tables for a batch of jobs: 16 lanes per (job, matrix, rate) problem, a
+// lane per matrix element (expm_k4_coop16: pmatrix_k4_kernel's arithmetic, element by
+// element); a wave works off 64 problems, four at a time.  No LDS and ~40 registers: the
+// launch runs beside the evaluator of the batch in front of it (evaluate.hip, pipelined
+// batches) and its waves must fit the slots that launch's waves leave -- the one-lane-per-
+// problem form (128 registers for the matrix, 9.7 KB of LDS to turn the results into
+// contiguous stores) did not, and sat between the evaluators instead of beside them
+// (profiles/micro/side_kernel_latency.hip).  Every store instruction writes 128 contiguous
+// bytes per problem; the values are the same bits as before.
 __global__ void __launch_bounds__(64)
 fused_pmatrix_k4_kernel(const double *__restrict__ q, const double *__restrict__ rates,
                         FusedJob *__restrict__ jobs, unsigned n_jobs,
                         unsigned n_mat, unsigned R, double *__restrict__ pmat,
                         double *__restrict__ tiptab, size_t pmat_job_stride, size_t tiptab_job_stride,
                         unsigned table_rows, unsigned *__restrict__ any_unsafe) {
-  // the wave's 64 results, for the cooperative stores below ([problem][17]: no bank conflict
-  // when every lane reads its own row)
-  __shared__ double sh[64 * 17];
-  __shared__ unsigned long long base_pm[64], base_tt[64];
-  const unsigned lane = threadIdx.x;
+  const unsigned lane = threadIdx.x, e = lane & 15u;
+  const int base = (int)(lane & ~15u);
   const size_t per_job = (size_t)n_mat * R;
   const size_t total = per_job * n_jobs;
-  const size_t gid_raw = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const bool live = gid_raw < total;
-  const size_t gid = live ? gid_raw : total - 1;   // (idle lanes of the last wave repeat its last problem)
-  const unsigned job = (unsigned)(gid / per_job);
-  const unsigned rem = (unsigned)(gid % per_job);
-  const unsigned m = rem / R, r = rem % R;
-  const double t = jobs[job].brlen[m] * rates[(size_t)job * R + r];
-  const double *qq = q + (size_t)job * 16;
-  double x[16], term[16], out[16], tmp[16];
-  double norm = 0.0;
+  for (unsigned pass = 0; pass < 16; ++pass) {
+    const size_t first = (size_t)blockIdx.x * 64 + pass * 4;
+    if (first >= total) break;   // (wave-uniform)
+    const size_t gid_raw = first + (lane >> 4);
+    const bool live = gid_raw < total;
+    const size_t gid = live ? gid_raw : total - 1;   // (idle groups of the last wave repeat its last problem)
+    const unsigned job = (unsigned)(gid / per_job);
+    const unsigned rem = (unsigned)(gid % per_job);
+    const unsigned m = rem / R, r = rem % R;
+    const double t = jobs[job].brlen[m] * rates[(size_t)job * R + r];
+    double v = expm_k4_coop16(q + (size_t)job * 16, t);
+    v = v <= 0.0 ? 0.0 : v;   // (<=: a -0.0 becomes +0.0 -- the rescale tests read high words)
+    if (live) pmat[(size_t)job * pmat_job_stride + ((size_t)m * R + r) * 16 + e] = v;
+    // tip table of the (matrix, rate): row c = sum over the states in code c; this lane's four
+    // of its 64 entries (64-row launches: the evaluator's LDS image, [half][code][2 states] -- it
+    // goes there by DMA; 16-row launches: [code][state])
+    double *tt = tiptab + (size_t)job * tiptab_job_stride + ((size_t)m * R + r) * 64;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    double cs = 0.0;
+    for (unsigned k = 0; k < 4; ++k) {
+      const unsigned L = e + 16u * k;
+      const unsigned c = table_rows > 16 ? (L >> 1) & 15u : L >> 2;
+      const unsigned i = table_rows > 16 ? (L >> 5) * 2 + (L & 1u) : L & 3u;
+      double acc = 0.0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      x[i * 4 + j] = qq[i * 4 + j] * t;
-      cs += fabs(x[i * 4 + j]);
+      for (int j = 0; j < 4; ++j) {
+        const double pj = __shfl(v, base + (int)i * 4 + j);
+        if ((c >> j) & 1) acc += pj;
+      }
+      if (live) tt[L] = acc;
     }
-    norm = fmax(norm, cs);
-  }
-  int s = 0;
-  double scale = 1.0;
-  while (norm * scale > 0.25 && s < 60) { scale *= 0.5; ++s; }
-#pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    x[i] *= scale;
-    term[i] = out[i] = (i % 5 == 0) ? 1.0 : 0.0;
-  }
-  for (int k = 1; k <= 16; ++k) {
-    const double inv = 1.0 / (double)k;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        double acc = 0.0;
-#pragma unroll
-        for (int l = 0; l < 4; ++l) acc += term[i * 4 + l] * x[l * 4 + j];
-        tmp[i * 4 + j] = acc * inv;
-      }
-#pragma unroll
-    for (int i = 0; i < 16; ++i) { term[i] = tmp[i]; out[i] += tmp[i]; }
-  }
-  for (int k = 0; k < s; ++k) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        double acc = 0.0;
-#pragma unroll
-        for (int l = 0; l < 4; ++l) acc += out[i * 4 + l] * out[l * 4 + j];
-        tmp[i * 4 + j] = acc;
-      }
-#pragma unroll
-    for (int i = 0; i < 16; ++i) out[i] = tmp[i];
-  }
-  // Stores: a thread's own 16 + 64 doubles would go out as 80 instructions of 64 lanes x 8
-  // bytes, 512 bytes apart -- 64 cache lines each (235 MB of HBM traffic for 100 MB of data
-  // on c2).  Instead the wave parks its results in LDS and writes problem by problem, a lane
-  // per element: 512 contiguous bytes per instruction.
-#pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    out[i] = out[i] <= 0.0 ? 0.0 : out[i];   // (<=: a -0.0 becomes +0.0 -- the rescale tests read high words)
-    sh[lane * 17 + i] = out[i];
-  }
-  base_pm[lane] = (unsigned long long)job * pmat_job_stride + ((size_t)m * R + r) * 16;
-  base_tt[lane] = (unsigned long long)job * tiptab_job_stride + ((size_t)m * R + r) * 64;
-  __syncthreads();
-  const unsigned n_live = (unsigned)(total - (size_t)blockIdx.x * 64 < 64 ? total - (size_t)blockIdx.x * 64 : 64);
-#pragma unroll 4
-  for (unsigned it = 0; it < 16; ++it) {   // P: four problems per instruction
-    const unsigned e = it * 64 + lane, pr = e >> 4, k = e & 15u;
-    if (pr < n_live) pmat[base_pm[pr] + k] = sh[pr * 17 + k];
-  }
-  // tip table of a (matrix, rate): row c = sum over the states in code c; my element of every
-  // problem's table (64-row launches: the evaluator's LDS image, [half][code][2 states] -- it
-  // goes there by DMA; 16-row launches: [code][state])
-  const unsigned c = table_rows > 16 ? (lane >> 1) & 15u : lane >> 2;
-  const unsigned i = table_rows > 16 ? (lane >> 5) * 2 + (lane & 1u) : lane & 3u;
-  for (unsigned pr = 0; pr < n_live; ++pr) {
-    const double *o = sh + pr * 17 + i * 4;
-    double acc = 0.0;
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-      if ((c >> j) & 1) acc += o[j];
-    tiptab[base_tt[pr] + lane] = acc;
-  }
-  // every table entry is a sum of P entries, so the smallest non-zero P entry bounds
-  // them all from below (FusedJob::tt_unsafe; 2^-128 = 0x1p-128)
-  bool tiny = false;
-#pragma unroll
-  for (int k = 0; k < 16; ++k) tiny = tiny || (out[k] > 0.0 && out[k] < 0x1p-128);
-  if (tiny) {
-    jobs[job].tt_unsafe = 1u;   // (every writer stores the same value)
-    *any_unsafe = 1u;
+    // every table entry is a sum of P entries, so the smallest non-zero P entry bounds
+    // them all from below (FusedJob::tt_unsafe; 2^-128 = 0x1p-128)
+    if (live && v > 0.0 && v < 0x1p-128) {
+      jobs[job].tt_unsafe = 1u;   // (every writer stores the same value)
+      *any_unsafe = 1u;
+    }
   }
 }
 
@@ -818,24 +791,24 @@ static hipError_t launch_fused_variant_rl(const FusedArgs &a, unsigned n_jobs, u
 template <int NS, int TR>
 static hipError_t launch_fused_eval_ns(const FusedArgs &a, unsigned n_jobs, const unsigned max_depth[2],
                                        unsigned blocks_x, const unsigned reg_levels[2], bool unsafe_pass,
-                                       double *d_out, hipStream_t stream) {
+                                       double *d_out, double *h_out, unsigned *h_flag, hipStream_t stream) {
   const unsigned gx = (blocks_x + NS - 1) / NS;   // blocks_x counts 64-site blocks
   hipError_t e = unsafe_pass ? launch_fused_variant_rl<NS, true, TR>(a, n_jobs, max_depth[1], gx, reg_levels[1], stream)
                              : launch_fused_variant_rl<NS, false, TR>(a, n_jobs, max_depth[0], gx, reg_levels[0], stream);
   if (e != hipSuccess) return e;
-  fused_finish_kernel<<<n_jobs, 256, 0, stream>>>(a.partials, gx * NS, d_out);   // 64-site blocks per job
+  fused_finish_kernel<<<n_jobs, 256, 0, stream>>>(a.partials, gx * NS, a.jobs, unsafe_pass ? 1u : 0u, d_out, h_out, a.any_unsafe, h_flag);   // 64-site blocks per job
   return hipGetLastError();
 }
 
 hipError_t launch_fused_eval(const FusedArgs &a, unsigned n_jobs, const unsigned max_depth[2],
                              unsigned blocks_x, unsigned sites_per_lane, const unsigned reg_levels[2],
-                             bool unsafe_pass, double *d_out, hipStream_t stream) {
+                             bool unsafe_pass, double *d_out, double *h_out, unsigned *h_flag, hipStream_t stream) {
   if (!n_jobs) return hipSuccess;
   if (a.table_rows > 16)   // 16-bit code arena, 64-row table slots
-    return sites_per_lane == 2 ? launch_fused_eval_ns<2, 64>(a, n_jobs, max_depth, blocks_x, reg_levels, unsafe_pass, d_out, stream)
-                               : launch_fused_eval_ns<1, 64>(a, n_jobs, max_depth, blocks_x, reg_levels, unsafe_pass, d_out, stream);
-  return sites_per_lane == 2 ? launch_fused_eval_ns<2, 16>(a, n_jobs, max_depth, blocks_x, reg_levels, unsafe_pass, d_out, stream)
-                             : launch_fused_eval_ns<1, 16>(a, n_jobs, max_depth, blocks_x, reg_levels, unsafe_pass, d_out, stream);
+    return sites_per_lane == 2 ? launch_fused_eval_ns<2, 64>(a, n_jobs, max_depth, blocks_x, reg_levels, unsafe_pass, d_out, h_out, h_flag, stream)
+                               : launch_fused_eval_ns<1, 64>(a, n_jobs, max_depth, blocks_x, reg_levels, unsafe_pass, d_out, h_out, h_flag, stream);
+  return sites_per_lane == 2 ? launch_fused_eval_ns<2, 16>(a, n_jobs, max_depth, blocks_x, reg_levels, unsafe_pass, d_out, h_out, h_flag, stream)
+                             : launch_fused_eval_ns<1, 16>(a, n_jobs, max_depth, blocks_x, reg_levels, unsafe_pass, d_out, h_out, h_flag, stream);
 }
 
 }  // namespace rdamd

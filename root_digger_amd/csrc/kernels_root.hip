@@ -216,64 +216,76 @@ finish_sum_kernel(const double *__restrict__ partials, unsigned n, double *__res
 // launch-latency, not bandwidth: one launch + one stream wait instead of three
 // copies, three launches and a copy back.
 // ---------------------------------------------------------------------------
-// (the body: `bid` of `nblocks` workgroups work on one root operation -- the whole grid of
-// root_single_dna_kernel, one row of root_multi_dna_kernel's)
-template <int R, int NA>
+// (the body: wave `w` of virtual block `bid` of `nblocks` works on one root operation -- the
+// whole grid of root_single_dna_kernel, one row of root_multi_dna_kernel's)
+//
+// ONE WAVE PER WORKGROUP.  The arithmetic is laid out over "virtual blocks" of 256 lanes --
+// grid shape, per-lane accumulation order and reduction tree of root_lnl_group_kernel, so every
+// value has that kernel's bits -- but each of a block's four waves is a workgroup of its own
+// (blockIdx.x = 4 bid + w) and the four wave sums meet in the final fold instead of in LDS.
+// Why: these launches run BESIDE the fused evaluator's (the lock-stepped search, model.cpp),
+// whose one-wave workgroups fill every wave slot of the device; a 256-lane workgroup starts
+// only once four slots of one CU are free at the same moment -- the scheduler holds freed
+// slots idle until then -- and a root step that takes 24 us alone cost the evaluator seven
+// times that (profiles/r4_e2e_*).  A one-wave workgroup takes the first slot that opens.
+template <int R>
 __device__ __forceinline__ void
 root_single_body(const DeviceView &v, const LevelOp &op, const RootSingleArgs &ra, const double *__restrict__ q,
                  const double *__restrict__ rates, const double *__restrict__ freqs,
                  const double *__restrict__ rate_w, const unsigned *__restrict__ pw,
                  const uint64_t *__restrict__ codemask, double *__restrict__ partials,
                  unsigned *__restrict__ counter, double *__restrict__ result, const unsigned bid,
-                 const unsigned nblocks) {
-  __shared__ double spm[NA][2][R][16];     // P-matrices
-  __shared__ double smat[NA][2][R * 64];   // what the site loop reads: P (inner child) or tip table
-  __shared__ double lds[4];
-  __shared__ unsigned ticket;
-  const unsigned tid = threadIdx.x, S = v.sites;
+                 const unsigned w, const unsigned nblocks) {
+  constexpr unsigned kMaxPos = R <= 4 ? 8u : 4u;   // root_single_max_positions(R)
+  __shared__ double spm[kMaxPos][2][R][16];        // P-matrices, 8 KB
+  const unsigned lane = threadIdx.x, tid = w * 64u + lane, S = v.sites;   // tid: lane of the virtual block
+  const unsigned NA = (unsigned)__builtin_amdgcn_readfirstlane((int)ra.n_positions);
   const bool tip1 = op.child1_clv < v.tips, tip2 = op.child2_clv < v.tips;
-  if (tid < NA * 2 * R) {
-    const unsigned a = tid / (2 * R), c = (tid / R) & 1u, r = tid % R;
-    double out[16];
-    expm_k4(q + (size_t)ra.params_idx[r] * 16, (c ? ra.len2[a] : ra.len1[a]) * rates[r], out);
+  // (`ra` may be a kernel argument: a per-lane index into its arrays would make the compiler
+  // copy the whole record into every lane's private memory -- selects over constant indices
+  // read it where it is)
+  auto pidx_of = [&](unsigned r) {
+    unsigned x = ra.params_idx[0];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) spm[a][c][r][i] = out[i] <= 0.0 ? 0.0 : out[i];
+    for (int k = 1; k < R; ++k) x = r == (unsigned)k ? ra.params_idx[k] : x;
+    return x;
+  };
+  auto len_of = [&](unsigned a, unsigned c) {
+    double x = c ? ra.len2[0] : ra.len1[0];
+#pragma unroll
+    for (unsigned k = 1; k < kMaxPos; ++k) x = a == k ? (c ? ra.len2[k] : ra.len1[k]) : x;
+    return x;
+  };
+  // the NA x 2 x R matrices, four at a time: 16 lanes per matrix, a lane per element
+  // (expm_k4_coop16: pmatrix_k4_kernel's arithmetic without its 128 registers)
+  for (unsigned m0 = 0; m0 < NA * 2 * R; m0 += 4) {
+    const unsigned m = m0 + (lane >> 4);
+    const bool have = m < NA * 2 * R;
+    const unsigned mm = have ? m : 0u;
+    const unsigned a = mm / (2 * R), c = (mm / R) & 1u, r = mm % R;
+    const double e = expm_k4_coop16(q + (size_t)pidx_of(r) * 16, have ? len_of(a, c) * rates[r] : 0.0);
+    if (have) spm[a][c][r][lane & 15u] = e <= 0.0 ? 0.0 : e;
   }
   __syncthreads();
-  for (unsigned e = tid; e < NA * 2 * R * 64; e += 256) {
-    const unsigned a = e / (2 * R * 64), c = (e / (R * 64)) & 1u, w = e % (R * 64);
-    const bool tip = c ? tip2 : tip1;
-    if (tip) {   // tiptab[r][code][i] = sum_j P[r][i][j] * bit_j(code), pmatrix_k4_kernel's order
-      const unsigned r = w / 64, code = (w / 4) & 15u, i = w & 3u;
-      const uint64_t mask = codemask[code];
-      double acc = 0.0;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc += ((mask >> j) & 1) ? spm[a][c][r][i * 4 + j] : 0.0;
-      smat[a][c][w] = acc;
-    } else if (w < R * 16) {
-      smat[a][c][w] = spm[a][c][w / 16][w % 16];
-    }
-  }
   // the state contract: the LAST position's matrices (and their tip tables) are
   // what rdamd_update_prob_matrices would have left in the partition
   if (bid == 0) {
     for (unsigned e = tid; e < 2 * R * 16; e += 256) {
-      const unsigned c = e / (R * 16), w = e % (R * 16);
+      const unsigned c = e / (R * 16), ww = e % (R * 16);
       const unsigned m = c ? op.child2_mat : op.child1_mat;
-      v.pmat[(size_t)m * R * 16 + w] = spm[NA - 1][c][w / 16][w % 16];
+      v.pmat[(size_t)m * R * 16 + ww] = spm[NA - 1][c][ww / 16][ww % 16];
     }
     for (unsigned e = tid; e < 2 * R * 64; e += 256) {
-      const unsigned c = e / (R * 64), w = e % (R * 64);
+      const unsigned c = e / (R * 64), ww = e % (R * 64);
       const unsigned m = c ? op.child2_mat : op.child1_mat;
-      const unsigned r = w / 64, code = (w / 4) & 15u, i = w & 3u;
+      const unsigned r = ww / 64, code = (ww / 4) & 15u, i = ww & 3u;
       const uint64_t mask = codemask[code];
       double acc = 0.0;
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc += ((mask >> j) & 1) ? spm[NA - 1][c][r][i * 4 + j] : 0.0;
-      v.tiptab[(size_t)m * R * 64 + w] = acc;
+      v.tiptab[(size_t)m * R * 64 + ww] = acc;
     }
   }
-  __syncthreads();
 
   const size_t total = (size_t)S * R, stride = (size_t)nblocks * 256;
   const double2 *c1 = tip1 ? nullptr
@@ -287,41 +299,47 @@ root_single_body(const DeviceView &v, const LevelOp &op, const RootSingleArgs &r
   const unsigned *lsc = op.child1_sc >= 0 ? v.scaler + (size_t)op.child1_sc * S : nullptr;
   const unsigned *rsc = op.child2_sc >= 0 ? v.scaler + (size_t)op.child2_sc * S : nullptr;
 
-  double acc[NA];
-#pragma unroll
-  for (int a = 0; a < NA; ++a) acc[a] = 0.0;
-  for (size_t idx = (size_t)bid * 256 + tid; idx < total; idx += stride) {
-    const unsigned s = (unsigned)(idx / R), r = (unsigned)(idx % R);
-    double x[4] = {0, 0, 0, 0}, y[4] = {0, 0, 0, 0};
-    unsigned cx = 0, cy = 0;
-    if (tip1) cx = code1[s];
-    else { const double2 a = c1[idx * 2], b = c1[idx * 2 + 1]; x[0] = a.x; x[1] = a.y; x[2] = b.x; x[3] = b.y; }
-    if (tip2) cy = code2[s];
-    else { const double2 a = c2[idx * 2], b = c2[idx * 2 + 1]; y[0] = a.x; y[1] = a.y; y[2] = b.x; y[3] = b.y; }
-    const unsigned sc0 = (lsc ? lsc[s] : 0u) + (rsc ? rsc[s] : 0u);
-    const double *f = freqs + (size_t)ra.params_idx[r] * 4;
-    const double w = rate_w[r];
-    const double weight = (double)pw[s];
-    const int base = (int)(threadIdx.x & 63) & ~(R - 1);
-#pragma unroll
-    for (int a = 0; a < NA; ++a) {
-      double t1[4], t2[4], o[4];
+  // One pass over this wave's (site, rate) pairs PER POSITION (the children are re-read: they
+  // come from L2, and a lane holds one pair in all but the largest alignments): the registers
+  // the pass needs do not grow with the number of positions, and one kernel serves any number.
+#pragma unroll 1
+  for (unsigned a = 0; a < NA; ++a) {
+    const bool last = a + 1 == NA;
+    double acc = 0.0;
+    for (size_t idx = (size_t)bid * 256 + tid; idx < total; idx += stride) {
+      // (the P-matrices in LDS do not change inside this loop, which usually runs once: left
+      // alone the compiler reads all 32 entries ahead of it and keeps them in 64 registers)
+      asm volatile("" ::: "memory");
+      const unsigned s = (unsigned)(idx / R), r = (unsigned)(idx % R);
+      // A tip child is the 0/1 vector of its code's states and goes through the same product as
+      // an inner child: P . (0/1 vector) adds the selected entries of a row in state order --
+      // the tip table's sum (pmatrix_k4_kernel) term for term, products with 0 and 1 being
+      // exact, so the bits are the table's -- and the kernel needs no table in LDS.
+      double x[4], y[4];
       if (tip1) {
-        const double *row = &smat[a][0][(r * 16 + cx) * 4];
+        const uint64_t mask = codemask[code1[s]];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) t1[k] = row[k];
-      } else {
-        const double *m = &smat[a][0][r * 16];
+        for (int j = 0; j < 4; ++j) x[j] = (double)((mask >> j) & 1);
+      } else { const double2 u = c1[idx * 2], b = c1[idx * 2 + 1]; x[0] = u.x; x[1] = u.y; x[2] = b.x; x[3] = b.y; }
+      if (tip2) {
+        const uint64_t mask = codemask[code2[s]];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) y[j] = (double)((mask >> j) & 1);
+      } else { const double2 u = c2[idx * 2], b = c2[idx * 2 + 1]; y[0] = u.x; y[1] = u.y; y[2] = b.x; y[3] = b.y; }
+      const unsigned sc0 = (lsc ? lsc[s] : 0u) + (rsc ? rsc[s] : 0u);
+      const double *f = freqs + (size_t)pidx_of(r) * 4;
+      const double wgt = rate_w[r];
+      const double weight = (double)pw[s];
+      const int base = (int)lane & ~(R - 1);
+      double t1[4], t2[4], o[4];
+      {
+        const double *m = &spm[a][0][r][0];
 #pragma unroll
         for (int k = 0; k < 4; ++k)
           t1[k] = m[k * 4 + 0] * x[0] + m[k * 4 + 1] * x[1] + m[k * 4 + 2] * x[2] + m[k * 4 + 3] * x[3];
       }
-      if (tip2) {
-        const double *row = &smat[a][1][(r * 16 + cy) * 4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) t2[k] = row[k];
-      } else {
-        const double *m = &smat[a][1][r * 16];
+      {
+        const double *m = &spm[a][1][r][0];
 #pragma unroll
         for (int k = 0; k < 4; ++k)
           t2[k] = m[k * 4 + 0] * y[0] + m[k * 4 + 1] * y[1] + m[k * 4 + 2] * y[2] + m[k * 4 + 3] * y[3];
@@ -338,54 +356,64 @@ root_single_body(const DeviceView &v, const LevelOp &op, const RootSingleArgs &r
         for (int k = 0; k < 4; ++k) o[k] *= kScaleFactor;
         sc += 1;
       }
-      const double tr = dot_freq(o, f, 4) * w;
+      const double tr = dot_freq(o, f, 4) * wgt;
       double term = 0.0;
 #pragma unroll
       for (int q2 = 0; q2 < R; ++q2) term += __shfl(tr, base + q2);
       if (r == 0) {
         double l = log(term);
         if (sc) l += (double)sc * kLogScaleThreshold;
-        acc[a] += l * weight;
+        acc += l * weight;
       }
-      if (a == NA - 1) {
+      if (last) {
         if (r == 0) psc[s] = sc;
         pc[idx * 2] = make_double2(o[0], o[1]);
         pc[idx * 2 + 1] = make_double2(o[2], o[3]);
       }
     }
-  }
+    // this wave's share of block_sum_256: the wave tree; the four wave sums of a virtual block
+    // are combined -- ((w0 + w1) + w2) + w3, block_sum_256's order -- in the final fold
 #pragma unroll
-  for (int a = 0; a < NA; ++a) {
-    const double b = block_sum_256(acc[a], lds);
-    if (threadIdx.x == 0) partials[(size_t)a * nblocks + bid] = b;
-    __syncthreads();
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+    if (lane == 0) partials[((size_t)a * nblocks + bid) * 4 + w] = acc;
   }
-  // the block that arrives last folds the partials (finish_sum_kernel's order)
+  // the wave that arrives last folds the partials (finish_sum_kernel's order: lane t of a
+  // 256-lane block adds the block sums t, t + 256, ..., then block_sum_256 over the lanes --
+  // one wave plays the block's four in turn)
   __threadfence();
-  if (tid == 0) ticket = atomicAdd(counter, 1u);
-  __syncthreads();
-  if (ticket != nblocks - 1) return;
+  unsigned ticket = 0;
+  if (lane == 0) ticket = atomicAdd(counter, 1u);
+  ticket = (unsigned)__builtin_amdgcn_readfirstlane((int)ticket);
+  if (ticket != nblocks * 4 - 1) return;
   __threadfence();
-  for (int a = 0; a < NA; ++a) {
-    const volatile double *p = partials + (size_t)a * nblocks;
-    double sum = 0.0;
-    for (unsigned i = tid; i < nblocks; i += 256) sum += p[i];
-    const double b = block_sum_256(sum, lds);
-    if (tid == 0) result[a] = b;
-    __syncthreads();
+  for (unsigned a = 0; a < NA; ++a) {
+    const volatile double *p = partials + (size_t)a * nblocks * 4;
+    double wave_sum[4];
+#pragma unroll
+    for (unsigned vw = 0; vw < 4; ++vw) {
+      double sum = 0.0;
+      for (unsigned i = vw * 64 + lane; i < nblocks; i += 256)
+        sum += ((p[i * 4] + p[i * 4 + 1]) + p[i * 4 + 2]) + p[i * 4 + 3];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off);
+      wave_sum[vw] = sum;
+    }
+    if (lane == 0) result[a] = ((wave_sum[0] + wave_sum[1]) + wave_sum[2]) + wave_sum[3];
   }
-  if (tid == 0) *counter = 0u;   // ready for the next launch on this stream
+  if (lane == 0) *counter = 0u;   // ready for the next launch on this stream
 }
 
-template <int R, int NA>
-__global__ void __launch_bounds__(256)
+// (at least four waves per SIMD = at most 128 registers: a wave of these kernels must fit the
+// slot a wave of the fused evaluator leaves)
+template <int R>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4)))
 root_single_dna_kernel(DeviceView v, LevelOp op, RootSingleArgs ra, const double *__restrict__ q,
                        const double *__restrict__ rates, const double *__restrict__ freqs,
                        const double *__restrict__ rate_w, const unsigned *__restrict__ pw,
                        const uint64_t *__restrict__ codemask, double *__restrict__ partials,
                        unsigned *__restrict__ counter, double *__restrict__ result) {
-  root_single_body<R, NA>(v, op, ra, q, rates, freqs, rate_w, pw, codemask, partials, counter, result,
-                          blockIdx.x, gridDim.x);
+  root_single_body<R>(v, op, ra, q, rates, freqs, rate_w, pw, codemask, partials, counter, result,
+                      blockIdx.x >> 2, blockIdx.x & 3u, gridDim.x >> 2);
 }
 
 // The same for SEVERAL partitions at once (grid.y): the root-only steps of the candidates that
@@ -393,13 +421,13 @@ root_single_dna_kernel(DeviceView v, LevelOp op, RootSingleArgs ra, const double
 // CLVs, parameters and scratch -- as one launch instead of one launch per candidate and step
 // (rdamd_root_loglikelihood_fused_multi).  Every row keeps the grid shape it would have had
 // alone, so each value has the bits of the single launch.
-template <int R, int NA>
-__global__ void __launch_bounds__(256)
+template <int R>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4)))
 root_multi_dna_kernel(const RootItem *__restrict__ items) {
   const RootItem &it = items[blockIdx.y];
-  if (blockIdx.x >= it.blocks) return;
-  root_single_body<R, NA>(it.v, it.op, it.ra, it.q, it.rates, it.freqs, it.rate_w, it.pw, it.codemask,
-                          it.partials, it.counter, it.result, blockIdx.x, it.blocks);
+  if ((blockIdx.x >> 2) >= it.blocks) return;
+  root_single_body<R>(it.v, it.op, it.ra, it.q, it.rates, it.freqs, it.rate_w, it.pw, it.codemask,
+                      it.partials, it.counter, it.result, blockIdx.x >> 2, blockIdx.x & 3u, it.blocks);
 }
 
 hipError_t launch_root_lnl(rdamd_partition *p, unsigned clv_index, int scaler_index,
@@ -475,17 +503,9 @@ template <int R>
 static hipError_t launch_root_single_r(rdamd_partition *p, const DeviceView &v, const LevelOp &op,
                                        const RootSingleArgs &ra, unsigned blocks, unsigned *d_counter,
                                        double *result) {
-#define RDAMD_RS(NA)                                                                         \
-  root_single_dna_kernel<R, NA><<<blocks, 256, 0, p->stream>>>(                               \
-      v, op, ra, p->d_q, p->d_rates, p->d_freqs, p->d_rate_weights, p->d_pattern_weights,      \
-      p->d_codemask, p->d_partials, d_counter, result)
-  switch (ra.n_positions) {
-    case 1: RDAMD_RS(1); break;
-    case 2: RDAMD_RS(2); break;
-    case 3: RDAMD_RS(3); break;
-    default: RDAMD_RS(4); break;
-  }
-#undef RDAMD_RS
+  root_single_dna_kernel<R><<<blocks * 4, 64, 0, p->stream>>>(
+      v, op, ra, p->d_q, p->d_rates, p->d_freqs, p->d_rate_weights, p->d_pattern_weights,
+      p->d_codemask, p->d_partials, d_counter, result);
   return hipGetLastError();
 }
 
@@ -495,11 +515,11 @@ hipError_t launch_root_single(rdamd_partition *p, const LevelOp &op, const doubl
                               const double *len2, unsigned n_positions,
                               const unsigned *params_indices, unsigned *d_counter, double *result) {
   const unsigned S = p->sites, R = p->rate_cats;
-  if (n_positions == 0 || n_positions > 4 || R > 8) return hipErrorInvalidValue;
+  if (n_positions == 0 || n_positions > root_single_max_positions(R) || R > 8) return hipErrorInvalidValue;
   RootSingleArgs ra;
-  for (unsigned a = 0; a < 4; ++a) {
-    ra.len1[a] = a < n_positions ? len1[a] : 0.0;
-    ra.len2[a] = a < n_positions ? len2[a] : 0.0;
+  for (unsigned a = 0; a < kRootMaxPositions; ++a) {
+    ra.len1[a] = len1[a < n_positions ? a : n_positions - 1];
+    ra.len2[a] = len2[a < n_positions ? a : n_positions - 1];
   }
   for (unsigned r = 0; r < 8; ++r) ra.params_idx[r] = r < R ? params_indices[r] : 0u;
   ra.n_positions = n_positions;
@@ -527,19 +547,15 @@ unsigned root_single_blocks(const rdamd_partition *p) {
 hipError_t launch_root_multi(const RootItem *d_items, unsigned n_items, unsigned R, unsigned max_positions,
                              unsigned max_blocks, hipStream_t stream) {
   if (!n_items) return hipSuccess;
-  const dim3 grid(max_blocks, n_items);
-#define RDAMD_RM(RR, NA) root_multi_dna_kernel<RR, NA><<<grid, 256, 0, stream>>>(d_items)
-#define RDAMD_RM_R(RR)                                                                        \
-  if (max_positions <= 1) RDAMD_RM(RR, 1); else if (max_positions == 2) RDAMD_RM(RR, 2); else RDAMD_RM(RR, 4)
+  const dim3 grid(max_blocks * 4, n_items);
+  if (max_positions > root_single_max_positions(R)) return hipErrorInvalidValue;
   switch (R) {
-    case 1: RDAMD_RM_R(1); break;
-    case 2: RDAMD_RM_R(2); break;
-    case 4: RDAMD_RM_R(4); break;
-    case 8: RDAMD_RM_R(8); break;
+    case 1: root_multi_dna_kernel<1><<<grid, 64, 0, stream>>>(d_items); break;
+    case 2: root_multi_dna_kernel<2><<<grid, 64, 0, stream>>>(d_items); break;
+    case 4: root_multi_dna_kernel<4><<<grid, 64, 0, stream>>>(d_items); break;
+    case 8: root_multi_dna_kernel<8><<<grid, 64, 0, stream>>>(d_items); break;
     default: return hipErrorInvalidValue;
   }
-#undef RDAMD_RM_R
-#undef RDAMD_RM
   return hipGetLastError();
 }
 

@@ -321,6 +321,83 @@ double model_t::compute_lh_root(const root_location_t &root) {
   return lh;
 }
 
+// lnL with the root at `ratios` along root's branch: ONE launch per partition for up to eight
+// positions (both child CLVs are read once whatever their number).  Tree and partitions are
+// left at the LAST position, as a sequence of compute_lh_root calls would leave them; every
+// value has the bits of its own compute_lh_root call.
+std::vector<double> model_t::root_lh_at(const root_location_t &root, const std::vector<double> &ratios) {
+  const size_t n = ratios.size();
+  std::vector<double> l1(n), l2(n), total(n, 0.0);
+  root_location_t at{root};
+  for (size_t a = 0; a < n; ++a) {
+    at.brlen_ratio = ratios[a];
+    l1[a] = at.brlen();
+    l2[a] = at.brlen_compliment();
+  }
+  auto res = _tree.generate_derivative_operations(at);   // (the last position)
+  const rdamd_operation_t &op = std::get<0>(res);
+  _n_root_positions += n;
+  const size_t chunk = RDAMD_ROOT_MAX_POSITIONS;
+  if (_root_combiner && _partitions.size() == 1 && !_reduce) {   // meets the other candidates' steps
+    const size_t step = rdamd_partition_rate_cats(_partitions[0]) <= 4 ? chunk : chunk / 2;
+    for (size_t lo = 0; lo < n; lo += step)
+      _root_combiner->evaluate(_partitions[0], op, _param_indicies[0].data(), &l1[lo], &l2[lo],
+                               (unsigned)std::min(step, n - lo), &total[lo]);
+  } else {
+    std::vector<double> v(n);
+    for (size_t i = 0; i < _partitions.size(); ++i) {
+      if (rdamd_root_loglikelihood_fused(_partitions[i], &op, _param_indicies[i].data(), l1.data(), l2.data(),
+                                         (unsigned)n, v.data()) != RDAMD_SUCCESS)
+        fail("root_lh_at");
+      for (size_t a = 0; a < n; ++a) total[a] += v[a];
+    }
+  }
+  reduce_values(total.data(), n);
+  return total;
+}
+
+// the two positions compute_dlh evaluates for `root` -- alpha' first, alpha last -- and the
+// sign of the difference (src/model.cpp:481-519)
+static void dlh_positions(const root_location_t &root, double out[2], double *sign) {
+  constexpr double EPSILON = 1e-8;
+  double prime = root.brlen_ratio + EPSILON;
+  *sign = 1.0;
+  if (prime >= 1.0) {
+    prime = root.brlen_ratio - EPSILON;
+    *sign = -1.0;
+  }
+  out[0] = prime;
+  out[1] = root.brlen_ratio;
+}
+static dlh_t dlh_from(double fx, double fxh, double sign, const root_location_t &root) {
+  constexpr double EPSILON = 1e-8;
+  if (std::isnan(fx))
+    throw std::runtime_error("fx is not finite when computing derivative: " +
+                             std::to_string(root.saved_brlen));
+  if (std::isnan(fxh))
+    throw std::runtime_error("fxh is not finite when computing derivative: " +
+                             std::to_string(root.saved_brlen));
+  if (std::isinf(fxh) && std::isinf(fx)) return {fx, 0};
+  return {fx, (fxh - fx) / EPSILON * sign};
+}
+
+// compute_dlh for SEVERAL positions of one branch at once: two positions each, up to four
+// derivatives per launch (optimize_alpha's scan levels; the same values as one call each)
+std::vector<dlh_t> model_t::compute_dlh_many(const std::vector<root_location_t> &roots) {
+  std::vector<double> ratios;
+  std::vector<double> signs(roots.size());
+  for (size_t i = 0; i < roots.size(); ++i) {
+    double pos[2];
+    dlh_positions(roots[i], pos, &signs[i]);
+    ratios.push_back(pos[0]);
+    ratios.push_back(pos[1]);
+  }
+  const std::vector<double> lh = root_lh_at(roots.front(), ratios);
+  std::vector<dlh_t> out;
+  for (size_t i = 0; i < roots.size(); ++i) out.push_back(dlh_from(lh[2 * i + 1], lh[2 * i], signs[i], roots[i]));
+  return out;
+}
+
 // src/model.cpp:481-519: one-sided difference with EPSILON = 1e-8 (backward
 // when alpha + eps would reach 1); both positions go to the device in one call.
 dlh_t model_t::compute_dlh(const root_location_t &root) {
@@ -580,14 +657,24 @@ std::pair<root_location_t, double> model_t::brents(root_location_t beg, dlh_t d_
   throw std::runtime_error("Brents method failed to converge");
 }
 
-// src/model.cpp:679-794
+// src/model.cpp:679-794.  The reference's opening -- compute_lh_root(root), compute_dlh at
+// alpha = 0 and at alpha = 1 -- is five independent positions of one branch: one launch here
+// (same values, same checks in the same order, the partition left at alpha = 1 as there).
+// The scan that follows when both ends have the same sign takes its levels one launch each.
 root_location_t model_t::optimize_alpha(const root_location_t &root, double atol) {
-  if (std::isnan(compute_lh_root(root)))
-    throw std::runtime_error("initial likelihood calculation is not finite");
   root_location_t beg{root}, end{root};
   beg.brlen_ratio = 0.0;
   end.brlen_ratio = 1.0;
-  const dlh_t d_beg = compute_dlh(beg), d_end = compute_dlh(end);
+  dlh_t d_beg, d_end;
+  {
+    double pb[2], pe[2], sb, se;
+    dlh_positions(beg, pb, &sb);
+    dlh_positions(end, pe, &se);
+    const std::vector<double> lh = root_lh_at(root, {root.brlen_ratio, pb[0], pb[1], pe[0], pe[1]});
+    if (std::isnan(lh[0])) throw std::runtime_error("lh at root is not a number: " + std::to_string(lh[0]));
+    d_beg = dlh_from(lh[2], lh[1], sb, beg);
+    d_end = dlh_from(lh[4], lh[3], se, end);
+  }
   if (std::isnan(d_beg.dlh) || std::isnan(d_end.dlh))
     throw std::runtime_error("Initial derivatives failed when optimizing alpha: " +
                              std::to_string(root.saved_brlen));
@@ -599,16 +686,30 @@ root_location_t model_t::optimize_alpha(const root_location_t &root, double atol
     return lh_best_endpoint.lh > mid.second ? best_endpoint : mid.first;
   }
   // same sign at both ends: scan alpha = k/2, k/4, ... k/32 (odd k) for a sign
-  // change and solve on both sides of it
+  // change and solve on both sides of it.  The positions of a level do not depend on each
+  // other: they are evaluated together (four derivatives per launch) and looked at in the
+  // reference's order, k ascending -- the first sign change decides, as there.
   const bool both_pos = d_beg.dlh > 0.0 && d_end.dlh > 0.0;
   dlh_t best_mid_lh{-std::numeric_limits<double>::infinity(), 0};
   root_location_t best_mid;
   bool found_mid = false;
   for (size_t parts = 2; parts <= 32; parts *= 2) {
+    std::vector<root_location_t> mids;
     for (size_t k = 1; k <= parts; k += 2) {
       root_location_t mid{beg};
       mid.brlen_ratio = 1.0 / (double)parts * k;
-      const dlh_t d_mid = compute_dlh(mid);
+      mids.push_back(mid);
+    }
+    std::vector<dlh_t> d_mids;
+    for (size_t lo = 0; lo < mids.size(); lo += 4) {
+      const std::vector<root_location_t> part(mids.begin() + (std::ptrdiff_t)lo,
+                                              mids.begin() + (std::ptrdiff_t)std::min(lo + 4, mids.size()));
+      const auto d = compute_dlh_many(part);
+      d_mids.insert(d_mids.end(), d.begin(), d.end());
+    }
+    for (size_t j = 0; j < mids.size(); ++j) {
+      const root_location_t &mid = mids[j];
+      const dlh_t d_mid = d_mids[j];
       if (std::fabs(d_mid.dlh) < atol && best_mid_lh.lh < d_mid.lh) {
         best_mid_lh = d_mid;
         best_mid = mid;

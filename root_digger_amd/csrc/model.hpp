@@ -99,6 +99,9 @@ public:
   double compute_lh(const root_location_t &root_location);      // src/model.cpp:384-413
   double compute_lh_root(const root_location_t &root);          // :415-452
   dlh_t  compute_dlh(const root_location_t &root_location);     // :481-519
+  // several positions of one root branch per launch (optimize_alpha's opening and scan levels)
+  std::vector<double> root_lh_at(const root_location_t &root, const std::vector<double> &ratios);
+  std::vector<dlh_t>  compute_dlh_many(const std::vector<root_location_t> &roots);
   void   move_root(const root_location_t &new_root);            // :823-854
   std::vector<double> compute_all_root_lh();                    // :1737-1746
   // the same sweep at the current parameters as ONE fused launch (every root a

@@ -37,6 +37,8 @@ struct rdamd_model {
   void    *setulb = nullptr;
   rdamd::checkpoint_t *checkpoint = nullptr;
   std::unique_ptr<rdamd::model_t::progress_t> progress;   // set by rdamd_model_set_progress
+  int lockstep_priority = 1;      // stream priority of the shared objective partition in a lock-stepped search
+  unsigned lockstep_groups = 0;   // 0: the library's choice; 1: one group, blocking launches (rdamd_model_set_lockstep_groups)
   uint64_t lockstep_stats[4] = {0, 0, 0, 0};   // of the last lock-stepped search (rdamd_model_lockstep_stats)
   ~rdamd_model() { delete model; }
 };
@@ -429,12 +431,8 @@ static int search_with_replicas(rdamd_model_t *m, unsigned int workers, bool loc
       throw std::runtime_error("a site-sharded model runs its candidates sequentially "
                                "(rdamd_model_exhaustive_search): replicas would reorder the "
                                "site group's collectives");
-    std::unique_ptr<rdamd::batch_combiner_t> combiner;
+    std::unique_ptr<rdamd::batch_combiner_t> combiner[2];
     std::unique_ptr<rdamd::root_combiner_t> root_combiner;
-    if (lockstep) {
-      combiner.reset(new rdamd::batch_combiner_t(m->model->partition(0)));
-      root_combiner.reset(new rdamd::root_combiner_t());
-    }
     const std::vector<size_t> todo = m->model->assigned_indicies();
     if (workers < 1) workers = 1;
     workers = (unsigned)std::min<size_t>(workers, std::max<size_t>(todo.size(), 1));
@@ -446,6 +444,20 @@ static int search_with_replicas(rdamd_model_t *m, unsigned int workers, bool loc
                              "running %u\n", workers, (double)bytes / 1e9, fit);
         workers = fit;
       }
+    }
+    // From four candidates in flight on they form two groups whose batches alternate on the
+    // shared partition (batch_combiner.hpp): one group's hosts work while the other's batch runs
+    const unsigned n_groups = lockstep && workers >= 4 && m->lockstep_groups != 1 ? 2u : 1u;
+    if (lockstep) {
+      // the objective launches fill every CU for a millisecond: on low priority, the kernels
+      // beside them (front halves of the other group's batch, the replicas' root-only steps and
+      // traversals) get the wave slots that become free instead of waiting for the launch to end
+      if (m->lockstep_priority &&
+          rdamd_partition_set_stream_priority(m->model->partition(0), m->lockstep_priority) != RDAMD_SUCCESS)
+        throw std::runtime_error(std::string("set_stream_priority: ") + rdamd_errmsg());
+      for (unsigned g = 0; g < n_groups; ++g)
+        combiner[g].reset(new rdamd::batch_combiner_t(m->model->partition(0), n_groups == 2 ? (int)g : -1));
+      root_combiner.reset(new rdamd::root_combiner_t());
     }
     int device = 0;
     if (hipGetDevice(&device) != hipSuccess) throw std::runtime_error("no HIP device");
@@ -463,7 +475,11 @@ static int search_with_replicas(rdamd_model_t *m, unsigned int workers, bool loc
         if (m->setulb) replica.set_lbfgsb(reinterpret_cast<rdamd::model_t::setulb_fn>(m->setulb));
         replica.set_checkpoint(m->checkpoint);
         replica.set_progress(m->progress.get());
-        replica.set_combiner(combiner.get());
+        replica.set_combiner(combiner[wid % n_groups].get());
+        if (lockstep && m->lockstep_priority)   // (the replicas' short kernels in front of the shared partition's long ones)
+          for (size_t pi = 0; pi < replica.partition_count(); ++pi)
+            if (rdamd_partition_set_stream_priority(replica.partition(pi), -1) != RDAMD_SUCCESS)
+              throw std::runtime_error(std::string("set_stream_priority: ") + rdamd_errmsg());
         replica.initialize();
         replica.set_root_combiner(root_combiner.get());   // (after initialize(): that evaluates on its own)
         for (;;) {
@@ -484,8 +500,12 @@ static int search_with_replicas(rdamd_model_t *m, unsigned int workers, bool loc
     std::vector<std::thread> pool;
     for (unsigned w = 0; w < workers; ++w) pool.emplace_back(work, w);
     for (auto &t : pool) t.join();
-    if (combiner) {
-      m->lockstep_stats[0] = combiner->launches(); m->lockstep_stats[1] = combiner->jobs();
+    if (lockstep) {
+      m->lockstep_stats[0] = m->lockstep_stats[1] = 0;
+      for (unsigned g = 0; g < n_groups; ++g) {
+        m->lockstep_stats[0] += combiner[g]->launches();
+        m->lockstep_stats[1] += combiner[g]->jobs();
+      }
       m->lockstep_stats[2] = root_combiner->launches(); m->lockstep_stats[3] = root_combiner->steps();
     }
     if (!first_error.empty()) throw std::runtime_error(first_error);
@@ -544,6 +564,8 @@ int rdamd_model_optimize_params(rdamd_model_t *m, const rdamd_root_location_t *r
     return RDAMD_SUCCESS;
   })
 }
+void rdamd_model_set_lockstep_groups(rdamd_model_t *m, unsigned int groups) { m->lockstep_groups = groups; }
+void rdamd_model_set_lockstep_priority(rdamd_model_t *m, int level) { m->lockstep_priority = level; }
 void rdamd_model_lockstep_stats(const rdamd_model_t *m, uint64_t out[4]) {
   for (int i = 0; i < 4; ++i) out[i] = m->lockstep_stats[i];
 }

@@ -236,7 +236,7 @@ rdamd_partition_t *rdamd_partition_create(unsigned int tips, unsigned int clv_bu
   TRY(hipMalloc(&p->d_rates, R * sizeof(double)));
   TRY(hipMalloc(&p->d_rate_weights, R * sizeof(double)));
   TRY(hipMalloc(&p->d_pattern_weights, std::max<size_t>(4, S * sizeof(unsigned))));
-  TRY(hipMalloc(&p->d_partials, 8192 * sizeof(double)));
+  TRY(hipMalloc(&p->d_partials, 32768 * sizeof(double)));   // (8 root positions x 1024 blocks x 4 waves)
   TRY(hipMalloc(&p->d_counter, sizeof(unsigned)));
   TRY(hipMemsetAsync(p->d_counter, 0, sizeof(unsigned), p->stream));
   TRY(hipMalloc(&p->d_result, 64 * sizeof(double)));
@@ -292,6 +292,10 @@ void rdamd_partition_destroy(rdamd_partition_t *p) {
   for (void *d : dev)
     if (d) (void)hipFree(d);
   rdamd::fused_workspace_free(p->fused);
+  rdamd::fused_workspace_free(p->fused1);
+  for (auto &b : p->sched_pool) (void)hipFree(b.ptr);
+  for (auto &b : p->sched_retired) (void)hipFree(b.ptr);
+  if (p->stream_pre) (void)hipStreamDestroy(p->stream_pre);
   rdamd::clade_cache_free(p->clades);
   for (auto &sp : p->prof_spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
   for (auto &e : p->prof_pool) (void)hipEventDestroy(e);
@@ -348,15 +352,15 @@ int rdamd_set_tip_states(rdamd_partition_t *p, unsigned int tip_index,
   // compiled with pseudo-tips notice through the generation count)
   p->tip_generation += 1;
   if (p->clades) {
-    RDAMD_HIP_TRY(hipStreamSynchronize(p->stream), RDAMD_FAILURE);
+    RDAMD_HIP_TRY(sync_streams(p), RDAMD_FAILURE);
     const unsigned keep = p->clades->max_classes;
     rdamd::clade_cache_free(p->clades);
     p->clades = new rdamd::CladeCache();
     p->clades->max_classes = keep;
     p->code_rows = p->tips;
   }
-  if (p->d_codes_wide) {   // (rebuilt from the host copy when the next wide schedule is compiled)
-    RDAMD_HIP_TRY(hipStreamSynchronize(p->stream), RDAMD_FAILURE);
+  if (p->d_codes_wide) {   // (rebuilt from the host copy when the next wide schedule is compiled or run)
+    RDAMD_HIP_TRY(sync_streams(p), RDAMD_FAILURE);
     (void)hipFree(p->d_codes_wide);
     p->d_codes_wide = nullptr;
     p->wide_rows = p->wide_rows_cap = 0;
@@ -451,6 +455,21 @@ double rdamd_partition_weight_sum(const rdamd_partition_t *p) {
   return total;
 }
 void *rdamd_partition_stream(const rdamd_partition_t *p) { return (void *)p->stream; }
+
+int rdamd_partition_set_stream_priority(rdamd_partition_t *p, int level) {
+  clear_error();
+  std::lock_guard<std::mutex> guard(p->launch_mu);
+  RDAMD_HIP_TRY(sync_streams(p), RDAMD_FAILURE);
+  int least = 0, greatest = 0;   // (numerically: greatest priority = lowest number)
+  RDAMD_HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest), RDAMD_FAILURE);
+  const int prio = level < 0 ? greatest : (level > 0 ? least : (least + greatest) / 2);
+  hipStream_t fresh = nullptr;
+  RDAMD_HIP_TRY(hipStreamCreateWithPriority(&fresh, hipStreamNonBlocking, prio), RDAMD_FAILURE);
+  if (p->stream) (void)hipStreamDestroy(p->stream);
+  p->stream = fresh;
+  p->stream_priority = level < 0 ? -1 : (level > 0 ? 1 : 0);
+  return RDAMD_SUCCESS;
+}
 const double *rdamd_partition_subst_params(const rdamd_partition_t *p, unsigned int i) {
   if (i >= p->rate_matrices) return nullptr;
   return p->embedded() ? p->api_subst[i].data() : p->subst[i].data();
@@ -842,7 +861,8 @@ int rdamd_root_loglikelihood_fused(rdamd_partition_t *p, const rdamd_operation_t
     RDAMD_HIP_TRY(launch_tiptab_all(p), RDAMD_FAILURE);
     p->tiptab_stale = false;
   }
-  // One launch per chunk of up to four positions (root_single_dna_kernel): branch
+  // One launch per chunk of up to eight positions (four at 8 rate categories;
+  // root_single_dna_kernel): branch
   // lengths and parameter indices travel as kernel arguments, the P-matrices are
   // exponentiated inside the kernel, the result lands in the pinned host block.
   // The LAST position of the call leaves its matrices, root CLV and scaler in the
@@ -859,8 +879,9 @@ int rdamd_root_loglikelihood_fused(rdamd_partition_t *p, const rdamd_operation_t
       set_error(9, "rdamd_root_loglikelihood_fused: invalid branch length");
       return RDAMD_FAILURE;
     }
-  for (unsigned base = 0; base < n_alpha; base += 4) {
-    const unsigned n = std::min(4u, n_alpha - base);
+  const unsigned chunk = root_single_max_positions(R);
+  for (unsigned base = 0; base < n_alpha; base += chunk) {
+    const unsigned n = std::min(chunk, n_alpha - base);
     p->prof_begin(2);
     hipError_t e = launch_root_single(p, op, lengths1 + base, lengths2 + base, n, params_indices,
                                       p->d_counter, p->h_result);
@@ -875,7 +896,8 @@ int rdamd_root_loglikelihood_fused(rdamd_partition_t *p, const rdamd_operation_t
 // Root-only evaluations of SEVERAL partitions in one launch (root_multi_dna_kernel): the
 // Brent / finite-difference steps of the candidates a lock-stepped search has in flight, each
 // on its own replica.  Item i: partition parts[i], its root operation ops[i], n_positions[i]
-// <= 4 root positions with branch lengths len1[4 i + a], len2[4 i + a]; out[4 i + a] = lnL.
+// <= 8 root positions (<= 4 at 8 rate categories) with branch lengths len1[8 i + a],
+// len2[8 i + a]; out[8 i + a] = lnL.
 // Every partition is left exactly as rdamd_root_loglikelihood_fused leaves it, and every value
 // has that call's bits.  Shapes the one-launch kernel does not take fall back to it item by item.
 int rdamd_root_loglikelihood_fused_multi(unsigned int n_items, rdamd_partition_t *const *parts,
@@ -892,12 +914,12 @@ int rdamd_root_loglikelihood_fused_multi(unsigned int n_items, rdamd_partition_t
     fast = fast && p->states == 4 && p->ncodes_cap == 16 && p->rate_cats == parts[0]->rate_cats &&
            (p->rate_cats == 1 || p->rate_cats == 2 || p->rate_cats == 4 || p->rate_cats == 8) &&
            ops[i].parent_scaler_index >= 0 && p->sites > 0 && p->device == parts[0]->device &&
-           n_positions[i] >= 1 && n_positions[i] <= 4;
+           n_positions[i] >= 1 && n_positions[i] <= root_single_max_positions(p->rate_cats);
   }
   if (!fast || n_items == 1) {
     for (unsigned i = 0; i < n_items; ++i)
-      if (rdamd_root_loglikelihood_fused(parts[i], &ops[i], params_indices[i], len1 + 4 * i, len2 + 4 * i,
-                                         n_positions[i], out + 4 * i) != RDAMD_SUCCESS)
+      if (rdamd_root_loglikelihood_fused(parts[i], &ops[i], params_indices[i], len1 + 8 * i, len2 + 8 * i,
+                                         n_positions[i], out + 8 * i) != RDAMD_SUCCESS)
         return RDAMD_FAILURE;
     return RDAMD_SUCCESS;
   }
@@ -908,12 +930,12 @@ int rdamd_root_loglikelihood_fused_multi(unsigned int n_items, rdamd_partition_t
     if (lead->h_root_items) (void)hipHostFree(lead->h_root_items);
     lead->d_root_items = lead->h_root_items = nullptr;
     lead->root_items_cap = std::max(64u, n_items * 2);
-    const size_t bytes = (size_t)lead->root_items_cap * (sizeof(RootItem) + 4 * sizeof(double));
+    const size_t bytes = (size_t)lead->root_items_cap * (sizeof(RootItem) + kRootMaxPositions * sizeof(double));
     RDAMD_HIP_TRY(hipMalloc(&lead->d_root_items, bytes), RDAMD_FAILURE);
     RDAMD_HIP_TRY(hipHostMalloc(&lead->h_root_items, bytes, hipHostMallocDefault), RDAMD_FAILURE);
   }
   RootItem *h_items = (RootItem *)lead->h_root_items, *d_items = (RootItem *)lead->d_root_items;
-  double *h_res = (double *)(h_items + lead->root_items_cap), *d_res = (double *)(d_items + lead->root_items_cap);
+  double *h_res = (double *)(h_items + lead->root_items_cap);
   for (unsigned i = 0; i < n_items; ++i) {
     rdamd_partition *p = parts[i];
     const rdamd_operation_t &o = ops[i];
@@ -927,10 +949,10 @@ int rdamd_root_loglikelihood_fused_multi(unsigned int n_items, rdamd_partition_t
     }
     RootItem &it = h_items[i];
     memset(&it, 0, sizeof it);
-    for (unsigned a = 0; a < 4; ++a) {   // (unused positions repeat the last one: same state left behind)
+    for (unsigned a = 0; a < kRootMaxPositions; ++a) {   // (unused positions repeat the last one: same state left behind)
       const unsigned src = std::min(a, n_positions[i] - 1);
-      it.ra.len1[a] = len1[4 * i + src];
-      it.ra.len2[a] = len2[4 * i + src];
+      it.ra.len1[a] = len1[8 * i + src];
+      it.ra.len2[a] = len2[8 * i + src];
       if (!(it.ra.len1[a] >= 0.0) || !(it.ra.len2[a] >= 0.0) || !std::isfinite(it.ra.len1[a]) ||
           !std::isfinite(it.ra.len2[a])) {
         set_error(9, "rdamd_root_loglikelihood_fused_multi: item %u: invalid branch length", i);
@@ -960,7 +982,7 @@ int rdamd_root_loglikelihood_fused_multi(unsigned int n_items, rdamd_partition_t
     it.q = p->d_q; it.rates = p->d_rates; it.freqs = p->d_freqs; it.rate_w = p->d_rate_weights;
     it.pw = p->d_pattern_weights; it.codemask = p->d_codemask;
     it.partials = p->d_partials; it.counter = p->d_counter;
-    it.result = d_res + 4 * i;
+    it.result = h_res + kRootMaxPositions * i;   // (pinned host memory: the folding wave writes it there, no copy launch)
     it.blocks = root_single_blocks(p);
     it.ra.n_positions = n_positions[i];
     max_pos = std::max(max_pos, n_positions[i]);
@@ -972,11 +994,9 @@ int rdamd_root_loglikelihood_fused_multi(unsigned int n_items, rdamd_partition_t
   hipError_t e = launch_root_multi(d_items, n_items, R, max_pos, max_blocks, lead->stream);
   lead->prof_end();
   RDAMD_HIP_TRY(e, RDAMD_FAILURE);
-  RDAMD_HIP_TRY(hipMemcpyAsync(h_res, d_res, sizeof(double) * 4 * n_items, hipMemcpyDeviceToHost, lead->stream),
-                RDAMD_FAILURE);
   RDAMD_HIP_TRY(hipStreamSynchronize(lead->stream), RDAMD_FAILURE);
   for (unsigned i = 0; i < n_items; ++i)
-    for (unsigned a = 0; a < n_positions[i]; ++a) out[4 * i + a] = h_res[4 * i + a];
+    for (unsigned a = 0; a < n_positions[i]; ++a) out[8 * i + a] = h_res[8 * i + a];
   return RDAMD_SUCCESS;
 }
 

@@ -254,6 +254,41 @@ def test_fused_root_evaluation_matches_unfused():
     assert abs(d_gpu - d_orc) <= 1e-3 * max(1.0, abs(d_orc))
 
 
+@pytest.mark.parametrize("R", [1, 4, 8])
+def test_fused_root_positions_do_not_depend_on_their_launch(R):
+    """optimize_alpha's opening (five positions: the root itself and the two finite-difference
+    pairs at alpha = 0 and 1, src/model.cpp:679-700) and its scan levels (eight) ride in one
+    launch; a position's value must be the one its own launch would give, bit for bit, the state
+    left behind that of the LAST position, and full == root-only (test/src/model.cpp:285-286)
+    must hold for every one of them."""
+    w = synth.workload(24, 1500, 4, R, 77 + R)
+    tree = rd.Tree.from_newick(w["newick"])
+    g, o = pair(tree, w["seqs"], 4, R)
+    set_model((g, o), w["subst"], g.empirical_frequencies(), w["rates"])
+    rl = tree.root_location(11).with_ratio(0.42)
+    util.compute_lh(g, tree, rl)
+    util.compute_lh(o, tree, rl)
+    op, pmi, brl = tree.generate_derivative_operations(rl)
+    alphas = [0.42, 1e-8, 0.0, 1.0 - 1e-8, 1.0, 0.125, 0.125 + 1e-8, 0.875]
+    l1 = [rl.saved_brlen * a for a in alphas]
+    l2 = [rl.saved_brlen * (1 - a) for a in alphas]
+    single = np.array([g.root_loglikelihood_fused(op, [x], [y])[0] for x, y in zip(l1, l2)])
+    for n in (2, 3, 4, 5, 7, 8):
+        got = g.root_loglikelihood_fused(op, l1[:n], l2[:n])
+        assert np.array_equal(got, single[:n]), n
+        # the state contract: root CLV, scaler and matrices of the LAST position
+        clv, sc = g.get_clv(op.parent_clv_index), g.get_scaler(op.parent_scaler_index)
+        g.root_loglikelihood_fused(op, l1[n - 1:n], l2[n - 1:n])
+        assert np.array_equal(clv, g.get_clv(op.parent_clv_index)) and np.array_equal(sc, g.get_scaler(op.parent_scaler_index))
+    want = o.root_loglikelihood_fused(op, l1, l2)
+    for a, b in zip(single, want):
+        assert util.rel_err(a, b) < LNL_TOL
+    # the unfused call sequence gives the same bits (compute_lh_root's three calls)
+    g.update_prob_matrices(pmi, [l1[5], l2[5]])
+    g.update_clvs([op])
+    assert g.compute_root_loglikelihood(op.parent_clv_index, op.parent_scaler_index) == single[5]
+
+
 def test_error_paths():
     tree = rd.Tree.from_file(os.path.join(util.DATA, "single.tree"))
     g = rd.Partition.for_tree(tree, 4, 4, 1)

@@ -30,6 +30,10 @@ if workers or lockstep:
     lib.rdamd_model_assign_by_rank  # noqa
     # first `ncand` candidates in one call, `workers` threads
     m._ok(lib.rdamd_model_assign_by_rank(m._h, 0, max(1, tree.root_count() // ncand)), "assign")
+    if "GROUPS" in os.environ:
+        m.set_lockstep_groups(int(os.environ["GROUPS"]))
+    if "PRIO" in os.environ:
+        m.set_lockstep_priority(int(os.environ["PRIO"]))
     t1 = time.time()
     res = m.exhaustive_search(1e-7, 1e-7, 1e-12, 1e4, workers=workers, lockstep=lockstep)
     dt = time.time() - t1
