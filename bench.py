@@ -212,6 +212,9 @@ def main():
                     help="gloo + --device lets several ranks share one GPU (how the N>1 code "
                          "path is exercised on a one-GPU box); the driver's runs use nccl (RCCL)")
     ap.add_argument("--device", type=int, default=None, help="HIP device (default: LOCAL_RANK)")
+    ap.add_argument("--no-shard-legs", action="store_true",
+                    help="N>1 without --shard: skip the extra `site_sharded` / `grid` objects (the same "
+                         "workload site-sharded with the all-reduce of the per-block lnLs)")
     ap.add_argument("--site-groups", type=int, default=2,
                     help="--shard grid: ranks per candidate group, i.e. site shards (BASELINE c5: "
                          "candidate groups x site shards = N)")
@@ -295,6 +298,7 @@ def main():
             if c == cgroup:
                 site_group = g
     S_total = S
+    full_seqs = dict(w["seqs"])
     if site_sharded:   # this rank's contiguous block of patterns (dist.site_block)
         lo, hi = rdist.site_block(S, srank, sgroups)
         w["seqs"] = {k: v[lo:hi] for k, v in w["seqs"].items()}
@@ -362,15 +366,19 @@ def main():
 
     prepared = {}
 
+    def step_jobs(s, params_, count):
+        """which candidates step s evaluates and with which parameter draws"""
+        idx = [(s * nb + b) % count for b in range(nb)]
+        # every job of every step is a distinct (root, parameter set) pair
+        jitter = 1.0 + 1e-3 * (((s % 97) + 1) + np.arange(nb)[:, None] / (4.0 * nb))
+        return idx, np.ascontiguousarray(params_[idx] * jitter * (1.0 + 0.05 * np.sin(np.arange(K * K - K) + s)))
+
     def prepare(s):
         """the arguments of step s (harness work: which candidates, their parameter draws, the
         handle array): made before the timed region for the steps it times, so that the region
         holds the library's work -- parameter upload, P-matrices, tables, traversal, reduction,
         copy back -- and not numpy's"""
-        idx = [(s * nb + b) % len(mine) for b in range(nb)]
-        # every job of every step is a distinct (root, parameter set) pair
-        jitter = 1.0 + 1e-3 * (((s % 97) + 1) + np.arange(nb)[:, None] / (4.0 * nb))
-        sub = np.ascontiguousarray(params[idx] * jitter * (1.0 + 0.05 * np.sin(np.arange(K * K - K) + s)))
+        idx, sub = step_jobs(s, params, len(mine))
         return {"handles": rd.Partition.schedule_handles([scheds[i] for i in idx]), "sub": sub,
                 "freqs": np.ascontiguousarray(freqs_b[idx]),
                 "steps": sum(sched_stats[i]["steps"] for i in idx),
@@ -470,6 +478,98 @@ def main():
     evals_per_rank = args.steps * nb
     total_evals = evals_per_rank * cgroups      # one set of evaluations per candidate group
     value = total_evals / elapsed
+
+    def sharded_leg(mode):
+        """The SAME workload with the sites split over the ranks -- north_star's "site blocks
+        shard across the GPUs with an RCCL all-reduce of per-block log-likelihoods" -- as an extra
+        object of the default N > 1 line, so that the driver's scaling run measures it without
+        asking: mode "sites" = every rank a site block of all candidates (BASELINE c4's layout,
+        strong scaling), "grid" = candidate groups x site shards (c5's).  Every batch leaves its
+        per-block lnLs on the device (rdamd_evaluate_batch_device), one all-reduce inside the site
+        group sums them.  lnl_check = the sum of the all-reduced lnLs rank 0 saw: for "sites"
+        the N = 1 line's value, for "grid" that of `--as-candidate-group 0/<groups>`."""
+        cg, sg = (1, world) if mode == "sites" else rdist.grid_2d(world, args.site_groups)
+        cgi, sr = rdist.rank_coords(rank, sg)
+        group = None
+        if mode == "grid":
+            for c in range(cg):      # every rank creates every group, in the same order
+                g = tdist.new_group(list(range(c * sg, (c + 1) * sg)))
+                if c == cgi:
+                    group = g
+        lo, hi = rdist.site_block(S_total, sr, sg)
+        p2 = rd.Partition.for_tree(tree, K, hi - lo, R, attributes=rd.ATTRIB_SITE_REPEATS if repeats else 0)
+        if repeats and args.repeat_classes is not None:
+            p2.set_site_repeats(args.repeat_classes)
+        for label, seq in full_seqs.items():
+            p2.set_tip_states(tree.tip_index(label), cmap, seq[lo:hi])
+        if data_weights is not None:
+            p2.set_pattern_weights(np.ascontiguousarray(data_weights[lo:hi]))
+        fr = rdist.global_frequencies(p2.empirical_frequencies(), hi - lo, group=group,
+                                      device="cpu" if host_collectives else "cuda")
+        p2.set_frequencies(0, fr)
+        p2.set_category_rates(w["rates"])
+        mine2 = rdist.assign_candidates(tree.root_count(), cgi, cg)
+        rng2 = np.random.default_rng(seed + 1000 + cgi)
+        params2 = np.array([synth.random_params(K * K - K, rng2) for _ in range(len(mine2))])
+        scheds2 = [p2.schedule(*tree.generate_operations(tree.root_location(i))) for i in mine2]
+        frb = np.tile(np.asarray(fr), (len(mine2), 1))
+        rows = torch.zeros((args.steps, nb), dtype=torch.float64, device="cuda")
+        warm = torch.zeros(nb, dtype=torch.float64, device="cuda")
+        jobs = {}
+        for s_ in range(args.warmup + args.steps):
+            idx, sub = step_jobs(s_, params2, len(mine2))
+            jobs[s_] = (rd.Partition.schedule_handles([scheds2[i] for i in idx]), sub,
+                        np.ascontiguousarray(frb[idx]))
+
+        def one(s_):
+            row = s_ - args.warmup
+            dev = rows[row] if row >= 0 else warm
+            p2.evaluate_batch_device(jobs[s_][0], jobs[s_][1], jobs[s_][2], dev.data_ptr())
+            if not host_collectives:
+                rdist.allreduce_lnl(dev, group)
+            else:                                # gloo test path: through the host
+                host = dev.cpu()
+                rdist.allreduce_lnl(host, group)
+                dev.copy_(host)
+
+        def sync():
+            tdist.barrier()
+            torch.cuda.synchronize()
+            p2.sync()
+
+        for s_ in range(args.warmup):
+            one(s_)
+        sync()
+        t_ = time.perf_counter()
+        for s_ in range(args.warmup, args.warmup + args.steps):
+            one(s_)
+        sync()
+        dt = time.perf_counter() - t_
+        tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if host_collectives else "cuda")
+        tdist.all_reduce(tt, op=tdist.ReduceOp.MAX)
+        dt = float(tt.item())
+        out = {"value": round(args.steps * nb * cg / dt, 2), "unit": "evals/s",
+               "ms_per_step": round(dt / args.steps * 1e3, 4),
+               "scaling": "strong" if mode == "sites" else "weak",
+               "sharding": ("site blocks of all candidates + all-reduce of the per-block lnLs" if mode == "sites"
+                            else "%d candidate groups x %d site shards, all-reduce inside a group" % (cg, sg)),
+               "sites_per_rank": hi - lo, "batch_per_step": nb,
+               "collective": "gloo (host)" if host_collectives else "RCCL all-reduce, f64 sum, %d values per batch" % nb,
+               "lnl_check": float(rows.sum().item())}
+        p2.destroy()
+        return out
+
+    legs = {}
+    if use_pg and world > 1 and args.shard == "candidates" and use_fused and not args.no_shard_legs:
+        check_one_hip_runtime(rd)
+        legs["site_sharded"] = sharded_leg("sites")
+        if world % args.site_groups == 0 and world // args.site_groups > 1:
+            legs["grid"] = sharded_leg("grid")
+    rccl_ranks = None
+    if use_pg and not host_collectives:   # a real all-reduce over the communicator the line ran on
+        ones = torch.ones(1, dtype=torch.float64, device="cuda")
+        tdist.all_reduce(ones)
+        rccl_ranks = int(round(float(ones.item())))
 
     def clv_roofline(ms, launches, evals):
         bytes_clv = clv_kernel_bytes(n, S, R, K) * evals
@@ -603,6 +703,9 @@ def main():
         "roofline": roofline,
     }
     result.update(extra)
+    result.update(legs)
+    if rccl_ranks is not None:
+        result["rccl_ranks"] = rccl_ranks
 
     def gpu_eval(j):
         if not use_fused:

@@ -5,11 +5,11 @@
 # ablation library (make -C root_digger_amd/csrc ablation).  Round 3, before the change:
 # c5 2 451 -> 2 995, 125.phy 102k -> 124k evaluations/s.
 mkdir -p gpurun_out/abl
-export RDAMD_LIBRARY=$PWD/root_digger_amd/lib/librdamd_ablation.so RDAMD_BENCH_TIMING_ONLY=1
+ABL="profiles/with_ablation.py $PWD/root_digger_amd/lib/librdamd_ablation.so"; export RDAMD_BENCH_TIMING_ONLY=1
 for c in d125 c5; do
   st=""; [ $c = c5 ] && st="--steps 3 --warmup 1"
-  python bench.py --config $c $st --allow-stale-profile --no-cpu-baseline > gpurun_out/abl/${c}_base.json 2> gpurun_out/abl/${c}_base.err
-  RDAMD_FUSED_DEPTH=1 python bench.py --config $c $st --allow-stale-profile --no-cpu-baseline > gpurun_out/abl/${c}_d1.json 2> gpurun_out/abl/${c}_d1.err
+  python $ABL bench.py --config $c $st --allow-stale-profile --no-cpu-baseline > gpurun_out/abl/${c}_base.json 2> gpurun_out/abl/${c}_base.err
+  RDAMD_FUSED_DEPTH=1 python $ABL bench.py --config $c $st --allow-stale-profile --no-cpu-baseline > gpurun_out/abl/${c}_d1.json 2> gpurun_out/abl/${c}_d1.err
 done
 python - <<'PY'
 import json,glob

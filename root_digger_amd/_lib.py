@@ -4,10 +4,6 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 lib_path = os.path.join(_HERE, "lib", "librdamd.so")
-# profiles/*_ab.sh only: the ablation build of the same sources (`make -C csrc ablation`),
-# whose timing-only kernel variants do not exist in librdamd.so
-if os.environ.get("RDAMD_LIBRARY"):
-    lib_path = os.path.abspath(os.environ["RDAMD_LIBRARY"])
 
 
 class RdamdError(RuntimeError):

@@ -85,6 +85,6 @@ struct FusedArgs;
 // scratch: [job][step][rate][rows][4] with rows = a.table_rows
 hipError_t launch_clade_tables(const FusedArgs &a, const uint8_t *d_maps, double *d_scratch,
                                size_t scratch_job_stride, unsigned n_jobs, unsigned max_groups,
-                               hipStream_t stream);
+                               bool slim, hipStream_t stream);
 
 }  // namespace rdamd

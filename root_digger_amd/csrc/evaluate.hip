@@ -706,9 +706,9 @@ static int batch_submit(rdamd_partition_t *p, FusedWorkspace *&slot, bool pipeli
     if (getenv("RDAMD_FUSED_RW")) a.rates_across_waves = atoi(getenv("RDAMD_FUSED_RW")) != 0 && R >= 2 && R <= 8;
 #endif
     if (!pipelined) p->prof_begin(4);
-    e = launch_fused_pmatrix(a, w->d_q, w->d_rates, n_jobs, p->prob_matrices, pre);
+    e = launch_fused_pmatrix(a, w->d_q, w->d_rates, n_jobs, p->prob_matrices, pipelined, pre);
     if (e == hipSuccess && max_groups)   // the pseudo-tips' tables, from the P-matrices and tip tables just made
-      e = launch_clade_tables(a, p->clades->d_maps, w->d_clade_scratch, clade_scratch_job, n_jobs, max_groups, pre);
+      e = launch_clade_tables(a, p->clades->d_maps, w->d_clade_scratch, clade_scratch_job, n_jobs, max_groups, pipelined, pre);
     if (!pipelined) p->prof_end();
     RDAMD_HIP_TRY(e, RDAMD_FAILURE);
     if (pipelined) {

@@ -120,7 +120,7 @@ hipError_t launch_fused20_eval(const Fused20Args &a, unsigned n_jobs, unsigned m
                                double *d_out, hipStream_t stream);
 
 hipError_t launch_fused_pmatrix(const FusedArgs &a, const double *d_q, const double *d_rates,
-                                unsigned n_jobs, unsigned n_mat, hipStream_t stream);
+                                unsigned n_jobs, unsigned n_mat, bool slim, hipStream_t stream);
 // depth / reg_levels: [0] of the programs with pseudo-tips (FusedJob::prog), [1] of the plain
 // programs (prog_plain); the two evaluator variants are launched with their own LDS sizes
 // unsafe_pass: false = the jobs whose tt_unsafe flag is down (programs with pseudo-tips, no

@@ -174,11 +174,12 @@ hipError_t clade_upload_map(rdamd_partition *p, unsigned id) {
 // pseudo-tip of up to 16 classes lands in its branch's 16-row table, in the tip tables'
 // layout ([class][state]); one of up to 64 classes in its own 64-row table, stored as the
 // evaluator's LDS slot image ([half][class][2 states]: the table goes to LDS by DMA).
-// (One wave per workgroup whatever the table size: the launch runs beside the evaluator of the
-// batch in front of it, whose one-wave workgroups fill the device -- a four-wave workgroup
-// waits until four slots of one CU are free at once, a wave takes the first that opens.)
-template <int ROWS>
-__global__ void __launch_bounds__(64)
+// THREADS: 256 lanes per workgroup for 64-row tables when the launch has the device to itself;
+// 64 when it runs beside the evaluator of the batch in front of it (pipelined batches), whose
+// one-wave workgroups fill the device -- a four-wave workgroup waits until four slots of one
+// CU are free at once, a wave takes the first that opens.
+template <int ROWS, int THREADS>
+__global__ void __launch_bounds__(THREADS)
 clade_table_kernel(FusedJob *__restrict__ jobs, const uint8_t *__restrict__ maps,
                    const double *__restrict__ pmat, double *__restrict__ tiptab, size_t pmat_job_stride,
                    size_t tiptab_job_stride, double *__restrict__ scratch, size_t scratch_job_stride, unsigned R,
@@ -246,14 +247,18 @@ clade_table_kernel(FusedJob *__restrict__ jobs, const uint8_t *__restrict__ maps
 
 hipError_t launch_clade_tables(const FusedArgs &a, const uint8_t *d_maps, double *d_scratch,
                                size_t scratch_job_stride, unsigned n_jobs, unsigned max_groups,
-                               hipStream_t stream) {
+                               bool slim, hipStream_t stream) {
   if (!n_jobs || !max_groups) return hipSuccess;
-  if (a.table_rows > 16)
-    clade_table_kernel<64><<<dim3(max_groups, n_jobs), 64, 0, stream>>>(
+  if (a.table_rows > 16 && slim)
+    clade_table_kernel<64, 64><<<dim3(max_groups, n_jobs), 64, 0, stream>>>(
+        const_cast<FusedJob *>(a.jobs), d_maps, a.pmat, const_cast<double *>(a.tiptab), a.pmat_job_stride,
+        a.tiptab_job_stride, d_scratch, scratch_job_stride, a.rate_cats, a.any_unsafe);
+  else if (a.table_rows > 16)
+    clade_table_kernel<64, 256><<<dim3(max_groups, n_jobs), 256, 0, stream>>>(
         const_cast<FusedJob *>(a.jobs), d_maps, a.pmat, const_cast<double *>(a.tiptab), a.pmat_job_stride,
         a.tiptab_job_stride, d_scratch, scratch_job_stride, a.rate_cats, a.any_unsafe);
   else
-    clade_table_kernel<16><<<dim3(max_groups, n_jobs), 64, 0, stream>>>(
+    clade_table_kernel<16, 64><<<dim3(max_groups, n_jobs), 64, 0, stream>>>(
         const_cast<FusedJob *>(a.jobs), d_maps, a.pmat, const_cast<double *>(a.tiptab), a.pmat_job_stride,
         a.tiptab_job_stride, d_scratch, scratch_job_stride, a.rate_cats, a.any_unsafe);
   return hipGetLastError();

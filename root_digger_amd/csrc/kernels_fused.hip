@@ -142,9 +142,18 @@ __device__ __forceinline__ unsigned load_code(__amdgpu_buffer_rsrc_t rs, int vof
 // ordinary case: a 100-taxon tree never comes near 2^-256) are jumped over instead of being
 // issued with an empty EXEC mask -- which costs their issue cycles all the same: ten vector
 // instructions per step at two sites per lane, c2 70.5k -> 75.2k - 76.7k evaluations/s.
-template <int NS>
+// (RDAMD_ABL_NOCHECK, ablation builds only -- timing, results are garbage where a rescale is due:
+// 1 = no rescale test on the running-CLV x tip steps, 2 = none at all; profiles/rescale_ab.sh)
+template <int NS, bool TEST = true>
 __device__ __forceinline__ void combine_sites(const double (&tx)[NS][4], const double (&ty)[NS][4],
                                               double (&v)[NS][4], int (&sc)[NS]) {
+  if constexpr (!TEST) {
+#pragma unroll
+    for (int q = 0; q < NS; ++q)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[q][k] = tx[q][k] * ty[q][k];
+    return;
+  }
   unsigned hmax[NS];
   bool any_small = false;
 #pragma unroll
@@ -165,6 +174,12 @@ __device__ __forceinline__ void combine_sites(const double (&tx)[NS][4], const d
       }
   }
 }
+
+#if defined(RDAMD_ABLATION) && defined(RDAMD_ABL_NOCHECK)
+constexpr bool kTestRT = false, kTestRP = RDAMD_ABL_NOCHECK < 2;
+#else
+constexpr bool kTestRT = true, kTestRP = true;
+#endif
 
 // TTCHECK: rescale test on tip-tip steps too.  A variant is queued over all jobs of a batch
 // (the one with the test only if the batch raised a flag at all, launch_fused_eval_ns); a
@@ -488,20 +503,20 @@ fused_dna_eval_kernel(FusedArgs a) {
       RDAMD_LOAD_TIPS(nxt, ncx, ncy, nex, ney) RDAMD_LATE_DESC(cur, idx2)                       \
       _Pragma("unroll") for (int q = 0; q < NS; ++q) matvec(M, st.v[q], tx[q]);                 \
       RDAMD_LOAD_M(nxt, M)                                                                      \
-      combine_sites<NS>(tx, ty, st.v, st.sc);                                                   \
+      combine_sites<NS, kTestRT>(tx, ty, st.v, st.sc);                                          \
     } else { /* kFusedRP: running CLV times M, sibling already multiplied when parked */        \
       if (kind & 0x400u) { /* the sibling waits in the register slot: used in place */          \
         RDAMD_LOAD_TIPS(nxt, ncx, ncy, nex, ney) RDAMD_LATE_DESC(cur, idx2)                     \
         _Pragma("unroll") for (int q = 0; q < NS; ++q) matvec(M, st.v[q], tx[q]);               \
         RDAMD_LOAD_M(nxt, M)                                                                    \
         _Pragma("unroll") for (int q = 0; q < NS; ++q) st.sc[q] += s0sc[q];                     \
-        combine_sites<NS>(tx, s0, st.v, st.sc);                                                 \
+        combine_sites<NS, kTestRP>(tx, s0, st.v, st.sc);                                                 \
       } else if (RL >= 2 && (kind & 0x1000u)) {                                                 \
         RDAMD_LOAD_TIPS(nxt, ncx, ncy, nex, ney) RDAMD_LATE_DESC(cur, idx2)                     \
         _Pragma("unroll") for (int q = 0; q < NS; ++q) matvec(M, st.v[q], tx[q]);               \
         RDAMD_LOAD_M(nxt, M)                                                                    \
         _Pragma("unroll") for (int q = 0; q < NS; ++q) st.sc[q] += s1sc[q];                     \
-        combine_sites<NS>(tx, s1, st.v, st.sc);                                                 \
+        combine_sites<NS, kTestRP>(tx, s1, st.v, st.sc);                                                 \
       } else {                                                                                  \
         int scy[NS];                                                                            \
         --sp;                                                                                   \
@@ -519,7 +534,7 @@ fused_dna_eval_kernel(FusedArgs a) {
         _Pragma("unroll") for (int q = 0; q < NS; ++q) matvec(M, st.v[q], tx[q]);               \
         RDAMD_LOAD_M(nxt, M)                                                                    \
         _Pragma("unroll") for (int q = 0; q < NS; ++q) st.sc[q] += scy[q];                      \
-        combine_sites<NS>(tx, ty, st.v, st.sc);                                                 \
+        combine_sites<NS, kTestRP>(tx, ty, st.v, st.sc);                                        \
       }                                                                                         \
     }                                                                                           \
   }
@@ -716,13 +731,89 @@ fused_pmatrix_k4_kernel(const double *__restrict__ q, const double *__restrict__
   }
 }
 
+// P-matrices for a batch of jobs, the form for a launch that has the device to itself
+// (rdamd_evaluate_batch: everything on one stream): one thread per (job, matrix, rate).
+// Same scaling-and-squaring / 16-term Taylor core as pmatrix_k4_kernel.
+__global__ void __launch_bounds__(64)
+fused_pmatrix_k4_wide_kernel(const double *__restrict__ q, const double *__restrict__ rates,
+                        FusedJob *__restrict__ jobs, unsigned n_jobs,
+                        unsigned n_mat, unsigned R, double *__restrict__ pmat,
+                        double *__restrict__ tiptab, size_t pmat_job_stride, size_t tiptab_job_stride,
+                        unsigned table_rows, unsigned *__restrict__ any_unsafe) {
+  // the wave's 64 results, for the cooperative stores below ([problem][17]: no bank conflict
+  // when every lane reads its own row)
+  __shared__ double sh[64 * 17];
+  __shared__ unsigned long long base_pm[64], base_tt[64];
+  const unsigned lane = threadIdx.x;
+  const size_t per_job = (size_t)n_mat * R;
+  const size_t total = per_job * n_jobs;
+  const size_t gid_raw = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = gid_raw < total;
+  const size_t gid = live ? gid_raw : total - 1;   // (idle lanes of the last wave repeat its last problem)
+  const unsigned job = (unsigned)(gid / per_job);
+  const unsigned rem = (unsigned)(gid % per_job);
+  const unsigned m = rem / R, r = rem % R;
+  const double t = jobs[job].brlen[m] * rates[(size_t)job * R + r];
+  const double *qq = q + (size_t)job * 16;
+  double out[16];
+  expm_k4(qq, t, out);   // (the one definition of the arithmetic, expm_k4.hpp)
+  // Stores: a thread's own 16 + 64 doubles would go out as 80 instructions of 64 lanes x 8
+  // bytes, 512 bytes apart -- 64 cache lines each (235 MB of HBM traffic for 100 MB of data
+  // on c2).  Instead the wave parks its results in LDS and writes problem by problem, a lane
+  // per element: 512 contiguous bytes per instruction.
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    out[i] = out[i] <= 0.0 ? 0.0 : out[i];   // (<=: a -0.0 becomes +0.0 -- the rescale tests read high words)
+    sh[lane * 17 + i] = out[i];
+  }
+  base_pm[lane] = (unsigned long long)job * pmat_job_stride + ((size_t)m * R + r) * 16;
+  base_tt[lane] = (unsigned long long)job * tiptab_job_stride + ((size_t)m * R + r) * 64;
+  __syncthreads();
+  const unsigned n_live = (unsigned)(total - (size_t)blockIdx.x * 64 < 64 ? total - (size_t)blockIdx.x * 64 : 64);
+#pragma unroll 4
+  for (unsigned it = 0; it < 16; ++it) {   // P: four problems per instruction
+    const unsigned e = it * 64 + lane, pr = e >> 4, k = e & 15u;
+    if (pr < n_live) pmat[base_pm[pr] + k] = sh[pr * 17 + k];
+  }
+  // tip table of a (matrix, rate): row c = sum over the states in code c; my element of every
+  // problem's table (64-row launches: the evaluator's LDS image, [half][code][2 states] -- it
+  // goes there by DMA; 16-row launches: [code][state])
+  const unsigned c = table_rows > 16 ? (lane >> 1) & 15u : lane >> 2;
+  const unsigned i = table_rows > 16 ? (lane >> 5) * 2 + (lane & 1u) : lane & 3u;
+  for (unsigned pr = 0; pr < n_live; ++pr) {
+    const double *o = sh + pr * 17 + i * 4;
+    double acc = 0.0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if ((c >> j) & 1) acc += o[j];
+    tiptab[base_tt[pr] + lane] = acc;
+  }
+  // every table entry is a sum of P entries, so the smallest non-zero P entry bounds
+  // them all from below (FusedJob::tt_unsafe; 2^-128 = 0x1p-128)
+  bool tiny = false;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) tiny = tiny || (out[k] > 0.0 && out[k] < 0x1p-128);
+  if (tiny) {
+    jobs[job].tt_unsafe = 1u;   // (every writer stores the same value)
+    *any_unsafe = 1u;
+  }
+}
+
+// slim: the launch runs BESIDE an evaluator (pipelined batches): one-wave workgroups that fit
+// the wave slots it leaves; otherwise the one-thread-per-problem form, which is ~60 us per
+// 197-job batch cheaper when it has the device to itself.  Same bits either way.
 hipError_t launch_fused_pmatrix(const FusedArgs &a, const double *d_q, const double *d_rates,
-                                unsigned n_jobs, unsigned n_mat, hipStream_t stream) {
+                                unsigned n_jobs, unsigned n_mat, bool slim, hipStream_t stream) {
   const size_t total = (size_t)n_jobs * n_mat * a.rate_cats;
   if (!total) return hipSuccess;
-  fused_pmatrix_k4_kernel<<<(unsigned)((total + 63) / 64), 64, 0, stream>>>(
-      d_q, d_rates, const_cast<FusedJob *>(a.jobs), n_jobs, n_mat, a.rate_cats, const_cast<double *>(a.pmat),
-      const_cast<double *>(a.tiptab), a.pmat_job_stride, a.tiptab_job_stride, a.table_rows, a.any_unsafe);
+  if (slim)
+    fused_pmatrix_k4_kernel<<<(unsigned)((total + 63) / 64), 64, 0, stream>>>(
+        d_q, d_rates, const_cast<FusedJob *>(a.jobs), n_jobs, n_mat, a.rate_cats, const_cast<double *>(a.pmat),
+        const_cast<double *>(a.tiptab), a.pmat_job_stride, a.tiptab_job_stride, a.table_rows, a.any_unsafe);
+  else
+    fused_pmatrix_k4_wide_kernel<<<(unsigned)((total + 63) / 64), 64, 0, stream>>>(
+        d_q, d_rates, const_cast<FusedJob *>(a.jobs), n_jobs, n_mat, a.rate_cats, const_cast<double *>(a.pmat),
+        const_cast<double *>(a.tiptab), a.pmat_job_stride, a.tiptab_job_stride, a.table_rows, a.any_unsafe);
   return hipGetLastError();
 }
 

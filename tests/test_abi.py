@@ -3,6 +3,8 @@ include/root_digger_amd.h declares (no compute calls are made here)."""
 import ctypes
 import os
 import re
+import subprocess
+import sys
 
 import pytest
 
@@ -69,6 +71,19 @@ def test_product_library_has_no_timing_only_switches():
     for name in (b"RDAMD_K20_VAR", b"RDAMD_FUSED_NS", b"RDAMD_FUSED_DEPTH", b"RDAMD_FUSED_RL", b"RDAMD_FUSED_RW",
                  b"RDAMD_FUSED_SPILL_MIN"):
         assert name not in blob, name
+
+
+def test_package_loader_knows_one_library():
+    """no environment variable may swap the product library for another
+    build (the ablation library computes garbage by design); A/B tooling hands the package a
+    pre-loaded module instead (profiles/with_ablation.py)."""
+    src = open(os.path.join(util.ROOT, "root_digger_amd", "_lib.py")).read()
+    assert "environ" not in src and "getenv" not in src
+    env = dict(os.environ, RDAMD_LIBRARY="/nonexistent/librdamd_ablation.so")
+    out = subprocess.run([sys.executable, "-c", "import root_digger_amd as rd; print(rd.lib_path)"],
+                         cwd=util.ROOT, env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    assert out.stdout.strip().endswith(os.path.join("root_digger_amd", "lib", "librdamd.so"))
 
 
 def test_host_side_gamma_and_maps_work_without_gpu():

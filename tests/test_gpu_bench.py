@@ -110,3 +110,4 @@ def test_rccl_calls_of_the_multi_gpu_path_with_one_rank():
     assert a["n_gpus"] == 1 and a["lnl_check"] == b["lnl_check"]
     c = run_bench("--no-cpu-baseline", env=env)          # candidate sharding: barrier + MAX only
     assert c["value"] > 0
+    assert c["rccl_ranks"] == 1 and a["rccl_ranks"] == 1   # a real all-reduce over the communicator

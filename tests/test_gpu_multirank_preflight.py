@@ -49,6 +49,33 @@ def test_eight_rank_grid_bench_on_the_c5_tree():
     assert abs(s["lnl_check"] - full["lnl_check"]) <= 1e-9 * abs(full["lnl_check"])
 
 
+def test_default_eight_rank_line_carries_the_site_sharded_and_grid_legs():
+    """what the DRIVER runs -- `bench.py --gpus 8`, no --shard -- must measure
+    what north_star names.  Beside the candidate-sharded value (weak scaling, no data-path
+    collective) the line carries `site_sharded` (the same workload, every rank a site block, an
+    all-reduce of the per-block lnLs per batch) and `grid` (4 candidate groups x 2 site shards);
+    their checksums are the one-rank run's.  (gloo here: eight ranks share device 0, which RCCL
+    refuses; the driver's run goes through RCCL and adds `rccl_ranks`.)"""
+    shape = ["--config", "c5", "--sites", "512", "--steps", "2", "--batch", "8"]
+    d = run_bench("--gpus", "8", "--dist-backend", "gloo", "--device", "0", *shape)
+    assert d["n_gpus"] == 8 and d["scaling"] == "weak" and d["config"]["sharding"] == "candidate roots"
+    full = run_bench(*shape)
+    ss, gr = d["site_sharded"], d["grid"]
+    assert ss["scaling"] == "strong" and ss["sites_per_rank"] == 64 and ss["value"] > 0
+    assert abs(ss["lnl_check"] - full["lnl_check"]) <= 1e-9 * abs(full["lnl_check"])
+    one = run_bench("--as-candidate-group", "0/4", *shape)
+    assert gr["scaling"] == "weak" and gr["sharding"].startswith("4 candidate groups x 2 site shards")
+    assert gr["sites_per_rank"] == 256
+    assert abs(gr["lnl_check"] - one["lnl_check"]) <= 1e-9 * abs(one["lnl_check"])
+    # rank 0's own candidates (the first eighth) in the headline value's checksum
+    mine = run_bench("--as-candidate-group", "0/8", *shape)
+    assert abs(d["lnl_check"] - mine["lnl_check"]) <= 1e-9 * abs(mine["lnl_check"])
+    # two ranks: no grid (one candidate group would be left), the site-sharded leg only
+    d2 = run_bench("--gpus", "2", "--dist-backend", "gloo", "--device", "0", *shape)
+    assert "site_sharded" in d2 and "grid" not in d2
+    assert abs(d2["site_sharded"]["lnl_check"] - full["lnl_check"]) <= 1e-9 * abs(full["lnl_check"])
+
+
 def test_eight_rank_site_sharded_rd_amd_on_the_c5_tree(tmp_path):
     """rd_amd --site-shards 2 --site-reduce host with 8 ranks (4 x 2 grid) on c5's tree at 192
     sites: the checkpoint holds the one-rank run's records (root position optimised at every

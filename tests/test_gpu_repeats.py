@@ -227,6 +227,78 @@ def test_repeats_switch_and_stale_schedules():
     b.destroy()
 
 
+def test_wide_schedule_without_pseudo_tips_survives_new_tip_states():
+    """a 64-row schedule in which no clade is small enough to fold (ambiguity codes
+    everywhere: a cherry has up to 225 classes) holds no class codes, so it stays valid when a
+    tip gets new characters -- but rdamd_set_tip_states drops the 16-bit code arena it reads.
+    The next batch must find the arena rebuilt from the new characters."""
+    rng = np.random.default_rng(611)
+    w = synth.workload(9, 1500, 4, 4, 611)
+    tree = rd.Tree.from_newick(w["newick"])
+    iupac = np.frombuffer(b"ACGTRYSWKMBDHVN", dtype=np.uint8)
+    seqs = {k: iupac[rng.integers(0, 15, 1500)].tobytes().decode() for k in w["seqs"]}
+    a = rd.Partition.for_tree(tree, 4, 1500, 4, attributes=rd.ATTRIB_SITE_REPEATS)
+    o = OraclePartition.for_tree(tree, 4, 1500, 4)
+    util.load_tips(a, tree, seqs, rd.MAP_NT)
+    util.load_tips(o, tree, seqs, ORC_MAP_NT)
+    rl = tree.root_location(5).with_ratio(0.3)
+    s = a.schedule(*tree.generate_operations(rl))
+    assert s.stats()["pseudo_tips"] == 0
+    freqs = [0.2, 0.3, 0.3, 0.2]
+    rates = rd.compute_gamma_cats(0.7, 4)
+    got = a.evaluate_batch([s], [w["subst"]], [freqs], [rates])[0]
+    assert util.rel_err(got, oracle_eval(o, tree, rl, w["subst"], freqs, rates)) < LNL_TOL
+    label = sorted(seqs)[2]
+    seqs[label] = seqs[label][::-1]
+    for p, m in ((a, rd.MAP_NT), (o, ORC_MAP_NT)):
+        p.set_tip_states(tree.tip_index(label), m, seqs[label])
+    got2 = a.evaluate_batch([s], [w["subst"]], [freqs], [rates])[0]      # the SAME schedule
+    want2 = oracle_eval(o, tree, rl, w["subst"], freqs, rates)
+    assert got2 != got and util.rel_err(got2, want2) < LNL_TOL
+    a.destroy()
+
+
+@pytest.mark.parametrize("classes", CLASSES)
+def test_shared_matrix_index_is_not_folded(classes):
+    """the C ABI (like coraxlib's) lets two branches share a P-matrix index.  A
+    pseudo-tip's table lives in the tip-table slot of the branch above it, which is only free
+    when that index belongs to this one branch: a list that shares an index is evaluated
+    without folding, and still agrees with the oracle."""
+    w = synth.workload(12, 900, 4, 4, 623)
+    tree = rd.Tree.from_newick(w["newick"])
+    a, b, o = trio(tree, w["seqs"], 4, classes=classes)
+    rl = tree.root_location(4).with_ratio(0.6)
+    ops, pmi, brl = tree.generate_operations(rl)
+    ops = list(ops)
+    pmi, brl = list(pmi), list(brl)
+    # the branch above a folded cherry and one tip branch elsewhere share a matrix (same length)
+    plain = a.schedule(ops, pmi, brl)
+    assert plain.stats()["pseudo_tips"] > 0
+    inner = [i for i, op in enumerate(ops[:-1]) if op.child1_clv_index < tree.tip_count()
+             and op.child2_clv_index < tree.tip_count()]
+    cherry = ops[inner[0]]
+    above = next(op for op in ops if cherry.parent_clv_index in (op.child1_clv_index, op.child2_clv_index))
+    m_above = above.child1_matrix_index if above.child1_clv_index == cherry.parent_clv_index else above.child2_matrix_index
+    other = ops[inner[1]]
+    m_old = other.child1_matrix_index
+    other.child1_matrix_index = m_above                    # a tip branch now reads the cherry's branch matrix
+    ops[inner[1]] = other
+    keep = [k for k, m in enumerate(pmi) if m != m_old]
+    pmi2, brl2 = [pmi[k] for k in keep], [brl[k] for k in keep]
+    s = a.schedule(ops, pmi2, brl2)
+    assert s.stats()["pseudo_tips"] == 0
+    freqs = [0.25, 0.25, 0.3, 0.2]
+    rates = rd.compute_gamma_cats(1.3, 4)
+    got = a.evaluate_batch([s], [w["subst"]], [freqs], [rates])[0]
+    for p in (o,):
+        p.set_subst_params(0, w["subst"]); p.set_frequencies(0, freqs); p.set_category_rates(rates)
+        p.update_prob_matrices(pmi2, brl2)
+        p.update_clvs(ops)
+        want = p.compute_root_loglikelihood(tree.root_clv_index(), tree.root_scaler_index())
+    assert util.rel_err(got, want) < LNL_TOL
+    a.destroy(); b.destroy()
+
+
 def test_binary_data_with_repeats():
     """2-state partitions run on the 4-state kernels and fold their clades too."""
     rng = np.random.default_rng(171)
