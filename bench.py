@@ -574,8 +574,17 @@ def main():
     def clv_roofline(ms, launches, evals):
         bytes_clv = clv_kernel_bytes(n, S, R, K) * evals
         achieved = bytes_clv / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        # `achieved` counts SURVEY 8d's algorithmic bytes; the kernel forwards most CLV reads
+        # through registers / LDS (measured traffic ~0.53 x algorithmic), so on shapes that
+        # fill the chip the algorithmic rate can pass the nominal HBM peak: frac is capped at 1
+        # and the uncapped ratio is stated beside it -- as is, where counters exist for the
+        # command, the rate of the bytes that really crossed HBM (`counter_gbs`, filled below)
+        ratio = achieved / HBM_PEAK_GBS
+        capped = {"frac_uncapped": round(ratio, 4),
+                  "frac_note": "algorithmic bytes / time exceeds the nominal HBM peak: reads are forwarded "
+                               "on chip; frac capped at 1"} if ratio > 1.0 else {}
         return {"kernel": clv_kernel, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "unit": "GB/s", "frac": round(min(ratio, 1.0), 4), **capped, "traffic": None,
                 "bytes_per_launch": round(bytes_clv / max(launches, 1)),
                 "avg_launch_ms": round(ms / max(launches, 1), 5), "launches": launches}
 
@@ -624,7 +633,7 @@ def main():
                          "matvecs_per_evaluation": round(executed_timed["matvecs"] / ev, 2),
                          "clade_table_rows_per_evaluation_and_rate": round(executed_timed["clade_rows"] / ev, 1),
                          "site_repeats": bool(repeats),
-                         "max_classes": (args.repeat_classes if repeats else 0)},
+                         "max_classes": (part.site_repeats() if repeats else 0)},
             "issued_fp64_tflops": round(fp64_issued / (ms * 1e-3) / 1e12, 2) if ms > 0 else 0.0,
             "avg_launch_ms": round(ms / max(launches, 1), 4), "launches": launches,
             "share_of_step": round(ms * 1e-3 / elapsed, 3),
@@ -673,6 +682,10 @@ def main():
             if default_cmd:
                 extra["clv_kernel"]["traffic"], extra["clv_kernel"]["traffic_source"] = profiled_traffic(
                     clv_kernel, nb, args.config)
+                if extra["clv_kernel"]["traffic"]:   # the bytes that really crossed HBM, per second
+                    gbs = extra["clv_kernel"]["traffic"] / (extra["clv_kernel"]["avg_launch_ms"] * 1e-3) / 1e9
+                    extra["clv_kernel"]["counter_gbs"] = round(gbs, 1)
+                    extra["clv_kernel"]["counter_frac"] = round(gbs / HBM_PEAK_GBS, 4)
         except StaleProfile as e:
             if not args.allow_stale_profile:
                 raise SystemExit("bench.py: " + str(e))
@@ -696,7 +709,14 @@ def main():
                                 % (cgroups, sgroups) if grid else
                                 "site blocks + RCCL all-reduce" if site_sharded else "candidate roots"),
                    "path": "fused batch" if use_fused else "per-operation"},
+        # BASELINE's second metric, two ways: over all n-1 operations of every evaluation (the
+        # ALGORITHMIC-EQUIVALENT figure: what a traversal without site repeats would update) and
+        # over the operations the schedules really run per site (clades folded into per-class
+        # tables are not site-CLV updates)
         "site_clv_updates_per_sec": round(value * (n - 1) * S_total, 1),
+        "site_clv_updates_per_sec_note": "algorithmic equivalent: (n-1) operations x sites per evaluation",
+        "site_clv_updates_per_sec_executed": round(
+            value * (executed_timed["steps"] / max(executed_timed["evals"], 1) if use_fused else n - 1) * S_total, 1),
         # sum of the lnLs rank 0 saw in the timed region: identical across world
         # sizes when site-sharded (each job's lnL is the all-reduced total)
         "lnl_check": check,
@@ -753,6 +773,27 @@ def host_topology():
         by_socket.setdefault(p_, []).append(c)
     sockets = len(by_socket)
     return sockets, max(1, len(cores) // sockets), logical, {k: sorted(v) for k, v in by_socket.items()}
+
+
+def host_load():
+    """What else the host is doing / is allowed to do: the cgroup's CPU quota (cpu.max), its
+    memory limit, the load average, and the CPUs this process may run on."""
+    def read(path):
+        try:
+            return open(path).read().strip()
+        except OSError:
+            return None
+    out = {"cgroup_cpu_max": read("/sys/fs/cgroup/cpu.max"),
+           "cgroup_memory_max": read("/sys/fs/cgroup/memory.max"),
+           "affinity_cpus": len(os.sched_getaffinity(0))}
+    try:
+        out["loadavg"] = [round(x, 2) for x in os.getloadavg()]
+    except OSError:
+        out["loadavg"] = None
+    if out["cgroup_cpu_max"] is None:   # cgroup v1
+        q, per = read("/sys/fs/cgroup/cpu/cpu.cfs_quota_us"), read("/sys/fs/cgroup/cpu/cpu.cfs_period_us")
+        out["cgroup_cpu_max"] = "%s %s" % (q, per) if q and per else None
+    return out
 
 
 def site_repeats_class_ratio(tree, seqs, samples=3):
@@ -862,7 +903,16 @@ def cpu_baseline(w, tree, cmap, freqs, n, S, K, R, params, roots, budget, gpu_ev
     per_part = (2 * n - 2) * S * R * K * 8 * 1.15 + n * S * 8
     allowed = os.sched_getaffinity(0)
     socket0 = [c for c in socket_cpus[min(socket_cpus)] if c in allowed]
-    threads = int(max(1, min(len(socket0), 0.4 * avail // per_part, len(scheds))))
+    # (a cgroup CPU quota below the core count -- a leased slice of a node -- is all the CPU
+    # time the threads can get: more threads than that only take turns)
+    quota = None
+    cm = host_load()["cgroup_cpu_max"]
+    if cm and cm.split()[0] not in ("max", "-1"):
+        try:
+            quota = max(1, int(float(cm.split()[0]) / float(cm.split()[1])))
+        except (ValueError, IndexError, ZeroDivisionError):
+            quota = None
+    threads = int(max(1, min(len(socket0), quota or len(socket0), 0.4 * avail // per_part, len(scheds))))
     if threads > 1:
         counts = [0] * threads
         window = max(0.4 * budget, 2.0 / max(out["value"], 1e-9))
@@ -895,16 +945,32 @@ def cpu_baseline(w, tree, cmap, freqs, n, S, K, R, params, roots, budget, gpu_ev
         for th in ths:
             th.join()
         wall = time.perf_counter() - t0
-        out["one_socket"] = {"value": round(sum(counts) / wall, 4), "unit": "evals/s",
-                             "cores": threads,
-                             "sample": "%d evaluations, one candidate root per thread, %d threads%s, each "
-                                       "with its own partition first-touched from its core "
-                                       "(%d socket(s) x %d physical cores on this host%s) for %.1f s"
-                                       % (sum(counts), threads,
-                                          " pinned one per physical core of socket 0" if all(pinned) else " (not pinned)",
-                                          sockets, per_socket,
-                                          "" if threads == per_socket else "; capped by memory/affinity",
-                                          wall)}
+        rates = sorted(c / wall for c in counts)
+        agg = sum(counts) / wall
+        # An honest name for what was measured: "one socket" only if the threads
+        # really had a socket's cores to themselves -- i.e. the aggregate is at least 20 x the
+        # one-thread rate (64 cores streaming their own CLVs reach that on an idle socket).  On
+        # a leased slice of a busy node (cgroup CPU quota, neighbours on the memory system) the
+        # figure is "what this many host threads got here", and says so.
+        leg = "one_socket" if agg >= 20.0 * out["value"] and threads >= 0.9 * per_socket else "host_threads"
+        out[leg] = {"value": round(agg, 4), "unit": "evals/s", "cores": threads,
+                    "ratio_to_one_thread": round(agg / max(out["value"], 1e-12), 2),
+                    "per_thread_evals_per_s": {"min": round(rates[0], 4), "median": round(rates[len(rates) // 2], 4),
+                                               "max": round(rates[-1], 4)},
+                    "sample": "%d evaluations, one candidate root per thread, %d threads%s, each "
+                              "with its own partition first-touched from its core "
+                              "(%d socket(s) x %d physical cores on this host%s) for %.1f s"
+                              % (sum(counts), threads,
+                                 " pinned one per physical core of socket 0" if all(pinned) else " (not pinned)",
+                                 sockets, per_socket,
+                                 "" if threads == per_socket else "; capped by memory/affinity",
+                                 wall)}
+        if leg == "host_threads":
+            out[leg]["note"] = ("NOT a single-socket figure: %d pinned threads (cgroup CPU quota: %s CPUs) reached "
+                                "%.1f x the one-thread rate; the host is a leased, shared slice of a %d x %d-core "
+                                "node, see `host`" % (threads, quota if quota else "none", agg / max(out["value"], 1e-12),
+                                                      sockets, per_socket))
+    out["host"].update(host_load())
     o.destroy()
     return out
 

@@ -240,6 +240,9 @@ unsigned int rdamd_schedule_stack_depth(const rdamd_schedule_t *s);
  * 64 (the attribute's default and the largest accepted value) = 64-row tables as well, 16-bit
  * codes.  Schedules compiled under limits on different sides of 16 cannot share a batch. */
 int rdamd_partition_set_site_repeats(rdamd_partition_t *p, unsigned int max_classes);
+/* the class limit in force (64 unless rdamd_partition_set_site_repeats changed it); 0: no
+ * site repeats on this partition */
+unsigned int rdamd_partition_site_repeats(const rdamd_partition_t *p);
 /* What one (site, rate) executes per traversal of a compiled schedule, and what the
  * repeats saved: the denominators of the roofline figures (bench.py). */
 typedef struct rdamd_schedule_stats {

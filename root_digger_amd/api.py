@@ -102,6 +102,7 @@ class ScheduleStats(C.Structure):
 
 _sig("rdamd_schedule_stats", C.c_int, _vp, C.POINTER(ScheduleStats))
 _sig("rdamd_partition_set_site_repeats", C.c_int, _vp, _u)
+_sig("rdamd_partition_site_repeats", _u, _vp)
 _sig("rdamd_evaluate_batch", C.c_int, _vp, _u, C.POINTER(_vp), _pd, _pd, _pd, _pd, _pd)
 _sig("rdamd_evaluate_batch_device", C.c_int, _vp, _u, C.POINTER(_vp), _pd, _pd, _pd, _pd, _vp)
 _sig("rdamd_evaluate_batch_submit", C.c_int, _vp, _u, _u, C.POINTER(_vp), _pd, _pd, _pd, _pd)
@@ -574,6 +575,10 @@ class Partition:
         """rdamd_partition_set_site_repeats: class limit of the pseudo-tips (0 = off)."""
         if lib.rdamd_partition_set_site_repeats(self._h, max_classes) != 1:
             _fail("partition_set_site_repeats")
+
+    def site_repeats(self):
+        """the pseudo-tips' class limit in force (0: no site repeats)."""
+        return int(lib.rdamd_partition_site_repeats(self._h))
 
     def set_tip_states(self, tip_index, cmap, sequence):
         if isinstance(sequence, str):

@@ -479,6 +479,11 @@ int rdamd_schedule_stats(const rdamd_schedule_t *s, rdamd_schedule_stats_t *out)
   return RDAMD_SUCCESS;
 }
 
+unsigned int rdamd_partition_site_repeats(const rdamd_partition_t *p) {
+  if (p->states != 4 || !(p->attributes & RDAMD_ATTRIB_SITE_REPEATS)) return 0;
+  return p->clades ? p->clades->max_classes : rdamd::CladeCache().max_classes;
+}
+
 int rdamd_partition_set_site_repeats(rdamd_partition_t *p, unsigned int max_classes) {
   clear_error();
   std::lock_guard<std::mutex> guard(p->launch_mu);

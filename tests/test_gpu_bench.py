@@ -49,8 +49,35 @@ def test_bench_line_has_the_contract_fields():
     # the stated baseline is the oracle's AVX2 loop; host sockets x cores are stated
     assert "AVX2" in c["sample"] and c["scalar_loop_1_thread"] > 0
     assert c["host"]["sockets"] >= 1 and c["host"]["cores_per_socket"] >= 1
-    if "one_socket" in c:
-        assert 1 < c["one_socket"]["cores"] <= c["host"]["cores_per_socket"]
+    # the many-thread leg names itself by what was measured: "one_socket" only when
+    # the threads reached >= 20 x the one-thread rate, "host_threads" (with a note) otherwise
+    legs = [k for k in ("one_socket", "host_threads") if k in c]
+    assert len(legs) <= 1
+    for k in legs:
+        assert 1 < c[k]["cores"] <= c["host"]["cores_per_socket"]
+        assert c[k]["per_thread_evals_per_s"]["min"] <= c[k]["per_thread_evals_per_s"]["max"]
+        assert (k == "one_socket") == (c[k]["ratio_to_one_thread"] >= 20.0 and
+                                       c[k]["cores"] >= 0.9 * c["host"]["cores_per_socket"])
+    assert "loadavg" in c["host"] and "cgroup_cpu_max" in c["host"] and c["host"]["affinity_cpus"] >= 1
+    # BASELINE's second metric: algorithmic-equivalent and executed (site repeats fold operations)
+    assert 0 < d["site_clv_updates_per_sec_executed"] <= d["site_clv_updates_per_sec"]
+    assert r["schedule"]["max_classes"] == 64       # the library's effective limit, not null
+
+
+@pytest.mark.parametrize("config,extra", [("c2", []), ("c3", []), ("c4", ["--sites", "20000"]),
+                                          ("c5", ["--sites", "20000"])])
+def test_no_roofline_fraction_exceeds_one(config, extra):
+    """every published fraction is a statement about a kernel against a peak: <= 1 on every
+    BASELINE shape (c4 / c5 at a site count that keeps the test short; c1 above).  Where the
+    CLV kernel's algorithmic-byte rate passes the nominal HBM peak (reads forwarded on chip),
+    the cap is stated."""
+    d = run_bench("--no-cpu-baseline", "--sustain-seconds", "0", "--allow-stale-profile", *extra,
+                  config=config, steps="2", batch="40")
+    assert 0 < d["roofline"]["frac"] <= 1.0
+    k = d["clv_kernel"]
+    assert 0 < k["frac"] <= 1.0
+    if "frac_uncapped" in k:
+        assert k["frac_uncapped"] > 1.0 and k["frac"] == 1.0
 
 
 def test_site_sharded_bench_matches_candidate_sharded_checksum():
