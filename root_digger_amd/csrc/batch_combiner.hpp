@@ -188,11 +188,12 @@ public:
     scope_t &operator=(const scope_t &) = delete;
   };
 
-  // n <= 8 root positions (4 at 8 rate categories) of `op` on `part`: branch lengths l1 / l2,
-  // values to out
-  void evaluate(rdamd_partition_t *part, const rdamd_operation_t &op, const unsigned *params_idx,
-                const double *l1, const double *l2, unsigned n, double *out) {
-    request_t req{part, op, params_idx, {0}, {0}, n, out};
+  // n <= 8 root positions (4 at 8 rate categories) of `op` on every one of the model's
+  // `n_parts` partitions: branch lengths l1 / l2; out[8 i + a] = lnL of partition i at
+  // position a (the caller sums over its partitions)
+  void evaluate(rdamd_partition_t *const *parts, const unsigned *const *params_idx, unsigned n_parts,
+                const rdamd_operation_t &op, const double *l1, const double *l2, unsigned n, double *out) {
+    request_t req{parts, params_idx, n_parts, op, {0}, {0}, n, out};
     for (unsigned a = 0; a < n; ++a) { req.l1[a] = l1[a]; req.l2[a] = l2[a]; }
     std::unique_lock<std::mutex> lk(_mu);
     _pending.push_back(&req);
@@ -229,9 +230,10 @@ public:
 
 private:
   struct request_t {
-    rdamd_partition_t *part;
+    rdamd_partition_t *const *parts;
+    const unsigned *const *params_idx;
+    unsigned n_parts;
     rdamd_operation_t op;
-    const unsigned *params_idx;
     double l1[RDAMD_ROOT_MAX_POSITIONS], l2[RDAMD_ROOT_MAX_POSITIONS];
     unsigned n;
     double *out;
@@ -239,23 +241,28 @@ private:
     std::string error;
   };
   static std::string launch(const std::vector<request_t *> &batch) {
-    const size_t m = batch.size();
-    std::vector<rdamd_partition_t *> parts(m);
-    std::vector<rdamd_operation_t> ops(m);
-    std::vector<const unsigned *> pidx(m);
     constexpr unsigned P = RDAMD_ROOT_MAX_POSITIONS;
-    std::vector<double> l1(P * m), l2(P * m), out(P * m);
-    std::vector<unsigned> npos(m);
-    for (size_t i = 0; i < m; ++i) {
-      parts[i] = batch[i]->part; ops[i] = batch[i]->op; pidx[i] = batch[i]->params_idx;
-      npos[i] = batch[i]->n;
-      for (unsigned a = 0; a < P; ++a) { l1[P * i + a] = batch[i]->l1[a]; l2[P * i + a] = batch[i]->l2[a]; }
-    }
+    size_t m = 0;
+    for (auto *r : batch) m += r->n_parts;
+    std::vector<rdamd_partition_t *> parts;
+    std::vector<rdamd_operation_t> ops;
+    std::vector<const unsigned *> pidx;
+    std::vector<double> l1, l2, out(P * m);
+    std::vector<unsigned> npos;
+    for (auto *r : batch)
+      for (unsigned i = 0; i < r->n_parts; ++i) {   // one item per (candidate, partition)
+        parts.push_back(r->parts[i]); ops.push_back(r->op); pidx.push_back(r->params_idx[i]);
+        npos.push_back(r->n);
+        l1.insert(l1.end(), r->l1, r->l1 + P);
+        l2.insert(l2.end(), r->l2, r->l2 + P);
+      }
     if (rdamd_root_loglikelihood_fused_multi((unsigned)m, parts.data(), ops.data(), pidx.data(), l1.data(),
                                              l2.data(), npos.data(), out.data()) != RDAMD_SUCCESS)
       return std::string("combined root step failed: ") + rdamd_errmsg();
-    for (size_t i = 0; i < m; ++i)
-      for (unsigned a = 0; a < batch[i]->n; ++a) batch[i]->out[a] = out[P * i + a];
+    size_t at = 0;
+    for (auto *r : batch)
+      for (unsigned i = 0; i < r->n_parts; ++i, ++at)
+        for (unsigned a = 0; a < r->n; ++a) r->out[P * i + a] = out[P * at + a];
     return std::string();
   }
   std::mutex _mu;

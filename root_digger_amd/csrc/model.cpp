@@ -306,8 +306,13 @@ double model_t::compute_lh_root(const root_location_t &root) {
   const auto &brl = std::get<2>(res);
   ++_n_root_positions;
   double lh = 0.0;
-  if (_root_combiner && _partitions.size() == 1 && !_reduce) {   // meets the other candidates' steps
-    _root_combiner->evaluate(_partitions[0], op, _param_indicies[0].data(), &brl[0], &brl[1], 1, &lh);
+  if (_root_combiner && !_reduce) {   // meets the other candidates' steps
+    std::vector<const unsigned *> pidx;
+    for (size_t i = 0; i < _partitions.size(); ++i) pidx.push_back(_param_indicies[i].data());
+    std::vector<double> v(_partitions.size() * RDAMD_ROOT_MAX_POSITIONS);
+    _root_combiner->evaluate(_partitions.data(), pidx.data(), (unsigned)_partitions.size(), op, &brl[0], &brl[1], 1,
+                             v.data());
+    for (size_t i = 0; i < _partitions.size(); ++i) lh += v[i * RDAMD_ROOT_MAX_POSITIONS];
   } else
   for (size_t i = 0; i < _partitions.size(); ++i) {
     double v = 0.0;
@@ -338,11 +343,19 @@ std::vector<double> model_t::root_lh_at(const root_location_t &root, const std::
   const rdamd_operation_t &op = std::get<0>(res);
   _n_root_positions += n;
   const size_t chunk = RDAMD_ROOT_MAX_POSITIONS;
-  if (_root_combiner && _partitions.size() == 1 && !_reduce) {   // meets the other candidates' steps
-    const size_t step = rdamd_partition_rate_cats(_partitions[0]) <= 4 ? chunk : chunk / 2;
-    for (size_t lo = 0; lo < n; lo += step)
-      _root_combiner->evaluate(_partitions[0], op, _param_indicies[0].data(), &l1[lo], &l2[lo],
-                               (unsigned)std::min(step, n - lo), &total[lo]);
+  if (_root_combiner && !_reduce) {   // meets the other candidates' steps
+    size_t step = chunk;
+    for (auto part : _partitions) step = std::min(step, rdamd_partition_rate_cats(part) <= 4 ? chunk : chunk / 2);
+    std::vector<const unsigned *> pidx;
+    for (size_t i = 0; i < _partitions.size(); ++i) pidx.push_back(_param_indicies[i].data());
+    std::vector<double> v(_partitions.size() * chunk);
+    for (size_t lo = 0; lo < n; lo += step) {
+      const unsigned cnt = (unsigned)std::min(step, n - lo);
+      _root_combiner->evaluate(_partitions.data(), pidx.data(), (unsigned)_partitions.size(), op, &l1[lo], &l2[lo],
+                               cnt, v.data());
+      for (size_t i = 0; i < _partitions.size(); ++i)   // (summed in partition order, as the plain loop does)
+        for (unsigned a = 0; a < cnt; ++a) total[lo + a] += v[i * chunk + a];
+    }
   } else {
     std::vector<double> v(n);
     for (size_t i = 0; i < _partitions.size(); ++i) {
@@ -417,11 +430,15 @@ dlh_t model_t::compute_dlh(const root_location_t &root) {
   const double l2[2] = {root_prime.brlen_compliment(), root.brlen_compliment()};
   _n_root_positions += 2;
   double fx = 0.0, fxh = 0.0;
-  if (_root_combiner && _partitions.size() == 1 && !_reduce) {
-    double v[2];
-    _root_combiner->evaluate(_partitions[0], op, _param_indicies[0].data(), l1, l2, 2, v);
-    fxh = v[0];
-    fx = v[1];
+  if (_root_combiner && !_reduce) {
+    std::vector<const unsigned *> pidx;
+    for (size_t i = 0; i < _partitions.size(); ++i) pidx.push_back(_param_indicies[i].data());
+    std::vector<double> v(_partitions.size() * RDAMD_ROOT_MAX_POSITIONS);
+    _root_combiner->evaluate(_partitions.data(), pidx.data(), (unsigned)_partitions.size(), op, l1, l2, 2, v.data());
+    for (size_t i = 0; i < _partitions.size(); ++i) {
+      fxh += v[i * RDAMD_ROOT_MAX_POSITIONS];
+      fx += v[i * RDAMD_ROOT_MAX_POSITIONS + 1];
+    }
   } else
   for (size_t i = 0; i < _partitions.size(); ++i) {
     double v[2];
@@ -850,7 +867,7 @@ void model_t::assign_indicies_by_rank_exhaustive(size_t rank, size_t num_tasks,
 // full traversal with different parameters.  Here those 1 + n evaluations are
 // one rdamd_evaluate_batch call on a schedule compiled once per optimize_params.
 double model_t::bfgs_params(model_params_t &initial, size_t pi, bfgs_target what,
-                            rdamd_schedule_t *sched, double p_min, double p_max,
+                            rdamd_schedule_t *sched, batch_combiner_t *combiner, double p_min, double p_max,
                             double epsilon, double pgtol, double factor) {
   rdamd_partition_t *part = _partitions[pi];
   const unsigned R = rdamd_partition_rate_cats(part);
@@ -888,8 +905,8 @@ double model_t::bfgs_params(model_params_t &initial, size_t pi, bfgs_target what
       std::copy(r.begin(), r.end(), rates.begin() + j * R);
       std::copy(_rate_weights[pi].begin(), _rate_weights[pi].end(), weights.begin() + j * R);
     }
-    if (_combiner) {   // meets the other candidates' requests in one launch
-      _combiner->evaluate((unsigned)m, sched, subst.data(), freqs.data(), rates.data(),
+    if (combiner) {   // meets the other candidates' requests in one launch
+      combiner->evaluate((unsigned)m, sched, subst.data(), freqs.data(), rates.data(),
                           weights.data(), out.data());
     } else if (_reduce && _reduce_device) {
       // site-sharded: the per-block lnLs stay on the device, the all-reduce is queued
@@ -972,36 +989,43 @@ void model_t::optimize_params(std::vector<partition_parameters_t> &params,
   if (!_setulb)
     throw std::runtime_error("optimize_params: no L-BFGS-B entry point set (set_lbfgsb)");
   auto sc = _tree.generate_operations(rl);
-  if (_combiner && _partitions.size() != 1)
-    throw std::runtime_error("optimize_params: the batch combiner handles one partition");
-  if (_combiner && _reduce)
+  if (!_combiners.empty() && _combiners.size() != _partitions.size())
+    throw std::runtime_error("optimize_params: one batch combiner per partition is required");
+  if (!_combiners.empty() && _reduce)
     throw std::runtime_error("optimize_params: a site-sharded model runs its candidates "
                              "sequentially (no batch combiner)");
-  batch_combiner_t::scope_t in_lockstep(_combiner);
   for (size_t i = 0; i < _partitions.size(); ++i) {
-    if (rdamd_partition_states(_partitions[i]) != 4 && rdamd_partition_states(_partitions[i]) != 2)
-      throw std::runtime_error("optimize_params: the batched objective handles 4-state and binary data");
+    // The batched objective runs on the fused evaluators: 4-state and binary data, and 20
+    // states with up to four rate categories (the 381 finite-difference evaluations of a
+    // 20-state rate matrix are one launch of fused20_eval_kernel, src/model.cpp:1490-1502).
+    const unsigned st = rdamd_partition_states(_partitions[i]);
+    if (st != 4 && st != 2 && !(st == 20 && rdamd_partition_rate_cats(_partitions[i]) <= 4))
+      throw std::runtime_error("optimize_params: the batched objective handles 4-state and binary data, and "
+                               "20-state data with up to 4 rate categories");
+    batch_combiner_t *combiner = _combiners.empty() ? nullptr : _combiners[i];
+    // (lock step: this candidate is inside partition i's objective phase from here on)
+    batch_combiner_t::scope_t in_lockstep(combiner);
     set_subst_rates(i, params[i].subst_rates);
     set_freqs_all_free(i, params[i].freqs);
     set_gamma_rates(i, params[i].gamma_alpha);
     if (_rate_category_types[i] == rate_category::FREE) set_gamma_weights(i, params[i].gamma_weights);
     auto destroy = [&](rdamd_schedule_t *s) {
-      if (_combiner) _combiner->schedule_destroy(s);
+      if (combiner) combiner->schedule_destroy(s);
       else rdamd_schedule_destroy(s);
     };
     rdamd_schedule_t *sched =
-        _combiner ? _combiner->schedule_create(std::get<0>(sc).data(), (unsigned)std::get<0>(sc).size(),
-                                               std::get<1>(sc).data(), std::get<2>(sc).data(),
-                                               (unsigned)std::get<1>(sc).size())
-                  : rdamd_schedule_create(_partitions[i], std::get<0>(sc).data(),
-                                          (unsigned)std::get<0>(sc).size(), std::get<1>(sc).data(),
-                                          std::get<2>(sc).data(), (unsigned)std::get<1>(sc).size());
+        combiner ? combiner->schedule_create(std::get<0>(sc).data(), (unsigned)std::get<0>(sc).size(),
+                                             std::get<1>(sc).data(), std::get<2>(sc).data(),
+                                             (unsigned)std::get<1>(sc).size())
+                 : rdamd_schedule_create(_partitions[i], std::get<0>(sc).data(),
+                                         (unsigned)std::get<0>(sc).size(), std::get<1>(sc).data(),
+                                         std::get<2>(sc).data(), (unsigned)std::get<1>(sc).size());
     if (!sched) fail("schedule_create");
     try {
-      bfgs_params(params[i].subst_rates, i, bfgs_target::rates, sched, 1e-4, 1e4, 1e-4, pgtol, factor);
-      bfgs_params(params[i].freqs, i, bfgs_target::freqs, sched, 1e-4, 1.0 - 1e-4 * 3, 1e-4, pgtol, factor);
+      bfgs_params(params[i].subst_rates, i, bfgs_target::rates, sched, combiner, 1e-4, 1e4, 1e-4, pgtol, factor);
+      bfgs_params(params[i].freqs, i, bfgs_target::freqs, sched, combiner, 1e-4, 1.0 - 1e-4 * 3, 1e-4, pgtol, factor);
       if (optimize_gamma && !_rate_user_init[i] && _rate_category_types[i] != rate_category::FREE)
-        bfgs_params(params[i].gamma_alpha, i, bfgs_target::gamma, sched, 0.2, 10000.0, 1e-4, pgtol, factor);
+        bfgs_params(params[i].gamma_alpha, i, bfgs_target::gamma, sched, combiner, 0.2, 10000.0, 1e-4, pgtol, factor);
     } catch (...) {
       destroy(sched);
       throw;

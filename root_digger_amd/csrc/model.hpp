@@ -12,6 +12,7 @@
 
 #include <cstdint>
 #include <functional>
+#include <memory>
 #include <random>
 #include <stdexcept>
 #include <array>
@@ -71,6 +72,14 @@ struct msa_t {
   std::vector<unsigned int> weights;        // pattern weights; empty = all 1
   unsigned int              states = 4;
   const uint64_t           *map = rdamd_map_nt;
+  // a caller's character map is COPIED (the model -- and the replicas a parallel search makes
+  // from it -- outlive the call that handed it over); copies of the msa share the storage
+  std::shared_ptr<std::vector<uint64_t>> map_store;
+  void set_map(const uint64_t *m) {
+    if (!m || m == rdamd_map_nt) { map = rdamd_map_nt; map_store.reset(); return; }
+    map_store = std::make_shared<std::vector<uint64_t>>(m, m + 256);
+    map = map_store->data();
+  }
   size_t length() const { return sequences.empty() ? 0 : sequences[0].size(); }
   int    count() const { return (int)sequences.size(); }
   unsigned int total_weight() const;
@@ -158,7 +167,10 @@ public:
   void set_progress(progress_t *p) { _progress = p; }
   // the optimiser's objective batches go through this combiner (batch_combiner.hpp)
   // instead of being launched on this model's own partition; not owned
-  void set_combiner(batch_combiner_t *c) { _combiner = c; }
+  // (one per partition: a partitioned model optimises its partitions one after the other, each
+  // on its own objective, src/model.cpp:1935-1984 -- candidates meet per partition)
+  void set_combiners(std::vector<batch_combiner_t *> c) { _combiners = std::move(c); }
+  void set_combiner(batch_combiner_t *c) { _combiners.assign(c ? 1 : 0, c); }
   // ... and the root-only steps (compute_lh_root / compute_dlh) through this one
   void set_root_combiner(root_combiner_t *c) { _root_combiner = c; }
   // Site-sharded runs: this model holds one block of the alignment's
@@ -261,7 +273,7 @@ private:
   std::vector<msa_t>                     _sweep_msa;          // what it needs to load its tips
   progress_t                            *_progress = nullptr;
   checkpoint_t                          *_checkpoint = nullptr;
-  batch_combiner_t                      *_combiner = nullptr;
+  std::vector<batch_combiner_t *>        _combiners;          // [partition], or empty
   root_combiner_t                       *_root_combiner = nullptr;
   bool                                   _invariant_sites, _early_stop;   // +I is inert (:292-300)
   uint64_t                               _seed;
@@ -272,8 +284,8 @@ private:
 
   enum class bfgs_target { rates, freqs, gamma };
   double bfgs_params(model_params_t &initial, size_t partition, bfgs_target what,
-                     rdamd_schedule_t *sched, double p_min, double p_max, double epsilon,
-                     double pgtol, double factor);
+                     rdamd_schedule_t *sched, batch_combiner_t *combiner, double p_min, double p_max,
+                     double epsilon, double pgtol, double factor);
 };
 
 }  // namespace rdamd

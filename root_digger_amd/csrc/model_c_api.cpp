@@ -79,7 +79,7 @@ rdamd_model_t *rdamd_model_create(const rdamd_tree_t *tree, unsigned int n_taxa,
   GUARD(nullptr, {
     auto *m = new rdamd_model();
     m->msa.states = states;
-    m->msa.map = map ? map : rdamd_map_nt;
+    m->msa.set_map(map);
     for (unsigned i = 0; i < n_taxa; ++i) {
       m->msa.labels.emplace_back(labels[i]);
       m->msa.sequences.emplace_back(sequences[i]);
@@ -431,7 +431,7 @@ static int search_with_replicas(rdamd_model_t *m, unsigned int workers, bool loc
       throw std::runtime_error("a site-sharded model runs its candidates sequentially "
                                "(rdamd_model_exhaustive_search): replicas would reorder the "
                                "site group's collectives");
-    std::unique_ptr<rdamd::batch_combiner_t> combiner[2];
+    std::vector<std::unique_ptr<rdamd::batch_combiner_t>> combiner[2];   // [group][partition]
     std::unique_ptr<rdamd::root_combiner_t> root_combiner;
     const std::vector<size_t> todo = m->model->assigned_indicies();
     if (workers < 1) workers = 1;
@@ -452,11 +452,12 @@ static int search_with_replicas(rdamd_model_t *m, unsigned int workers, bool loc
       // the objective launches fill every CU for a millisecond: on low priority, the kernels
       // beside them (front halves of the other group's batch, the replicas' root-only steps and
       // traversals) get the wave slots that become free instead of waiting for the launch to end
-      if (m->lockstep_priority &&
-          rdamd_partition_set_stream_priority(m->model->partition(0), m->lockstep_priority) != RDAMD_SUCCESS)
-        throw std::runtime_error(std::string("set_stream_priority: ") + rdamd_errmsg());
+      for (size_t pi = 0; m->lockstep_priority && pi < m->model->partition_count(); ++pi)
+        if (rdamd_partition_set_stream_priority(m->model->partition(pi), m->lockstep_priority) != RDAMD_SUCCESS)
+          throw std::runtime_error(std::string("set_stream_priority: ") + rdamd_errmsg());
       for (unsigned g = 0; g < n_groups; ++g)
-        combiner[g].reset(new rdamd::batch_combiner_t(m->model->partition(0), n_groups == 2 ? (int)g : -1));
+        for (size_t pi = 0; pi < m->model->partition_count(); ++pi)
+          combiner[g].emplace_back(new rdamd::batch_combiner_t(m->model->partition(pi), n_groups == 2 ? (int)g : -1));
       root_combiner.reset(new rdamd::root_combiner_t());
     }
     int device = 0;
@@ -475,7 +476,11 @@ static int search_with_replicas(rdamd_model_t *m, unsigned int workers, bool loc
         if (m->setulb) replica.set_lbfgsb(reinterpret_cast<rdamd::model_t::setulb_fn>(m->setulb));
         replica.set_checkpoint(m->checkpoint);
         replica.set_progress(m->progress.get());
-        replica.set_combiner(combiner[wid % n_groups].get());
+        {
+          std::vector<rdamd::batch_combiner_t *> mine;
+          for (auto &c : combiner[wid % n_groups]) mine.push_back(c.get());
+          replica.set_combiners(mine);
+        }
         if (lockstep && m->lockstep_priority)   // (the replicas' short kernels in front of the shared partition's long ones)
           for (size_t pi = 0; pi < replica.partition_count(); ++pi)
             if (rdamd_partition_set_stream_priority(replica.partition(pi), -1) != RDAMD_SUCCESS)
@@ -502,10 +507,11 @@ static int search_with_replicas(rdamd_model_t *m, unsigned int workers, bool loc
     for (auto &t : pool) t.join();
     if (lockstep) {
       m->lockstep_stats[0] = m->lockstep_stats[1] = 0;
-      for (unsigned g = 0; g < n_groups; ++g) {
-        m->lockstep_stats[0] += combiner[g]->launches();
-        m->lockstep_stats[1] += combiner[g]->jobs();
-      }
+      for (unsigned g = 0; g < n_groups; ++g)
+        for (auto &c : combiner[g]) {
+          m->lockstep_stats[0] += c->launches();
+          m->lockstep_stats[1] += c->jobs();
+        }
       m->lockstep_stats[2] = root_combiner->launches(); m->lockstep_stats[3] = root_combiner->steps();
     }
     if (!first_error.empty()) throw std::runtime_error(first_error);

@@ -99,7 +99,7 @@ bool parse_phylip(std::istream &in, msa_t &m) {
 msa_t msa_t::from_file(const std::string &filename, const uint64_t *map, unsigned int states,
                        bool compress_patterns) {
   msa_t m;
-  m.map = map ? map : rdamd_map_nt;
+  m.set_map(map);
   m.states = states;
   {
     std::ifstream in(filename);
@@ -165,6 +165,7 @@ msa_t msa_t::columns(size_t lo, size_t hi) const {
   out.labels = labels;
   out.states = states;
   out.map = map;
+  out.map_store = map_store;
   for (const auto &s : sequences) out.sequences.push_back(s.substr(lo, hi - lo));
   if (!weights.empty()) out.weights.assign(hi - lo, 1u);
   return out;

@@ -251,6 +251,7 @@ std::vector<msa_t> partition_msa(const msa_t &whole, const msa_partitions_t &par
     m.labels = whole.labels;
     m.states = whole.states;
     m.map = whole.map;
+    m.map_store = whole.map_store;
     m.sequences.assign(whole.sequences.size(), std::string());
     for (const auto &range : pi.parts) {
       if (range.first == 0)

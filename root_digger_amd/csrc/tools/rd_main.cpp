@@ -298,7 +298,7 @@ static int run(int argc, char **argv) {
   need(rdamd_tree_root_location(tree, 0, &rl0), "root_location");
   rdamd_model_compute_lh(model, &rl0);                                   // model.initialize()
   if (ckp && srank == 0) rdamd_model_set_checkpoint(model, ckp);   // one record per candidate
-  if (o.lockstep < 0) o.lockstep = (!o.lbfgsb.empty() && o.partition.empty()) ? 16 : 0;
+  if (o.lockstep < 0) o.lockstep = !o.lbfgsb.empty() ? 32 : 0;   // (partitioned models lock-step too)
   if (G > 1) o.lockstep = o.workers = 0;   // a site group walks its candidates in step
 
   // While the ranks search they exchange nothing over the rendezvous: the end of a

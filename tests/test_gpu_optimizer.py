@@ -392,3 +392,117 @@ def test_replica_count_is_clamped_to_device_memory():
     res = m.exhaustive_search(1e-2, 1e-2, 1e-2, 1e12, workers=1000)
     assert len(res["root_id"]) == 2 and np.all(np.isfinite(res["llh"]))
     m.destroy()
+
+
+def _aa_map(alphabet):
+    cmap = (C.c_uint64 * 256)()
+    for i, ch in enumerate(alphabet):
+        cmap[ord(ch)] = 1 << i
+    return cmap
+
+
+def test_optimize_params_20_states_with_reference_lbfgsb(lbfgsb):
+    """the search on 20-state data.  The 381 evaluations of one L-BFGS-B
+    iteration over a 20-state rate matrix (the objective + 380 finite differences,
+    src/model.cpp:1490-1502) are ONE launch of fused20_eval_kernel; the same optimisation is
+    replayed on the CPU oracle with the same setulb."""
+    from root_digger_amd import synth
+    R = 4
+    w = synth.workload(9, 120, 20, R, 515)
+    tree = rd.Tree.from_newick(w["newick"])
+    cmap = _aa_map(w["alphabet"])
+    m = rd.Model(tree, w["seqs"], states=20, cmap=cmap, rate_cats=R, seed=7)
+    m.initialize_partitions()
+    m.set_lbfgsb(lbfgsb.setulb)
+    rl = tree.root_location(4).with_ratio(0.4)
+    subst0, freqs0 = [1.0 / 380] * 380, [0.05] * 20
+    m.set_subst_rates(subst0)
+    m.set_freqs(freqs0)
+    m.set_gamma_alpha(1.0)
+    before = m.compute_lh(rl)
+    res = m.optimize_params(rl, subst0, freqs0, 1.0, pgtol=1e-3, factor=1e9)
+    assert res["evaluations"] >= 381 and res["evaluations"] > 100 * res["batches"] / 2   # 381-job batches
+    m.set_subst_rates(res["subst"])
+    m.set_freqs(np.array(res["freqs"]) / np.sum(res["freqs"]))
+    m.set_gamma_alpha(res["gamma_alpha"])
+    after = m.compute_lh(rl)
+    assert after > before + 1.0
+
+    o = OraclePartition.for_tree(tree, 20, 120, R)
+    util.load_tips(o, tree, w["seqs"], cmap)
+    t2 = rd.Tree.from_newick(w["newick"])
+    ops, pmi, brl = t2.generate_operations(rl)
+    state = {"subst": np.array(subst0), "freqs": np.array(freqs0), "alpha": 1.0}
+
+    def lnl():
+        o.set_subst_params(0, state["subst"])
+        o.set_frequencies(0, state["freqs"] / state["freqs"].sum())
+        o.set_category_rates(rd.compute_gamma_cats(state["alpha"], R, rd.GAMMA_RATES_MEDIAN))
+        o.update_prob_matrices(pmi, brl)
+        o.update_clvs(ops)
+        return o.compute_root_loglikelihood(t2.root_clv_index(), t2.root_scaler_index())
+
+    def obj(key):
+        def f(x):
+            old = state[key]
+            state[key] = np.array(x) if key != "alpha" else float(x[0])
+            v = -lnl()
+            state[key] = old
+            return v
+        return f
+
+    x, _ = bfgs_on(obj("subst"), state["subst"], 1e-4, 1e4, 1e-4, 1e-3, 1e9, lbfgsb.setulb)
+    state["subst"] = x
+    x, _ = bfgs_on(obj("freqs"), state["freqs"], 1e-4, 1 - 3e-4, 1e-4, 1e-3, 1e9, lbfgsb.setulb)
+    state["freqs"] = x
+    x, _ = bfgs_on(obj("alpha"), [state["alpha"]], 0.2, 1e4, 1e-4, 1e-3, 1e9, lbfgsb.setulb)
+    state["alpha"] = float(x[0])
+    cpu_after = lnl()
+    assert abs(after - cpu_after) < 1e-3 * abs(cpu_after)
+
+
+def test_exhaustive_search_on_20_states_lockstep_equals_sequential(lbfgsb):
+    """... and the whole per-candidate loop (src/model.cpp:1139-1272) on a 20-state alignment:
+    sequential, and with the candidates' 381-job batches meeting in one launch."""
+    from root_digger_amd import synth
+    w = synth.workload(7, 300, 20, 4, 516)
+    tree = rd.Tree.from_newick(w["newick"])
+    m = rd.Model(tree, w["seqs"], states=20, cmap=_aa_map(w["alphabet"]), rate_cats=4, seed=3)
+    m.initialize_partitions()
+    m.set_lbfgsb(lbfgsb.setulb)
+    m.compute_lh(tree.root_location(0))
+    m._ok(rd.lib.rdamd_model_assign_by_rank(m._h, 0, 2), "assign")     # half of the 11 roots
+    seq = m.exhaustive_search(1e-2, 1e-2, 1e-3, 1e12)
+    order = np.argsort(seq["root_id"])
+    lock = m.exhaustive_search(1e-2, 1e-2, 1e-3, 1e12, lockstep=4)
+    assert lock["root_id"] == sorted(seq["root_id"])
+    assert np.array_equal(lock["llh"], seq["llh"][order])
+    assert np.array_equal(lock["alpha"], seq["alpha"][order])
+    assert np.all(np.isfinite(seq["llh"])) and np.all(seq["llh"] < 0)
+
+
+@pytest.mark.parametrize("lines", ["UNREST+G4, a = 1-400\nUNREST+G4, b = 401-1000\n",
+                                   "UNREST+G4, a = 1-300\nUNREST, b = 301-1000\n"])
+def test_partitioned_model_searches_in_lock_step(lbfgsb, tmp_path, lines):
+    """a partitioned model (src/main.cpp:512-555; the reference optimises
+    its partitions side by side under OpenMP, src/model.cpp:1935) in the lock-stepped search:
+    one batch combiner per partition, root-only steps of all partitions of all candidates in
+    flight in one launch (per-partition fall-back where the rate categories differ).  Same
+    records as the sequential loop, bit for bit."""
+    pf = tmp_path / "parts.txt"
+    pf.write_text(lines)
+    tree = rd.Tree.from_file(os.path.join(util.DATA, "10.tree"))
+    m = rd.Model.from_partition_file(tree, os.path.join(util.DATA, "10.fasta"), str(pf), seed=11)
+    assert m.partition_count() == 2
+    m.initialize_partitions()
+    m.set_lbfgsb(lbfgsb.setulb)
+    m.compute_lh(tree.root_location(0))
+    seq = m.exhaustive_search(1e-3, 1e-3, 1e-3, 1e12)
+    order = np.argsort(seq["root_id"])
+    for in_flight in (3, 8):
+        lock = m.exhaustive_search(1e-3, 1e-3, 1e-3, 1e12, lockstep=in_flight)
+        assert lock["root_id"] == sorted(seq["root_id"])
+        assert np.array_equal(lock["llh"], seq["llh"][order])
+        assert np.array_equal(lock["alpha"], seq["alpha"][order])
+    st = m.lockstep_stats()
+    assert st["objective_jobs"] > st["objective_launches"] and st["root_steps"] > 0

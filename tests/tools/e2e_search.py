@@ -13,9 +13,15 @@ from root_digger_amd import synth
 
 ncand = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 n, S = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (100, 50000)
-w = synth.workload(n, S, 4, 4, 0xD166E5 + 1)
+K = int(sys.argv[4]) if len(sys.argv) > 4 else 4          # 20: BASELINE c3's kind of data
+w = synth.workload(n, S, K, 4, 0xD166E5 + (1 if K == 4 else 2))
 tree = rd.Tree.from_newick(w["newick"])
-m = rd.Model(tree, w["seqs"], rate_cats=4, seed=3)
+cmap = None
+if K != 4:
+    cmap = (ctypes.c_uint64 * 256)()
+    for i, ch in enumerate(w["alphabet"]):
+        cmap[ord(ch)] = 1 << i
+m = rd.Model(tree, w["seqs"], states=K, cmap=cmap, rate_cats=4, seed=3)
 m.initialize_partitions()
 ref = os.path.join(ROOT, "oracle", "_ref", "liblbfgsb_ref.so")
 lb = ctypes.CDLL(ref)
@@ -35,7 +41,8 @@ if workers or lockstep:
     if "PRIO" in os.environ:
         m.set_lockstep_priority(int(os.environ["PRIO"]))
     t1 = time.time()
-    res = m.exhaustive_search(1e-7, 1e-7, 1e-12, 1e4, workers=workers, lockstep=lockstep)
+    tol = (1e-7, 1e-7, 1e-12, 1e4) if K == 4 else (1e-3, 1e-3, 1e-6, 1e9)   # (380 parameters per candidate)
+    res = m.exhaustive_search(*tol, workers=workers, lockstep=lockstep)
     dt = time.time() - t1
     print("%d candidates, %s: %.2fs  (%.3fs per candidate)  sum llh %.6f" % (
         len(res["root_id"]), "%d in lock step" % lockstep if lockstep else "%d workers" % workers,
