@@ -707,6 +707,19 @@ static int batch_submit(rdamd_partition_t *p, FusedWorkspace *&slot, bool pipeli
     // box): c4 (850 MB of codes) 200.6 -> 181.1 ms per launch; c5 (340 MB) 77.9 -> 78.2; c2
     // (16 MB) 2.88 -> 3.08; 125.phy 1.86 -> 1.80.
     a.rates_across_waves = R >= 2 && R <= 8 && a.tipcodes_bytes >= (512u << 20);
+    a.n_jobs = n_jobs;
+    // Which workgroups share an XCD (and its 4 MB of L2): an eighth of the sites of EVERY job (the
+    // default: each L2 then only ever sees an eighth of the code arena), or whole jobs, job j on
+    // XCD j % 8 (its L2 then sees the tables of the one or two jobs it is working on).  The second
+    // pays once the tables of the jobs that are on the device together outgrow the L2s: measured
+    // (one box, round 4) c4 / 8 +2.4 %, c5 shard +0.8 %, 125.phy +2.3 %, c2 -2.6 %.
+    {
+      const double jobs_in_flight = 4096.0 / std::max(1u, w->blocks_x / 2u);   // ~16 one-wave workgroups on 256 CUs
+      a.job_major = n_jobs >= 16 && jobs_in_flight * (double)tiptab_job * 8.0 > 16.0 * (1 << 20);
+    }
+#ifdef RDAMD_ABLATION
+    if (getenv("RDAMD_FUSED_JOBMAJOR")) a.job_major = atoi(getenv("RDAMD_FUSED_JOBMAJOR")) != 0;
+#endif
 #ifdef RDAMD_ABLATION
     if (getenv("RDAMD_FUSED_RW")) a.rates_across_waves = atoi(getenv("RDAMD_FUSED_RW")) != 0 && R >= 2 && R <= 8;
 #endif

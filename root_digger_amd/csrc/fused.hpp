@@ -83,6 +83,10 @@ struct FusedArgs {
   unsigned table_rows;               // 16 or 64: rows per LDS table slot (and the code arena's entry width)
   unsigned rates_across_waves;       // 1: a workgroup is R waves, one per rate category (kernels_fused.hip, RW)
   unsigned *any_unsafe;              // device word, 0 when the batch starts: set with the first FusedJob::tt_unsafe
+  unsigned n_jobs;                   // jobs of the launch (grid.y may be padded, see job_major)
+  unsigned job_major;                // 1: every XCD walks WHOLE jobs (job j on XCD j % 8) instead of an eighth of
+                                     // the sites of every job: its L2 then sees the tables of the one or two jobs it
+                                     // is working on (deep trees: 4 MB of tables per job) -- grid.y is padded to x8
 };
 
 // ---- 20-state variant (kernels_fused_k20.hip) ---------------------------------

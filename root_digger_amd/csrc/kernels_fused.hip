@@ -292,7 +292,13 @@ fused_dna_eval_kernel(FusedArgs a) {
   // a multiple of 8, so an XCD owns a fixed eighth of the sites and sees every job's
   // tables.  (Measured alternative: every XCD walks whole jobs, so that its L2 holds one
   // job's tables -- c2 -4 %, c4 +2 %, c5 +1 %: not worth a second mapping.)
-  const unsigned job = blockIdx.y, bx = blockIdx.x;
+  unsigned job = blockIdx.y, bx = blockIdx.x;
+  if (a.job_major) {   // (wave-uniform) workgroup L of the launch runs on XCD L % 8: give it a block of job (..) * 8 + L % 8
+    const unsigned gx = gridDim.x, L = job * gx + bx, seq = L >> 3;
+    job = uni((seq / gx) * 8u + (L & 7u));
+    bx = uni(seq % gx);
+    if (job >= a.n_jobs) return;
+  }
   const unsigned S = a.sites, R = a.rate_cats;
   unsigned site[NS];
   bool valid[NS];
@@ -838,7 +844,7 @@ static hipError_t launch_fused_variant(const FusedArgs &a, unsigned n_jobs, unsi
            attr.sharedSizeBytes == 0;
   }();
   if (!lds_starts_at_zero) return hipErrorInvalidValue;
-  fused_dna_eval_kernel<NS, TTCHECK, RL, TR, RW, SP><<<dim3(gx, n_jobs), 64 * n_waves, lds, stream>>>(a);
+  fused_dna_eval_kernel<NS, TTCHECK, RL, TR, RW, SP><<<dim3(gx, a.job_major ? (n_jobs + 7u) / 8u * 8u : n_jobs), 64 * n_waves, lds, stream>>>(a);
   return hipGetLastError();
 }
 
