@@ -32,6 +32,7 @@ import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -212,6 +213,9 @@ def main():
                     help="gloo + --device lets several ranks share one GPU (how the N>1 code "
                          "path is exercised on a one-GPU box); the driver's runs use nccl (RCCL)")
     ap.add_argument("--device", type=int, default=None, help="HIP device (default: LOCAL_RANK)")
+    ap.add_argument("--leg-timeout", type=float, default=240.0,
+                    help="N>1: seconds the extra legs (site_sharded / grid / rccl_ranks) may take before the "
+                         "line is printed without them")
     ap.add_argument("--no-shard-legs", action="store_true",
                     help="N>1 without --shard: skip the extra `site_sharded` / `grid` objects (the same "
                          "workload site-sharded with the all-reduce of the per-block lnLs)")
@@ -559,18 +563,6 @@ def main():
         p2.destroy()
         return out
 
-    legs = {}
-    if use_pg and world > 1 and args.shard == "candidates" and use_fused and not args.no_shard_legs:
-        check_one_hip_runtime(rd)
-        legs["site_sharded"] = sharded_leg("sites")
-        if world % args.site_groups == 0 and world // args.site_groups > 1:
-            legs["grid"] = sharded_leg("grid")
-    rccl_ranks = None
-    if use_pg and not host_collectives:   # a real all-reduce over the communicator the line ran on
-        ones = torch.ones(1, dtype=torch.float64, device="cuda")
-        tdist.all_reduce(ones)
-        rccl_ranks = int(round(float(ones.item())))
-
     def clv_roofline(ms, launches, evals):
         bytes_clv = clv_kernel_bytes(n, S, R, K) * evals
         achieved = bytes_clv / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
@@ -723,9 +715,6 @@ def main():
         "roofline": roofline,
     }
     result.update(extra)
-    result.update(legs)
-    if rccl_ranks is not None:
-        result["rccl_ranks"] = rccl_ranks
 
     def gpu_eval(j):
         if not use_fused:
@@ -736,13 +725,56 @@ def main():
         result["cpu_baseline"] = cpu_baseline(w, tree, cmap, freqs, n, S, K, R,
                                               params, roots, args.cpu_seconds,
                                               gpu_eval, data_weights)
-    if rank == 0:
-        line = json.dumps(result) + "\n"
-        if real_stdout is not None:
-            os.write(real_stdout, line.encode())
-        else:
-            sys.stdout.write(line)
-            sys.stdout.flush()
+
+    emitted = threading.Event()
+
+    def emit():
+        if emitted.is_set():
+            return
+        emitted.set()
+        if rank == 0:
+            line = json.dumps(result) + "\n"
+            if real_stdout is not None:
+                os.write(real_stdout, line.encode())
+            else:
+                sys.stdout.write(line)
+                sys.stdout.flush()
+
+    # The extra legs of the default N > 1 line (site blocks / grid with the all-reduce of the
+    # per-block lnLs, and the all-reduce that counts the RCCL ranks) come AFTER the measurement the
+    # line is about, and must never cost it: if a leg raises, its object says so; if the ranks do not
+    # get through the legs within --leg-timeout seconds (a collective that never completes on this
+    # fabric), every rank prints / leaves on its own -- rank 0 with the line as far as it got.
+    want_legs = use_pg and world > 1 and args.shard == "candidates" and use_fused and not args.no_shard_legs
+    if use_pg and (want_legs or not host_collectives):
+        def give_up():
+            for key in ("site_sharded", "grid"):
+                if want_legs and key not in result and (key == "site_sharded" or
+                                                        (world % args.site_groups == 0 and world // args.site_groups > 1)):
+                    result[key] = {"error": "not finished within %.0f s" % args.leg_timeout}
+            emit()
+            os._exit(0)
+        watchdog = threading.Timer(args.leg_timeout, give_up)
+        watchdog.daemon = True
+        watchdog.start()
+        try:
+            if want_legs:
+                check_one_hip_runtime(rd)
+                for key, mode in (("site_sharded", "sites"), ("grid", "grid")):
+                    if mode == "grid" and not (world % args.site_groups == 0 and world // args.site_groups > 1):
+                        continue
+                    try:
+                        result[key] = sharded_leg(mode)
+                    except Exception as e:   # noqa: BLE001  (the headline must survive a failing leg)
+                        result[key] = {"error": "%s: %s" % (type(e).__name__, e)}
+                        break                # (the other ranks may be inside a collective: no further legs)
+            if not host_collectives and not any("error" in v for v in result.values() if isinstance(v, dict)):
+                ones = torch.ones(1, dtype=torch.float64, device="cuda")   # a real all-reduce over the communicator
+                tdist.all_reduce(ones)
+                result["rccl_ranks"] = int(round(float(ones.item())))
+        finally:
+            watchdog.cancel()
+    emit()
     if use_pg:
         tdist.destroy_process_group()
 
