@@ -473,6 +473,38 @@ def main():
                      "kernel_ms": sprof["fused"][0], "launches": sprof["fused"][1],
                      "executed": dict(executed)}
 
+    # `pipelined`: the same steps with TWO batches in flight (rdamd_evaluate_batch_submit / _wait,
+    # slots 0 / 1 -- what the lock-stepped search does): the upload, P-matrices and clade
+    # tables of step s + 1 and the host's work run beside the evaluator of step s.  Reported beside
+    # the headline, which stays the blocking call (one batch at a time, comparable across rounds).
+    pipelined = None
+    if use_fused and not site_sharded and args.sustain_seconds > 0 and world == 1:
+        base = args.warmup + args.steps
+        inputs = [prepare(base + 1000 + i) for i in range(8)]
+        lnl_sum = 0.0
+        barrier()
+        t1 = time.perf_counter()
+        k = 0
+        pending = None
+        while True:
+            a = inputs[k % len(inputs)]
+            part.evaluate_batch_submit(k & 1, a["handles"], a["sub"], a["freqs"])
+            if pending is not None:
+                lnl_sum += float(part.evaluate_batch_wait(pending, nb).sum())
+            pending = k & 1
+            k += 1
+            if time.perf_counter() - t1 >= args.sustain_seconds:
+                break
+        lnl_sum += float(part.evaluate_batch_wait(pending, nb).sum())
+        barrier()
+        dt = time.perf_counter() - t1
+        if not np.isfinite(lnl_sum) and not os.environ.get("RDAMD_BENCH_TIMING_ONLY"):
+            raise SystemExit("non-finite lnL in the pipelined leg")
+        pipelined = {"seconds": round(dt, 3), "steps": k, "evals_per_s": round(k * nb / dt, 2),
+                     "ms_per_step": round(dt / k * 1e3, 4), "batches_in_flight": 2,
+                     "note": "rdamd_evaluate_batch_submit / _wait, slots alternating: step s + 1 is queued "
+                             "before step s is waited for"}
+
     if use_pg:
         t = torch.tensor([elapsed], dtype=torch.float64,
                          device="cpu" if host_collectives else "cuda")
@@ -639,6 +671,8 @@ def main():
                           "note": "SURVEY 8d bytes_full per evaluation / launch time; CLVs stay in "
                                   "registers/LDS, so this exceeds the HBM peak by design"},
         }
+        if pipelined:
+            roofline["pipelined"] = pipelined
         if sustained:
             sms, sl = sustained.pop("kernel_ms"), sustained["launches"]
             sx = sustained.pop("executed")

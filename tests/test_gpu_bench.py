@@ -80,6 +80,13 @@ def test_no_roofline_fraction_exceeds_one(config, extra):
         assert k["frac_uncapped"] > 1.0 and k["frac"] == 1.0
 
 
+def test_pipelined_leg_is_reported_beside_the_blocking_headline():
+    d = run_bench("--no-cpu-baseline", "--sustain-seconds", "0.3")
+    pl = d["roofline"]["pipelined"]
+    assert pl["batches_in_flight"] == 2 and pl["steps"] >= 2 and pl["evals_per_s"] > 0
+    assert d["roofline"]["sustained"]["evals_per_s"] > 0
+
+
 def test_site_sharded_bench_matches_candidate_sharded_checksum():
     a = run_bench("--no-cpu-baseline", "--shard", "sites")
     b = run_bench("--no-cpu-baseline")
