@@ -77,9 +77,9 @@ def test_pipelined_batches_equal_blocking_batches(n, S, R, seed):
         except Exception as e:   # noqa: BLE001
             errors.append(("churn", repr(e)))
 
-    ts = [threading.Thread(target=group, args=(0, 60, seed + 1)),
-          threading.Thread(target=group, args=(1, 60, seed + 2)),
-          threading.Thread(target=churn, args=(150, seed + 3))]
+    ts = [threading.Thread(target=group, args=(0, 250, seed + 1)),
+          threading.Thread(target=group, args=(1, 250, seed + 2)),
+          threading.Thread(target=churn, args=(500, seed + 3))]
     for t in ts:
         t.start()
     for t in ts:
