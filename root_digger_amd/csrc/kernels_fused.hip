@@ -264,6 +264,43 @@ __device__ __forceinline__ void stack_pop(unsigned sp, unsigned lds_pos, int q, 
   v[0] = lo.x; v[1] = lo.y; v[2] = hi.x; v[3] = hi.y;
 }
 
+// The pop in two halves: the loads are ISSUED at the top of the step and awaited where the popped
+// sibling is first needed, behind the step's matrix-vector product -- a scratch entry that was
+// evicted from L2 takes a microsecond to come back, and with the wait inside the pop nothing of
+// the wave's own work covered it.  (The wait statement takes the values as in / out operands:
+// that is what orders their uses behind it.)
+template <int NS>
+__device__ __forceinline__ void stack_pop_issue(unsigned sp, unsigned lds_pos, int q, unsigned stk_lds,
+                                                unsigned stksc_lds, unsigned spill_off, f64x2_t &lo, f64x2_t &hi,
+                                                int &sc) {
+  const unsigned la = stk_lds + q * 2048u, lsc = stksc_lds + q * 256u;
+  sp = uni(sp);
+  const unsigned so = spill_off + (sp * NS + q) * 48u;
+  asm volatile(
+      "s_cmp_eq_u32 %[sp], %[cap]\n\t"
+      "s_cbranch_scc1 1f\n\t"
+      "scratch_load_dwordx4 %[lo], off, %[so]\n\t"
+      "scratch_load_dwordx4 %[hi], off, %[so] offset:16\n\t"
+      "scratch_load_dword %[sc], off, %[so] offset:32\n\t"
+      "s_branch 2f\n"
+      "1:\n\t"
+      "ds_read_b128 %[lo], %[la]\n\t"
+      "ds_read_b128 %[hi], %[la] offset:1024\n\t"
+      "ds_read_b32 %[sc], %[lsc]\n"
+      "2:"
+      : [lo] "=&v"(lo), [hi] "=&v"(hi), [sc] "=&v"(sc)
+      : [sp] "s"(sp), [cap] "s"(lds_pos), [so] "s"(so), [la] "v"(la), [lsc] "v"(lsc)
+      : "memory", "scc");
+}
+template <int NS>
+__device__ __forceinline__ void stack_pop_wait(f64x2_t (&lo)[NS], f64x2_t (&hi)[NS], int (&sc)[NS]) {
+  if constexpr (NS == 2)
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)"
+                 : "+v"(lo[0]), "+v"(hi[0]), "+v"(sc[0]), "+v"(lo[1]), "+v"(hi[1]), "+v"(sc[1])::"memory");
+  else
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(lo[0]), "+v"(hi[0]), "+v"(sc[0])::"memory");
+}
+
 // SP ("spill levels"): the LDS stack is what limits the resident waves once a program needs
 // two levels of it (13.2 KB per two-sites wave: 12 waves per CU instead of 16 -- and with
 // every wave waiting on its own dependent chain, throughput follows the wave count: c5 and
@@ -525,10 +562,11 @@ fused_dna_eval_kernel(FusedArgs a) {
         combine_sites<NS, kTestRP>(tx, s1, st.v, st.sc);                                                 \
       } else {                                                                                  \
         int scy[NS];                                                                            \
+        f64x2_t plo[NS], phi[NS];                                                               \
         --sp;                                                                                   \
         _Pragma("unroll") for (int q = 0; q < NS; ++q) {                                        \
-          if (SP > 0) {                                                                         \
-            stack_pop<NS>(sp, lds_pos, q, stk_lds, stksc_lds, spill_off, ty[q], scy[q]);        \
+          if (SP > 0) {   /* issued here, awaited behind the product (stack_pop_issue) */       \
+            stack_pop_issue<NS>(sp, lds_pos, q, stk_lds, stksc_lds, spill_off, plo[q], phi[q], scy[q]); \
           } else {                                                                              \
             const double2 *d = stk + (size_t)(sp * NS + q) * 128;                               \
             const double2 lo = d[0], hi = d[64];                                                \
@@ -539,6 +577,12 @@ fused_dna_eval_kernel(FusedArgs a) {
         RDAMD_LOAD_TIPS(nxt, ncx, ncy, nex, ney) RDAMD_LATE_DESC(cur, idx2)                     \
         _Pragma("unroll") for (int q = 0; q < NS; ++q) matvec(M, st.v[q], tx[q]);               \
         RDAMD_LOAD_M(nxt, M)                                                                    \
+        if (SP > 0) {                                                                           \
+          stack_pop_wait<NS>(plo, phi, scy);                                                    \
+          _Pragma("unroll") for (int q = 0; q < NS; ++q) {                                      \
+            ty[q][0] = plo[q].x; ty[q][1] = plo[q].y; ty[q][2] = phi[q].x; ty[q][3] = phi[q].y; \
+          }                                                                                     \
+        }                                                                                       \
         _Pragma("unroll") for (int q = 0; q < NS; ++q) st.sc[q] += scy[q];                      \
         combine_sites<NS, kTestRP>(tx, ty, st.v, st.sc);                                        \
       }                                                                                         \
