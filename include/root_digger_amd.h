@@ -295,6 +295,26 @@ int rdamd_evaluate_batch_submit(rdamd_partition_t *p, unsigned int slot, unsigne
                                 const double *rates, const double *rate_weights);
 int rdamd_evaluate_batch_wait(rdamd_partition_t *p, unsigned int slot, double *lnl_out);
 
+/* compute_lh for a caller that goes on with root-only steps (model_t::exhaustive_search between
+ * optimize_params and optimize_alpha, src/model.cpp:1154-1229): ONE evaluation of the whole
+ * operation list -- the last operation being the root's -- through the fused evaluator, which
+ * also LEAVES THE ROOT OPERATION'S TWO CHILDREN BEHIND: their CLVs and per-site scalers are
+ * written to the buffers the root operation names (child*_clv_index / child*_scaler_index; a
+ * tip child has nothing to write), in the layout and with the meaning rdamd_update_clvs gives
+ * them, so that rdamd_root_loglikelihood_fused / rdamd_compute_root_loglikelihood-style calls
+ * on that operation find what a full traversal would have left.  NO OTHER CLV, scaler or
+ * P-matrix of the partition is touched (they keep whatever an earlier call left): this replaces
+ * corax_update_prob_matrices + corax_update_clvs + corax_compute_root_loglikelihood
+ * (src/model.cpp:357-409) where only the root's children are read afterwards -- 13 MB written
+ * instead of 1.3 GB moved on BASELINE c2.  Parameters as one job of rdamd_evaluate_batch.
+ * 4-state and binary partitions; the children need scale buffers.  *lnl_out = the tree's
+ * log-likelihood (every operation of the list evaluated, the reference's rescaling rule at
+ * every step). */
+int rdamd_evaluate_root_children(rdamd_partition_t *p, const rdamd_operation_t *ops, unsigned int n_ops,
+                                 const unsigned int *matrix_indices, const double *branch_lengths,
+                                 unsigned int n_matrices, const double *subst, const double *freqs,
+                                 const double *rates, const double *rate_weights, double *lnl_out);
+
 
 /* parity/debug views: copy device buffers to host.  rdamd_get_clv returns coraxlib's
  * layout, out[site][rate][state] (what partition->clv[i] holds in the reference),
@@ -501,6 +521,10 @@ void rdamd_model_set_lockstep_groups(rdamd_model_t *m, unsigned int groups);
 /* stream priority (rdamd_partition_set_stream_priority) of the shared objective partition
  * during a lock-stepped search: +1 low (default), 0 leave it as it is */
 void rdamd_model_set_lockstep_priority(rdamd_model_t *m, int level);
+/* The searches' compute_lh between optimize_params and the root-only steps: 1 (default) =
+ * rdamd_evaluate_root_children where the partition allows it (4-state / binary), 0 = always
+ * the full traversal that materialises every CLV (rdamd_update_clvs). */
+void rdamd_model_set_root_children_only(rdamd_model_t *m, int on);
 /* assign_indicies_by_rank_exhaustive, :1867-1911 */
 int rdamd_model_assign_by_rank(rdamd_model_t *m, unsigned int rank, unsigned int num_tasks);
 /* exhaustive_search, :1139-1272, over the assigned roots.  root_id / llh /

@@ -37,7 +37,7 @@ def main(path):
     print("traced span %.3f s, device busy (union of kernels) %.3f s = %.1f %%" % (span, busy / 1e9, 100 * busy / 1e9 / span))
 
     def kind(n):
-        if "fused_dna_eval_kernel" in n: return "eval"
+        if "fused_dna_eval_kernel" in n: return "export" if ", true>(" in n else "eval"
         if "root_single" in n or "root_multi" in n: return "root"
         if "clv_dna_traversal" in n: return "trav"
         if "copyBuffer" in n or "fillBuffer" in n: return "copy"
@@ -51,7 +51,7 @@ def main(path):
         print("  %-6s %7d launches  total %8.3f s  mean %9.1f us" % (k, len(v), tot / 1e9, tot / 1e3 / max(len(v), 1)))
 
     ev = by_kind["eval"]
-    others = sorted(by_kind["root"] + by_kind["trav"] + by_kind["other"])
+    others = sorted(by_kind["root"] + by_kind["trav"] + by_kind["other"] + by_kind["export"])
     # overlap of each evaluator launch with non-evaluator kernels (sum of overlapped ns of each)
     import bisect
     starts = [o[0] for o in others]
@@ -88,6 +88,21 @@ def main(path):
         if jobs < 48: continue
         b = min(cnt, 8)
         bins[b][0] += 1; bins[b][1] += upj
+    # who the overlappers of the crowded launches are (>= 48 jobs, >= 5 others), by kernel and by overlapped time
+    who = defaultdict(lambda: [0, 0])
+    for s, e, n, gx, gy, wx in ev:
+        if gy < 48: continue
+        lo = bisect.bisect_left(starts, s - maxlen)
+        hi = bisect.bisect_right(starts, e)
+        ov = [(o, min(e, o[1]) - max(s, o[0])) for o in others[lo:hi] if min(e, o[1]) > max(s, o[0])]
+        if len(ov) < 5: continue
+        for o, t in ov:
+            k = o[2].split("(")[0].replace("void rdamd::", "").replace("rdamd::", "")[:60]
+            who[k][0] += 1; who[k][1] += t
+    if who:
+        print("  overlappers of the launches with >= 5 of them: kernel, launches, overlapped time")
+        for k, (c, t) in sorted(who.items(), key=lambda kv: -kv[1][1])[:8]:
+            print("    %-60s %7d %8.3f s" % (k, c, t / 1e9))
     print("  launches of >= 48 jobs, us/job against the number of overlapping other kernels:")
     for b in sorted(bins):
         print("    %s%d other kernels: %6d launches  %7.2f us/job" % (">=" if b == 8 else "", b, bins[b][0], bins[b][1] / 1e3 / bins[b][0]))

@@ -107,6 +107,7 @@ _sig("rdamd_evaluate_batch", C.c_int, _vp, _u, C.POINTER(_vp), _pd, _pd, _pd, _p
 _sig("rdamd_evaluate_batch_device", C.c_int, _vp, _u, C.POINTER(_vp), _pd, _pd, _pd, _pd, _vp)
 _sig("rdamd_evaluate_batch_submit", C.c_int, _vp, _u, _u, C.POINTER(_vp), _pd, _pd, _pd, _pd)
 _sig("rdamd_evaluate_batch_wait", C.c_int, _vp, _u, _pd)
+_sig("rdamd_evaluate_root_children", C.c_int, _vp, _pop, _u, _pu, _pd, _u, _pd, _pd, _pd, _pd, _pd)
 _sig("rdamd_get_clv", C.c_int, _vp, _u, _pd)
 _sig("rdamd_get_scaler", C.c_int, _vp, _u, _pu)
 _sig("rdamd_get_pmatrix", C.c_int, _vp, _u, _pd)
@@ -232,6 +233,7 @@ _sig("rdamd_model_counters", None, C.c_void_p, C.POINTER(C.c_uint64))
 _sig("rdamd_model_lockstep_stats", None, C.c_void_p, C.POINTER(C.c_uint64))
 _sig("rdamd_model_set_lockstep_groups", None, C.c_void_p, _u)
 _sig("rdamd_model_set_lockstep_priority", None, C.c_void_p, C.c_int)
+_sig("rdamd_model_set_root_children_only", None, C.c_void_p, C.c_int)
 _sig("rdamd_partition_set_stream_priority", C.c_int, _vp, C.c_int)
 _sig("rdamd_model_assign_by_rank", C.c_int, _vp, _u, _u)
 _sig("rdamd_model_exhaustive_search_parallel", C.c_int, _vp, _u, C.c_double, C.c_double,
@@ -748,6 +750,36 @@ class Partition:
             _fail("evaluate_batch")
         return out
 
+    def set_stream_priority(self, level):
+        """-1 high, 0 normal, +1 low (rdamd_partition_set_stream_priority): the lock-stepped search
+        runs its long objective launches low and the replicas' short kernels high."""
+        if lib.rdamd_partition_set_stream_priority(self._h, level) != 1:
+            _fail("set_stream_priority")
+
+    def evaluate_root_children(self, ops, matrix_indices, branch_lengths, subst, freqs, rates=None,
+                               rate_weights=None):
+        """lnL of the whole operation list through the fused evaluator; the root operation's two
+        children are left in the partition's CLV / scaler buffers (rdamd_evaluate_root_children)."""
+        n = len(ops)
+        if not isinstance(ops, C.Array):
+            arr = (Operation * n)()
+            for i, o in enumerate(ops):
+                arr[i] = o
+            ops = arr
+        mi = np.ascontiguousarray(matrix_indices, dtype=np.uint32)
+        bl = np.ascontiguousarray(branch_lengths, dtype=np.float64)
+        subst = np.ascontiguousarray(subst, dtype=np.float64)
+        freqs = np.ascontiguousarray(freqs, dtype=np.float64)
+        rates = None if rates is None else np.ascontiguousarray(rates, dtype=np.float64)
+        rw = None if rate_weights is None else np.ascontiguousarray(rate_weights, dtype=np.float64)
+        out = C.c_double(0.0)
+        if lib.rdamd_evaluate_root_children(self._h, ops, n, _uptr(mi), _dptr(bl), mi.size, _dptr(subst),
+                                            _dptr(freqs), _dptr(rates) if rates is not None else None,
+                                            _dptr(rw) if rw is not None else None,
+                                            C.cast(C.byref(out), _pd)) != 1:
+            _fail("evaluate_root_children")
+        return out.value
+
     def evaluate_batch_submit(self, slot, schedules, subst, freqs, rates=None, rate_weights=None):
         """Queue the batch on `slot` (0 or 1) and return (rdamd_evaluate_batch_submit); returns the
         number of jobs, which evaluate_batch_wait needs."""
@@ -1248,6 +1280,11 @@ class Model:
         """0: the library's choice (two pipelined groups from four candidates in flight on);
         1: one group, blocking launches (rdamd_model_set_lockstep_groups)."""
         lib.rdamd_model_set_lockstep_groups(self._h, groups)
+
+    def set_root_children_only(self, on):
+        """the searches' compute_lh in front of the root-only steps: True (default) = one fused job
+        that leaves only the root's children behind, False = the full traversal."""
+        lib.rdamd_model_set_root_children_only(self._h, 1 if on else 0)
 
     def set_lockstep_priority(self, level):
         """stream priority of the shared objective partition during a lock-stepped search

@@ -267,6 +267,9 @@ struct RootSingleArgs {
   double len1[kRootMaxPositions], len2[kRootMaxPositions];      // child1 / child2 branch length per position
   unsigned params_idx[8];       // rate -> rate matrix (also the frequency set)
   unsigned n_positions;
+#ifdef RDAMD_ABLATION
+  unsigned abl;                 // timing experiments (profiles/root_interference.py): 1 = no exponentiation
+#endif
 };
 // one row of root_multi_dna_kernel: everything root_single_dna_kernel takes as arguments
 struct RootItem {

@@ -42,6 +42,9 @@ struct rdamd_schedule {
   unsigned n_wide = 0;                // 64-row tables per job
   // what one (site, rate) executes: operations and matrix-vector products per traversal
   unsigned matvecs = 0, matvecs_plain = 0, clade_rows = 0;
+  // the root operation's children (rdamd_evaluate_root_children): clv and scaler indices as the caller named them
+  unsigned root_child_clv[2] = {0, 0};
+  int root_child_sc[2] = {-1, -1};
 };
 
 namespace rdamd {
@@ -59,6 +62,7 @@ struct FusedWorkspace {
   double *d_pmat = nullptr, *d_tiptab = nullptr, *d_partials = nullptr, *d_out = nullptr;
   double *d_clade_scratch = nullptr;   // nested clade tables of a launch: [job][step][rate][rows][4]
   size_t clade_scratch_doubles = 0;
+  unsigned *d_export_cnt = nullptr;    // rdamd_evaluate_root_children: rescale counts [2 children][site][rate]
   size_t tiptab_doubles = 0;           // allocated behind d_tiptab
   double *h_out = nullptr;   // pinned
   char *h_in = nullptr;      // pinned parameter staging
@@ -77,7 +81,7 @@ struct FusedWorkspace {
 
 void fused_workspace_free(FusedWorkspace *w) {
   if (!w) return;
-  void *dev[] = {w->d_in, w->d_pmat, w->d_tiptab, w->d_partials, w->d_out, w->d_clade_scratch};
+  void *dev[] = {w->d_in, w->d_pmat, w->d_tiptab, w->d_partials, w->d_out, w->d_clade_scratch, w->d_export_cnt};
   for (void *d : dev)
     if (d) (void)hipFree(d);
   if (w->h_out) (void)hipHostFree(w->h_out);
@@ -135,7 +139,7 @@ static hipError_t ensure_workspace(rdamd_partition *p, FusedWorkspace *&slot, un
   if (n_jobs <= w->cap_jobs) return hipSuccess;
   hipError_t e = sync_streams(p);
   if (e != hipSuccess) return e;
-  void *dev[] = {w->d_in, w->d_pmat, w->d_tiptab, w->d_partials, w->d_out, w->d_clade_scratch};
+  void *dev[] = {w->d_in, w->d_pmat, w->d_tiptab, w->d_partials, w->d_out, w->d_clade_scratch, w->d_export_cnt};
   for (void *d : dev)
     if (d) (void)hipFree(d);
   if (w->h_out) (void)hipHostFree(w->h_out);
@@ -184,14 +188,13 @@ static void rdamd_schedule_destroy_locked(rdamd_schedule *s) {
   delete s;
 }
 
-extern "C" {
-
-rdamd_schedule_t *rdamd_schedule_create(rdamd_partition_t *p, const rdamd_operation_t *ops,
-                                        unsigned int n_ops,
-                                        const unsigned int *matrix_indices,
-                                        const double *branch_lengths,
-                                        unsigned int n_matrices) {
-  clear_error();
+// allow_repeats = false: the plain program only, 16-row tables, nothing of the clade cache is
+// touched (rdamd_evaluate_root_children: a schedule that lives for one launch)
+static rdamd_schedule_t *schedule_create_impl(rdamd_partition_t *p, const rdamd_operation_t *ops,
+                                              unsigned int n_ops,
+                                              const unsigned int *matrix_indices,
+                                              const double *branch_lengths,
+                                              unsigned int n_matrices, bool allow_repeats) {
   // (clade cache, code arenas and the block pool belong to the partition: one thread at a time)
   std::lock_guard<std::mutex> guard(p->launch_mu);
   const bool k20 = p->states == 20 && p->rate_cats <= 4;
@@ -262,7 +265,7 @@ rdamd_schedule_t *rdamd_schedule_create(rdamd_partition_t *p, const rdamd_operat
       for (unsigned m : {ops[i].child1_matrix_index, ops[i].child2_matrix_index})
         if (uses[m]++) matrix_shared = true;
   }
-  const bool repeats = !k20 && (p->attributes & RDAMD_ATTRIB_SITE_REPEATS) && p->sites > 0;
+  const bool repeats = allow_repeats && !k20 && (p->attributes & RDAMD_ATTRIB_SITE_REPEATS) && p->sites > 0;
   if (repeats && !p->clades) p->clades = new CladeCache();
   // (the 16-bit arena needs twice the bytes per row: a partition whose tip rows alone would not
   // fit 32-bit offsets there keeps the 8-bit arena and 16-row tables -- for every schedule, so
@@ -281,6 +284,11 @@ rdamd_schedule_t *rdamd_schedule_create(rdamd_partition_t *p, const rdamd_operat
     c.pseudo_row = pseudo_row;
     c.pseudo_wide = pseudo_wide;
     c.wide_base = 8u * p->prob_matrices * p->rate_cats * 16u;
+    if (!k20) {   // the steps that compute the root operation's inner children (fused.hpp, 0x8000 / 0x10000)
+      const rdamd_operation_t &root = list.back();
+      if (root.child1_clv_index >= p->tips) c.mark_clv[0] = root.child1_clv_index;
+      if (root.child2_clv_index >= p->tips) c.mark_clv[1] = root.child2_clv_index;
+    }
     for (unsigned i = 0; i < c.n_ops; ++i) c.producer[list[i].parent_clv_index] = i;
     c.need.assign(c.n_ops, 0);
     c.compute_need(c.n_ops - 1);
@@ -374,6 +382,8 @@ rdamd_schedule_t *rdamd_schedule_create(rdamd_partition_t *p, const rdamd_operat
   rdamd_schedule *s = new rdamd_schedule();
   s->part = p;
   s->tip_generation = p->tip_generation;
+  s->root_child_clv[0] = ops[n_ops - 1].child1_clv_index; s->root_child_sc[0] = ops[n_ops - 1].child1_scaler_index;
+  s->root_child_clv[1] = ops[n_ops - 1].child2_clv_index; s->root_child_sc[1] = ops[n_ops - 1].child2_scaler_index;
 #define TRY(expr) RDAMD_HIP_TRY(expr, (rdamd_schedule_destroy_locked(s), nullptr))
   s->table_rows = wide_mode ? 64u : 16u;
   s->n_wide = n_wide;
@@ -446,6 +456,17 @@ rdamd_schedule_t *rdamd_schedule_create(rdamd_partition_t *p, const rdamd_operat
   }
 #undef TRY
   return s;
+}
+
+extern "C" {
+
+rdamd_schedule_t *rdamd_schedule_create(rdamd_partition_t *p, const rdamd_operation_t *ops,
+                                        unsigned int n_ops,
+                                        const unsigned int *matrix_indices,
+                                        const double *branch_lengths,
+                                        unsigned int n_matrices) {
+  clear_error();
+  return schedule_create_impl(p, ops, n_ops, matrix_indices, branch_lengths, n_matrices, true);
 }
 
 void rdamd_schedule_destroy(rdamd_schedule_t *s) {
@@ -523,7 +544,7 @@ static int batch_submit(rdamd_partition_t *p, FusedWorkspace *&slot, bool pipeli
                         const rdamd_schedule_t *const *schedules,
                         const double *subst, const double *freqs,
                         const double *rates, const double *rate_weights,
-                        bool host_out, void *lnl_device) {
+                        bool host_out, void *lnl_device, bool export_children = false) {
   const bool k20 = p->states == 20 && p->rate_cats <= 4;
   if (p->states != 4 && !k20) {
     set_error(40, "rdamd_evaluate_batch: 4-state data, or 20-state data with up to 4 rate categories");
@@ -590,7 +611,8 @@ static int batch_submit(rdamd_partition_t *p, FusedWorkspace *&slot, bool pipeli
     hj[j].clade_steps = s->d_steps; hj[j].clade_groups = s->d_groups;
     hj[j].n_groups = s->n_groups; hj[j].n_clade_steps = s->n_steps;
     hj[j].depth = hj[j].depth_plain = 0;   // patched below: every block uses the launch-wide depth
-    hj[j].tt_unsafe = 0;                   // (set again by the P-matrix / clade-table steps of this batch)
+    hj[j].tt_unsafe = export_children ? 1u : 0u;   // (set again by the P-matrix / clade-table steps of this batch;
+                                                   // the exporting variant is one with every rescale test)
     hj[j].lds_pos = s->lds_pos | (s->lds_pos_plain << 16);
     max_depth[0] = std::max(max_depth[0], s->depth);
     max_depth[1] = std::max(max_depth[1], s->depth_plain);
@@ -684,7 +706,7 @@ static int batch_submit(rdamd_partition_t *p, FusedWorkspace *&slot, bool pipeli
     if (host_out)
       RDAMD_HIP_TRY(hipMemcpyAsync(w->h_out, d_out, sizeof(double) * n_jobs, hipMemcpyDeviceToHost, p->stream), RDAMD_FAILURE);
   } else {
-    FusedArgs a;
+    FusedArgs a = {};
     const bool wide_codes = table_rows > 16;
     // (rdamd_set_tip_states drops the 16-bit arena; a 64-row schedule WITHOUT pseudo-tips
     // survives that call -- its programs only address tip rows -- and finds the arena rebuilt here)
@@ -723,9 +745,32 @@ static int batch_submit(rdamd_partition_t *p, FusedWorkspace *&slot, bool pipeli
 #ifdef RDAMD_ABLATION
     if (getenv("RDAMD_FUSED_RW")) a.rates_across_waves = atoi(getenv("RDAMD_FUSED_RW")) != 0 && R >= 2 && R <= 8;
 #endif
+    unsigned *export_scaler[2] = {nullptr, nullptr};
+    if (export_children) {
+      // where the root operation's inner children go: the partition's own CLV / scaler buffers
+      const rdamd_schedule_t *s0 = schedules[0];
+      if (n_jobs != 1 || pipelined || table_rows != 16 || p->mfma_layout) {
+        set_error(50, "rdamd_evaluate_root_children: one job of a 16-row schedule on the partition's stream");
+        return RDAMD_FAILURE;
+      }
+      for (int k = 0; k < 2; ++k) {
+        if (s0->root_child_clv[k] < p->tips) continue;   // a tip: nothing to leave behind
+        if (s0->root_child_sc[k] < 0 || (unsigned)s0->root_child_sc[k] >= p->scale_buffers) {
+          set_error(50, "rdamd_evaluate_root_children: child %d of the root operation needs a scale buffer", k + 1);
+          return RDAMD_FAILURE;
+        }
+        if (!w->d_export_cnt)
+          RDAMD_HIP_TRY(hipMalloc((void **)&w->d_export_cnt, sizeof(unsigned) * 2 * (size_t)p->sites * R), RDAMD_FAILURE);
+        a.export_clv[k] = p->d_clv + (size_t)(s0->root_child_clv[k] - p->tips) * p->clv_doubles();
+        a.export_cnt[k] = w->d_export_cnt + (size_t)k * p->sites * R;
+        export_scaler[k] = p->d_scaler + (size_t)s0->root_child_sc[k] * p->sites;
+      }
+      a.rates_across_waves = 0;
+      a.job_major = 0;
+    }
     if (!pipelined) p->prof_begin(4);
     e = launch_fused_pmatrix(a, w->d_q, w->d_rates, n_jobs, p->prob_matrices, pipelined, pre);
-    if (e == hipSuccess && max_groups)   // the pseudo-tips' tables, from the P-matrices and tip tables just made
+    if (e == hipSuccess && max_groups && !export_children)   // the pseudo-tips' tables, from the P-matrices and tip tables just made
       e = launch_clade_tables(a, p->clades->d_maps, w->d_clade_scratch, clade_scratch_job, n_jobs, max_groups, pipelined, pre);
     if (!pipelined) p->prof_end();
     RDAMD_HIP_TRY(e, RDAMD_FAILURE);
@@ -746,6 +791,11 @@ static int batch_submit(rdamd_partition_t *p, FusedWorkspace *&slot, bool pipeli
     if (getenv("RDAMD_FUSED_RL")) reg_levels[0] = (unsigned)atoi(getenv("RDAMD_FUSED_RL"));
 #endif
     unsigned *h_flag = (unsigned *)(w->h_out + w->cap_jobs);
+    if (export_children) {
+      *h_flag = 0;   // (no second pass behind this one: batch_wait reads the word)
+      e = launch_fused_export(a, max_depth[1], w->blocks_x, reg_levels[1], export_scaler, d_out,
+                              host_out ? w->h_out : nullptr, p->stream);
+    } else
     e = launch_fused_eval(a, n_jobs, max_depth, w->blocks_x, ns, reg_levels, false, d_out,
                           host_out ? w->h_out : nullptr, h_flag, p->stream);
     p->prof_end();
@@ -812,6 +862,25 @@ int rdamd_evaluate_batch(rdamd_partition_t *p, unsigned int n_jobs,
   if (batch_submit(p, p->fused, false, n_jobs, schedules, subst, freqs, rates, rate_weights, true, nullptr) != RDAMD_SUCCESS)
     return RDAMD_FAILURE;
   return batch_wait(p, p->fused, false, lnl_out);
+}
+
+int rdamd_evaluate_root_children(rdamd_partition_t *p, const rdamd_operation_t *ops, unsigned int n_ops,
+                                 const unsigned int *matrix_indices, const double *branch_lengths,
+                                 unsigned int n_matrices, const double *subst, const double *freqs,
+                                 const double *rates, const double *rate_weights, double *lnl_out) {
+  clear_error();
+  if (p->states != 4 || p->mfma_layout) {
+    set_error(50, "rdamd_evaluate_root_children: 4-state (or binary) partitions");
+    return RDAMD_FAILURE;
+  }
+  // a schedule for this one launch: the plain program (its block comes from the partition's pool)
+  rdamd_schedule_t *s = schedule_create_impl(p, ops, n_ops, matrix_indices, branch_lengths, n_matrices, false);
+  if (!s) return RDAMD_FAILURE;
+  const rdamd_schedule_t *list[1] = {s};
+  int rc = batch_submit(p, p->fused, false, 1, list, subst, freqs, rates, rate_weights, true, nullptr, true);
+  if (rc == RDAMD_SUCCESS) rc = batch_wait(p, p->fused, false, lnl_out);
+  rdamd_schedule_destroy(s);
+  return rc;
 }
 
 int rdamd_evaluate_batch_device(rdamd_partition_t *p, unsigned int n_jobs,

@@ -32,6 +32,8 @@ struct FusedOp {
   uint32_t cX, cY;       // byte offset of the tip rows inside tipcodes
   uint32_t flags;        // kind | 0x100 park first | 0x200 park in register level 0 | 0x400 pop it |
                          // 0x800 park in register level 1 | 0x1000 pop it (4-state programs compiled for two)
+                         // | 0x2000 / 0x4000 X / Y table has 64 rows | 0x8000 / 0x10000 this step computes the
+                         // root operation's child 1 / child 2 (read by the exporting variant only)
   uint32_t pad[2];
 };
 
@@ -87,6 +89,11 @@ struct FusedArgs {
   unsigned job_major;                // 1: every XCD walks WHOLE jobs (job j on XCD j % 8) instead of an eighth of
                                      // the sites of every job: its L2 then sees the tables of the one or two jobs it
                                      // is working on (deep trees: 4 MB of tables per job) -- grid.y is padded to x8
+  // the exporting variant only (rdamd_evaluate_root_children): where the CLVs of the root operation's
+  // two children go ([site][rate][4], the partition's own buffers; null for a tip child) and their
+  // rescale counts per (site, rate) ([site][rate]; launch_fused_export turns them into per-site scalers)
+  double   *export_clv[2];
+  unsigned *export_cnt[2];
 };
 
 // ---- 20-state variant (kernels_fused_k20.hip) ---------------------------------
@@ -136,6 +143,11 @@ hipError_t launch_fused_eval(const FusedArgs &a, unsigned n_jobs, const unsigned
                              unsigned blocks_x, unsigned sites_per_lane, const unsigned reg_levels[2],
                              bool unsafe_pass, double *d_out, double *h_out, unsigned *h_flag,
                              hipStream_t stream);
+// ONE job (its tt_unsafe word set by the caller: the plain program, every rescale test) through the
+// exporting variant: the evaluation as above, and the root operation's inner children left in
+// a.export_clv / d_scaler[] as a traversal with per-site scalers leaves them.  16-row schedules only.
+hipError_t launch_fused_export(const FusedArgs &a, unsigned max_depth, unsigned blocks_x, unsigned reg_levels,
+                               unsigned *const d_scaler[2], double *d_out, double *h_out, hipStream_t stream);
 
 
 }  // namespace rdamd

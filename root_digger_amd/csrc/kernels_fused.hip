@@ -311,7 +311,10 @@ __device__ __forceinline__ void stack_pop_wait(f64x2_t (&lo)[NS], f64x2_t (&hi)[
 // three loads whose latency the other waves cover.  Which entries are the busy ones the host
 // knows (evaluate.hip counts the parks per level): the busiest level gets the register slot,
 // the runner-up the LDS slot (FusedJob::lds_pos), the private segment the quiet rest.
-template <int NS, bool TTCHECK, int RL, int TR, bool RW, int SP>
+// EXPORT (rdamd_evaluate_root_children): the steps the host flagged (0x8000 / 0x10000: they compute the
+// root operation's two children) also store the running CLV and its rescale count -- the one thing
+// of a traversal the root-only steps of the search need afterwards (a6, src/model.cpp:415-446).
+template <int NS, bool TTCHECK, int RL, int TR, bool RW, int SP, bool EXPORT = false>
 __global__ void __launch_bounds__(RW ? 512 : 64)
 fused_dna_eval_kernel(FusedArgs a) {
   extern __shared__ double lds[];
@@ -587,6 +590,17 @@ fused_dna_eval_kernel(FusedArgs a) {
         combine_sites<NS, kTestRP>(tx, ty, st.v, st.sc);                                        \
       }                                                                                         \
     }                                                                                           \
+    if (EXPORT && (kind & 0x18000u)) {   /* a child of the root operation: leave it behind */  \
+      double *ec = (kind & 0x8000u) ? a.export_clv[0] : a.export_clv[1];                        \
+      unsigned *en = (kind & 0x8000u) ? a.export_cnt[0] : a.export_cnt[1];                      \
+      _Pragma("unroll") for (int q = 0; q < NS; ++q)                                            \
+        if (valid[q]) {                                                                         \
+          const size_t at = (size_t)site[q] * R + r;                                            \
+          reinterpret_cast<double2 *>(ec + at * 4)[0] = make_double2(st.v[q][0], st.v[q][1]);   \
+          reinterpret_cast<double2 *>(ec + at * 4)[1] = make_double2(st.v[q][2], st.v[q][3]);   \
+          en[at] = (unsigned)st.sc[q];                                                          \
+        }                                                                                       \
+    }                                                                                           \
   }
 
     double s0[NS][4];   // stack level 0 (the most frequently used) stays in registers
@@ -723,6 +737,65 @@ fused_finish_kernel(const double *__restrict__ partials, unsigned per_job,
   }
 }
 
+// rdamd_evaluate_root_children: the exporting evaluator left a child's CLV with one rescale count
+// per (site, rate); the root kernels (and rdamd_get_clv) read the reference's form, one count per
+// site.  s = the smallest count of the site's rates, a rate that was rescaled d times more goes
+// back by 2^(-256 d) -- an exact power of two, the value the per-site rule would hold there
+// (or 0 / a denormal where that rule would have lost the rate to underflow as well).
+// One-wave workgroups, both children in one launch (blockIdx.y): the call runs beside the
+// objective launches of a lock-stepped search, where a four-wave workgroup waits for the end of
+// the launch that fills the device (profiles/micro/side_kernel_latency.hip; measured here: 360 us
+// per launch as 256-lane workgroups against 4 us alone).
+struct ExportFixupArgs {
+  double *clv[2];
+  const unsigned *cnt[2];
+  unsigned *scaler[2];
+  unsigned sites, R;
+};
+__global__ void __launch_bounds__(64)
+fused_export_fixup_kernel(ExportFixupArgs x) {
+  const unsigned k = blockIdx.y;
+  double *__restrict__ clv = x.clv[k];
+  const unsigned *__restrict__ cnt = x.cnt[k];
+  if (!clv) return;
+  const unsigned R = x.R;
+  for (unsigned site = blockIdx.x * 1024u + threadIdx.x; site < min(x.sites, (blockIdx.x + 1) * 1024u); site += 64u) {
+  unsigned smin = cnt[(size_t)site * R];
+  for (unsigned r = 1; r < R; ++r) smin = min(smin, cnt[(size_t)site * R + r]);
+  for (unsigned r = 0; r < R; ++r) {
+    const unsigned d = cnt[(size_t)site * R + r] - smin;
+    if (d) {
+      const double f = pow2_neg256((int)d);
+      double *v = clv + ((size_t)site * R + r) * 4;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] *= f;
+    }
+  }
+  x.scaler[k][site] = smin;
+  }
+}
+
+// fused_finish_kernel for ONE job as a single wave (same reason): lane l plays threads l, l + 64,
+// l + 128, l + 192 of that kernel's workgroup and the four wave sums meet in its order -- the
+// same bits.
+__global__ void __launch_bounds__(64)
+fused_finish_wave_kernel(const double *__restrict__ partials, unsigned per_job, double *__restrict__ out,
+                         double *__restrict__ host_out) {
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (unsigned w = 0; w < 4; ++w)
+    for (unsigned i = w * 64u + threadIdx.x; i < per_job; i += 256) acc[w] += partials[i];
+#pragma unroll
+  for (unsigned w = 0; w < 4; ++w)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc[w] += __shfl_down(acc[w], off);
+  if (threadIdx.x == 0) {
+    const double v = ((acc[0] + acc[1]) + acc[2]) + acc[3];
+    out[0] = v;
+    if (host_out) host_out[0] = v;
+  }
+}
+
 // P-matrices and tip tables for a batch of jobs: 16 lanes per (job, matrix, rate) problem, a
 // lane per matrix element (expm_k4_coop16: pmatrix_k4_kernel's arithmetic, element by
 // element); a wave works off 64 problems, four at a time.  No LDS and ~40 registers: the
@@ -732,6 +805,10 @@ fused_finish_kernel(const double *__restrict__ partials, unsigned per_job,
 // contiguous stores) did not, and sat between the evaluators instead of beside them
 // (profiles/micro/side_kernel_latency.hip).  Every store instruction writes 128 contiguous
 // bytes per problem; the values are the same bits as before.
+// (problems per wave = 4 x kSlimPasses.  Four times fewer, four times longer workgroups here and
+// in the clade-table launch -- what pays for the root-only steps, kernels_root.hip -- measured no
+// gain in the search: 21.9 s against 22.2 s for 66 candidates, three runs each on one box)
+constexpr unsigned kSlimPasses = 16;
 __global__ void __launch_bounds__(64)
 fused_pmatrix_k4_kernel(const double *__restrict__ q, const double *__restrict__ rates,
                         FusedJob *__restrict__ jobs, unsigned n_jobs,
@@ -742,8 +819,8 @@ fused_pmatrix_k4_kernel(const double *__restrict__ q, const double *__restrict__
   const int base = (int)(lane & ~15u);
   const size_t per_job = (size_t)n_mat * R;
   const size_t total = per_job * n_jobs;
-  for (unsigned pass = 0; pass < 16; ++pass) {
-    const size_t first = (size_t)blockIdx.x * 64 + pass * 4;
+  for (unsigned pass = 0; pass < kSlimPasses; ++pass) {
+    const size_t first = (size_t)blockIdx.x * (kSlimPasses * 4) + pass * 4;
     if (first >= total) break;   // (wave-uniform)
     const size_t gid_raw = first + (lane >> 4);
     const bool live = gid_raw < total;
@@ -857,7 +934,7 @@ hipError_t launch_fused_pmatrix(const FusedArgs &a, const double *d_q, const dou
   const size_t total = (size_t)n_jobs * n_mat * a.rate_cats;
   if (!total) return hipSuccess;
   if (slim)
-    fused_pmatrix_k4_kernel<<<(unsigned)((total + 63) / 64), 64, 0, stream>>>(
+    fused_pmatrix_k4_kernel<<<(unsigned)((total + kSlimPasses * 4 - 1) / (kSlimPasses * 4)), 64, 0, stream>>>(
         d_q, d_rates, const_cast<FusedJob *>(a.jobs), n_jobs, n_mat, a.rate_cats, const_cast<double *>(a.pmat),
         const_cast<double *>(a.tiptab), a.pmat_job_stride, a.tiptab_job_stride, a.table_rows, a.any_unsafe);
   else
@@ -867,7 +944,7 @@ hipError_t launch_fused_pmatrix(const FusedArgs &a, const double *d_q, const dou
   return hipGetLastError();
 }
 
-template <int NS, bool TTCHECK, int RL, int TR, bool RW, int SP>
+template <int NS, bool TTCHECK, int RL, int TR, bool RW, int SP, bool EXPORT = false>
 static hipError_t launch_fused_variant(const FusedArgs &a, unsigned n_jobs, unsigned max_depth, unsigned gx,
                                        hipStream_t stream) {
   const unsigned n_waves = RW ? a.rate_cats : 1u;
@@ -877,18 +954,18 @@ static hipError_t launch_fused_variant(const FusedArgs &a, unsigned n_jobs, unsi
   const size_t lds = std::max<size_t>(per_wave * n_waves, (size_t)n_waves * NS * 64 * 12);
   static size_t lds_allowed = 48 * 1024;
   if (lds > lds_allowed) {   // deep stacks (very unbalanced 10^3-taxon trees), or R of them: raise the limit
-    hipError_t e = hipFuncSetAttribute((const void *)fused_dna_eval_kernel<NS, TTCHECK, RL, TR, RW, SP>,
+    hipError_t e = hipFuncSetAttribute((const void *)fused_dna_eval_kernel<NS, TTCHECK, RL, TR, RW, SP, EXPORT>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     lds_allowed = lds;
   }
   static const bool lds_starts_at_zero = [] {   // see the note at the top of the kernel
     hipFuncAttributes attr;
-    return hipFuncGetAttributes(&attr, (const void *)fused_dna_eval_kernel<NS, TTCHECK, RL, TR, RW, SP>) == hipSuccess &&
+    return hipFuncGetAttributes(&attr, (const void *)fused_dna_eval_kernel<NS, TTCHECK, RL, TR, RW, SP, EXPORT>) == hipSuccess &&
            attr.sharedSizeBytes == 0;
   }();
   if (!lds_starts_at_zero) return hipErrorInvalidValue;
-  fused_dna_eval_kernel<NS, TTCHECK, RL, TR, RW, SP><<<dim3(gx, a.job_major ? (n_jobs + 7u) / 8u * 8u : n_jobs), 64 * n_waves, lds, stream>>>(a);
+  fused_dna_eval_kernel<NS, TTCHECK, RL, TR, RW, SP, EXPORT><<<dim3(gx, a.job_major ? (n_jobs + 7u) / 8u * 8u : n_jobs), 64 * n_waves, lds, stream>>>(a);
   return hipGetLastError();
 }
 
@@ -950,6 +1027,25 @@ hipError_t launch_fused_eval(const FusedArgs &a, unsigned n_jobs, const unsigned
                                : launch_fused_eval_ns<1, 64>(a, n_jobs, max_depth, blocks_x, reg_levels, unsafe_pass, d_out, h_out, h_flag, stream);
   return sites_per_lane == 2 ? launch_fused_eval_ns<2, 16>(a, n_jobs, max_depth, blocks_x, reg_levels, unsafe_pass, d_out, h_out, h_flag, stream)
                              : launch_fused_eval_ns<1, 16>(a, n_jobs, max_depth, blocks_x, reg_levels, unsafe_pass, d_out, h_out, h_flag, stream);
+}
+
+// One site per lane (a single job is a few hundred waves either way), all-LDS stack behind the
+// register level(s), plain program with every rescale test; then the finishing kernel and, per
+// exported child, the counts -> per-site scalers step.
+hipError_t launch_fused_export(const FusedArgs &a, unsigned max_depth, unsigned blocks_x, unsigned reg_levels,
+                               unsigned *const d_scaler[2], double *d_out, double *h_out, hipStream_t stream) {
+  if (a.table_rows != 16 || a.rates_across_waves || a.job_major || a.n_jobs != 1) return hipErrorInvalidValue;
+  hipError_t e = reg_levels >= 2 ? launch_fused_variant<1, true, 2, 16, false, 0, true>(a, 1, max_depth, blocks_x, stream)
+                                 : launch_fused_variant<1, true, 1, 16, false, 0, true>(a, 1, max_depth, blocks_x, stream);
+  if (e != hipSuccess) return e;
+  fused_finish_wave_kernel<<<1, 64, 0, stream>>>(a.partials, blocks_x, d_out, h_out);
+  if (a.export_clv[0] || a.export_clv[1]) {
+    ExportFixupArgs x;
+    for (int k = 0; k < 2; ++k) { x.clv[k] = a.export_clv[k]; x.cnt[k] = a.export_cnt[k]; x.scaler[k] = d_scaler[k]; }
+    x.sites = a.sites; x.R = a.rate_cats;
+    fused_export_fixup_kernel<<<dim3((a.sites + 1023u) / 1024u, 2), 64, 0, stream>>>(x);
+  }
+  return hipGetLastError();
 }
 
 }  // namespace rdamd

@@ -234,11 +234,11 @@ root_single_body(const DeviceView &v, const LevelOp &op, const RootSingleArgs &r
                  const double *__restrict__ rates, const double *__restrict__ freqs,
                  const double *__restrict__ rate_w, const unsigned *__restrict__ pw,
                  const uint64_t *__restrict__ codemask, double *__restrict__ partials,
-                 unsigned *__restrict__ counter, double *__restrict__ result, const unsigned bid,
-                 const unsigned w, const unsigned nblocks) {
+                 unsigned *__restrict__ counter, double *__restrict__ result, const unsigned phys,
+                 const unsigned n_phys, const unsigned nblocks) {
   constexpr unsigned kMaxPos = R <= 4 ? 8u : 4u;   // root_single_max_positions(R)
   __shared__ double spm[kMaxPos][2][R][16];        // P-matrices, 8 KB
-  const unsigned lane = threadIdx.x, tid = w * 64u + lane, S = v.sites;   // tid: lane of the virtual block
+  const unsigned lane = threadIdx.x, S = v.sites;
   const unsigned NA = (unsigned)__builtin_amdgcn_readfirstlane((int)ra.n_positions);
   const bool tip1 = op.child1_clv < v.tips, tip2 = op.child2_clv < v.tips;
   // (`ra` may be a kernel argument: a per-lane index into its arrays would make the compiler
@@ -258,6 +258,11 @@ root_single_body(const DeviceView &v, const LevelOp &op, const RootSingleArgs &r
   };
   // the NA x 2 x R matrices, four at a time: 16 lanes per matrix, a lane per element
   // (expm_k4_coop16: pmatrix_k4_kernel's arithmetic without its 128 registers)
+#ifdef RDAMD_ABLATION
+  if (ra.abl & 1u) {   // timing only: garbage matrices, no exponentiation
+    for (unsigned e = lane; e < NA * 2 * R * 16; e += 64) (&spm[0][0][0][0])[e] = 0.25;
+  } else
+#endif
   for (unsigned m0 = 0; m0 < NA * 2 * R; m0 += 4) {
     const unsigned m = m0 + (lane >> 4);
     const bool have = m < NA * 2 * R;
@@ -269,13 +274,13 @@ root_single_body(const DeviceView &v, const LevelOp &op, const RootSingleArgs &r
   __syncthreads();
   // the state contract: the LAST position's matrices (and their tip tables) are
   // what rdamd_update_prob_matrices would have left in the partition
-  if (bid == 0) {
-    for (unsigned e = tid; e < 2 * R * 16; e += 256) {
+  if (phys == 0) {
+    for (unsigned e = lane; e < 2 * R * 16; e += 64) {
       const unsigned c = e / (R * 16), ww = e % (R * 16);
       const unsigned m = c ? op.child2_mat : op.child1_mat;
       v.pmat[(size_t)m * R * 16 + ww] = spm[NA - 1][c][ww / 16][ww % 16];
     }
-    for (unsigned e = tid; e < 2 * R * 64; e += 256) {
+    for (unsigned e = lane; e < 2 * R * 64; e += 64) {
       const unsigned c = e / (R * 64), ww = e % (R * 64);
       const unsigned m = c ? op.child2_mat : op.child1_mat;
       const unsigned r = ww / 64, code = (ww / 4) & 15u, i = ww & 3u;
@@ -305,6 +310,10 @@ root_single_body(const DeviceView &v, const LevelOp &op, const RootSingleArgs &r
 #pragma unroll 1
   for (unsigned a = 0; a < NA; ++a) {
     const bool last = a + 1 == NA;
+    // the virtual waves this workgroup plays, one after the other: wave w of virtual block bid
+#pragma unroll 1
+    for (unsigned vw = phys; vw < nblocks * 4; vw += n_phys) {
+    const unsigned bid = vw >> 2, w = vw & 3u, tid = w * 64u + lane;   // tid: lane of the virtual block
     double acc = 0.0;
     for (size_t idx = (size_t)bid * 256 + tid; idx < total; idx += stride) {
       // (the P-matrices in LDS do not change inside this loop, which usually runs once: left
@@ -376,6 +385,7 @@ root_single_body(const DeviceView &v, const LevelOp &op, const RootSingleArgs &r
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
     if (lane == 0) partials[((size_t)a * nblocks + bid) * 4 + w] = acc;
+    }
   }
   // the wave that arrives last folds the partials (finish_sum_kernel's order: lane t of a
   // 256-lane block adds the block sums t, t + 256, ..., then block_sum_256 over the lanes --
@@ -384,7 +394,7 @@ root_single_body(const DeviceView &v, const LevelOp &op, const RootSingleArgs &r
   unsigned ticket = 0;
   if (lane == 0) ticket = atomicAdd(counter, 1u);
   ticket = (unsigned)__builtin_amdgcn_readfirstlane((int)ticket);
-  if (ticket != nblocks * 4 - 1) return;
+  if (ticket != n_phys - 1) return;
   __threadfence();
   for (unsigned a = 0; a < NA; ++a) {
     const volatile double *p = partials + (size_t)a * nblocks * 4;
@@ -411,9 +421,9 @@ root_single_dna_kernel(DeviceView v, LevelOp op, RootSingleArgs ra, const double
                        const double *__restrict__ rates, const double *__restrict__ freqs,
                        const double *__restrict__ rate_w, const unsigned *__restrict__ pw,
                        const uint64_t *__restrict__ codemask, double *__restrict__ partials,
-                       unsigned *__restrict__ counter, double *__restrict__ result) {
+                       unsigned *__restrict__ counter, double *__restrict__ result, unsigned nblocks) {
   root_single_body<R>(v, op, ra, q, rates, freqs, rate_w, pw, codemask, partials, counter, result,
-                      blockIdx.x >> 2, blockIdx.x & 3u, gridDim.x >> 2);
+                      blockIdx.x, gridDim.x, nblocks);
 }
 
 // The same for SEVERAL partitions at once (grid.y): the root-only steps of the candidates that
@@ -425,9 +435,11 @@ template <int R>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4)))
 root_multi_dna_kernel(const RootItem *__restrict__ items) {
   const RootItem &it = items[blockIdx.y];
-  if ((blockIdx.x >> 2) >= it.blocks) return;
+  // (a row with fewer virtual waves than the launch has workgroups per row uses as many as it has)
+  const unsigned n_phys = min(gridDim.x, it.blocks * 4u);
+  if (blockIdx.x >= n_phys) return;
   root_single_body<R>(it.v, it.op, it.ra, it.q, it.rates, it.freqs, it.rate_w, it.pw, it.codemask,
-                      it.partials, it.counter, it.result, blockIdx.x >> 2, blockIdx.x & 3u, it.blocks);
+                      it.partials, it.counter, it.result, blockIdx.x, n_phys, it.blocks);
 }
 
 hipError_t launch_root_lnl(rdamd_partition *p, unsigned clv_index, int scaler_index,
@@ -499,13 +511,30 @@ hipError_t launch_root_lnl_batch(rdamd_partition *p, unsigned count, const unsig
   return hipGetLastError();
 }
 
+// Workgroups (= waves) a root step is launched with.  Its arithmetic is laid out over
+// blocks x 4 VIRTUAL waves (above); how many physical waves play them changes no bit.  With the
+// device to itself a step wants them all side by side (24 us on c2).  BESIDE the objective
+// launches of a lock-stepped search (the replicas' streams run on high priority then, model_c_api.cpp)
+// every workgroup that is dispatched between the evaluator's costs that kernel ~27 ns of the whole
+// device, whatever the workgroup does -- measured, profiles/root_interference.py: 3 128 workgroups
+// 85 us per step, 782: 22 us, 196: 5 us, with or without the exponentiation in them -- so there a
+// wave plays 16 virtual ones.
+static unsigned root_workgroups(unsigned blocks, bool beside) {
+  const unsigned vw = blocks * 4u;
+  unsigned per_wave = 16u;
+#ifdef RDAMD_ABLATION
+  if (getenv("RDAMD_ROOT_PER_WAVE")) per_wave = (unsigned)std::max(1, atoi(getenv("RDAMD_ROOT_PER_WAVE")));
+#endif
+  return beside ? std::max(1u, (vw + per_wave - 1u) / per_wave) : vw;
+}
+
 template <int R>
 static hipError_t launch_root_single_r(rdamd_partition *p, const DeviceView &v, const LevelOp &op,
                                        const RootSingleArgs &ra, unsigned blocks, unsigned *d_counter,
                                        double *result) {
-  root_single_dna_kernel<R><<<blocks * 4, 64, 0, p->stream>>>(
+  root_single_dna_kernel<R><<<root_workgroups(blocks, p->stream_priority < 0), 64, 0, p->stream>>>(
       v, op, ra, p->d_q, p->d_rates, p->d_freqs, p->d_rate_weights, p->d_pattern_weights,
-      p->d_codemask, p->d_partials, d_counter, result);
+      p->d_codemask, p->d_partials, d_counter, result, blocks);
   return hipGetLastError();
 }
 
@@ -527,6 +556,9 @@ hipError_t launch_root_single(rdamd_partition *p, const LevelOp &op, const doubl
   unsigned blocks = (unsigned)((total + 255) / 256);
   if (blocks > kRootBlocks) blocks = kRootBlocks;   // same shape as launch_root_lnl
   if (blocks == 0) blocks = 1;
+#ifdef RDAMD_ABLATION
+  ra.abl = getenv("RDAMD_ROOT_NOEXPM") ? 1u : 0u;
+#endif
   const DeviceView v = p->view();
   switch (R) {
     case 1: return launch_root_single_r<1>(p, v, op, ra, blocks, d_counter, result);
@@ -547,7 +579,7 @@ unsigned root_single_blocks(const rdamd_partition *p) {
 hipError_t launch_root_multi(const RootItem *d_items, unsigned n_items, unsigned R, unsigned max_positions,
                              unsigned max_blocks, hipStream_t stream) {
   if (!n_items) return hipSuccess;
-  const dim3 grid(max_blocks * 4, n_items);
+  const dim3 grid(root_workgroups(max_blocks, true), n_items);   // (the lock-stepped search's call: always beside)
   if (max_positions > root_single_max_positions(R)) return hipErrorInvalidValue;
   switch (R) {
     case 1: root_multi_dna_kernel<1><<<grid, 64, 0, stream>>>(d_items); break;

@@ -300,6 +300,43 @@ double model_t::compute_lh(const root_location_t &root_location) {
   return reduce_value(lh);
 }
 
+// compute_lh for the searches, between optimize_params and the root-only steps: the same
+// value for the caller's convergence test, but only what those steps read is left behind --
+// the CLVs and scalers of the root's two children (rdamd_evaluate_root_children: one job of
+// the fused evaluator instead of a traversal that writes every CLV).  Partitions the fused
+// evaluator does not take (20 states, general K) go through the three calls of compute_lh.
+double model_t::compute_lh_for_root_steps(const root_location_t &root_location) {
+  if (!_children_only) return compute_lh(root_location);
+  auto sched = _tree.generate_operations(root_location);
+  const auto &ops = std::get<0>(sched);
+  const auto &pmi = std::get<1>(sched);
+  const auto &brl = std::get<2>(sched);
+  ++_n_full;
+  double lh = 0.0;
+  for (size_t i = 0; i < _partitions.size(); ++i) {
+    rdamd_partition_t *part = _partitions[i];
+    const unsigned st = rdamd_partition_states(part);
+    if (st == 4 || st == 2) {
+      double v = 0.0;
+      if (rdamd_evaluate_root_children(part, ops.data(), (unsigned)ops.size(), pmi.data(), brl.data(),
+                                       (unsigned)pmi.size(), rdamd_partition_subst_params(part, 0),
+                                       rdamd_partition_frequencies(part, 0), _rate_rates[i].data(),
+                                       _rate_weights[i].data(), &v) != RDAMD_SUCCESS)
+        fail("evaluate_root_children");
+      lh += v;
+    } else {
+      if (rdamd_update_prob_matrices(part, _param_indicies[i].data(), pmi.data(), brl.data(),
+                                     (unsigned)pmi.size()) != RDAMD_SUCCESS)
+        fail("update_prob_matrices");
+      rdamd_update_clvs(part, ops.data(), (unsigned)ops.size());
+      if (rdamd_errno()) fail("update_clvs");
+      lh += rdamd_compute_root_loglikelihood(part, _tree.root_clv_index(), _tree.root_scaler_index(),
+                                             _param_indicies[i].data(), nullptr);
+    }
+  }
+  return reduce_value(lh);
+}
+
 double model_t::compute_lh_root(const root_location_t &root) {
   auto res = _tree.generate_derivative_operations(root);
   const rdamd_operation_t &op = std::get<0>(res);
@@ -1117,7 +1154,9 @@ std::pair<root_location_t, double> model_t::exhaustive_search(double atol, doubl
     set_subst_rates_uniform();
     set_empirical_freqs();
     _tree.root_by(rl);
-    compute_lh(rl);
+    // (a caller-supplied optimiser may read any CLV; optimize_params reads none)
+    if (_optimizer) compute_lh(rl);
+    else compute_lh_for_root_steps(rl);
     std::vector<partition_parameters_t> params;
     for (size_t p = 0; p < _partitions.size(); ++p)
       params.push_back(make_partition_parameters(rdamd_partition_states(_partitions[p]),
@@ -1128,7 +1167,7 @@ std::pair<root_location_t, double> model_t::exhaustive_search(double atol, doubl
     for (size_t iter = 0; iter < 1000; ++iter) {
       if (_optimizer) _optimizer(*this, params, rl, pgtol, factor, iter % 10 == 0);
       else if (_setulb) optimize_params(params, rl, pgtol, factor, iter % 10 == 0);
-      if (std::fabs(compute_lh(rl) - cur_best_llh) < atol) break;
+      if (std::fabs(compute_lh_for_root_steps(rl) - cur_best_llh) < atol) break;
       root_location_t cur_rl;
       double cur_llh;
       {   // (lock step: this candidate's root-only steps may now meet the others')

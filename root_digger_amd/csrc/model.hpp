@@ -106,6 +106,9 @@ public:
 
   // ---- likelihood facade (hot-path callers) -------------------------------
   double compute_lh(const root_location_t &root_location);      // src/model.cpp:384-413
+  // the same value; only the root's two children are left materialised (model.cpp)
+  double compute_lh_for_root_steps(const root_location_t &root_location);
+  void set_root_children_only(bool on) { _children_only = on; }
   double compute_lh_root(const root_location_t &root);          // :415-452
   dlh_t  compute_dlh(const root_location_t &root_location);     // :481-519
   // several positions of one root branch per launch (optimize_alpha's opening and scan levels)
@@ -276,6 +279,7 @@ private:
   std::vector<batch_combiner_t *>        _combiners;          // [partition], or empty
   root_combiner_t                       *_root_combiner = nullptr;
   bool                                   _invariant_sites, _early_stop;   // +I is inert (:292-300)
+  bool                                   _children_only = true;           // compute_lh_for_root_steps
   uint64_t                               _seed;
   param_optimizer_t                      _optimizer;
   setulb_fn                              _setulb = nullptr;

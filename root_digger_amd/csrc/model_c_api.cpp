@@ -38,6 +38,7 @@ struct rdamd_model {
   rdamd::checkpoint_t *checkpoint = nullptr;
   std::unique_ptr<rdamd::model_t::progress_t> progress;   // set by rdamd_model_set_progress
   int lockstep_priority = 1;      // stream priority of the shared objective partition in a lock-stepped search
+  bool children_only = true;      // rdamd_model_set_root_children_only
   unsigned lockstep_groups = 0;   // 0: the library's choice; 1: one group, blocking launches (rdamd_model_set_lockstep_groups)
   uint64_t lockstep_stats[4] = {0, 0, 0, 0};   // of the last lock-stepped search (rdamd_model_lockstep_stats)
   ~rdamd_model() { delete model; }
@@ -476,6 +477,7 @@ static int search_with_replicas(rdamd_model_t *m, unsigned int workers, bool loc
         if (m->setulb) replica.set_lbfgsb(reinterpret_cast<rdamd::model_t::setulb_fn>(m->setulb));
         replica.set_checkpoint(m->checkpoint);
         replica.set_progress(m->progress.get());
+        replica.set_root_children_only(m->children_only);
         {
           std::vector<rdamd::batch_combiner_t *> mine;
           for (auto &c : combiner[wid % n_groups]) mine.push_back(c.get());
@@ -572,6 +574,10 @@ int rdamd_model_optimize_params(rdamd_model_t *m, const rdamd_root_location_t *r
 }
 void rdamd_model_set_lockstep_groups(rdamd_model_t *m, unsigned int groups) { m->lockstep_groups = groups; }
 void rdamd_model_set_lockstep_priority(rdamd_model_t *m, int level) { m->lockstep_priority = level; }
+void rdamd_model_set_root_children_only(rdamd_model_t *m, int on) {
+  m->children_only = on != 0;
+  if (m->model) m->model->set_root_children_only(on != 0);
+}
 void rdamd_model_lockstep_stats(const rdamd_model_t *m, uint64_t out[4]) {
   for (int i = 0; i < 4; ++i) out[i] = m->lockstep_stats[i];
 }

@@ -31,6 +31,8 @@ struct Compiler {
   std::unordered_map<unsigned, unsigned> pseudo_row;
   std::unordered_map<unsigned, unsigned> pseudo_wide;   // ... and, for a 64-row table, its slot among the job's
   unsigned wide_base = 0;                               // tX of wide slot 0 (behind the 16-row tables)
+  unsigned mark_clv[2] = {~0u, ~0u};                 // the root operation's children: the steps that compute them are
+                                                     // flagged 0x8000 / 0x10000 (fused.hpp; the exporting variant)
   unsigned matvecs = 0;                              // inner children = matrix-vector products per (site, rate)
   std::vector<unsigned> need;                        // stack slots a subtree needs
   std::vector<FusedOp> out;
@@ -136,6 +138,8 @@ struct Compiler {
     f.cX = tipX_row * tip_stride;
     f.cY = tipY_row * tip_stride;
     f.flags = kind | (spill << 8) | wide_flags;   // (a 20-state TT never parks: its spill bits were moved to the park step)
+    if (o.parent_clv_index == mark_clv[0]) f.flags |= 0x8000u;
+    if (o.parent_clv_index == mark_clv[1]) f.flags |= 0x10000u;
     out.push_back(f);
   }
   // Second pass: which level gets the register slot.  The first pass (emit) counted the parks

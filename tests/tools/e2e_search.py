@@ -27,6 +27,8 @@ ref = os.path.join(ROOT, "oracle", "_ref", "liblbfgsb_ref.so")
 lb = ctypes.CDLL(ref)
 m.set_lbfgsb(lb.setulb)
 m.compute_lh(tree.root_location(0))
+if "CHILDREN" in os.environ:   # 0: the searches' compute_lh stays the full traversal
+    m.set_root_children_only(int(os.environ["CHILDREN"]) != 0)
 lib = rd.lib
 import ctypes as C
 workers = int(os.environ.get("WORKERS", "0"))
