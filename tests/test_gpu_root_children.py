@@ -126,3 +126,34 @@ def test_root_children_binary_and_errors():
     ops, pmi, brl = t20.generate_operations(t20.root_location(0))
     with pytest.raises(rd.RdamdError):
         g20.evaluate_root_children(ops, pmi, brl, w20["subst"], [0.05] * 20, w20["rates"])
+
+
+def test_search_with_root_children_agrees_with_the_traversal_search():
+    """exhaustive_search with compute_lh_for_root_steps (the default) against the same search on
+    full traversals: the same optimiser on values that differ in their last bits -- the records
+    agree to the optimiser's tolerances, lock step == sequential stays bit for bit, and no
+    traversal kernel is asked for between the candidates' root-only steps."""
+    import ctypes
+    import os
+    ref = os.path.join(util.ROOT, "oracle", "_ref", "liblbfgsb_ref.so")
+    if not os.path.exists(ref):
+        pytest.skip("oracle/_ref/liblbfgsb_ref.so not built (make -C oracle ref)")
+    lb = ctypes.CDLL(ref)
+    w = synth.workload(12, 4000, 4, 4, 978)
+    tree = rd.Tree.from_newick(w["newick"])
+    m = rd.Model(tree, w["seqs"], rate_cats=4, seed=5)
+    m.initialize_partitions()
+    m.set_lbfgsb(lb.setulb)
+    m.compute_lh(tree.root_location(0))
+    tol = (1e-6, 1e-6, 1e-8, 1e7)
+    new = m.exhaustive_search(*tol)
+    lock = m.exhaustive_search(*tol, lockstep=6)
+    order = np.argsort(new["root_id"])
+    assert np.array_equal(lock["llh"], new["llh"][order]) and np.array_equal(lock["alpha"], new["alpha"][order])
+    m.set_root_children_only(False)
+    old = m.exhaustive_search(*tol)
+    m.set_root_children_only(True)
+    assert list(old["root_id"]) == list(new["root_id"])
+    assert np.allclose(old["llh"], new["llh"], rtol=1e-7, atol=0.0)
+    assert np.allclose(old["alpha"], new["alpha"], atol=1e-3)
+    assert abs(old["best_llh"] - new["best_llh"]) <= 1e-7 * abs(old["best_llh"])
