@@ -765,7 +765,9 @@ fused_export_fixup_kernel(ExportFixupArgs x) {
   for (unsigned r = 0; r < R; ++r) {
     const unsigned d = cnt[(size_t)site * R + r] - smin;
     if (d) {
-      const double f = pow2_neg256((int)d);
+      // (2^-1024 is still a number -- a denormal --, and so may be the product: what the per-site
+      // rule's chain of small products arrives at, up to the denormals' rounding)
+      const double f = d < 4u ? pow2_neg256((int)d) : (d == 4u ? 0x1p-1024 : 0.0);
       double *v = clv + ((size_t)site * R + r) * 4;
 #pragma unroll
       for (int i = 0; i < 4; ++i) v[i] *= f;

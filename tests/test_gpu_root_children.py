@@ -22,7 +22,8 @@ def _scaled_equal(a, sa, b, sb, rtol):
     lo = np.minimum(sa, sb)
     fa = np.ldexp(a, (-256 * (sa - lo)).astype(np.int64))
     fb = np.ldexp(b, (-256 * (sb - lo)).astype(np.int64))
-    return np.allclose(fa, fb, rtol=rtol, atol=0.0)
+    # (atol: entries the per-site rule leaves in the denormal range have lost bits on ITS side)
+    return np.allclose(fa, fb, rtol=rtol, atol=1e-250)
 
 
 def _check_children(g, o, tree, rl, subst, freqs, rates, weights=None, clv_rtol=1e-12):
@@ -157,3 +158,17 @@ def test_search_with_root_children_agrees_with_the_traversal_search():
     assert np.allclose(old["llh"], new["llh"], rtol=1e-7, atol=0.0)
     assert np.allclose(old["alpha"], new["alpha"], atol=1e-3)
     assert abs(old["best_llh"] - new["best_llh"]) <= 1e-7 * abs(old["best_llh"])
+
+
+def test_root_children_with_a_vanishing_rate_category():
+    """A category whose rate is ~0 never rescales while the others do: the evaluator's counts per
+    (site, rate) drift apart by several 2^256 steps and the per-site scalers written for the
+    root kernels put that category back by 2^(-256 d) -- into or below the denormal range, where
+    the per-site rule's own chain of products ends up too (entries there are compared by
+    magnitude only); the likelihoods agree to the usual tolerance."""
+    gd = util.golden("deep_scaling.json")
+    tree = rd.Tree.from_newick(gd["newick"])
+    g, o = pair(tree, gd["seqs"], 4, 4)
+    rates = [1e-42] + list(gd["rates"][1:])
+    for i in (0, 100, tree.root_count() - 1):
+        _check_children(g, o, tree, tree.root_location(i).with_ratio(0.31), gd["subst"], gd["freqs"], rates)

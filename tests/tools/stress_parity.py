@@ -21,7 +21,7 @@ import util
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
-t0, rounds, worst, folded = time.time(), 0, 0.0, 0
+t0, rounds, worst, folded, children = time.time(), 0, 0.0, 0, 0
 while time.time() - t0 < budget:
     n = int(rng.integers(4, 260))
     R = int(rng.choice([1, 2, 4, 8]))
@@ -93,9 +93,43 @@ while time.time() - t0 < budget:
         fused = g.evaluate_batch([g.schedule(ops, pmi, brl)], [w["subst"]], [freqs])[0]
     err = max(abs(la - lb), abs(fused - lb)) / abs(lb)
     assert err < 1e-11, (n, S, R, K, la, lb, fused)
+    if K != 20:                  # the root's children left behind by the exporting evaluator
+        # (rdamd_evaluate_root_children): the value, the two CLVs up to their scalers, and the
+        # root-only evaluation on top of them, with other parameters than the traversal above
+        subst2 = [v * float(rng.uniform(0.5, 2.0)) for v in w["subst"]]
+        lc = g.evaluate_root_children(ops, pmi, brl, subst2, freqs, w["rates"])
+        o.set_subst_params(0, subst2)
+        g.set_subst_params(0, subst2)
+        o.update_prob_matrices(pmi, brl)
+        o.update_clvs(ops)
+        lo = o.compute_root_loglikelihood(tree.root_clv_index(), tree.root_scaler_index())
+        rop, _, _ = tree.generate_derivative_operations(rl)
+        lr = g.root_loglikelihood_fused(rop, [rl.saved_brlen * rl.brlen_ratio], [rl.saved_brlen * (1 - rl.brlen_ratio)])[0]
+        err2 = max(abs(lc - lo), abs(lr - lo)) / abs(lo)
+        assert err2 < 1e-11, (n, S, R, K, lc, lr, lo)
+        root = ops[-1]
+        for clv, sc in ((root.child1_clv_index, root.child1_scaler_index), (root.child2_clv_index, root.child2_scaler_index)):
+            if clv < n:
+                continue
+            a, b = g.get_clv(clv), o.get_clv(clv)
+            sa = g.get_scaler(sc).astype(np.int64)[:, None, None]
+            sb = o.get_scaler(sc).astype(np.int64)[:, None, None]
+            lo_s = np.minimum(sa, sb)
+            fa, fb = np.ldexp(a, -256 * (sa - lo_s)), np.ldexp(b, -256 * (sb - lo_s))
+            # (atol: where the per-site rule leaves a rate in or below the denormal range -- a vanishing
+            # category: 1.3e-264 here against 0 there, 0 here against 1.9e-309 there in this soak -- its
+            # own chain of products has lost the bits; the evaluator's count per (site, rate) has not)
+            if not np.allclose(fa, fb, rtol=1e-12, atol=1e-250):
+                rel = np.abs(fa - fb) / np.maximum(np.abs(fb), 1e-300)
+                i = np.unravel_index(np.argmax(rel), rel.shape)
+                print("CLV mismatch", (n, S, R, K, clv, repeats), "worst rel", rel.max(), "at", i, fa[i], fb[i],
+                      "scalers", int(sa[i[0], 0, 0]), int(sb[i[0], 0, 0]), "raw", a[i], b[i], "rates", w["rates"][:2])
+                raise AssertionError("CLV mismatch")
+        err = max(err, err2)
+        children += 1
     worst = max(worst, err)
     rounds += 1
     g.destroy()
     o.destroy()
-print("%d random cases (%d with subtree site repeats) in %.0f s, worst lnL rel. err %.2e"
-      % (rounds, folded, time.time() - t0, worst))
+print("%d random cases (%d with subtree site repeats, %d with the root's children from the evaluator) in %.0f s, "
+      "worst lnL rel. err %.2e" % (rounds, folded, children, time.time() - t0, worst))
