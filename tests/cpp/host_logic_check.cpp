@@ -98,8 +98,13 @@ static uint64_t expected(const rdamd::Compiler &c, const std::vector<rdamd_opera
 
 // runs the program the way the kernels do (kernels_fused.hip / kernels_fused_k20.hip): one or
 // two register slots, the other entries on a stack addressed by the count of entries in it
-static int replay(const rdamd::Compiler &c, unsigned lds_pos, uint64_t want, unsigned &mem_depth) {
+// marked[k] (k = 0, 1): what the running CLV must be behind the step flagged 0x8000 << k -- the root
+// operation's child k + 1 as the list defines it (0: that child is no inner node of the program,
+// no step may carry the flag)
+static int replay(const rdamd::Compiler &c, unsigned lds_pos, uint64_t want, unsigned &mem_depth,
+                  const uint64_t marked[2] = nullptr) {
   using namespace rdamd;
+  unsigned seen[2] = {0, 0};
   uint64_t run = 0, s0 = 0, s1 = 0;
   bool s0_full = false, s1_full = false;
   std::vector<uint64_t> mem;
@@ -131,7 +136,15 @@ static int replay(const rdamd::Compiler &c, unsigned lds_pos, uint64_t want, uns
       else { if (mem.empty()) return fail("pop from an empty stack", (int)i); sib = mem.back(); mem.pop_back(); }
       run = h_mul(h_mv(f.pM, run), sib);
     }
+    for (int k = 0; marked && k < 2; ++k)
+      if (f.flags & (0x8000u << k)) {
+        if (kind == kFusedPark || !marked[k] || run != marked[k])
+          return fail("a step is flagged as the root operation's child but does not leave it in the running CLV", (int)i, k);
+        ++seen[k];
+      }
   }
+  for (int k = 0; marked && k < 2; ++k)
+    if (seen[k] != (marked[k] ? 1u : 0u)) return fail("root child: flagged steps", k, (int)seen[k]);
   if (s0_full || s1_full || !mem.empty()) return fail("entries left on the stack");
   if (run != want) return fail("the program does not compute the root CLV");
   if (mem_depth >= 2 && c.reg_levels == 1 && lds_pos >= mem_depth) return fail("lds_pos out of range", (int)lds_pos, (int)mem_depth);
@@ -178,6 +191,15 @@ static int check_compiler(std::mt19937 &rng, int &cases) {
           if (rng() % 2) c.pseudo_wide[ops[i].parent_clv_index] = wide++;
         }
     }
+    // the steps that compute the root operation's inner children carry 0x8000 / 0x10000 (4 states:
+    // the exporting evaluator, rdamd_evaluate_root_children)
+    uint64_t marked[2] = {0, 0};
+    if (!k20) {
+      const rdamd_operation_t &root = ops.back();
+      const unsigned kid[2] = {root.child1_clv_index, root.child2_clv_index};
+      for (int k = 0; k < 2; ++k)
+        if (kid[k] >= n) c.mark_clv[k] = kid[k];
+    }
     c.need.assign(c.n_ops, 0);
     c.compute_need(c.n_ops - 1);
     c.emit(c.n_ops - 1, false, 0);
@@ -196,7 +218,13 @@ static int check_compiler(std::mt19937 &rng, int &cases) {
     if (k20 && c.reg_levels != 1) return fail("20-state programs have one register level");
     if (!k20 && (c.reg_levels == 2) != (c.max_depth > beyond)) return fail("two register levels", (int)c.max_depth);
     unsigned mem_depth = 0;
-    if (replay(c, lds_pos, expected(c, ops, c.n_ops - 1), mem_depth)) return 1;
+    if (!k20) {
+      const rdamd_operation_t &root = ops.back();
+      const unsigned kid[2] = {root.child1_clv_index, root.child2_clv_index};
+      for (int k = 0; k < 2; ++k)   // (a child folded into a pseudo-tip is no step of the program)
+        if (kid[k] >= n && c.is_inner(kid[k])) marked[k] = expected(c, ops, c.producer.at(kid[k]));
+    }
+    if (replay(c, lds_pos, expected(c, ops, c.n_ops - 1), mem_depth, k20 ? nullptr : marked)) return 1;
     if (mem_depth != (c.max_depth > c.reg_levels ? c.max_depth - c.reg_levels : 0)) return fail("in-memory depth", (int)mem_depth, (int)c.max_depth);
     if (c.reg_levels == 1 && !k20 && mem_depth + 1 > beyond) return fail("more in-memory entries than the kernel has places for");
     // steps: one per operation left in the program (+ one per park for 20 states)
