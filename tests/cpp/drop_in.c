@@ -63,6 +63,24 @@ int main(void) {
       }
   const double want = log(like);
   printf("lnL %.15f closed form %.15f\n", lnl, want);
+
+  /* The same evaluation as one job of the fused evaluator that leaves only the root's two children
+   * behind (rdamd_evaluate_root_children: what exhaustive_search needs between optimize_params
+   * and its root-only steps, src/model.cpp:1154-1229), then the root-only evaluation the
+   * reference's compute_lh_root makes on them (:415-446) at the same position. */
+  double lnl2 = 0.0, lnl3 = 0.0;
+  if (rdamd_evaluate_root_children(p, ops, 3, matrices, lengths, 6, rates, freqs, &one, &one, &lnl2) != RDAMD_SUCCESS) {
+    fprintf(stderr, "evaluate_root_children: %s\n", rdamd_errmsg());
+    return 3;
+  }
+  if (rdamd_root_loglikelihood_fused(p, &ops[2], params_indices, &lengths[4], &lengths[5], 1, &lnl3) != RDAMD_SUCCESS) {
+    fprintf(stderr, "root_loglikelihood_fused: %s\n", rdamd_errmsg());
+    return 3;
+  }
+  printf("root children %.15f root-only on them %.15f\n", lnl2, lnl3);
   rdamd_partition_destroy(p);
-  return fabs(lnl - want) <= 1e-12 * fabs(want) ? 0 : 1;
+  return fabs(lnl - want) <= 1e-12 * fabs(want) && fabs(lnl2 - want) <= 1e-12 * fabs(want) &&
+                 fabs(lnl3 - want) <= 1e-12 * fabs(want)
+             ? 0
+             : 1;
 }
