@@ -36,6 +36,7 @@ struct rdamd_schedule {
   unsigned lds_pos = 0, lds_pos_plain = 0;    // FusedJob::lds_pos of the two programs
   rdamd::CladeStep *d_steps = nullptr;
   rdamd::CladeGroup *d_groups = nullptr;
+  uint32_t *d_tipmask = nullptr;              // 20 states: bit m = P-matrix m belongs to a branch that ends in a tip
   unsigned n_steps = 0, n_groups = 0;
   unsigned tip_generation = 0;
   unsigned table_rows = 16;           // 16: 8-bit code arena, 16-row tables only; 64: 16-bit arena, 64-row tables too
@@ -59,6 +60,7 @@ struct FusedWorkspace {
   unsigned *d_any_unsafe = nullptr;   // inside d_in, behind the batch's inputs
   FusedJob *d_jobs = nullptr;   // ... and where this batch's pieces sit inside it
   double *d_q = nullptr, *d_rates = nullptr, *d_freqs = nullptr, *d_rw = nullptr;
+  double *d_qpow20 = nullptr;   // 20 states: the powers of every job's Q (kernels_fused_k20.hip)
   double *d_pmat = nullptr, *d_tiptab = nullptr, *d_partials = nullptr, *d_out = nullptr;
   double *d_clade_scratch = nullptr;   // nested clade tables of a launch: [job][step][rate][rows][4]
   size_t clade_scratch_doubles = 0;
@@ -81,7 +83,7 @@ struct FusedWorkspace {
 
 void fused_workspace_free(FusedWorkspace *w) {
   if (!w) return;
-  void *dev[] = {w->d_in, w->d_pmat, w->d_tiptab, w->d_partials, w->d_out, w->d_clade_scratch, w->d_export_cnt};
+  void *dev[] = {w->d_in, w->d_pmat, w->d_tiptab, w->d_partials, w->d_out, w->d_clade_scratch, w->d_export_cnt, w->d_qpow20};
   for (void *d : dev)
     if (d) (void)hipFree(d);
   if (w->h_out) (void)hipHostFree(w->h_out);
@@ -139,7 +141,7 @@ static hipError_t ensure_workspace(rdamd_partition *p, FusedWorkspace *&slot, un
   if (n_jobs <= w->cap_jobs) return hipSuccess;
   hipError_t e = sync_streams(p);
   if (e != hipSuccess) return e;
-  void *dev[] = {w->d_in, w->d_pmat, w->d_tiptab, w->d_partials, w->d_out, w->d_clade_scratch, w->d_export_cnt};
+  void *dev[] = {w->d_in, w->d_pmat, w->d_tiptab, w->d_partials, w->d_out, w->d_clade_scratch, w->d_export_cnt, w->d_qpow20};
   for (void *d : dev)
     if (d) (void)hipFree(d);
   if (w->h_out) (void)hipHostFree(w->h_out);
@@ -163,6 +165,7 @@ static hipError_t ensure_workspace(rdamd_partition *p, FusedWorkspace *&slot, un
   // (+ 8 bytes: the batch's any-unsafe word, zeroed by the same copy, FusedArgs::any_unsafe)
   A(w->d_in, (size_t)cap * (sizeof(FusedJob) + sizeof(double) * (K * K + K + 2 * R)) + 8);
   A(w->d_pmat, sizeof(double) * pm_per_job * cap);
+  if (K == 20) A(w->d_qpow20, sizeof(double) * fused20_qpow_doubles() * cap);
   w->tiptab_doubles = (K == 4 ? pm_per_job * 4 : (size_t)p->prob_matrices * R * kFused20TabDoubles) * cap;
   A(w->d_tiptab, sizeof(double) * (w->tiptab_doubles + kTiptabPad));
   A(w->d_partials, sizeof(double) * w->blocks_x * cap);
@@ -434,13 +437,21 @@ static rdamd_schedule_t *schedule_create_impl(rdamd_partition_t *p, const rdamd_
                  o_steps = up(o_plain + sizeof(FusedOp) * pp.size()),
                  o_groups = up(o_steps + sizeof(CladeStep) * steps.size()),
                  o_brlen = up(o_groups + sizeof(CladeGroup) * groups.size()),
-                 total = up(o_brlen + sizeof(double) * p->prob_matrices);
+                 o_tipmask = up(o_brlen + sizeof(double) * p->prob_matrices),
+                 total = up(o_tipmask + (k20 ? sizeof(uint32_t) * ((p->prob_matrices + 31) / 32) : 0));
     std::vector<char> host(total, 0);
     memcpy(host.data() + o_prog, pm.data(), sizeof(FusedOp) * pm.size());
     if (!pp.empty()) memcpy(host.data() + o_plain, pp.data(), sizeof(FusedOp) * pp.size());
     if (!steps.empty()) memcpy(host.data() + o_steps, steps.data(), sizeof(CladeStep) * steps.size());
     if (!groups.empty()) memcpy(host.data() + o_groups, groups.data(), sizeof(CladeGroup) * groups.size());
     memcpy(host.data() + o_brlen, brlen.data(), sizeof(double) * p->prob_matrices);
+    if (k20) {   // which branches end in a tip: only their tip tables are ever read (fused20_pmatrix_kernel)
+      uint32_t *mask = (uint32_t *)(host.data() + o_tipmask);
+      for (unsigned i = 0; i < n_ops; ++i) {
+        if (ops[i].child1_clv_index < p->tips) mask[ops[i].child1_matrix_index >> 5] |= 1u << (ops[i].child1_matrix_index & 31u);
+        if (ops[i].child2_clv_index < p->tips) mask[ops[i].child2_matrix_index >> 5] |= 1u << (ops[i].child2_matrix_index & 31u);
+      }
+    }
     s->d_block = schedule_block_alloc(p, total, &s->block_bytes);
     if (!s->d_block) {
       set_error(100 + (int)hipErrorOutOfMemory, "rdamd_schedule_create: no device memory for a %zu-byte schedule", total);
@@ -453,6 +464,7 @@ static rdamd_schedule_t *schedule_create_impl(rdamd_partition_t *p, const rdamd_
     s->d_steps = groups.empty() ? nullptr : (CladeStep *)(s->d_block + o_steps);
     s->d_groups = groups.empty() ? nullptr : (CladeGroup *)(s->d_block + o_groups);
     s->d_brlen = (double *)(s->d_block + o_brlen);
+    s->d_tipmask = k20 ? (uint32_t *)(s->d_block + o_tipmask) : nullptr;
   }
 #undef TRY
   return s;
@@ -609,6 +621,7 @@ static int batch_submit(rdamd_partition_t *p, FusedWorkspace *&slot, bool pipeli
     hj[j].prog = s->d_prog; hj[j].brlen = s->d_brlen; hj[j].n_ops = s->n_ops;
     hj[j].prog_plain = s->d_prog_plain; hj[j].n_ops_plain = s->n_ops_plain;
     hj[j].clade_steps = s->d_steps; hj[j].clade_groups = s->d_groups;
+    if (k20) hj[j].clade_steps = reinterpret_cast<const CladeStep *>(s->d_tipmask);   // (20 states: FusedJob::clade_steps carries the tip mask)
     hj[j].n_groups = s->n_groups; hj[j].n_clade_steps = s->n_steps;
     hj[j].depth = hj[j].depth_plain = 0;   // patched below: every block uses the launch-wide depth
     hj[j].tt_unsafe = export_children ? 1u : 0u;   // (set again by the P-matrix / clade-table steps of this batch;
@@ -692,7 +705,7 @@ static int batch_submit(rdamd_partition_t *p, FusedWorkspace *&slot, bool pipeli
     b.pmat_job_stride = (size_t)p->prob_matrices * R * K * K;
     b.sites = p->sites; b.rate_cats = R; b.tiles = w->blocks_x;
     if (!pipelined) p->prof_begin(4);
-    e = launch_fused20_pmatrix(b, w->d_q, w->d_rates, n_jobs, p->prob_matrices, pre);
+    e = launch_fused20_pmatrix(b, w->d_q, w->d_qpow20, w->d_rates, n_jobs, p->prob_matrices, pre);
     if (!pipelined) p->prof_end();
     RDAMD_HIP_TRY(e, RDAMD_FAILURE);
     if (pipelined) {

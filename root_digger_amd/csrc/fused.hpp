@@ -60,7 +60,8 @@ struct FusedJob {
   uint32_t lds_pos;
   // subtree site repeats (clades.hpp); without pseudo-tips prog_plain == prog, n_groups == 0
   const FusedOp    *prog_plain;
-  const CladeStep  *clade_steps;
+  const CladeStep  *clade_steps;     // (20-state jobs, which have no clades: a bitmap over the P-matrix indices, bit m
+                                     // set = matrix m belongs to a branch that ends in a tip and needs its tip table)
   const CladeGroup *clade_groups;
   uint32_t n_ops_plain, depth_plain, n_groups, n_clade_steps;
 };
@@ -125,7 +126,10 @@ constexpr unsigned kFusedSpillLevels = 7;
 constexpr unsigned kFused20TabCodes = 64;                        // rows per (matrix, rate)
 constexpr unsigned kFused20TabRow = 4 * 6;                       // doubles per code
 constexpr unsigned kFused20TabDoubles = kFused20TabCodes * kFused20TabRow;   // per (matrix, rate)
-hipError_t launch_fused20_pmatrix(const Fused20Args &a, const double *d_q, const double *d_rates,
+// d_qpow: n_jobs x fused20_qpow_doubles() doubles of scratch -- the powers Q^1 .. Q^16 of every job's Q
+// (and its 1-norm), made in front of the P-matrices they all share
+size_t fused20_qpow_doubles();
+hipError_t launch_fused20_pmatrix(const Fused20Args &a, const double *d_q, double *d_qpow, const double *d_rates,
                                   unsigned n_jobs, unsigned n_mat, hipStream_t stream);
 hipError_t launch_fused20_eval(const Fused20Args &a, unsigned n_jobs, unsigned max_depth,
                                double *d_out, hipStream_t stream);

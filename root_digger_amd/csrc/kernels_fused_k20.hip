@@ -75,22 +75,24 @@ __device__ __forceinline__ Step load_step(const_u32_ptr prog, unsigned i) {
 }  // namespace
 
 // ---- P-matrices of a batch, straight into the MFMA-ready layout ---------------
-// exp(Q t) by scaling and squaring around the same degree-16 Taylor polynomial
-// as pmatrix_generic_kernel (||A / 2^s||_1 <= 1/4), evaluated Paterson-
-// Stockmeyer style: X^2..X^4 (3 products), then Horner in X^4 over four cubic
-// blocks (3 products) -- 6 matrix products instead of 16.  The products are bound by LDS
-// bandwidth, so a thread owns a 4x4 tile of every 20x20 product: per inner step four 8-byte
-// reads of A (a row each, shared by the five threads of a tile row) and two 16-byte reads of
-// B feed 16 FMAs -- 4 bytes per FMA (round 2: 2x2 tiles, 8 bytes per FMA, 3.6 ms per c3
-// batch).  25 threads of a 32-lane half wave work on a (job, matrix, rate) problem, a
-// 128-thread workgroup holds four; a problem needs three matrices in LDS at any time
-// (X, X^2, X^4, then X^4 and two Horner / squaring buffers), its own tiles of X, X^2 and X^3
-// for the cubic blocks stay in registers.
+// exp(Q t) by scaling and squaring around the degree-16 Taylor polynomial of pmatrix_generic_kernel
+// (||Q t / 2^s||_1 <= 1/4).  All (matrix, rate) problems of a job share Q, so its powers
+// Q^1 .. Q^16 are made ONCE per job (fused20_qpowers_kernel, 15 products) and a problem's
+// polynomial is
+//     p = I + sum_k (tau^k / k!) Q^k,   tau = t / 2^s
+// -- 16 multiply-adds per element, the powers read from L2 (51 KB per job, read by its ~1 600
+// problems), no matrix product -- followed by the s squarings, which are the LDS-tiled 20x20
+// products of before: a thread owns a 4x4 tile of the product, per inner step four 8-byte reads
+// of A (a row each, shared by the five threads of a tile row) and two 16-byte reads of B feed 16
+// FMAs.  25 threads of a 32-lane half wave work on a (job, matrix, rate) problem, a 128-thread
+// workgroup holds four.  (Until round 4 every problem evaluated the polynomial itself,
+// Paterson-Stockmeyer style: 6 products + the squarings, 2.64 ms per c3 batch.)
 namespace {
 
 constexpr int kLd = 20;             // row stride in LDS (doubles).  Unpadded: the tile rows of A collide on banks (stride 22 avoids
-                                    // that), but 38.9 instead of 42.9 KB per workgroup is a fourth workgroup per CU: 2.65 against 2.82 ms
+                                    // that), but less LDS per workgroup is another workgroup per CU
 constexpr int kMatLds = kK * kLd;   // doubles per matrix in LDS
+constexpr unsigned kQPow20Stride = 16 * kK * kK + 8;   // doubles per job: Q^1 .. Q^16, ||Q||_1 at [6400]
 
 // c = A . B for this thread's 4x4 tile (rows 4 ti .., columns 4 tj ..)
 __device__ __forceinline__ void tile_product(const double *A, const double *B, unsigned ti, unsigned tj,
@@ -121,14 +123,65 @@ __device__ __forceinline__ void tile_store(double *C, unsigned ti, unsigned tj, 
 
 }  // namespace
 
+// The powers of every job's Q: 32 lanes (25 workers) per job, four jobs per workgroup;
+// Q^(k+1) = Q^k . Q through two LDS buffers, each power also written to qpow[job][k][i][j]
+// (row-major, unpadded); ||Q||_1 behind them.
 __global__ void __launch_bounds__(128)
-fused20_pmatrix_kernel(const double *__restrict__ q, const double *__restrict__ rates,
+fused20_qpowers_kernel(const double *__restrict__ q, unsigned n_jobs, double *__restrict__ qpow) {
+  __shared__ __attribute__((aligned(16))) double lds[4][3][kMatLds];
+  const unsigned sub = threadIdx.x >> 5, w = threadIdx.x & 31u;
+  const unsigned job_raw = blockIdx.x * 4 + sub;
+  const bool live = job_raw < n_jobs;
+  const unsigned job = live ? job_raw : n_jobs - 1;
+  const bool worker = w < 25;
+  const unsigned ti = worker ? w / 5 : 0, tj = worker ? w % 5 : 0;
+  double *Q = lds[sub][0], *A = lds[sub][1], *B = lds[sub][2];
+  const double *qq = q + (size_t)job * (kK * kK);
+  double *out = qpow + (size_t)job * kQPow20Stride;
+  for (unsigned e = w; e < (unsigned)(kK * kK); e += 32) {
+    const double v = qq[e];
+    Q[(e / kK) * kLd + e % kK] = v;
+    A[(e / kK) * kLd + e % kK] = v;
+    if (live) out[e] = v;
+  }
+  __syncthreads();
+  if (w == 0 && live) {   // ||Q||_1: the largest column sum of absolute values, columns in order
+    double norm = 0.0;
+    for (unsigned j = 0; j < (unsigned)kK; ++j) {
+      double cs = 0.0;
+      for (unsigned i = 0; i < (unsigned)kK; ++i) cs += fabs(Q[i * kLd + j]);
+      norm = fmax(norm, cs);
+    }
+    out[16 * kK * kK] = norm;
+  }
+  for (int k = 1; k < 16; ++k) {   // A = Q^k  ->  B = Q^(k+1)
+    double c[16];
+    if (worker) {
+      tile_product(A, Q, ti, tj, c);
+      tile_store(B, ti, tj, c);
+      if (live) {
+        double *o = out + (size_t)k * (kK * kK);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          double *row = o + (4 * ti + r) * kK + 4 * tj;
+          *reinterpret_cast<double2 *>(row) = make_double2(c[4 * r], c[4 * r + 1]);
+          *reinterpret_cast<double2 *>(row + 2) = make_double2(c[4 * r + 2], c[4 * r + 3]);
+        }
+      }
+    }
+    __syncthreads();
+    double *swap = A; A = B; B = swap;
+  }
+}
+
+__global__ void __launch_bounds__(128)
+fused20_pmatrix_kernel(const double *__restrict__ qpow, const double *__restrict__ rates,
                        const FusedJob *__restrict__ jobs, unsigned n_mat, unsigned R, unsigned total,
                        double *__restrict__ pmat, size_t pmat_job_stride,
                        double *__restrict__ tiptab, size_t tiptab_job_stride,
                        const uint64_t *__restrict__ codemask, unsigned ncodes) {
-  __shared__ __attribute__((aligned(16))) double lds[4][3][kMatLds];
-  __shared__ double red[4][kK];
+  __shared__ __attribute__((aligned(16))) double lds[4][2][kMatLds];
+  __shared__ __attribute__((aligned(16))) double stage_lds[2][kK * kK];   // the power in use / the next one
   __shared__ int sq[4];
   const unsigned sub = threadIdx.x >> 5, w = threadIdx.x & 31u;
   const unsigned prob = blockIdx.x * 4 + sub;
@@ -137,74 +190,89 @@ fused20_pmatrix_kernel(const double *__restrict__ q, const double *__restrict__ 
   const unsigned per_job = n_mat * R;
   const unsigned job = pr / per_job, rem = pr % per_job;
   const unsigned m = rem / R, r = rem % R;
-  double *M0 = lds[sub][0], *M1 = lds[sub][1], *M2 = lds[sub][2];
   const bool worker = w < 25;
   const unsigned ti = worker ? w / 5 : 0, tj = worker ? w % 5 : 0;
 
   const double t = jobs[job].brlen[m] * rates[(size_t)job * R + r];
-  const double *qq = q + (size_t)job * (kK * kK);
-  for (unsigned e = w; e < (unsigned)(kK * kK); e += 32) M0[(e / kK) * kLd + e % kK] = qq[e] * t;
-  __syncthreads();
-  if (w < (unsigned)kK) {
-    double cs = 0.0;
-    for (unsigned i = 0; i < (unsigned)kK; ++i) cs += fabs(M0[i * kLd + w]);
-    red[sub][w] = cs;
+  const double *__restrict__ qp = qpow + (size_t)job * kQPow20Stride;
+  // scaling: the smallest s with ||Q||_1 t / 2^s <= 1/4 (every lane works it out for itself)
+  int s_mine = 0;
+  double scale = 1.0;
+  {
+    const double norm = qp[16 * kK * kK] * t;
+    while (norm * scale > 0.25 && s_mine < 60) { scale *= 0.5; ++s_mine; }
   }
-  __syncthreads();
-  if (w == 0) {
-    double norm = 0.0;
-    for (unsigned j = 0; j < (unsigned)kK; ++j) norm = fmax(norm, red[sub][j]);
-    int s = 0;
-    double scale = 1.0;
-    while (norm * scale > 0.25 && s < 60) { scale *= 0.5; ++s; }
-    sq[sub] = s;
-    red[sub][0] = scale;
-  }
-  __syncthreads();
-  const int s_mine = sq[sub], s_max = max(max(sq[0], sq[1]), max(sq[2], sq[3]));
-  const double scale = red[sub][0];
-  for (unsigned e = w; e < (unsigned)(kK * kK); e += 32) M0[(e / kK) * kLd + e % kK] *= scale;
-  __syncthreads();
+  if (w == 0) sq[sub] = s_mine;
+  const double tau = t * scale;
   // 1/k!, k = 0..16
   constexpr double f[17] = {1.0, 1.0, 1.0 / 2, 1.0 / 6, 1.0 / 24, 1.0 / 120, 1.0 / 720, 1.0 / 5040,
                             1.0 / 40320, 1.0 / 362880, 1.0 / 3628800, 1.0 / 39916800, 1.0 / 479001600,
                             1.0 / 6227020800.0, 1.0 / 87178291200.0, 1.0 / 1307674368000.0,
                             1.0 / 20922789888000.0};
-  double x1[16], x2[16], x3[16], c[16];   // my tiles of X, X^2, X^3; the product in hand
+  double *H = lds[sub][0], *T = lds[sub][1];
+  double c[16];
 #pragma unroll
-  for (int e = 0; e < 16; ++e) x1[e] = M0[(4 * ti + (e >> 2)) * kLd + 4 * tj + (e & 3)];
-  if (worker) { tile_product(M0, M0, ti, tj, x2); tile_store(M1, ti, tj, x2); }   // X^2
-  __syncthreads();
-  if (worker) {
-    tile_product(M1, M0, ti, tj, x3);                                              // X^3 (registers only)
-    tile_product(M1, M1, ti, tj, c); tile_store(M2, ti, tj, c);                    // X^4
-  }
-  __syncthreads();   // (X and X^2 are not read again: M0 / M1 become the Horner buffers)
-  // block qb: B_qb = f[4qb] I + f[4qb+1] X + f[4qb+2] X^2 + f[4qb+3] X^3 ;
-  // p = B0 + X^4 (B1 + X^4 (B2 + X^4 (B3 + f16 X^4)))
-  auto block_plus = [&](int qb, const double (&acc)[16], double *dst) {   // dst tile = B_qb tile + acc
-    double o[16];
+  for (int e = 0; e < 16; ++e) c[e] = (4 * ti + (e >> 2) == 4 * tj + (e & 3)) ? 1.0 : 0.0;
+  // The polynomial, power by power.  The four problems of a workgroup belong to ONE job whenever
+  // n_mat R is a multiple of 4 (always with 4 rate categories): the workgroup then fetches each
+  // power once into LDS (double-buffered: power k + 1 is on its way while power k is used) and the
+  // four problems read it there -- a quarter of the L2 traffic, which is what bounds this loop
+  // (51 KB of powers per problem).  A workgroup that straddles two jobs reads them from L2 directly.
+  const unsigned first = blockIdx.x * 4, last = min(first + 3u, total - 1u);
+  const bool one_job = first / per_job == last / per_job;   // (workgroup-uniform)
+  double pw = 1.0;
+  if (one_job) {
+    double *stage = &stage_lds[0][0];
+    constexpr unsigned kPer = (kK * kK + 127) / 128;   // elements of a power per thread (4, the last one partly)
+    double nxt[kPer];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const unsigned i = 4 * ti + (e >> 2), j = 4 * tj + (e & 3);
-      o[e] = acc[e] + (i == j ? f[4 * qb] : 0.0) + f[4 * qb + 1] * x1[e] + f[4 * qb + 2] * x2[e] +
-             f[4 * qb + 3] * x3[e];
+    for (unsigned u = 0; u < kPer; ++u) {
+      const unsigned e = threadIdx.x + 128 * u;
+      nxt[u] = e < (unsigned)(kK * kK) ? qp[e] : 0.0;
     }
-    tile_store(dst, ti, tj, o);
-  };
-  double *H = M0, *T = M1;
-  if (worker) {   // H = B3 + f16 X^4
-    double acc[16];
+    for (int k = 1; k <= 16; ++k) {
+      double *buf = stage + (k & 1) * (kK * kK);
 #pragma unroll
-    for (int e = 0; e < 16; ++e) acc[e] = f[16] * c[e];
-    block_plus(3, acc, H);
+      for (unsigned u = 0; u < kPer; ++u) {
+        const unsigned e = threadIdx.x + 128 * u;
+        if (e < (unsigned)(kK * kK)) buf[e] = nxt[u];
+      }
+      __syncthreads();   // (also: everybody is done with the buffer that power k + 1 will go into)
+      if (k < 16) {
+#pragma unroll
+        for (unsigned u = 0; u < kPer; ++u) {
+          const unsigned e = threadIdx.x + 128 * u;
+          nxt[u] = e < (unsigned)(kK * kK) ? qp[(size_t)k * (kK * kK) + e] : 0.0;
+        }
+      }
+      pw *= tau;
+      const double ck = f[k] * pw;
+      const double *qk = buf + (4 * ti) * kK + 4 * tj;
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const double2 lo = *reinterpret_cast<const double2 *>(qk + rr * kK);
+        const double2 hi = *reinterpret_cast<const double2 *>(qk + rr * kK + 2);
+        c[4 * rr + 0] = fma(ck, lo.x, c[4 * rr + 0]); c[4 * rr + 1] = fma(ck, lo.y, c[4 * rr + 1]);
+        c[4 * rr + 2] = fma(ck, hi.x, c[4 * rr + 2]); c[4 * rr + 3] = fma(ck, hi.y, c[4 * rr + 3]);
+      }
+    }
+  } else if (worker) {
+    for (int k = 1; k <= 16; ++k) {
+      pw *= tau;
+      const double ck = f[k] * pw;
+      const double *__restrict__ qk = qp + (size_t)(k - 1) * (kK * kK) + (4 * ti) * kK + 4 * tj;
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const double2 lo = *reinterpret_cast<const double2 *>(qk + rr * kK);
+        const double2 hi = *reinterpret_cast<const double2 *>(qk + rr * kK + 2);
+        c[4 * rr + 0] = fma(ck, lo.x, c[4 * rr + 0]); c[4 * rr + 1] = fma(ck, lo.y, c[4 * rr + 1]);
+        c[4 * rr + 2] = fma(ck, hi.x, c[4 * rr + 2]); c[4 * rr + 3] = fma(ck, hi.y, c[4 * rr + 3]);
+      }
+    }
   }
+  if (worker) tile_store(H, ti, tj, c);
   __syncthreads();
-  for (int qb = 2; qb >= 0; --qb) {   // H <- B_qb + X^4 . H   (through T)
-    if (worker) { tile_product(M2, H, ti, tj, c); block_plus(qb, c, T); }
-    __syncthreads();
-    double *swap = H; H = T; T = swap;
-  }
+  const int s_max = max(max(sq[0], sq[1]), max(sq[2], sq[3]));
   for (int k = 0; k < s_max; ++k) {   // squarings
     if (worker && k < s_mine) { tile_product(H, H, ti, tj, c); tile_store(T, ti, tj, c); }
     __syncthreads();
@@ -224,17 +292,26 @@ fused20_pmatrix_kernel(const double *__restrict__ q, const double *__restrict__ 
   // sum over the states j of the code of P[4 s + g][j].  The four lanes of a site then
   // read 64 + 64 + 32 CONTIGUOUS bytes with three instructions (one cache line per site
   // and instruction instead of two).
+  // (only where the evaluator will look: a branch that ends in a tip -- half of them, and the table
+  // is four fifths of what this kernel writes)
+  const unsigned *tipmask = reinterpret_cast<const unsigned *>(jobs[job].clade_steps);
+  if (tipmask && !((tipmask[m >> 5] >> (m & 31u)) & 1u)) return;
   double *tt = tiptab + (size_t)job * tiptab_job_stride + ((size_t)m * R + r) * kFused20TabDoubles;
   for (unsigned e = w; e < ncodes * kFused20TabRow; e += 32) {
     const unsigned cc = e / kFused20TabRow, ww = e % kFused20TabRow;
     const unsigned g = ww < 16 ? (ww & 7u) >> 1 : ww - 16, sidx = ww < 16 ? 2 * (ww >> 3) + (ww & 1u) : 4;
     double acc = 0.0;
     if (ww < 20) {
-      const uint64_t mask = codemask[cc];
+      // (the states of the code in ascending order, as a loop over all twenty would add them --
+      // adding the zeros of the others changes nothing --: an unambiguous residue is ONE read
+      // instead of twenty, and most codes of real alignments are)
+      uint64_t mask = codemask[cc] & ((1ull << kK) - 1);
       const double *row = out + (4 * sidx + g) * kLd;
-      for (unsigned j = 0; j < (unsigned)kK; ++j) {
+      while (mask) {
+        const unsigned j = (unsigned)__builtin_ctzll(mask);
+        mask &= mask - 1;
         const double v = row[j] <= 0.0 ? 0.0 : row[j];
-        acc += ((mask >> j) & 1) ? v : 0.0;
+        acc += v;
       }
     }
     tt[e] = acc;
@@ -563,12 +640,15 @@ fused20_finish_kernel(const double *__restrict__ partials, unsigned per_job,
   if (threadIdx.x == 0) out[blockIdx.x] = ((lds[0] + lds[1]) + lds[2]) + lds[3];
 }
 
-hipError_t launch_fused20_pmatrix(const Fused20Args &a, const double *d_q, const double *d_rates,
+size_t fused20_qpow_doubles() { return kQPow20Stride; }
+
+hipError_t launch_fused20_pmatrix(const Fused20Args &a, const double *d_q, double *d_qpow, const double *d_rates,
                                   unsigned n_jobs, unsigned n_mat, hipStream_t stream) {
   const size_t total = (size_t)n_jobs * n_mat * a.rate_cats;
   if (!total) return hipSuccess;
+  fused20_qpowers_kernel<<<(n_jobs + 3) / 4, 128, 0, stream>>>(d_q, n_jobs, d_qpow);
   fused20_pmatrix_kernel<<<(unsigned)((total + 3) / 4), 128, 0, stream>>>(
-      d_q, d_rates, a.jobs, n_mat, a.rate_cats, (unsigned)total, const_cast<double *>(a.pmat), a.pmat_job_stride,
+      d_qpow, d_rates, a.jobs, n_mat, a.rate_cats, (unsigned)total, const_cast<double *>(a.pmat), a.pmat_job_stride,
       const_cast<double *>(a.tiptab), a.tiptab_job_stride, a.codemask, a.ncodes);
   return hipGetLastError();
 }
