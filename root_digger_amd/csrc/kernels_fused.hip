@@ -954,12 +954,17 @@ static hipError_t launch_fused_variant(const FusedArgs &a, unsigned n_jobs, unsi
                           (size_t)(SP > 0 || !max_depth ? 1 : max_depth) * NS * 64 * (4 * sizeof(double) + sizeof(int));
   // (RW: at least the room the rate terms need when they meet: R x NS x 64 x 12 bytes)
   const size_t lds = std::max<size_t>(per_wave * n_waves, (size_t)n_waves * NS * 64 * 12);
-  static size_t lds_allowed = 48 * 1024;
-  if (lds > lds_allowed) {   // deep stacks (very unbalanced 10^3-taxon trees), or R of them: raise the limit
-    hipError_t e = hipFuncSetAttribute((const void *)fused_dna_eval_kernel<NS, TTCHECK, RL, TR, RW, SP, EXPORT>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    lds_allowed = lds;
+  {   // deep stacks (very unbalanced 10^3-taxon trees), or R of them: raise the limit -- never lower it:
+      // partitions launch from their own host threads (the replicas of a lock-stepped search)
+    static std::mutex lds_mu;
+    static size_t lds_allowed = 48 * 1024;
+    std::lock_guard<std::mutex> guard(lds_mu);
+    if (lds > lds_allowed) {
+      hipError_t e = hipFuncSetAttribute((const void *)fused_dna_eval_kernel<NS, TTCHECK, RL, TR, RW, SP, EXPORT>,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return e;
+      lds_allowed = lds;
+    }
   }
   static const bool lds_starts_at_zero = [] {   // see the note at the top of the kernel
     hipFuncAttributes attr;

@@ -664,10 +664,17 @@ hipError_t launch_fused20_eval(const Fused20Args &a, unsigned n_jobs, unsigned m
                                double *d_out, hipStream_t stream) {
   if (!n_jobs) return hipSuccess;
   const size_t lds = fused20_lds_bytes(a.rate_cats, max_depth);
-  if (lds > 64 * 1024) {   // more than 64 KB of LDS per workgroup has to be asked for
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fused20_eval_kernel<kFused20Tiles>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
+  {   // more than 64 KB of LDS per workgroup has to be asked for -- raised, never lowered: partitions
+      // launch from their own host threads
+    static std::mutex lds_mu;
+    static size_t lds_allowed = 64 * 1024;
+    std::lock_guard<std::mutex> guard(lds_mu);
+    if (lds > lds_allowed) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fused20_eval_kernel<kFused20Tiles>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return e;
+      lds_allowed = lds;
+    }
   }
   const unsigned groups = (a.tiles + kFused20Tiles - 1) / kFused20Tiles;
   fused20_eval_kernel<kFused20Tiles><<<dim3(groups, n_jobs), 64 * a.rate_cats, lds, stream>>>(a, max_depth);
