@@ -973,8 +973,13 @@ double model_t::bfgs_params(model_params_t &initial, size_t pi, bfgs_target what
   };
 
   int task = 1 /* START */, csave = 0, iprint = -1, m_corr = 20;
-  double score = objective({initial})[0];
-  const double initial_score = score;
+  // The reference evaluates the starting point before it calls the optimiser (src/model.cpp:1447)
+  // and again as the value of its first FG request; f is deterministic and a job's value does not
+  // depend on its launch, so the second one IS the first: no launch of its own for it (a
+  // single-job launch per optimised block and round, a fifth of a lock-stepped search's launches)
+  // unless the optimiser moved the point before asking.
+  double score = 0.0, initial_score = 0.0;
+  bool have_initial = false;
   std::vector<double> gradient((size_t)n, 0.0);
   std::vector<double> wa((2 * (size_t)m_corr + 5) * (size_t)n + 12 * (size_t)m_corr * ((size_t)m_corr + 1), 0.0);
   std::vector<int> iwa(3 * (size_t)n, 0), bound_type((size_t)n, 2);
@@ -1006,6 +1011,10 @@ double model_t::bfgs_params(model_params_t &initial, size_t pi, bfgs_target what
       score = f[0];
       last_x = x;
       last_f = score;
+      if (!have_initial) {
+        initial_score = x == initial ? score : objective({initial})[0];
+        have_initial = true;
+      }
       for (int i = 0; i < n; ++i) gradient[i] = (f[i + 1] - score) / h[i];
     } else {
       // the reference re-evaluates after every return (src/model.cpp:1500-1503);
@@ -1015,6 +1024,7 @@ double model_t::bfgs_params(model_params_t &initial, size_t pi, bfgs_target what
     }
   }
   score = value_at(x);
+  if (!have_initial) initial_score = objective({initial})[0];   // (the optimiser never asked for a value)
   if (initial_score >= score) initial = x;   // improved (scores are -lnL)
   apply(initial);
   return score;
