@@ -787,7 +787,7 @@ def main():
                                                         (world % args.site_groups == 0 and world // args.site_groups > 1)):
                     result[key] = {"error": "not finished within %.0f s" % args.leg_timeout}
             emit()
-            os._exit(0)
+            os._exit(3)   # a hung leg is not a clean run: the partial line is out, the status says so
         watchdog = threading.Timer(args.leg_timeout, give_up)
         watchdog.daemon = True
         watchdog.start()

@@ -36,6 +36,13 @@ extern "C" {
 #define RDAMD_ATTRIB_ARCH_AVX2 (1u << 2)
 #define RDAMD_ATTRIB_SITE_REPEATS (1u << 10)
 #define RDAMD_ATTRIB_NONREV (1u << 11)
+/* New here (coraxlib has no such thing): the partition's CLV and scale buffers get device memory
+ * when a call first names them instead of at creation, and rdamd_partition_discard_clvs() returns
+ * it all.  Indices, results and every other call are unchanged.  For partitions of which only a
+ * few buffers are ever live -- the model replicas of a lock-stepped search keep the root's two
+ * children and nothing else (rdamd_evaluate_root_children): megabytes instead of the
+ * clv_buffers x sites x rates x states x 8 bytes of a dense partition. */
+#define RDAMD_ATTRIB_SPARSE_CLVS (1u << 20)
 
 #define RDAMD_GAMMA_RATES_MEAN 0   /* CORAX_GAMMA_RATES_MEAN   */
 #define RDAMD_GAMMA_RATES_MEDIAN 1 /* CORAX_GAMMA_RATES_MEDIAN */
@@ -81,6 +88,12 @@ rdamd_partition_t *rdamd_partition_create(unsigned int tips,
                                           unsigned int attributes);
 /* replaces corax_partition_destroy, src/model.cpp:180 */
 void rdamd_partition_destroy(rdamd_partition_t *p);
+/* RDAMD_ATTRIB_SPARSE_CLVS partitions: every CLV and scale buffer becomes undefined (scalers read
+ * as 0 again) and its device memory is free for the buffers named next.  Queued work of the
+ * partition is not disturbed.  A no-op on dense partitions (their buffers keep their contents). */
+void rdamd_partition_discard_clvs(rdamd_partition_t *p);
+/* device bytes the CLV and scale buffers of the partition hold right now */
+uint64_t rdamd_partition_clv_bytes(const rdamd_partition_t *p);
 
 /* replaces corax_set_tip_states, src/model.cpp:310.  `map` is a 256-entry
  * char -> state-bitmask table (rdamd_map_nt / rdamd_map_bin or the caller's).
@@ -128,7 +141,8 @@ void         *rdamd_partition_stream(const rdamd_partition_t *p);
  * objective partition -- long launches that fill every CU -- on LOW priority, so that the
  * short kernels beside it (the other group's P-matrices and clade tables, the candidates'
  * root-only steps) start when a slot frees up instead of when the launch ends.  The stream is
- * re-created: call it while nothing is queued on the partition (it waits for that). */
+ * re-created: call it while nothing is queued on the partition (it waits for that).  A handle
+ * rdamd_partition_stream() returned before the call is INVALID afterwards: ask again. */
 int           rdamd_partition_set_stream_priority(rdamd_partition_t *p, int level);
 const double *rdamd_partition_subst_params(const rdamd_partition_t *p,
                                            unsigned int params_index);
@@ -294,6 +308,30 @@ int rdamd_evaluate_batch_submit(rdamd_partition_t *p, unsigned int slot, unsigne
                                 const double *subst, const double *freqs,
                                 const double *rates, const double *rate_weights);
 int rdamd_evaluate_batch_wait(rdamd_partition_t *p, unsigned int slot, double *lnl_out);
+
+/* The STREAM-ORDERED form of a slot's batch, for callers that queue more work behind it on
+ * rdamd_partition_stream(p) -- the all-reduce of a site group's per-block lnLs, a
+ * copy -- without a host round trip in between.  _submit_device queues the batch like _submit;
+ * its finishing kernel writes the n_jobs results to DEVICE memory d_lnl_out[0 .. n_jobs) and,
+ * into d_lnl_out[n_jobs], 1.0 if some job of the batch needs the second evaluator pass (see
+ * rdamd_evaluate_batch_device) and 0.0 otherwise -- so a sum over the ranks of a site group
+ * carries the answer "did anybody's?" to all of them together with the sums.  d_lnl_out must
+ * hold n_jobs + 1 doubles.  Nothing is decided on the host in between: whatever the caller
+ * queues on the stream next runs right behind the batch.
+ *   flag (summed) == 0, the common case: the results are final; _finish_device releases the slot.
+ *   flag != 0: EVERY rank of the group calls _redo_device -- it runs the second pass where THIS
+ *   rank's batch asked for it, writes this rank's results to d_lnl_out[0 .. n_jobs) again (the
+ *   collective summed over the first copy in place) and 0.0 behind them, all in stream order --
+ *   and queues its collective again; then _finish_device.
+ * _finish_device waits for what _submit_device / _redo_device queued and frees the slot.
+ * Results are those of rdamd_evaluate_batch, bit for bit. */
+int rdamd_evaluate_batch_submit_device(rdamd_partition_t *p, unsigned int slot, unsigned int n_jobs,
+                                       const rdamd_schedule_t *const *schedules,
+                                       const double *subst, const double *freqs,
+                                       const double *rates, const double *rate_weights,
+                                       void *d_lnl_out);
+int rdamd_evaluate_batch_redo_device(rdamd_partition_t *p, unsigned int slot, void *d_lnl_out);
+int rdamd_evaluate_batch_finish_device(rdamd_partition_t *p, unsigned int slot);
 
 /* compute_lh for a caller that goes on with root-only steps (model_t::exhaustive_search between
  * optimize_params and optimize_alpha, src/model.cpp:1154-1229): ONE evaluation of the whole
@@ -518,6 +556,22 @@ void rdamd_model_lockstep_stats(const rdamd_model_t *m, uint64_t out[4]);
  * L-BFGS-B steps while the other group's batch runs); 1 = one group, blocking launches.
  * The records are the same either way (a job's value does not depend on its launch). */
 void rdamd_model_set_lockstep_groups(rdamd_model_t *m, unsigned int groups);
+/* How a lock-stepped search forms its launches.  In ARRIVAL ORDER (batch combiners: whoever has
+ * asked when the others are busy elsewhere goes), or in DETERMINISTIC ROUNDS: a round closes when
+ * every candidate in flight has posted its next request -- an L-BFGS-B step's evaluations, root
+ * positions of its branch, a value to be summed, or "next candidate" --, the requests run as one
+ * objective launch plus one root-only launch, and ONE collective sums everything the round
+ * produced over the site group (csrc/lockstep_conductor.hpp).  The ranks of a site group then
+ * form identical rounds, which is what lets a SITE-SHARDED model search in lock step at all.
+ * mode -1 (default): rounds for site-sharded models, arrival order otherwise; 0: arrival order
+ * (a site-sharded model refuses); 1: rounds always.  Records are the sequential search's either
+ * way.  Rounds take single-partition models. */
+void rdamd_model_set_lockstep_rounds(rdamd_model_t *m, int mode);
+/* the last search in rounds: out[0] rounds closed, [1] collectives queued (rounds that had
+ * anything to sum, plus repeats), [2] rounds repeated because a rank's batch needed its second
+ * evaluator pass; [3] (any search) collectives THIS model asked its reducer for by itself --
+ * the sequential site-sharded search's count, one per request */
+void rdamd_model_round_stats(const rdamd_model_t *m, uint64_t out[4]);
 /* stream priority (rdamd_partition_set_stream_priority) of the shared objective partition
  * during a lock-stepped search: +1 low (default), 0 leave it as it is */
 void rdamd_model_set_lockstep_priority(rdamd_model_t *m, int level);
@@ -694,10 +748,24 @@ extern const uint64_t rdamd_map_bin[256];
  *   producing launch was queued on: queue the collective on that stream
  *   (ncclAllReduce(values, values, n, ncclDouble, ncclSum, comm, stream)).
  * Return RDAMD_SUCCESS.  A site-sharded model runs its candidates sequentially
- * (the replica / lock-step searches would reorder the collectives). */
+ * (rdamd_model_exhaustive_search) or in lock step in deterministic rounds
+ * (rdamd_model_exhaustive_search_lockstep; every rank of the group with the same `in_flight`);
+ * free-running replicas (rdamd_model_exhaustive_search_parallel) would reorder the collectives. */
 typedef int (*rdamd_lnl_reducer_t)(double *values, unsigned int n, void *stream, void *user);
 int rdamd_model_set_lnl_reducer(rdamd_model_t *m, rdamd_lnl_reducer_t reduce, void *user,
                                 int on_device);
+/* A device-side reducer in TWO halves, for the lock-stepped search of a site-sharded model
+ * (rdamd_model_exhaustive_search_lockstep): `queue` only queues the collective on the stream it
+ * is given and returns; `wait(event, user)` blocks until the HIP event `event` -- recorded by the
+ * library on that stream, behind the collective and the copy that brings the sums back -- has
+ * happened, or fails.  While one group of candidates waits for its sums the other group's round
+ * is queued behind them.  The blocking form every other path uses is `queue` followed by a
+ * synchronisation of the stream.
+ * rdamd_model_set_lnl_reducer(m, rdamd_comm_reducer, comm, 1) installs rdamd_comm_reducer_queue /
+ * rdamd_comm_reducer_wait by itself. */
+typedef int (*rdamd_lnl_wait_t)(void *event, void *user);
+int rdamd_model_set_lnl_reducer_async(rdamd_model_t *m, rdamd_lnl_reducer_t queue, rdamd_lnl_wait_t wait,
+                                      void *user);
 /* rdamd_model_create_from_file_ratehet on block `block` of `n_blocks` contiguous
  * column blocks of the alignment (chunking of src/model.cpp:1899-1907 applied to
  * columns; the block is cut BEFORE pattern compression).  n_columns: optional,
@@ -729,6 +797,10 @@ rdamd_comm_t *rdamd_comm_create(const char id[128], int rank, int n_ranks);
 int           rdamd_comm_allreduce_sum(rdamd_comm_t *c, double *device_values, unsigned int n,
                                        void *stream);
 int           rdamd_comm_reducer(double *values, unsigned int n, void *stream, void *user);
+/* its two halves (rdamd_model_set_lnl_reducer_async): queue the all-reduce and return; wait for
+ * a HIP event recorded behind it, with rdamd_comm_reducer's failure handling */
+int           rdamd_comm_reducer_queue(double *values, unsigned int n, void *stream, void *user);
+int           rdamd_comm_reducer_wait(void *event, void *user);
 void          rdamd_comm_set_timeout(rdamd_comm_t *c, double seconds);
 void          rdamd_comm_abort(rdamd_comm_t *c);   /* any thread */
 void          rdamd_comm_destroy(rdamd_comm_t *c);
@@ -753,8 +825,9 @@ uint64_t    rdamd_partition_footprint(unsigned int tips, unsigned int clv_buffer
                                       unsigned int scale_buffers);
 /* Replicas rdamd_model_exhaustive_search_parallel / _lockstep may hold for this
  * model on the current device: `requested`, clamped so that the replicas'
- * partitions (each a full copy: all CLV and scaler buffers) fit in 85 % of the
- * device memory that is free now; at least 1.  replica_bytes (optional): what one
+ * partitions fit in 85 % of the device memory that is free now; at least 1.  A replica's
+ * 4-state / binary partitions are RDAMD_ATTRIB_SPARSE_CLVS ones while the searches'
+ * compute_lh is the children-only one (the default): three CLVs, not 2n - 3.  replica_bytes (optional): what one
  * replica takes.  The two searches apply this clamp themselves and say so on
  * stderr when it bites. */
 unsigned int rdamd_model_max_replicas(const rdamd_model_t *m, unsigned int requested,

@@ -26,10 +26,12 @@ from .api import (  # noqa: F401
     MAP_NT,
     MAP_BIN,
     compute_gamma_cats,
+    root_loglikelihood_fused_multi,
     GAMMA_RATES_MEAN,
     GAMMA_RATES_MEDIAN,
     ATTRIB_SITE_REPEATS,
     ATTRIB_NONREV,
+    ATTRIB_SPARSE_CLVS,
     device_count,
     hip_runtime_path,
     mapped_hip_runtimes,
@@ -42,7 +44,7 @@ __all__ = [
     "lib", "lib_path", "RdamdError", "Operation", "RootLocation", "Tree", "Partition", "Schedule", "Model", "Checkpoint", "Comm", "LNL_REDUCER", "parse_model_info", "parse_partition_info",
     "msa_partition_probe",
     "checkpoint_checksum_result", "checkpoint_checksum_params",
-    "MAP_NT", "MAP_BIN", "compute_gamma_cats", "GAMMA_RATES_MEAN", "GAMMA_RATES_MEDIAN",
-    "ATTRIB_SITE_REPEATS", "ATTRIB_NONREV",
+    "MAP_NT", "MAP_BIN", "compute_gamma_cats", "root_loglikelihood_fused_multi", "GAMMA_RATES_MEAN", "GAMMA_RATES_MEDIAN",
+    "ATTRIB_SITE_REPEATS", "ATTRIB_NONREV", "ATTRIB_SPARSE_CLVS",
     "device_count", "hip_runtime_path", "mapped_hip_runtimes", "set_device", "device_memory", "msa_probe",
 ]

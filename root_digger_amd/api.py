@@ -10,6 +10,7 @@ GAMMA_RATES_MEAN = 0
 GAMMA_RATES_MEDIAN = 1
 ATTRIB_SITE_REPEATS = 1 << 10   # RDAMD_ATTRIB_SITE_REPEATS (CORAX_ATTRIB_SITE_REPEATS, src/model.cpp:145-149)
 ATTRIB_NONREV = 1 << 11
+ATTRIB_SPARSE_CLVS = 1 << 20    # RDAMD_ATTRIB_SPARSE_CLVS: CLV / scale buffers get memory when first named
 SCALE_BUFFER_NONE = -1
 
 
@@ -89,6 +90,7 @@ _sig("rdamd_update_prob_matrices", C.c_int, _vp, _pu, _pu, _pd, _u)
 _sig("rdamd_update_clvs", None, _vp, _pop, _u)
 _sig("rdamd_compute_root_loglikelihood", C.c_double, _vp, _u, C.c_int, _pu, _pd)
 _sig("rdamd_root_loglikelihood_fused", C.c_int, _vp, _pop, _pu, _pd, _pd, _u, _pd)
+_sig("rdamd_root_loglikelihood_fused_multi", C.c_int, _u, C.POINTER(_vp), _pop, C.POINTER(_pu), _pd, _pd, _pu, _pd)
 _sig("rdamd_schedule_create", _vp, _vp, _pop, _u, _pu, _pd, _u)
 _sig("rdamd_schedule_destroy", None, _vp)
 _sig("rdamd_schedule_stack_depth", _u, _vp)
@@ -107,6 +109,11 @@ _sig("rdamd_evaluate_batch", C.c_int, _vp, _u, C.POINTER(_vp), _pd, _pd, _pd, _p
 _sig("rdamd_evaluate_batch_device", C.c_int, _vp, _u, C.POINTER(_vp), _pd, _pd, _pd, _pd, _vp)
 _sig("rdamd_evaluate_batch_submit", C.c_int, _vp, _u, _u, C.POINTER(_vp), _pd, _pd, _pd, _pd)
 _sig("rdamd_evaluate_batch_wait", C.c_int, _vp, _u, _pd)
+_sig("rdamd_evaluate_batch_submit_device", C.c_int, _vp, _u, _u, C.POINTER(_vp), _pd, _pd, _pd, _pd, _vp)
+_sig("rdamd_evaluate_batch_redo_device", C.c_int, _vp, _u, _vp)
+_sig("rdamd_evaluate_batch_finish_device", C.c_int, _vp, _u)
+_sig("rdamd_partition_discard_clvs", None, _vp)
+_sig("rdamd_partition_clv_bytes", C.c_uint64, _vp)
 _sig("rdamd_evaluate_root_children", C.c_int, _vp, _pop, _u, _pu, _pd, _u, _pd, _pd, _pd, _pd, _pd)
 _sig("rdamd_get_clv", C.c_int, _vp, _u, _pd)
 _sig("rdamd_get_scaler", C.c_int, _vp, _u, _pu)
@@ -232,6 +239,8 @@ _sig("rdamd_tree_generate_directional_operations", C.c_int, _vp, _pd, _pop, _pu,
 _sig("rdamd_model_counters", None, C.c_void_p, C.POINTER(C.c_uint64))
 _sig("rdamd_model_lockstep_stats", None, C.c_void_p, C.POINTER(C.c_uint64))
 _sig("rdamd_model_set_lockstep_groups", None, C.c_void_p, _u)
+_sig("rdamd_model_set_lockstep_rounds", None, C.c_void_p, C.c_int)
+_sig("rdamd_model_round_stats", None, C.c_void_p, C.POINTER(C.c_uint64))
 _sig("rdamd_model_set_lockstep_priority", None, C.c_void_p, C.c_int)
 _sig("rdamd_model_set_root_children_only", None, C.c_void_p, C.c_int)
 _sig("rdamd_partition_set_stream_priority", C.c_int, _vp, C.c_int)
@@ -332,6 +341,27 @@ def compute_gamma_cats(alpha, cats, mode=GAMMA_RATES_MEAN):
 
 def _dptr(a):
     return a.ctypes.data_as(_pd)
+
+
+def root_loglikelihood_fused_multi(parts, ops, lengths1, lengths2):
+    """rdamd_root_loglikelihood_fused_multi: item i = partition parts[i], root operation ops[i],
+    up to 8 positions with branch lengths lengths1[i] / lengths2[i]; -> list of lnL arrays."""
+    n = len(parts)
+    hs = (_vp * n)(*[p._h for p in parts])
+    cops = (Operation * n)(*ops)
+    pidx = (_pu * n)(*[_uptr(p.params_indices) for p in parts])
+    l1 = np.zeros((n, 8), dtype=np.float64)
+    l2 = np.zeros((n, 8), dtype=np.float64)
+    npos = np.zeros(n, dtype=np.uint32)
+    for i in range(n):
+        npos[i] = len(lengths1[i])
+        l1[i, :npos[i]] = lengths1[i]
+        l2[i, :npos[i]] = lengths2[i]
+    out = np.zeros((n, 8), dtype=np.float64)
+    if lib.rdamd_root_loglikelihood_fused_multi(n, hs, cops, pidx, _dptr(l1), _dptr(l2), _uptr(npos),
+                                                _dptr(out)) != 1:
+        _fail("root_loglikelihood_fused_multi")
+    return [out[i, :npos[i]].copy() for i in range(n)]
 
 
 def _uptr(a):
@@ -790,6 +820,36 @@ class Partition:
                                            _dptr(rw) if rw is not None else None) != 1:
             _fail("evaluate_batch_submit")
         return n
+
+    def evaluate_batch_submit_device(self, slot, schedules, subst, freqs, device_ptr, rates=None,
+                                     rate_weights=None):
+        """The stream-ordered form (rdamd_evaluate_batch_submit_device): results to device memory
+        at `device_ptr` (n + 1 float64: the lnLs, then the second-pass flag as 0.0 / 1.0),
+        written by the batch's finishing kernel; returns the number of jobs."""
+        n, hs, subst, freqs, rates, rw = self._batch_args(schedules, subst, freqs, rates,
+                                                          rate_weights)
+        if lib.rdamd_evaluate_batch_submit_device(self._h, slot, n, hs, _dptr(subst), _dptr(freqs),
+                                                  _dptr(rates) if rates is not None else None,
+                                                  _dptr(rw) if rw is not None else None,
+                                                  C.c_void_p(device_ptr)) != 1:
+            _fail("evaluate_batch_submit_device")
+        return n
+
+    def evaluate_batch_redo_device(self, slot, device_ptr):
+        if lib.rdamd_evaluate_batch_redo_device(self._h, slot, C.c_void_p(device_ptr)) != 1:
+            _fail("evaluate_batch_redo_device")
+
+    def evaluate_batch_finish_device(self, slot):
+        if lib.rdamd_evaluate_batch_finish_device(self._h, slot) != 1:
+            _fail("evaluate_batch_finish_device")
+
+    def discard_clvs(self):
+        """ATTRIB_SPARSE_CLVS partitions: every CLV / scale buffer gives its memory back."""
+        lib.rdamd_partition_discard_clvs(self._h)
+
+    def clv_bytes(self):
+        """device bytes the CLV and scale buffers hold right now"""
+        return int(lib.rdamd_partition_clv_bytes(self._h))
 
     def evaluate_batch_wait(self, slot, n):
         """Results of the batch last submitted on `slot`."""
@@ -1280,6 +1340,17 @@ class Model:
         """0: the library's choice (two pipelined groups from four candidates in flight on);
         1: one group, blocking launches (rdamd_model_set_lockstep_groups)."""
         lib.rdamd_model_set_lockstep_groups(self._h, groups)
+
+    def set_lockstep_rounds(self, mode):
+        """-1 (default): a site-sharded model's lock-stepped search runs in deterministic rounds,
+        others in arrival order; 0: arrival order; 1: rounds (rdamd_model_set_lockstep_rounds)."""
+        lib.rdamd_model_set_lockstep_rounds(self._h, mode)
+
+    def round_stats(self):
+        """the last search in rounds + this model's own collectives (rdamd_model_round_stats)."""
+        out = (C.c_uint64 * 4)()
+        lib.rdamd_model_round_stats(self._h, out)
+        return dict(zip(("rounds", "collectives", "redos", "own_collectives"), (int(v) for v in out)))
 
     def set_root_children_only(self, on):
         """the searches' compute_lh in front of the root-only steps: True (default) = one fused job

@@ -121,10 +121,12 @@ void abort_comm(rccl_api *a, rdamd_comm *c) {
 
 // Wait for everything queued on `stream` (the all-reduce last) without blocking in the
 // runtime: see the header comment.
-bool wait_for_collective(rccl_api *a, rdamd_comm *c, hipStream_t stream) {
+// (`event` not null: wait for that event instead of for the whole stream -- work queued on the
+// stream BEHIND the collective, the next round of a lock-stepped search, is not waited for)
+bool wait_for_collective(rccl_api *a, rdamd_comm *c, hipStream_t stream, hipEvent_t event = nullptr) {
   const auto t0 = std::chrono::steady_clock::now();
   for (unsigned spin = 0;; ++spin) {
-    const hipError_t q = hipStreamQuery(stream);
+    const hipError_t q = event ? hipEventQuery(event) : hipStreamQuery(stream);
     if (q == hipSuccess) return true;
     if (q != hipErrorNotReady) {
       rdamd::set_error(63, "site-group all-reduce: %s", hipGetErrorString(q));
@@ -213,6 +215,23 @@ int rdamd_comm_reducer(double *values, unsigned int n, void *stream, void *user)
   rccl_api *a = rccl();
   if (c->n_ranks <= 1 || !a) return RDAMD_SUCCESS;
   return wait_for_collective(a, c, (hipStream_t)stream) ? RDAMD_SUCCESS : RDAMD_FAILURE;
+}
+
+// the two halves on their own (rdamd_model_set_lnl_reducer_async): queue only ...
+int rdamd_comm_reducer_queue(double *values, unsigned int n, void *stream, void *user) {
+  return rdamd_comm_allreduce_sum((rdamd_comm_t *)user, values, n, stream);
+}
+// ... and wait for the HIP event recorded behind it, the way rdamd_comm_reducer waits
+int rdamd_comm_reducer_wait(void *event, void *user) {
+  rdamd_comm_t *c = (rdamd_comm_t *)user;
+  rccl_api *a = rccl();
+  if (!a || !c || !event) return RDAMD_FAILURE;
+  if (c->n_ranks <= 1) {
+    if (hipEventSynchronize((hipEvent_t)event) == hipSuccess) return RDAMD_SUCCESS;
+    rdamd::set_error(63, "site-group all-reduce: the stream failed");
+    return RDAMD_FAILURE;
+  }
+  return wait_for_collective(a, c, nullptr, (hipEvent_t)event) ? RDAMD_SUCCESS : RDAMD_FAILURE;
 }
 
 void rdamd_comm_set_timeout(rdamd_comm_t *c, double seconds) {

@@ -120,6 +120,13 @@ struct rdamd_partition {
     return mfma_layout ? (size_t)rate_cats * clv_tiles() * 16u * states : (size_t)sites * rate_cats * states;
   }
   unsigned *d_scaler = nullptr;
+  // RDAMD_ATTRIB_SPARSE_CLVS: d_clv / d_scaler are POOLS of slots; a caller's buffer index gets a
+  // slot when an entry point first names it (rdamd::op_phys and friends, partition.hip), and
+  // rdamd_partition_discard_clvs hands all slots back.  The kernels never know: they see slot
+  // numbers where a dense partition shows them the caller's indices.
+  bool      sparse = false;
+  std::vector<int> clv_slot, sc_slot;            // caller's index -> slot, or -1
+  unsigned  clv_slots_used = 0, clv_slots_cap = 0, sc_slots_used = 0, sc_slots_cap = 0;
   double   *d_pmat = nullptr;
   double   *d_tiptab = nullptr;
   double   *d_pmat_mfma = nullptr;   // 20-state only: MFMA-ready copy of d_pmat
@@ -197,6 +204,13 @@ inline hipError_t sync_streams(rdamd_partition *p) {
   if (e == hipSuccess && p->stream_pre) e = hipStreamSynchronize(p->stream_pre);
   return e;
 }
+
+// partition.hip: the device buffer behind a caller's CLV / scaler index.  Dense partitions: the
+// index itself; sparse ones (rdamd_partition::sparse): its pool slot, taken now if it has none
+// (the pool grows -- a device-wide wait -- when it is full).  hipErrorInvalidValue: out of range.
+hipError_t clv_phys(rdamd_partition *p, unsigned clv_index, unsigned *phys);
+hipError_t scaler_phys(rdamd_partition *p, int scaler_index, int *phys);
+hipError_t op_phys(rdamd_partition *p, const rdamd_operation_t &o, rdamd_operation_t *out);
 
 // kernels_pmatrix.hip
 // Rebuild Q for one rate matrix on the host into q[K*K].

@@ -77,6 +77,7 @@ struct FusedWorkspace {
     unsigned n_jobs = 0, ns = 1, max_depth[2] = {1, 1}, reg_levels[2] = {1, 1};
     FusedArgs a;
     double *d_out = nullptr;
+    double *mirror = nullptr;   // rdamd_evaluate_batch_submit_device: the caller's device copy, [n_jobs] + the flag
     uint64_t seq = 0;
   } pend;
 };
@@ -151,7 +152,9 @@ static hipError_t ensure_workspace(rdamd_partition *p, FusedWorkspace *&slot, un
     *w = FusedWorkspace();
     w->ev_ready = r; w->ev_done = d;
   }
-  const unsigned cap = std::max(16u, n_jobs + n_jobs / 2);
+  // (a model replica only ever runs one-job batches -- rdamd_evaluate_root_children -- and there
+  // may be 32 of them on a device: no 16-job floor)
+  const unsigned cap = std::max(2u, n_jobs + n_jobs / 2);
   const unsigned R = p->rate_cats, K = p->states;
   // 4 states: site blocks padded to a multiple of 16 (8 at two sites per lane) so that blockIdx.x % 8 (the
   // XCD a workgroup lands on) is the same for every job: each XCD's L2 then only
@@ -552,11 +555,11 @@ int rdamd_partition_set_site_repeats(rdamd_partition_t *p, unsigned int max_clas
 // (rdamd_evaluate_batch_submit): the part in front of the evaluator goes to stream_pre, so that
 // it runs beside the evaluator of the batch submitted before, and the evaluators follow each
 // other on the partition's stream (a stream is a FIFO: batches finish in submission order).
-static int batch_submit(rdamd_partition_t *p, FusedWorkspace *&slot, bool pipelined, unsigned int n_jobs,
-                        const rdamd_schedule_t *const *schedules,
-                        const double *subst, const double *freqs,
-                        const double *rates, const double *rate_weights,
-                        bool host_out, void *lnl_device, bool export_children = false) {
+static int batch_submit_impl(rdamd_partition_t *p, FusedWorkspace *&slot, bool pipelined, unsigned int n_jobs,
+                             const rdamd_schedule_t *const *schedules,
+                             const double *subst, const double *freqs,
+                             const double *rates, const double *rate_weights,
+                             bool host_out, void *lnl_device, bool export_children, double *mirror) {
   const bool k20 = p->states == 20 && p->rate_cats <= 4;
   if (p->states != 4 && !k20) {
     set_error(40, "rdamd_evaluate_batch: 4-state data, or 20-state data with up to 4 rate categories");
@@ -573,12 +576,15 @@ static int batch_submit(rdamd_partition_t *p, FusedWorkspace *&slot, bool pipeli
   w->pend = FusedWorkspace::Pending();
   w->pend.n_jobs = n_jobs; w->pend.k20 = k20; w->pend.host_out = host_out;
   w->pend.d_out = lnl_device ? (double *)lnl_device : w->d_out;
+  w->pend.mirror = mirror;
   if (n_jobs == 0 || p->sites == 0) {   // an empty alignment has likelihood 1
     w->pend.active = true;
     w->pend.n_jobs = p->sites == 0 ? n_jobs : 0;
     w->pend.seq = 0;
     if (p->sites == 0 && lnl_device && n_jobs)
       RDAMD_HIP_TRY(hipMemset(lnl_device, 0, sizeof(double) * n_jobs), RDAMD_FAILURE);
+    if (mirror)   // (zeros and a flag that is down, in stream order like a real batch's results)
+      RDAMD_HIP_TRY(hipMemsetAsync(mirror, 0, sizeof(double) * ((size_t)n_jobs + 1), p->stream), RDAMD_FAILURE);
     return RDAMD_SUCCESS;
   }
   hipStream_t pre = p->stream;
@@ -718,6 +724,10 @@ static int batch_submit(rdamd_partition_t *p, FusedWorkspace *&slot, bool pipeli
     RDAMD_HIP_TRY(e, RDAMD_FAILURE);
     if (host_out)
       RDAMD_HIP_TRY(hipMemcpyAsync(w->h_out, d_out, sizeof(double) * n_jobs, hipMemcpyDeviceToHost, p->stream), RDAMD_FAILURE);
+    if (mirror) {   // (20 states: no second pass, the flag stays down)
+      RDAMD_HIP_TRY(hipMemcpyAsync(mirror, d_out, sizeof(double) * n_jobs, hipMemcpyDeviceToDevice, p->stream), RDAMD_FAILURE);
+      RDAMD_HIP_TRY(hipMemsetAsync(mirror + n_jobs, 0, sizeof(double), p->stream), RDAMD_FAILURE);
+    }
   } else {
     FusedArgs a = {};
     const bool wide_codes = table_rows > 16;
@@ -766,17 +776,24 @@ static int batch_submit(rdamd_partition_t *p, FusedWorkspace *&slot, bool pipeli
         set_error(50, "rdamd_evaluate_root_children: one job of a 16-row schedule on the partition's stream");
         return RDAMD_FAILURE;
       }
+      unsigned phys_clv[2] = {0, 0};   // (sparse partitions: the children's pool slots, taken now -- both
+      int phys_sc[2] = {-1, -1};       // before any address is formed: a pool that grows moves)
       for (int k = 0; k < 2; ++k) {
         if (s0->root_child_clv[k] < p->tips) continue;   // a tip: nothing to leave behind
         if (s0->root_child_sc[k] < 0 || (unsigned)s0->root_child_sc[k] >= p->scale_buffers) {
           set_error(50, "rdamd_evaluate_root_children: child %d of the root operation needs a scale buffer", k + 1);
           return RDAMD_FAILURE;
         }
+        RDAMD_HIP_TRY(clv_phys(p, s0->root_child_clv[k], &phys_clv[k]), RDAMD_FAILURE);
+        RDAMD_HIP_TRY(scaler_phys(p, s0->root_child_sc[k], &phys_sc[k]), RDAMD_FAILURE);
+      }
+      for (int k = 0; k < 2; ++k) {
+        if (s0->root_child_clv[k] < p->tips) continue;
         if (!w->d_export_cnt)
           RDAMD_HIP_TRY(hipMalloc((void **)&w->d_export_cnt, sizeof(unsigned) * 2 * (size_t)p->sites * R), RDAMD_FAILURE);
-        a.export_clv[k] = p->d_clv + (size_t)(s0->root_child_clv[k] - p->tips) * p->clv_doubles();
+        a.export_clv[k] = p->d_clv + (size_t)(phys_clv[k] - p->tips) * p->clv_doubles();
         a.export_cnt[k] = w->d_export_cnt + (size_t)k * p->sites * R;
-        export_scaler[k] = p->d_scaler + (size_t)s0->root_child_sc[k] * p->sites;
+        export_scaler[k] = p->d_scaler + (size_t)phys_sc[k] * p->sites;
       }
       a.rates_across_waves = 0;
       a.job_major = 0;
@@ -810,7 +827,8 @@ static int batch_submit(rdamd_partition_t *p, FusedWorkspace *&slot, bool pipeli
                               host_out ? w->h_out : nullptr, p->stream);
     } else
     e = launch_fused_eval(a, n_jobs, max_depth, w->blocks_x, ns, reg_levels, false, d_out,
-                          host_out ? w->h_out : nullptr, h_flag, p->stream);
+                          mirror ? mirror : (host_out ? w->h_out : nullptr), h_flag, p->stream,
+                          mirror ? mirror + n_jobs : nullptr);
     p->prof_end();
     RDAMD_HIP_TRY(e, RDAMD_FAILURE);
     // The jobs whose tt_unsafe flag went up in this batch (a table entry in (0, 2^-128), a
@@ -828,6 +846,32 @@ static int batch_submit(rdamd_partition_t *p, FusedWorkspace *&slot, bool pipeli
   return RDAMD_SUCCESS;
 }
 
+// Everything queued on the partition up to now is waited for, then counted as finished (what was
+// submitted AFTER the count was taken is not: another thread's batch may have come in meanwhile).
+static void drain_after_failure(rdamd_partition_t *p, uint64_t at_least) {
+  uint64_t upto;
+  {
+    std::lock_guard<std::mutex> guard(p->launch_mu);
+    upto = std::max(p->batch_submitted, at_least);
+  }
+  (void)sync_streams(p);
+  uint64_t cur = p->batch_completed.load(std::memory_order_relaxed);
+  while (cur < upto && !p->batch_completed.compare_exchange_weak(cur, upto, std::memory_order_release)) {}
+}
+
+// A submit that fails half-way may have queued copies and kernels on the slot's workspace: nothing
+// may reuse it (or a schedule block those kernels read) before they have drained.
+static int batch_submit(rdamd_partition_t *p, FusedWorkspace *&slot, bool pipelined, unsigned int n_jobs,
+                        const rdamd_schedule_t *const *schedules,
+                        const double *subst, const double *freqs,
+                        const double *rates, const double *rate_weights,
+                        bool host_out, void *lnl_device, bool export_children = false, double *mirror = nullptr) {
+  const int rc = batch_submit_impl(p, slot, pipelined, n_jobs, schedules, subst, freqs, rates, rate_weights, host_out,
+                                   lnl_device, export_children, mirror);
+  if (rc != RDAMD_SUCCESS) drain_after_failure(p, 0);
+  return rc;
+}
+
 static int batch_wait(rdamd_partition_t *p, FusedWorkspace *w, bool pipelined, double *lnl_host) {
   if (!w || !w->pend.active) {
     set_error(49, "rdamd_evaluate_batch_wait: no batch was submitted on this slot");
@@ -842,26 +886,47 @@ static int batch_wait(rdamd_partition_t *p, FusedWorkspace *w, bool pipelined, d
     if (lnl_host && pd.host_out) std::fill(lnl_host, lnl_host + pd.n_jobs, 0.0);
     return RDAMD_SUCCESS;
   }
-  if (pipelined) RDAMD_HIP_TRY(hipEventSynchronize(w->ev_done), RDAMD_FAILURE);
-  else RDAMD_HIP_TRY(hipStreamSynchronize(p->stream), RDAMD_FAILURE);
   auto completed = [&] {   // (batches of one stream finish in submission order)
     uint64_t cur = p->batch_completed.load(std::memory_order_relaxed);
     while (cur < pd.seq && !p->batch_completed.compare_exchange_weak(cur, pd.seq, std::memory_order_release)) {}
   };
+  // A failed wait or second pass must not leave the sequence number behind (parked schedule
+  // blocks would wait for it for ever): drain the partition's streams, then everything queued
+  // so far HAS finished, one way or the other.
+  auto failed = [&] {
+    drain_after_failure(p, pd.seq);
+    return RDAMD_FAILURE;
+  };
+#define WAIT_TRY(expr) RDAMD_HIP_TRY(expr, failed())
+  if (pipelined) WAIT_TRY(hipEventSynchronize(w->ev_done));
+  else WAIT_TRY(hipStreamSynchronize(p->stream));
   const unsigned *h_flag = (const unsigned *)(w->h_out + w->cap_jobs);
   if (!pd.k20 && *h_flag) {
+    hipError_t e = hipSuccess;
     {
       std::lock_guard<std::mutex> guard(p->launch_mu);
-      p->prof_begin(3);
-      hipError_t e = launch_fused_eval(pd.a, pd.n_jobs, pd.max_depth, w->blocks_x, pd.ns, pd.reg_levels, true, pd.d_out,
-                                       pd.host_out ? w->h_out : nullptr, nullptr, p->stream);
-      p->prof_end();
-      RDAMD_HIP_TRY(e, RDAMD_FAILURE);
-      if (pipelined) RDAMD_HIP_TRY(hipEventRecord(w->ev_done, p->stream), RDAMD_FAILURE);
+      // Between submit and here another thread may have compiled a schedule that GREW the code
+      // arena (kernels_clade.hip, ensure_code_rows: new block, old one freed): the pointer the
+      // first pass was queued with may be gone.  The plain programs of this pass address tip rows
+      // only, which every generation of the arena holds at the same offsets.
+      const bool wide_codes = pd.a.table_rows > 16;
+      if (wide_codes) e = ensure_wide_arena(p);
+      pd.a.tipcodes = wide_codes ? p->d_codes_wide : p->d_tipcodes16;
+      pd.a.tipcodes_bytes = (unsigned)std::min<size_t>(wide_codes ? (size_t)p->wide_rows * p->tip_stride() * 2
+                                                                  : (size_t)p->code_rows * p->tip_stride(), 0xffffffffu);
+      if (e == hipSuccess) {
+        p->prof_begin(3);
+        e = launch_fused_eval(pd.a, pd.n_jobs, pd.max_depth, w->blocks_x, pd.ns, pd.reg_levels, true, pd.d_out,
+                              pd.host_out ? w->h_out : nullptr, nullptr, p->stream);
+        p->prof_end();
+      }
+      if (e == hipSuccess && pipelined) e = hipEventRecord(w->ev_done, p->stream);
     }
-    if (pipelined) RDAMD_HIP_TRY(hipEventSynchronize(w->ev_done), RDAMD_FAILURE);
-    else RDAMD_HIP_TRY(hipStreamSynchronize(p->stream), RDAMD_FAILURE);
+    WAIT_TRY(e);
+    if (pipelined) WAIT_TRY(hipEventSynchronize(w->ev_done));
+    else WAIT_TRY(hipStreamSynchronize(p->stream));
   }
+#undef WAIT_TRY
   completed();
   if (lnl_host && pd.host_out) memcpy(lnl_host, w->h_out, sizeof(double) * pd.n_jobs);
   return RDAMD_SUCCESS;
@@ -917,6 +982,76 @@ int rdamd_evaluate_batch_submit(rdamd_partition_t *p, unsigned int slot, unsigne
     return RDAMD_FAILURE;
   }
   return batch_submit(p, slot ? p->fused1 : p->fused, true, n_jobs, schedules, subst, freqs, rates, rate_weights, true, nullptr);
+}
+
+// ---- the stream-ordered form (include/root_digger_amd.h) ------------------------------------
+int rdamd_evaluate_batch_submit_device(rdamd_partition_t *p, unsigned int slot, unsigned int n_jobs,
+                                       const rdamd_schedule_t *const *schedules,
+                                       const double *subst, const double *freqs,
+                                       const double *rates, const double *rate_weights, void *d_lnl_out) {
+  clear_error();
+  if (slot > 1 || !d_lnl_out) {
+    set_error(49, "rdamd_evaluate_batch_submit_device: slot %u (0 or 1), device destination %p", slot, d_lnl_out);
+    return RDAMD_FAILURE;
+  }
+  return batch_submit(p, slot ? p->fused1 : p->fused, true, n_jobs, schedules, subst, freqs, rates, rate_weights, false,
+                      nullptr, false, (double *)d_lnl_out);
+}
+
+int rdamd_evaluate_batch_redo_device(rdamd_partition_t *p, unsigned int slot, void *d_lnl_out) {
+  clear_error();
+  FusedWorkspace *w = slot > 1 ? nullptr : (slot ? p->fused1 : p->fused);
+  if (!w || !w->pend.active || !w->pend.mirror || !d_lnl_out) {
+    set_error(49, "rdamd_evaluate_batch_redo_device: no device batch on slot %u", slot);
+    return RDAMD_FAILURE;
+  }
+  FusedWorkspace::Pending &pd = w->pend;
+  if (pd.seq == 0) {
+    RDAMD_HIP_TRY(hipMemsetAsync(d_lnl_out, 0, sizeof(double) * ((size_t)pd.n_jobs + 1), p->stream), RDAMD_FAILURE);
+    return RDAMD_SUCCESS;
+  }
+  // (the caller has seen the batch's summed flag: the batch itself is done, the pinned word is in)
+  RDAMD_HIP_TRY(hipEventSynchronize(w->ev_done), RDAMD_FAILURE);
+  const unsigned *h_flag = (const unsigned *)(w->h_out + w->cap_jobs);
+  std::lock_guard<std::mutex> guard(p->launch_mu);
+  if (!pd.k20 && *h_flag) {   // THIS rank's jobs need the pass (batch_wait has the notes)
+    const bool wide_codes = pd.a.table_rows > 16;
+    if (wide_codes) RDAMD_HIP_TRY(ensure_wide_arena(p), RDAMD_FAILURE);
+    pd.a.tipcodes = wide_codes ? p->d_codes_wide : p->d_tipcodes16;
+    pd.a.tipcodes_bytes = (unsigned)std::min<size_t>(wide_codes ? (size_t)p->wide_rows * p->tip_stride() * 2
+                                                                : (size_t)p->code_rows * p->tip_stride(), 0xffffffffu);
+    p->prof_begin(3);
+    hipError_t e = launch_fused_eval(pd.a, pd.n_jobs, pd.max_depth, w->blocks_x, pd.ns, pd.reg_levels, true, pd.d_out,
+                                     nullptr, nullptr, p->stream);
+    p->prof_end();
+    RDAMD_HIP_TRY(e, RDAMD_FAILURE);
+  }
+  // this rank's results again (a collective has summed over the first copy in place), flag down
+  RDAMD_HIP_TRY(hipMemcpyAsync(d_lnl_out, pd.d_out, sizeof(double) * pd.n_jobs, hipMemcpyDeviceToDevice, p->stream),
+                RDAMD_FAILURE);
+  RDAMD_HIP_TRY(hipMemsetAsync((double *)d_lnl_out + pd.n_jobs, 0, sizeof(double), p->stream), RDAMD_FAILURE);
+  RDAMD_HIP_TRY(hipEventRecord(w->ev_done, p->stream), RDAMD_FAILURE);
+  return RDAMD_SUCCESS;
+}
+
+int rdamd_evaluate_batch_finish_device(rdamd_partition_t *p, unsigned int slot) {
+  clear_error();
+  FusedWorkspace *w = slot > 1 ? nullptr : (slot ? p->fused1 : p->fused);
+  if (!w || !w->pend.active || !w->pend.mirror) {
+    set_error(49, "rdamd_evaluate_batch_finish_device: no device batch on slot %u", slot);
+    return RDAMD_FAILURE;
+  }
+  FusedWorkspace::Pending &pd = w->pend;
+  pd.active = false;
+  if (pd.seq == 0) return RDAMD_SUCCESS;
+  if (hipEventSynchronize(w->ev_done) != hipSuccess) {
+    set_error(100, "rdamd_evaluate_batch_finish_device: the batch did not complete");
+    drain_after_failure(p, pd.seq);
+    return RDAMD_FAILURE;
+  }
+  uint64_t cur = p->batch_completed.load(std::memory_order_relaxed);
+  while (cur < pd.seq && !p->batch_completed.compare_exchange_weak(cur, pd.seq, std::memory_order_release)) {}
+  return RDAMD_SUCCESS;
 }
 
 int rdamd_evaluate_batch_wait(rdamd_partition_t *p, unsigned int slot, double *lnl_out) {

@@ -142,11 +142,12 @@ hipError_t launch_fused_pmatrix(const FusedArgs &a, const double *d_q, const dou
 // tip-tip rescale test), true = the others (plain programs, with the test).  The caller runs
 // the second pass only when FusedArgs::any_unsafe came back set.
 // h_out / h_flag (pinned host memory, or null): the finishing kernel writes the results and the
-// batch's any-unsafe word there as well -- no copy launches behind the batch.
+// batch's any-unsafe word there as well -- no copy launches behind the batch.  flag_f64 (device
+// memory, or null): the word once more, as 0.0 / 1.0 (rdamd_evaluate_batch_submit_device).
 hipError_t launch_fused_eval(const FusedArgs &a, unsigned n_jobs, const unsigned max_depth[2],
                              unsigned blocks_x, unsigned sites_per_lane, const unsigned reg_levels[2],
                              bool unsafe_pass, double *d_out, double *h_out, unsigned *h_flag,
-                             hipStream_t stream);
+                             hipStream_t stream, double *flag_f64 = nullptr);
 // ONE job (its tt_unsafe word set by the caller: the plain program, every rescale test) through the
 // exporting variant: the evaluation as above, and the root operation's inner children left in
 // a.export_clv / d_scaler[] as a traversal with per-site scalers leaves them.  16-row schedules only.

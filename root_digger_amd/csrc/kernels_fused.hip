@@ -717,11 +717,16 @@ __global__ void __launch_bounds__(256)
 fused_finish_kernel(const double *__restrict__ partials, unsigned per_job,
                     const FusedJob *__restrict__ jobs, unsigned unsafe_pass,
                     double *__restrict__ out, double *__restrict__ host_out,
-                    const unsigned *__restrict__ any_unsafe, unsigned *__restrict__ host_flag) {
+                    const unsigned *__restrict__ any_unsafe, unsigned *__restrict__ host_flag,
+                    double *__restrict__ flag_f64) {
   __shared__ double lds[4];
   // (host_out / host_flag: pinned host memory, written from here -- the results and the word
-  // that says whether the second pass is needed arrive with the kernel's end, no copy launches)
+  // that says whether the second pass is needed arrive with the kernel's end, no copy launches.
+  // flag_f64: the same word as a double BEHIND a device-side copy of the results (host_out then
+  // points at device memory): a collective queued behind this kernel sums it with them, and the
+  // ranks of a site group learn together whether any of them needs the second pass)
   if (host_flag && blockIdx.x == 0 && threadIdx.x == 0) *host_flag = *any_unsafe;
+  if (flag_f64 && blockIdx.x == 0 && threadIdx.x == 0) *flag_f64 = *any_unsafe ? 1.0 : 0.0;
   if ((jobs[blockIdx.x].tt_unsafe != 0u) != (unsafe_pass != 0u)) return;
   const double *p = partials + (size_t)blockIdx.x * per_job;
   double acc = 0.0;
@@ -1016,24 +1021,26 @@ static hipError_t launch_fused_variant_rl(const FusedArgs &a, unsigned n_jobs, u
 template <int NS, int TR>
 static hipError_t launch_fused_eval_ns(const FusedArgs &a, unsigned n_jobs, const unsigned max_depth[2],
                                        unsigned blocks_x, const unsigned reg_levels[2], bool unsafe_pass,
-                                       double *d_out, double *h_out, unsigned *h_flag, hipStream_t stream) {
+                                       double *d_out, double *h_out, unsigned *h_flag, double *flag_f64,
+                                       hipStream_t stream) {
   const unsigned gx = (blocks_x + NS - 1) / NS;   // blocks_x counts 64-site blocks
   hipError_t e = unsafe_pass ? launch_fused_variant_rl<NS, true, TR>(a, n_jobs, max_depth[1], gx, reg_levels[1], stream)
                              : launch_fused_variant_rl<NS, false, TR>(a, n_jobs, max_depth[0], gx, reg_levels[0], stream);
   if (e != hipSuccess) return e;
-  fused_finish_kernel<<<n_jobs, 256, 0, stream>>>(a.partials, gx * NS, a.jobs, unsafe_pass ? 1u : 0u, d_out, h_out, a.any_unsafe, h_flag);   // 64-site blocks per job
+  fused_finish_kernel<<<n_jobs, 256, 0, stream>>>(a.partials, gx * NS, a.jobs, unsafe_pass ? 1u : 0u, d_out, h_out, a.any_unsafe, h_flag, flag_f64);   // 64-site blocks per job
   return hipGetLastError();
 }
 
 hipError_t launch_fused_eval(const FusedArgs &a, unsigned n_jobs, const unsigned max_depth[2],
                              unsigned blocks_x, unsigned sites_per_lane, const unsigned reg_levels[2],
-                             bool unsafe_pass, double *d_out, double *h_out, unsigned *h_flag, hipStream_t stream) {
+                             bool unsafe_pass, double *d_out, double *h_out, unsigned *h_flag, hipStream_t stream,
+                             double *flag_f64) {
   if (!n_jobs) return hipSuccess;
   if (a.table_rows > 16)   // 16-bit code arena, 64-row table slots
-    return sites_per_lane == 2 ? launch_fused_eval_ns<2, 64>(a, n_jobs, max_depth, blocks_x, reg_levels, unsafe_pass, d_out, h_out, h_flag, stream)
-                               : launch_fused_eval_ns<1, 64>(a, n_jobs, max_depth, blocks_x, reg_levels, unsafe_pass, d_out, h_out, h_flag, stream);
-  return sites_per_lane == 2 ? launch_fused_eval_ns<2, 16>(a, n_jobs, max_depth, blocks_x, reg_levels, unsafe_pass, d_out, h_out, h_flag, stream)
-                             : launch_fused_eval_ns<1, 16>(a, n_jobs, max_depth, blocks_x, reg_levels, unsafe_pass, d_out, h_out, h_flag, stream);
+    return sites_per_lane == 2 ? launch_fused_eval_ns<2, 64>(a, n_jobs, max_depth, blocks_x, reg_levels, unsafe_pass, d_out, h_out, h_flag, flag_f64, stream)
+                               : launch_fused_eval_ns<1, 64>(a, n_jobs, max_depth, blocks_x, reg_levels, unsafe_pass, d_out, h_out, h_flag, flag_f64, stream);
+  return sites_per_lane == 2 ? launch_fused_eval_ns<2, 16>(a, n_jobs, max_depth, blocks_x, reg_levels, unsafe_pass, d_out, h_out, h_flag, flag_f64, stream)
+                             : launch_fused_eval_ns<1, 16>(a, n_jobs, max_depth, blocks_x, reg_levels, unsafe_pass, d_out, h_out, h_flag, flag_f64, stream);
 }
 
 // One site per lane (a single job is a few hundred waves either way), all-LDS stack behind the

@@ -1,0 +1,410 @@
+// Lock step in DETERMINISTIC ROUNDS: the meeting point of the candidates a site-sharded model
+// has in flight (SURVEY.md 8e + 8(f)1; north star: "the outer root-edge loop batches lnL
+// evaluations so candidate edges and site blocks shard across the 8 GPUs ... with an RCCL
+// all-reduce of per-block log-likelihoods").
+//
+// The reference walks its candidate roots one after the other (src/model.cpp:1154-1229) and every
+// likelihood it looks at is one traversal.  The batch combiners of batch_combiner.hpp let the
+// candidates of ONE process meet in whatever launches their arrival order produces -- fine while
+// nobody else has to agree with that order.  The ranks of a site group do have to: each holds a
+// block of the alignment's columns, every value any optimiser sees is the SUM over the group,
+// and a collective only works if all ranks issue the same collectives in the same order.
+//
+// What makes that possible: the ranks of a group run the same candidates on the same reduced
+// values, so every candidate's SEQUENCE of requests is the same on every rank.  A round closes
+// when EVERY live candidate of a worker group has posted its next request, whatever it is --
+//   * the n + 1 evaluations of an L-BFGS-B step (src/model.cpp:1430-1522),
+//   * up to eight root positions of its branch (compute_lh_root / compute_dlh / Brent /
+//     optimize_alpha's scans, src/model.cpp:415-519, :606-794),
+//   * values it only needs summed (compute_lh's lnL, src/model.cpp:384-413),
+//   * or "my candidate is done, give me the next one" --
+// so its composition is a function of the data, not of thread timing.  The round then is: the
+// objective jobs of all candidates in worker order as ONE launch of the fused evaluator on the
+// shared partition, the root positions of all candidates as ONE root_multi launch beside it,
+// and ONE all-reduce over [objective lnLs | second-pass flag | root lnLs | plain values] queued
+// behind them on the shared partition's stream: one collective per round instead of one per
+// request (13 / 5 / 2-job batches and single Brent steps in the sequential loop).
+//
+// Two worker groups alternate STRICTLY (A0 B0 A1 B1 ...): while one group's round is on the
+// device and in the collective, the other group's hosts take their optimiser steps; the turn is
+// handed over when a round has been QUEUED, so the order of everything on the stream -- and of
+// the collectives -- is the same on every rank.  Candidates are handed out inside the rounds, in
+// worker order, from one counter: which worker runs which candidate is deterministic too.
+//
+// The evaluator's second pass (jobs whose tables make the per-site rescaling rule matter,
+// fused.hpp) is the one decision a batch used to take on the host.  Here the flag travels
+// through the all-reduce as one more summand (rdamd_evaluate_batch_submit_device): all ranks
+// learn together that some rank needs the pass, all redo the collective, in the same place of
+// the order (the redo waits for the group's turn).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <condition_variable>
+#include <cstring>
+#include <mutex>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/root_digger_amd.h"
+
+namespace rdamd {
+
+class conductor_t {
+public:
+  struct config_t {
+    rdamd_partition_t *shared = nullptr;   // the objective partition (the parent model's; not owned)
+    unsigned n_workers = 1, n_groups = 1;
+    size_t n_candidates = 0;
+    // the site group's sum (all null: a one-rank "group", nothing to sum)
+    rdamd_lnl_reducer_t reduce = nullptr;   // blocking form; host arrays unless `device`
+    bool device = false;
+    rdamd_lnl_reducer_t queue = nullptr;    // two halves of a device-side reducer (optional)
+    rdamd_lnl_wait_t wait = nullptr;
+    void *user = nullptr, *async_user = nullptr;   // of `reduce` / of `queue` and `wait`
+  };
+
+  explicit conductor_t(const config_t &c) : _c(c) {
+    if (!_c.shared || _c.n_workers < 1 || _c.n_groups < 1 || _c.n_groups > 2)
+      throw std::invalid_argument("conductor: a shared partition, >= 1 workers, 1 or 2 groups");
+    _c.n_groups = std::min(_c.n_groups, _c.n_workers);
+    for (unsigned w = 0; w < _c.n_workers; ++w) ++_g[w % _c.n_groups].live;
+  }
+  ~conductor_t() {
+    for (group_t &g : _g) {
+      if (g.d_vec) (void)hipFree(g.d_vec);
+      if (g.h_in) (void)hipHostFree(g.h_in);
+      if (g.h_res) (void)hipHostFree(g.h_res);
+      if (g.ev) (void)hipEventDestroy(g.ev);
+    }
+  }
+  conductor_t(const conductor_t &) = delete;
+  conductor_t &operator=(const conductor_t &) = delete;
+
+  rdamd_partition_t *shared() const { return _c.shared; }
+
+  // ---- what a worker (one candidate in flight, on its own model replica) may ask for ---------
+  // index of its next candidate, or -1: nothing left, the worker has left its group
+  long next_candidate(unsigned worker) {
+    request_t r;
+    r.kind = NEXT; r.worker = worker;
+    post(r);
+    return r.candidate;
+  }
+  // n jobs of one schedule of the shared partition (rdamd_evaluate_batch's blocks); out[j] =
+  // the lnL of job j summed over the site group
+  void objective(unsigned worker, unsigned n, const rdamd_schedule_t *sched, const double *subst,
+                 const double *freqs, const double *rates, const double *weights, double *out) {
+    request_t r;
+    r.kind = OBJECTIVE; r.worker = worker; r.n = n; r.sched = sched;
+    r.subst = subst; r.freqs = freqs; r.rates = rates; r.weights = weights; r.out = out;
+    post(r);
+  }
+  // n <= 8 positions of root operation `op` on the worker's own partitions; out[a] = the lnL of
+  // position a, summed over the partitions (in their order) and then over the site group
+  void root(unsigned worker, rdamd_partition_t *const *parts, const unsigned *const *params_idx,
+            unsigned n_parts, const rdamd_operation_t &op, const double *l1, const double *l2,
+            unsigned n, double *out) {
+    request_t r;
+    r.kind = ROOT; r.worker = worker; r.n = n; r.parts = parts; r.params_idx = params_idx;
+    r.n_parts = n_parts; r.op = op; r.out = out;
+    for (unsigned a = 0; a < n; ++a) { r.l1[a] = l1[a]; r.l2[a] = l2[a]; }
+    post(r);
+  }
+  // values[0 .. n) summed over the site group, in place
+  void reduce(unsigned worker, double *values, unsigned n) {
+    request_t r;
+    r.kind = REDUCE; r.worker = worker; r.n = n; r.out = values;
+    post(r);
+  }
+  // a worker that dies takes the search down: nobody may be left waiting for its request
+  void fail(const std::string &what) {
+    std::lock_guard<std::mutex> lk(_mu);
+    if (_error.empty()) _error = what.empty() ? "a candidate failed" : what;
+    _cv.notify_all();
+  }
+
+  // rounds closed, collectives queued, objective launches / their jobs, root launches / their steps
+  struct stats_t { uint64_t rounds = 0, collectives = 0, obj_launches = 0, obj_jobs = 0, root_launches = 0, root_steps = 0, redos = 0; };
+  stats_t stats() const {
+    std::lock_guard<std::mutex> lk(_mu);
+    return _stats;
+  }
+
+private:
+  enum kind_t { NEXT, OBJECTIVE, ROOT, REDUCE };
+  struct request_t {
+    kind_t kind = NEXT;
+    unsigned worker = 0, n = 0;
+    // objective
+    const rdamd_schedule_t *sched = nullptr;
+    const double *subst = nullptr, *freqs = nullptr, *rates = nullptr, *weights = nullptr;
+    // root
+    rdamd_partition_t *const *parts = nullptr;
+    const unsigned *const *params_idx = nullptr;
+    unsigned n_parts = 0;
+    rdamd_operation_t op{};
+    double l1[RDAMD_ROOT_MAX_POSITIONS] = {0}, l2[RDAMD_ROOT_MAX_POSITIONS] = {0};
+    double *out = nullptr;    // objective / root: results; reduce: the values, in place
+    long candidate = -1;      // next
+    bool done = false;
+  };
+  struct group_t {
+    unsigned live = 0;
+    bool busy = false;
+    std::vector<request_t *> posted;
+    // the round's vector: [objective lnLs | flag | root lnLs | plain values]
+    double *d_vec = nullptr, *h_in = nullptr, *h_res = nullptr;
+    size_t cap = 0;
+    hipEvent_t ev = nullptr;   // behind the round's collective and the copy of its sums
+  };
+
+  [[noreturn]] static void hip_fail(const char *what, hipError_t e) {
+    throw std::runtime_error(std::string("lock-step round: ") + what + ": " + hipGetErrorString(e));
+  }
+#define RDAMD_ROUND_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) hip_fail(#expr, e_); } while (0)
+
+  bool my_turn(unsigned g) const { return _c.n_groups == 1 || _turn == g || _g[g ^ 1u].live == 0; }
+  void pass_turn(unsigned g) {
+    if (_c.n_groups == 2 && _g[g ^ 1u].live > 0) _turn = g ^ 1u;
+    else _turn = g;
+  }
+
+  void post(request_t &req) {
+    const unsigned g = req.worker % _c.n_groups;
+    group_t &grp = _g[g];
+    std::unique_lock<std::mutex> lk(_mu);
+    if (!_error.empty()) throw std::runtime_error(_error);
+    grp.posted.push_back(&req);
+    _cv.notify_all();
+    for (;;) {
+      if (req.done) break;
+      if (!_error.empty()) throw std::runtime_error(_error);
+      if (!grp.busy && !grp.posted.empty() && grp.posted.size() == grp.live && my_turn(g)) {
+        // everybody of the group has asked and it is the group's turn: this thread runs the round
+        std::vector<request_t *> round;
+        round.swap(grp.posted);
+        grp.busy = true;
+        try {
+          run_round(g, round, lk);
+        } catch (const std::exception &e) {
+          if (!lk.owns_lock()) lk.lock();
+          if (_error.empty()) _error = e.what();
+        }
+        grp.busy = false;
+        for (request_t *r : round) r->done = true;
+        _cv.notify_all();
+        continue;
+      }
+      _cv.wait(lk);
+    }
+    if (!_error.empty() && req.kind != NEXT) throw std::runtime_error(_error);
+  }
+
+  void ensure_vec(group_t &grp, size_t n) {
+    if (n <= grp.cap) return;
+    RDAMD_ROUND_TRY(hipStreamSynchronize(_stream));
+    if (grp.d_vec) (void)hipFree(grp.d_vec);
+    if (grp.h_in) (void)hipHostFree(grp.h_in);
+    if (grp.h_res) (void)hipHostFree(grp.h_res);
+    grp.d_vec = grp.h_in = grp.h_res = nullptr;
+    grp.cap = std::max<size_t>(2 * n, 1024);
+    RDAMD_ROUND_TRY(hipMalloc((void **)&grp.d_vec, grp.cap * sizeof(double)));
+    RDAMD_ROUND_TRY(hipHostMalloc((void **)&grp.h_in, grp.cap * sizeof(double), hipHostMallocDefault));
+    RDAMD_ROUND_TRY(hipHostMalloc((void **)&grp.h_res, grp.cap * sizeof(double), hipHostMallocDefault));
+  }
+
+  // `lk` is held on entry and on return
+  void run_round(unsigned g, std::vector<request_t *> &round, std::unique_lock<std::mutex> &lk) {
+    group_t &grp = _g[g];
+    // (asked for every round: rdamd_partition_set_stream_priority re-creates the stream)
+    _stream = (hipStream_t)rdamd_partition_stream(_c.shared);
+    if (!grp.ev) RDAMD_ROUND_TRY(hipEventCreateWithFlags(&grp.ev, hipEventDisableTiming));
+    std::sort(round.begin(), round.end(), [](const request_t *a, const request_t *b) { return a->worker < b->worker; });
+    // ---- candidates, in worker order (under the lock: the counter is shared by the groups,
+    // and the turn makes the order of the groups' rounds the same everywhere)
+    std::vector<request_t *> obj, root, red;
+    for (request_t *r : round) {
+      switch (r->kind) {
+        case NEXT:
+          if (_next < _c.n_candidates) r->candidate = (long)_next++;
+          else { r->candidate = -1; --grp.live; }
+          break;
+        case OBJECTIVE: obj.push_back(r); break;
+        case ROOT: root.push_back(r); break;
+        case REDUCE: red.push_back(r); break;
+      }
+    }
+    ++_stats.rounds;
+    if (obj.empty() && root.empty() && red.empty()) {
+      pass_turn(g);
+      return;
+    }
+    lk.unlock();
+
+    // ---- the round's vector
+    size_t m = 0, n_root = 0, n_red = 0;
+    for (request_t *r : obj) m += r->n;
+    for (request_t *r : root) n_root += r->n;
+    for (request_t *r : red) n_red += r->n;
+    const size_t o_flag = m, o_root = m + 1, o_red = o_root + n_root, total = o_red + n_red;
+    ensure_vec(grp, total);
+    const bool two_phase = _c.device && _c.queue && _c.wait;
+    const bool device_path = !_c.reduce || _c.device;   // (no reducer at all: the device path without a collective)
+
+    // ---- the objective jobs: one launch on the shared partition
+    if (m) {
+      const unsigned R = rdamd_partition_rate_cats(_c.shared);
+      const unsigned K = rdamd_partition_states(_c.shared), NP = K * K - K;
+      std::vector<const rdamd_schedule_t *> scheds;
+      std::vector<double> subst, freqs, rates, weights;
+      scheds.reserve(m);
+      for (request_t *r : obj) {
+        scheds.insert(scheds.end(), r->n, r->sched);
+        subst.insert(subst.end(), r->subst, r->subst + (size_t)r->n * NP);
+        freqs.insert(freqs.end(), r->freqs, r->freqs + (size_t)r->n * K);
+        rates.insert(rates.end(), r->rates, r->rates + (size_t)r->n * R);
+        weights.insert(weights.end(), r->weights, r->weights + (size_t)r->n * R);
+      }
+      const int rc = device_path
+          ? rdamd_evaluate_batch_submit_device(_c.shared, g, (unsigned)m, scheds.data(), subst.data(), freqs.data(),
+                                               rates.data(), weights.data(), grp.d_vec)
+          : rdamd_evaluate_batch_submit(_c.shared, g, (unsigned)m, scheds.data(), subst.data(), freqs.data(),
+                                        rates.data(), weights.data());
+      if (rc != RDAMD_SUCCESS) throw std::runtime_error(std::string("lock-step round: objective batch: ") + rdamd_errmsg());
+    }
+    // ---- the root positions: one launch over the candidates' own partitions, beside it
+    if (!root.empty()) {
+      constexpr unsigned P = RDAMD_ROOT_MAX_POSITIONS;
+      std::vector<rdamd_partition_t *> parts;
+      std::vector<rdamd_operation_t> ops;
+      std::vector<const unsigned *> pidx;
+      std::vector<double> l1, l2;
+      std::vector<unsigned> npos;
+      for (request_t *r : root)
+        for (unsigned i = 0; i < r->n_parts; ++i) {
+          parts.push_back(r->parts[i]); ops.push_back(r->op); pidx.push_back(r->params_idx[i]);
+          npos.push_back(r->n);
+          l1.insert(l1.end(), r->l1, r->l1 + P);
+          l2.insert(l2.end(), r->l2, r->l2 + P);
+        }
+      std::vector<double> v(P * parts.size());
+      if (rdamd_root_loglikelihood_fused_multi((unsigned)parts.size(), parts.data(), ops.data(), pidx.data(), l1.data(),
+                                               l2.data(), npos.data(), v.data()) != RDAMD_SUCCESS)
+        throw std::runtime_error(std::string("lock-step round: root step: ") + rdamd_errmsg());
+      size_t item = 0, at = o_root;
+      for (request_t *r : root) {   // (a candidate's partitions summed in their order, as compute_lh_root does)
+        for (unsigned a = 0; a < r->n; ++a) grp.h_in[at + a] = 0.0;
+        for (unsigned i = 0; i < r->n_parts; ++i, ++item)
+          for (unsigned a = 0; a < r->n; ++a) grp.h_in[at + a] += v[P * item + a];
+        at += r->n;
+      }
+    }
+    {
+      size_t at = o_red;
+      for (request_t *r : red) {
+        std::copy(r->out, r->out + r->n, grp.h_in + at);
+        at += r->n;
+      }
+    }
+
+    // ---- the sum over the site group
+    double *res = grp.h_res;
+    bool need_redo_check = false;
+    if (device_path) {
+      if (!m) grp.h_in[o_flag] = 0.0;
+      // (host-made values go up behind the batch; the front of the vector is the batch's)
+      const size_t lo = m ? o_root : 0;
+      if (total > lo)
+        RDAMD_ROUND_TRY(hipMemcpyAsync(grp.d_vec + lo, grp.h_in + lo, (total - lo) * sizeof(double), hipMemcpyHostToDevice, _stream));
+      queue_sum(grp.d_vec, total, two_phase);
+      RDAMD_ROUND_TRY(hipMemcpyAsync(grp.h_res, grp.d_vec, total * sizeof(double), hipMemcpyDeviceToHost, _stream));
+      RDAMD_ROUND_TRY(hipEventRecord(grp.ev, _stream));
+      need_redo_check = m > 0;
+    } else {
+      // host reducer (ranks that share a device): the batch's own wait runs the second pass where
+      // this rank needs it -- its values are final before they are summed
+      if (m && rdamd_evaluate_batch_wait(_c.shared, g, grp.h_in) != RDAMD_SUCCESS)
+        throw std::runtime_error(std::string("lock-step round: objective batch: ") + rdamd_errmsg());
+      grp.h_in[o_flag] = 0.0;
+      if (_c.reduce(grp.h_in, (unsigned)total, nullptr, _c.user) != RDAMD_SUCCESS)
+        throw std::runtime_error(std::string("lock-step round: site-group reduction failed: ") + rdamd_errmsg());
+      res = grp.h_in;
+    }
+
+    // ---- queued: the other group may go
+    lk.lock();
+    ++_stats.collectives;
+    if (m) { ++_stats.obj_launches; _stats.obj_jobs += m; }
+    if (!root.empty()) { ++_stats.root_launches; _stats.root_steps += root.size(); }
+    pass_turn(g);
+    _cv.notify_all();
+    lk.unlock();
+
+    // ---- results
+    if (device_path) {
+      wait_round(grp, two_phase);
+      if (need_redo_check && grp.h_res[o_flag] != 0.0) {
+        // some rank's batch wants its second pass: every rank repeats the collective -- in the
+        // group's turn, so that it sits at the same place of the stream's order everywhere
+        lk.lock();
+        while (!my_turn(g) && _error.empty()) _cv.wait(lk);
+        if (!_error.empty()) throw std::runtime_error(_error);
+        ++_stats.redos; ++_stats.collectives;
+        lk.unlock();   // (the turn stays here: the other group passes it only when it has it)
+        if (rdamd_evaluate_batch_redo_device(_c.shared, g, grp.d_vec) != RDAMD_SUCCESS)
+          throw std::runtime_error(std::string("lock-step round: second pass: ") + rdamd_errmsg());
+        if (total > o_root)
+          RDAMD_ROUND_TRY(hipMemcpyAsync(grp.d_vec + o_root, grp.h_in + o_root, (total - o_root) * sizeof(double), hipMemcpyHostToDevice, _stream));
+        queue_sum(grp.d_vec, total, two_phase);
+        RDAMD_ROUND_TRY(hipMemcpyAsync(grp.h_res, grp.d_vec, total * sizeof(double), hipMemcpyDeviceToHost, _stream));
+        RDAMD_ROUND_TRY(hipEventRecord(grp.ev, _stream));
+        wait_round(grp, two_phase);
+      }
+      if (m && rdamd_evaluate_batch_finish_device(_c.shared, g) != RDAMD_SUCCESS)
+        throw std::runtime_error(std::string("lock-step round: objective batch: ") + rdamd_errmsg());
+    }
+    {
+      size_t at = 0;
+      for (request_t *r : obj) { std::copy(res + at, res + at + r->n, r->out); at += r->n; }
+      at = o_root;
+      for (request_t *r : root) { std::copy(res + at, res + at + r->n, r->out); at += r->n; }
+      at = o_red;
+      for (request_t *r : red) { std::copy(res + at, res + at + r->n, r->out); at += r->n; }
+    }
+    lk.lock();
+  }
+
+  // the site group's sum over d[0 .. n), queued on the shared partition's stream
+  void queue_sum(double *d, size_t n, bool two_phase) {
+    if (!_c.reduce && !_c.queue) return;   // a one-rank group
+    const int rc = two_phase ? _c.queue(d, (unsigned)n, (void *)_stream, _c.async_user)
+                             : _c.reduce(d, (unsigned)n, (void *)_stream, _c.user);
+    if (rc != RDAMD_SUCCESS)
+      throw std::runtime_error(std::string("lock-step round: site-group reduction failed: ") + rdamd_errmsg());
+  }
+  // (the round's event, not the stream: the other group's round may be queued behind this one)
+  void wait_round(group_t &grp, bool two_phase) {
+    if (two_phase) {
+      if (_c.wait((void *)grp.ev, _c.async_user) != RDAMD_SUCCESS)
+        throw std::runtime_error(std::string("lock-step round: site-group reduction failed: ") + rdamd_errmsg());
+    } else {
+      RDAMD_ROUND_TRY(hipEventSynchronize(grp.ev));
+    }
+  }
+#undef RDAMD_ROUND_TRY
+
+  config_t _c;
+  hipStream_t _stream = nullptr;
+  mutable std::mutex _mu;
+  std::condition_variable _cv;
+  group_t _g[2];
+  unsigned _turn = 0;
+  size_t _next = 0;
+  std::string _error;
+  stats_t _stats;
+};
+
+}  // namespace rdamd

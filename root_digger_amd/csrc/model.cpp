@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include "batch_combiner.hpp"
 #include "checkpoint.hpp"
+#include "lockstep_conductor.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -36,8 +37,8 @@ model_params_t random_params(size_t size, uint64_t seed) {
 // src/model.cpp:99-176
 model_t::model_t(rooted_tree_t tree, const std::vector<msa_t> &msas,
                  const std::vector<ratehet_opts_t> &rate_cats, bool invariant_sites,
-                 uint64_t seed, bool early_stop)
-    : _invariant_sites(invariant_sites), _early_stop(early_stop), _seed(seed) {
+                 uint64_t seed, bool early_stop, bool sparse_clvs)
+    : _invariant_sites(invariant_sites), _early_stop(early_stop), _sparse(sparse_clvs), _seed(seed) {
   _random_engine = std::minstd_rand((std::minstd_rand::result_type)_seed);
   _tree = std::move(tree);
   if (rate_cats.size() != msas.size())
@@ -61,6 +62,7 @@ model_t::model_t(rooted_tree_t tree, const std::vector<msa_t> &msas,
     const auto &msa = msas[p];
     unsigned int attributes = RDAMD_ATTRIB_NONREV;
     if (msa.states == 4) attributes |= RDAMD_ATTRIB_SITE_REPEATS;
+    if (_sparse && (msa.states == 4 || msa.states == 2)) attributes |= RDAMD_ATTRIB_SPARSE_CLVS;
     rdamd_partition_t *part = rdamd_partition_create(
         _tree.tip_count(), _tree.branch_count(), msa.states, (unsigned)msa.length(), 1,
         _tree.branch_count(), (unsigned)_rate_rates[p].size(), _tree.branch_count(), attributes);
@@ -99,7 +101,13 @@ double *model_t::reduce_scratch(size_t n) {
 
 // host values in, their sums over the site group out (identical on every rank)
 void model_t::reduce_values(double *values, size_t n) {
-  if (!_reduce || n == 0) return;
+  if (n == 0) return;
+  if (_conductor) {   // a candidate in flight: its sums travel with the round's collective
+    _conductor->reduce(_worker, values, (unsigned)n);
+    return;
+  }
+  if (!_reduce) return;
+  ++_n_collectives;
   if (!_reduce_device) {
     if (_reduce(values, (unsigned)n, nullptr, _reduce_user) != RDAMD_SUCCESS)
       throw std::runtime_error("site-group reduction failed");
@@ -179,12 +187,21 @@ void model_t::set_tip_states(size_t p, const msa_t &msa) {
       fail("failed to set tip " + std::to_string(i));
   }
   if (!msa.weights.empty()) rdamd_set_pattern_weights(_partitions[p], msa.weights.data());
+  if (p < _empirical.size()) _empirical[p].clear();   // (new data: new empirical frequencies)
 }
 
 void model_t::set_empirical_freqs(size_t p) {
-  double *f = rdamd_msa_empirical_frequencies(_partitions[p]);
   unsigned states = rdamd_partition_states(_partitions[p]);
-  if (_reduce) {   // one model for the whole alignment: blocks weighted by their columns
+  // They depend on the data alone: computed once (the reference recomputes them for every
+  // candidate, src/model.cpp:1157; the same numbers).  A site-sharded model's are sums over the
+  // group -- one collective per model instead of one per candidate, and none at all from the
+  // replicas of a lock-stepped search, which take them over (adopt_empirical_freqs).
+  if (p < _empirical.size() && _empirical[p].size() == states) {
+    rdamd_set_frequencies(_partitions[p], 0, _empirical[p].data());
+    return;
+  }
+  double *f = rdamd_msa_empirical_frequencies(_partitions[p]);
+  if (_reduce || _conductor) {   // one model for the whole alignment: blocks weighted by their columns
     const double w = rdamd_partition_weight_sum(_partitions[p]);
     std::vector<double> acc(states + 1);
     for (unsigned i = 0; i < states; ++i) acc[i] = f[i] * w;
@@ -199,6 +216,8 @@ void model_t::set_empirical_freqs(size_t p) {
                                "frequencies");
     }
   rdamd_set_frequencies(_partitions[p], 0, f);
+  if (_empirical.size() <= p) _empirical.resize(p + 1);
+  _empirical[p].assign(f, f + states);
   free(f);
 }
 
@@ -318,6 +337,9 @@ double model_t::compute_lh_for_root_steps(const root_location_t &root_location) 
     const unsigned st = rdamd_partition_states(part);
     if (st == 4 || st == 2) {
       double v = 0.0;
+      // (a replica's sparse partition: the children of the LAST root, and whatever else an earlier
+      // call named, give their memory back -- nothing reads them after this call)
+      if (_sparse) rdamd_partition_discard_clvs(part);
       if (rdamd_evaluate_root_children(part, ops.data(), (unsigned)ops.size(), pmi.data(), brl.data(),
                                        (unsigned)pmi.size(), rdamd_partition_subst_params(part, 0),
                                        rdamd_partition_frequencies(part, 0), _rate_rates[i].data(),
@@ -337,28 +359,39 @@ double model_t::compute_lh_for_root_steps(const root_location_t &root_location) 
   return reduce_value(lh);
 }
 
+void model_t::root_positions(const rdamd_operation_t &op, const double *l1, const double *l2, unsigned n,
+                             double *total) {
+  std::fill(total, total + n, 0.0);
+  constexpr size_t P = RDAMD_ROOT_MAX_POSITIONS;
+  if (_conductor || (_root_combiner && !_reduce)) {   // meets the other candidates' steps
+    std::vector<const unsigned *> pidx;
+    for (size_t i = 0; i < _partitions.size(); ++i) pidx.push_back(_param_indicies[i].data());
+    if (_conductor) {   // (summed over partitions and site group there)
+      _conductor->root(_worker, _partitions.data(), pidx.data(), (unsigned)_partitions.size(), op, l1, l2, n, total);
+      return;
+    }
+    std::vector<double> v(_partitions.size() * P);
+    _root_combiner->evaluate(_partitions.data(), pidx.data(), (unsigned)_partitions.size(), op, l1, l2, n, v.data());
+    for (size_t i = 0; i < _partitions.size(); ++i)   // (summed in partition order, as the plain loop does)
+      for (unsigned a = 0; a < n; ++a) total[a] += v[i * P + a];
+  } else {
+    double v[P];
+    for (size_t i = 0; i < _partitions.size(); ++i) {
+      if (rdamd_root_loglikelihood_fused(_partitions[i], &op, _param_indicies[i].data(), l1, l2, n, v) != RDAMD_SUCCESS)
+        fail("root-only evaluation");
+      for (unsigned a = 0; a < n; ++a) total[a] += v[a];
+    }
+  }
+  reduce_values(total, n);
+}
+
 double model_t::compute_lh_root(const root_location_t &root) {
   auto res = _tree.generate_derivative_operations(root);
   const rdamd_operation_t &op = std::get<0>(res);
   const auto &brl = std::get<2>(res);
   ++_n_root_positions;
   double lh = 0.0;
-  if (_root_combiner && !_reduce) {   // meets the other candidates' steps
-    std::vector<const unsigned *> pidx;
-    for (size_t i = 0; i < _partitions.size(); ++i) pidx.push_back(_param_indicies[i].data());
-    std::vector<double> v(_partitions.size() * RDAMD_ROOT_MAX_POSITIONS);
-    _root_combiner->evaluate(_partitions.data(), pidx.data(), (unsigned)_partitions.size(), op, &brl[0], &brl[1], 1,
-                             v.data());
-    for (size_t i = 0; i < _partitions.size(); ++i) lh += v[i * RDAMD_ROOT_MAX_POSITIONS];
-  } else
-  for (size_t i = 0; i < _partitions.size(); ++i) {
-    double v = 0.0;
-    if (rdamd_root_loglikelihood_fused(_partitions[i], &op, _param_indicies[i].data(), &brl[0],
-                                       &brl[1], 1, &v) != RDAMD_SUCCESS)
-      fail("compute_lh_root");
-    lh += v;
-  }
-  lh = reduce_value(lh);
+  root_positions(op, &brl[0], &brl[1], 1, &lh);
   if (std::isnan(lh)) throw std::runtime_error("lh at root is not a number: " + std::to_string(lh));
   return lh;
 }
@@ -379,30 +412,10 @@ std::vector<double> model_t::root_lh_at(const root_location_t &root, const std::
   auto res = _tree.generate_derivative_operations(at);   // (the last position)
   const rdamd_operation_t &op = std::get<0>(res);
   _n_root_positions += n;
-  const size_t chunk = RDAMD_ROOT_MAX_POSITIONS;
-  if (_root_combiner && !_reduce) {   // meets the other candidates' steps
-    size_t step = chunk;
-    for (auto part : _partitions) step = std::min(step, rdamd_partition_rate_cats(part) <= 4 ? chunk : chunk / 2);
-    std::vector<const unsigned *> pidx;
-    for (size_t i = 0; i < _partitions.size(); ++i) pidx.push_back(_param_indicies[i].data());
-    std::vector<double> v(_partitions.size() * chunk);
-    for (size_t lo = 0; lo < n; lo += step) {
-      const unsigned cnt = (unsigned)std::min(step, n - lo);
-      _root_combiner->evaluate(_partitions.data(), pidx.data(), (unsigned)_partitions.size(), op, &l1[lo], &l2[lo],
-                               cnt, v.data());
-      for (size_t i = 0; i < _partitions.size(); ++i)   // (summed in partition order, as the plain loop does)
-        for (unsigned a = 0; a < cnt; ++a) total[lo + a] += v[i * chunk + a];
-    }
-  } else {
-    std::vector<double> v(n);
-    for (size_t i = 0; i < _partitions.size(); ++i) {
-      if (rdamd_root_loglikelihood_fused(_partitions[i], &op, _param_indicies[i].data(), l1.data(), l2.data(),
-                                         (unsigned)n, v.data()) != RDAMD_SUCCESS)
-        fail("root_lh_at");
-      for (size_t a = 0; a < n; ++a) total[a] += v[a];
-    }
-  }
-  reduce_values(total.data(), n);
+  size_t step = RDAMD_ROOT_MAX_POSITIONS;   // (four at 8 rate categories)
+  for (auto part : _partitions) step = std::min<size_t>(step, rdamd_partition_rate_cats(part) <= 4 ? 8 : 4);
+  for (size_t lo = 0; lo < n; lo += step)
+    root_positions(op, &l1[lo], &l2[lo], (unsigned)std::min(step, n - lo), &total[lo]);
   return total;
 }
 
@@ -466,31 +479,9 @@ dlh_t model_t::compute_dlh(const root_location_t &root) {
   const double l1[2] = {root_prime.brlen(), root.brlen()};
   const double l2[2] = {root_prime.brlen_compliment(), root.brlen_compliment()};
   _n_root_positions += 2;
-  double fx = 0.0, fxh = 0.0;
-  if (_root_combiner && !_reduce) {
-    std::vector<const unsigned *> pidx;
-    for (size_t i = 0; i < _partitions.size(); ++i) pidx.push_back(_param_indicies[i].data());
-    std::vector<double> v(_partitions.size() * RDAMD_ROOT_MAX_POSITIONS);
-    _root_combiner->evaluate(_partitions.data(), pidx.data(), (unsigned)_partitions.size(), op, l1, l2, 2, v.data());
-    for (size_t i = 0; i < _partitions.size(); ++i) {
-      fxh += v[i * RDAMD_ROOT_MAX_POSITIONS];
-      fx += v[i * RDAMD_ROOT_MAX_POSITIONS + 1];
-    }
-  } else
-  for (size_t i = 0; i < _partitions.size(); ++i) {
-    double v[2];
-    if (rdamd_root_loglikelihood_fused(_partitions[i], &op, _param_indicies[i].data(), l1, l2, 2,
-                                       v) != RDAMD_SUCCESS)
-      fail("compute_dlh");
-    fxh += v[0];
-    fx += v[1];
-  }
-  if (_reduce) {
-    double both[2] = {fxh, fx};
-    reduce_values(both, 2);
-    fxh = both[0];
-    fx = both[1];
-  }
+  double both[2] = {0.0, 0.0};
+  root_positions(op, l1, l2, 2, both);
+  const double fxh = both[0], fx = both[1];
   if (std::isnan(fx))
     throw std::runtime_error("fx is not finite when computing derivative: " +
                              std::to_string(root.saved_brlen));
@@ -725,7 +716,8 @@ root_location_t model_t::optimize_alpha(const root_location_t &root, double atol
     dlh_positions(beg, pb, &sb);
     dlh_positions(end, pe, &se);
     const std::vector<double> lh = root_lh_at(root, {root.brlen_ratio, pb[0], pb[1], pe[0], pe[1]});
-    if (std::isnan(lh[0])) throw std::runtime_error("lh at root is not a number: " + std::to_string(lh[0]));
+    // (the reference's text for this check, src/model.cpp:681-684)
+    if (std::isnan(lh[0])) throw std::runtime_error("initial likelihood calculation is not finite");
     d_beg = dlh_from(lh[2], lh[1], sb, beg);
     d_end = dlh_from(lh[4], lh[3], se, end);
   }
@@ -942,10 +934,14 @@ double model_t::bfgs_params(model_params_t &initial, size_t pi, bfgs_target what
       std::copy(r.begin(), r.end(), rates.begin() + j * R);
       std::copy(_rate_weights[pi].begin(), _rate_weights[pi].end(), weights.begin() + j * R);
     }
-    if (combiner) {   // meets the other candidates' requests in one launch
+    if (_conductor) {   // meets the other candidates' requests in the round's launch; summed over the group
+      _conductor->objective(_worker, (unsigned)m, sched, subst.data(), freqs.data(), rates.data(), weights.data(),
+                            out.data());
+    } else if (combiner) {   // meets the other candidates' requests in one launch
       combiner->evaluate((unsigned)m, sched, subst.data(), freqs.data(), rates.data(),
                           weights.data(), out.data());
     } else if (_reduce && _reduce_device) {
+      ++_n_collectives;
       // site-sharded: the per-block lnLs stay on the device, the all-reduce is queued
       // behind the batch on the partition's stream, one copy brings the sums back
       double *d = reduce_scratch(m);
@@ -1039,8 +1035,10 @@ void model_t::optimize_params(std::vector<partition_parameters_t> &params,
   if (!_combiners.empty() && _combiners.size() != _partitions.size())
     throw std::runtime_error("optimize_params: one batch combiner per partition is required");
   if (!_combiners.empty() && _reduce)
-    throw std::runtime_error("optimize_params: a site-sharded model runs its candidates "
-                             "sequentially (no batch combiner)");
+    throw std::runtime_error("optimize_params: the candidates of a site-sharded model meet in rounds "
+                             "(lockstep_conductor.hpp), not in batch combiners");
+  if (_conductor && _partitions.size() != 1)
+    throw std::runtime_error("optimize_params: lock step in rounds takes single-partition models");
   for (size_t i = 0; i < _partitions.size(); ++i) {
     // The batched objective runs on the fused evaluators: 4-state and binary data, and 20
     // states with up to four rate categories (the 381 finite-difference evaluations of a
@@ -1061,6 +1059,9 @@ void model_t::optimize_params(std::vector<partition_parameters_t> &params,
       else rdamd_schedule_destroy(s);
     };
     rdamd_schedule_t *sched =
+        _conductor ? rdamd_schedule_create(_conductor->shared(), std::get<0>(sc).data(), (unsigned)std::get<0>(sc).size(),
+                                           std::get<1>(sc).data(), std::get<2>(sc).data(),
+                                           (unsigned)std::get<1>(sc).size()) :
         combiner ? combiner->schedule_create(std::get<0>(sc).data(), (unsigned)std::get<0>(sc).size(),
                                              std::get<1>(sc).data(), std::get<2>(sc).data(),
                                              (unsigned)std::get<1>(sc).size())

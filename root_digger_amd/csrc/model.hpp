@@ -31,6 +31,7 @@ namespace rdamd {
 class checkpoint_t;
 class batch_combiner_t;
 class root_combiner_t;
+class conductor_t;
 
 typedef std::vector<double> model_params_t;
 
@@ -97,9 +98,12 @@ model_params_t random_params(size_t size, uint64_t seed);   // src/model.cpp:87-
 
 class model_t {
 public:
+  // sparse_clvs: 4-state / binary partitions are created with RDAMD_ATTRIB_SPARSE_CLVS -- the
+  // replicas of a lock-stepped search, which only ever hold the root's two children
+  // (compute_lh_for_root_steps discards everything else before it writes them)
   model_t(rooted_tree_t t, const std::vector<msa_t> &msa,
           const std::vector<ratehet_opts_t> &rate_cats, bool invariant_sites,
-          uint64_t seed, bool early_stop);
+          uint64_t seed, bool early_stop, bool sparse_clvs = false);
   ~model_t();
   model_t(const model_t &) = delete;
   model_t &operator=(const model_t &) = delete;
@@ -182,8 +186,28 @@ public:
   // rdamd_lnl_reducer_t).  device = true: fn takes device memory + the stream.
   void set_lnl_reducer(rdamd_lnl_reducer_t fn, void *user, bool device) {
     _reduce = fn; _reduce_user = user; _reduce_device = device;
+    _reduce_queue = nullptr; _reduce_wait = nullptr;
+    _empirical.clear();
+  }
+  // the same reducer in two halves (include/root_digger_amd.h, rdamd_model_set_lnl_reducer_async):
+  // what the lock-stepped search of a site-sharded model queues behind its rounds
+  void set_lnl_reducer_async(rdamd_lnl_reducer_t queue, rdamd_lnl_wait_t wait, void *user) {
+    _reduce_queue = queue; _reduce_wait = wait; _reduce_async_user = user;
   }
   bool site_sharded() const { return _reduce != nullptr; }
+  struct reducer_t { rdamd_lnl_reducer_t reduce, queue; rdamd_lnl_wait_t wait; void *user, *async_user; bool device; };
+  reducer_t reducer() const { return {_reduce, _reduce_queue, _reduce_wait, _reduce_user, _reduce_async_user, _reduce_device}; }
+  // Lock step in deterministic rounds (lockstep_conductor.hpp): this model is the replica one
+  // candidate in flight runs on; its objective batches, its root-only steps and every value it
+  // needs summed over the site group go through the conductor as worker `worker`.  Not owned.
+  void set_conductor(conductor_t *c, unsigned worker) { _conductor = c; _worker = worker; }
+  // empirical frequencies a replica takes over from the model it was made from (they depend on
+  // the data only; for a site-sharded model they are SUMS over the group, which a replica --
+  // running on a thread of its own -- must not ask for by itself)
+  void adopt_empirical_freqs(const model_t &other) { _empirical = other._empirical; }
+  // collectives this model has asked its reducer for (a sequential site-sharded search: one per
+  // request; the lock-stepped one counts in the conductor)
+  uint64_t collectives() const { return _n_collectives; }
   // src/model.cpp:1925-1984
   void optimize_params(std::vector<partition_parameters_t> &params, const root_location_t &rl,
                        double pgtol, double factor, bool optimize_gamma);
@@ -258,9 +282,14 @@ private:
   double reduce_value(double v) { reduce_values(&v, 1); return v; }
   double *reduce_scratch(size_t n);                 // device buffer of >= n doubles
 
-  rdamd_lnl_reducer_t                    _reduce = nullptr;
-  void                                  *_reduce_user = nullptr;
+  rdamd_lnl_reducer_t                    _reduce = nullptr, _reduce_queue = nullptr;
+  rdamd_lnl_wait_t                       _reduce_wait = nullptr;
+  void                                  *_reduce_user = nullptr, *_reduce_async_user = nullptr;
   bool                                   _reduce_device = false;
+  conductor_t                           *_conductor = nullptr;
+  unsigned                               _worker = 0;
+  std::vector<model_params_t>            _empirical;           // [partition]: empirical frequencies, once computed
+  uint64_t                               _n_collectives = 0;
   double                                *_d_reduce = nullptr;
   size_t                                 _d_reduce_cap = 0;
   double                                *_h_reduce = nullptr;   // pinned twin of _d_reduce
@@ -280,6 +309,7 @@ private:
   root_combiner_t                       *_root_combiner = nullptr;
   bool                                   _invariant_sites, _early_stop;   // +I is inert (:292-300)
   bool                                   _children_only = true;           // compute_lh_for_root_steps
+  bool                                   _sparse = false;                 // RDAMD_ATTRIB_SPARSE_CLVS partitions
   uint64_t                               _seed;
   param_optimizer_t                      _optimizer;
   setulb_fn                              _setulb = nullptr;
@@ -287,6 +317,10 @@ private:
   uint64_t _n_full = 0, _n_root_positions = 0, _n_move_root = 0, _n_lbfgsb_iters = 0;
 
   enum class bfgs_target { rates, freqs, gamma };
+  // lnL at up to RDAMD_ROOT_MAX_POSITIONS positions of the root operation, all partitions, summed
+  // over the site group: one launch (or one request to the combiner / conductor it meets the
+  // other candidates' steps in)
+  void root_positions(const rdamd_operation_t &op, const double *l1, const double *l2, unsigned n, double *total);
   double bfgs_params(model_params_t &initial, size_t partition, bfgs_target what,
                      rdamd_schedule_t *sched, batch_combiner_t *combiner, double p_min, double p_max,
                      double epsilon, double pgtol, double factor);

@@ -12,6 +12,7 @@
 #include "common.hpp"
 #include "batch_combiner.hpp"
 #include "checkpoint.hpp"
+#include "lockstep_conductor.hpp"
 #include "model.hpp"
 #include "partition_info.hpp"
 #include "tree_c_api.hpp"
@@ -41,6 +42,10 @@ struct rdamd_model {
   bool children_only = true;      // rdamd_model_set_root_children_only
   unsigned lockstep_groups = 0;   // 0: the library's choice; 1: one group, blocking launches (rdamd_model_set_lockstep_groups)
   uint64_t lockstep_stats[4] = {0, 0, 0, 0};   // of the last lock-stepped search (rdamd_model_lockstep_stats)
+  uint64_t round_stats[3] = {0, 0, 0};         // ... in rounds: rounds, collectives, second-pass redos
+  struct async_reducer_t { rdamd_lnl_reducer_t queue; void *user; };   // rdamd_model_set_lnl_reducer_async
+  std::unique_ptr<async_reducer_t> async_reducer;
+  int lockstep_rounds = -1;       // -1: rounds for site-sharded models only; 0 never; 1 always (rdamd_model_set_lockstep_rounds)
   ~rdamd_model() { delete model; }
 };
 
@@ -176,6 +181,25 @@ int rdamd_model_set_lnl_reducer(rdamd_model_t *m, rdamd_lnl_reducer_t reduce, vo
                                 int on_device) {
   GUARD(RDAMD_FAILURE, {
     m->model->set_lnl_reducer(reduce, user, on_device != 0);
+    // the ready-made RCCL reducer comes with its two halves
+    if (reduce == rdamd_comm_reducer && on_device)
+      m->model->set_lnl_reducer_async(rdamd_comm_reducer_queue, rdamd_comm_reducer_wait, user);
+    return RDAMD_SUCCESS;
+  })
+}
+// the blocking form of a two-halves reducer: queue, then wait for the stream
+static int blocking_from_async(double *values, unsigned int n, void *stream, void *user) {
+  auto *a = (rdamd_model::async_reducer_t *)user;
+  if (a->queue(values, n, stream, a->user) != RDAMD_SUCCESS) return RDAMD_FAILURE;
+  return hipStreamSynchronize((hipStream_t)stream) == hipSuccess ? RDAMD_SUCCESS : RDAMD_FAILURE;
+}
+int rdamd_model_set_lnl_reducer_async(rdamd_model_t *m, rdamd_lnl_reducer_t queue, rdamd_lnl_wait_t wait,
+                                      void *user) {
+  GUARD(RDAMD_FAILURE, {
+    if (!queue || !wait) throw std::invalid_argument("set_lnl_reducer_async: both halves are required");
+    m->async_reducer.reset(new rdamd_model::async_reducer_t{queue, user});
+    m->model->set_lnl_reducer(blocking_from_async, m->async_reducer.get(), true);
+    m->model->set_lnl_reducer_async(queue, wait, user);
     return RDAMD_SUCCESS;
   })
 }
@@ -404,21 +428,154 @@ void rdamd_model_set_lbfgsb(rdamd_model_t *m, void *fn) {
 // threads, each with its own model replica (own partition, own HIP stream),
 // pulling candidates from a shared counter -- their small launches (13-job
 // L-BFGS-B batches, root-only Brent steps) overlap on the device.
+// replicas keep only what the root-only steps read when the searches' compute_lh is the
+// children-only one (rdamd_model_set_root_children_only, the default)
+static bool replicas_are_sparse(const rdamd_model_t *m) { return m->children_only; }
+
 unsigned int rdamd_model_max_replicas(const rdamd_model_t *m, unsigned int requested,
                                       uint64_t *replica_bytes) {
   const unsigned tips = m->model->tree().tip_count(), branches = m->model->tree().branch_count();
   uint64_t per_replica = 0;
   const auto ratehets = m->all_ratehets();
   const auto msas = m->all_msas();
-  for (size_t i = 0; i < msas.size(); ++i)
-    per_replica += rdamd_partition_footprint(tips, branches, msas[i].states, (unsigned)msas[i].length(),
-                                             branches, (unsigned)ratehets[std::min(i, ratehets.size() - 1)].rate_cats,
-                                             branches);
+  for (size_t i = 0; i < msas.size(); ++i) {
+    // a replica's 4-state / binary partitions hold the root's two children and the root CLV, not
+    // all 2n - 3 buffers (RDAMD_ATTRIB_SPARSE_CLVS; their pools start at four slots) -- plus the
+    // evaluator's workspace for the one job that writes them
+    const bool sparse = replicas_are_sparse(m) && (msas[i].states == 4 || msas[i].states == 2);
+    const unsigned R = (unsigned)ratehets[std::min(i, ratehets.size() - 1)].rate_cats;
+    per_replica += rdamd_partition_footprint(tips, sparse ? 4u : branches, msas[i].states, (unsigned)msas[i].length(),
+                                             branches, R, sparse ? 4u : branches);
+    if (sparse) per_replica += (uint64_t)branches * R * (16 + 64) * 8 * 2 + (uint64_t)msas[i].length() * R * 8 + ((uint64_t)2 << 20);
+  }
   if (replica_bytes) *replica_bytes = per_replica;
   uint64_t free_b = 0, total_b = 0;
   if (rdamd_device_memory(&free_b, &total_b) != RDAMD_SUCCESS || per_replica == 0) return requested ? requested : 1;
   const uint64_t fit = (uint64_t)(0.85 * (double)free_b) / per_replica;
   return (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(requested, fit));
+}
+
+// The shared objective partition(s) on LOW stream priority for the duration of a lock-stepped
+// search: their launches fill every CU for a millisecond, and the kernels beside them (front
+// halves of the other group's batch, the replicas' root-only steps and traversals) get the wave
+// slots that become free instead of waiting for the launch to end.  Normal priority again when
+// the search is over, however it ends (the stream is re-created: rdamd_partition_stream handles
+// taken before are invalid, as the header says).
+struct shared_priority_t {
+  rdamd_model_t *m;
+  bool active;
+  shared_priority_t(rdamd_model_t *m_, bool lockstep) : m(m_), active(lockstep && m_->lockstep_priority != 0) {
+    for (size_t pi = 0; active && pi < m->model->partition_count(); ++pi)
+      if (rdamd_partition_set_stream_priority(m->model->partition(pi), m->lockstep_priority) != RDAMD_SUCCESS)
+        throw std::runtime_error(std::string("set_stream_priority: ") + rdamd_errmsg());
+  }
+  ~shared_priority_t() {
+    for (size_t pi = 0; active && pi < m->model->partition_count(); ++pi)
+      (void)rdamd_partition_set_stream_priority(m->model->partition(pi), 0);
+  }
+};
+
+// Lock step in deterministic rounds (lockstep_conductor.hpp): what a site-sharded model's
+// lock-stepped search is -- every rank of the site group runs this with the same candidates and
+// forms the same rounds, one collective each.  Worker w is a host thread with a model replica
+// (sparse: the root's children only); the objective partition is m's own.
+static int search_in_rounds(rdamd_model_t *m, unsigned int workers, double atol, double pgtol, double brtol,
+                            double factor, uint64_t *root_id, double *llh, double *alpha,
+                            unsigned int *n_results, rdamd_root_location_t *best_rl, double *best_llh) {
+  GUARD(RDAMD_FAILURE, {
+    if (m->model->partition_count() != 1)
+      throw std::runtime_error("lock step in rounds takes single-partition models");
+    const std::vector<size_t> todo = m->model->assigned_indicies();
+    if (workers < 1) workers = 1;
+    workers = (unsigned)std::min<size_t>(workers, std::max<size_t>(todo.size(), 1));
+    {
+      uint64_t bytes = 0;
+      const unsigned fit = rdamd_model_max_replicas(m, workers, &bytes);
+      if (fit < workers) {
+        // (every rank of a site group must run the same number: the blocks have the same shape
+        // up to one column, the devices the same memory -- say so loudly)
+        std::fprintf(stderr, "rdamd: %u replicas of %.2f GB each do not fit the free device memory; "
+                             "running %u (all ranks of a site group must agree on this number)\n",
+                     workers, (double)bytes / 1e9, fit);
+        workers = fit;
+      }
+    }
+    shared_priority_t shared_priority(m, true);
+    rdamd::conductor_t::config_t cfg;
+    cfg.shared = m->model->partition(0);
+    cfg.n_workers = workers;
+    cfg.n_groups = workers >= 4 && m->lockstep_groups != 1 ? 2u : 1u;
+    cfg.n_candidates = todo.size();
+    const auto red = m->model->reducer();
+    cfg.reduce = red.reduce; cfg.device = red.device; cfg.queue = red.queue; cfg.wait = red.wait;
+    cfg.user = red.user; cfg.async_user = red.async_user;
+    rdamd::conductor_t conductor(cfg);
+    int device = 0;
+    if (hipGetDevice(&device) != hipSuccess) throw std::runtime_error("no HIP device");
+    std::mutex mu;
+    std::vector<rdamd::rd_result_t> results;
+    std::string first_error;
+    auto work = [&](unsigned wid) {
+      try {
+        if (hipSetDevice(device) != hipSuccess) throw std::runtime_error("hipSetDevice failed");
+        const auto msas = m->all_msas();
+        const bool sparse = replicas_are_sparse(m);
+        rdamd::model_t replica(m->model->tree(), msas, m->all_ratehets(), false, m->seed + wid, m->early_stop, sparse);
+        // (no collective of its own: the group's frequencies come from the parent, every other
+        // sum goes through the rounds)
+        replica.adopt_empirical_freqs(*m->model);
+        replica.initialize_partitions(msas);
+        if (m->setulb) replica.set_lbfgsb(reinterpret_cast<rdamd::model_t::setulb_fn>(m->setulb));
+        replica.set_checkpoint(m->checkpoint);
+        replica.set_progress(m->progress.get());
+        replica.set_root_children_only(m->children_only);
+        if (m->lockstep_priority)
+          for (size_t pi = 0; pi < replica.partition_count(); ++pi)
+            if (rdamd_partition_set_stream_priority(replica.partition(pi), -1) != RDAMD_SUCCESS)
+              throw std::runtime_error(std::string("set_stream_priority: ") + rdamd_errmsg());
+        if (!sparse) replica.initialize();
+        replica.set_conductor(&conductor, wid);
+        for (;;) {
+          const long k = conductor.next_candidate(wid);
+          if (k < 0) break;
+          replica.assign_indicies(std::vector<size_t>{todo[(size_t)k]});
+          std::vector<rdamd::rd_result_t> r;
+          replica.exhaustive_search(atol, pgtol, brtol, factor, &r);
+          std::lock_guard<std::mutex> g(mu);
+          results.insert(results.end(), r.begin(), r.end());
+        }
+      } catch (const std::exception &e) {
+        conductor.fail(e.what());
+        std::lock_guard<std::mutex> g(mu);
+        if (first_error.empty()) first_error = e.what();
+      }
+    };
+    std::vector<std::thread> pool;
+    for (unsigned w = 0; w < workers; ++w) pool.emplace_back(work, w);
+    for (auto &t : pool) t.join();
+    const auto st = conductor.stats();
+    m->lockstep_stats[0] = st.obj_launches; m->lockstep_stats[1] = st.obj_jobs;
+    m->lockstep_stats[2] = st.root_launches; m->lockstep_stats[3] = st.root_steps;
+    m->round_stats[0] = st.rounds; m->round_stats[1] = st.collectives; m->round_stats[2] = st.redos;
+    if (!first_error.empty()) throw std::runtime_error(first_error);
+    std::sort(results.begin(), results.end(),
+              [](const rdamd::rd_result_t &a, const rdamd::rd_result_t &b) { return a.root_id < b.root_id; });
+    double bl = -INFINITY;
+    for (size_t i = 0; i < results.size(); ++i) {
+      root_id[i] = results[i].root_id; llh[i] = results[i].llh; alpha[i] = results[i].alpha;
+      if (results[i].llh > bl) {
+        bl = results[i].llh;
+        if (best_rl) {
+          auto rl = m->model->tree().root_location(results[i].root_id);
+          rl.brlen_ratio = results[i].alpha;
+          to_c(rl, best_rl);
+        }
+      }
+    }
+    *n_results = (unsigned)results.size();
+    if (best_llh) *best_llh = bl;
+    return RDAMD_SUCCESS;
+  })
 }
 
 static int search_with_replicas(rdamd_model_t *m, unsigned int workers, bool lockstep, double atol,
@@ -429,9 +586,9 @@ static int search_with_replicas(rdamd_model_t *m, unsigned int workers, bool loc
     // lock-step: the replicas' objective batches meet in one launch on THIS
     // model's partition (batch_combiner.hpp); it does nothing else meanwhile
     if (m->model->site_sharded())
-      throw std::runtime_error("a site-sharded model runs its candidates sequentially "
-                               "(rdamd_model_exhaustive_search): replicas would reorder the "
-                               "site group's collectives");
+      throw std::runtime_error("the candidates of a site-sharded model advance in rounds "
+                               "(rdamd_model_exhaustive_search_lockstep); free-running replicas would "
+                               "reorder the site group's collectives");
     std::vector<std::unique_ptr<rdamd::batch_combiner_t>> combiner[2];   // [group][partition]
     std::unique_ptr<rdamd::root_combiner_t> root_combiner;
     const std::vector<size_t> todo = m->model->assigned_indicies();
@@ -449,13 +606,8 @@ static int search_with_replicas(rdamd_model_t *m, unsigned int workers, bool loc
     // From four candidates in flight on they form two groups whose batches alternate on the
     // shared partition (batch_combiner.hpp): one group's hosts work while the other's batch runs
     const unsigned n_groups = lockstep && workers >= 4 && m->lockstep_groups != 1 ? 2u : 1u;
+    shared_priority_t shared_priority(m, lockstep);
     if (lockstep) {
-      // the objective launches fill every CU for a millisecond: on low priority, the kernels
-      // beside them (front halves of the other group's batch, the replicas' root-only steps and
-      // traversals) get the wave slots that become free instead of waiting for the launch to end
-      for (size_t pi = 0; m->lockstep_priority && pi < m->model->partition_count(); ++pi)
-        if (rdamd_partition_set_stream_priority(m->model->partition(pi), m->lockstep_priority) != RDAMD_SUCCESS)
-          throw std::runtime_error(std::string("set_stream_priority: ") + rdamd_errmsg());
       for (unsigned g = 0; g < n_groups; ++g)
         for (size_t pi = 0; pi < m->model->partition_count(); ++pi)
           combiner[g].emplace_back(new rdamd::batch_combiner_t(m->model->partition(pi), n_groups == 2 ? (int)g : -1));
@@ -471,8 +623,10 @@ static int search_with_replicas(rdamd_model_t *m, unsigned int workers, bool loc
       try {
         if (hipSetDevice(device) != hipSuccess) throw std::runtime_error("hipSetDevice failed");
         const auto msas = m->all_msas();
+        const bool sparse = replicas_are_sparse(m);
         rdamd::model_t replica(m->model->tree(), msas, m->all_ratehets(), false, m->seed + wid,
-                               m->early_stop);
+                               m->early_stop, sparse);
+        replica.adopt_empirical_freqs(*m->model);
         replica.initialize_partitions(msas);
         if (m->setulb) replica.set_lbfgsb(reinterpret_cast<rdamd::model_t::setulb_fn>(m->setulb));
         replica.set_checkpoint(m->checkpoint);
@@ -487,7 +641,9 @@ static int search_with_replicas(rdamd_model_t *m, unsigned int workers, bool loc
           for (size_t pi = 0; pi < replica.partition_count(); ++pi)
             if (rdamd_partition_set_stream_priority(replica.partition(pi), -1) != RDAMD_SUCCESS)
               throw std::runtime_error(std::string("set_stream_priority: ") + rdamd_errmsg());
-        replica.initialize();
+        // (model_t::initialize is a full traversal whose CLVs the search never reads: a sparse
+        // replica, whose first step writes the two it needs, does without)
+        if (!sparse) replica.initialize();
         replica.set_root_combiner(root_combiner.get());   // (after initialize(): that evaluates on its own)
         for (;;) {
           const size_t k = next.fetch_add(1);
@@ -549,6 +705,11 @@ int rdamd_model_exhaustive_search_lockstep(rdamd_model_t *m, unsigned int in_fli
                                            uint64_t *root_id, double *llh, double *alpha,
                                            unsigned int *n_results,
                                            rdamd_root_location_t *best_rl, double *best_llh) {
+  // a site-sharded model's candidates meet in deterministic rounds (the ranks of its site group
+  // must form the same launches and collectives); others in arrival order, unless asked
+  const bool rounds = m->lockstep_rounds < 0 ? m->model->site_sharded() : m->lockstep_rounds != 0;
+  if (rounds)
+    return search_in_rounds(m, in_flight, atol, pgtol, brtol, factor, root_id, llh, alpha, n_results, best_rl, best_llh);
   return search_with_replicas(m, in_flight, true, atol, pgtol, brtol, factor, root_id, llh, alpha,
                               n_results, best_rl, best_llh);
 }
@@ -580,6 +741,11 @@ void rdamd_model_set_root_children_only(rdamd_model_t *m, int on) {
 }
 void rdamd_model_lockstep_stats(const rdamd_model_t *m, uint64_t out[4]) {
   for (int i = 0; i < 4; ++i) out[i] = m->lockstep_stats[i];
+}
+void rdamd_model_set_lockstep_rounds(rdamd_model_t *m, int mode) { m->lockstep_rounds = mode; }
+void rdamd_model_round_stats(const rdamd_model_t *m, uint64_t out[4]) {
+  for (int i = 0; i < 3; ++i) out[i] = m->round_stats[i];
+  out[3] = m->model->collectives();
 }
 void rdamd_model_counters(const rdamd_model_t *m, uint64_t out[6]) {
   const auto c = m->model->counters();

@@ -115,6 +115,80 @@ void rdamd_partition::prof_end() {
 
 using namespace rdamd;
 
+
+namespace rdamd {
+// one more slot of a sparse pool: a bigger block, the live slots copied over (everything queued
+// on the partition has drained first -- kernels in flight hold the old addresses)
+static hipError_t grow_pool(rdamd_partition *p, bool scalers) {
+  unsigned &cap = scalers ? p->sc_slots_cap : p->clv_slots_cap;
+  const unsigned used = scalers ? p->sc_slots_used : p->clv_slots_used;
+  const unsigned limit = scalers ? p->scale_buffers : p->clv_buffers;
+  const size_t slot_bytes = scalers ? (size_t)p->sites * sizeof(unsigned) : p->clv_doubles() * sizeof(double);
+  const unsigned fresh_cap = std::min(limit, std::max(cap * 2u, 4u));
+  if (fresh_cap <= cap) return hipErrorOutOfMemory;   // (cannot happen: a pool never holds more slots than indices)
+  hipError_t e = sync_streams(p);
+  if (e != hipSuccess) return e;
+  void *fresh = nullptr;
+  e = hipMalloc(&fresh, std::max<size_t>(8, (size_t)fresh_cap * slot_bytes));
+  if (e != hipSuccess) return e;
+  void *old = scalers ? (void *)p->d_scaler : (void *)p->d_clv;
+  if (used && slot_bytes) e = hipMemcpy(fresh, old, (size_t)used * slot_bytes, hipMemcpyDeviceToDevice);
+  if (e != hipSuccess) { (void)hipFree(fresh); return e; }
+  (void)hipFree(old);
+  if (scalers) p->d_scaler = (unsigned *)fresh; else p->d_clv = (double *)fresh;
+  cap = fresh_cap;
+  return hipSuccess;
+}
+
+hipError_t clv_phys(rdamd_partition *p, unsigned clv_index, unsigned *phys) {
+  if (clv_index >= p->tips + p->clv_buffers) return hipErrorInvalidValue;
+  *phys = clv_index;
+  if (!p->sparse || clv_index < p->tips) return hipSuccess;
+  int &slot = p->clv_slot[clv_index - p->tips];
+  if (slot < 0) {
+    if (p->clv_slots_used == p->clv_slots_cap) {
+      hipError_t e = grow_pool(p, false);
+      if (e != hipSuccess) return e;
+    }
+    slot = (int)p->clv_slots_used++;
+  }
+  *phys = p->tips + (unsigned)slot;
+  return hipSuccess;
+}
+
+hipError_t scaler_phys(rdamd_partition *p, int scaler_index, int *phys) {
+  if (scaler_index >= (int)p->scale_buffers) return hipErrorInvalidValue;
+  *phys = scaler_index;
+  if (!p->sparse || scaler_index < 0) return hipSuccess;
+  int &slot = p->sc_slot[(size_t)scaler_index];
+  if (slot < 0) {
+    if (p->sc_slots_used == p->sc_slots_cap) {
+      hipError_t e = grow_pool(p, true);
+      if (e != hipSuccess) return e;
+    }
+    slot = (int)p->sc_slots_used++;
+    // a scale buffer nobody has written reads as zeros, as in a dense partition
+    hipError_t e = hipMemsetAsync(p->d_scaler + (size_t)slot * p->sites, 0, (size_t)p->sites * sizeof(unsigned), p->stream);
+    if (e != hipSuccess) return e;
+  }
+  *phys = slot;
+  return hipSuccess;
+}
+
+hipError_t op_phys(rdamd_partition *p, const rdamd_operation_t &o, rdamd_operation_t *out) {
+  *out = o;
+  if (!p->sparse) return hipSuccess;
+  if (o.parent_clv_index < p->tips) return hipErrorInvalidValue;
+  hipError_t e = clv_phys(p, o.parent_clv_index, &out->parent_clv_index);
+  if (e == hipSuccess) e = clv_phys(p, o.child1_clv_index, &out->child1_clv_index);
+  if (e == hipSuccess) e = clv_phys(p, o.child2_clv_index, &out->child2_clv_index);
+  if (e == hipSuccess) e = scaler_phys(p, o.parent_scaler_index, &out->parent_scaler_index);
+  if (e == hipSuccess) e = scaler_phys(p, o.child1_scaler_index, &out->child1_scaler_index);
+  if (e == hipSuccess) e = scaler_phys(p, o.child2_scaler_index, &out->child2_scaler_index);
+  return e;
+}
+}  // namespace rdamd
+
 extern "C" {
 
 int rdamd_errno(void) { return g_errno; }
@@ -161,7 +235,8 @@ uint64_t rdamd_partition_footprint(unsigned int tips, unsigned int clv_buffers, 
   const uint64_t K = states == 2 ? 4 : states, R = rate_cats, S = sites;
   const uint64_t codes = K == 4 ? 16 : 64;
   const uint64_t Sclv = (K == 20 && R <= 8) ? (S + 15) / 16 * 16 : S;   // operand layout: whole 16-site tiles
-  uint64_t b = (uint64_t)tips * ((S + 3) / 4 * 4) + (uint64_t)clv_buffers * Sclv * R * K * 8 +
+  // (4 states: the tip codes twice -- as codes and as LDS row offsets for the fused evaluator)
+  uint64_t b = (uint64_t)tips * ((S + 3) / 4 * 4) * (K == 4 ? 2 : 1) + (uint64_t)clv_buffers * Sclv * R * K * 8 +
                (uint64_t)scale_buffers * S * 4 + (uint64_t)prob_matrices * R * K * K * 8 +
                (uint64_t)prob_matrices * R * codes * K * 8 + S * 4 + ((uint64_t)6 << 20);
   if (K == 20 && R <= 8) b += (uint64_t)prob_matrices * R * k20_mfma_copy_doubles() * 8;
@@ -224,8 +299,16 @@ rdamd_partition_t *rdamd_partition_create(unsigned int tips, unsigned int clv_bu
   p->mfma_layout = K == 20 && R <= 8 &&
                    (size_t)p->clv_tiles() * 16u * R * K * sizeof(double) < ((size_t)1 << 31) &&
                    (size_t)prob_matrices * R * k20_mfma_copy_doubles() * sizeof(double) < ((size_t)1 << 31);
-  TRY(hipMalloc(&p->d_clv, std::max<size_t>(8, (size_t)clv_buffers * p->clv_doubles() * sizeof(double))));
-  TRY(hipMalloc(&p->d_scaler, std::max<size_t>(4, (size_t)scale_buffers * S * sizeof(unsigned))));
+  p->sparse = (attributes & RDAMD_ATTRIB_SPARSE_CLVS) != 0;
+  if (p->sparse) {   // a small pool to start with (common.hpp); it grows when more buffers are live at once
+    p->clv_slot.assign(clv_buffers, -1);
+    p->sc_slot.assign(scale_buffers, -1);
+    p->clv_slots_cap = std::min(clv_buffers, 4u);
+    p->sc_slots_cap = std::min(scale_buffers, 4u);
+  }
+  const size_t clv_alloc = p->sparse ? p->clv_slots_cap : clv_buffers, sc_alloc = p->sparse ? p->sc_slots_cap : scale_buffers;
+  TRY(hipMalloc(&p->d_clv, std::max<size_t>(8, clv_alloc * p->clv_doubles() * sizeof(double))));
+  TRY(hipMalloc(&p->d_scaler, std::max<size_t>(4, sc_alloc * S * sizeof(unsigned))));
   TRY(hipMalloc(&p->d_pmat, (size_t)prob_matrices * R * K * K * sizeof(double)));
   TRY(hipMalloc(&p->d_tiptab, (size_t)prob_matrices * R * p->ncodes_cap * K * sizeof(double)));
   if (p->mfma_layout)
@@ -244,7 +327,7 @@ rdamd_partition_t *rdamd_partition_create(unsigned int tips, unsigned int clv_bu
   TRY(hipHostMalloc(&p->h_stage, p->stage_bytes, hipHostMallocDefault));
   TRY(hipHostMalloc(&p->h_result, 64 * sizeof(double), hipHostMallocDefault));
   TRY(ensure_scratch(p, (size_t)1 << 20));
-  TRY(hipMemsetAsync(p->d_scaler, 0, std::max<size_t>(4, (size_t)scale_buffers * S * sizeof(unsigned)), p->stream));
+  TRY(hipMemsetAsync(p->d_scaler, 0, std::max<size_t>(4, sc_alloc * S * sizeof(unsigned)), p->stream));
   TRY(hipMemsetAsync(p->d_tipcodes, 0, (size_t)tips * p->tip_stride() + kTipcodePad, p->stream));
   if (K == 4) TRY(hipMemsetAsync(p->d_tipcodes16, 0, (size_t)tips * p->tip_stride() + kTipcodePad, p->stream));
 
@@ -305,6 +388,21 @@ void rdamd_partition_destroy(rdamd_partition_t *p) {
   if (p->h_root_items) (void)hipHostFree(p->h_root_items);
   if (p->stream) (void)hipStreamDestroy(p->stream);
   delete p;
+}
+
+void rdamd_partition_discard_clvs(rdamd_partition_t *p) {
+  if (!p || !p->sparse) return;
+  // (slots are reused by later calls on the partition's stream, i.e. after everything queued so
+  // far; a combined root step of ANOTHER partition's stream has returned before its caller can
+  // get here)
+  std::fill(p->clv_slot.begin(), p->clv_slot.end(), -1);
+  std::fill(p->sc_slot.begin(), p->sc_slot.end(), -1);
+  p->clv_slots_used = p->sc_slots_used = 0;
+}
+
+uint64_t rdamd_partition_clv_bytes(const rdamd_partition_t *p) {
+  const uint64_t c = p->sparse ? p->clv_slots_cap : p->clv_buffers, s = p->sparse ? p->sc_slots_cap : p->scale_buffers;
+  return c * p->clv_doubles() * sizeof(double) + s * (uint64_t)p->sites * sizeof(unsigned);
 }
 
 int rdamd_set_tip_states(rdamd_partition_t *p, unsigned int tip_index,
@@ -463,6 +561,7 @@ int rdamd_partition_set_stream_priority(rdamd_partition_t *p, int level) {
   int least = 0, greatest = 0;   // (numerically: greatest priority = lowest number)
   RDAMD_HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest), RDAMD_FAILURE);
   const int prio = level < 0 ? greatest : (level > 0 ? least : (least + greatest) / 2);
+  if ((level < 0 ? -1 : (level > 0 ? 1 : 0)) == p->stream_priority && p->stream) return RDAMD_SUCCESS;   // (nothing to re-create)
   hipStream_t fresh = nullptr;
   RDAMD_HIP_TRY(hipStreamCreateWithPriority(&fresh, hipStreamNonBlocking, prio), RDAMD_FAILURE);
   if (p->stream) (void)hipStreamDestroy(p->stream);
@@ -534,6 +633,19 @@ void rdamd_update_clvs(rdamd_partition_t *p, const rdamd_operation_t *ops,
   clear_error();
   if (count == 0) return;
   const unsigned nclv = p->tips + p->clv_buffers;
+  std::vector<rdamd_operation_t> phys_ops;
+  if (p->sparse) {   // from here on the list names pool slots (common.hpp)
+    phys_ops.resize(count);
+    for (unsigned i = 0; i < count; ++i) {
+      const hipError_t pe = op_phys(p, ops[i], &phys_ops[i]);
+      if (pe != hipSuccess) {
+        set_error(pe == hipErrorInvalidValue ? 10 : 100 + (int)pe, "rdamd_update_clvs: operation %u: %s", i,
+                  pe == hipErrorInvalidValue ? "an index out of range" : hipGetErrorString(pe));
+        return;
+      }
+    }
+    ops = phys_ops.data();
+  }
   // (20 states: independent subtrees side by side, see k20_split)
   std::vector<rdamd_operation_t> k20_order;
   std::vector<unsigned> k20_bounds;
@@ -744,6 +856,8 @@ double rdamd_compute_root_loglikelihood(rdamd_partition_t *p, unsigned int clv_i
       return nan;
     }
   if (p->sites == 0) return 0.0;   // an empty alignment has likelihood 1
+  RDAMD_HIP_TRY(clv_phys(p, clv_index, &clv_index), nan);
+  RDAMD_HIP_TRY(scaler_phys(p, scaler_index, &scaler_index), nan);
   RDAMD_HIP_TRY(flush_q(p), nan);
   RDAMD_HIP_TRY(ensure_scratch(p, 1024 + sizeof(unsigned) * p->rate_cats), nan);
   Scratch sc{p};
@@ -777,6 +891,17 @@ int rdamd_compute_root_loglikelihoods(rdamd_partition_t *p, unsigned int count,
       return RDAMD_FAILURE;
     }
     rel[i] = clv_indices[i] - p->tips;
+  }
+  std::vector<int> phys_sc;
+  if (p->sparse && p->sites) {
+    phys_sc.assign(scaler_indices, scaler_indices + count);
+    for (unsigned i = 0; i < count; ++i) {
+      unsigned c = 0;
+      RDAMD_HIP_TRY(clv_phys(p, clv_indices[i], &c), RDAMD_FAILURE);
+      RDAMD_HIP_TRY(scaler_phys(p, scaler_indices[i], &phys_sc[i]), RDAMD_FAILURE);
+      rel[i] = c - p->tips;
+    }
+    scaler_indices = phys_sc.data();
   }
   for (unsigned r = 0; r < p->rate_cats; ++r)
     if (freqs_indices[r] >= p->rate_matrices) {
@@ -856,6 +981,9 @@ int rdamd_root_loglikelihood_fused(rdamd_partition_t *p, const rdamd_operation_t
       set_error(7, "rdamd_root_loglikelihood_fused: params index out of range");
       return RDAMD_FAILURE;
     }
+  rdamd_operation_t phys_root;
+  RDAMD_HIP_TRY(op_phys(p, *root_op, &phys_root), RDAMD_FAILURE);
+  root_op = &phys_root;
   RDAMD_HIP_TRY(flush_q(p), RDAMD_FAILURE);
   if (p->tiptab_stale) {
     RDAMD_HIP_TRY(launch_tiptab_all(p), RDAMD_FAILURE);
@@ -938,15 +1066,16 @@ int rdamd_root_loglikelihood_fused_multi(unsigned int n_items, rdamd_partition_t
   double *h_res = (double *)(h_items + lead->root_items_cap);
   for (unsigned i = 0; i < n_items; ++i) {
     rdamd_partition *p = parts[i];
-    const rdamd_operation_t &o = ops[i];
     const unsigned nclv = p->tips + p->clv_buffers;
-    if (o.parent_clv_index < p->tips || o.parent_clv_index >= nclv || o.child1_clv_index >= nclv ||
-        o.child2_clv_index >= nclv || o.child1_matrix_index >= p->prob_matrices ||
-        o.child2_matrix_index >= p->prob_matrices || o.parent_scaler_index >= (int)p->scale_buffers ||
-        o.child1_scaler_index >= (int)p->scale_buffers || o.child2_scaler_index >= (int)p->scale_buffers) {
+    if (ops[i].parent_clv_index < p->tips || ops[i].parent_clv_index >= nclv || ops[i].child1_clv_index >= nclv ||
+        ops[i].child2_clv_index >= nclv || ops[i].child1_matrix_index >= p->prob_matrices ||
+        ops[i].child2_matrix_index >= p->prob_matrices || ops[i].parent_scaler_index >= (int)p->scale_buffers ||
+        ops[i].child1_scaler_index >= (int)p->scale_buffers || ops[i].child2_scaler_index >= (int)p->scale_buffers) {
       set_error(10, "rdamd_root_loglikelihood_fused_multi: item %u: index out of range", i);
       return RDAMD_FAILURE;
     }
+    rdamd_operation_t o;
+    RDAMD_HIP_TRY(op_phys(p, ops[i], &o), RDAMD_FAILURE);
     RootItem &it = h_items[i];
     memset(&it, 0, sizeof it);
     for (unsigned a = 0; a < kRootMaxPositions; ++a) {   // (unused positions repeat the last one: same state left behind)
@@ -1016,6 +1145,7 @@ int rdamd_get_clv(rdamd_partition_t *p, unsigned int clv_index, double *out) {
     set_error(11, "rdamd_get_clv: index out of range");
     return RDAMD_FAILURE;
   }
+  RDAMD_HIP_TRY(clv_phys(p, clv_index, &clv_index), RDAMD_FAILURE);
   RDAMD_HIP_TRY(hipStreamSynchronize(p->stream), RDAMD_FAILURE);
   const double *src = p->d_clv + (size_t)(clv_index - p->tips) * p->clv_doubles();
   if (p->mfma_layout) {   // device: [rate][tile][operand layout] -> the ABI's [site][rate][state]
@@ -1049,6 +1179,9 @@ int rdamd_get_scaler(rdamd_partition_t *p, unsigned int scaler_index, unsigned i
     set_error(11, "rdamd_get_scaler: index out of range");
     return RDAMD_FAILURE;
   }
+  int phys_sc = (int)scaler_index;
+  RDAMD_HIP_TRY(scaler_phys(p, (int)scaler_index, &phys_sc), RDAMD_FAILURE);
+  scaler_index = (unsigned)phys_sc;
   RDAMD_HIP_TRY(hipStreamSynchronize(p->stream), RDAMD_FAILURE);
   RDAMD_HIP_TRY(hipMemcpy(out, p->d_scaler + (size_t)scaler_index * p->sites,
                           sizeof(unsigned) * p->sites, hipMemcpyDeviceToHost), RDAMD_FAILURE);

@@ -41,8 +41,8 @@ namespace {
 struct options_t {
   std::string msa, tree, prefix, partition, model, lbfgsb, rate_cats_type = "mean";
   unsigned states = 4, rate_cats = 1, min_roots = 1, workers = 4;
-  int lockstep = -1, device = -1, site_shards = 1;
-  bool site_reduce_host = false;
+  int lockstep = -1, device = -1, site_shards = 1, lockstep_rounds = -1;
+  bool site_reduce_host = false, stats = false;
   uint64_t seed = 1;
   double root_ratio = 0.01, atol = 1e-7, bfgstol = 1e-7, brtol = 1e-12, factor = 1e4;
   int early_stop = 0;   // initialized_flag_t: 0 unset, 1 true, 2 false
@@ -66,7 +66,7 @@ void usage() {
       "  --rate-cats-type {mean,median,free}  --seed <N>  --min-roots <N>  --root-ratio <X>\n"
       "  --atol <X>  --brtol <X>  --bfgstol <X>  --factor <X>  --early-stop  --no-early-stop\n"
       "  --initial-root-strategy {random,midpoint,modified-mad}  --threads <N>  --lockstep <N>\n"
-      "  --site-shards <G>  --site-reduce {rccl,host}\n"
+      "  --site-shards <G>  --site-reduce {rccl,host}  --lockstep-rounds {0,1}  --stats\n"
       "  --lbfgsb <LIB>  --device <N>  --silent  --echo  --clean  --no-checkpoint  --version");
 }
 
@@ -89,7 +89,8 @@ options_t parse(int argc, char **argv) {
       {"help", no_argument, 0, 0},               {"lbfgsb", required_argument, 0, 0},
       {"lockstep", required_argument, 0, 0},     {"device", required_argument, 0, 0},
       {"no-checkpoint", no_argument, 0, 0},      {"site-shards", required_argument, 0, 0},
-      {"site-reduce", required_argument, 0, 0},  {0, 0, 0, 0}};
+      {"site-reduce", required_argument, 0, 0},  {"lockstep-rounds", required_argument, 0, 0},
+      {"stats", no_argument, 0, 0},              {0, 0, 0, 0}};
   options_t o;
   int index = 0;
   while (getopt_long_only(argc, argv, "", long_opts, &index) == 0) {
@@ -129,6 +130,8 @@ options_t parse(int argc, char **argv) {
     else if (name == "device") o.device = std::atoi(v);
     else if (name == "no-checkpoint") o.no_checkpoint = true;
     else if (name == "site-shards") o.site_shards = std::atoi(v);
+    else if (name == "lockstep-rounds") o.lockstep_rounds = std::atoi(v);
+    else if (name == "stats") o.stats = true;
     else if (name == "site-reduce") {
       const std::string s = v;
       if (s != "rccl" && s != "host") die("--site-reduce takes rccl or host");
@@ -299,7 +302,11 @@ static int run(int argc, char **argv) {
   rdamd_model_compute_lh(model, &rl0);                                   // model.initialize()
   if (ckp && srank == 0) rdamd_model_set_checkpoint(model, ckp);   // one record per candidate
   if (o.lockstep < 0) o.lockstep = !o.lbfgsb.empty() ? 32 : 0;   // (partitioned models lock-step too)
-  if (G > 1) o.lockstep = o.workers = 0;   // a site group walks its candidates in step
+  // A site group's candidates advance in lock step in deterministic rounds (every rank of the
+  // group forms the same launches and one collective per round; --lockstep 0: one candidate
+  // at a time, a collective per request); free-running replicas would reorder the collectives.
+  if (G > 1) o.workers = 0;
+  if (o.lockstep_rounds >= 0) rdamd_model_set_lockstep_rounds(model, o.lockstep_rounds);
 
   // While the ranks search they exchange nothing over the rendezvous: the end of a
   // connection now means that a rank has died.  Nobody must stay behind inside a
@@ -359,6 +366,25 @@ static int run(int argc, char **argv) {
       ids[0] = best.id; llh[0] = best_llh; alpha[0] = best.brlen_ratio;
       n_results = 1;
     }
+  }
+  if (o.stats) {   // one line per rank on stderr: what the search launched and summed
+    uint64_t ls[4] = {0, 0, 0, 0}, rs[4] = {0, 0, 0, 0}, ct[6] = {0, 0, 0, 0, 0, 0};
+    rdamd_model_lockstep_stats(model, ls);
+    rdamd_model_round_stats(model, rs);
+    rdamd_model_counters(model, ct);
+    const std::chrono::duration<double> took = std::chrono::steady_clock::now() - start;
+    uint64_t digest = 1469598103934665603ull;   // FNV-1a over the bits of this rank's (id, lnL, alpha) triples
+    auto mix = [&digest](const void *ptr, size_t n) {
+      for (size_t i = 0; i < n; ++i) digest = (digest ^ ((const unsigned char *)ptr)[i]) * 1099511628211ull;
+    };
+    for (unsigned i = 0; i < n_results; ++i) { mix(&ids[i], 8); mix(&llh[i], 8); mix(&alpha[i], 8); }
+    std::fprintf(stderr, "[rank %d] stats: candidates=%u results_digest=%016llx lockstep=%d rounds=%llu collectives=%llu redos=%llu "
+                         "own_collectives=%llu objective_launches=%llu objective_jobs=%llu root_launches=%llu "
+                         "root_steps=%llu seconds=%.3f\n",
+                 rank, n_results, (unsigned long long)digest, o.lockstep, (unsigned long long)rs[0], (unsigned long long)rs[1],
+                 (unsigned long long)rs[2], (unsigned long long)rs[3],
+                 (unsigned long long)(ls[0] ? ls[0] : ct[0]), (unsigned long long)(ls[1] ? ls[1] : ct[1]),
+                 (unsigned long long)ls[2], (unsigned long long)ls[3], took.count());
   }
   ranks.barrier();
   if (rank != 0) {

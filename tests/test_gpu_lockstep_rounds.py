@@ -1,0 +1,226 @@
+"""Lock step in DETERMINISTIC ROUNDS (csrc/lockstep_conductor.hpp) -- north star: "the outer
+root-edge loop batches lnL evaluations so candidate edges and site blocks shard across the 8 GPUs
+... with an RCCL all-reduce of per-block log-likelihoods".  The reference's loop is
+src/model.cpp:1154-1229 (one candidate at a time), its rank split :1867-1911.
+
+* the stream-ordered device batch the rounds are built on (rdamd_evaluate_batch_submit_device /
+  _redo_device / _finish_device) against the blocking call, the second-pass flag included;
+* one process: the search in rounds == the sequential search, bit for bit, with one and two worker
+  groups, without a reducer and with the RCCL communicator (one rank) as the device-side reducer --
+  and with a fraction of the collectives;
+* rd_amd --site-shards G --lockstep N on 2 / 4 / 8 ranks of one device (host reducer: RCCL refuses
+  two ranks on a GPU; the model hook is the same): the ranks of a group hold the same bits, the
+  records are the sequential sharded run's bit for bit and the one-rank run's to tolerance."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import root_digger_amd as rd
+from root_digger_amd import synth
+import util
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+RD = os.path.join(ROOT, "root_digger_amd", "bin", "rd_amd")
+REF = os.path.join(ROOT, "oracle", "_ref", "liblbfgsb_ref.so")
+MSA, TREE = os.path.join(util.DATA, "10.fasta"), os.path.join(util.DATA, "10.tree")
+LOOSE = (1e-3, 1e-3, 1e-3, 1e12)      # atol, pgtol, brtol, factor
+
+
+class _Hip:
+    """device memory from the HIP runtime librdamd itself runs on (no torch here: a PyTorch
+    imported beside the library may bring a second runtime instance, bench.py has the check)"""
+
+    def __init__(self):
+        self.rt = C.CDLL(rd.hip_runtime_path())
+        self.rt.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+        self.rt.hipFree.argtypes = [C.c_void_p]
+        self.rt.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        self.rt.hipDeviceSynchronize.argtypes = []
+
+    def alloc(self, nbytes):
+        p = C.c_void_p()
+        assert self.rt.hipMalloc(C.byref(p), nbytes) == 0
+        return p.value
+
+    def read(self, ptr, n):
+        out = np.zeros(n, dtype=np.float64)
+        assert self.rt.hipDeviceSynchronize() == 0
+        assert self.rt.hipMemcpy(out.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), 8 * n, 2) == 0
+        return out
+
+    def free(self, ptr):
+        self.rt.hipFree(C.c_void_p(ptr))
+
+
+def test_stream_ordered_device_batch_equals_the_blocking_call():
+    hip = _Hip()
+    w = synth.workload(30, 700, 4, 4, 151)
+    tree = rd.Tree.from_newick(w["newick"])
+    p = rd.Partition.for_tree(tree, 4, 700, 4, attributes=rd.ATTRIB_SITE_REPEATS)
+    util.load_tips(p, tree, w["seqs"], rd.MAP_NT)
+    rng = np.random.default_rng(7)
+    rls = [tree.root_location(int(i)).with_ratio(0.4) for i in rng.choice(tree.root_count(), 6, replace=False)]
+    scheds = [p.schedule(*tree.generate_operations(rl)) for rl in rls]
+    assert all(s.stats()["pseudo_tips"] > 0 for s in scheds)
+    J = 6
+    subst = rng.uniform(1e-2, 1.0, (J, 12))
+    freqs = rng.dirichlet(np.ones(4) * 5, J)
+    rates = np.tile(rd.compute_gamma_cats(1.0, 4), (J, 1))
+    d = hip.alloc(8 * (J + 1))
+    # ordinary parameters: flag down, results final behind the finishing kernel
+    want = p.evaluate_batch(scheds, subst, freqs, rates)
+    for slot in (0, 1):
+        n = p.evaluate_batch_submit_device(slot, scheds, subst, freqs, d, rates)
+        got = hip.read(d, n + 1)
+        assert got[n] == 0.0 and np.array_equal(got[:n], want)
+        p.evaluate_batch_finish_device(slot)
+    # two jobs whose tables need the per-site rescaling rule (a rate of 1e-42: P entries below
+    # 2^-128): the flag is up, their entries are not final until the redo, the others' are
+    rates[1] = rates[4] = [1e-42, 0.5, 1.0, 2.5]
+    want = p.evaluate_batch(scheds, subst, freqs, rates)
+    n = p.evaluate_batch_submit_device(0, scheds, subst, freqs, d, rates)
+    got = hip.read(d, n + 1)
+    assert got[n] == 1.0
+    keep = [0, 2, 3, 5]
+    assert np.array_equal(got[keep], want[keep])
+    p.evaluate_batch_redo_device(0, d)
+    got = hip.read(d, n + 1)
+    assert got[n] == 0.0 and np.array_equal(got[:n], want)
+    # a second batch in flight on the other slot while this one is redone
+    n1 = p.evaluate_batch_submit_device(1, scheds[:3], subst[:3], freqs[:3], d, rates[:3])
+    assert n1 == 3
+    p.evaluate_batch_finish_device(0)
+    with pytest.raises(rd.RdamdError):
+        p.evaluate_batch_finish_device(0)          # nothing in flight on the slot any more
+    got = hip.read(d, 4)
+    assert got[3] == 1.0                            # (job 1 of this batch is a flagged one)
+    p.evaluate_batch_redo_device(1, d)
+    assert np.array_equal(hip.read(d, 4)[:3], want[:3])
+    p.evaluate_batch_finish_device(1)
+    assert np.array_equal(p.evaluate_batch(scheds, subst, freqs, rates), want)
+    hip.free(d)
+
+
+def _model(seed=3):
+    tree = rd.Tree.from_file(TREE)
+    seqs, w = util.compress(util.read_fasta(MSA))
+    m = rd.Model(tree, seqs, rate_cats=4, weights=w, seed=seed)
+    m.initialize_partitions()
+    m.set_lbfgsb(C.CDLL(REF).setulb)
+    return m
+
+
+def _search(m, lockstep, candidates=17):
+    m.assign_by_rank(0, 17 // candidates)
+    r = m.exhaustive_search(*LOOSE, lockstep=lockstep)
+    return list(r["root_id"]), list(r["llh"]), list(r["alpha"])
+
+
+@pytest.fixture(scope="module")
+def sequential_records():
+    if not os.path.exists(REF):
+        pytest.skip("oracle/_ref/liblbfgsb_ref.so not built (needs /root/reference at build time)")
+    m = _model()
+    out = _search(m, 0)
+    m.destroy()
+    return out
+
+
+@pytest.mark.parametrize("in_flight", [3, 6, 17])
+def test_rounds_reproduce_the_sequential_search_on_one_rank(sequential_records, in_flight):
+    """no reducer: the rounds' machinery alone (one group below four candidates in flight, two
+    alternating groups from four on); a job's value does not depend on its launch"""
+    m = _model()
+    m.set_lockstep_rounds(1)
+    assert _search(m, in_flight) == sequential_records
+    st, ls = m.round_stats(), m.lockstep_stats()
+    assert st["rounds"] > 0 and st["redos"] == 0 and st["own_collectives"] == 0
+    assert ls["objective_jobs"] > ls["objective_launches"] > 0 and ls["root_steps"] > ls["root_launches"] > 0
+    if in_flight == 17:      # every candidate in flight from the first round on
+        assert ls["objective_jobs"] / ls["objective_launches"] > 40
+    m.destroy()
+
+
+def test_rounds_with_the_rccl_communicator_as_reducer(sequential_records):
+    """the device path of a site group -- batch to device memory, ncclAllReduce queued behind it on
+    the partition's stream, the sums copied back, the event waited for with the communicator's
+    failure handling -- on a one-rank group: a one-rank sum changes nothing, so the records are
+    the sequential ones, and the collectives are counted"""
+    comm = rd.Comm(rd.Comm.unique_id(), 0, 1)
+    seq = _model()
+    seq.set_lnl_reducer(comm.reducer, on_device=True, user=comm.handle)
+    assert _search(seq, 0) == sequential_records
+    per_request = seq.round_stats()["own_collectives"]
+    seq.destroy()
+    m = _model()
+    m.set_lnl_reducer(comm.reducer, on_device=True, user=comm.handle)
+    assert _search(m, 17) == sequential_records
+    st = m.round_stats()
+    assert st["own_collectives"] == 0 and 0 < st["collectives"] <= st["rounds"]
+    assert per_request > 8 * st["collectives"], (per_request, st)
+    # a model that refuses rounds refuses the lock-stepped search when it is site-sharded
+    m.set_lockstep_rounds(0)
+    with pytest.raises(rd.RdamdError):
+        _search(m, 4)
+    m.destroy()
+    comm.destroy()
+
+
+def _run_ranks(args, world, timeout=900):
+    s = __import__("socket").socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    procs = [subprocess.Popen(args, env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+             for r in range(world)]
+    outs = [p.communicate(timeout=timeout) for p in procs]
+    assert [p.returncode for p in procs] == [0] * world, outs
+    stats = {}
+    for _, err in outs:
+        for line in err.splitlines():
+            mt = re.match(r"\[rank (\d+)\] stats: (.*)", line)
+            if mt:
+                stats[int(mt.group(1))] = dict(kv.split("=") for kv in mt.group(2).split())
+    assert sorted(stats) == list(range(world)), outs
+    return stats
+
+
+@pytest.mark.parametrize("world,shards", [(2, 2), (4, 2), (8, 8), (8, 2)])
+def test_site_sharded_lock_step_equals_the_sequential_sharded_search(tmp_path, world, shards):
+    """c4's layout (site blocks only: 2/2, 8/8) and c5's grid (candidate groups x site blocks:
+    4/2, 8/2).  Same G, same reducer: the sums are the same numbers in the same order, so the
+    lock-stepped records must be the sequential ones BIT FOR BIT whatever the tolerances; every
+    rank of a site group ends with the same bits; one collective per round instead of one per
+    request."""
+    if not os.path.exists(REF):
+        pytest.skip("oracle/_ref/liblbfgsb_ref.so not built")
+    common = ["--msa", MSA, "--tree", TREE, "--exhaustive", "--silent", "--rate-cats", "4",
+              "--atol", "1e-3", "--brtol", "1e-3", "--bfgstol", "1e-3", "--factor", "1e12",
+              "--seed", "5", "--lbfgsb", REF, "--device", "0", "--site-shards", str(shards),
+              "--site-reduce", "host", "--stats"]
+    seq, lock = str(tmp_path / "seq"), str(tmp_path / "lock")
+    st_seq = _run_ranks([RD] + common + ["--prefix", seq, "--lockstep", "0"], world)
+    st_lock = _run_ranks([RD] + common + ["--prefix", lock, "--lockstep", "6"], world)
+    ra = sorted(rd.Checkpoint(seq).read_results())
+    rb = sorted(rd.Checkpoint(lock).read_results())
+    assert [r[0] for r in ra] == list(range(17))
+    assert ra == rb                                         # ids, lnL, alpha, parameters: same bits
+    groups = world // shards
+    for g in range(groups):
+        members = range(g * shards, (g + 1) * shards)
+        assert len({st_lock[r]["results_digest"] for r in members}) == 1      # the ranks of a group agree
+        assert len({st_lock[r]["collectives"] for r in members}) == 1
+        assert st_lock[g * shards]["results_digest"] == st_seq[g * shards]["results_digest"]
+    per_request = int(st_seq[0]["own_collectives"])
+    per_round = int(st_lock[0]["collectives"])
+    assert int(st_lock[0]["own_collectives"]) == 0 and per_round > 0
+    # up to six candidates per round (fewer towards the end of a group's list)
+    assert per_request > (3.0 if groups == 1 else 2.0) * per_round, (per_request, per_round)
+    assert open(seq + ".rooted.tree").read() == open(lock + ".rooted.tree").read()

@@ -373,14 +373,17 @@ def test_binary_characters_with_parameter_optimisation(lbfgsb, tmp_path):
 
 
 def test_replica_count_is_clamped_to_device_memory():
-    """every replica of the parallel / lock-step search is a full model
-    (all CLV buffers); asking for more than fit must be clamped, not die in
-    hipMalloc.  A 60-taxon x 400 000-site Γ4 model is 6.1 GB per replica."""
+    """a replica of the parallel / lock-step search whose compute_lh is the full
+    traversal is a full model (all CLV buffers); asking for more than fit must be clamped, not
+    die in hipMalloc.  A 60-taxon x 400 000-site Γ4 model is 6.1 GB per such replica.  (With the
+    children-only compute_lh, the default, a replica holds three CLVs: tests/test_gpu_sparse.py.)"""
     from root_digger_amd import synth
     w = synth.workload(60, 400000, 4, 4, 77, simulate_seqs=False)
     tree = rd.Tree.from_newick(w["newick"])
     m = rd.Model(tree, w["seqs"], rate_cats=4, seed=1)
     free, total = rd.device_memory()
+    assert m.max_replicas(32)[0] == 32 and m.max_replicas(32)[1] < 0.4e9
+    m.set_root_children_only(False)
     fit, per = m.max_replicas(1000)
     want = rd.lib.rdamd_partition_footprint(60, 118, 4, 400000, 118, 4, 118)
     assert per == want and 5.9e9 < per < 6.6e9

@@ -171,7 +171,8 @@ def test_rccl_communicator_as_device_side_reducer():
     sharded = _measure(m, tree, True, tight=False)
     for key in plain:
         assert sharded[key] == plain[key], key
-    with pytest.raises(rd.RdamdError):       # replicas would reorder the collectives
-        m.exhaustive_search(1e-3, 1e-3, 1e-3, 1e12, lockstep=4)
+    with pytest.raises(rd.RdamdError):       # free-running replicas would reorder the collectives
+        m.exhaustive_search(1e-3, 1e-3, 1e-3, 1e12, workers=4)
+    # (in lock step a site-sharded model advances in rounds: tests/test_gpu_lockstep_rounds.py)
     m.destroy()
     comm.destroy()
