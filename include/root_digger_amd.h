@@ -572,6 +572,10 @@ void rdamd_model_set_lockstep_rounds(rdamd_model_t *m, int mode);
  * evaluator pass; [3] (any search) collectives THIS model asked its reducer for by itself --
  * the sequential site-sharded search's count, one per request */
 void rdamd_model_round_stats(const rdamd_model_t *m, uint64_t out[4]);
+/* ... and where its rounds spent their host time, seconds summed over the rounds: out[0] queueing
+ * the objective batch, [1] the root-only launch (it blocks), [2] queueing the sum (a host
+ * reducer: waiting for the batch and summing), [3] waiting for the round's event */
+void rdamd_model_round_seconds(const rdamd_model_t *m, double out[4]);
 /* stream priority (rdamd_partition_set_stream_priority) of the shared objective partition
  * during a lock-stepped search: +1 low (default), 0 leave it as it is */
 void rdamd_model_set_lockstep_priority(rdamd_model_t *m, int level);

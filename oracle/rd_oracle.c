@@ -30,6 +30,7 @@ struct orc_partition {
   double       *rate_weights; /* [R] */
   double       *prop_invar;   /* rate_matrices (always 0, src/model.cpp:297) */
   unsigned int *pattern_weights; /* [S] */
+  struct orc_repeats *rep;       /* site repeats (orc_update_clvs_repeats), lazily built */
 };
 
 const uint64_t orc_map_nt[256] = {
@@ -88,6 +89,8 @@ orc_partition_t *orc_partition_create(unsigned int tips,
   return p;
 }
 
+static void orc_repeats_free(orc_partition_t *p);
+
 void orc_partition_destroy(orc_partition_t *p) {
   if (!p) return;
   for (unsigned int i = 0; i < p->tips + p->clv_buffers; ++i) free(p->clv[i]);
@@ -102,6 +105,7 @@ void orc_partition_destroy(orc_partition_t *p) {
   }
   free(p->subst); free(p->freqs); free(p->rates); free(p->rate_weights);
   free(p->prop_invar); free(p->pattern_weights);
+  orc_repeats_free(p);
   free(p);
 }
 
@@ -110,6 +114,7 @@ void orc_partition_destroy(orc_partition_t *p) {
 int orc_set_tip_states(orc_partition_t *p, unsigned int tip_index,
                        const uint64_t *map, const char *sequence) {
   double *clv = p->clv[tip_index];
+  orc_repeats_free(p);   /* (tip classes are derived from the tip CLVs) */
   for (unsigned int s = 0; s < p->sites; ++s) {
     uint64_t st = map[(unsigned char)sequence[s]];
     if (!st) return ORC_FAILURE;
@@ -467,6 +472,241 @@ int orc_update_clvs_avx2(orc_partition_t *p, const orc_operation_t *ops, unsigne
   (void)p; (void)ops; (void)count;
   return ORC_FAILURE;
 #endif
+}
+
+
+/* ---- subtree site repeats (CORAX_ATTRIB_SITE_REPEATS) ----------------------
+ * The reference switches coraxlib's site repeats on for every 4-state partition
+ * (src/model.cpp:145-149): two alignment columns that show the same characters at
+ * all tips below a node have the same CLV there, so the node's CLV is computed
+ * once per CLASS of columns and the columns index into it.  This restates the
+ * published scheme (Kobert, Stamatakis, Flouri 2017, "Efficient detection of
+ * repeating sites to accelerate phylogenetic likelihood calculations"; libpll-2's
+ * pll_update_repeats): a node's class of a column is the pair (class at child 1,
+ * class at child 2), numbered in order of first appearance through a lookup table
+ * of n1 x n2 entries; a node whose table would pass PLL_REPEATS_LOOKUP_SIZE
+ * (2 000 000 entries) keeps one class per column.  CLVs and scalers are stored
+ * per class (at the front of the ordinary buffers); tips get a small per-code
+ * table.  The arithmetic per class is update_one's, so every value -- and the
+ * log-likelihood -- is bit-identical to the plain loop's (tests/test_oracle_golden.py).
+ *
+ * This is bench.py's HONEST CPU comparator (cpu_baseline.with_site_repeats): what
+ * one `rd` rank really executes per evaluation, class bookkeeping included.  A
+ * partition driven through these two calls holds per-class buffers: do not mix
+ * them with the plain calls inside one traversal. */
+#define ORC_REPEATS_LOOKUP_SIZE 2000000u
+
+typedef struct {
+  unsigned int *site_id;       /* [S] class of every column */
+  unsigned int *rep1, *rep2;   /* [n] per class: the children's classes (inner nodes) */
+  unsigned int n;              /* classes */
+} orc_rep_node;
+
+struct orc_repeats {
+  orc_rep_node *node;          /* tips + clv_buffers */
+  double      **tipclv;        /* [tips] per-class tip CLVs [n][R][K] */
+  unsigned int *lookup;        /* ORC_REPEATS_LOOKUP_SIZE entries, all 0 between calls */
+  unsigned long long class_ops, plain_ops;   /* classes computed / columns a plain loop would have */
+};
+
+static void orc_repeats_free(orc_partition_t *p) {
+  struct orc_repeats *r = p->rep;
+  if (!r) return;
+  for (unsigned int i = 0; i < p->tips + p->clv_buffers; ++i) {
+    free(r->node[i].site_id); free(r->node[i].rep1); free(r->node[i].rep2);
+  }
+  for (unsigned int i = 0; i < p->tips; ++i) free(r->tipclv[i]);
+  free(r->node); free(r->tipclv); free(r->lookup); free(r);
+  p->rep = NULL;
+}
+
+static struct orc_repeats *orc_repeats_get(orc_partition_t *p) {
+  if (p->rep) return p->rep;
+  const unsigned int K = p->states, R = p->rate_cats, S = p->sites, N = p->tips + p->clv_buffers;
+  struct orc_repeats *r = (struct orc_repeats *)calloc(1, sizeof(*r));
+  r->node = (orc_rep_node *)calloc(N, sizeof(orc_rep_node));
+  r->tipclv = (double **)calloc(p->tips ? p->tips : 1, sizeof(double *));
+  r->lookup = (unsigned int *)calloc(ORC_REPEATS_LOOKUP_SIZE, sizeof(unsigned int));
+  for (unsigned int i = 0; i < N; ++i) {
+    r->node[i].site_id = (unsigned int *)calloc(S ? S : 1, sizeof(unsigned int));
+    if (i >= p->tips) {
+      r->node[i].rep1 = (unsigned int *)calloc(S ? S : 1, sizeof(unsigned int));
+      r->node[i].rep2 = (unsigned int *)calloc(S ? S : 1, sizeof(unsigned int));
+    }
+  }
+  /* tips: one class per distinct state set (the 0/1 vector of rate 0 read as a bit mask);
+   * more than 2^20 distinct sets (K > 20 with wild data) cannot happen for K <= 20 */
+  const size_t span = (size_t)R * K;
+  for (unsigned int t = 0; t < p->tips; ++t) {
+    orc_rep_node *nd = &r->node[t];
+    unsigned int *first = (unsigned int *)calloc(S ? S : 1, sizeof(unsigned int));   /* class -> a column that shows it */
+    unsigned long long *mask_of = (unsigned long long *)calloc(S ? S : 1, sizeof(unsigned long long));
+    nd->n = 0;
+    for (unsigned int s = 0; s < S; ++s) {
+      unsigned long long mask = 0;
+      for (unsigned int j = 0; j < K && j < 64; ++j)
+        if (p->clv[t][s * span + j] != 0.0) mask |= 1ull << j;
+      unsigned int c = 0;
+      for (; c < nd->n; ++c)   /* (a handful of classes: linear search) */
+        if (mask_of[c] == mask) break;
+      if (c == nd->n) { mask_of[c] = mask; first[c] = s; ++nd->n; }
+      nd->site_id[s] = c;
+    }
+    r->tipclv[t] = (double *)calloc((size_t)(nd->n ? nd->n : 1) * span, sizeof(double));
+    for (unsigned int c = 0; c < nd->n; ++c)
+      memcpy(r->tipclv[t] + c * span, p->clv[t] + (size_t)first[c] * span, span * sizeof(double));
+    free(first); free(mask_of);
+  }
+  p->rep = r;
+  return r;
+}
+
+/* classes of the parent from its children's (libpll-2: pll_update_repeats) */
+static void repeats_classes(orc_partition_t *p, struct orc_repeats *r, const orc_operation_t *op) {
+  const unsigned int S = p->sites;
+  orc_rep_node *pn = &r->node[op->parent_clv_index];
+  const orc_rep_node *a = &r->node[op->child1_clv_index], *b = &r->node[op->child2_clv_index];
+  if ((unsigned long long)a->n * b->n > ORC_REPEATS_LOOKUP_SIZE) {   /* no table: one class per column */
+    pn->n = S;
+    for (unsigned int s = 0; s < S; ++s) {
+      pn->site_id[s] = s; pn->rep1[s] = a->site_id[s]; pn->rep2[s] = b->site_id[s];
+    }
+    return;
+  }
+  unsigned int n = 0;
+  for (unsigned int s = 0; s < S; ++s) {
+    const unsigned int key = a->site_id[s] * b->n + b->site_id[s];
+    unsigned int id = r->lookup[key];
+    if (!id) {
+      pn->rep1[n] = a->site_id[s]; pn->rep2[n] = b->site_id[s];
+      id = r->lookup[key] = ++n;
+    }
+    pn->site_id[s] = id - 1;
+  }
+  for (unsigned int c = 0; c < n; ++c) r->lookup[pn->rep1[c] * b->n + pn->rep2[c]] = 0;   /* leave the table clean */
+  pn->n = n;
+}
+
+static void update_one_repeats(orc_partition_t *p, struct orc_repeats *r, const orc_operation_t *op, int avx2) {
+  const unsigned int K = p->states, R = p->rate_cats;
+  repeats_classes(p, r, op);
+  const orc_rep_node *pn = &r->node[op->parent_clv_index];
+  double *parent = p->clv[op->parent_clv_index];
+  const double *left = op->child1_clv_index < p->tips ? r->tipclv[op->child1_clv_index] : p->clv[op->child1_clv_index];
+  const double *right = op->child2_clv_index < p->tips ? r->tipclv[op->child2_clv_index] : p->clv[op->child2_clv_index];
+  const double *lm = p->pmatrix[op->child1_matrix_index];
+  const double *rm = p->pmatrix[op->child2_matrix_index];
+  unsigned int *psc = op->parent_scaler_index == ORC_SCALE_BUFFER_NONE ? NULL : p->scaler[op->parent_scaler_index];
+  const unsigned int *lsc = op->child1_scaler_index == ORC_SCALE_BUFFER_NONE ? NULL : p->scaler[op->child1_scaler_index];
+  const unsigned int *rsc = op->child2_scaler_index == ORC_SCALE_BUFFER_NONE ? NULL : p->scaler[op->child2_scaler_index];
+  const size_t span = (size_t)R * K;
+  r->class_ops += pn->n;
+  r->plain_ops += p->sites;
+#if defined(__AVX2__)
+  if (avx2 && K == 4) {
+    __m256d *lcol = (__m256d *)aligned_alloc(32, sizeof(__m256d) * 8 * R);
+    __m256d *rcol = lcol + 4 * R;
+    for (unsigned int q = 0; q < R; ++q)
+      for (unsigned int j = 0; j < 4; ++j) {
+        const double *a = lm + (size_t)q * 16, *b = rm + (size_t)q * 16;
+        lcol[q * 4 + j] = _mm256_set_pd(a[12 + j], a[8 + j], a[4 + j], a[j]);
+        rcol[q * 4 + j] = _mm256_set_pd(b[12 + j], b[8 + j], b[4 + j], b[j]);
+      }
+    const __m256d thr = _mm256_set1_pd(ORC_SCALE_THRESHOLD), fac = _mm256_set1_pd(ORC_SCALE_FACTOR);
+    for (unsigned int c = 0; c < pn->n; ++c) {
+      double *pc = parent + c * span;
+      const double *lc = left + pn->rep1[c] * span, *rc = right + pn->rep2[c] * span;
+      int all_small = 0xF;
+      for (unsigned int q = 0; q < R; ++q) {
+        __m256d ta = _mm256_setzero_pd(), tb = _mm256_setzero_pd();
+        for (unsigned int j = 0; j < 4; ++j) {
+          ta = _mm256_add_pd(ta, _mm256_mul_pd(lcol[q * 4 + j], _mm256_broadcast_sd(lc + q * 4 + j)));
+          tb = _mm256_add_pd(tb, _mm256_mul_pd(rcol[q * 4 + j], _mm256_broadcast_sd(rc + q * 4 + j)));
+        }
+        const __m256d v = _mm256_mul_pd(ta, tb);
+        _mm256_storeu_pd(pc + q * 4, v);
+        all_small &= _mm256_movemask_pd(_mm256_cmp_pd(v, thr, _CMP_LT_OQ));
+      }
+      if (psc) {
+        unsigned int sc = (lsc ? lsc[pn->rep1[c]] : 0u) + (rsc ? rsc[pn->rep2[c]] : 0u);
+        if (all_small == 0xF) {
+          for (unsigned int q = 0; q < R; ++q)
+            _mm256_storeu_pd(pc + q * 4, _mm256_mul_pd(_mm256_loadu_pd(pc + q * 4), fac));
+          sc += 1;
+        }
+        psc[c] = sc;
+      }
+    }
+    free(lcol);
+    return;
+  }
+#else
+  (void)avx2;
+#endif
+  for (unsigned int c = 0; c < pn->n; ++c) {   /* update_one's loop body, per class */
+    double *pc = parent + c * span;
+    const double *lc = left + pn->rep1[c] * span, *rc = right + pn->rep2[c] * span;
+    int scaling = psc ? 1 : 0;
+    if (psc) psc[c] = (lsc ? lsc[pn->rep1[c]] : 0u) + (rsc ? rsc[pn->rep2[c]] : 0u);
+    for (unsigned int q = 0; q < R; ++q) {
+      const double *lmat = lm + (size_t)q * K * K, *rmat = rm + (size_t)q * K * K;
+      for (unsigned int i = 0; i < K; ++i) {
+        double ta = 0.0, tb = 0.0;
+        for (unsigned int j = 0; j < K; ++j) {
+          ta += lmat[i * K + j] * lc[q * K + j];
+          tb += rmat[i * K + j] * rc[q * K + j];
+        }
+        const double v = ta * tb;
+        pc[q * K + i] = v;
+        scaling = scaling && (v < ORC_SCALE_THRESHOLD);
+      }
+    }
+    if (scaling) {
+      for (size_t i = 0; i < span; ++i) pc[i] *= ORC_SCALE_FACTOR;
+      psc[c] += 1;
+    }
+  }
+}
+
+void orc_update_clvs_repeats(orc_partition_t *p, const orc_operation_t *ops, unsigned int count, int avx2) {
+  struct orc_repeats *r = orc_repeats_get(p);
+  for (unsigned int i = 0; i < count; ++i) update_one_repeats(p, r, &ops[i], avx2);
+}
+
+/* orc_compute_root_loglikelihood on the per-class buffers orc_update_clvs_repeats left:
+ * the same terms in the same (column) order */
+double orc_compute_root_loglikelihood_repeats(orc_partition_t *p, unsigned int clv_index, int scaler_index,
+                                              const unsigned int *freqs_indices) {
+  struct orc_repeats *r = orc_repeats_get(p);
+  const unsigned int K = p->states, R = p->rate_cats;
+  const orc_rep_node *nd = &r->node[clv_index];
+  const double *base = p->clv[clv_index];
+  const unsigned int *sc = scaler_index == ORC_SCALE_BUFFER_NONE ? NULL : p->scaler[scaler_index];
+  const double log_thr = log(ORC_SCALE_THRESHOLD);
+  const size_t span = (size_t)R * K;
+  double logl = 0.0;
+  for (unsigned int s = 0; s < p->sites; ++s) {
+    const unsigned int c = nd->site_id[s];
+    const double *clv = base + c * span;
+    double term = 0.0;
+    for (unsigned int q = 0; q < R; ++q) {
+      const double *f = p->freqs[freqs_indices[q]];
+      double tr = 0.0;
+      for (unsigned int k = 0; k < K; ++k) tr += clv[k] * f[k];
+      term += tr * p->rate_weights[q];
+      clv += K;
+    }
+    term = log(term);
+    if (sc && sc[c]) term += sc[c] * log_thr;
+    term *= p->pattern_weights[s];
+    logl += term;
+  }
+  return logl;
+}
+
+/* classes computed / columns a plain loop would have computed, since the partition was created */
+double orc_repeats_ratio(const orc_partition_t *p) {
+  return p->rep && p->rep->plain_ops ? (double)p->rep->class_ops / (double)p->rep->plain_ops : 1.0;
 }
 
 /* ---- root log-likelihood (row a3; Appendix A5) --------------------------- */

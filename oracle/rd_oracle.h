@@ -102,6 +102,20 @@ double orc_compute_root_loglikelihood(orc_partition_t    *p,
                                       const unsigned int *freqs_indices,
                                       double             *persite_lnl);
 
+/* The same traversal WITH subtree site repeats (the reference sets
+ * CORAX_ATTRIB_SITE_REPEATS for 4-state data, src/model.cpp:145-149): every node's
+ * CLV is computed once per class of alignment columns that agree at all tips below
+ * it (libpll-2's pll_update_repeats scheme, restated in rd_oracle.c).  Values and
+ * log-likelihood are bit-identical to the plain calls'; the buffers hold per-class
+ * data afterwards, so a traversal uses either these two calls or the plain ones.
+ * avx2 != 0: the 256-bit-vector inner loop for 4 states.  bench.py's honest CPU
+ * comparator (cpu_baseline.with_site_repeats). */
+void orc_update_clvs_repeats(orc_partition_t *p, const orc_operation_t *ops, unsigned int count, int avx2);
+double orc_compute_root_loglikelihood_repeats(orc_partition_t *p, unsigned int clv_index, int scaler_index,
+                                              const unsigned int *freqs_indices);
+/* classes computed / columns a plain loop would have computed so far (1.0: no repeats found) */
+double orc_repeats_ratio(const orc_partition_t *p);
+
 /* raw views for parity tests */
 const double       *orc_get_clv(const orc_partition_t *p, unsigned int idx);
 const unsigned int *orc_get_scaler(const orc_partition_t *p, unsigned int idx);

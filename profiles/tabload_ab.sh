@@ -1,0 +1,14 @@
+#!/bin/bash
+# A/B on ONE box: the fused evaluator's table loads as round 4 had them (two asm statements per
+# step, M0 saved / restored, offsets computed in the loop: tmp_libs/old.so, an ablation build with
+# -DRDAMD_ABL_OLD_TABLOAD) against round 5's single statement (tmp_libs/new.so = the product library).
+one() {
+  python bench.py "$@" --no-cpu-baseline --allow-stale-profile --sustain-seconds 0 2>/dev/null | python -c "
+import sys,json
+d=json.loads(sys.stdin.read()); r=d['roofline']
+print('   %-28s %9.1f evals/s  kernel %8.4f ms  frac %.4f' % (' '.join(sys.argv[1:]), d['value'], r['avg_launch_ms'], r['frac']))" "$@"
+}
+LIBS="old new"   # old = the product form (round 4), new = -DRDAMD_ABL_ONE_TABLOAD: build both into profiles/tmp_libs first CMD='one --steps 20 --warmup 3; one --config c4 --sites 62500 --steps 4 --warmup 1; one --config c5 --sites 50000 --steps 4 --warmup 1; one --config d125 --steps 20 --warmup 3'
+cp root_digger_amd/lib/librdamd.so /tmp/librdamd_keep.so
+for rep in 1 2; do for l in $LIBS; do cp profiles/tmp_libs/$l.so root_digger_amd/lib/librdamd.so; echo "== $l"; eval "$CMD"; done; done
+cp /tmp/librdamd_keep.so root_digger_amd/lib/librdamd.so

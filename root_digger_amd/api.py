@@ -241,6 +241,7 @@ _sig("rdamd_model_lockstep_stats", None, C.c_void_p, C.POINTER(C.c_uint64))
 _sig("rdamd_model_set_lockstep_groups", None, C.c_void_p, _u)
 _sig("rdamd_model_set_lockstep_rounds", None, C.c_void_p, C.c_int)
 _sig("rdamd_model_round_stats", None, C.c_void_p, C.POINTER(C.c_uint64))
+_sig("rdamd_model_round_seconds", None, C.c_void_p, _pd)
 _sig("rdamd_model_set_lockstep_priority", None, C.c_void_p, C.c_int)
 _sig("rdamd_model_set_root_children_only", None, C.c_void_p, C.c_int)
 _sig("rdamd_partition_set_stream_priority", C.c_int, _vp, C.c_int)
@@ -1350,7 +1351,11 @@ class Model:
         """the last search in rounds + this model's own collectives (rdamd_model_round_stats)."""
         out = (C.c_uint64 * 4)()
         lib.rdamd_model_round_stats(self._h, out)
-        return dict(zip(("rounds", "collectives", "redos", "own_collectives"), (int(v) for v in out)))
+        sec = (C.c_double * 4)()
+        lib.rdamd_model_round_seconds(self._h, sec)
+        d = dict(zip(("rounds", "collectives", "redos", "own_collectives"), (int(v) for v in out)))
+        d["seconds"] = dict(zip(("objective_queued", "root_launch", "sum_queued", "waiting"), (float(v) for v in sec)))
+        return d
 
     def set_root_children_only(self, on):
         """the searches' compute_lh in front of the root-only steps: True (default) = one fused job

@@ -91,6 +91,16 @@ struct rdamd_partition {
            prob_matrices = 0, rate_cats = 0, scale_buffers = 0, attributes = 0;
   int device = 0;
   hipStream_t stream = nullptr;
+  // Something may be queued on `stream` that no host-side wait has covered yet.  Set by
+  // everything that queues there (uploads, launches), cleared where the host has waited for the
+  // stream (rdamd::sync_main).  rdamd_root_loglikelihood_fused_multi reads the partitions of MANY
+  // streams from one launch on the leader's: it waits only for the streams that are dirty -- the
+  // root-only steps of 32 candidates in lock step cost 32 stream synchronisations per launch
+  // before, nearly all of them on idle streams.
+  std::atomic<bool> stream_dirty{true};
+  // rdamd_partition_stream() has handed the stream out: the caller may queue on it what the
+  // library never sees -- always treated as dirty from then on
+  std::atomic<bool> stream_external{false};
 
   // ---- HBM-resident state ------------------------------------------------
   uint8_t  *d_tipcodes = nullptr;
@@ -198,9 +208,17 @@ struct rdamd_partition {
 
 namespace rdamd {
 
+// the partition's own stream, waited for on the host
+inline hipError_t sync_main(rdamd_partition *p) {
+  // (cleared BEFORE the wait: what another thread queues while we wait marks it again)
+  p->stream_dirty = false;
+  const hipError_t e = hipStreamSynchronize(p->stream);
+  if (e != hipSuccess) p->stream_dirty = true;
+  return e;
+}
 // everything queued for the partition, pipelined batches' front halves included
 inline hipError_t sync_streams(rdamd_partition *p) {
-  hipError_t e = hipStreamSynchronize(p->stream);
+  hipError_t e = sync_main(p);
   if (e == hipSuccess && p->stream_pre) e = hipStreamSynchronize(p->stream_pre);
   return e;
 }

@@ -50,9 +50,9 @@ struct rdamd_schedule {
 
 namespace rdamd {
 
-// doubles in front of the tables: the 64-row evaluator's buffer descriptor starts 1 KB
-// before a job's tables (kernels_fused.hip, RDAMD_LOAD_TAB)
-constexpr size_t kTiptabPad = 128;
+// doubles in front of the tables: the 64-row evaluator's buffer descriptor starts kFusedDmaBias
+// bytes before a job's tables (kernels_fused.hip, RDAMD_LOAD_TABS64)
+constexpr size_t kTiptabPad = kFusedDmaBias / 8;
 
 struct FusedWorkspace {
   unsigned cap_jobs = 0, blocks_x = 0;
@@ -290,6 +290,7 @@ static rdamd_schedule_t *schedule_create_impl(rdamd_partition_t *p, const rdamd_
     c.pseudo_row = pseudo_row;
     c.pseudo_wide = pseudo_wide;
     c.wide_base = 8u * p->prob_matrices * p->rate_cats * 16u;
+    c.dma_offsets = !k20 && wide_mode;
     if (!k20) {   // the steps that compute the root operation's inner children (fused.hpp, 0x8000 / 0x10000)
       const rdamd_operation_t &root = list.back();
       if (root.child1_clv_index >= p->tips) c.mark_clv[0] = root.child1_clv_index;
@@ -689,6 +690,7 @@ static int batch_submit_impl(rdamd_partition_t *p, FusedWorkspace *&slot, bool p
     const size_t in_bytes = (size_t)n_jobs * (sizeof(FusedJob) + sizeof(double) * (K * K + K + 2 * R));
     memset(w->h_in + in_bytes, 0, 8);   // the any-unsafe word behind the block
     w->d_any_unsafe = (unsigned *)(w->d_in + in_bytes);
+    p->stream_dirty = true;
     RDAMD_HIP_TRY(hipMemcpyAsync(w->d_in, w->h_in, in_bytes + 8, hipMemcpyHostToDevice, pre), RDAMD_FAILURE);
     w->d_jobs = (FusedJob *)(w->d_in + ((char *)hj - w->h_in));
     w->d_q = (double *)(w->d_in + ((char *)hq - w->h_in));
@@ -899,7 +901,7 @@ static int batch_wait(rdamd_partition_t *p, FusedWorkspace *w, bool pipelined, d
   };
 #define WAIT_TRY(expr) RDAMD_HIP_TRY(expr, failed())
   if (pipelined) WAIT_TRY(hipEventSynchronize(w->ev_done));
-  else WAIT_TRY(hipStreamSynchronize(p->stream));
+  else WAIT_TRY(sync_main(p));
   const unsigned *h_flag = (const unsigned *)(w->h_out + w->cap_jobs);
   if (!pd.k20 && *h_flag) {
     hipError_t e = hipSuccess;

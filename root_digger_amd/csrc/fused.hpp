@@ -34,8 +34,15 @@ struct FusedOp {
                          // 0x800 park in register level 1 | 0x1000 pop it (4-state programs compiled for two)
                          // | 0x2000 / 0x4000 X / Y table has 64 rows | 0x8000 / 0x10000 this step computes the
                          // root operation's child 1 / child 2 (read by the exporting variant only)
+  // 4-state programs compiled for 64-row table slots: the SCALAR OFFSETS of the LDS-DMA loads
+  // that bring the X / Y operand's table of rate 0 into its slot -- tX * 4 + kFusedDmaBias, and
+  // for Y minus kFusedDmaYSlot: the evaluator reaches the Y slot through the instruction offset,
+  // which moves the source address along (kernels_fused.hip, RDAMD_LOAD_TABS64).
+  // 20-state programs: the tip children's table offsets.
   uint32_t pad[2];
 };
+constexpr uint32_t kFusedDmaBias = 4096;    // the tables' buffer descriptor starts this far in front of them
+constexpr uint32_t kFusedDmaYSlot = 2048;   // LDS byte offset of a wave's Y slot at 64 rows (32 TR)
 
 struct CladeStep;
 struct CladeGroup;

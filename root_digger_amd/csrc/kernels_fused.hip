@@ -370,19 +370,20 @@ fused_dna_eval_kernel(FusedArgs a) {
   // per-operation part of every address is a scalar offset, the per-lane part
   // a loop-invariant VGPR, so address generation costs no vector instruction
   const __amdgpu_buffer_rsrc_t tips_rs = make_rsrc(a.tipcodes, a.tipcodes_bytes);
-  // (TR = 64: 1 KB in front of the job's tables, see RDAMD_LOAD_TAB; the workspace has that pad)
+  // (TR = 64: kFusedDmaBias bytes in front of the job's tables, see RDAMD_LOAD_TABS64; the workspace has that pad)
   const __amdgpu_buffer_rsrc_t tab_rs =
-      make_rsrc(reinterpret_cast<const char *>(a.tiptab + (size_t)job * a.tiptab_job_stride) - (TR == 16 ? 0 : 1024),
-                (unsigned)(a.tiptab_job_stride * 8) + (TR == 16 ? 0u : 1024u));
-  // (the tables' descriptor as four dwords, for the asm block in RDAMD_LOAD_TAB)
+      make_rsrc(reinterpret_cast<const char *>(a.tiptab + (size_t)job * a.tiptab_job_stride) - (TR == 16 ? 0 : kFusedDmaBias),
+                (unsigned)(a.tiptab_job_stride * 8) + (TR == 16 ? 0u : kFusedDmaBias));
+  // (the tables' descriptor as four dwords, for the asm block in RDAMD_LOAD_TABS64)
   typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
   const unsigned long long tab_base = reinterpret_cast<unsigned long long>(
-      reinterpret_cast<const char *>(a.tiptab + (size_t)job * a.tiptab_job_stride) - (TR == 16 ? 0 : 1024));
+      reinterpret_cast<const char *>(a.tiptab + (size_t)job * a.tiptab_job_stride) - (TR == 16 ? 0 : kFusedDmaBias));
   const u32x4_t tab_desc = {uni((unsigned)tab_base), uni((unsigned)(tab_base >> 32)),
-                            uni((unsigned)(a.tiptab_job_stride * 8) + (TR == 16 ? 0u : 1024u)), 0x00020000u};
+                            uni((unsigned)(a.tiptab_job_stride * 8) + (TR == 16 ? 0u : kFusedDmaBias)), 0x00020000u};
   const int lane8 = (int)lane * 8, lane16 = (int)lane * 16;
   const int lane4 = (int)lane * 4;
-  static_assert(TR == 16 || TR == 64, "RDAMD_LOAD_TAB's asm spells out the half-table offset of 64-row slots");
+  static_assert(TR == 16 || TR == 64, "RDAMD_LOAD_TABS64's asm spells out the slot offsets of 64-row slots");
+  static_assert(kFusedDmaYSlot == 32u * 64u, "... the Y slot's among them");
   static_assert(kFusedTT == 0 && kFusedRP == 2, "... and the step kinds it skips an operand for");
   // where this lane's entry of a 16-row table (code lane / 4, state lane % 4) goes in LDS: see read_row
   const unsigned tab_wr = wbase + ((lane & 2u) ? 16u * TR : 0u) + (lane >> 2) * 16u + (lane & 1u) * 8u;
@@ -415,6 +416,7 @@ fused_dna_eval_kernel(FusedArgs a) {
     }
     unsigned sp = 0;
     const unsigned roff = uni(r * 128u);   // byte offset of rate r inside a matrix slot
+    const unsigned roff4 = uni(r * 512u), roff16 = uni(r * 2048u);   // ... inside a 16-row / a 64-row table
     // Software pipeline, unrolled by two with ping-pong register sets (A/B) so
     // that no prefetched value is ever copied at the loop edge (a copy would
     // force the wait for the prefetch into the same iteration): while op i
@@ -439,15 +441,73 @@ fused_dna_eval_kernel(FusedArgs a) {
     // A 16-row table's second half sits 256 bytes behind the first in memory but 16 TR bytes
     // behind it in the slot (the instruction offset moves source AND destination,
     // profiles/micro/lds_dma_offset.hip; the scalar offset makes up the difference, which is
-    // why the descriptor starts 1 KB in front of the job's tables).  The wait in front: this
+    // why the descriptor starts kFusedDmaBias bytes in front of the job's tables).  The wait in front: this
     // operation's own rows must have left the slots before new tables land in them.
+#define RDAMD_LOAD_TAB16(op, tOFF, e)                                                           \
+  e = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(                          \
+      tab_rs, lane8, (int)((uni(op.tOFF) + roff) * 4u), 0));
+    // TR = 64, BOTH operands in one statement (round 5: the scalar side on a diet -- the step
+    // issued 40 scalar instructions for 40 FP64 ones, two thirds of them here).  M0, the LDS base
+    // of an LDS-DMA load, is set ONCE, to the wave's slot base: the Y slot and the second half of
+    // a table are reached through the instruction offset, which moves source and destination
+    // alike -- the host has taken the Y slot's 2 KB off the Y operand's scalar offset
+    // (FusedOp::pad, traversal_compiler.hpp; the descriptor starts kFusedDmaBias bytes in front of
+    // the job's tables so that no offset goes negative).  M0 is a reserved register to the
+    // compiler (never allocated: it sets it right in front of each of its own uses), so it is
+    // neither saved nor restored.  The per-rate part of the offset is one s_add inside the arm
+    // that knows the table's size.
+#define RDAMD_LOAD_TABS64(op)                                                                   \
+  {                                                                                             \
+    unsigned t0;                                                                                \
+    asm volatile(                                                                               \
+        "s_cmp_eq_u32 %[kind], 2\n\t"   /* the step pops: no table at all */                  \
+        "s_cbranch_scc1 9f\n\t"                                                               \
+        "s_mov_b32 m0, %[wb]\n\t"                                                             \
+        "s_bitcmp1_b32 %[fl], 14\n\t"   /* 0x4000: Y has 64 rows */                           \
+        "s_cbranch_scc1 1f\n\t"                                                               \
+        "s_add_u32 %[t0], %[soy], %[r4]\n\t"                                                  \
+        "buffer_load_dword %[vo4], %[rs], %[t0] offen offset:2048 lds\n\t"                    \
+        "s_sub_u32 %[t0], %[t0], 0x300\n\t"                                                   \
+        "buffer_load_dword %[vo4], %[rs], %[t0] offen offset:3072 lds\n\t"                    \
+        "s_branch 2f\n"                                                                        \
+        "1:\n\t"                                                                              \
+        "s_add_u32 %[t0], %[soy], %[r16]\n\t"                                                 \
+        "buffer_load_dwordx4 %[vo16], %[rs], %[t0] offen offset:2048 lds\n\t"                 \
+        "buffer_load_dwordx4 %[vo16], %[rs], %[t0] offen offset:3072 lds\n"                    \
+        "2:\n\t"                                                                              \
+        "s_cmp_lg_u32 %[kind], 0\n\t"   /* X: tip-tip steps only */                           \
+        "s_cbranch_scc1 9f\n\t"                                                               \
+        "s_bitcmp1_b32 %[fl], 13\n\t"   /* 0x2000: X has 64 rows */                           \
+        "s_cbranch_scc1 3f\n\t"                                                               \
+        "s_add_u32 %[t0], %[sox], %[r4]\n\t"                                                  \
+        "buffer_load_dword %[vo4], %[rs], %[t0] offen lds\n\t"                                \
+        "s_sub_u32 %[t0], %[t0], 0x300\n\t"                                                   \
+        "buffer_load_dword %[vo4], %[rs], %[t0] offen offset:1024 lds\n\t"                    \
+        "s_branch 9f\n"                                                                        \
+        "3:\n\t"                                                                              \
+        "s_add_u32 %[t0], %[sox], %[r16]\n\t"                                                 \
+        "buffer_load_dwordx4 %[vo16], %[rs], %[t0] offen lds\n\t"                             \
+        "buffer_load_dwordx4 %[vo16], %[rs], %[t0] offen offset:1024 lds\n"                    \
+        "9:"                                                                                    \
+        : [t0] "=&s"(t0)                                                                        \
+        : [kind] "s"(uni(op.flags) & 3u), [fl] "s"(uni(op.flags)), [wb] "s"(wbase),             \
+          [sox] "s"(uni(op.pad[0])), [soy] "s"(uni(op.pad[1])), [r4] "s"(roff4), [r16] "s"(roff16), \
+          [vo4] "v"(lane4), [vo16] "v"(lane16), [rs] "s"(tab_desc)                              \
+        : "memory", "scc");                                                                     \
+  }
+    // THE PRODUCT'S FORM: one statement per operand, M0 saved and restored around it, the offsets
+    // worked out in the loop -- 15 scalar instructions per step more than RDAMD_LOAD_TABS64 above
+    // and 1.5 - 2 % FASTER on c2 and c5's shard, equal on c4's and 125.phy (same box, two rounds
+    // each: profiles/r5_tabload_ab.txt; the ISA budget: profiles/r5_fused_step_isa.md).  The scalar
+    // unit is not what a step waits for.  RDAMD_LOAD_TABS64 stays for the A/B (ablation builds,
+    // -DRDAMD_ABL_ONE_TABLOAD).
 #define RDAMD_LOAD_TAB(op, SLOT, WIDE, tOFF, e, SKIP_IF)                                        \
   if (TR == 16) {                                                                               \
     e = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(                         \
         tab_rs, lane8, (int)((uni(op.tOFF) + roff) * 4u), 0));                                  \
   } else {                                                                                      \
     const unsigned wide = uni(op.flags) & WIDE;                                                 \
-    const int so = (int)((uni(op.tOFF) + (wide ? roff * 4u : roff)) * 4u) + 1024;               \
+    const int so = (int)((uni(op.tOFF) + (wide ? roff * 4u : roff)) * 4u) + (int)kFusedDmaBias; \
     unsigned m0_saved;                                                                          \
     asm volatile(                                                                               \
         SKIP_IF "\n\t"   /* an operand the step does not have: nothing to load */               \
@@ -470,14 +530,26 @@ fused_dna_eval_kernel(FusedArgs a) {
           [so] "s"(so), [so2] "s"(so - 768), [kind] "s"(uni(op.flags) & 3u)                     \
         : "memory", "scc");                                                                     \
   }
+#if !(defined(RDAMD_ABLATION) && defined(RDAMD_ABL_ONE_TABLOAD))
+#define RDAMD_LOAD_TABS(op, ex, ey) \
+  if (TR > 16) __builtin_amdgcn_s_waitcnt(0xc07f);   /* lgkmcnt(0) */                           \
+  RDAMD_LOAD_TAB(op, 0u, 0x2000u, tX, ex, "s_cmp_lg_u32 %[kind], 0")       /* X: tip-tip steps only */ \
+  RDAMD_LOAD_TAB(op, kYSlot, 0x4000u, tY, ey, "s_cmp_eq_u32 %[kind], 2")   /* Y: not when the step pops */
+#else
+#define RDAMD_LOAD_TABS(op, ex, ey) \
+  if (TR > 16) {                                                                                \
+    __builtin_amdgcn_s_waitcnt(0xc07f);   /* lgkmcnt(0) */                                      \
+    RDAMD_LOAD_TABS64(op)                                                                       \
+  } else {                                                                                      \
+    RDAMD_LOAD_TAB16(op, tX, ex) RDAMD_LOAD_TAB16(op, tY, ey)                                   \
+  }
+#endif
 #define RDAMD_LOAD_TIPS(op, cx, cy, ex, ey)                                                     \
   _Pragma("unroll") for (int q = 0; q < NS; ++q) {                                              \
     cx[q] = load_code<TR>(tips_rs, site_off[q], (int)uni(op.cX)) | wbase;                       \
     cy[q] = load_code<TR>(tips_rs, site_off[q], (int)uni(op.cY)) | wbase;                       \
   }                                                                                             \
-  if (TR > 16) __builtin_amdgcn_s_waitcnt(0xc07f);   /* lgkmcnt(0) */                           \
-  RDAMD_LOAD_TAB(op, 0u, 0x2000u, tX, ex, "s_cmp_lg_u32 %[kind], 0")       /* X: tip-tip steps only */ \
-  RDAMD_LOAD_TAB(op, kYSlot, 0x4000u, tY, ey, "s_cmp_eq_u32 %[kind], 2")   /* Y: not when the step pops */
+  RDAMD_LOAD_TABS(op, ex, ey)
     // (TR = 64: the descriptor of the operation after next only now -- fetched at the top of
     // the step it would sit in front of the wait above)
 #define RDAMD_LATE_DESC(cur, idx2) if (TR > 16) cur = load_const(prog + (idx2));

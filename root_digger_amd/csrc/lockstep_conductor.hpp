@@ -41,7 +41,10 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <stdexcept>
@@ -127,7 +130,13 @@ public:
   }
 
   // rounds closed, collectives queued, objective launches / their jobs, root launches / their steps
-  struct stats_t { uint64_t rounds = 0, collectives = 0, obj_launches = 0, obj_jobs = 0, root_launches = 0, root_steps = 0, redos = 0; };
+  // seconds[]: host time of the rounds' phases, summed: [0] the objective batch queued, [1] the
+  // root-only launch (blocking), [2] the sum queued (host reducer: batch waited for and summed),
+  // [3] waiting for the round's event and handing out the results
+  struct stats_t {
+    uint64_t rounds = 0, collectives = 0, obj_launches = 0, obj_jobs = 0, root_launches = 0, root_steps = 0, redos = 0;
+    double seconds[4] = {0, 0, 0, 0};
+  };
   stats_t stats() const {
     std::lock_guard<std::mutex> lk(_mu);
     return _stats;
@@ -198,7 +207,17 @@ private:
         _cv.notify_all();
         continue;
       }
-      _cv.wait(lk);
+      if (!_debug) {
+        _cv.wait(lk);
+      } else if (_cv.wait_for(lk, std::chrono::seconds(20)) == std::cv_status::timeout) {
+        // RDAMD_LOCKSTEP_DEBUG: who is everybody waiting for?
+        std::fprintf(stderr, "[lockstep] worker %u (group %u, kind %d) still waiting: turn %u", req.worker, g, (int)req.kind, _turn);
+        for (unsigned k = 0; k < _c.n_groups; ++k) {
+          std::fprintf(stderr, " | group %u live %u busy %d posted", k, _g[k].live, (int)_g[k].busy);
+          for (const request_t *r : _g[k].posted) std::fprintf(stderr, " %u:%d", r->worker, (int)r->kind);
+        }
+        std::fprintf(stderr, " | rounds %llu next %zu/%zu\n", (unsigned long long)_stats.rounds, _next, _c.n_candidates);
+      }
     }
     if (!_error.empty() && req.kind != NEXT) throw std::runtime_error(_error);
   }
@@ -243,6 +262,13 @@ private:
       return;
     }
     lk.unlock();
+    double phase[4] = {0, 0, 0, 0};
+    auto t_mark = std::chrono::steady_clock::now();
+    auto lap = [&](int k) {
+      const auto now = std::chrono::steady_clock::now();
+      phase[k] += std::chrono::duration<double>(now - t_mark).count();
+      t_mark = now;
+    };
 
     // ---- the round's vector
     size_t m = 0, n_root = 0, n_red = 0;
@@ -275,6 +301,7 @@ private:
                                         rates.data(), weights.data());
       if (rc != RDAMD_SUCCESS) throw std::runtime_error(std::string("lock-step round: objective batch: ") + rdamd_errmsg());
     }
+    lap(0);
     // ---- the root positions: one launch over the candidates' own partitions, beside it
     if (!root.empty()) {
       constexpr unsigned P = RDAMD_ROOT_MAX_POSITIONS;
@@ -310,6 +337,7 @@ private:
       }
     }
 
+    lap(1);
     // ---- the sum over the site group
     double *res = grp.h_res;
     bool need_redo_check = false;
@@ -334,6 +362,7 @@ private:
       res = grp.h_in;
     }
 
+    lap(2);
     // ---- queued: the other group may go
     lk.lock();
     ++_stats.collectives;
@@ -374,7 +403,9 @@ private:
       at = o_red;
       for (request_t *r : red) { std::copy(res + at, res + at + r->n, r->out); at += r->n; }
     }
+    lap(3);
     lk.lock();
+    for (int k = 0; k < 4; ++k) _stats.seconds[k] += phase[k];
   }
 
   // the site group's sum over d[0 .. n), queued on the shared partition's stream
@@ -403,6 +434,7 @@ private:
   group_t _g[2];
   unsigned _turn = 0;
   size_t _next = 0;
+  const bool _debug = std::getenv("RDAMD_LOCKSTEP_DEBUG") != nullptr;
   std::string _error;
   stats_t _stats;
 };

@@ -43,6 +43,7 @@ struct rdamd_model {
   unsigned lockstep_groups = 0;   // 0: the library's choice; 1: one group, blocking launches (rdamd_model_set_lockstep_groups)
   uint64_t lockstep_stats[4] = {0, 0, 0, 0};   // of the last lock-stepped search (rdamd_model_lockstep_stats)
   uint64_t round_stats[3] = {0, 0, 0};         // ... in rounds: rounds, collectives, second-pass redos
+  double round_seconds[4] = {0, 0, 0, 0};      // ... and the host time of the rounds' phases
   struct async_reducer_t { rdamd_lnl_reducer_t queue; void *user; };   // rdamd_model_set_lnl_reducer_async
   std::unique_ptr<async_reducer_t> async_reducer;
   int lockstep_rounds = -1;       // -1: rounds for site-sharded models only; 0 never; 1 always (rdamd_model_set_lockstep_rounds)
@@ -557,6 +558,7 @@ static int search_in_rounds(rdamd_model_t *m, unsigned int workers, double atol,
     m->lockstep_stats[0] = st.obj_launches; m->lockstep_stats[1] = st.obj_jobs;
     m->lockstep_stats[2] = st.root_launches; m->lockstep_stats[3] = st.root_steps;
     m->round_stats[0] = st.rounds; m->round_stats[1] = st.collectives; m->round_stats[2] = st.redos;
+    for (int k = 0; k < 4; ++k) m->round_seconds[k] = st.seconds[k];
     if (!first_error.empty()) throw std::runtime_error(first_error);
     std::sort(results.begin(), results.end(),
               [](const rdamd::rd_result_t &a, const rdamd::rd_result_t &b) { return a.root_id < b.root_id; });
@@ -743,6 +745,9 @@ void rdamd_model_lockstep_stats(const rdamd_model_t *m, uint64_t out[4]) {
   for (int i = 0; i < 4; ++i) out[i] = m->lockstep_stats[i];
 }
 void rdamd_model_set_lockstep_rounds(rdamd_model_t *m, int mode) { m->lockstep_rounds = mode; }
+void rdamd_model_round_seconds(const rdamd_model_t *m, double out[4]) {
+  for (int i = 0; i < 4; ++i) out[i] = m->round_seconds[i];
+}
 void rdamd_model_round_stats(const rdamd_model_t *m, uint64_t out[4]) {
   for (int i = 0; i < 3; ++i) out[i] = m->round_stats[i];
   out[3] = m->model->collectives();

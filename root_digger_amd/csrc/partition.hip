@@ -51,6 +51,7 @@ static hipError_t upload(rdamd_partition *p, void *dst, const void *src, size_t 
   }
   void *st = stage_alloc(p, bytes);
   memcpy(st, src, bytes);
+  p->stream_dirty = true;
   return hipMemcpyAsync(dst, st, bytes, hipMemcpyHostToDevice, p->stream);
 }
 
@@ -98,6 +99,7 @@ static hipError_t flush_q(rdamd_partition *p) {
 }  // namespace rdamd
 
 hipEvent_t rdamd_partition::prof_begin(int kind) {
+  stream_dirty = true;   // (every launch of the partition passes here)
   if (!profiling) return nullptr;
   hipEvent_t ev[2];
   for (auto &e : ev) {
@@ -168,6 +170,7 @@ hipError_t scaler_phys(rdamd_partition *p, int scaler_index, int *phys) {
     }
     slot = (int)p->sc_slots_used++;
     // a scale buffer nobody has written reads as zeros, as in a dense partition
+    p->stream_dirty = true;
     hipError_t e = hipMemsetAsync(p->d_scaler + (size_t)slot * p->sites, 0, (size_t)p->sites * sizeof(unsigned), p->stream);
     if (e != hipSuccess) return e;
   }
@@ -552,7 +555,10 @@ double rdamd_partition_weight_sum(const rdamd_partition_t *p) {
   for (unsigned s = 0; s < p->sites; ++s) total += p->pattern_weights[s];
   return total;
 }
-void *rdamd_partition_stream(const rdamd_partition_t *p) { return (void *)p->stream; }
+void *rdamd_partition_stream(const rdamd_partition_t *p) {
+  const_cast<rdamd_partition_t *>(p)->stream_external = true;
+  return (void *)p->stream;
+}
 
 int rdamd_partition_set_stream_priority(rdamd_partition_t *p, int level) {
   clear_error();
@@ -803,7 +809,7 @@ void rdamd_update_clvs(rdamd_partition_t *p, const rdamd_operation_t *ops,
   const size_t padded = lops.size();
   hipError_t e = ensure_scratch(p, sizeof(LevelOp) * padded + 256);
   if (e == hipSuccess && p->tiptab_stale) {
-    e = launch_tiptab_all(p);
+    e = (p->stream_dirty = true, launch_tiptab_all(p));
     p->tiptab_stale = false;
   }
   Scratch sc{p};
@@ -986,7 +992,7 @@ int rdamd_root_loglikelihood_fused(rdamd_partition_t *p, const rdamd_operation_t
   root_op = &phys_root;
   RDAMD_HIP_TRY(flush_q(p), RDAMD_FAILURE);
   if (p->tiptab_stale) {
-    RDAMD_HIP_TRY(launch_tiptab_all(p), RDAMD_FAILURE);
+    RDAMD_HIP_TRY((p->stream_dirty = true, launch_tiptab_all(p)), RDAMD_FAILURE);
     p->tiptab_stale = false;
   }
   // One launch per chunk of up to eight positions (four at 8 rate categories;
@@ -1015,7 +1021,7 @@ int rdamd_root_loglikelihood_fused(rdamd_partition_t *p, const rdamd_operation_t
                                       p->d_counter, p->h_result);
     p->prof_end();
     RDAMD_HIP_TRY(e, RDAMD_FAILURE);
-    RDAMD_HIP_TRY(hipStreamSynchronize(p->stream), RDAMD_FAILURE);
+    RDAMD_HIP_TRY(sync_main(p), RDAMD_FAILURE);
     for (unsigned a = 0; a < n; ++a) lnl_out[base + a] = p->h_result[a];
   }
   return RDAMD_SUCCESS;
@@ -1097,12 +1103,12 @@ int rdamd_root_loglikelihood_fused_multi(unsigned int n_items, rdamd_partition_t
     }
     RDAMD_HIP_TRY(flush_q(p), RDAMD_FAILURE);
     if (p->tiptab_stale) {
-      RDAMD_HIP_TRY(launch_tiptab_all(p), RDAMD_FAILURE);
+      RDAMD_HIP_TRY((p->stream_dirty = true, launch_tiptab_all(p)), RDAMD_FAILURE);
       p->tiptab_stale = false;
     }
     // whatever this partition's own stream still has queued (parameter uploads just now) must
     // be done before the leader's stream reads it
-    if (p != lead) RDAMD_HIP_TRY(hipStreamSynchronize(p->stream), RDAMD_FAILURE);
+    if (p != lead && (p->stream_dirty || p->stream_external)) RDAMD_HIP_TRY(sync_main(p), RDAMD_FAILURE);
     it.v = p->view();
     it.op.parent_clv = o.parent_clv_index; it.op.child1_clv = o.child1_clv_index;
     it.op.child2_clv = o.child2_clv_index; it.op.child1_mat = o.child1_matrix_index;
@@ -1123,7 +1129,7 @@ int rdamd_root_loglikelihood_fused_multi(unsigned int n_items, rdamd_partition_t
   hipError_t e = launch_root_multi(d_items, n_items, R, max_pos, max_blocks, lead->stream);
   lead->prof_end();
   RDAMD_HIP_TRY(e, RDAMD_FAILURE);
-  RDAMD_HIP_TRY(hipStreamSynchronize(lead->stream), RDAMD_FAILURE);
+  RDAMD_HIP_TRY(sync_main(lead), RDAMD_FAILURE);
   for (unsigned i = 0; i < n_items; ++i)
     for (unsigned a = 0; a < n_positions[i]; ++a) out[8 * i + a] = h_res[8 * i + a];
   return RDAMD_SUCCESS;

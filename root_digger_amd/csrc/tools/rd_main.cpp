@@ -372,6 +372,8 @@ static int run(int argc, char **argv) {
     rdamd_model_lockstep_stats(model, ls);
     rdamd_model_round_stats(model, rs);
     rdamd_model_counters(model, ct);
+    double rsec[4] = {0, 0, 0, 0};
+    rdamd_model_round_seconds(model, rsec);
     const std::chrono::duration<double> took = std::chrono::steady_clock::now() - start;
     uint64_t digest = 1469598103934665603ull;   // FNV-1a over the bits of this rank's (id, lnL, alpha) triples
     auto mix = [&digest](const void *ptr, size_t n) {
@@ -380,11 +382,11 @@ static int run(int argc, char **argv) {
     for (unsigned i = 0; i < n_results; ++i) { mix(&ids[i], 8); mix(&llh[i], 8); mix(&alpha[i], 8); }
     std::fprintf(stderr, "[rank %d] stats: candidates=%u results_digest=%016llx lockstep=%d rounds=%llu collectives=%llu redos=%llu "
                          "own_collectives=%llu objective_launches=%llu objective_jobs=%llu root_launches=%llu "
-                         "root_steps=%llu seconds=%.3f\n",
+                         "root_steps=%llu round_seconds=%.2f/%.2f/%.2f/%.2f seconds=%.3f\n",
                  rank, n_results, (unsigned long long)digest, o.lockstep, (unsigned long long)rs[0], (unsigned long long)rs[1],
                  (unsigned long long)rs[2], (unsigned long long)rs[3],
                  (unsigned long long)(ls[0] ? ls[0] : ct[0]), (unsigned long long)(ls[1] ? ls[1] : ct[1]),
-                 (unsigned long long)ls[2], (unsigned long long)ls[3], took.count());
+                 (unsigned long long)ls[2], (unsigned long long)ls[3], rsec[0], rsec[1], rsec[2], rsec[3], took.count());
   }
   ranks.barrier();
   if (rank != 0) {

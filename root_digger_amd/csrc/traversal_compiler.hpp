@@ -31,6 +31,8 @@ struct Compiler {
   std::unordered_map<unsigned, unsigned> pseudo_row;
   std::unordered_map<unsigned, unsigned> pseudo_wide;   // ... and, for a 64-row table, its slot among the job's
   unsigned wide_base = 0;                               // tX of wide slot 0 (behind the 16-row tables)
+  bool dma_offsets = false;                             // 4-state programs for 64-row slots: FusedOp::pad = the
+                                                        // scalar offsets of the table DMAs (fused.hpp)
   unsigned mark_clv[2] = {~0u, ~0u};                 // the root operation's children: the steps that compute them are
                                                      // flagged 0x8000 / 0x10000 (fused.hpp; the exporting variant)
   unsigned matvecs = 0;                              // inner children = matrix-vector products per (site, rate)
@@ -135,6 +137,10 @@ struct Compiler {
     // 20 states: the tip tables' byte offsets ([matrix][rate 0], 12288 B per (matrix, rate))
     f.pad[0] = matX * rate_cats * (kFused20TabDoubles * 8u);
     f.pad[1] = matY * rate_cats * (kFused20TabDoubles * 8u);
+    if (dma_offsets) {
+      f.pad[0] = f.tX * 4u + kFusedDmaBias;
+      f.pad[1] = f.tY * 4u + kFusedDmaBias - kFusedDmaYSlot;
+    }
     f.cX = tipX_row * tip_stride;
     f.cY = tipY_row * tip_stride;
     f.flags = kind | (spill << 8) | wide_flags;   // (a 20-state TT never parks: its spill bits were moved to the park step)

@@ -43,6 +43,9 @@ _sig("orc_update_prob_matrices", C.c_int, _vp, _pu, _pu, _pd, _u)
 _sig("orc_update_clvs", None, _vp, C.POINTER(OrcOperation), _u)
 _sig("orc_update_clvs_avx2", C.c_int, _vp, C.POINTER(OrcOperation), _u)
 _sig("orc_compute_root_loglikelihood", C.c_double, _vp, _u, C.c_int, _pu, _pd)
+_sig("orc_update_clvs_repeats", None, _vp, C.POINTER(OrcOperation), _u, C.c_int)
+_sig("orc_compute_root_loglikelihood_repeats", C.c_double, _vp, _u, C.c_int, _pu)
+_sig("orc_repeats_ratio", C.c_double, _vp)
 _sig("orc_get_clv", _pd, _vp, _u)
 _sig("orc_get_scaler", _pu, _vp, _u)
 _sig("orc_get_pmatrix", _pd, _vp, _u)
@@ -152,6 +155,22 @@ class OraclePartition:
                 raise RuntimeError("oracle: the AVX2 loop takes 4-state data (and an AVX2 build)")
         else:
             olib.orc_update_clvs(self._h, arr, n)
+
+    def update_clvs_repeats(self, ops, avx2=True):
+        """the traversal with subtree site repeats (orc_update_clvs_repeats): per-class buffers,
+        read back by compute_root_loglikelihood_repeats; bench.py's honest CPU comparator"""
+        arr = ops if isinstance(ops, C.Array) and ops._type_ is OrcOperation else self.pack_ops(ops)
+        olib.orc_update_clvs_repeats(self._h, arr, len(arr), 1 if avx2 else 0)
+
+    def compute_root_loglikelihood_repeats(self, clv_index, scaler_index, freqs_indices=None):
+        fi = self.params_indices if freqs_indices is None else np.ascontiguousarray(
+            freqs_indices, dtype=np.uint32)
+        return olib.orc_compute_root_loglikelihood_repeats(self._h, clv_index, scaler_index,
+                                                           fi.ctypes.data_as(_pu))
+
+    def repeats_ratio(self):
+        """classes computed / columns a plain loop would have computed so far"""
+        return olib.orc_repeats_ratio(self._h)
 
     @staticmethod
     def pack_ops(ops):

@@ -142,7 +142,7 @@ def test_rounds_reproduce_the_sequential_search_on_one_rank(sequential_records, 
     assert st["rounds"] > 0 and st["redos"] == 0 and st["own_collectives"] == 0
     assert ls["objective_jobs"] > ls["objective_launches"] > 0 and ls["root_steps"] > ls["root_launches"] > 0
     if in_flight == 17:      # every candidate in flight from the first round on
-        assert ls["objective_jobs"] / ls["objective_launches"] > 40
+        assert ls["objective_jobs"] / ls["objective_launches"] > 20     # (two groups of 8 - 9: 13 / 5 / 2 jobs each)
     m.destroy()
 
 
@@ -162,7 +162,8 @@ def test_rounds_with_the_rccl_communicator_as_reducer(sequential_records):
     assert _search(m, 17) == sequential_records
     st = m.round_stats()
     assert st["own_collectives"] == 0 and 0 < st["collectives"] <= st["rounds"]
-    assert per_request > 8 * st["collectives"], (per_request, st)
+    # (two groups of 8 - 9 candidates, each as long as its longest one: 5.6 x fewer on this data)
+    assert per_request > 4 * st["collectives"], (per_request, st)
     # a model that refuses rounds refuses the lock-stepped search when it is site-sharded
     m.set_lockstep_rounds(0)
     with pytest.raises(rd.RdamdError):
@@ -207,7 +208,7 @@ def test_site_sharded_lock_step_equals_the_sequential_sharded_search(tmp_path, w
               "--site-reduce", "host", "--stats"]
     seq, lock = str(tmp_path / "seq"), str(tmp_path / "lock")
     st_seq = _run_ranks([RD] + common + ["--prefix", seq, "--lockstep", "0"], world)
-    st_lock = _run_ranks([RD] + common + ["--prefix", lock, "--lockstep", "6"], world)
+    st_lock = _run_ranks([RD] + common + ["--prefix", lock, "--lockstep", "8"], world)
     ra = sorted(rd.Checkpoint(seq).read_results())
     rb = sorted(rd.Checkpoint(lock).read_results())
     assert [r[0] for r in ra] == list(range(17))
@@ -220,7 +221,9 @@ def test_site_sharded_lock_step_equals_the_sequential_sharded_search(tmp_path, w
         assert st_lock[g * shards]["results_digest"] == st_seq[g * shards]["results_digest"]
     per_request = int(st_seq[0]["own_collectives"])
     per_round = int(st_lock[0]["collectives"])
-    assert int(st_lock[0]["own_collectives"]) == 0 and per_round > 0
-    # up to six candidates per round (fewer towards the end of a group's list)
-    assert per_request > (3.0 if groups == 1 else 2.0) * per_round, (per_request, per_round)
+    # (the model's own: the empirical frequencies and model_t::initialize, before the search)
+    assert int(st_lock[0]["own_collectives"]) <= 2 and per_round > 0
+    # eight candidates in flight = two alternating worker groups of four: up to four candidates'
+    # requests per collective (fewer towards the end of the list; measured 2.7 of 3 with six)
+    assert per_request > (2.5 if groups == 1 else 2.0) * per_round, (per_request, per_round)
     assert open(seq + ".rooted.tree").read() == open(lock + ".rooted.tree").read()

@@ -285,3 +285,55 @@ def test_avx2_clv_loop_is_bit_identical_to_the_scalar_one():
     p20 = OraclePartition(4, 6, 20, 8, 1, 6, 1, 6)
     with pytest.raises(RuntimeError):
         p20.update_clvs([], avx2=True)
+
+
+def test_site_repeats_traversal_is_bit_identical_to_the_plain_one():
+    """The reference runs coraxlib WITH subtree site repeats on 4-state data
+    (src/model.cpp:145-149); bench.py's cpu_baseline.with_site_repeats times the oracle's
+    restatement of that scheme (orc_update_clvs_repeats: a node's CLV once per class of columns
+    that agree at all tips below it).  Same arithmetic per class, so the log-likelihood must be
+    the plain loop's bit for bit -- scalar and 256-bit loops, pattern weights, ambiguity codes
+    (101.phy), the deep caterpillar where the 2^256 rule fires, 20 states -- over several
+    rootings of one partition (the class tables are rebuilt per traversal)."""
+    import root_digger_amd as rd
+    cases = []
+    tree = rd.Tree.from_file(os.path.join(util.DATA, "101.tree"))
+    seqs, w = util.compress(util.read_phylip(os.path.join(util.DATA, "101.phy")))
+    cases.append((tree, seqs, w, 4, ORC_MAP_NT, [.34, .42, .24, .74, .16, .88, .75, .54, .20, .06, .08, .41],
+                  [0.21, 0.29, 0.24, 0.26], orc_gamma_cats(0.7, 4)))
+    tree10 = rd.Tree.from_file(os.path.join(util.DATA, "10.tree"))
+    cases.append((tree10, util.read_fasta(os.path.join(util.DATA, "10.fasta")), None, 4, ORC_MAP_NT,
+                  [.3, .4, .2, .7, .1, .8, .7, .5, .2, .1, .1, .4], [0.25, 0.25, 0.25, 0.25], [1.0]))
+    gd = util.golden("deep_scaling.json")
+    cases.append((rd.Tree.from_newick(gd["newick"]), gd["seqs"], None, 4, ORC_MAP_NT, gd["subst"], gd["freqs"], gd["rates"]))
+    gp = util.golden("protein20.json")
+    aa = gp["alphabet"]
+    cases.append((rd.Tree.from_newick(gp["newick"]), gp["seqs"], None, 20,
+                  util.make_map(aa, {"X": (1 << 20) - 1, "B": (1 << aa.index("N")) | (1 << aa.index("D"))}),
+                  gp["subst"], gp["freqs"], gp["rates"]))
+    for tree, seqs, w, K, cmap, subst, freqs, rates in cases:
+        S = len(next(iter(seqs.values())))
+        R = len(rates)
+        a = OraclePartition.for_tree(tree, K, S, R)
+        b = OraclePartition.for_tree(tree, K, S, R)
+        for p in (a, b):
+            util.load_tips(p, tree, seqs, cmap, w)
+            p.set_subst_params(0, subst)
+            p.set_frequencies(0, freqs)
+            p.set_category_rates(rates)
+        for i, vec in ((7, False), (0, True), (tree.root_count() - 1, K == 4)):
+            rl = tree.root_location(i).with_ratio(0.3)
+            ops, pmi, brl = tree.generate_operations(rl)
+            a.update_prob_matrices(pmi, brl)
+            a.update_clvs(ops)
+            want = a.compute_root_loglikelihood(tree.root_clv_index(), tree.root_scaler_index())
+            b.update_prob_matrices(pmi, brl)
+            b.update_clvs_repeats(ops, avx2=vec)
+            got = b.compute_root_loglikelihood_repeats(tree.root_clv_index(), tree.root_scaler_index())
+            assert got == want, (K, i, got, want)
+        assert 0.0 < b.repeats_ratio() <= 1.0
+        if tree is tree10:       # 1000 columns of 10 taxa: most subtrees see few distinct patterns
+            assert b.repeats_ratio() < 0.5
+        if K == 4 and w is None and tree is not tree10:
+            # the caterpillar's first cherries fold, its deep nodes hold a class per column
+            assert b.repeats_ratio() < 1.0
