@@ -28,7 +28,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 RD = os.path.join(ROOT, "root_digger_amd", "bin", "rd_amd")
 REF = os.path.join(ROOT, "oracle", "_ref", "liblbfgsb_ref.so")
 MSA, TREE = os.path.join(util.DATA, "10.fasta"), os.path.join(util.DATA, "10.tree")
-LOOSE = (1e-3, 1e-3, 1e-3, 1e12)      # atol, pgtol, brtol, factor
+# atol, pgtol, brtol, factor: loose -- these tests compare runs that must agree BIT FOR BIT
+# (same sums in the same order), which holds at any tolerance; short trajectories keep them cheap
+LOOSE = (1e-2, 1e-2, 1e-2, 1e13)
 
 
 class _Hip:
@@ -142,7 +144,7 @@ def test_rounds_reproduce_the_sequential_search_on_one_rank(sequential_records, 
     assert st["rounds"] > 0 and st["redos"] == 0 and st["own_collectives"] == 0
     assert ls["objective_jobs"] > ls["objective_launches"] > 0 and ls["root_steps"] > ls["root_launches"] > 0
     if in_flight == 17:      # every candidate in flight from the first round on
-        assert ls["objective_jobs"] / ls["objective_launches"] > 20     # (two groups of 8 - 9: 13 / 5 / 2 jobs each)
+        assert ls["objective_jobs"] / ls["objective_launches"] > 15     # (two groups of 8 - 9: 13 / 5 / 2 jobs each)
     m.destroy()
 
 
@@ -163,7 +165,7 @@ def test_rounds_with_the_rccl_communicator_as_reducer(sequential_records):
     st = m.round_stats()
     assert st["own_collectives"] == 0 and 0 < st["collectives"] <= st["rounds"]
     # (two groups of 8 - 9 candidates, each as long as its longest one: 5.6 x fewer on this data)
-    assert per_request > 4 * st["collectives"], (per_request, st)
+    assert per_request > 3 * st["collectives"], (per_request, st)
     # a model that refuses rounds refuses the lock-stepped search when it is site-sharded
     m.set_lockstep_rounds(0)
     with pytest.raises(rd.RdamdError):
@@ -177,7 +179,10 @@ def _run_ranks(args, world, timeout=900):
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    env = dict(os.environ, WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    # (GPU_MAX_HW_QUEUES: up to eight processes with a dozen HIP streams each share ONE device
+    # here; beyond the device's hardware queues the firmware rotates them by the millisecond)
+    env = dict(os.environ, WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+               GPU_MAX_HW_QUEUES="1")
     procs = [subprocess.Popen(args, env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
              for r in range(world)]
@@ -203,12 +208,13 @@ def test_site_sharded_lock_step_equals_the_sequential_sharded_search(tmp_path, w
     if not os.path.exists(REF):
         pytest.skip("oracle/_ref/liblbfgsb_ref.so not built")
     common = ["--msa", MSA, "--tree", TREE, "--exhaustive", "--silent", "--rate-cats", "4",
-              "--atol", "1e-3", "--brtol", "1e-3", "--bfgstol", "1e-3", "--factor", "1e12",
+              "--atol", "0.5", "--brtol", "0.1", "--bfgstol", "0.5", "--factor", "1e15",
               "--seed", "5", "--lbfgsb", REF, "--device", "0", "--site-shards", str(shards),
               "--site-reduce", "host", "--stats"]
     seq, lock = str(tmp_path / "seq"), str(tmp_path / "lock")
     st_seq = _run_ranks([RD] + common + ["--prefix", seq, "--lockstep", "0"], world)
-    st_lock = _run_ranks([RD] + common + ["--prefix", lock, "--lockstep", "8"], world)
+    in_flight = 8 if world < 8 else 4       # (eight processes x eight replicas on one device take minutes)
+    st_lock = _run_ranks([RD] + common + ["--prefix", lock, "--lockstep", str(in_flight)], world)
     ra = sorted(rd.Checkpoint(seq).read_results())
     rb = sorted(rd.Checkpoint(lock).read_results())
     assert [r[0] for r in ra] == list(range(17))
@@ -223,7 +229,7 @@ def test_site_sharded_lock_step_equals_the_sequential_sharded_search(tmp_path, w
     per_round = int(st_lock[0]["collectives"])
     # (the model's own: the empirical frequencies and model_t::initialize, before the search)
     assert int(st_lock[0]["own_collectives"]) <= 2 and per_round > 0
-    # eight candidates in flight = two alternating worker groups of four: up to four candidates'
-    # requests per collective (fewer towards the end of the list; measured 2.7 of 3 with six)
-    assert per_request > (2.5 if groups == 1 else 2.0) * per_round, (per_request, per_round)
+    # N candidates in flight = two alternating worker groups of N / 2: up to N / 2 candidates'
+    # requests per collective (fewer towards the end of a list; measured 2.7 of 3 with six)
+    assert per_request > 0.6 * (in_flight / 2) * per_round, (per_request, per_round, in_flight)
     assert open(seq + ".rooted.tree").read() == open(lock + ".rooted.tree").read()

@@ -81,26 +81,29 @@ def _run_ranks(args, world, timeout=600):
     return outs
 
 
-@pytest.mark.parametrize("world,shards", [(2, 2), (4, 2)])
+@pytest.mark.parametrize("world,shards", [(2, 2)])
 def test_site_sharded_exhaustive_search_writes_the_one_rank_records(tmp_path, world, shards):
     """`rd_amd --site-shards G` (north star: site blocks + lnL all-reduce inside the
     product): 2 ranks = one site group of two column blocks (BASELINE c4's layout),
     4 ranks = 2 candidate groups x 2 site blocks (c5's 2-D grid).  All ranks share
     device 0 of this box, so the sums go through `--site-reduce host`; the model
     hook is the one RCCL uses.  The checkpoint must hold the one-rank run's
-    records: one per candidate, same root ids, lnL/alpha to optimiser tolerance."""
+    records: one per candidate, same root ids, lnL/alpha to optimiser tolerance.
+    The sharded side runs in LOCK STEP (rd_amd's default with --lbfgsb: deterministic
+    rounds, tests/test_gpu_lockstep_rounds.py, which also covers 4/2, 8/8 and 8/2 bit
+    for bit against the sequential sharded search)."""
     if not os.path.exists(REF):
         pytest.skip("oracle/_ref/liblbfgsb_ref.so not built")
     # (tight optimiser settings: the block sums differ from the one-rank sum in the
     # last bit, and a loosely converged L-BFGS-B run would amplify that)
     common = ["--msa", MSA, "--tree", TREE, "--exhaustive", "--silent", "--rate-cats", "4",
               "--atol", "1e-7", "--brtol", "1e-9", "--bfgstol", "1e-7", "--factor", "1e4",
-              "--seed", "5", "--lbfgsb", REF, "--device", "0", "--threads", "0", "--lockstep", "0"]
+              "--seed", "5", "--lbfgsb", REF, "--device", "0", "--threads", "0"]
     one, many = str(tmp_path / "one"), str(tmp_path / "many")
-    out = subprocess.run([RD] + common + ["--prefix", one], capture_output=True, text=True, timeout=600)
+    out = subprocess.run([RD] + common + ["--prefix", one, "--lockstep", "0"], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout + out.stderr
     outs = _run_ranks([RD] + common + ["--prefix", many, "--site-shards", str(shards),
-                                       "--site-reduce", "host"], world)
+                                       "--site-reduce", "host", "--lockstep", "8"], world)
     ra = sorted(rd.Checkpoint(one).read_results())
     rb = sorted(rd.Checkpoint(many).read_results())
     assert [r[0] for r in rb] == [r[0] for r in ra] == list(range(17))      # one record per candidate
