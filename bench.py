@@ -259,12 +259,13 @@ def main():
     # a one-GPU box (tests/test_gpu_bench.py)
     use_pg = world > 1 or os.environ.get("RDAMD_BENCH_PG") == "1"
     real_stdout = None
-    if use_pg:
+    if use_pg or args.one_rank_comm:
         # RCCL prints a version banner on the process's stdout when a communicator comes
         # up: keep file descriptor 1 for the ONE JSON line, send everything else to stderr
         sys.stdout.flush()
         real_stdout = os.dup(1)
         os.dup2(2, 1)
+    if use_pg:
         import torch.distributed as tdist
         if host_collectives:
             tdist.init_process_group("gloo")

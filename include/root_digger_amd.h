@@ -345,7 +345,8 @@ int rdamd_evaluate_batch_finish_device(rdamd_partition_t *p, unsigned int slot);
  * corax_update_prob_matrices + corax_update_clvs + corax_compute_root_loglikelihood
  * (src/model.cpp:357-409) where only the root's children are read afterwards -- 13 MB written
  * instead of 1.3 GB moved on BASELINE c2.  Parameters as one job of rdamd_evaluate_batch.
- * 4-state and binary partitions; the children need scale buffers.  *lnl_out = the tree's
+ * 4-state and binary partitions, and 20-state ones with up to 4 rate categories (the fused
+ * evaluators' shapes); the children need scale buffers.  *lnl_out = the tree's
  * log-likelihood (every operation of the list evaluated, the reference's rescaling rule at
  * every step). */
 int rdamd_evaluate_root_children(rdamd_partition_t *p, const rdamd_operation_t *ops, unsigned int n_ops,

@@ -291,7 +291,7 @@ static rdamd_schedule_t *schedule_create_impl(rdamd_partition_t *p, const rdamd_
     c.pseudo_wide = pseudo_wide;
     c.wide_base = 8u * p->prob_matrices * p->rate_cats * 16u;
     c.dma_offsets = !k20 && wide_mode;
-    if (!k20) {   // the steps that compute the root operation's inner children (fused.hpp, 0x8000 / 0x10000)
+    {   // the steps that compute the root operation's inner children (fused.hpp, 0x8000 / 0x10000)
       const rdamd_operation_t &root = list.back();
       if (root.child1_clv_index >= p->tips) c.mark_clv[0] = root.child1_clv_index;
       if (root.child2_clv_index >= p->tips) c.mark_clv[1] = root.child2_clv_index;
@@ -720,8 +720,40 @@ static int batch_submit_impl(rdamd_partition_t *p, FusedWorkspace *&slot, bool p
       RDAMD_HIP_TRY(hipEventRecord(w->ev_ready, pre), RDAMD_FAILURE);
       RDAMD_HIP_TRY(hipStreamWaitEvent(p->stream, w->ev_ready, 0), RDAMD_FAILURE);
     }
+    unsigned *export_scaler20[2] = {nullptr, nullptr};
+    b.export_clv[0] = b.export_clv[1] = nullptr;
+    b.export_cnt[0] = b.export_cnt[1] = nullptr;
+    if (export_children) {
+      // where the root operation's inner children go: the partition's own CLV / scaler buffers
+      // (operand layout: rdamd_evaluate_root_children only takes partitions that keep it)
+      const rdamd_schedule_t *s0 = schedules[0];
+      if (n_jobs != 1 || pipelined || !p->mfma_layout) {
+        set_error(50, "rdamd_evaluate_root_children: one job on the partition's stream (20 states: up to 4 rate categories)");
+        return RDAMD_FAILURE;
+      }
+      unsigned phys_clv[2] = {0, 0};
+      int phys_sc[2] = {-1, -1};
+      for (int k = 0; k < 2; ++k) {
+        if (s0->root_child_clv[k] < p->tips) continue;   // a tip: nothing to leave behind
+        if (s0->root_child_sc[k] < 0 || (unsigned)s0->root_child_sc[k] >= p->scale_buffers) {
+          set_error(50, "rdamd_evaluate_root_children: child %d of the root operation needs a scale buffer", k + 1);
+          return RDAMD_FAILURE;
+        }
+        RDAMD_HIP_TRY(clv_phys(p, s0->root_child_clv[k], &phys_clv[k]), RDAMD_FAILURE);
+        RDAMD_HIP_TRY(scaler_phys(p, s0->root_child_sc[k], &phys_sc[k]), RDAMD_FAILURE);
+      }
+      for (int k = 0; k < 2; ++k) {
+        if (s0->root_child_clv[k] < p->tips) continue;
+        if (!w->d_export_cnt)
+          RDAMD_HIP_TRY(hipMalloc((void **)&w->d_export_cnt, sizeof(unsigned) * 2 * (size_t)p->sites * R), RDAMD_FAILURE);
+        b.export_clv[k] = p->d_clv + (size_t)(phys_clv[k] - p->tips) * p->clv_doubles();
+        b.export_cnt[k] = w->d_export_cnt + (size_t)k * p->sites * R;
+        export_scaler20[k] = p->d_scaler + (size_t)phys_sc[k] * p->sites;
+      }
+    }
     p->prof_begin(3);
-    e = launch_fused20_eval(b, n_jobs, max_depth[0], d_out, p->stream);
+    e = export_children ? launch_fused20_export(b, max_depth[0], export_scaler20, d_out, p->stream)
+                        : launch_fused20_eval(b, n_jobs, max_depth[0], d_out, p->stream);
     p->prof_end();
     RDAMD_HIP_TRY(e, RDAMD_FAILURE);
     if (host_out)
@@ -949,8 +981,8 @@ int rdamd_evaluate_root_children(rdamd_partition_t *p, const rdamd_operation_t *
                                  unsigned int n_matrices, const double *subst, const double *freqs,
                                  const double *rates, const double *rate_weights, double *lnl_out) {
   clear_error();
-  if (p->states != 4 || p->mfma_layout) {
-    set_error(50, "rdamd_evaluate_root_children: 4-state (or binary) partitions");
+  if (!(p->states == 4 && !p->mfma_layout) && !(p->states == 20 && p->rate_cats <= 4 && p->mfma_layout)) {
+    set_error(50, "rdamd_evaluate_root_children: 4-state (or binary) partitions, and 20-state ones with up to 4 rate categories");
     return RDAMD_FAILURE;
   }
   // a schedule for this one launch: the plain program (its block comes from the partition's pool)

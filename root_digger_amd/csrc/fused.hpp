@@ -124,6 +124,13 @@ struct Fused20Args {
   size_t   pmat_job_stride;          // doubles per job
   size_t   tiptab_job_stride;        // doubles per job
   unsigned sites, rate_cats, tiles, ncodes;
+  // the exporting variant only (rdamd_evaluate_root_children on a 20-state partition): where the
+  // CLVs of the root operation's two children go -- the partition's own buffers, in its matrix-core
+  // operand layout [rate][tile][320] (common.hpp, k20_tile_index); null for a tip child -- and
+  // their rescale counts per (site, rate) ([site][rate]; the fix-up kernel turns them into the
+  // reference's per-site scalers)
+  double   *export_clv[2];
+  unsigned *export_cnt[2];
 };
 // 4 states: in-memory stack entries of a program whose stack lives in one register slot, one
 // LDS slot and the wave's private segment (kernels_fused.hip, SP; the private segment has a
@@ -140,6 +147,11 @@ hipError_t launch_fused20_pmatrix(const Fused20Args &a, const double *d_q, doubl
                                   unsigned n_jobs, unsigned n_mat, hipStream_t stream);
 hipError_t launch_fused20_eval(const Fused20Args &a, unsigned n_jobs, unsigned max_depth,
                                double *d_out, hipStream_t stream);
+// ONE job through the exporting variant: the evaluation, and the root operation's inner children left
+// in a.export_clv / d_scaler[] as a traversal with per-site scalers leaves them (launch_fused_export's
+// 20-state sibling)
+hipError_t launch_fused20_export(const Fused20Args &a, unsigned max_depth, unsigned *const d_scaler[2],
+                                 double *d_out, hipStream_t stream);
 
 hipError_t launch_fused_pmatrix(const FusedArgs &a, const double *d_q, const double *d_rates,
                                 unsigned n_jobs, unsigned n_mat, bool slim, hipStream_t stream);

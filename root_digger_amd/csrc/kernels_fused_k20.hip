@@ -326,7 +326,11 @@ fused20_pmatrix_kernel(const double *__restrict__ qpow, const double *__restrict
 // and the scalar control flow are shared by NT x 16 sites.
 // Dynamic LDS: [root exchange R x NT x 16 x (8 + 4) B][per wave: one A copy (4 KB) +
 // `depth` stack levels of NT tiles].
-template <int NT>
+// EXPORT (rdamd_evaluate_root_children): the steps the host flagged (0x8000 / 0x10000: they compute
+// the root operation's two children) also store the running CLV -- in the partition's operand
+// layout -- and its rescale count: what the root-only steps of the search read afterwards
+// (src/model.cpp:415-446), instead of a traversal that materialises every CLV.
+template <int NT, bool EXPORT>
 __global__ void __launch_bounds__(256)
 fused20_eval_kernel(Fused20Args a, unsigned depth) {
   extern __shared__ char lds_raw[];
@@ -574,6 +578,18 @@ fused20_eval_kernel(Fused20Args a, unsigned depth) {
     if (!rows_early && has_tip1(nxt)) request_tab(nxt.tabX, cw1, t1);
     if (!rows_early && has_tip2(nxt)) request_tab(nxt.tabY, cw2, t2);
     if (next_product) stage();
+    if (EXPORT && (cur.flags & 0x18000u)) {   // a child of the root operation: leave it behind
+      double *ec = (cur.flags & 0x8000u) ? a.export_clv[0] : a.export_clv[1];
+      unsigned *en = (cur.flags & 0x8000u) ? a.export_cnt[0] : a.export_cnt[1];
+#pragma unroll
+      for (int q = 0; q < NT; ++q)
+        if (site[q] < S) {
+          double *tile = ec + ((size_t)r * a.tiles + (blockIdx.x * NT + q)) * (16 * kK);
+#pragma unroll
+          for (int s = 0; s < kSteps; ++s) tile[k20_tile_index(col, 4u * s + grp)] = v[q][s];
+          if (grp == 0) en[(size_t)site[q] * R + r] = (unsigned)sc[q];
+        }
+    }
     cur = nxt;
     nxt = nx2;
     nx2 = nx3;
@@ -640,6 +656,37 @@ fused20_finish_kernel(const double *__restrict__ partials, unsigned per_job,
   if (threadIdx.x == 0) out[blockIdx.x] = ((lds[0] + lds[1]) + lds[2]) + lds[3];
 }
 
+// the exporting evaluator left a child's CLV with one rescale count per (site, rate); the root
+// kernels (and rdamd_get_clv) read the reference's form, one count per site: the smallest count of
+// the site's rates, a rate that was rescaled d times more goes back by 2^(-256 d)
+// (fused_export_fixup_kernel's 20-state sibling; one-wave workgroups, both children in one launch)
+struct Export20FixupArgs {
+  double *clv[2];
+  const unsigned *cnt[2];
+  unsigned *scaler[2];
+  unsigned sites, R, tiles;
+};
+__global__ void __launch_bounds__(64)
+fused20_export_fixup_kernel(Export20FixupArgs x) {
+  const unsigned k = blockIdx.y;
+  double *__restrict__ clv = x.clv[k];
+  const unsigned *__restrict__ cnt = x.cnt[k];
+  if (!clv) return;
+  const unsigned R = x.R, site = blockIdx.x * 64u + threadIdx.x;
+  if (site >= x.sites) return;
+  unsigned smin = cnt[(size_t)site * R];
+  for (unsigned r = 1; r < R; ++r) smin = min(smin, cnt[(size_t)site * R + r]);
+  for (unsigned r = 0; r < R; ++r) {
+    const unsigned d = cnt[(size_t)site * R + r] - smin;
+    if (d) {
+      const double f = d < 4u ? pow2_neg256((int)d) : (d == 4u ? 0x1p-1024 : 0.0);
+      double *tile = clv + ((size_t)r * x.tiles + site / 16u) * (16 * kK);
+      for (unsigned st = 0; st < (unsigned)kK; ++st) tile[k20_tile_index(site % 16u, st)] *= f;
+    }
+  }
+  x.scaler[k][site] = smin;
+}
+
 size_t fused20_qpow_doubles() { return kQPow20Stride; }
 
 hipError_t launch_fused20_pmatrix(const Fused20Args &a, const double *d_q, double *d_qpow, const double *d_rates,
@@ -670,17 +717,45 @@ hipError_t launch_fused20_eval(const Fused20Args &a, unsigned n_jobs, unsigned m
     static size_t lds_allowed = 64 * 1024;
     std::lock_guard<std::mutex> guard(lds_mu);
     if (lds > lds_allowed) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fused20_eval_kernel<kFused20Tiles>),
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fused20_eval_kernel<kFused20Tiles, false>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return e;
       lds_allowed = lds;
     }
   }
   const unsigned groups = (a.tiles + kFused20Tiles - 1) / kFused20Tiles;
-  fused20_eval_kernel<kFused20Tiles><<<dim3(groups, n_jobs), 64 * a.rate_cats, lds, stream>>>(a, max_depth);
+  fused20_eval_kernel<kFused20Tiles, false><<<dim3(groups, n_jobs), 64 * a.rate_cats, lds, stream>>>(a, max_depth);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   fused20_finish_kernel<<<n_jobs, 256, 0, stream>>>(a.partials, a.tiles, d_out);
+  return hipGetLastError();
+}
+
+hipError_t launch_fused20_export(const Fused20Args &a, unsigned max_depth, unsigned *const d_scaler[2],
+                                 double *d_out, hipStream_t stream) {
+  const size_t lds = fused20_lds_bytes(a.rate_cats, max_depth);
+  {
+    static std::mutex lds_mu;
+    static size_t lds_allowed = 64 * 1024;
+    std::lock_guard<std::mutex> guard(lds_mu);
+    if (lds > lds_allowed) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fused20_eval_kernel<kFused20Tiles, true>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return e;
+      lds_allowed = lds;
+    }
+  }
+  const unsigned groups = (a.tiles + kFused20Tiles - 1) / kFused20Tiles;
+  fused20_eval_kernel<kFused20Tiles, true><<<dim3(groups, 1), 64 * a.rate_cats, lds, stream>>>(a, max_depth);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  fused20_finish_kernel<<<1, 256, 0, stream>>>(a.partials, a.tiles, d_out);
+  if (a.export_clv[0] || a.export_clv[1]) {
+    Export20FixupArgs x;
+    for (int k = 0; k < 2; ++k) { x.clv[k] = a.export_clv[k]; x.cnt[k] = a.export_cnt[k]; x.scaler[k] = d_scaler[k]; }
+    x.sites = a.sites; x.R = a.rate_cats; x.tiles = a.tiles;
+    fused20_export_fixup_kernel<<<dim3((a.sites + 63u) / 64u, 2), 64, 0, stream>>>(x);
+  }
   return hipGetLastError();
 }
 

@@ -62,7 +62,9 @@ model_t::model_t(rooted_tree_t tree, const std::vector<msa_t> &msas,
     const auto &msa = msas[p];
     unsigned int attributes = RDAMD_ATTRIB_NONREV;
     if (msa.states == 4) attributes |= RDAMD_ATTRIB_SITE_REPEATS;
-    if (_sparse && (msa.states == 4 || msa.states == 2)) attributes |= RDAMD_ATTRIB_SPARSE_CLVS;
+    // (the shapes rdamd_evaluate_root_children takes: what compute_lh_for_root_steps runs on)
+    if (_sparse && (msa.states == 4 || msa.states == 2 || (msa.states == 20 && _rate_rates[p].size() <= 4)))
+      attributes |= RDAMD_ATTRIB_SPARSE_CLVS;
     rdamd_partition_t *part = rdamd_partition_create(
         _tree.tip_count(), _tree.branch_count(), msa.states, (unsigned)msa.length(), 1,
         _tree.branch_count(), (unsigned)_rate_rates[p].size(), _tree.branch_count(), attributes);
@@ -322,8 +324,9 @@ double model_t::compute_lh(const root_location_t &root_location) {
 // compute_lh for the searches, between optimize_params and the root-only steps: the same
 // value for the caller's convergence test, but only what those steps read is left behind --
 // the CLVs and scalers of the root's two children (rdamd_evaluate_root_children: one job of
-// the fused evaluator instead of a traversal that writes every CLV).  Partitions the fused
-// evaluator does not take (20 states, general K) go through the three calls of compute_lh.
+// the fused evaluator instead of a traversal that writes every CLV; 4-state, binary and -- up to
+// four rate categories -- 20-state partitions).  Partitions the fused evaluators do not take
+// (general K) go through the three calls of compute_lh.
 double model_t::compute_lh_for_root_steps(const root_location_t &root_location) {
   if (!_children_only) return compute_lh(root_location);
   auto sched = _tree.generate_operations(root_location);
@@ -335,7 +338,7 @@ double model_t::compute_lh_for_root_steps(const root_location_t &root_location) 
   for (size_t i = 0; i < _partitions.size(); ++i) {
     rdamd_partition_t *part = _partitions[i];
     const unsigned st = rdamd_partition_states(part);
-    if (st == 4 || st == 2) {
+    if (st == 4 || st == 2 || (st == 20 && rdamd_partition_rate_cats(part) <= 4)) {
       double v = 0.0;
       // (a replica's sparse partition: the children of the LAST root, and whatever else an earlier
       // call named, give their memory back -- nothing reads them after this call)

@@ -443,11 +443,16 @@ unsigned int rdamd_model_max_replicas(const rdamd_model_t *m, unsigned int reque
     // a replica's 4-state / binary partitions hold the root's two children and the root CLV, not
     // all 2n - 3 buffers (RDAMD_ATTRIB_SPARSE_CLVS; their pools start at four slots) -- plus the
     // evaluator's workspace for the one job that writes them
-    const bool sparse = replicas_are_sparse(m) && (msas[i].states == 4 || msas[i].states == 2);
     const unsigned R = (unsigned)ratehets[std::min(i, ratehets.size() - 1)].rate_cats;
+    const bool sparse = replicas_are_sparse(m) &&
+                        (msas[i].states == 4 || msas[i].states == 2 || (msas[i].states == 20 && R <= 4));
     per_replica += rdamd_partition_footprint(tips, sparse ? 4u : branches, msas[i].states, (unsigned)msas[i].length(),
                                              branches, R, sparse ? 4u : branches);
-    if (sparse) per_replica += (uint64_t)branches * R * (16 + 64) * 8 * 2 + (uint64_t)msas[i].length() * R * 8 + ((uint64_t)2 << 20);
+    if (sparse) {
+      const uint64_t K = msas[i].states == 20 ? 20 : 4;
+      per_replica += (uint64_t)branches * R * (K * K + (K == 4 ? 64 : 64 * 24)) * 8 * 2 +
+                     (uint64_t)msas[i].length() * R * 8 + ((uint64_t)2 << 20);
+    }
   }
   if (replica_bytes) *replica_bytes = per_replica;
   uint64_t free_b = 0, total_b = 0;

@@ -118,15 +118,67 @@ def test_root_children_binary_and_errors():
     ops, pmi, brl = tree.generate_operations(tree.root_location(0))
     with pytest.raises(rd.RdamdError):
         g.evaluate_root_children([ops[len(ops) - 1]], pmi, brl, [0.7, 1.9], g.empirical_frequencies(), w["rates"])
-    # 20-state partitions are refused (the searches keep the traversal there)
-    w20 = synth.workload(12, 40, 20, 2, 6)
-    t20 = rd.Tree.from_newick(w20["newick"])
-    cm20 = util.make_map(w20["alphabet"])
-    g20 = rd.Partition.for_tree(t20, 20, 40, 2)
-    util.load_tips(g20, t20, w20["seqs"], cm20)
-    ops, pmi, brl = t20.generate_operations(t20.root_location(0))
-    with pytest.raises(rd.RdamdError):
-        g20.evaluate_root_children(ops, pmi, brl, w20["subst"], [0.05] * 20, w20["rates"])
+    # 20 states with more than four rate categories, and general state counts, are refused (the
+    # searches keep the traversal there)
+    for K, R in ((20, 8), (5, 2)):
+        wk = synth.workload(12, 40, K, R, 6)
+        tk = rd.Tree.from_newick(wk["newick"])
+        gk = rd.Partition.for_tree(tk, K, 40, R)
+        util.load_tips(gk, tk, wk["seqs"], util.make_map(wk["alphabet"]))
+        ops, pmi, brl = tk.generate_operations(tk.root_location(0))
+        with pytest.raises(rd.RdamdError):
+            gk.evaluate_root_children(ops, pmi, brl, wk["subst"], [1.0 / K] * K, wk["rates"])
+
+
+@pytest.mark.parametrize("n,S,R,seed", [(30, 500, 4, 131), (9, 33, 1, 132), (64, 130, 2, 133), (200, 300, 4, 134)])
+def test_root_children_20_states_vs_oracle(n, S, R, seed):
+    """the exporting variant of fused20_eval_kernel -- the searches' compute_lh in
+    front of the root-only steps on protein data (src/model.cpp:415-446) is one job of the fused
+    evaluator that leaves the root's two children behind in the partition's operand layout"""
+    w = synth.workload(n, S, 20, R, seed)
+    tree = rd.Tree.from_newick(w["newick"])
+    cmap = util.make_map(w["alphabet"])
+    g, o = pair(tree, w["seqs"], 20, R, cmap, cmap)
+    freqs = g.empirical_frequencies()
+    for i in (0, 3, tree.root_count() // 2, tree.root_count() - 1):
+        _check_children(g, o, tree, tree.root_location(i).with_ratio(0.37), w["subst"], freqs, w["rates"])
+
+
+def test_root_children_20_states_rescaling_and_sparse():
+    """a 161-taxon caterpillar of protein data: the per-(site, rate) counts of the evaluator become
+    the per-site scalers the root kernels read; and the same on a sparse partition (a replica's)"""
+    gd = util.golden("deep_scaling.json")
+    tree = rd.Tree.from_newick(gd["newick"])
+    rng = np.random.default_rng(5)
+    aa = synth.AA
+    seqs = {k: "".join(aa[i] for i in rng.integers(0, 20, 96)) for k in gd["seqs"]}
+    cmap = util.make_map(aa)
+    g, o = pair(tree, seqs, 20, 4, cmap, cmap)
+    subst = list(rng.uniform(0.05, 2.0, 380))
+    freqs = list(rng.dirichlet(np.ones(20) * 20))
+    rates = rd.compute_gamma_cats(0.5, 4)
+    seen = 0
+    for i in (0, 100, tree.root_count() - 1):
+        rl = tree.root_location(i).with_ratio(0.31)
+        _check_children(g, o, tree, rl, subst, freqs, rates, clv_rtol=1e-11)
+        ops, _, _ = tree.generate_operations(rl)
+        root = ops[len(ops) - 1]
+        for sc in (root.child1_scaler_index, root.child2_scaler_index):
+            if sc >= 0:
+                seen = max(seen, int(g.get_scaler(sc).max()))
+    assert seen >= 1   # the case really rescales
+    sp = rd.Partition.for_tree(tree, 20, 96, 4, rd.ATTRIB_NONREV | rd.ATTRIB_SPARSE_CLVS)
+    util.load_tips(sp, tree, seqs, cmap)
+    rl = tree.root_location(100).with_ratio(0.31)
+    ops, pmi, brl = tree.generate_operations(rl)
+    sp.discard_clvs()
+    assert sp.evaluate_root_children(ops, pmi, brl, subst, freqs, rates) == \
+        g.evaluate_root_children(ops, pmi, brl, subst, freqs, rates)
+    root = ops[len(ops) - 1]
+    for clv in (root.child1_clv_index, root.child2_clv_index):
+        if clv >= tree.tip_count():
+            assert np.array_equal(sp.get_clv(clv), g.get_clv(clv))
+    assert sp.clv_bytes() < g.clv_bytes() / 20
 
 
 def test_search_with_root_children_agrees_with_the_traversal_search():
