@@ -49,6 +49,11 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *p, unsig
   return __builtin_amdgcn_make_buffer_rsrc(q, 0, (int)uni(bytes), 0x00020000);
 }
 constexpr unsigned kOutOfRange = 0x80000000u;   // offset no descriptor here reaches
+#if defined(RDAMD_ABLATION) && defined(RDAMD_CLV_STORE_AUX)
+constexpr int kClvStoreAux = RDAMD_CLV_STORE_AUX;
+#else
+constexpr int kClvStoreAux = 0;
+#endif
 
 // read-only data through the scalar cache: a load from the constant address
 // space at a wave-uniform address is an s_load
@@ -94,8 +99,24 @@ clv_dna_traversal_kernel(DeviceView v, const LevelOp *__restrict__ ops, unsigned
   const unsigned s = cidx / R, r = cidx % R;
 
   const unsigned clv_bytes = (unsigned)(v.clv_stride * sizeof(double));
-  const unsigned off_clv_st = active ? idx * 32u : kOutOfRange;
   const unsigned off_sc_st = (active && r == 0) ? s * 4u : kOutOfRange;
+  // Stores.  A lane's result is a 32-byte record, written as the lane's own two 16-byte halves: a
+  // store instruction touches half of every 64-byte sector of the wave's 2 KB (round 4: the store
+  // stream ran at 3.99 TB/s of real HBM traffic, 62 % of what plain stores reach).  Round 5 tried
+  // whole sectors: the four lanes of a QUAD exchange halves (DPP quad_perm: no LDS) so that one
+  // instruction writes the quad's records 0 and 1 -- 64 contiguous bytes -- and the other its
+  // records 2 and 3 (ablation builds, -DRDAMD_ABL_QUAD_STORES; bit-identical CLVs).  Same box,
+  // profiles/r5_clv_store_ab.txt: c2 176.7 -> 174.2 us (+1.4 %), c5's shard +0.7 %, 125.phy
+  // 132.3 -> 136.8 us (-3.4 %): the sector fill of a store instruction is not what holds the
+  // stream back.  RDAMD_CLV_STORE_AUX: the cache-policy bits of the stores, for the same A/B.
+#if !(defined(RDAMD_ABLATION) && defined(RDAMD_ABL_QUAD_STORES))
+  const unsigned off_clv_st = active ? idx * 32u : kOutOfRange;
+#else
+  const unsigned ql = lane & 3u, rec_a = (idx & ~3u) + (ql >> 1), rec_b = rec_a + 2u;
+  const unsigned off_st_a = rec_a < total ? rec_a * 32u + (ql & 1u) * 16u : kOutOfRange;
+  const unsigned off_st_b = rec_b < total ? rec_b * 32u + (ql & 1u) * 16u : kOutOfRange;
+  const bool odd_lane = (ql & 1u) != 0u;
+#endif
 
   // ---- P-matrix staging, one chunk ahead ------------------------------------
   // wave w stages the (operation, child) pairs w, w+4, ... of the chunk: the
@@ -268,8 +289,28 @@ clv_dna_traversal_kernel(DeviceView v, const LevelOp *__restrict__ ops, unsigned
           off_sc_st, 0, 0);
       const __amdgpu_buffer_rsrc_t prs =
           make_rsrc(clv_bytes_base + op.parent_off, op.noop ? 0u : clv_bytes);
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, make_double2(o[0], o[1])), prs, off_clv_st, 0, 0);
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, make_double2(o[2], o[3])), prs, off_clv_st + 16, 0, 0);
+#if !(defined(RDAMD_ABLATION) && defined(RDAMD_ABL_QUAD_STORES))
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, make_double2(o[0], o[1])), prs, off_clv_st, 0, kClvStoreAux);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, make_double2(o[2], o[3])), prs, off_clv_st + 16, 0, kClvStoreAux);
+#else
+      {
+        const v4u lo = __builtin_bit_cast(v4u, make_double2(o[0], o[1]));
+        const v4u hi = __builtin_bit_cast(v4u, make_double2(o[2], o[3]));
+        v4u wa, wb;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          // quad_perm [0,0,1,1] = 0x50: lanes 0, 1 read lane 0 and lanes 2, 3 read lane 1; [2,2,3,3] = 0xFA
+          const unsigned la = (unsigned)__builtin_amdgcn_mov_dpp((int)lo[k], 0x50, 0xF, 0xF, true);
+          const unsigned ha = (unsigned)__builtin_amdgcn_mov_dpp((int)hi[k], 0x50, 0xF, 0xF, true);
+          const unsigned lb = (unsigned)__builtin_amdgcn_mov_dpp((int)lo[k], 0xFA, 0xF, 0xF, true);
+          const unsigned hb = (unsigned)__builtin_amdgcn_mov_dpp((int)hi[k], 0xFA, 0xF, 0xF, true);
+          wa[k] = odd_lane ? ha : la;
+          wb[k] = odd_lane ? hb : lb;
+        }
+        __builtin_amdgcn_raw_buffer_store_b128(wa, prs, off_st_a, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(wb, prs, off_st_b, 0, 0);
+      }
+#endif
       if (op.park) {
         const unsigned slot = op.park - 1;
         park_lds[(slot * 2) * 256 + tid] = make_double2(o[0], o[1]);
