@@ -554,7 +554,9 @@ void rdamd_model_lockstep_stats(const rdamd_model_t *m, uint64_t out[4]);
 /* How the candidates in flight of a lock-stepped search meet: 0 (default) = the library's
  * choice -- from four candidates on, TWO groups whose objective batches alternate on the
  * shared partition (rdamd_evaluate_batch_submit / _wait: one group's hosts take their
- * L-BFGS-B steps while the other group's batch runs); 1 = one group, blocking launches.
+ * L-BFGS-B steps while the other group's batch runs), except for a site-sharded model, whose
+ * rounds each end in a collective: ONE group there (launches twice as large, half the
+ * collectives); 1 = one group; 2 = two groups.
  * The records are the same either way (a job's value does not depend on its launch). */
 void rdamd_model_set_lockstep_groups(rdamd_model_t *m, unsigned int groups);
 /* How a lock-stepped search forms its launches.  In ARRIVAL ORDER (batch combiners: whoever has

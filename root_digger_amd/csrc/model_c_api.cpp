@@ -510,7 +510,15 @@ static int search_in_rounds(rdamd_model_t *m, unsigned int workers, double atol,
     rdamd::conductor_t::config_t cfg;
     cfg.shared = m->model->partition(0);
     cfg.n_workers = workers;
-    cfg.n_groups = workers >= 4 && m->lockstep_groups != 1 ? 2u : 1u;
+    // One worker group or two alternating ones (rdamd_model_set_lockstep_groups)?  Two hide the
+    // hosts' steps behind the other group's launch; one makes every launch twice as large and
+    // HALVES the collectives.  Measured on one GPU (profiles/r5_shard_search.txt): an unsharded c2
+    // gains from two; c2 / 8's shard is faster with one (0.201 against 0.218 s per candidate, 244
+    // against 397 collectives per candidate), the deep shards are evaluator-bound either way --
+    // and on real links every round pays the collective's latency.  So: a site-sharded model
+    // defaults to ONE group, an unsharded one to two.
+    const unsigned want_groups = m->lockstep_groups ? m->lockstep_groups : (m->model->site_sharded() ? 1u : 2u);
+    cfg.n_groups = workers >= 4 && want_groups >= 2 ? 2u : 1u;
     cfg.n_candidates = todo.size();
     const auto red = m->model->reducer();
     cfg.reduce = red.reduce; cfg.device = red.device; cfg.queue = red.queue; cfg.wait = red.wait;

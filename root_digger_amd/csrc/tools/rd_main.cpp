@@ -41,7 +41,7 @@ namespace {
 struct options_t {
   std::string msa, tree, prefix, partition, model, lbfgsb, rate_cats_type = "mean";
   unsigned states = 4, rate_cats = 1, min_roots = 1, workers = 4;
-  int lockstep = -1, device = -1, site_shards = 1, lockstep_rounds = -1;
+  int lockstep = -1, device = -1, site_shards = 1, lockstep_rounds = -1, lockstep_groups = 0;
   bool site_reduce_host = false, stats = false;
   uint64_t seed = 1;
   double root_ratio = 0.01, atol = 1e-7, bfgstol = 1e-7, brtol = 1e-12, factor = 1e4;
@@ -66,7 +66,7 @@ void usage() {
       "  --rate-cats-type {mean,median,free}  --seed <N>  --min-roots <N>  --root-ratio <X>\n"
       "  --atol <X>  --brtol <X>  --bfgstol <X>  --factor <X>  --early-stop  --no-early-stop\n"
       "  --initial-root-strategy {random,midpoint,modified-mad}  --threads <N>  --lockstep <N>\n"
-      "  --site-shards <G>  --site-reduce {rccl,host}  --lockstep-rounds {0,1}  --stats\n"
+      "  --site-shards <G>  --site-reduce {rccl,host}  --lockstep-rounds {0,1}  --lockstep-groups {1,2}  --stats\n"
       "  --lbfgsb <LIB>  --device <N>  --silent  --echo  --clean  --no-checkpoint  --version");
 }
 
@@ -90,7 +90,8 @@ options_t parse(int argc, char **argv) {
       {"lockstep", required_argument, 0, 0},     {"device", required_argument, 0, 0},
       {"no-checkpoint", no_argument, 0, 0},      {"site-shards", required_argument, 0, 0},
       {"site-reduce", required_argument, 0, 0},  {"lockstep-rounds", required_argument, 0, 0},
-      {"stats", no_argument, 0, 0},              {0, 0, 0, 0}};
+      {"stats", no_argument, 0, 0},              {"lockstep-groups", required_argument, 0, 0},
+      {0, 0, 0, 0}};
   options_t o;
   int index = 0;
   while (getopt_long_only(argc, argv, "", long_opts, &index) == 0) {
@@ -131,6 +132,7 @@ options_t parse(int argc, char **argv) {
     else if (name == "no-checkpoint") o.no_checkpoint = true;
     else if (name == "site-shards") o.site_shards = std::atoi(v);
     else if (name == "lockstep-rounds") o.lockstep_rounds = std::atoi(v);
+    else if (name == "lockstep-groups") o.lockstep_groups = std::atoi(v);
     else if (name == "stats") o.stats = true;
     else if (name == "site-reduce") {
       const std::string s = v;
@@ -307,6 +309,7 @@ static int run(int argc, char **argv) {
   // at a time, a collective per request); free-running replicas would reorder the collectives.
   if (G > 1) o.workers = 0;
   if (o.lockstep_rounds >= 0) rdamd_model_set_lockstep_rounds(model, o.lockstep_rounds);
+  if (o.lockstep_groups > 0) rdamd_model_set_lockstep_groups(model, (unsigned)o.lockstep_groups);
 
   // While the ranks search they exchange nothing over the rendezvous: the end of a
   // connection now means that a rank has died.  Nobody must stay behind inside a

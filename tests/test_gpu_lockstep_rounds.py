@@ -214,7 +214,11 @@ def test_site_sharded_lock_step_equals_the_sequential_sharded_search(tmp_path, w
     seq, lock = str(tmp_path / "seq"), str(tmp_path / "lock")
     st_seq = _run_ranks([RD] + common + ["--prefix", seq, "--lockstep", "0"], world)
     in_flight = 8 if world < 8 else 4       # (eight processes x eight replicas on one device take minutes)
-    st_lock = _run_ranks([RD] + common + ["--prefix", lock, "--lockstep", str(in_flight)], world)
+    # a site-sharded model's default is ONE worker group; the c4-style layouts also run with two
+    # alternating groups (the turn protocol between them is what keeps the ranks' collectives in step)
+    groups_opt = ["--lockstep-groups", "2"] if shards == world else []
+    per_group = in_flight // 2 if groups_opt else in_flight
+    st_lock = _run_ranks([RD] + common + ["--prefix", lock, "--lockstep", str(in_flight)] + groups_opt, world)
     ra = sorted(rd.Checkpoint(seq).read_results())
     rb = sorted(rd.Checkpoint(lock).read_results())
     assert [r[0] for r in ra] == list(range(17))
@@ -229,7 +233,7 @@ def test_site_sharded_lock_step_equals_the_sequential_sharded_search(tmp_path, w
     per_round = int(st_lock[0]["collectives"])
     # (the model's own: the empirical frequencies and model_t::initialize, before the search)
     assert int(st_lock[0]["own_collectives"]) <= 2 and per_round > 0
-    # N candidates in flight = two alternating worker groups of N / 2: up to N / 2 candidates'
-    # requests per collective (fewer towards the end of a list; measured 2.7 of 3 with six)
-    assert per_request > 0.6 * (in_flight / 2) * per_round, (per_request, per_round, in_flight)
+    # a worker group of W candidates: up to W candidates' requests per collective (fewer towards
+    # the end of a list; measured 2.7 of 3 with two groups of three)
+    assert per_request > 0.45 * per_group * per_round, (per_request, per_round, per_group)
     assert open(seq + ".rooted.tree").read() == open(lock + ".rooted.tree").read()
