@@ -21,6 +21,12 @@ $B --config c4 --sites 62500 --steps 4 --warmup 1 --no-cpu-baseline > $O/c4_shar
 $B --config c5 --sites 50000 --steps 4 --warmup 1 --no-cpu-baseline > $O/c5_shard_bench.json 2> $O/c5_shard.err
 $B --shard sites --sites 6250 --steps 40 --warmup 5 --no-cpu-baseline > $O/c2_8_sites_pipelined.json 2> $O/c2_8_sites.err
 $B --shard sites --sites 6250 --steps 40 --warmup 5 --no-cpu-baseline --one-rank-comm > $O/c2_8_sites_pipelined_comm.json 2> $O/c2_8_sites_comm.err
+# the per-rank shapes of the default N = 2 / 4 / 8 line's site_sharded leg (c2's sites / N), one rank, the collective's
+# launch included: what profiles/r5_scale_prediction.md extrapolates from
+for sites in 25000 12500 6250; do $B --shard sites --sites $sites --steps 40 --warmup 5 --no-cpu-baseline --one-rank-comm 2> /dev/null | python3 -c "
+import sys,json
+d=json.loads(sys.stdin.read()); r=d['roofline']
+print('c2 sites/%d = %5d per rank, pipelined + one-rank all-reduce: %9.1f evals/s  %.4f ms per 197-job step  evaluator kernel %.4f ms' % (50000 // $sites, $sites, d['value'], d['ms_per_step'], r['avg_launch_ms']))"; done | tee $O/per_rank_shapes.txt
 for c in c2 c3 c4 c5 d125 c4_shard c5_shard; do python3 -c "
 import json
 d=json.load(open('$O/${c}_bench.json')); r=d['roofline']; k=d.get('clv_kernel',{})
