@@ -142,6 +142,12 @@ def test_rccl_calls_of_the_multi_gpu_path_with_one_rank():
     a = run_bench("--no-cpu-baseline", "--shard", "sites", env=env)
     b = run_bench("--no-cpu-baseline", "--shard", "sites")
     assert a["n_gpus"] == 1 and a["lnl_check"] == b["lnl_check"]
+    # ... and with the LIBRARY's communicator beside torch's in one process: its id travels over the
+    # process group (broadcast_object_list), its all-reduce of the lnLs + the second-pass flag is
+    # queued on the partition's stream behind every stream-ordered batch (what the site_sharded /
+    # grid legs of the N > 1 line do on real links)
+    a2 = run_bench("--no-cpu-baseline", "--shard", "sites", "--one-rank-comm", env=env)
+    assert a2["lnl_check"] == b["lnl_check"]
     c = run_bench("--no-cpu-baseline", env=env)          # candidate sharding: barrier + MAX only
     assert c["value"] > 0
     assert c["rccl_ranks"] == 1 and a["rccl_ranks"] == 1   # a real all-reduce over the communicator
