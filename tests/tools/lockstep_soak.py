@@ -17,9 +17,10 @@ import root_digger_amd as rd          # noqa: E402
 from root_digger_amd import synth     # noqa: E402
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+comm = rd.Comm(rd.Comm.unique_id(), 0, 1)     # a one-rank site group: the device path of the rounds
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 lb = ctypes.CDLL(os.path.join(ROOT, "oracle", "_ref", "liblbfgsb_ref.so"))
-t0, rounds, cands = time.time(), 0, 0
+t0, rounds, cands, sharded = time.time(), 0, 0, 0
 while time.time() - t0 < budget:
     n = int(rng.integers(5, 40))
     S = int(rng.choice([130, 1000, 4097, 20000]))
@@ -46,7 +47,22 @@ while time.time() - t0 < budget:
         assert lock["root_id"] == sorted(seq["root_id"]), (n, S, R, in_flight)
         assert np.array_equal(lock["llh"], seq["llh"][order]), (n, S, R, in_flight, lock["llh"], seq["llh"][order])
         assert np.array_equal(lock["alpha"], seq["alpha"][order]), (n, S, R, in_flight)
+    # round 5: the same search in DETERMINISTIC ROUNDS (lockstep_conductor.hpp), one or two worker groups ...
+    m.set_lockstep_rounds(1)
+    m.set_lockstep_groups(int(rng.integers(1, 3)))
+    lock = m.exhaustive_search(*tol, lockstep=int(rng.integers(2, 12)))
+    assert lock["root_id"] == sorted(seq["root_id"]), (n, S, R, "rounds")
+    assert np.array_equal(lock["llh"], seq["llh"][order]) and np.array_equal(lock["alpha"], seq["alpha"][order]), (n, S, R, "rounds")
+    m.set_lockstep_rounds(-1)
+    m.set_lockstep_groups(0)
+    if rounds % 3 == 0:   # ... and as a site-sharded model would run it: the RCCL reducer behind every round
+        m.set_lnl_reducer(comm.reducer, on_device=True, user=comm.handle)
+        lock = m.exhaustive_search(*tol, lockstep=int(rng.integers(2, 12)))
+        assert np.array_equal(lock["llh"], seq["llh"][order]) and np.array_equal(lock["alpha"], seq["alpha"][order]), (n, S, R, "rccl rounds")
+        m.set_lnl_reducer(None)
+        sharded += 1
     rounds += 1
     cands += len(seq["root_id"])
-print("%d random models, %d candidates each searched sequentially and twice in lock step: identical records; %.0f s"
-      % (rounds, cands, time.time() - t0))
+print("%d random models, %d candidates each searched sequentially, twice in lock step (arrival order) and once in "
+      "deterministic rounds (%d of the models also with the one-rank RCCL reducer behind every round): identical records; %.0f s"
+      % (rounds, cands, sharded, time.time() - t0))

@@ -93,11 +93,19 @@ while time.time() - t0 < budget:
         fused = g.evaluate_batch([g.schedule(ops, pmi, brl)], [w["subst"]], [freqs])[0]
     err = max(abs(la - lb), abs(fused - lb)) / abs(lb)
     assert err < 1e-11, (n, S, R, K, la, lb, fused)
-    if K != 20:                  # the root's children left behind by the exporting evaluator
+    if K != 20 or R <= 4:        # the root's children left behind by the exporting evaluators (4 / 2 / 20 states)
         # (rdamd_evaluate_root_children): the value, the two CLVs up to their scalers, and the
         # root-only evaluation on top of them, with other parameters than the traversal above
         subst2 = [v * float(rng.uniform(0.5, 2.0)) for v in w["subst"]]
         lc = g.evaluate_root_children(ops, pmi, brl, subst2, freqs, w["rates"])
+        if rng.random() < 0.3:   # the same on a SPARSE partition (a search replica's): the dense one's bits
+            sp = rd.Partition.for_tree(tree, K, S, R, attributes=rd.ATTRIB_SPARSE_CLVS)
+            util.load_tips(sp, tree, w["seqs"], cmap)
+            assert sp.evaluate_root_children(ops, pmi, brl, subst2, freqs, w["rates"]) == lc, (n, S, R, K, "sparse")
+            for clv in (ops[-1].child1_clv_index, ops[-1].child2_clv_index):
+                if clv >= n:
+                    assert np.array_equal(sp.get_clv(clv), g.get_clv(clv)), (n, S, R, K, clv, "sparse CLV")
+            sp.destroy()
         o.set_subst_params(0, subst2)
         g.set_subst_params(0, subst2)
         o.update_prob_matrices(pmi, brl)
