@@ -222,9 +222,9 @@ private:
     if (!_error.empty() && req.kind != NEXT) throw std::runtime_error(_error);
   }
 
-  void ensure_vec(group_t &grp, size_t n) {
+  void ensure_vec(group_t &grp, size_t n, hipStream_t stream) {
     if (n <= grp.cap) return;
-    RDAMD_ROUND_TRY(hipStreamSynchronize(_stream));
+    RDAMD_ROUND_TRY(hipStreamSynchronize(stream));
     if (grp.d_vec) (void)hipFree(grp.d_vec);
     if (grp.h_in) (void)hipHostFree(grp.h_in);
     if (grp.h_res) (void)hipHostFree(grp.h_res);
@@ -238,8 +238,9 @@ private:
   // `lk` is held on entry and on return
   void run_round(unsigned g, std::vector<request_t *> &round, std::unique_lock<std::mutex> &lk) {
     group_t &grp = _g[g];
-    // (asked for every round: rdamd_partition_set_stream_priority re-creates the stream)
-    _stream = (hipStream_t)rdamd_partition_stream(_c.shared);
+    // (asked for every round: rdamd_partition_set_stream_priority re-creates the stream; a local --
+    // the other group's round may be under way)
+    const hipStream_t stream = (hipStream_t)rdamd_partition_stream(_c.shared);
     if (!grp.ev) RDAMD_ROUND_TRY(hipEventCreateWithFlags(&grp.ev, hipEventDisableTiming));
     std::sort(round.begin(), round.end(), [](const request_t *a, const request_t *b) { return a->worker < b->worker; });
     // ---- candidates, in worker order (under the lock: the counter is shared by the groups,
@@ -276,7 +277,7 @@ private:
     for (request_t *r : root) n_root += r->n;
     for (request_t *r : red) n_red += r->n;
     const size_t o_flag = m, o_root = m + 1, o_red = o_root + n_root, total = o_red + n_red;
-    ensure_vec(grp, total);
+    ensure_vec(grp, total, stream);
     const bool two_phase = _c.device && _c.queue && _c.wait;
     const bool device_path = !_c.reduce || _c.device;   // (no reducer at all: the device path without a collective)
 
@@ -346,10 +347,10 @@ private:
       // (host-made values go up behind the batch; the front of the vector is the batch's)
       const size_t lo = m ? o_root : 0;
       if (total > lo)
-        RDAMD_ROUND_TRY(hipMemcpyAsync(grp.d_vec + lo, grp.h_in + lo, (total - lo) * sizeof(double), hipMemcpyHostToDevice, _stream));
-      queue_sum(grp.d_vec, total, two_phase);
-      RDAMD_ROUND_TRY(hipMemcpyAsync(grp.h_res, grp.d_vec, total * sizeof(double), hipMemcpyDeviceToHost, _stream));
-      RDAMD_ROUND_TRY(hipEventRecord(grp.ev, _stream));
+        RDAMD_ROUND_TRY(hipMemcpyAsync(grp.d_vec + lo, grp.h_in + lo, (total - lo) * sizeof(double), hipMemcpyHostToDevice, stream));
+      queue_sum(grp.d_vec, total, two_phase, stream);
+      RDAMD_ROUND_TRY(hipMemcpyAsync(grp.h_res, grp.d_vec, total * sizeof(double), hipMemcpyDeviceToHost, stream));
+      RDAMD_ROUND_TRY(hipEventRecord(grp.ev, stream));
       need_redo_check = m > 0;
     } else {
       // host reducer (ranks that share a device): the batch's own wait runs the second pass where
@@ -386,10 +387,10 @@ private:
         if (rdamd_evaluate_batch_redo_device(_c.shared, g, grp.d_vec) != RDAMD_SUCCESS)
           throw std::runtime_error(std::string("lock-step round: second pass: ") + rdamd_errmsg());
         if (total > o_root)
-          RDAMD_ROUND_TRY(hipMemcpyAsync(grp.d_vec + o_root, grp.h_in + o_root, (total - o_root) * sizeof(double), hipMemcpyHostToDevice, _stream));
-        queue_sum(grp.d_vec, total, two_phase);
-        RDAMD_ROUND_TRY(hipMemcpyAsync(grp.h_res, grp.d_vec, total * sizeof(double), hipMemcpyDeviceToHost, _stream));
-        RDAMD_ROUND_TRY(hipEventRecord(grp.ev, _stream));
+          RDAMD_ROUND_TRY(hipMemcpyAsync(grp.d_vec + o_root, grp.h_in + o_root, (total - o_root) * sizeof(double), hipMemcpyHostToDevice, stream));
+        queue_sum(grp.d_vec, total, two_phase, stream);
+        RDAMD_ROUND_TRY(hipMemcpyAsync(grp.h_res, grp.d_vec, total * sizeof(double), hipMemcpyDeviceToHost, stream));
+        RDAMD_ROUND_TRY(hipEventRecord(grp.ev, stream));
         wait_round(grp, two_phase);
       }
       if (m && rdamd_evaluate_batch_finish_device(_c.shared, g) != RDAMD_SUCCESS)
@@ -409,10 +410,10 @@ private:
   }
 
   // the site group's sum over d[0 .. n), queued on the shared partition's stream
-  void queue_sum(double *d, size_t n, bool two_phase) {
+  void queue_sum(double *d, size_t n, bool two_phase, hipStream_t stream) {
     if (!_c.reduce && !_c.queue) return;   // a one-rank group
-    const int rc = two_phase ? _c.queue(d, (unsigned)n, (void *)_stream, _c.async_user)
-                             : _c.reduce(d, (unsigned)n, (void *)_stream, _c.user);
+    const int rc = two_phase ? _c.queue(d, (unsigned)n, (void *)stream, _c.async_user)
+                             : _c.reduce(d, (unsigned)n, (void *)stream, _c.user);
     if (rc != RDAMD_SUCCESS)
       throw std::runtime_error(std::string("lock-step round: site-group reduction failed: ") + rdamd_errmsg());
   }
@@ -428,7 +429,6 @@ private:
 #undef RDAMD_ROUND_TRY
 
   config_t _c;
-  hipStream_t _stream = nullptr;
   mutable std::mutex _mu;
   std::condition_variable _cv;
   group_t _g[2];
