@@ -354,6 +354,16 @@ fused_dna_eval_kernel(FusedArgs a) {
   // >= 2^-256 and the rescale test cannot fire on a non-zero vector: it is compiled
   // out of the variant that runs then (+3.5 % on c2; a run-time branch gave nothing)
   if ((uni(to_const(&a.jobs[job].tt_unsafe)[0]) != 0u) != TTCHECK) return;
+  // A padding block of the grid (blocks_x is a multiple of 16 so that an XCD keeps its eighth of
+  // the sites: up to 15 blocks of 64 sites beyond the alignment's end -- 12.5 % of the workgroups
+  // of a 6 250-site shard, 0.25 % of c2's): nothing to evaluate, its partial sums are the zeros a
+  // wave of clamped sites would have arrived at after a whole traversal (round 5).
+  if (bx * (64u * NS) >= S) {
+    if (threadIdx.x == 0)
+#pragma unroll
+      for (int q = 0; q < NS; ++q) a.partials[(size_t)job * (gridDim.x * NS) + bx * NS + q] = 0.0;
+    return;
+  }
   constexpr bool tt_safe = !TTCHECK;
   // (the variant with the test walks the PLAIN programs -- no pseudo-tips, every rescale
   // where the reference rule has it; fused.hpp)
