@@ -174,6 +174,49 @@ def test_rounds_with_the_rccl_communicator_as_reducer(sequential_records):
     comm.destroy()
 
 
+def test_rounds_repeat_the_collective_when_a_batch_needs_its_second_pass(tmp_path):
+    """A branch of length 1e-40 puts P-matrix entries into (0, 2^-128): every job that meets it is
+    flagged (FusedJob::tt_unsafe) and must run the evaluator's second pass.  In a round that
+    decision travels through the sum: the batch's flag comes back non-zero, the round runs the
+    pass, restores this rank's values and repeats its collective (rdamd_evaluate_batch_redo_device)
+    -- with and without a reducer, one and two worker groups; the records are the sequential
+    search's, whose blocking batches take the pass inside rdamd_evaluate_batch."""
+    if not os.path.exists(REF):
+        pytest.skip("oracle/_ref/liblbfgsb_ref.so not built")
+    nw = open(TREE).read()
+    mt = re.search(r":[0-9.eE+-]+", nw)
+    tree = rd.Tree.from_newick(nw[:mt.start()] + ":1e-40" + nw[mt.end():])
+    seqs, w = util.compress(util.read_fasta(MSA))
+
+    def model():
+        m = rd.Model(tree, seqs, rate_cats=4, weights=w, seed=3)
+        m.initialize_partitions()
+        m.set_lbfgsb(C.CDLL(REF).setulb)
+        return m
+
+    def search(m, lockstep):
+        m.assign_by_rank(0, 3)                     # the first six candidates
+        r = m.exhaustive_search(*LOOSE, lockstep=lockstep)
+        return list(r["root_id"]), list(r["llh"]), list(r["alpha"])
+
+    seq = model()
+    want = search(seq, 0)
+    assert np.all(np.isfinite(want[1]))
+    seq.destroy()
+    comm = rd.Comm(rd.Comm.unique_id(), 0, 1)
+    for with_reducer, groups, in_flight in ((False, 1, 3), (False, 2, 6), (True, 1, 6), (True, 2, 4)):
+        m = model()
+        if with_reducer:
+            m.set_lnl_reducer(comm.reducer, on_device=True, user=comm.handle)
+        m.set_lockstep_rounds(1)
+        m.set_lockstep_groups(groups)
+        assert search(m, in_flight) == want, (with_reducer, groups)
+        st = m.round_stats()
+        assert st["redos"] > 0 and st["collectives"] > st["redos"], st
+        m.destroy()
+    comm.destroy()
+
+
 def _run_ranks(args, world, timeout=900):
     s = __import__("socket").socket()
     s.bind(("127.0.0.1", 0))
