@@ -777,10 +777,17 @@ def main():
         p2 = part.profile_read()
         part.profile_enable(False)
         extra["clv_kernel"] = clv_roofline(p2["clv"][0], p2["clv"][1], 6)
+        # (a traversal may be several launches of the kernel -- independent subtrees side by side,
+        # level by level: `avg_launch_ms` and `traffic` are per TRAVERSAL, a profiler's per-kernel
+        # average times this count)
+        lpt = part.update_clvs_launches()
+        extra["clv_kernel"]["kernel_launches_per_traversal"] = lpt
         try:
             if default_cmd:
                 extra["clv_kernel"]["traffic"], extra["clv_kernel"]["traffic_source"] = profiled_traffic(
                     clv_kernel, nb, args.config)
+                if extra["clv_kernel"]["traffic"]:
+                    extra["clv_kernel"]["traffic"] *= lpt
                 if extra["clv_kernel"]["traffic"]:   # the bytes that really crossed HBM, per second
                     gbs = extra["clv_kernel"]["traffic"] / (extra["clv_kernel"]["avg_launch_ms"] * 1e-3) / 1e9
                     extra["clv_kernel"]["counter_gbs"] = round(gbs, 1)

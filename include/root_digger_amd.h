@@ -165,6 +165,11 @@ int rdamd_update_prob_matrices(rdamd_partition_t  *p,
  * be in dependency (post-) order, as corax_utree_create_operations emits. */
 void rdamd_update_clvs(rdamd_partition_t *p, const rdamd_operation_t *ops,
                        unsigned int count);
+/* Diagnostic: kernel launches the partition's last rdamd_update_clvs call took.  A full traversal
+ * that leaves most of the device's wave slots empty is cut into independent subtrees that run
+ * side by side, level by level -- one launch per level (a profiler sees that many launches of the
+ * traversal kernel per call). */
+unsigned int rdamd_update_clvs_launches(const rdamd_partition_t *p);
 /* replaces corax_compute_root_loglikelihood, src/model.cpp:406, :441, :466.
  * persite_lnl may be NULL (the reference always passes nullptr). */
 double rdamd_compute_root_loglikelihood(rdamd_partition_t  *p,

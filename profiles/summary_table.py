@@ -17,7 +17,7 @@ summ = json.load(open(os.path.join(root, tag + "_summary.json")))
 out = ["# Round %s: one table (`profiles/%s_*_bench.json`, `%s_summary.json`; one box; regenerate: `python profiles/summary_table.py %s`)\n"
        % (tag[1:], tag, tag, tag),
        "| config | evals/s | evaluator ms / launch | frac of FP64 peak, operations executed | frac, FP64 instructions issued | "
-       "steps of / operations per evaluation | materialising traversal (frac of HBM peak, algorithmic bytes) |",
+       "steps of / operations per evaluation | materialising traversal: time, frac of HBM peak in algorithmic bytes |",
        "|---|---|---|---|---|---|---|"]
 for key, label in names:
     path = os.path.join(root, "%s_%s_bench.json" % (tag, key))
@@ -30,7 +30,12 @@ for key, label in names:
     out.append("| %s | %.1f | %.3f | %.4f | %s | %s | %s |" % (
         label, d["value"], r["avg_launch_ms"], r["frac"], "%.3f" % (issued / 78.6) if issued else "--",
         "%.1f / %d" % (sch.get("steps_per_evaluation", 0), sch.get("operations_per_evaluation", 0)) if sch else "--",
-        k.get("frac", "--")))
+        ("%.0f us in %d launch%s: %s%s%s" % (
+            1e3 * k["avg_launch_ms"], k.get("kernel_launches_per_traversal", 1),
+            "" if k.get("kernel_launches_per_traversal", 1) == 1 else "es", k["frac"],
+            " (uncapped %.3f)" % k["frac_uncapped"] if "frac_uncapped" in k else "",
+            "; %.2f of the peak in bytes that crossed HBM" % k["counter_frac"] if k.get("counter_frac") else ""))
+        if k else "--"))
 iss = json.load(open(os.path.join(root, tag + "_c2_bench.json")))["roofline"]["issue"]
 v = max((v for k, v in summ.items() if k.startswith("fused_dna_eval_kernel") and "SQ_INSTS_SALU" in v),
         key=lambda v: v.get("avg_us", 0))

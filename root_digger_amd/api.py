@@ -114,6 +114,7 @@ _sig("rdamd_evaluate_batch_redo_device", C.c_int, _vp, _u, _vp)
 _sig("rdamd_evaluate_batch_finish_device", C.c_int, _vp, _u)
 _sig("rdamd_partition_discard_clvs", None, _vp)
 _sig("rdamd_partition_clv_bytes", C.c_uint64, _vp)
+_sig("rdamd_update_clvs_launches", C.c_uint, _vp)
 _sig("rdamd_evaluate_root_children", C.c_int, _vp, _pop, _u, _pu, _pd, _u, _pd, _pd, _pd, _pd, _pd)
 _sig("rdamd_get_clv", C.c_int, _vp, _u, _pd)
 _sig("rdamd_get_scaler", C.c_int, _vp, _u, _pu)
@@ -847,6 +848,11 @@ class Partition:
     def discard_clvs(self):
         """ATTRIB_SPARSE_CLVS partitions: every CLV / scale buffer gives its memory back."""
         lib.rdamd_partition_discard_clvs(self._h)
+
+    def update_clvs_launches(self):
+        """kernel launches the last update_clvs call took (a list that leaves the device empty is
+        cut into independent subtrees, one launch per level of the cut)"""
+        return int(lib.rdamd_update_clvs_launches(self._h))
 
     def clv_bytes(self):
         """device bytes the CLV and scale buffers hold right now"""

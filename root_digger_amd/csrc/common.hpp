@@ -137,6 +137,7 @@ struct rdamd_partition {
   bool      sparse = false;
   std::vector<int> clv_slot, sc_slot;            // caller's index -> slot, or -1
   unsigned  clv_slots_used = 0, clv_slots_cap = 0, sc_slots_used = 0, sc_slots_cap = 0;
+  unsigned  last_clv_launches = 0;   // rdamd_update_clvs_launches
   double   *d_pmat = nullptr;
   double   *d_tiptab = nullptr;
   double   *d_pmat_mfma = nullptr;   // 20-state only: MFMA-ready copy of d_pmat
@@ -269,17 +270,26 @@ constexpr uint64_t kNoOffset = ~0ull;
 unsigned clv_traversal_slots(const rdamd_partition *p);
 // the 4-state kernel wants its list padded with no-ops to a multiple of this (else 1)
 unsigned clv_traversal_chunk(const rdamd_partition *p);
-hipError_t launch_clv_traversal(rdamd_partition *p, const LevelOp *d_ops, unsigned nops,
-                                unsigned slots);
-
-// kernels_clv_mfma.hip (20 states)
-hipError_t launch_pmat_to_mfma(rdamd_partition *p, const unsigned *d_matrix_indices, unsigned count);
 // independent pieces of one operation list, run side by side (grid.y): [start, start + len) each
 constexpr unsigned kK20MaxPieces = 8;
 struct K20Pieces {
   unsigned n = 0;
   unsigned start[kK20MaxPieces] = {0}, len[kK20MaxPieces] = {0};
 };
+// the 4-state kernel's pieces
+constexpr unsigned kDnaMaxPieces = 32;
+struct DnaPieces {
+  unsigned n = 0;
+  unsigned start[kDnaMaxPieces] = {0}, len[kDnaMaxPieces] = {0};
+};
+// most pieces per launch a list of `count` operations of this partition is worth cutting into
+// (0: run the list as it is)
+unsigned clv_traversal_pieces(const rdamd_partition *p, unsigned count);
+hipError_t launch_clv_traversal(rdamd_partition *p, const LevelOp *d_ops, const DnaPieces &pieces,
+                                unsigned slots);
+
+// kernels_clv_mfma.hip (20 states)
+hipError_t launch_pmat_to_mfma(rdamd_partition *p, const unsigned *d_matrix_indices, unsigned count);
 hipError_t launch_clv_k20_traversal(rdamd_partition *p, const LevelOp *d_ops, const K20Pieces &pieces);
 size_t k20_mfma_copy_doubles();               // doubles per (matrix, rate) in d_pmat_mfma
 

@@ -43,11 +43,18 @@ inline bool k20_hazard(unsigned tips, const rdamd_operation_t *ops, unsigned i, 
 // operations that join them.  Returns the re-ordered list (pieces, then top) and the piece
 // boundaries; leaves both empty when the list is no such nest (arbitrary operation orders,
 // partial traversals) or too short to be worth a second launch.
+// (`forwarding_hazards` = false: the 4-state kernel, which reads a memory child at use, behind
+// every earlier store of the lane -- no piece can need a cut of its own there.  `small`: a piece
+// of at most this many operations is not cut further; 0 = a quarter of the list, at least 12.
+// `min_count`: shorter lists stay whole.  `external_children`: an inner child nothing in the list
+// computes is taken as given, like a tip -- the top list of an earlier cut is such a list.)
 inline void k20_split(unsigned tips, unsigned clv_buffers, const rdamd_operation_t *ops, unsigned count,
-                      unsigned max_pieces, std::vector<rdamd_operation_t> &order, std::vector<unsigned> &bounds) {
+                      unsigned max_pieces, std::vector<rdamd_operation_t> &order, std::vector<unsigned> &bounds,
+                      bool forwarding_hazards = true, unsigned small = 0, unsigned min_count = 24,
+                      bool external_children = false) {
   order.clear();
   bounds.clear();
-  if (count < 24) return;
+  if (count < min_count || count < 3) return;
   const unsigned nclv = tips + clv_buffers;
   std::vector<int> producer(nclv, -1), parent(count, -1);
   std::vector<unsigned> size(count, 1);
@@ -62,6 +69,7 @@ inline void k20_split(unsigned tips, unsigned clv_buffers, const rdamd_operation
     for (unsigned ch : {o.child1_clv_index, o.child2_clv_index})
       if (ch >= tips) {
         const int j = producer[ch];
+        if (j < 0 && external_children) continue;
         if (j < 0 || parent[j] >= 0) return;   // not computed in this list / used twice
         kids[nk++] = j;
       }
@@ -83,7 +91,7 @@ inline void k20_split(unsigned tips, unsigned clv_buffers, const rdamd_operation
     for (size_t k = 1; k < pieces.size(); ++k)
       if (size[pieces[k]] > size[pieces[big]]) big = k;
     const unsigned r = pieces[big];
-    if (size[r] <= std::max(12u, count / 4) || pieces.size() + 1 > max_pieces) break;
+    if (size[r] <= (small ? small : std::max(12u, count / 4)) || pieces.size() + 1 > max_pieces) break;
     top[r] = 1;
     pieces.erase(pieces.begin() + (std::ptrdiff_t)big);
     for (unsigned j = 0; j < r; ++j)
@@ -101,13 +109,50 @@ inline void k20_split(unsigned tips, unsigned clv_buffers, const rdamd_operation
   for (unsigned j = 0; j < count; ++j)
     if (top[j]) order.push_back(ops[j]);
   // no piece may need a further cut of its own (then the plain order runs)
-  for (size_t k = 0; k + 1 < bounds.size(); ++k)
+  for (size_t k = 0; forwarding_hazards && k + 1 < bounds.size(); ++k)
     for (unsigned i = bounds[k] + 1; i < bounds[k + 1]; ++i)
       if (k20_hazard(tips, order.data(), i, bounds[k])) {
         order.clear();
         bounds.clear();
         return;
       }
+}
+
+// The 4-state traversal kernel's launches for one list (kernels_clv.hip: every lane walks its
+// list alone, so a launch lasts as long as its longest list): the list is cut into pieces, the
+// operations that join them -- a list with external children -- are cut again, and so on until what
+// is left is short.  `seg`: segment boundaries in `order` (segments = pieces, or a whole remaining
+// list), `level`: the first segment of every launch (+ the segment count).  Empty `order`: the list
+// runs as it is.
+struct ListLevels {
+  std::vector<rdamd_operation_t> order;
+  std::vector<unsigned> seg, level;
+};
+inline void list_levels(unsigned tips, unsigned clv_buffers, const rdamd_operation_t *ops, unsigned count,
+                        unsigned max_pieces, unsigned small, unsigned min_count, ListLevels &out) {
+  out.order.clear();
+  out.seg.clear();
+  out.level.clear();
+  std::vector<rdamd_operation_t> cur(ops, ops + count), order;
+  std::vector<unsigned> bounds;
+  bool external = false;
+  for (;;) {
+    k20_split(tips, clv_buffers, cur.data(), (unsigned)cur.size(), max_pieces, order, bounds, false,
+              std::max(small, (unsigned)cur.size() / std::max(1u, max_pieces)), min_count, external);
+    if (order.empty()) break;
+    const unsigned base = (unsigned)out.order.size(), top = bounds.back();
+    out.level.push_back((unsigned)out.seg.size());
+    for (size_t k = 0; k + 1 < bounds.size(); ++k) out.seg.push_back(base + bounds[k]);
+    out.order.insert(out.order.end(), order.begin(), order.begin() + top);
+    cur.assign(order.begin() + top, order.end());
+    external = true;
+  }
+  if (out.order.empty()) return;   // never cut
+  out.level.push_back((unsigned)out.seg.size());   // what is left: one segment, one launch
+  out.seg.push_back((unsigned)out.order.size());
+  out.order.insert(out.order.end(), cur.begin(), cur.end());
+  out.seg.push_back((unsigned)out.order.size());
+  out.level.push_back((unsigned)out.seg.size() - 1);
 }
 
 }  // namespace rdamd

@@ -25,6 +25,7 @@
 #include "common.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 
 namespace rdamd {
 
@@ -71,8 +72,17 @@ constexpr unsigned kChunk = 4;
 
 template <int R>
 __global__ void __launch_bounds__(256)
-clv_dna_traversal_kernel(DeviceView v, const LevelOp *__restrict__ ops, unsigned nops,
+clv_dna_traversal_kernel(DeviceView v, const LevelOp *__restrict__ all_ops, DnaPieces pieces,
                          unsigned slots) {
+  // Independent PIECES of the list side by side (grid.y; round 5): all of c2's waves are resident
+  // from the start, three per SIMD, so a launch lasts as long as ONE wave needs for its whole
+  // list -- and a wave that waits (LDS reads, scalar loads, its turn on the SIMD) does not store
+  // (profiles/micro/clv_store_pattern.hip: the stores alone 126 us, with half a microsecond
+  // between a wave's stores 143 - 161 us).  Subtrees of the list are independent chains: the
+  // host cuts it (k20_split.hpp), the pieces run as the rows of this launch, the few operations
+  // that join them follow as a second launch.
+  const LevelOp *__restrict__ ops = all_ops + pieces.start[blockIdx.y];
+  const unsigned nops = pieces.len[blockIdx.y];
   // Why the memory pipe sees (almost) only stores inside the loop: vector-memory
   // operations retire in issue order, so a load queued behind the CLV stores of
   // the previous operation cannot return before they are acknowledged, and with
@@ -415,26 +425,47 @@ unsigned clv_traversal_slots(const rdamd_partition *p) {
 
 unsigned clv_traversal_chunk(const rdamd_partition *p) { return dna_fast_ok(p) ? kChunk : 1u; }
 
-hipError_t launch_clv_traversal(rdamd_partition *p, const LevelOp *d_ops, unsigned nops,
+// A list whose one row of blocks leaves most of the device's wave slots empty is cut into pieces
+// (k20_split.hpp, list_levels).  How many per launch, measured on one box (profiles/
+// r5_clv_pieces_ab.txt; us per traversal, whole list -> best cut):
+//   c2 / 8 (98 blocks, 99 operations)      102 ->   65 with 16 (32: 69)
+//   125.phy (304 blocks, 124)              133 ->   91 with 16 (8: 110, 32: 100)
+//   c2 (782 blocks, 99)                    175 ->  158 with  8 (16: 188 -- a third of the list is the
+//                                                  tree's spine then, a chain no cut shortens)
+//   c5's shard (782 blocks, 999)          1848 -> 1610 with 16 - 32 (8: 1800)
+//   c4's shard (977 blocks, 499)          1013 ~  1000 with  8; c5 (1 563 blocks), c4 (7 813): no gain
+// i.e. about 6 000 blocks per launch, at least a piece per 64 operations, no piece under 6.
+unsigned clv_traversal_pieces(const rdamd_partition *p, unsigned count) {
+  if (!dna_fast_ok(p) || p->sites == 0 || count < 24) return 0;
+  const size_t blocks = ((size_t)p->sites * p->rate_cats + 255) / 256;
+  size_t want = blocks <= 896 ? std::min<size_t>(std::max<size_t>(6144 / blocks, count / 64), count / 6) : 0;
+#ifdef RDAMD_ABLATION
+  if (getenv("RDAMD_CLV_PIECES")) want = (size_t)atoi(getenv("RDAMD_CLV_PIECES"));
+#endif
+  return want >= 2 ? (unsigned)std::min<size_t>(want, kDnaMaxPieces) : 0u;
+}
+
+hipError_t launch_clv_traversal(rdamd_partition *p, const LevelOp *d_ops, const DnaPieces &pieces,
                                 unsigned slots) {
-  if (nops == 0 || p->sites == 0) return hipSuccess;
+  if (pieces.n == 0 || p->sites == 0) return hipSuccess;
   DeviceView v = p->view();
   const unsigned R = p->rate_cats;
   if (dna_fast_ok(p)) {
     // one (site, rate) pair per lane where possible: maximum memory-level
     // parallelism; the lane -> pair map is identical for every operation
     size_t total = (size_t)p->sites * R;
-    unsigned gx = (unsigned)((total + 255) / 256);
+    const dim3 grid((unsigned)((total + 255) / 256), pieces.n);
     const size_t lds = (size_t)slots * 256 * (32 + 4);
     switch (R) {
-      case 1: clv_dna_traversal_kernel<1><<<gx, 256, lds, p->stream>>>(v, d_ops, nops, slots); break;
-      case 2: clv_dna_traversal_kernel<2><<<gx, 256, lds, p->stream>>>(v, d_ops, nops, slots); break;
-      case 4: clv_dna_traversal_kernel<4><<<gx, 256, lds, p->stream>>>(v, d_ops, nops, slots); break;
-      default: clv_dna_traversal_kernel<8><<<gx, 256, lds, p->stream>>>(v, d_ops, nops, slots); break;
+      case 1: clv_dna_traversal_kernel<1><<<grid, 256, lds, p->stream>>>(v, d_ops, pieces, slots); break;
+      case 2: clv_dna_traversal_kernel<2><<<grid, 256, lds, p->stream>>>(v, d_ops, pieces, slots); break;
+      case 4: clv_dna_traversal_kernel<4><<<grid, 256, lds, p->stream>>>(v, d_ops, pieces, slots); break;
+      default: clv_dna_traversal_kernel<8><<<grid, 256, lds, p->stream>>>(v, d_ops, pieces, slots); break;
     }
   } else {
     unsigned gx = (p->sites + 255) / 256;
-    clv_generic_traversal_kernel<<<gx, 256, 0, p->stream>>>(v, d_ops, nops);
+    for (unsigned k = 0; k < pieces.n; ++k)   // (this path never cuts its lists: one piece)
+      clv_generic_traversal_kernel<<<gx, 256, 0, p->stream>>>(v, d_ops + pieces.start[k], pieces.len[k]);
   }
   return hipGetLastError();
 }

@@ -403,6 +403,8 @@ void rdamd_partition_discard_clvs(rdamd_partition_t *p) {
   p->clv_slots_used = p->sc_slots_used = 0;
 }
 
+unsigned int rdamd_update_clvs_launches(const rdamd_partition_t *p) { return p->last_clv_launches; }
+
 uint64_t rdamd_partition_clv_bytes(const rdamd_partition_t *p) {
   const uint64_t c = p->sparse ? p->clv_slots_cap : p->clv_buffers, s = p->sparse ? p->sc_slots_cap : p->scale_buffers;
   return c * p->clv_doubles() * sizeof(double) + s * (uint64_t)p->sites * sizeof(unsigned);
@@ -656,7 +658,19 @@ void rdamd_update_clvs(rdamd_partition_t *p, const rdamd_operation_t *ops,
   std::vector<rdamd_operation_t> k20_order;
   std::vector<unsigned> k20_bounds;
   if (p->mfma_layout) k20_split(p->tips, p->clv_buffers, ops, count, kK20MaxPieces, k20_order, k20_bounds);
+  // (4 states: the same cut where one row of blocks leaves the device's wave slots empty, kernels_clv.hip)
+  const unsigned dna_rows = p->mfma_layout ? 0u : clv_traversal_pieces(p, count);
+  ListLevels lv;
+  if (dna_rows >= 2) {
+    unsigned small = 8, min_count = 16;
+#ifdef RDAMD_ABLATION
+    if (getenv("RDAMD_CLV_PIECE_OPS")) small = (unsigned)atoi(getenv("RDAMD_CLV_PIECE_OPS"));
+    if (getenv("RDAMD_CLV_MIN_SPLIT")) min_count = (unsigned)atoi(getenv("RDAMD_CLV_MIN_SPLIT"));
+#endif
+    list_levels(p->tips, p->clv_buffers, ops, count, dna_rows, small, min_count, lv);
+  }
   if (!k20_order.empty()) ops = k20_order.data();
+  if (!lv.order.empty()) ops = lv.order.data();
   std::vector<LevelOp> lops(count);
   for (unsigned i = 0; i < count; ++i) {
     const rdamd_operation_t &o = ops[i];
@@ -696,9 +710,12 @@ void rdamd_update_clvs(rdamd_partition_t *p, const rdamd_operation_t *ops,
   // slots are full the value needed furthest in the future gives its slot up
   // and is read back from HBM instead -- every CLV is written there anyway).
   // A child is forwarded only when its scaler index is the producer's.
-  const unsigned nslots = clv_traversal_slots(p);
-  // (`cuts` splits a list into separate launches; nothing needs that today:
-  // memory children are read at use, after every earlier store of the lane.)
+  // (`cuts` splits a list into segments, each analysed on its own: the pieces of a split list, which
+  // run side by side with the slots their row count leaves them, then the operations that join them;
+  // the 4-state kernel needs no other cut -- memory children are read at use, after every earlier
+  // store of the lane.)
+  const size_t n_pieces = k20_bounds.empty() ? 0 : k20_bounds.size() - 1;
+  const unsigned slots_whole = clv_traversal_slots(p);
   std::vector<unsigned> cuts{0u};
   // The 20-state kernel requests the operands of operation i+1 a whole
   // operation ahead and stores the result of operation i one operation late:
@@ -718,13 +735,23 @@ void rdamd_update_clvs(rdamd_partition_t *p, const rdamd_operation_t *ops,
       }
       if (k20_hazard(p->tips, ops, i, cuts.back())) cuts.push_back(i);
     }
+  } else if (!lv.order.empty()) {
+    cuts.assign(lv.seg.begin(), lv.seg.end() - 1);
   }
   cuts.push_back(count);
-  std::vector<int> producer(nclv), consumer(count), which(count);
-  for (size_t seg = 0; seg + 1 < cuts.size(); ++seg) {
-    const unsigned lo = cuts[seg], hi = cuts[seg + 1];
-    std::fill(producer.begin(), producer.end(), -1);   // clv -> op of this segment that wrote it
-    for (unsigned i = lo; i < hi; ++i) consumer[i] = -1;   // op -> first later op reading its parent
+  // (4 states) the launches: segments [levels[l], levels[l + 1]) side by side
+  std::vector<unsigned> levels = lv.level;
+  if (levels.empty()) levels = {0u, 1u};
+  std::vector<int> producer(nclv, -1), consumer(count), which(count);
+  // one segment with `nslots` parking slots; returns the number of children it reads back from memory
+  // (producer: clv -> op of this segment that wrote it; all -1 between calls)
+  auto analyse = [&](unsigned lo, unsigned hi, unsigned nslots) {
+    for (unsigned i = lo; i < hi; ++i) {
+      consumer[i] = -1;   // op -> first later op reading its parent
+      lops[i].src1 = ops[i].child1_clv_index < p->tips ? 0u : 1u;
+      lops[i].src2 = ops[i].child2_clv_index < p->tips ? 0u : 1u;
+      if (!use_k20) lops[i].park = 0;
+    }
     for (unsigned i = lo; i < hi; ++i) {
       const rdamd_operation_t &o = ops[i];
       const unsigned ch[2] = {o.child1_clv_index, o.child2_clv_index};
@@ -786,19 +813,72 @@ void rdamd_update_clvs(rdamd_partition_t *p, const rdamd_operation_t *ops,
         set_src((int)i, 3u + (unsigned)take);
       }
     }
+    unsigned readbacks = 0;
+    for (unsigned i = lo; i < hi; ++i) {
+      if (consumer[i] >= 0 && (which[i] ? lops[consumer[i]].src2 : lops[consumer[i]].src1) == 1u) ++readbacks;
+      producer[ops[i].parent_clv_index] = -1;
+    }
+    return readbacks;
+  };
+  // The pieces of a launch share one slot count: the fewest slots that leave no more read-backs than
+  // the whole-list count would, plus 6 in 100 operations (every slot less is LDS for another resident
+  // block, a read-back is one exposed round trip of one piece; measured, profiles/r5_clv_pieces_ab.txt:
+  // c2 in 8 pieces 162 / 172 / 189 us with 1 / 2 / 3 slots and 2 / 0 / 0 read-backs; c5's shard in
+  // 32 pieces 1.67 / 1.60 / 1.73 ms with 74 / 31 / 13).
+  std::vector<unsigned> seg_slots(cuts.size() - 1, slots_whole);
+  for (size_t l = 0; !use_k20 && l + 1 < levels.size(); ++l) {
+    const unsigned s0 = levels[l], s1 = levels[l + 1];
+    if (s1 - s0 < 2) continue;
+    auto level_readbacks = [&](unsigned nslots) {
+      unsigned n = 0;
+      for (unsigned seg = s0; seg < s1; ++seg) n += analyse(cuts[seg], cuts[seg + 1], nslots);
+      return n;
+    };
+    unsigned tolerance = 6;
+#ifdef RDAMD_ABLATION
+    if (getenv("RDAMD_CLV_READBACK_PCT")) tolerance = (unsigned)atoi(getenv("RDAMD_CLV_READBACK_PCT"));
+#endif
+    const unsigned allowed = level_readbacks(slots_whole) + (cuts[s1] - cuts[s0]) * tolerance / 100;
+    unsigned chosen = slots_whole;
+    while (chosen > 0 && level_readbacks(chosen - 1) <= allowed) --chosen;
+#ifdef RDAMD_ABLATION
+    if (getenv("RDAMD_CLV_PIECE_SLOTS")) chosen = std::min<unsigned>((unsigned)atoi(getenv("RDAMD_CLV_PIECE_SLOTS")), 6u);
+    if (getenv("RDAMD_CLV_DEBUG")) {
+      fprintf(stderr, "[clv pieces] launch %zu: %u operations in %u pieces (longest %u); read-backs by slots:", l,
+              cuts[s1] - cuts[s0], s1 - s0, cuts[s0 + 1] - cuts[s0]);
+      for (unsigned sl = 0; sl <= slots_whole; ++sl) fprintf(stderr, " %u:%u", sl, level_readbacks(sl));
+      fprintf(stderr, "; chosen %u\n", chosen);
+    }
+#endif
+    for (unsigned seg = s0; seg < s1; ++seg) seg_slots[seg] = chosen;
   }
+#ifdef RDAMD_ABLATION
+  if (getenv("RDAMD_CLV_DEBUG") && !use_k20 && levels.size() > 2)
+    fprintf(stderr, "[clv pieces] last launch: %u operations\n", count - cuts[levels[levels.size() - 2]]);
+#endif
+  for (size_t seg = 0; seg + 1 < cuts.size(); ++seg) analyse(cuts[seg], cuts[seg + 1], seg_slots[seg]);
   // Each segment (normally the whole list) runs as one launch in the caller's
   // order: every dependency is site-local, so the kernel needs no level
   // structure (kernels_clv.hip).
-  if (!use_k20) {   // pad to whole chunks with no-ops (a copy of the last op, stores off)
+  if (!use_k20) {   // every segment padded to whole chunks with no-ops (a copy of its last op, stores off)
     const unsigned chunk = clv_traversal_chunk(p);
-    LevelOp pad = lops[count - 1];
-    pad.src1 = pad.src2 = 2u;
-    pad.park = 0;
-    pad.noop = 1;
-    while (lops.size() % chunk) lops.push_back(pad);
-    cuts.back() = (unsigned)lops.size();   // (no cuts on this path: one segment)
-    lops.push_back(pad);   // terminator: the kernel looks one operation ahead
+    std::vector<LevelOp> padded_ops;
+    std::vector<unsigned> padded_cuts{0u};
+    padded_ops.reserve(count + cuts.size() * chunk + 1);
+    LevelOp pad{};
+    for (size_t seg = 0; seg + 1 < cuts.size(); ++seg) {
+      padded_ops.insert(padded_ops.end(), lops.begin() + cuts[seg], lops.begin() + cuts[seg + 1]);
+      pad = lops[cuts[seg + 1] - 1];
+      pad.src1 = pad.src2 = 2u;
+      pad.park = 0;
+      pad.noop = 1;
+      while ((padded_ops.size() - padded_cuts.back()) % chunk) padded_ops.push_back(pad);
+      padded_cuts.push_back((unsigned)padded_ops.size());
+    }
+    padded_ops.push_back(pad);   // terminator: the kernel looks one operation ahead (a segment's last
+                                 // operation looks at the next segment's first: tip codes it never uses)
+    lops.swap(padded_ops);
+    cuts.swap(padded_cuts);
   }
   if (use_k20)   // tip-code look-ahead of the 20-state kernel (LevelOp::ahead*)
     for (unsigned i = 0; i < count; ++i) {
@@ -819,13 +899,7 @@ void rdamd_update_clvs(rdamd_partition_t *p, const rdamd_operation_t *ops,
     p->prof_begin(0);
     // 20 states: the pieces of a split list (the first k20_bounds.size() - 1 segments) are ONE
     // launch, side by side; every other segment is a launch of its own, in order
-    const size_t n_pieces = k20_bounds.empty() ? 0 : k20_bounds.size() - 1;
-    for (size_t seg = 0; e == hipSuccess && seg + 1 < cuts.size(); ++seg) {
-      const unsigned lo = cuts[seg], n = cuts[seg + 1] - lo;
-      if (!use_k20) {
-        e = launch_clv_traversal(p, d_ops + lo, n, nslots);
-        continue;
-      }
+    for (size_t seg = 0; use_k20 && e == hipSuccess && seg + 1 < cuts.size(); ++seg) {
       K20Pieces pc;
       if (seg == 0 && n_pieces >= 2) {
         for (; seg < n_pieces; ++seg) {
@@ -834,10 +908,20 @@ void rdamd_update_clvs(rdamd_partition_t *p, const rdamd_operation_t *ops,
         }
         --seg;
       } else {
-        pc.n = 1; pc.start[0] = lo; pc.len[0] = n;
+        pc.n = 1; pc.start[0] = cuts[seg]; pc.len[0] = cuts[seg + 1] - cuts[seg];
       }
       e = launch_clv_k20_traversal(p, d_ops, pc);
     }
+    // 4 states: one launch per level of the cut
+    for (size_t l = 0; !use_k20 && e == hipSuccess && l + 1 < levels.size(); ++l) {
+      DnaPieces pc;
+      for (unsigned seg = levels[l]; seg < levels[l + 1]; ++seg) {
+        pc.start[pc.n] = cuts[seg];
+        pc.len[pc.n++] = cuts[seg + 1] - cuts[seg];
+      }
+      e = launch_clv_traversal(p, d_ops, pc, seg_slots[levels[l]]);
+    }
+    p->last_clv_launches = use_k20 ? (unsigned)(cuts.size() - 1 - (n_pieces >= 2 ? n_pieces - 1 : 0)) : (unsigned)levels.size() - 1;
     p->prof_end();
   }
   if (e != hipSuccess)

@@ -319,6 +319,48 @@ int main() {
     if (order[count - 1].parent_clv_index != ops[count - 1].parent_clv_index) return fail("the root operation must stay last");
     ++cases;
   }
+  // ---- list_levels (the 4-state traversal kernel's launches) --------------------------------
+  for (int rep = 0; rep < 300; ++rep) {
+    const unsigned n = 3 + rng() % 600;
+    std::vector<rdamd_operation_t> ops = random_postorder(n, rng);
+    const unsigned count = (unsigned)ops.size();
+    const unsigned max_pieces = 2 + rng() % 31, small = 4 + rng() % 12, min_count = 6 + rng() % 24;
+    rdamd::ListLevels lv;
+    rdamd::list_levels(n, 2 * n, ops.data(), count, max_pieces, small, min_count, lv);
+    if (lv.order.empty()) {
+      if (!lv.seg.empty() || !lv.level.empty()) return fail("levels without an order");
+      ++cases;
+      continue;
+    }
+    if (lv.order.size() != count) return fail("levels: not a permutation (size)");
+    if (lv.seg.front() != 0 || lv.seg.back() != count) return fail("levels: segment bounds");
+    if (lv.level.front() != 0 || lv.level.back() != lv.seg.size() - 1) return fail("levels: launch bounds");
+    if (lv.level.size() < 3) return fail("levels: a cut list has at least two launches");
+    std::set<unsigned> done_before;   // CLVs of earlier launches
+    std::set<unsigned> seen;
+    for (size_t l = 0; l + 1 < lv.level.size(); ++l) {
+      const unsigned s0 = lv.level[l], s1 = lv.level[l + 1];
+      if (s1 <= s0 || s1 - s0 > std::max(max_pieces, 1u)) return fail("levels: pieces per launch", (int)(s1 - s0));
+      if (l + 2 == lv.level.size() && s1 - s0 != 1) return fail("levels: the last launch is one list");
+      std::set<unsigned> this_launch;
+      for (unsigned seg = s0; seg < s1; ++seg) {
+        if (lv.seg[seg + 1] <= lv.seg[seg]) return fail("levels: empty segment");
+        std::set<unsigned> produced;
+        for (unsigned i = lv.seg[seg]; i < lv.seg[seg + 1]; ++i) {
+          const rdamd_operation_t &o = lv.order[i];
+          if (!seen.insert(o.parent_clv_index).second) return fail("levels: operation twice");
+          for (unsigned ch : {o.child1_clv_index, o.child2_clv_index})
+            if (ch >= n && !produced.count(ch) && !done_before.count(ch))
+              return fail("levels: a segment reads what neither it nor an earlier launch computed", (int)l, (int)i);
+          produced.insert(o.parent_clv_index);
+        }
+        this_launch.insert(produced.begin(), produced.end());
+      }
+      done_before.insert(this_launch.begin(), this_launch.end());
+    }
+    if (lv.order[count - 1].parent_clv_index != ops[count - 1].parent_clv_index) return fail("levels: the root operation must stay last");
+    ++cases;
+  }
   {   // not a post-order nest: two operations swapped across subtrees -> no split
     std::vector<rdamd_operation_t> ops = random_postorder(200, rng);
     std::swap(ops[3], ops[150]);

@@ -793,6 +793,39 @@ def test_many_sites_few_parking_slots_cross_check():
     h.destroy()
 
 
+@pytest.mark.parametrize("n,S,R,seed", [(100, 3000, 4, 81), (400, 1500, 4, 82), (130, 19436, 4, 83), (64, 700, 1, 84),
+                                        (90, 50000, 4, 85)])
+def test_cut_operation_lists_leave_the_whole_lists_state(n, S, R, seed):
+    """A full traversal of a 4-state partition whose one row of blocks leaves the device empty is
+    cut into independent subtrees that run side by side, level by level (k20_split.hpp
+    list_levels, kernels_clv.hip).  Every CLV and every scaler must be what the oracle's plain
+    loop leaves -- for the tree's post-order list (cut: several launches), for a short partial
+    list over that state (whole: one launch), and for the list re-run after a root move."""
+    w = synth.workload(n, S, 4, R, seed)
+    tree = rd.Tree.from_newick(w["newick"])
+    g, o = pair(tree, w["seqs"], 4, R)
+    set_model((g, o), w["subst"], g.empirical_frequencies(), w["rates"])
+    rng = np.random.default_rng(seed)
+    for k, i in enumerate(rng.choice(tree.root_count(), size=3 if S < 10000 else 1, replace=False)):
+        rl = tree.root_location(int(i)).with_ratio(float(rng.uniform(0.05, 0.95)))
+        ops, pmi, brl = tree.generate_operations(rl)
+        for p in (g, o):
+            p.update_prob_matrices(pmi, brl)
+            p.update_clvs(ops)
+        assert g.update_clvs_launches() >= 2, (len(ops), g.update_clvs_launches())
+        compare_state(g, o, ops, tree)
+        root = ops[-1]
+        a = g.compute_root_loglikelihood(root.parent_clv_index, root.parent_scaler_index, [0] * R)
+        b = o.compute_root_loglikelihood(root.parent_clv_index, root.parent_scaler_index, [0] * R)
+        assert util.rel_err(a, b) < LNL_TOL
+        if k == 0:   # the last few operations again: too short to cut, children left by the call above
+            tail = ops[-5:]
+            for p in (g, o):
+                p.update_clvs(tail)
+            assert g.update_clvs_launches() == 1
+            compare_state(g, o, tail, tree)
+
+
 @pytest.mark.parametrize("n,S,R,seed,K", [(64, 700, 4, 71, 4), (150, 300, 2, 72, 4), (40, 9000, 4, 73, 4),
                                           (48, 333, 4, 74, 20), (30, 100, 3, 75, 20)])
 def test_arbitrary_operation_orders(n, S, R, seed, K):
