@@ -271,26 +271,22 @@ unsigned clv_traversal_slots(const rdamd_partition *p);
 // the 4-state kernel wants its list padded with no-ops to a multiple of this (else 1)
 unsigned clv_traversal_chunk(const rdamd_partition *p);
 // independent pieces of one operation list, run side by side (grid.y): [start, start + len) each
-constexpr unsigned kK20MaxPieces = 8;
-struct K20Pieces {
+constexpr unsigned kMaxListPieces = 32;
+struct ListPieces {
   unsigned n = 0;
-  unsigned start[kK20MaxPieces] = {0}, len[kK20MaxPieces] = {0};
-};
-// the 4-state kernel's pieces
-constexpr unsigned kDnaMaxPieces = 32;
-struct DnaPieces {
-  unsigned n = 0;
-  unsigned start[kDnaMaxPieces] = {0}, len[kDnaMaxPieces] = {0};
+  unsigned start[kMaxListPieces] = {0}, len[kMaxListPieces] = {0};
 };
 // most pieces per launch a list of `count` operations of this partition is worth cutting into
 // (0: run the list as it is)
 unsigned clv_traversal_pieces(const rdamd_partition *p, unsigned count);
-hipError_t launch_clv_traversal(rdamd_partition *p, const LevelOp *d_ops, const DnaPieces &pieces,
+hipError_t launch_clv_traversal(rdamd_partition *p, const LevelOp *d_ops, const ListPieces &pieces,
                                 unsigned slots);
 
 // kernels_clv_mfma.hip (20 states)
 hipError_t launch_pmat_to_mfma(rdamd_partition *p, const unsigned *d_matrix_indices, unsigned count);
-hipError_t launch_clv_k20_traversal(rdamd_partition *p, const LevelOp *d_ops, const K20Pieces &pieces);
+// most pieces per launch / the size a piece keeps, for a list of `count` operations (pieces 0: run it whole)
+void clv_k20_traversal_cut(const rdamd_partition *p, unsigned count, unsigned *pieces, unsigned *small, unsigned *min_count);
+hipError_t launch_clv_k20_traversal(rdamd_partition *p, const LevelOp *d_ops, const ListPieces &pieces);
 size_t k20_mfma_copy_doubles();               // doubles per (matrix, rate) in d_pmat_mfma
 
 // kernels_root.hip

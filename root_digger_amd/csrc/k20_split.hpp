@@ -128,8 +128,11 @@ struct ListLevels {
   std::vector<rdamd_operation_t> order;
   std::vector<unsigned> seg, level;
 };
+// (`forwarding_hazards`: the 20-state kernel's pieces, see k20_split -- a level one of whose pieces
+// would need a cut of its own is not cut.)
 inline void list_levels(unsigned tips, unsigned clv_buffers, const rdamd_operation_t *ops, unsigned count,
-                        unsigned max_pieces, unsigned small, unsigned min_count, ListLevels &out) {
+                        unsigned max_pieces, unsigned small, unsigned min_count, ListLevels &out,
+                        bool forwarding_hazards = false) {
   out.order.clear();
   out.seg.clear();
   out.level.clear();
@@ -137,7 +140,7 @@ inline void list_levels(unsigned tips, unsigned clv_buffers, const rdamd_operati
   std::vector<unsigned> bounds;
   bool external = false;
   for (;;) {
-    k20_split(tips, clv_buffers, cur.data(), (unsigned)cur.size(), max_pieces, order, bounds, false,
+    k20_split(tips, clv_buffers, cur.data(), (unsigned)cur.size(), max_pieces, order, bounds, forwarding_hazards,
               std::max(small, (unsigned)cur.size() / std::max(1u, max_pieces)), min_count, external);
     if (order.empty()) break;
     const unsigned base = (unsigned)out.order.size(), top = bounds.back();

@@ -72,7 +72,7 @@ constexpr unsigned kChunk = 4;
 
 template <int R>
 __global__ void __launch_bounds__(256)
-clv_dna_traversal_kernel(DeviceView v, const LevelOp *__restrict__ all_ops, DnaPieces pieces,
+clv_dna_traversal_kernel(DeviceView v, const LevelOp *__restrict__ all_ops, ListPieces pieces,
                          unsigned slots) {
   // Independent PIECES of the list side by side (grid.y; round 5): all of c2's waves are resident
   // from the start, three per SIMD, so a launch lasts as long as ONE wave needs for its whole
@@ -442,10 +442,10 @@ unsigned clv_traversal_pieces(const rdamd_partition *p, unsigned count) {
 #ifdef RDAMD_ABLATION
   if (getenv("RDAMD_CLV_PIECES")) want = (size_t)atoi(getenv("RDAMD_CLV_PIECES"));
 #endif
-  return want >= 2 ? (unsigned)std::min<size_t>(want, kDnaMaxPieces) : 0u;
+  return want >= 2 ? (unsigned)std::min<size_t>(want, kMaxListPieces) : 0u;
 }
 
-hipError_t launch_clv_traversal(rdamd_partition *p, const LevelOp *d_ops, const DnaPieces &pieces,
+hipError_t launch_clv_traversal(rdamd_partition *p, const LevelOp *d_ops, const ListPieces &pieces,
                                 unsigned slots) {
   if (pieces.n == 0 || p->sites == 0) return hipSuccess;
   DeviceView v = p->view();

@@ -138,7 +138,7 @@ pmat_to_mfma_kernel(const double *__restrict__ pmat, double *__restrict__ out,
 template <int MAXT, int VAR = 0>   // 64 * rate categories, rounded up to 256 or 1024
 __global__ void __launch_bounds__(MAXT)
 clv_k20_traversal_kernel(DeviceView v, const double *__restrict__ pmfma,
-                         const LevelOp *__restrict__ ops_all, K20Pieces pieces) {
+                         const LevelOp *__restrict__ ops_all, ListPieces pieces) {
   // blockIdx.y = an independent piece of the operation list (a subtree: rdamd_update_clvs cuts
   // the list so that a shape with too few 16-site tiles for the chip still fills it)
   const LevelOp *__restrict__ ops_generic = ops_all + pieces.start[blockIdx.y];
@@ -429,7 +429,22 @@ hipError_t launch_pmat_to_mfma(rdamd_partition *p, const unsigned *d_matrix_indi
 
 size_t k20_mfma_copy_doubles() { return kMfmaCopy; }
 
-hipError_t launch_clv_k20_traversal(rdamd_partition *p, const LevelOp *d_ops, const K20Pieces &pieces) {
+// How a list is cut for this kernel.  Round 3: 8 pieces, one level (c3, 625 blocks per row: 593 -> 494 us).
+// Round 5, with the levels of list_levels: about 5 000 blocks per launch -- c3 keeps its 8 pieces (16: 514 - 520 us,
+// 32: 527 - 566), c3's tree on 1 000 sites (63 blocks per row) 227 -> 135 us with 32 pieces in three launches
+// (profiles/r5_clv_pieces_ab.txt, section 5).
+void clv_k20_traversal_cut(const rdamd_partition *p, unsigned count, unsigned *pieces, unsigned *small, unsigned *min_count) {
+  const unsigned blocks = (p->sites + 15) / 16;
+  *pieces = std::min(std::max(5000u / std::max(blocks, 1u), 8u), kMaxListPieces);
+  *small = 24;
+  *min_count = count < 24 ? 24 : 12;   // (lists under 24 operations run whole, the joining lists of a cut from 12)
+#ifdef RDAMD_ABLATION
+  if (getenv("RDAMD_CLV_PIECES")) *pieces = (unsigned)atoi(getenv("RDAMD_CLV_PIECES"));
+#endif
+  *pieces = std::min(*pieces, kMaxListPieces);
+}
+
+hipError_t launch_clv_k20_traversal(rdamd_partition *p, const LevelOp *d_ops, const ListPieces &pieces) {
   if (pieces.n == 0 || p->sites == 0) return hipSuccess;
   DeviceView v = p->view();
   const dim3 grid((p->sites + 15) / 16, pieces.n);

@@ -654,22 +654,20 @@ void rdamd_update_clvs(rdamd_partition_t *p, const rdamd_operation_t *ops,
     }
     ops = phys_ops.data();
   }
-  // (20 states: independent subtrees side by side, see k20_split)
-  std::vector<rdamd_operation_t> k20_order;
-  std::vector<unsigned> k20_bounds;
-  if (p->mfma_layout) k20_split(p->tips, p->clv_buffers, ops, count, kK20MaxPieces, k20_order, k20_bounds);
-  // (4 states: the same cut where one row of blocks leaves the device's wave slots empty, kernels_clv.hip)
-  const unsigned dna_rows = p->mfma_layout ? 0u : clv_traversal_pieces(p, count);
+  // Independent subtrees side by side, level by level (k20_split.hpp, list_levels): the 20-state
+  // kernel always (kernels_clv_mfma.hip), the 4-state one where one row of blocks leaves the device's
+  // wave slots empty (kernels_clv.hip).
   ListLevels lv;
-  if (dna_rows >= 2) {
-    unsigned small = 8, min_count = 16;
+  {
+    unsigned rows = 0, small = 8, min_count = 16;
+    if (p->mfma_layout) clv_k20_traversal_cut(p, count, &rows, &small, &min_count);
+    else rows = clv_traversal_pieces(p, count);
 #ifdef RDAMD_ABLATION
     if (getenv("RDAMD_CLV_PIECE_OPS")) small = (unsigned)atoi(getenv("RDAMD_CLV_PIECE_OPS"));
     if (getenv("RDAMD_CLV_MIN_SPLIT")) min_count = (unsigned)atoi(getenv("RDAMD_CLV_MIN_SPLIT"));
 #endif
-    list_levels(p->tips, p->clv_buffers, ops, count, dna_rows, small, min_count, lv);
+    if (rows >= 2) list_levels(p->tips, p->clv_buffers, ops, count, rows, small, min_count, lv, p->mfma_layout);
   }
-  if (!k20_order.empty()) ops = k20_order.data();
   if (!lv.order.empty()) ops = lv.order.data();
   std::vector<LevelOp> lops(count);
   for (unsigned i = 0; i < count; ++i) {
@@ -714,9 +712,14 @@ void rdamd_update_clvs(rdamd_partition_t *p, const rdamd_operation_t *ops,
   // run side by side with the slots their row count leaves them, then the operations that join them;
   // the 4-state kernel needs no other cut -- memory children are read at use, after every earlier
   // store of the lane.)
-  const size_t n_pieces = k20_bounds.empty() ? 0 : k20_bounds.size() - 1;
   const unsigned slots_whole = clv_traversal_slots(p);
-  std::vector<unsigned> cuts{0u};
+  // segment boundaries, and the first segment of every launch (segments [levels[l], levels[l + 1])
+  // run side by side)
+  std::vector<unsigned> cuts{0u}, levels{0u};
+  if (!lv.order.empty()) {
+    cuts.assign(lv.seg.begin(), lv.seg.end() - 1);
+    levels.assign(lv.level.begin(), lv.level.end() - 1);
+  }
   // The 20-state kernel requests the operands of operation i+1 a whole
   // operation ahead and stores the result of operation i one operation late:
   // operation i may not read from memory what i-1 or i-2 wrote.  Their parents
@@ -724,24 +727,17 @@ void rdamd_update_clvs(rdamd_partition_t *p, const rdamd_operation_t *ops,
   // value cannot be forwarded (same CLV under another scaler index, or the
   // other way round, or both earlier operations wrote it): there the list is
   // cut into two launches.
+  // (No piece of a cut list has such a place -- list_levels has checked --; the list that is left
+  // over, or the whole list, may.)
   const bool use_k20 = p->mfma_layout;   // fixed at creation, with the CLV layout
-  if (use_k20) {
-    size_t next_bound = 1;   // k20_bounds[0] = 0
-    for (unsigned i = 1; i < count; ++i) {
-      if (next_bound < k20_bounds.size() && i == k20_bounds[next_bound]) {   // a piece (or the top list) starts
+  if (use_k20)
+    for (unsigned i = cuts.back() + 1; i < count; ++i)
+      if (k20_hazard(p->tips, ops, i, cuts.back())) {
         cuts.push_back(i);
-        ++next_bound;
-        continue;
+        levels.push_back((unsigned)cuts.size() - 1);
       }
-      if (k20_hazard(p->tips, ops, i, cuts.back())) cuts.push_back(i);
-    }
-  } else if (!lv.order.empty()) {
-    cuts.assign(lv.seg.begin(), lv.seg.end() - 1);
-  }
   cuts.push_back(count);
-  // (4 states) the launches: segments [levels[l], levels[l + 1]) side by side
-  std::vector<unsigned> levels = lv.level;
-  if (levels.empty()) levels = {0u, 1u};
+  levels.push_back((unsigned)cuts.size() - 1);
   std::vector<int> producer(nclv, -1), consumer(count), which(count);
   // one segment with `nslots` parking slots; returns the number of children it reads back from memory
   // (producer: clv -> op of this segment that wrote it; all -1 between calls)
@@ -897,31 +893,16 @@ void rdamd_update_clvs(rdamd_partition_t *p, const rdamd_operation_t *ops,
     LevelOp *d_ops = (LevelOp *)sc.take(sizeof(LevelOp) * padded);
     e = upload(p, d_ops, lops.data(), sizeof(LevelOp) * padded);
     p->prof_begin(0);
-    // 20 states: the pieces of a split list (the first k20_bounds.size() - 1 segments) are ONE
-    // launch, side by side; every other segment is a launch of its own, in order
-    for (size_t seg = 0; use_k20 && e == hipSuccess && seg + 1 < cuts.size(); ++seg) {
-      K20Pieces pc;
-      if (seg == 0 && n_pieces >= 2) {
-        for (; seg < n_pieces; ++seg) {
-          pc.start[pc.n] = cuts[seg];
-          pc.len[pc.n++] = cuts[seg + 1] - cuts[seg];
-        }
-        --seg;
-      } else {
-        pc.n = 1; pc.start[0] = cuts[seg]; pc.len[0] = cuts[seg + 1] - cuts[seg];
-      }
-      e = launch_clv_k20_traversal(p, d_ops, pc);
-    }
-    // 4 states: one launch per level of the cut
-    for (size_t l = 0; !use_k20 && e == hipSuccess && l + 1 < levels.size(); ++l) {
-      DnaPieces pc;
+    // one launch per level of the cut: its pieces side by side
+    for (size_t l = 0; e == hipSuccess && l + 1 < levels.size(); ++l) {
+      ListPieces pc;
       for (unsigned seg = levels[l]; seg < levels[l + 1]; ++seg) {
         pc.start[pc.n] = cuts[seg];
         pc.len[pc.n++] = cuts[seg + 1] - cuts[seg];
       }
-      e = launch_clv_traversal(p, d_ops, pc, seg_slots[levels[l]]);
+      e = use_k20 ? launch_clv_k20_traversal(p, d_ops, pc) : launch_clv_traversal(p, d_ops, pc, seg_slots[levels[l]]);
     }
-    p->last_clv_launches = use_k20 ? (unsigned)(cuts.size() - 1 - (n_pieces >= 2 ? n_pieces - 1 : 0)) : (unsigned)levels.size() - 1;
+    p->last_clv_launches = (unsigned)levels.size() - 1;
     p->prof_end();
   }
   if (e != hipSuccess)
