@@ -58,11 +58,18 @@ inline void k20_split(unsigned tips, unsigned clv_buffers, const rdamd_operation
   const unsigned nclv = tips + clv_buffers;
   std::vector<int> producer(nclv, -1), parent(count, -1);
   std::vector<unsigned> size(count, 1);
+  std::vector<char> scaler_written;   // (pieces run side by side: no two operations may share a scale buffer)
   for (unsigned i = 0; i < count; ++i) {
     const rdamd_operation_t &o = ops[i];
     if (o.parent_clv_index < tips || o.parent_clv_index >= nclv || o.child1_clv_index >= nclv ||
         o.child2_clv_index >= nclv || producer[o.parent_clv_index] >= 0)
       return;
+    if (o.parent_scaler_index >= 0) {
+      const size_t sc = (size_t)o.parent_scaler_index;
+      if (sc >= scaler_written.size()) scaler_written.resize(sc + 1, 0);
+      if (scaler_written[sc]) return;
+      scaler_written[sc] = 1;
+    }
     // post-order: the later inner child sits right in front, the earlier one right in front of
     // the later one's whole subtree
     int kids[2], nk = 0;

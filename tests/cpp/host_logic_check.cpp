@@ -361,6 +361,15 @@ int main() {
     if (lv.order[count - 1].parent_clv_index != ops[count - 1].parent_clv_index) return fail("levels: the root operation must stay last");
     ++cases;
   }
+  {   // two operations writing one scale buffer may not end up side by side -> no split
+    std::vector<rdamd_operation_t> ops = random_postorder(200, rng);
+    ops[40].parent_scaler_index = ops[120].parent_scaler_index = 7;
+    std::vector<rdamd_operation_t> order;
+    std::vector<unsigned> bounds;
+    rdamd::k20_split(200, 400, ops.data(), (unsigned)ops.size(), 8, order, bounds);
+    if (!order.empty() || !bounds.empty()) return fail("a shared scale buffer must keep the list whole");
+    ++cases;
+  }
   {   // not a post-order nest: two operations swapped across subtrees -> no split
     std::vector<rdamd_operation_t> ops = random_postorder(200, rng);
     std::swap(ops[3], ops[150]);
