@@ -730,7 +730,11 @@ def main():
                          "matvecs_per_evaluation": round(executed_timed["matvecs"] / ev, 2),
                          "clade_table_rows_per_evaluation_and_rate": round(executed_timed["clade_rows"] / ev, 1),
                          "site_repeats": bool(repeats),
-                         "max_classes": (part.site_repeats() if repeats else 0)},
+                         "max_classes": (part.site_repeats() if repeats else 0),
+                         # parks per evaluation (mean over the schedules): all / in the register slot /
+                         # in the one LDS slot; the rest wait on the in-memory stack
+                         "parks_per_evaluation": [round(float(np.mean([st[k] for st in sched_stats])), 1)
+                                                  for k in ("parks", "parks_in_registers", "parks_in_lds_slot")]},
             "issued_fp64_tflops": round(fp64_issued / (ms * 1e-3) / 1e12, 2) if ms > 0 else 0.0,
             "avg_launch_ms": round(ms / max(launches, 1), 4), "launches": launches,
             "share_of_step": round(ms * 1e-3 / elapsed, 3),

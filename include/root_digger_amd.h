@@ -274,6 +274,10 @@ typedef struct rdamd_schedule_stats {
   unsigned int clade_rows;     /* table rows (class x node) computed per job and rate category */
   unsigned int stack_depth;    /* LDS stack levels of the program that runs */
   unsigned int stack_depth_plain;
+  /* the program's parks (a subtree's result waits while its sibling is evaluated): all of them, those
+   * that wait in the evaluator's register slot(s), those in its one LDS slot (kernels with a
+   * private-segment stack); the rest wait on the in-memory stack -- LDS levels or the private segment */
+  unsigned int parks, parks_in_registers, parks_in_lds_slot;
 } rdamd_schedule_stats_t;
 int rdamd_schedule_stats(const rdamd_schedule_t *s, rdamd_schedule_stats_t *out);
 

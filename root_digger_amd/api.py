@@ -99,7 +99,8 @@ _sig("rdamd_schedule_stack_depth", _u, _vp)
 class ScheduleStats(C.Structure):
     """rdamd_schedule_stats_t"""
     _fields_ = [(k, C.c_uint) for k in ("operations", "steps", "matvecs", "matvecs_plain", "pseudo_tips",
-                                        "clade_nodes", "clade_rows", "stack_depth", "stack_depth_plain")]
+                                        "clade_nodes", "clade_rows", "stack_depth", "stack_depth_plain",
+                                        "parks", "parks_in_registers", "parks_in_lds_slot")]
 
 
 _sig("rdamd_schedule_stats", C.c_int, _vp, C.POINTER(ScheduleStats))

@@ -291,6 +291,7 @@ static rdamd_schedule_t *schedule_create_impl(rdamd_partition_t *p, const rdamd_
     c.pseudo_wide = pseudo_wide;
     c.wide_base = 8u * p->prob_matrices * p->rate_cats * 16u;
     c.dma_offsets = !k20 && wide_mode;
+    c.place_parks = !k20 && wide_mode;   // (the kernels of these programs: one register slot, one LDS slot, a private-segment stack)
     {   // the steps that compute the root operation's inner children (fused.hpp, 0x8000 / 0x10000)
       const rdamd_operation_t &root = list.back();
       if (root.child1_clv_index >= p->tips) c.mark_clv[0] = root.child1_clv_index;
@@ -305,7 +306,7 @@ static rdamd_schedule_t *schedule_create_impl(rdamd_partition_t *p, const rdamd_
     // (traversal_compiler.hpp)
     // (two register levels: from 8 in-memory entries on where the kernel has private-segment
     // levels, i.e. 64-row table slots; from 3 on an all-LDS stack -- kernels_fused.hip)
-    const unsigned lds_pos = c.place_levels(k20 ? 0u : (wide_mode ? 1u + kFusedSpillLevels : 3u));
+    const unsigned lds_pos = c.place_levels(k20 ? 0u : (wide_mode ? 1u + kFusedSpillLevels : 3u), kFusedSpillLevels - 1u);
     size_t n_real = 0;
     for (const FusedOp &f : c.out)
       if (!c.split_park || (f.flags & 3u) != kFusedPark) ++n_real;
@@ -316,7 +317,9 @@ static rdamd_schedule_t *schedule_create_impl(rdamd_partition_t *p, const rdamd_
     }
     // LDS levels = stack depth minus the register levels (at least one is allocated)
     // (20 states: parking steps count as steps)
-    out.depth = std::max(1u, c.max_depth > c.reg_levels ? c.max_depth - c.reg_levels : 0);
+    // (parks placed one by one: the LDS slot + the private-segment entries)
+    out.depth = !c.park_class.empty() ? 1u + c.mem_depth
+                                      : std::max(1u, c.max_depth > c.reg_levels ? c.max_depth - c.reg_levels : 0);
     out.reg_levels = c.reg_levels;
     out.lds_pos = lds_pos;
     out.matvecs = c.matvecs;
@@ -513,6 +516,13 @@ int rdamd_schedule_stats(const rdamd_schedule_t *s, rdamd_schedule_stats_t *out)
   out->clade_rows = s->clade_rows;
   out->stack_depth = s->depth;
   out->stack_depth_plain = s->depth_plain;
+  out->parks = out->parks_in_registers = out->parks_in_lds_slot = 0;
+  for (const rdamd::FusedOp &f : s->prog) {
+    const bool park = k20 ? (f.flags & 3u) == rdamd::kFusedPark : (f.flags & 0x100u) != 0u;
+    out->parks += park;
+    out->parks_in_registers += park && (f.flags & 0xa00u) != 0u;
+    out->parks_in_lds_slot += park && (f.flags & 0x20000u) != 0u;
+  }
   return RDAMD_SUCCESS;
 }
 

@@ -34,6 +34,8 @@ struct FusedOp {
                          // 0x800 park in register level 1 | 0x1000 pop it (4-state programs compiled for two)
                          // | 0x2000 / 0x4000 X / Y table has 64 rows | 0x8000 / 0x10000 this step computes the
                          // root operation's child 1 / child 2 (read by the exporting variant only)
+                         // | 0x20000 park in the ONE LDS slot of the kernels with a private-segment stack | 0x40000
+                         // pop it (programs whose parks are placed one by one, traversal_compiler.hpp)
   // 4-state programs compiled for 64-row table slots: the SCALAR OFFSETS of the LDS-DMA loads
   // that bring the X / Y operand's table of rate 0 into its slot -- tX * 4 + kFusedDmaBias, and
   // for Y minus kFusedDmaYSlot: the evaluator reaches the Y slot through the instruction offset,
@@ -61,9 +63,9 @@ struct FusedJob {
   // workgroup whose job belongs to the other one returns at once; the second variant's pass
   // is only queued when the batch raised a flag at all, FusedArgs::any_unsafe.)
   uint32_t tt_unsafe;
-  // 4 states, stacks with private-segment levels (kernels_fused.hip, SP): which of a program's
-  // in-memory stack entries (counted from the bottom) sits in the one LDS slot -- the host
-  // picks the busiest; bits 0-15 `prog`, bits 16-31 `prog_plain`
+  // (rounds 3 - 4: which in-memory stack level of the program sits in the one LDS slot of the kernels
+  // with a private-segment stack.  Since round 5 the steps say it themselves, FusedOp::flags 0x20000 /
+  // 0x40000; the word keeps the struct's layout)
   uint32_t lds_pos;
   // subtree site repeats (clades.hpp); without pseudo-tips prog_plain == prog, n_groups == 0
   const FusedOp    *prog_plain;

@@ -203,9 +203,10 @@ constexpr bool kTestRT = true, kTestRP = true;
 // (850 MB / 340 MB) no longer fits any cache level, spend their time on exactly those
 // re-reads.  The rate terms meet in LDS and wave 0 folds them in rate order with
 // the loop's own arithmetic: the same bits as the one-wave form.
-// Stack entries of the SP > 0 kernels: in-memory entry `sp` (counted from the bottom) lives in
-// the wave's one LDS slot if it is entry `lds_pos` (FusedJob::lds_pos), in the wave's private
-// segment otherwise.  The choice is a scalar branch INSIDE one asm
+// Stack entries of the SP > 0 kernels: a parked entry lives in the wave's one LDS slot if its step
+// says so (flags 0x20000 park / 0x40000 pop: the host places every park on its own,
+// traversal_compiler.hpp), in the wave's private segment otherwise -- entry `sp` of a stack that
+// holds only those.  The choice is a scalar branch INSIDE one asm
 // statement, both sides writing the same registers: as an `if` in the source the two-sites
 // kernel grows from 124 to 146-164 VGPRs (register copies where the paths join) and loses
 // the fourth wave per SIMD that the whole exercise is about.  The compiler does not count
@@ -213,14 +214,14 @@ constexpr bool kTestRT = true, kTestRP = true;
 // waits for its data itself.
 typedef double f64x2_t __attribute__((ext_vector_type(2)));
 template <int NS>
-__device__ __forceinline__ void stack_push(unsigned sp, unsigned lds_pos, int q, unsigned stk_lds,
+__device__ __forceinline__ void stack_push(unsigned sp, unsigned flags, int q, unsigned stk_lds,
                                            unsigned stksc_lds, unsigned spill_off, const double (&v)[4], int sc) {
   const f64x2_t lo = {v[0], v[1]}, hi = {v[2], v[3]};
   const unsigned la = stk_lds + q * 2048u, lsc = stksc_lds + q * 256u;
   sp = uni(sp);   // (wave-uniform by construction; not every variant's compiler pass sees it)
   const unsigned so = spill_off + (sp * NS + q) * 48u;
   asm volatile(
-      "s_cmp_eq_u32 %[sp], %[cap]\n\t"
+      "s_bitcmp1_b32 %[fl], 17\n\t"   /* 0x20000: into the LDS slot */
       "s_cbranch_scc1 1f\n\t"
       "scratch_store_dwordx4 off, %[lo], %[so]\n\t"
       "scratch_store_dwordx4 off, %[hi], %[so] offset:16\n\t"
@@ -233,19 +234,19 @@ __device__ __forceinline__ void stack_push(unsigned sp, unsigned lds_pos, int q,
       "2:\n\t"
       "s_nop 0"   /* (a VALU write to 16-byte store data needs one wait state behind the store) */
       :
-      : [sp] "s"(sp), [cap] "s"(lds_pos), [lo] "v"(lo), [hi] "v"(hi), [sc] "v"(sc), [so] "s"(so),
+      : [fl] "s"(uni(flags)), [lo] "v"(lo), [hi] "v"(hi), [sc] "v"(sc), [so] "s"(so),
         [la] "v"(la), [lsc] "v"(lsc)
       : "memory", "scc");
 }
 template <int NS>
-__device__ __forceinline__ void stack_pop(unsigned sp, unsigned lds_pos, int q, unsigned stk_lds,
+__device__ __forceinline__ void stack_pop(unsigned sp, unsigned flags, int q, unsigned stk_lds,
                                           unsigned stksc_lds, unsigned spill_off, double (&v)[4], int &sc) {
   f64x2_t lo, hi;
   const unsigned la = stk_lds + q * 2048u, lsc = stksc_lds + q * 256u;
   sp = uni(sp);   // (wave-uniform by construction; not every variant's compiler pass sees it)
   const unsigned so = spill_off + (sp * NS + q) * 48u;
   asm volatile(
-      "s_cmp_eq_u32 %[sp], %[cap]\n\t"
+      "s_bitcmp1_b32 %[fl], 18\n\t"   /* 0x40000: from the LDS slot */
       "s_cbranch_scc1 1f\n\t"
       "scratch_load_dwordx4 %[lo], off, %[so]\n\t"
       "scratch_load_dwordx4 %[hi], off, %[so] offset:16\n\t"
@@ -259,7 +260,7 @@ __device__ __forceinline__ void stack_pop(unsigned sp, unsigned lds_pos, int q, 
       "s_waitcnt lgkmcnt(0)\n"
       "2:"
       : [lo] "=&v"(lo), [hi] "=&v"(hi), [sc] "=&v"(sc)
-      : [sp] "s"(sp), [cap] "s"(lds_pos), [so] "s"(so), [la] "v"(la), [lsc] "v"(lsc)
+      : [fl] "s"(uni(flags)), [so] "s"(so), [la] "v"(la), [lsc] "v"(lsc)
       : "memory", "scc");
   v[0] = lo.x; v[1] = lo.y; v[2] = hi.x; v[3] = hi.y;
 }
@@ -270,14 +271,14 @@ __device__ __forceinline__ void stack_pop(unsigned sp, unsigned lds_pos, int q, 
 // the wave's own work covered it.  (The wait statement takes the values as in / out operands:
 // that is what orders their uses behind it.)
 template <int NS>
-__device__ __forceinline__ void stack_pop_issue(unsigned sp, unsigned lds_pos, int q, unsigned stk_lds,
+__device__ __forceinline__ void stack_pop_issue(unsigned sp, unsigned flags, int q, unsigned stk_lds,
                                                 unsigned stksc_lds, unsigned spill_off, f64x2_t &lo, f64x2_t &hi,
                                                 int &sc) {
   const unsigned la = stk_lds + q * 2048u, lsc = stksc_lds + q * 256u;
   sp = uni(sp);
   const unsigned so = spill_off + (sp * NS + q) * 48u;
   asm volatile(
-      "s_cmp_eq_u32 %[sp], %[cap]\n\t"
+      "s_bitcmp1_b32 %[fl], 18\n\t"   /* 0x40000: from the LDS slot */
       "s_cbranch_scc1 1f\n\t"
       "scratch_load_dwordx4 %[lo], off, %[so]\n\t"
       "scratch_load_dwordx4 %[hi], off, %[so] offset:16\n\t"
@@ -289,7 +290,7 @@ __device__ __forceinline__ void stack_pop_issue(unsigned sp, unsigned lds_pos, i
       "ds_read_b32 %[sc], %[lsc]\n"
       "2:"
       : [lo] "=&v"(lo), [hi] "=&v"(hi), [sc] "=&v"(sc)
-      : [sp] "s"(sp), [cap] "s"(lds_pos), [so] "s"(so), [la] "v"(la), [lsc] "v"(lsc)
+      : [fl] "s"(uni(flags)), [so] "s"(so), [la] "v"(la), [lsc] "v"(lsc)
       : "memory", "scc");
 }
 template <int NS>
@@ -308,9 +309,10 @@ __device__ __forceinline__ void stack_pop_wait(f64x2_t (&lo)[NS], f64x2_t (&hi)[
 // ONE stack entry in LDS and has a slot for each of its up to SP in-memory entries in its
 // PRIVATE segment (scratch: memory the hardware hands out per wave slot, so the same few MB
 // serve every wave that passes through and stay in L2): a park there is three stores, the pop
-// three loads whose latency the other waves cover.  Which entries are the busy ones the host
-// knows (evaluate.hip counts the parks per level): the busiest level gets the register slot,
-// the runner-up the LDS slot (FusedJob::lds_pos), the private segment the quiet rest.
+// three loads whose latency the other waves cover.  Which parks go where the host decides, park
+// by park (traversal_compiler.hpp, place_levels; rounds 3 - 4: level by level, the busiest level
+// in the register slot, the runner-up in the LDS slot): as many as fit the two single slots --
+// c5's plain programs 237 of 250 where the two busiest levels hold 171 --, the rest here.
 // EXPORT (rdamd_evaluate_root_children): the steps the host flagged (0x8000 / 0x10000: they compute the
 // root operation's two children) also store the running CLV and its rescale count -- the one thing
 // of a traversal the root-only steps of the search need afterwards (a6, src/model.cpp:415-446).
@@ -372,7 +374,6 @@ fused_dna_eval_kernel(FusedArgs a) {
   const unsigned nops = TTCHECK ? jb.n_ops_plain : jb.n_ops;
   const unsigned job_levels = TTCHECK ? jb.depth_plain : jb.depth;
   const unsigned lds_levels = SP > 0 ? (job_levels < 1u ? job_levels : 1u) : job_levels;
-  const unsigned lds_pos = uni(TTCHECK ? jb.lds_pos >> 16 : jb.lds_pos & 0xffffu);
   const const_as<char> pm = to_const(reinterpret_cast<const char *>(a.pmat + (size_t)job * a.pmat_job_stride));
   const const_as<double> freqs = to_const(a.freqs + (size_t)job * 4);
   const const_as<double> rw = to_const(a.rate_weights + (size_t)job * R);
@@ -607,7 +608,7 @@ fused_dna_eval_kernel(FusedArgs a) {
             double tp[4];                                                                       \
             matvec(M, st.v[q], tp);                                                             \
             if (SP > 0) {                                                                       \
-              stack_push<NS>(sp, lds_pos, q, stk_lds, stksc_lds, spill_off, tp, st.sc[q]);      \
+              stack_push<NS>(sp, kind, q, stk_lds, stksc_lds, spill_off, tp, st.sc[q]);         \
             } else {                                                                            \
               double2 *d = stk + (size_t)(sp * NS + q) * 128;                                   \
               d[0] = make_double2(tp[0], tp[1]);                                                \
@@ -615,7 +616,7 @@ fused_dna_eval_kernel(FusedArgs a) {
               stk_sc[(sp * NS + q) * 64] = st.sc[q];                                            \
             }                                                                                   \
           }                                                                                     \
-          ++sp;                                                                                 \
+          if (SP == 0 || !(kind & 0x20000u)) ++sp;   /* (SP > 0: the private segment's entries) */ \
         }                                                                                       \
       }                                                                                         \
       RDAMD_LOAD_M(nxt, M)                                                                      \
@@ -648,10 +649,10 @@ fused_dna_eval_kernel(FusedArgs a) {
       } else {                                                                                  \
         int scy[NS];                                                                            \
         f64x2_t plo[NS], phi[NS];                                                               \
-        --sp;                                                                                   \
+        if (SP == 0 || !(kind & 0x40000u)) --sp;                                                \
         _Pragma("unroll") for (int q = 0; q < NS; ++q) {                                        \
           if (SP > 0) {   /* issued here, awaited behind the product (stack_pop_issue) */       \
-            stack_pop_issue<NS>(sp, lds_pos, q, stk_lds, stksc_lds, spill_off, plo[q], phi[q], scy[q]); \
+            stack_pop_issue<NS>(sp, kind, q, stk_lds, stksc_lds, spill_off, plo[q], phi[q], scy[q]); \
           } else {                                                                              \
             const double2 *d = stk + (size_t)(sp * NS + q) * 128;                               \
             const double2 lo = d[0], hi = d[64];                                                \

@@ -41,6 +41,15 @@ struct Compiler {
   unsigned depth = 0, max_depth = 0;
   unsigned parks_at[16] = {0};   // parks by stack level (0 = the first level, a register slot)
   bool ok = true;
+  // Kernels with ONE register slot, ONE LDS slot and a private-segment stack behind them (4 states,
+  // 64-row table slots: kernels_fused.hip, SP): every park is placed on its own instead of level by
+  // level (place_levels).  park_class: by operation -- the inner-inner node whose first child waits
+  // -- 1 = register slot (flags 0x200 / 0x400), 2 = LDS slot (0x20000 / 0x40000), 3 = private
+  // segment; empty: by level.  mem_depth: most private-segment entries at a time.
+  bool place_parks = false;
+  std::vector<unsigned char> park_class;
+  unsigned mem_now = 0, mem_depth = 0;
+  std::vector<int> place_memo;
 
   bool is_inner(unsigned clv) const { return clv >= tips && !pseudo_row.count(clv); }
   unsigned row_of(unsigned clv) const { return clv < tips ? clv : pseudo_row.at(clv); }
@@ -60,12 +69,13 @@ struct Compiler {
 
   // park_mat: the matrix the CURRENTLY running CLV will meet at its parent if it
   // has to be parked while this subtree is evaluated
-  void emit(unsigned i, bool live, unsigned park_mat) {
+  // park_cls: where the CURRENTLY running CLV goes if it has to be parked (0: its level decides)
+  void emit(unsigned i, bool live, unsigned park_mat, unsigned park_cls = 0) {
     const rdamd_operation_t &o = ops[i];
     const bool i1 = is_inner(o.child1_clv_index), i2 = is_inner(o.child2_clv_index);
     FusedOp f;
     memset(&f, 0, sizeof(f));
-    unsigned matM = 0, matX = 0, matY = 0, kind = 0, spill = 0, tipX_row = 0, tipY_row = 0;
+    unsigned matM = 0, matX = 0, matY = 0, kind = 0, spill = 0, tipX_row = 0, tipY_row = 0, placed = 0;
     if (!i1 && !i2) {
       kind = kFusedTT;
       spill = live ? 1 : 0;
@@ -73,7 +83,11 @@ struct Compiler {
       tipY_row = row_of(o.child2_clv_index); matY = o.child2_matrix_index;
       if (live) {
         matM = park_mat;              // pre-multiply the parked CLV
-        if (reg_levels >= 2) {        // levels 0 and 1 are register slots in the kernel
+        if (park_cls) {               // a park with a place of its own
+          if (park_cls == 1) spill |= 2;
+          else if (park_cls == 2) placed = 0x20000u;
+          else mem_depth = std::max(mem_depth, ++mem_now);
+        } else if (reg_levels >= 2) { // levels 0 and 1 are register slots in the kernel
           if (depth == 0) spill |= 2;
           else if (depth == 1) spill |= 8;
         } else if (depth == reg_level) {
@@ -94,7 +108,7 @@ struct Compiler {
       }
     } else if (i1 != i2) {
       const bool first_inner = i1;
-      emit(producer.at(first_inner ? o.child1_clv_index : o.child2_clv_index), live, park_mat);
+      emit(producer.at(first_inner ? o.child1_clv_index : o.child2_clv_index), live, park_mat, park_cls);
       kind = kFusedRT;
       matM = first_inner ? o.child1_matrix_index : o.child2_matrix_index;
       tipY_row = row_of(first_inner ? o.child2_clv_index : o.child1_clv_index);
@@ -104,12 +118,17 @@ struct Compiler {
       const bool a_first = need[a] >= need[b];
       const unsigned first = a_first ? a : b, second = a_first ? b : a;
       const unsigned mat_first = a_first ? o.child1_matrix_index : o.child2_matrix_index;
-      emit(first, live, park_mat);    // parked (times mat_first) by the first TT op of `second`
-      emit(second, true, mat_first);
+      const unsigned mine = park_class.empty() ? 0u : park_class[i];
+      emit(first, live, park_mat, park_cls);   // parked (times mat_first) by the first TT op of `second`
+      emit(second, true, mat_first, mine);
       kind = kFusedRP;                // running CLV = second; popped = mat_first . first
       matM = a_first ? o.child2_matrix_index : o.child1_matrix_index;
       --depth;
-      if (reg_levels >= 2) {
+      if (mine) {
+        if (mine == 1) spill |= 4;
+        else if (mine == 2) placed = 0x40000u;
+        else --mem_now;
+      } else if (reg_levels >= 2) {
         if (depth == 0) spill |= 4;   // the popped sibling sits in a register slot
         else if (depth == 1) spill |= 16;
       } else if (depth == reg_level) {
@@ -143,7 +162,7 @@ struct Compiler {
     }
     f.cX = tipX_row * tip_stride;
     f.cY = tipY_row * tip_stride;
-    f.flags = kind | (spill << 8) | wide_flags;   // (a 20-state TT never parks: its spill bits were moved to the park step)
+    f.flags = kind | (spill << 8) | wide_flags | placed;   // (a 20-state TT never parks: its spill bits were moved to the park step)
     if (o.parent_clv_index == mark_clv[0]) f.flags |= 0x8000u;
     if (o.parent_clv_index == mark_clv[1]) f.flags |= 0x10000u;
     out.push_back(f);
@@ -160,16 +179,79 @@ struct Compiler {
   // caller passes 1 + kFusedSpillLevels -- a balanced tree of more than 256 taxa -- for the
   // kernels that have private-segment levels, 3 for those that do not).
   // Returns the rank of the LDS level among the in-memory levels (FusedJob::lds_pos).
-  unsigned place_levels(unsigned two_reg_beyond) {
+  // place_parks: park by park.  The parks that are live together nest (a stack), so a set of them
+  // fits two single slots exactly when no three of it are live at once: the largest such set is a
+  // tree recursion over the operations -- below an inner-inner node the first child sees the
+  // slots its parent sees, the second child those the node's own park leaves -- and the level
+  // rule is one of its candidates.  c5's plain programs: 250 parks, 171 on the two busiest levels,
+  // 237 placed this way; 125.phy 33 / 26 / 31 (round 5).  The register slot counts a little more
+  // than the LDS slot.  What is left forms a stack of its own in the private segment.
+  int place_value(unsigned i, unsigned free_slots) {
+    int &memo = place_memo[4 * i + free_slots];
+    if (memo >= 0) return memo;
+    const rdamd_operation_t &o = ops[i];
+    const bool i1 = is_inner(o.child1_clv_index), i2 = is_inner(o.child2_clv_index);
+    int v = 0;
+    if (i1 != i2) {
+      v = place_value(producer.at(i1 ? o.child1_clv_index : o.child2_clv_index), free_slots);
+    } else if (i1 && i2) {
+      const unsigned a = producer.at(o.child1_clv_index), b = producer.at(o.child2_clv_index);
+      const bool a_first = need[a] >= need[b];
+      const unsigned first = a_first ? a : b, second = a_first ? b : a;
+      const int base = place_value(first, free_slots);
+      v = base + place_value(second, free_slots);
+      if (free_slots & 1u) v = std::max(v, base + 1025 + place_value(second, free_slots & ~1u));
+      if (free_slots & 2u) v = std::max(v, base + 1024 + place_value(second, free_slots & ~2u));
+    }
+    return memo = v;
+  }
+  void place_assign(unsigned i, unsigned free_slots) {
+    const rdamd_operation_t &o = ops[i];
+    const bool i1 = is_inner(o.child1_clv_index), i2 = is_inner(o.child2_clv_index);
+    if (i1 != i2) {
+      place_assign(producer.at(i1 ? o.child1_clv_index : o.child2_clv_index), free_slots);
+    } else if (i1 && i2) {
+      const unsigned a = producer.at(o.child1_clv_index), b = producer.at(o.child2_clv_index);
+      const bool a_first = need[a] >= need[b];
+      const unsigned first = a_first ? a : b, second = a_first ? b : a;
+      const int base = place_value(first, free_slots), v = place_value(i, free_slots);
+      unsigned cls = 3, left = free_slots;
+      if ((free_slots & 1u) && v == base + 1025 + place_value(second, free_slots & ~1u)) { cls = 1; left = free_slots & ~1u; }
+      else if ((free_slots & 2u) && v == base + 1024 + place_value(second, free_slots & ~2u)) { cls = 2; left = free_slots & ~2u; }
+      park_class[i] = (unsigned char)cls;
+      place_assign(first, free_slots);
+      place_assign(second, left);
+    }
+  }
+  // (`mem_limit`: private-segment entries a wave has room for)
+  unsigned place_levels(unsigned two_reg_beyond, unsigned mem_limit = 0) {
     const bool two_reg = two_reg_beyond > 0 && max_depth > two_reg_beyond;
     if (!two_reg && max_depth < 2) return 0;
+    bool again = false;
+    if (place_parks && !two_reg) {
+      place_memo.assign((size_t)4 * n_ops, -1);
+      park_class.assign(n_ops, 0);
+      place_value(n_ops - 1, 3u);
+      place_assign(n_ops - 1, 3u);
+      out.clear();
+      depth = max_depth = mem_now = mem_depth = 0;
+      matvecs = 0;
+      memset(parks_at, 0, sizeof parks_at);
+      emit(n_ops - 1, false, 0);
+      if (mem_depth <= mem_limit) return 0;
+      // (a chain of parks nobody placed, longer than the private segment has room for: the level rule
+      // serves -- the kernel then finds no LDS flags and keeps every in-memory entry in the private segment)
+      park_class.clear();
+      mem_now = mem_depth = 0;
+      again = true;
+    }
     unsigned busiest = 0;
     for (unsigned l = 1; l < max_depth && l < 16; ++l)
       if (parks_at[l] > parks_at[busiest]) busiest = l;
     unsigned second = busiest == 0 ? 1 : 0;
     for (unsigned l = 0; l < max_depth && l < 16; ++l)
       if (l != busiest && parks_at[l] > parks_at[second]) second = l;
-    if (two_reg || busiest != 0) {
+    if (two_reg || busiest != 0 || again) {
       out.clear();
       depth = max_depth = 0;
       matvecs = 0;

@@ -105,8 +105,9 @@ static int replay(const rdamd::Compiler &c, unsigned lds_pos, uint64_t want, uns
                   const uint64_t marked[2] = nullptr) {
   using namespace rdamd;
   unsigned seen[2] = {0, 0};
-  uint64_t run = 0, s0 = 0, s1 = 0;
-  bool s0_full = false, s1_full = false;
+  uint64_t run = 0, s0 = 0, s1 = 0, lds = 0;
+  bool s0_full = false, s1_full = false, lds_full = false;
+  const bool placed = !c.park_class.empty();   // parks with a place of their own: register slot, ONE LDS slot, the rest a stack
   std::vector<uint64_t> mem;
   mem_depth = 0;
   for (size_t i = 0; i < c.out.size(); ++i) {
@@ -115,7 +116,9 @@ static int replay(const rdamd::Compiler &c, unsigned lds_pos, uint64_t want, uns
     auto park = [&](uint64_t v) -> int {
       if (f.flags & 0x200u) { if (s0_full) return 1; s0 = v; s0_full = true; }
       else if (f.flags & 0x800u) { if (s1_full || c.reg_levels < 2) return 1; s1 = v; s1_full = true; }
+      else if (placed && (f.flags & 0x20000u)) { if (lds_full) return 1; lds = v; lds_full = true; }
       else { mem.push_back(v); mem_depth = std::max(mem_depth, (unsigned)mem.size()); }
+      if (!placed && (f.flags & 0x60000u)) return 1;
       return 0;
     };
     if (kind == kFusedPark) {
@@ -133,6 +136,7 @@ static int replay(const rdamd::Compiler &c, unsigned lds_pos, uint64_t want, uns
       uint64_t sib;
       if (f.flags & 0x400u) { if (!s0_full) return fail("pop from an empty register slot", (int)i); sib = s0; s0_full = false; }
       else if (f.flags & 0x1000u) { if (!s1_full) return fail("pop from an empty register slot 1", (int)i); sib = s1; s1_full = false; }
+      else if (placed && (f.flags & 0x40000u)) { if (!lds_full) return fail("pop from an empty LDS slot", (int)i); sib = lds; lds_full = false; }
       else { if (mem.empty()) return fail("pop from an empty stack", (int)i); sib = mem.back(); mem.pop_back(); }
       run = h_mul(h_mv(f.pM, run), sib);
     }
@@ -145,13 +149,15 @@ static int replay(const rdamd::Compiler &c, unsigned lds_pos, uint64_t want, uns
   }
   for (int k = 0; marked && k < 2; ++k)
     if (seen[k] != (marked[k] ? 1u : 0u)) return fail("root child: flagged steps", k, (int)seen[k]);
-  if (s0_full || s1_full || !mem.empty()) return fail("entries left on the stack");
+  if (s0_full || s1_full || lds_full || !mem.empty()) return fail("entries left on the stack");
   if (run != want) return fail("the program does not compute the root CLV");
-  if (mem_depth >= 2 && c.reg_levels == 1 && lds_pos >= mem_depth) return fail("lds_pos out of range", (int)lds_pos, (int)mem_depth);
+  if (!placed && mem_depth >= 2 && c.reg_levels == 1 && lds_pos >= mem_depth) return fail("lds_pos out of range", (int)lds_pos, (int)mem_depth);
+  if (placed && mem_depth != c.mem_depth) return fail("private-segment depth", (int)mem_depth, (int)c.mem_depth);
   return 0;
 }
 
 static int check_compiler(std::mt19937 &rng, int &cases) {
+  unsigned long placed_total = 0, placed_in_slots = 0, placed_by_levels = 0;
   for (int rep = 0; rep < 600; ++rep) {
     const bool k20 = rep % 3 == 2;
     // shapes: random joins (deep, unbalanced), balanced (deepest stacks), caterpillar (depth 1)
@@ -208,13 +214,25 @@ static int check_compiler(std::mt19937 &rng, int &cases) {
     for (unsigned l = 0; l < 16; ++l) parks += c.parks_at[l];
     // (the two thresholds rdamd_schedule_create uses: kernels with / without private-segment levels)
     const unsigned beyond = k20 ? 0u : (rep % 4 < 2 ? 1u + rdamd::kFusedSpillLevels : 3u);
-    const unsigned lds_pos = c.place_levels(beyond);
+    c.place_parks = !k20 && rep % 4 < 2;   // (what rdamd_schedule_create asks for with 64-row table slots)
+    const unsigned lds_pos = c.place_levels(beyond, rdamd::kFusedSpillLevels - 1u);
+    const bool placed = !c.park_class.empty();
     if (c.max_depth != first_pass_depth) return fail("the second pass changed the stack depth");
     unsigned parks2 = 0, busiest = 0;
     for (unsigned l = 0; l < 16; ++l) { parks2 += c.parks_at[l]; busiest = std::max(busiest, c.parks_at[l]); }
     if (parks2 != parks) return fail("the second pass changed the number of parks");
-    if (c.reg_levels == 1 && c.max_depth >= 1 && c.parks_at[c.reg_level] != busiest)
+    if (!placed && c.reg_levels == 1 && c.max_depth >= 1 && c.parks_at[c.reg_level] != busiest)
       return fail("the register slot is not on the busiest level", (int)c.reg_level);
+    if (placed) {   // placed park by park: never fewer in the two slots than the two busiest levels would hold
+      unsigned in_slots = 0, best = 0, second = 0;
+      for (const rdamd::FusedOp &f : c.out) in_slots += (f.flags & 0x100u) && (f.flags & 0x20200u);
+      for (unsigned l = 0; l < 16; ++l) {
+        if (c.parks_at[l] > best) { second = best; best = c.parks_at[l]; }
+        else if (c.parks_at[l] > second) second = c.parks_at[l];
+      }
+      if (in_slots < best + second) return fail("placing the parks one by one must not lose to the level rule", (int)in_slots, (int)(best + second));
+      placed_total += parks; placed_in_slots += in_slots; placed_by_levels += best + second;
+    }
     if (k20 && c.reg_levels != 1) return fail("20-state programs have one register level");
     if (!k20 && (c.reg_levels == 2) != (c.max_depth > beyond)) return fail("two register levels", (int)c.max_depth);
     unsigned mem_depth = 0;
@@ -225,7 +243,8 @@ static int check_compiler(std::mt19937 &rng, int &cases) {
         if (kid[k] >= n && c.is_inner(kid[k])) marked[k] = expected(c, ops, c.producer.at(kid[k]));
     }
     if (replay(c, lds_pos, expected(c, ops, c.n_ops - 1), mem_depth, k20 ? nullptr : marked)) return 1;
-    if (mem_depth != (c.max_depth > c.reg_levels ? c.max_depth - c.reg_levels : 0)) return fail("in-memory depth", (int)mem_depth, (int)c.max_depth);
+    if (!placed && mem_depth != (c.max_depth > c.reg_levels ? c.max_depth - c.reg_levels : 0)) return fail("in-memory depth", (int)mem_depth, (int)c.max_depth);
+    if (placed && mem_depth > rdamd::kFusedSpillLevels - 1u) return fail("more private-segment entries than a wave has room for", (int)mem_depth);
     if (c.reg_levels == 1 && !k20 && mem_depth + 1 > beyond) return fail("more in-memory entries than the kernel has places for");
     // steps: one per operation left in the program (+ one per park for 20 states)
     size_t real = 0;
@@ -233,6 +252,8 @@ static int check_compiler(std::mt19937 &rng, int &cases) {
     if (c.pseudo_row.empty() && real != c.n_ops) return fail("operations lost", (int)real, (int)c.n_ops);
     ++cases;
   }
+  std::fprintf(stderr, "parks placed one by one: %lu of %lu in the two slots (the two busiest levels: %lu)\n", placed_in_slots,
+              placed_total, placed_by_levels);
   return 0;
 }
 
