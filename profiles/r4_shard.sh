@@ -2,7 +2,7 @@
 # The shapes ONE GPU sees under BASELINE's sharding: c4 / 8 = 500 taxa x 62 500
 # sites, c5 as 4 candidate groups x 2 site shards = 1000 taxa x 50 000 sites.  Bench lines + the
 # memory-system counters of the fused evaluator (L2 hit / miss).  gpurun -- 'bash profiles/r4_shard.sh'
-O=gpurun_out/r4_shard; mkdir -p $O
+O=${OUT:-gpurun_out/r4_shard}; mkdir -p $O
 B="python3 bench.py --allow-stale-profile --no-cpu-baseline --sustain-seconds 0"
 $B --config c4 --sites 62500 --steps 4 --warmup 1 > $O/c4_shard_bench.json 2> $O/c4_shard.err
 $B --config c5 --sites 50000 --steps 4 --warmup 1 > $O/c5_shard_bench.json 2> $O/c5_shard.err
