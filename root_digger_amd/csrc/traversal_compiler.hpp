@@ -167,18 +167,6 @@ struct Compiler {
     if (o.parent_clv_index == mark_clv[1]) f.flags |= 0x10000u;
     out.push_back(f);
   }
-  // Second pass: which level gets the register slot.  The first pass (emit) counted the parks
-  // per level, and in a big tree the BOTTOM of the stack is the quiet end (an entry parked near
-  // the root waits for half the traversal; the churn is two or three levels up: c5's plain
-  // programs park 24 / 79 / 112 / 36 times on levels 0 - 3), so the slot goes to the busiest
-  // level, and -- 4 states -- the one LDS slot of the kernels with private-segment levels
-  // (kernels_fused.hip, SP) to the runner-up.  What is parked in memory is a sub-sequence of a
-  // stack, i.e. a stack: the kernel's count of in-memory entries addresses it whichever level
-  // sits in the register.  4 states (`two_reg_beyond` > 0): a program with more levels than
-  // that is compiled for TWO register levels (0 and 1) and an all-LDS stack instead (the
-  // caller passes 1 + kFusedSpillLevels -- a balanced tree of more than 256 taxa -- for the
-  // kernels that have private-segment levels, 3 for those that do not).
-  // Returns the rank of the LDS level among the in-memory levels (FusedJob::lds_pos).
   // place_parks: park by park.  The parks that are live together nest (a stack), so a set of them
   // fits two single slots exactly when no three of it are live at once: the largest such set is a
   // tree recursion over the operations -- below an inner-inner node the first child sees the
@@ -223,7 +211,19 @@ struct Compiler {
       place_assign(second, left);
     }
   }
-  // (`mem_limit`: private-segment entries a wave has room for)
+  // Second pass.  By LEVEL (20 states; 4 states without private-segment levels): the first pass
+  // (emit) counted the parks per level, and in a big tree the BOTTOM of the stack is the quiet end
+  // (an entry parked near the root waits for half the traversal; the churn is two or three levels
+  // up: c5's plain programs park 24 / 79 / 112 / 36 times on levels 0 - 3), so the register slot
+  // goes to the busiest level.  What is parked in memory is a sub-sequence of a stack, i.e. a
+  // stack: the kernel's count of in-memory entries addresses it whichever level sits in the
+  // register.  4 states (`two_reg_beyond` > 0): a program with more levels than that is compiled
+  // for TWO register levels (0 and 1) and an all-LDS stack instead (the caller passes
+  // 1 + kFusedSpillLevels -- a balanced tree of more than 256 taxa -- for the kernels that have
+  // private-segment levels, 3 for those that do not).  Park by park (`place_parks`, above) where
+  // the kernel has its one LDS slot and the private segment; `mem_limit`: private-segment entries
+  // a wave has room for.  Returns the rank of the runner-up level among the in-memory levels
+  // (rounds 3 - 4: FusedJob::lds_pos; no kernel reads it any more).
   unsigned place_levels(unsigned two_reg_beyond, unsigned mem_limit = 0) {
     const bool two_reg = two_reg_beyond > 0 && max_depth > two_reg_beyond;
     if (!two_reg && max_depth < 2) return 0;
