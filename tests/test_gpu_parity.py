@@ -645,6 +645,8 @@ def test_thousand_taxon_tree_vs_oracle():
         assert util.rel_err(a, b) < LNL_TOL
         assert util.rel_err(c, b) < LNL_TOL
     assert max(s.stack_depth() for s in scheds) <= 10
+    for st in (s.stats() for s in scheds):   # (no 64-row tables here: the register slot by stack level, the rest on LDS levels)
+        assert 50 < st["parks"] and st["parks"] > st["parks_in_registers"] > 0 and st["parks_in_lds_slot"] == 0, st
     ops, _, _ = tree.generate_operations(rls[2])
     compare_state(g, o, [ops[i] for i in (0, 500, 998)], tree)
 

@@ -88,6 +88,35 @@ def test_repeats_vs_oracle_on_random_shapes(n, S, R, seed, classes):
         p.destroy()
 
 
+def test_parks_of_a_deep_tree_find_a_slot():
+    """The programs of a partition with 64-row tables run on the kernels with ONE register slot, ONE
+    LDS slot and a private-segment stack, and the host places every park on its own
+    (traversal_compiler.hpp, place_levels): on a 700-taxon tree all but a few of a traversal's
+    parks must find one of the two slots -- two whole stack levels hold far fewer --, and the
+    values are the oracle's."""
+    n, S, R = 700, 300, 4
+    w = synth.workload(n, S, 4, R, 181)
+    tree = rd.Tree.from_newick(w["newick"])
+    a, b, o = trio(tree, w["seqs"], R, None, 64)
+    rng = np.random.default_rng(181)
+    rls = [tree.root_location(int(i)).with_ratio(float(rng.uniform(0.05, 0.95)))
+           for i in rng.choice(tree.root_count(), size=4, replace=False)]
+    sa = [a.schedule(*tree.generate_operations(rl)) for rl in rls]
+    subst = rng.uniform(1e-3, 1.0, (len(rls), 12))
+    freqs = rng.dirichlet(np.ones(4) * 5, len(rls))
+    rates = np.array([rd.compute_gamma_cats(x, R) for x in rng.uniform(0.3, 3.0, len(rls))])
+    got = a.evaluate_batch(sa, subst, freqs, rates)
+    for j, rl in enumerate(rls):
+        want = oracle_eval(o, tree, rl, subst[j], freqs[j], rates[j])
+        assert util.rel_err(got[j], want) < LNL_TOL, (j, got[j], want)
+    for st in (s.stats() for s in sa):
+        in_slots = st["parks_in_registers"] + st["parks_in_lds_slot"]
+        assert st["parks"] > 30 and st["parks_in_lds_slot"] > 0
+        assert st["parks"] >= in_slots >= 0.9 * st["parks"], st
+    for p in (a, b, o):
+        p.destroy()
+
+
 @pytest.mark.parametrize("classes", CLASSES)
 def test_repeats_on_the_reference_fixtures(classes):
     """10.fasta (all 17 roots, the four parameter sets of test/src/model.cpp:12-17) and 101.phy
