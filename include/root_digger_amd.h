@@ -762,7 +762,12 @@ extern const uint64_t rdamd_map_bin[256];
  * on_device = 0: `values` is a host array; sum it over the group in place.
  * on_device = 1: `values` is DEVICE memory and `stream` the HIP stream handle the
  *   producing launch was queued on: queue the collective on that stream
- *   (ncclAllReduce(values, values, n, ncclDouble, ncclSum, comm, stream)).
+ *   (rdamd_comm_allreduce_sum: ncclAllGather + a rank-order sum kernel by default, or
+ *   ncclAllReduce(values, values, n, ncclDouble, ncclSum, comm, stream)).
+ * EVERY RANK OF THE GROUP MUST RECEIVE THE SAME BITS: the optimisers branch on these sums.  A
+ * reducer that cannot promise that (see RDAMD_COMM_SUM_ALLREDUCE) forks the ranks' trajectories;
+ * the lock-stepped search checks for it every round and fails at once (divergence guard,
+ * csrc/lockstep_conductor.hpp) instead of waiting in a collective that no longer matches.
  * Return RDAMD_SUCCESS.  A site-sharded model runs its candidates sequentially
  * (rdamd_model_exhaustive_search) or in lock step in deterministic rounds
  * (rdamd_model_exhaustive_search_lockstep; every rank of the group with the same `in_flight`);
@@ -782,6 +787,15 @@ int rdamd_model_set_lnl_reducer(rdamd_model_t *m, rdamd_lnl_reducer_t reduce, vo
 typedef int (*rdamd_lnl_wait_t)(void *event, void *user);
 int rdamd_model_set_lnl_reducer_async(rdamd_model_t *m, rdamd_lnl_reducer_t queue, rdamd_lnl_wait_t wait,
                                       void *user);
+/* How to get this process OUT of the reducer (optional).  A lock-stepped search whose round
+ * fails -- the divergence guard of csrc/lockstep_conductor.hpp, a failed launch -- fails on every
+ * rank in the same round, but another worker group's round may already sit in a collective that
+ * the ranks which failed a moment earlier will never join.  `abort(user)` is called once, from
+ * the failing thread, and must make every pending and future call of the reducer / `wait` return
+ * failure promptly; it may be called from any thread.  rdamd_model_set_lnl_reducer(m,
+ * rdamd_comm_reducer, comm, 1) installs rdamd_comm_abort by itself. */
+typedef void (*rdamd_lnl_abort_t)(void *user);
+int rdamd_model_set_lnl_reducer_abort(rdamd_model_t *m, rdamd_lnl_abort_t abort, void *user);
 /* rdamd_model_create_from_file_ratehet on block `block` of `n_blocks` contiguous
  * column blocks of the alignment (chunking of src/model.cpp:1899-1907 applied to
  * columns; the block is cut BEFORE pattern compression).  n_columns: optional,
@@ -810,8 +824,28 @@ rdamd_model_t *rdamd_model_create_from_file_block(const rdamd_tree_t *tree, cons
 typedef struct rdamd_comm rdamd_comm_t;
 int           rdamd_comm_unique_id(char id[128]);
 rdamd_comm_t *rdamd_comm_create(const char id[128], int rank, int n_ranks);
+/* device_values[0 .. n) summed over the group in place, queued on `stream`.  HOW is the
+ * communicator's sum mode:
+ *   RDAMD_COMM_SUM_GATHER (default): ncclAllGather of the G vectors + a kernel on the same stream
+ *     that adds them in RANK ORDER, ((v0 + v1) + v2) + ...: every rank holds the same bits by
+ *     construction, whatever algorithm RCCL picks for a message of this size, and the sum is the
+ *     one a host loop over the ranks makes (rd_amd --site-reduce host, dist.py) -- so a
+ *     lock-stepped search gives the sequential sharded search's records bit for bit on real links;
+ *   RDAMD_COMM_SUM_ALLREDUCE: one ncclAllReduce(values, values, n, ncclDouble, ncclSum).  The
+ *     sum's association is RCCL's; identical bits on all ranks are NOT promised by the interface
+ *     (ring / tree algorithms deliver them, direct small-message paths need not).
+ * RDAMD_COMM_SUM=gather|allreduce in the environment sets the mode a new communicator starts in.
+ * All ranks of a group must use the same mode. */
+#define RDAMD_COMM_SUM_GATHER    0
+#define RDAMD_COMM_SUM_ALLREDUCE 1
+int           rdamd_comm_set_sum_mode(rdamd_comm_t *c, int mode);
+int           rdamd_comm_sum_mode(const rdamd_comm_t *c);
 int           rdamd_comm_allreduce_sum(rdamd_comm_t *c, double *device_values, unsigned int n,
                                        void *stream);
+/* the second half of RDAMD_COMM_SUM_GATHER by itself: `ranks` vectors of n doubles, one behind
+ * the other in device memory, added in rank order into out[0 .. n) (may be the first vector) */
+int           rdamd_rank_order_sum(const double *gathered, double *out, unsigned int n,
+                                   unsigned int ranks, void *stream);
 int           rdamd_comm_reducer(double *values, unsigned int n, void *stream, void *user);
 /* its two halves (rdamd_model_set_lnl_reducer_async): queue the all-reduce and return; wait for
  * a HIP event recorded behind it, with rdamd_comm_reducer's failure handling */

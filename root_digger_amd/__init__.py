@@ -38,6 +38,9 @@ from .api import (  # noqa: F401
     set_device,
     device_memory,
     msa_probe,
+    rank_order_sum,
+    COMM_SUM_GATHER,
+    COMM_SUM_ALLREDUCE,
 )
 
 __all__ = [
@@ -47,4 +50,5 @@ __all__ = [
     "MAP_NT", "MAP_BIN", "compute_gamma_cats", "root_loglikelihood_fused_multi", "GAMMA_RATES_MEAN", "GAMMA_RATES_MEDIAN",
     "ATTRIB_SITE_REPEATS", "ATTRIB_NONREV", "ATTRIB_SPARSE_CLVS",
     "device_count", "hip_runtime_path", "mapped_hip_runtimes", "set_device", "device_memory", "msa_probe",
+    "rank_order_sum", "COMM_SUM_GATHER", "COMM_SUM_ALLREDUCE",
 ]

@@ -269,6 +269,10 @@ _sig("rdamd_comm_unique_id", C.c_int, C.c_char * 128)
 _sig("rdamd_comm_create", _vp, C.c_char * 128, C.c_int, C.c_int)
 _sig("rdamd_comm_allreduce_sum", C.c_int, _vp, _vp, _u, _vp)
 _sig("rdamd_comm_destroy", None, _vp)
+_sig("rdamd_comm_set_sum_mode", C.c_int, _vp, C.c_int)
+_sig("rdamd_comm_sum_mode", C.c_int, _vp)
+_sig("rdamd_rank_order_sum", C.c_int, _vp, _vp, _u, _u, _vp)
+COMM_SUM_GATHER, COMM_SUM_ALLREDUCE = 0, 1
 
 _sig("rdamd_partition_footprint", C.c_uint64, _u, _u, _u, _u, _u, _u, _u)
 _sig("rdamd_model_max_replicas", _u, _vp, _u, C.POINTER(C.c_uint64))
@@ -1090,6 +1094,16 @@ class Comm:
         if lib.rdamd_comm_allreduce_sum(self._h, device_ptr, n, stream) != 1:
             _fail("comm_allreduce_sum")
 
+    def set_sum_mode(self, mode):
+        """COMM_SUM_GATHER (default: ncclAllGather + a sum in rank order, the same bits on every
+        rank by construction) or COMM_SUM_ALLREDUCE (one ncclAllReduce)"""
+        if lib.rdamd_comm_set_sum_mode(self._h, mode) != 1:
+            _fail("comm_set_sum_mode")
+
+    @property
+    def sum_mode(self):
+        return int(lib.rdamd_comm_sum_mode(self._h))
+
     def destroy(self):
         if getattr(self, "_h", None):
             lib.rdamd_comm_destroy(self._h)
@@ -1097,6 +1111,13 @@ class Comm:
 
     def __del__(self):
         self.destroy()
+
+
+def rank_order_sum(gathered_ptr, out_ptr, n, ranks, stream=None):
+    """out[i] = ((g[0][i] + g[1][i]) + ...) over `ranks` device vectors of n doubles lying one
+    behind the other (rdamd_rank_order_sum: the second half of COMM_SUM_GATHER)"""
+    if lib.rdamd_rank_order_sum(gathered_ptr, out_ptr, n, ranks, stream) != 1:
+        _fail("rank_order_sum")
 
 
 def checkpoint_checksum_result(root_id, llh, alpha):

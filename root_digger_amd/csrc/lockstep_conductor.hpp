@@ -36,12 +36,31 @@
 // through the all-reduce as one more summand (rdamd_evaluate_batch_submit_device): all ranks
 // learn together that some rank needs the pass, all redo the collective, in the same place of
 // the order (the redo waits for the group's turn).
+//
+// THE ASSUMPTION, AND ITS GUARD.  All of the above rests on one thing: every rank of the group
+// receives the same BITS from the reducer.  The library's RCCL reducer makes that true by
+// construction (comm.cpp, RDAMD_COMM_SUM_GATHER: gather + a sum in rank order); a caller's
+// reducer, or RDAMD_COMM_SUM_ALLREDUCE under an algorithm that lets each rank add for itself, may
+// not -- and one ulp of difference forks an optimiser's trajectory: some later round has other
+// requests on one rank than on the others, the collectives no longer match, and the group would
+// sit in one until the communicator's time limit.  So every round's vector ends in three GUARD
+// words that travel through the same sum:
+//   [ 1.0 | a 40-bit hash of (worker group, its round number, every request's worker / kind /
+//     length) | a 40-bit hash of the bits of the PREVIOUS round's results ]
+// and after the sum the round checks  word1 == G' x its own  and  word2 == G' x its own, with
+// G' = the summed first word (small integers in doubles: these sums are exact in any order).  A
+// rank whose results differed from the others' by a single bit is found in the very next round
+// of its worker group, before its candidates' requests have had a chance to differ; requests
+// that differ in kind or worker are found in the round they occur in.  The round fails AT ONCE on
+// every rank, with its number in the message.
 #pragma once
 
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <cmath>
 #include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
@@ -67,6 +86,11 @@ public:
     rdamd_lnl_reducer_t queue = nullptr;    // two halves of a device-side reducer (optional)
     rdamd_lnl_wait_t wait = nullptr;
     void *user = nullptr, *async_user = nullptr;   // of `reduce` / of `queue` and `wait`
+    // called once when the search fails: makes pending and future reducer calls of THIS process
+    // return failure (the other worker group's round may sit in a collective the ranks that failed
+    // a moment earlier never join)
+    void (*abort)(void *) = nullptr;
+    void *abort_user = nullptr;
   };
 
   explicit conductor_t(const config_t &c) : _c(c) {
@@ -125,7 +149,7 @@ public:
   // a worker that dies takes the search down: nobody may be left waiting for its request
   void fail(const std::string &what) {
     std::lock_guard<std::mutex> lk(_mu);
-    if (_error.empty()) _error = what.empty() ? "a candidate failed" : what;
+    set_error(what.empty() ? "a candidate failed" : what);
     _cv.notify_all();
   }
 
@@ -135,6 +159,7 @@ public:
   // [3] waiting for the round's event and handing out the results
   struct stats_t {
     uint64_t rounds = 0, collectives = 0, obj_launches = 0, obj_jobs = 0, root_launches = 0, root_steps = 0, redos = 0;
+    uint64_t group_size = 0;   // ranks the guard's counting word has seen in the sums (0: no round with a sum yet)
     double seconds[4] = {0, 0, 0, 0};
   };
   stats_t stats() const {
@@ -168,13 +193,31 @@ private:
     double *d_vec = nullptr, *h_in = nullptr, *h_res = nullptr;
     size_t cap = 0;
     hipEvent_t ev = nullptr;   // behind the round's collective and the copy of its sums
+    // the divergence guard (header comment): rounds of this group that carried a sum so far, and
+    // the hash of the last one's results
+    uint64_t seq = 0;
+    double prev_word = 0.0;
   };
+  static constexpr size_t GUARD_WORDS = 3;
+  static uint64_t fnv(uint64_t h, const void *p, size_t n) {
+    for (size_t i = 0; i < n; ++i) h = (h ^ ((const unsigned char *)p)[i]) * 1099511628211ull;
+    return h;
+  }
+  template <class T> static uint64_t fnv(uint64_t h, const T &v) { return fnv(h, &v, sizeof v); }
+  // 40 bits: G x word and the sum of G words are exact in a double for any G a node can hold
+  static double word40(uint64_t h) { return (double)((h ^ (h >> 40)) & ((1ull << 40) - 1)); }
 
   [[noreturn]] static void hip_fail(const char *what, hipError_t e) {
     throw std::runtime_error(std::string("lock-step round: ") + what + ": " + hipGetErrorString(e));
   }
 #define RDAMD_ROUND_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) hip_fail(#expr, e_); } while (0)
 
+  // under _mu; the first error stays
+  void set_error(const std::string &what) {
+    if (!_error.empty()) return;
+    _error = what;
+    if (_c.abort) _c.abort(_c.abort_user);
+  }
   bool my_turn(unsigned g) const { return _c.n_groups == 1 || _turn == g || _g[g ^ 1u].live == 0; }
   void pass_turn(unsigned g) {
     if (_c.n_groups == 2 && _g[g ^ 1u].live > 0) _turn = g ^ 1u;
@@ -190,7 +233,11 @@ private:
     _cv.notify_all();
     for (;;) {
       if (req.done) break;
-      if (!_error.empty()) throw std::runtime_error(_error);
+      if (!_error.empty()) {
+        // (`req` lives on the caller's stack: nothing may keep its address)
+        grp.posted.erase(std::remove(grp.posted.begin(), grp.posted.end(), &req), grp.posted.end());
+        throw std::runtime_error(_error);
+      }
       if (!grp.busy && !grp.posted.empty() && grp.posted.size() == grp.live && my_turn(g)) {
         // everybody of the group has asked and it is the group's turn: this thread runs the round
         std::vector<request_t *> round;
@@ -200,7 +247,7 @@ private:
           run_round(g, round, lk);
         } catch (const std::exception &e) {
           if (!lk.owns_lock()) lk.lock();
-          if (_error.empty()) _error = e.what();
+          set_error(e.what());
         }
         grp.busy = false;
         for (request_t *r : round) r->done = true;
@@ -246,7 +293,9 @@ private:
     // ---- candidates, in worker order (under the lock: the counter is shared by the groups,
     // and the turn makes the order of the groups' rounds the same everywhere)
     std::vector<request_t *> obj, root, red;
+    uint64_t comp = fnv(fnv(1469598103934665603ull, g), grp.seq);
     for (request_t *r : round) {
+      comp = fnv(fnv(fnv(comp, r->worker), (unsigned)r->kind), r->n);
       switch (r->kind) {
         case NEXT:
           if (_next < _c.n_candidates) r->candidate = (long)_next++;
@@ -276,8 +325,20 @@ private:
     for (request_t *r : obj) m += r->n;
     for (request_t *r : root) n_root += r->n;
     for (request_t *r : red) n_red += r->n;
-    const size_t o_flag = m, o_root = m + 1, o_red = o_root + n_root, total = o_red + n_red;
+    const size_t o_flag = m, o_root = m + 1, o_red = o_root + n_root, o_guard = o_red + n_red, total = o_guard + GUARD_WORDS;
     ensure_vec(grp, total, stream);
+    const uint64_t round_no = grp.seq++;   // (of this worker group, counting the rounds that carry a sum)
+    // what an objective batch in flight needs when the round fails after it was queued: its slot
+    // released and the partition's batch sequence advanced (parked schedule blocks wait for that)
+    struct batch_in_flight_t {
+      rdamd_partition_t *p; unsigned slot; bool device, armed = false;
+      ~batch_in_flight_t() {
+        if (!armed) return;
+        if (device) (void)rdamd_evaluate_batch_finish_device(p, slot);
+        else { std::vector<double> sink(n); (void)rdamd_evaluate_batch_wait(p, slot, sink.data()); }
+      }
+      size_t n = 0;
+    } in_flight{_c.shared, g, false};
     const bool two_phase = _c.device && _c.queue && _c.wait;
     const bool device_path = !_c.reduce || _c.device;   // (no reducer at all: the device path without a collective)
 
@@ -301,6 +362,7 @@ private:
           : rdamd_evaluate_batch_submit(_c.shared, g, (unsigned)m, scheds.data(), subst.data(), freqs.data(),
                                         rates.data(), weights.data());
       if (rc != RDAMD_SUCCESS) throw std::runtime_error(std::string("lock-step round: objective batch: ") + rdamd_errmsg());
+      in_flight.device = device_path; in_flight.n = m; in_flight.armed = true;
     }
     lap(0);
     // ---- the root positions: one launch over the candidates' own partitions, beside it
@@ -337,6 +399,29 @@ private:
         at += r->n;
       }
     }
+    // ---- the guard words (header comment)
+    const double comp_word = word40(comp), prev_word = grp.prev_word;
+    grp.h_in[o_guard] = 1.0;
+    grp.h_in[o_guard + 1] = comp_word;
+    grp.h_in[o_guard + 2] = prev_word;
+    const auto check_guard = [&](const double *sums) {
+      const double ranks = sums[o_guard];
+      const char *what = nullptr;
+      if (!(ranks >= 1.0) || ranks != std::floor(ranks) || ranks > 65536.0) what = "the ranks do not add up to a whole number";
+      else if (_group_size.load() && (double)_group_size.load() != ranks) what = "the number of ranks in the sum has changed";
+      else if (sums[o_guard + 1] != ranks * comp_word) what = "the ranks' candidates have posted different requests";
+      else if (sums[o_guard + 2] != ranks * prev_word)
+        what = "the ranks did not receive the same bits from the group's previous sum";
+      if (what) {
+        char msg[512];
+        std::snprintf(msg, sizeof msg,
+                      "lock-step round %llu of worker group %u (%zu values): the site group has diverged -- %s.  "
+                      "Every rank must get identical sums from the reducer (the library's default, ncclAllGather + a sum "
+                      "in rank order, does by construction)", (unsigned long long)round_no, g, total, what);
+        throw std::runtime_error(msg);
+      }
+      _group_size = (uint64_t)ranks;
+    };
 
     lap(1);
     // ---- the sum over the site group
@@ -355,12 +440,14 @@ private:
     } else {
       // host reducer (ranks that share a device): the batch's own wait runs the second pass where
       // this rank needs it -- its values are final before they are summed
+      in_flight.armed = false;   // (the wait releases the slot whether it succeeds or not)
       if (m && rdamd_evaluate_batch_wait(_c.shared, g, grp.h_in) != RDAMD_SUCCESS)
         throw std::runtime_error(std::string("lock-step round: objective batch: ") + rdamd_errmsg());
       grp.h_in[o_flag] = 0.0;
       if (_c.reduce(grp.h_in, (unsigned)total, nullptr, _c.user) != RDAMD_SUCCESS)
         throw std::runtime_error(std::string("lock-step round: site-group reduction failed: ") + rdamd_errmsg());
       res = grp.h_in;
+      check_guard(res);
     }
 
     lap(2);
@@ -376,6 +463,7 @@ private:
     // ---- results
     if (device_path) {
       wait_round(grp, two_phase);
+      check_guard(grp.h_res);
       if (need_redo_check && grp.h_res[o_flag] != 0.0) {
         // some rank's batch wants its second pass: every rank repeats the collective -- in the
         // group's turn, so that it sits at the same place of the stream's order everywhere
@@ -392,10 +480,14 @@ private:
         RDAMD_ROUND_TRY(hipMemcpyAsync(grp.h_res, grp.d_vec, total * sizeof(double), hipMemcpyDeviceToHost, stream));
         RDAMD_ROUND_TRY(hipEventRecord(grp.ev, stream));
         wait_round(grp, two_phase);
+        check_guard(grp.h_res);
       }
+      in_flight.armed = false;
       if (m && rdamd_evaluate_batch_finish_device(_c.shared, g) != RDAMD_SUCCESS)
         throw std::runtime_error(std::string("lock-step round: objective batch: ") + rdamd_errmsg());
     }
+    // (what the NEXT round of this group vouches for: the bits every candidate is about to see)
+    grp.prev_word = word40(fnv(1469598103934665603ull, res, o_guard * sizeof(double)));
     {
       size_t at = 0;
       for (request_t *r : obj) { std::copy(res + at, res + at + r->n, r->out); at += r->n; }
@@ -407,6 +499,7 @@ private:
     lap(3);
     lk.lock();
     for (int k = 0; k < 4; ++k) _stats.seconds[k] += phase[k];
+    _stats.group_size = _group_size.load();
   }
 
   // the site group's sum over d[0 .. n), queued on the shared partition's stream
@@ -434,6 +527,7 @@ private:
   group_t _g[2];
   unsigned _turn = 0;
   size_t _next = 0;
+  std::atomic<uint64_t> _group_size{0};   // the guard's counting word, once seen (the two worker groups' rounds overlap)
   const bool _debug = std::getenv("RDAMD_LOCKSTEP_DEBUG") != nullptr;
   std::string _error;
   stats_t _stats;

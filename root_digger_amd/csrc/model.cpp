@@ -189,7 +189,9 @@ void model_t::set_tip_states(size_t p, const msa_t &msa) {
       fail("failed to set tip " + std::to_string(i));
   }
   if (!msa.weights.empty()) rdamd_set_pattern_weights(_partitions[p], msa.weights.data());
-  if (p < _empirical.size()) _empirical[p].clear();   // (new data: new empirical frequencies)
+  // (new data: new empirical frequencies -- unless they are the whole alignment's, adopted from the
+  // model this replica was made from: a replica's own block may even lack a state)
+  if (!_empirical_adopted && p < _empirical.size()) _empirical[p].clear();
 }
 
 void model_t::set_empirical_freqs(size_t p) {

@@ -187,16 +187,26 @@ public:
   void set_lnl_reducer(rdamd_lnl_reducer_t fn, void *user, bool device) {
     _reduce = fn; _reduce_user = user; _reduce_device = device;
     _reduce_queue = nullptr; _reduce_wait = nullptr;
+    _reduce_abort = nullptr; _reduce_abort_user = nullptr;
     _empirical.clear();
   }
+  // how to get a thread of this process OUT of the reducer (include/root_digger_amd.h,
+  // rdamd_model_set_lnl_reducer_abort): a lock-stepped search that fails in one worker group's
+  // round must not wait for the other group's collective, which the failed ranks never join
+  void set_lnl_reducer_abort(rdamd_lnl_abort_t fn, void *user) { _reduce_abort = fn; _reduce_abort_user = user; }
   // the same reducer in two halves (include/root_digger_amd.h, rdamd_model_set_lnl_reducer_async):
   // what the lock-stepped search of a site-sharded model queues behind its rounds
   void set_lnl_reducer_async(rdamd_lnl_reducer_t queue, rdamd_lnl_wait_t wait, void *user) {
     _reduce_queue = queue; _reduce_wait = wait; _reduce_async_user = user;
   }
   bool site_sharded() const { return _reduce != nullptr; }
-  struct reducer_t { rdamd_lnl_reducer_t reduce, queue; rdamd_lnl_wait_t wait; void *user, *async_user; bool device; };
-  reducer_t reducer() const { return {_reduce, _reduce_queue, _reduce_wait, _reduce_user, _reduce_async_user, _reduce_device}; }
+  struct reducer_t {
+    rdamd_lnl_reducer_t reduce, queue; rdamd_lnl_wait_t wait; void *user, *async_user; bool device;
+    rdamd_lnl_abort_t abort; void *abort_user;
+  };
+  reducer_t reducer() const {
+    return {_reduce, _reduce_queue, _reduce_wait, _reduce_user, _reduce_async_user, _reduce_device, _reduce_abort, _reduce_abort_user};
+  }
   // Lock step in deterministic rounds (lockstep_conductor.hpp): this model is the replica one
   // candidate in flight runs on; its objective batches, its root-only steps and every value it
   // needs summed over the site group go through the conductor as worker `worker`.  Not owned.
@@ -204,7 +214,11 @@ public:
   // empirical frequencies a replica takes over from the model it was made from (they depend on
   // the data only; for a site-sharded model they are SUMS over the group, which a replica --
   // running on a thread of its own -- must not ask for by itself)
-  void adopt_empirical_freqs(const model_t &other) { _empirical = other._empirical; }
+  // (kept across the replica's own tip load: set_tip_states forgets computed frequencies, not adopted ones)
+  void adopt_empirical_freqs(const model_t &other) { _empirical = other._empirical; _empirical_adopted = true; }
+  const std::vector<model_params_t> &empirical_freqs() const { return _empirical; }
+  // host values summed over the site group in place (the model's own collective; no-op unsharded)
+  void sum_over_site_group(double *values, size_t n) { reduce_values(values, n); }
   // collectives this model has asked its reducer for (a sequential site-sharded search: one per
   // request; the lock-stepped one counts in the conductor)
   uint64_t collectives() const { return _n_collectives; }
@@ -284,11 +298,14 @@ private:
 
   rdamd_lnl_reducer_t                    _reduce = nullptr, _reduce_queue = nullptr;
   rdamd_lnl_wait_t                       _reduce_wait = nullptr;
+  rdamd_lnl_abort_t                      _reduce_abort = nullptr;
+  void                                  *_reduce_abort_user = nullptr;
   void                                  *_reduce_user = nullptr, *_reduce_async_user = nullptr;
   bool                                   _reduce_device = false;
   conductor_t                           *_conductor = nullptr;
   unsigned                               _worker = 0;
   std::vector<model_params_t>            _empirical;           // [partition]: empirical frequencies, once computed
+  bool                                   _empirical_adopted = false;   // ... by the model this replica was made from
   uint64_t                               _n_collectives = 0;
   double                                *_d_reduce = nullptr;
   size_t                                 _d_reduce_cap = 0;

@@ -183,8 +183,17 @@ int rdamd_model_set_lnl_reducer(rdamd_model_t *m, rdamd_lnl_reducer_t reduce, vo
   GUARD(RDAMD_FAILURE, {
     m->model->set_lnl_reducer(reduce, user, on_device != 0);
     // the ready-made RCCL reducer comes with its two halves
-    if (reduce == rdamd_comm_reducer && on_device)
+    if (reduce == rdamd_comm_reducer && on_device) {
       m->model->set_lnl_reducer_async(rdamd_comm_reducer_queue, rdamd_comm_reducer_wait, user);
+      m->model->set_lnl_reducer_abort([](void *u) { rdamd_comm_abort((rdamd_comm_t *)u); }, user);
+    }
+    return RDAMD_SUCCESS;
+  })
+}
+int rdamd_model_set_lnl_reducer_abort(rdamd_model_t *m, rdamd_lnl_abort_t abort, void *user) {
+  GUARD(RDAMD_FAILURE, {
+    if (!m->model->site_sharded()) throw std::invalid_argument("set_lnl_reducer_abort: set the reducer first");
+    m->model->set_lnl_reducer_abort(abort, user);
     return RDAMD_SUCCESS;
   })
 }
@@ -472,8 +481,12 @@ struct shared_priority_t {
   bool active;
   shared_priority_t(rdamd_model_t *m_, bool lockstep) : m(m_), active(lockstep && m_->lockstep_priority != 0) {
     for (size_t pi = 0; active && pi < m->model->partition_count(); ++pi)
-      if (rdamd_partition_set_stream_priority(m->model->partition(pi), m->lockstep_priority) != RDAMD_SUCCESS)
-        throw std::runtime_error(std::string("set_stream_priority: ") + rdamd_errmsg());
+      if (rdamd_partition_set_stream_priority(m->model->partition(pi), m->lockstep_priority) != RDAMD_SUCCESS) {
+        // (a constructor that throws has no destructor: put back what was switched so far)
+        const std::string why = rdamd_errmsg();
+        for (size_t pj = 0; pj < pi; ++pj) (void)rdamd_partition_set_stream_priority(m->model->partition(pj), 0);
+        throw std::runtime_error("set_stream_priority: " + why);
+      }
   }
   ~shared_priority_t() {
     for (size_t pi = 0; active && pi < m->model->partition_count(); ++pi)
@@ -495,13 +508,37 @@ static int search_in_rounds(rdamd_model_t *m, unsigned int workers, double atol,
     if (workers < 1) workers = 1;
     workers = (unsigned)std::min<size_t>(workers, std::max<size_t>(todo.size(), 1));
     {
+      // How many replicas fit is each rank's own finding (its free device memory), and every rank
+      // of a site group must run the SAME number of candidates in flight: a different count on
+      // one rank means other rounds, other vector lengths, collectives that do not match.  So
+      // the group agrees before it starts -- through the reducer, like everything else:
+      // [1, requested, requested^2, fit, fit^2] summed; all ranks equal <=> sum == G x own for
+      // the value AND its square (then sum (x_i - own)^2 = 0), which every rank decides alike.
       uint64_t bytes = 0;
-      const unsigned fit = rdamd_model_max_replicas(m, workers, &bytes);
+      const unsigned requested = workers;
+      unsigned fit = rdamd_model_max_replicas(m, workers, &bytes);
+      if (m->model->site_sharded()) {
+        double v[5] = {1.0, (double)requested, (double)requested * requested, (double)fit, (double)fit * fit};
+        m->model->sum_over_site_group(v, 5);
+        const double G = v[0];
+        if (v[1] != G * requested || v[2] != G * requested * requested)
+          throw std::runtime_error("lock step in rounds: the ranks of the site group were asked for different numbers of "
+                                   "candidates in flight (this rank: " + std::to_string(requested) + ")");
+        if (v[3] != G * fit || v[4] != G * (double)fit * fit) {
+          // they differ: everybody runs the smallest.  u[i] = 1 while i < fit; the sum is G exactly
+          // where every rank still fits
+          std::vector<double> u(requested, 0.0);
+          for (unsigned i = 0; i < fit && i < requested; ++i) u[i] = 1.0;
+          m->model->sum_over_site_group(u.data(), u.size());
+          unsigned least = 0;
+          while (least < requested && u[least] == G) ++least;
+          std::fprintf(stderr, "rdamd: the ranks of the site group fit different numbers of replicas (this rank: %u of %.2f GB "
+                               "each); all of them run %u candidates in flight\n", fit, (double)bytes / 1e9, std::max(least, 1u));
+          fit = std::max(least, 1u);
+        }
+      }
       if (fit < workers) {
-        // (every rank of a site group must run the same number: the blocks have the same shape
-        // up to one column, the devices the same memory -- say so loudly)
-        std::fprintf(stderr, "rdamd: %u replicas of %.2f GB each do not fit the free device memory; "
-                             "running %u (all ranks of a site group must agree on this number)\n",
+        std::fprintf(stderr, "rdamd: %u replicas of %.2f GB each do not fit the free device memory; running %u\n",
                      workers, (double)bytes / 1e9, fit);
         workers = fit;
       }
@@ -523,6 +560,7 @@ static int search_in_rounds(rdamd_model_t *m, unsigned int workers, double atol,
     const auto red = m->model->reducer();
     cfg.reduce = red.reduce; cfg.device = red.device; cfg.queue = red.queue; cfg.wait = red.wait;
     cfg.user = red.user; cfg.async_user = red.async_user;
+    cfg.abort = red.abort; cfg.abort_user = red.abort_user;
     rdamd::conductor_t conductor(cfg);
     int device = 0;
     if (hipGetDevice(&device) != hipSuccess) throw std::runtime_error("no HIP device");

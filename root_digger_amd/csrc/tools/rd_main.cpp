@@ -12,9 +12,10 @@
 // --site-shards G (new here; north star / SURVEY 8e): the ranks form WORLD_SIZE/G
 // candidate groups of G adjacent ranks.  A group shares its candidates; each
 // member holds one contiguous block of the alignment's columns, and every
-// log-likelihood is summed over the group -- with an RCCL all-reduce on the
-// device (default), or through the host with --site-reduce host (ranks that
-// share one GPU).  G = WORLD_SIZE is BASELINE config c4's layout (site blocks
+// log-likelihood is summed over the group -- on the device over RCCL (default:
+// ncclAllGather + a sum in rank order, identical bits on every rank by
+// construction; --site-reduce rccl-allreduce: one ncclAllReduce), or through the
+// host with --site-reduce host (ranks that share one GPU).  G = WORLD_SIZE is BASELINE config c4's layout (site blocks
 // only), 1 < G < WORLD_SIZE config c5's 2-D grid.
 //
 //   rd_amd --msa aln.fasta --tree t.nwk --prefix out --exhaustive --lbfgsb liblbfgsb.so
@@ -42,7 +43,7 @@ struct options_t {
   std::string msa, tree, prefix, partition, model, lbfgsb, rate_cats_type = "mean";
   unsigned states = 4, rate_cats = 1, min_roots = 1, workers = 4;
   int lockstep = -1, device = -1, site_shards = 1, lockstep_rounds = -1, lockstep_groups = 0;
-  bool site_reduce_host = false, stats = false;
+  bool site_reduce_host = false, site_allreduce = false, stats = false;
   uint64_t seed = 1;
   double root_ratio = 0.01, atol = 1e-7, bfgstol = 1e-7, brtol = 1e-12, factor = 1e4;
   int early_stop = 0;   // initialized_flag_t: 0 unset, 1 true, 2 false
@@ -66,7 +67,7 @@ void usage() {
       "  --rate-cats-type {mean,median,free}  --seed <N>  --min-roots <N>  --root-ratio <X>\n"
       "  --atol <X>  --brtol <X>  --bfgstol <X>  --factor <X>  --early-stop  --no-early-stop\n"
       "  --initial-root-strategy {random,midpoint,modified-mad}  --threads <N>  --lockstep <N>\n"
-      "  --site-shards <G>  --site-reduce {rccl,host}  --lockstep-rounds {0,1}  --lockstep-groups {1,2}  --stats\n"
+      "  --site-shards <G>  --site-reduce {rccl,rccl-allreduce,host}  --lockstep-rounds {0,1}  --lockstep-groups {1,2}  --stats\n"
       "  --lbfgsb <LIB>  --device <N>  --silent  --echo  --clean  --no-checkpoint  --version");
 }
 
@@ -136,8 +137,9 @@ options_t parse(int argc, char **argv) {
     else if (name == "stats") o.stats = true;
     else if (name == "site-reduce") {
       const std::string s = v;
-      if (s != "rccl" && s != "host") die("--site-reduce takes rccl or host");
+      if (s != "rccl" && s != "rccl-allreduce" && s != "host") die("--site-reduce takes rccl, rccl-allreduce or host");
       o.site_reduce_host = s == "host";
+      o.site_allreduce = s == "rccl-allreduce";
     }
   }
   return o;
@@ -179,6 +181,12 @@ static int run(int argc, char **argv) {
   rdamd_comm_t *comm = nullptr;
   if (G > 1 && o.site_reduce_host) {
     host_group.reset(new site_group_t(ranks, G));
+    // (test hook, see rendezvous.hpp: RDAMD_FAULT_ULP=<rank>:<call>)
+    if (const char *f = std::getenv("RDAMD_FAULT_ULP")) {
+      int fr = -1;
+      unsigned long long fc = 0;
+      if (std::sscanf(f, "%d:%llu", &fr, &fc) == 2 && fr == rank) host_group->set_fault(fc);
+    }
   } else if (G > 1) {   // the group leader's RCCL id reaches the members over the world star
     char id[128] = {0};
     if (srank == 0) need(rdamd_comm_unique_id(id), "RCCL unique id");
@@ -186,6 +194,7 @@ static int run(int argc, char **argv) {
     ranks.allgather(id, sizeof id, all);
     comm = rdamd_comm_create(all.data() + sizeof id * (size_t)(cgroup * G), srank, G);
     if (!comm) die(std::string("RCCL communicator: ") + rdamd_errmsg());
+    if (o.site_allreduce) need(rdamd_comm_set_sum_mode(comm, RDAMD_COMM_SUM_ALLREDUCE), "sum mode");
   }
 
   // ---- checkpoint: mpi_create_checkpoint + merge_options_checkpoint, src/main.cpp:335-409
@@ -282,9 +291,10 @@ static int run(int argc, char **argv) {
   }
   if (!model) die(rdamd_errmsg());
   // before anything is evaluated: the empirical frequencies are reduced too
-  if (host_group)
+  if (host_group) {
     need(rdamd_model_set_lnl_reducer(model, site_group_t::reducer, host_group.get(), 0), "reducer");
-  else if (comm)
+    need(rdamd_model_set_lnl_reducer_abort(model, site_group_t::abort_hook, host_group.get()), "reducer abort");
+  } else if (comm)
     need(rdamd_model_set_lnl_reducer(model, rdamd_comm_reducer, comm, 1), "reducer");
   if (o.echo) {
     char *nw = rdamd_tree_newick(tree, 1);

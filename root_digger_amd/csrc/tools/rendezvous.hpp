@@ -27,6 +27,7 @@
 
 #include <atomic>
 #include <cerrno>
+#include <cstdio>
 #include <chrono>
 #include <functional>
 #include <cstdint>
@@ -249,25 +250,49 @@ public:
 
   void allreduce_sum(double *values, unsigned n) {
     if (_size <= 1 || n == 0) return;
+    if (_aborted.load()) throw std::runtime_error("site group: aborted");
     const size_t bytes = sizeof(double) * n;
+    const uint32_t len = n;
     if (_srank == 0) {
       _tmp.resize(n);
-      for (int fd : _peers) {   // rank order
+      for (int fd : _peers) {   // rank order: ((v0 + v1) + v2) + ...
+        uint32_t theirs = 0;
+        recv_all(fd, &theirs, sizeof theirs);
+        // (ranks whose rounds have diverged: a device collective would hang or corrupt here)
+        if (theirs != len) throw std::runtime_error("site group: the ranks' vectors differ in length");
         recv_all(fd, _tmp.data(), bytes);
         for (unsigned i = 0; i < n; ++i) values[i] += _tmp[i];
       }
       for (int fd : _peers) send_all(fd, values, bytes);
     } else {
+      send_all(_peers[0], &len, sizeof len);
       send_all(_peers[0], values, bytes);
       recv_all(_peers[0], values, bytes);
     }
+    // FAULT INJECTION for the divergence-guard test (tests/test_gpu_lockstep_rounds.py): this
+    // rank's copy of the sums of its `_fault_call`-th reduction differs from the others' by one
+    // unit in the last place of one value -- what a reducer without a bit-identity promise may do
+    if (_fault_call && ++_calls == _fault_call) {
+      uint64_t b;
+      std::memcpy(&b, &values[0], 8);
+      b ^= 1;
+      std::memcpy(&values[0], &b, 8);
+    }
   }
+  void set_fault(uint64_t call) { _fault_call = call; }
+  // rdamd_lnl_abort_t: every pending and future reduction of this process fails (any thread)
+  void abort() {
+    _aborted = true;
+    for (int fd : _peers) shutdown(fd, SHUT_RDWR);
+  }
+  static void abort_hook(void *user) { ((site_group_t *)user)->abort(); }
   // rdamd_lnl_reducer_t with on_device = 0 and user = the site_group_t
   static int reducer(double *values, unsigned int n, void *, void *user) {
     try {
       ((site_group_t *)user)->allreduce_sum(values, n);
       return 1;
-    } catch (const std::exception &) {
+    } catch (const std::exception &e) {
+      std::fprintf(stderr, "%s\n", e.what());
       return 0;
     }
   }
@@ -276,6 +301,8 @@ private:
   int _size, _srank;
   std::vector<int> _peers;
   std::vector<double> _tmp;
+  std::atomic<bool> _aborted{false};
+  uint64_t _fault_call = 0, _calls = 0;
 };
 
 }  // namespace rdamd_tools

@@ -45,13 +45,30 @@ def rank_coords(rank, site_groups):
     return rank // site_groups, rank % site_groups
 
 
-def allreduce_lnl(values, group=None):
+def allreduce_lnl(values, group=None, mode="gather"):
     """Sum per-block log-likelihoods over the ranks of `group` in place.
-    `values` is a torch tensor (device tensor with RCCL, CPU tensor with gloo);
-    the sum order is fixed by the collective, so repeated calls are
-    bit-identical for a fixed world."""
+    `values` is a torch tensor (device tensor with RCCL, CPU tensor with gloo).
+
+    mode "gather" (default): all_gather + ((v0 + v1) + v2) + ... in RANK ORDER -- every rank
+    holds the same bits by construction, whatever algorithm the backend picks, and the sum is
+    the one the library's own reducer makes (csrc/comm.cpp RDAMD_COMM_SUM_GATHER,
+    rdamd_rank_order_sum) and rd_amd's host reducer (tools/rendezvous.hpp).  The optimisers
+    above branch on these sums: one ulp of difference between two ranks forks a trajectory.
+    mode "allreduce": one all_reduce; the association of the sum is the backend's."""
+    import torch
     import torch.distributed as dist
-    dist.all_reduce(values, op=dist.ReduceOp.SUM, group=group)
+    world = dist.get_world_size(group)
+    if mode == "allreduce" or world == 1:
+        dist.all_reduce(values, op=dist.ReduceOp.SUM, group=group)
+        return values
+    if mode != "gather":
+        raise ValueError("allreduce_lnl: mode is 'gather' or 'allreduce'")
+    parts = [torch.empty_like(values) for _ in range(world)]
+    dist.all_gather(parts, values.contiguous(), group=group)
+    acc = parts[0]
+    for p in parts[1:]:
+        acc = acc + p
+    values.copy_(acc)
     return values
 
 

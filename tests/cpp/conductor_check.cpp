@@ -12,9 +12,20 @@
 // depend on the SUMS it got back (as an optimiser's next step depends on the reduced lnL), for a
 // number of steps that differs per candidate, under random delays.
 //
-//   conductor_check <ranks G> <workers W> <groups 1|2> <candidates> <seed>
-// prints "conductor OK rounds=<n> collectives=<n> digest=<hex>"; exit code 0.  The digest covers
-// every value every worker received: the test driver compares it across seeds of the DELAYS.
+//   conductor_check <ranks G> <workers W> <groups 1|2> <candidates> <seed> [host|device] [<rank>:<collective>]
+// prints "conductor OK rounds=<n> collectives=<n> redos=<n> digest=<hex>"; exit code 0.  The digest
+// covers every value every worker received: the test driver compares it across seeds of the DELAYS.
+//
+// `device`: the path real RCCL runs take -- rdamd_evaluate_batch_submit_device / _redo_device /
+// _finish_device stand-ins whose SECOND-PASS FLAG is raised at random, differently on every rank
+// (so the flag must travel through the sum and every rank must repeat the collective, in its
+// worker group's turn), and a reducer in two halves (queue / wait).  The rendezvous then also
+// asserts that every rank's vector carries the same guard word for (worker group, round, requests)
+// -- i.e. that all ranks issue the SAME SEQUENCE of collectives, redos included.
+// `<rank>:<collective>`: that rank's copy of the sums of its <collective>-th reduction (and the
+// two after it) differs by one unit in the last place (a reducer without a bit-identity promise).  The conductor's
+// divergence guard must fail the run on every rank at once, naming the round: exit code 1, "has
+// diverged" on stderr.
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -77,11 +88,38 @@ int rdamd_evaluate_batch_wait(rdamd_partition_t *p, unsigned int slot, double *o
   v.clear();
   return RDAMD_SUCCESS;
 }
-// (the device path is not exercised here: the conductor's config has a HOST reducer)
-int rdamd_evaluate_batch_submit_device(rdamd_partition_t *, unsigned int, unsigned int, const rdamd_schedule_t *const *,
-                                       const double *, const double *, const double *, const double *, void *) { return RDAMD_FAILURE; }
-int rdamd_evaluate_batch_redo_device(rdamd_partition_t *, unsigned int, void *) { return RDAMD_FAILURE; }
-int rdamd_evaluate_batch_finish_device(rdamd_partition_t *, unsigned int) { return RDAMD_FAILURE; }
+// The device path: "device memory" is host memory here and the stream runs at once.  A batch's
+// second-pass flag is up with probability 1/6, decided per (rank, batch) -- the ranks disagree,
+// as real shards do; until its redo a flagged batch shows values that are NOT final.
+static std::atomic<uint64_t> g_batches[64];
+int rdamd_evaluate_batch_submit_device(rdamd_partition_t *p, unsigned int slot, unsigned int n, const rdamd_schedule_t *const *scheds,
+                                       const double *subst, const double *, const double *, const double *, void *d_vec) {
+  std::vector<double> out(n);
+  for (unsigned j = 0; j < n; ++j) out[j] = job_value(p->rank, scheds[j]->tag, subst + 2 * j);
+  const uint64_t k = g_batches[p->rank]++;
+  const bool flagged = ((k * 2654435761ull + (uint64_t)p->rank * 40503ull) >> 7) % 6 == 0;
+  double *d = (double *)d_vec;
+  for (unsigned j = 0; j < n; ++j) d[j] = flagged ? out[j] - 1000.0 : out[j];
+  d[n] = flagged ? 1.0 : 0.0;
+  std::lock_guard<std::mutex> g(g_slot_mu);
+  if (!g_slot[p->rank][slot].empty()) { g_err = "slot busy"; return RDAMD_FAILURE; }
+  g_slot[p->rank][slot] = out;
+  return RDAMD_SUCCESS;
+}
+int rdamd_evaluate_batch_redo_device(rdamd_partition_t *p, unsigned int slot, void *d_vec) {
+  std::lock_guard<std::mutex> g(g_slot_mu);
+  const std::vector<double> &v = g_slot[p->rank][slot];
+  if (v.empty()) { g_err = "nothing in flight"; return RDAMD_FAILURE; }
+  std::copy(v.begin(), v.end(), (double *)d_vec);
+  ((double *)d_vec)[v.size()] = 0.0;
+  return RDAMD_SUCCESS;
+}
+int rdamd_evaluate_batch_finish_device(rdamd_partition_t *p, unsigned int slot) {
+  std::lock_guard<std::mutex> g(g_slot_mu);
+  if (g_slot[p->rank][slot].empty()) { g_err = "nothing in flight"; return RDAMD_FAILURE; }
+  g_slot[p->rank][slot].clear();
+  return RDAMD_SUCCESS;
+}
 int rdamd_root_loglikelihood_fused_multi(unsigned int n_items, rdamd_partition_t *const *parts, const rdamd_operation_t *ops,
                                          const unsigned int *const *, const double *l1, const double *l2,
                                          const unsigned int *npos, double *out) {
@@ -104,9 +142,31 @@ struct group_t {
   std::vector<std::vector<double>> parts;
   bool failed = false;
   uint64_t collectives = 0;
+  bool check_sequence = false;   // every rank's vector must carry the same round identity
 };
-struct rank_ctx { group_t *g; int rank; };
-static int reducer(double *values, unsigned int n, void *, void *user) {
+struct rank_ctx { group_t *g; int rank; uint64_t calls = 0, fault_call = 0; };
+static int reducer_body(double *values, unsigned int n, void *, void *user);
+static int reducer(double *values, unsigned int n, void *stream, void *user) {
+  rank_ctx *c = (rank_ctx *)user;
+  if (reducer_body(values, n, stream, user) != RDAMD_SUCCESS) return RDAMD_FAILURE;
+  // this rank's copy of the sums: one ulp off (three reductions in a row: a first pass that is
+  // repeated for somebody's second-pass flag is thrown away, and legitimately leaves no trace)
+  if (c->fault_call && ++c->calls >= c->fault_call && c->calls < c->fault_call + 3) {
+    uint64_t b;
+    std::memcpy(&b, &values[0], 8);
+    b ^= 1;
+    std::memcpy(&values[0], &b, 8);
+  }
+  return RDAMD_SUCCESS;
+}
+static int reducer_wait(void *, void *) { return RDAMD_SUCCESS; }   // (the stand-in stream has run everything already)
+static void reducer_abort(void *user) {
+  group_t &g = *((rank_ctx *)user)->g;
+  std::lock_guard<std::mutex> lk(g.mu);
+  g.failed = true;
+  g.cv.notify_all();
+}
+static int reducer_body(double *values, unsigned int n, void *, void *user) {
   rank_ctx *c = (rank_ctx *)user;
   group_t &g = *c->g;
   std::unique_lock<std::mutex> lk(g.mu);
@@ -121,6 +181,14 @@ static int reducer(double *values, unsigned int n, void *, void *user) {
   g.parts[c->rank].assign(values, values + n);
   const uint64_t gen = g.generation;
   if (++g.arrived == g.G) {
+    // (the conductor's guard: [.. | 1.0 | hash(worker group, round, requests) | hash(previous results)])
+    for (int r = 1; g.check_sequence && r < g.G; ++r)
+      if (n < 3 || g.parts[r][n - 2] != g.parts[0][n - 2]) {
+        std::fprintf(stderr, "reducer: rank %d's collective is not the one rank 0 issued (order of the rounds differs)\n", r);
+        g.failed = true;
+        g.cv.notify_all();
+        return RDAMD_FAILURE;
+      }
     g.sum.assign(n, 0.0);
     for (int r = 0; r < g.G; ++r)
       for (unsigned i = 0; i < n; ++i) g.sum[i] += g.parts[r][i];
@@ -147,25 +215,34 @@ static uint64_t mix(uint64_t h, double v) {
 }
 
 int main(int argc, char **argv) {
-  if (argc != 6) return 2;
+  if (argc < 6 || argc > 8) return 2;
   const int G = std::atoi(argv[1]), W = std::atoi(argv[2]), groups = std::atoi(argv[3]), ncand = std::atoi(argv[4]);
   const unsigned seed = (unsigned)std::atoi(argv[5]);
+  const bool device = argc > 6 && !std::strcmp(argv[6], "device");
+  int fault_rank = -1;
+  unsigned long long fault_call = 0;
+  if (argc > 7 && std::sscanf(argv[7], "%d:%llu", &fault_rank, &fault_call) != 2) return 2;
   group_t group;
   group.G = G;
+  group.check_sequence = true;
   std::vector<rdamd_partition> parts(G);
   std::vector<rank_ctx> ctx(G);
   std::vector<std::unique_ptr<rdamd::conductor_t>> cond;
   for (int r = 0; r < G; ++r) {
     parts[r].rank = r;
-    ctx[r] = {&group, r};
+    ctx[r].g = &group; ctx[r].rank = r;
+    if (r == fault_rank) ctx[r].fault_call = fault_call;
     rdamd::conductor_t::config_t cfg;
     cfg.shared = &parts[r];
     cfg.n_workers = (unsigned)W;
     cfg.n_groups = (unsigned)groups;
     cfg.n_candidates = (size_t)ncand;
     cfg.reduce = reducer;
-    cfg.device = false;
+    cfg.device = device;
     cfg.user = &ctx[r];
+    if (device) { cfg.queue = reducer; cfg.wait = reducer_wait; cfg.async_user = &ctx[r]; }
+    cfg.abort = reducer_abort;
+    cfg.abort_user = &ctx[r];
     cond.emplace_back(new rdamd::conductor_t(cfg));
   }
   std::vector<uint64_t> digest((size_t)G * W, 1469598103934665603ull);
@@ -250,7 +327,11 @@ int main(int argc, char **argv) {
                 (unsigned long long)st.collectives, (unsigned long long)group.collectives);
     return 1;
   }
-  std::printf("conductor OK rounds=%llu collectives=%llu digest=%016llx\n", (unsigned long long)st.rounds,
-              (unsigned long long)st.collectives, (unsigned long long)all);
+  if (st.group_size != (uint64_t)G) {
+    std::printf("conductor FAILED: the guard counted %llu ranks, there are %d\n", (unsigned long long)st.group_size, G);
+    return 1;
+  }
+  std::printf("conductor OK rounds=%llu collectives=%llu redos=%llu digest=%016llx\n", (unsigned long long)st.rounds,
+              (unsigned long long)st.collectives, (unsigned long long)st.redos, (unsigned long long)all);
   return 0;
 }

@@ -189,6 +189,56 @@ def test_world_size_4_grid_of_candidate_groups_and_site_shards():
         assert abs(freqs[0] - want0) < 1e-15 and abs(sum(freqs) - 1.0) < 1e-15
 
 
+def _order_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    tdist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # contributions whose sum depends on the association: rank order gives
+        # ((1e16 + 1) - 1e16) + 1 = 1, pairwise (1e16 + 1) + (-1e16 + 1) = 0, and so on
+        table = [[1e16, 0.1, 3.0], [1.0, 0.2, 1e-17], [-1e16, 0.3, -3.0], [1.0, 0.4, 1e-17]]
+        part = torch.tensor(table[rank], dtype=torch.float64)
+        rdist.allreduce_lnl(part)
+        gathered = [None] * world
+        tdist.all_gather_object(gathered, part.tolist())
+        if rank == 0:
+            out.put(("ok", gathered, table))
+    except Exception as e:   # pragma: no cover
+        if rank == 0:
+            out.put(("err", repr(e)))
+        raise
+    finally:
+        tdist.destroy_process_group()
+
+
+def test_site_group_sum_is_the_rank_order_sum_on_every_rank():
+    """The optimisers branch on the group's sums, so every rank must hold the same BITS and the
+    bits must not depend on the collective's algorithm: allreduce_lnl gathers and adds in rank
+    order -- the sum csrc/comm.cpp's RDAMD_COMM_SUM_GATHER makes on the device and rd_amd's host
+    reducer makes through its leader (reference split: src/model.cpp:1867-1911)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_order_worker, args=(r, 4, port, q)) for r in range(4)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0] == "ok", res
+    _, gathered, table = res
+    want = []
+    for i in range(3):
+        acc = table[0][i]
+        for r in range(1, 4):
+            acc = acc + table[r][i]
+        want.append(acc)
+    assert want[0] == 1.0
+    for got in gathered:
+        assert got == want                    # bit for bit, on every rank
+
+
 def test_bench_parent_spawns_one_child_per_gpu(tmp_path):
     """`python bench.py --gpus 2` with no launcher must start two ranks itself
     (it used to run one rank and print n_gpus 1).  Without a GPU the

@@ -49,6 +49,10 @@ class _Hip:
         assert self.rt.hipMalloc(C.byref(p), nbytes) == 0
         return p.value
 
+    def write(self, ptr, arr):
+        arr = np.ascontiguousarray(arr, dtype=np.float64)
+        assert self.rt.hipMemcpy(C.c_void_p(ptr), arr.ctypes.data_as(C.c_void_p), arr.nbytes, 1) == 0
+
     def read(self, ptr, n):
         out = np.zeros(n, dtype=np.float64)
         assert self.rt.hipDeviceSynchronize() == 0
@@ -108,10 +112,10 @@ def test_stream_ordered_device_batch_equals_the_blocking_call():
     hip.free(d)
 
 
-def _model(seed=3):
+def _model(seed=3, early_stop=False):
     tree = rd.Tree.from_file(TREE)
     seqs, w = util.compress(util.read_fasta(MSA))
-    m = rd.Model(tree, seqs, rate_cats=4, weights=w, seed=seed)
+    m = rd.Model(tree, seqs, rate_cats=4, weights=w, seed=seed, early_stop=early_stop)
     m.initialize_partitions()
     m.set_lbfgsb(C.CDLL(REF).setulb)
     return m
@@ -133,13 +137,35 @@ def sequential_records():
     return out
 
 
+@pytest.fixture(scope="module")
+def sequential_records_early_stop():
+    """BASELINE config c5's mode: `--exhaustive --early-stop` (src/model.cpp:1187-1197: a candidate
+    whose root position moved by less than brtol leaves its loop at once, with the NEW position)"""
+    if not os.path.exists(REF):
+        pytest.skip("oracle/_ref/liblbfgsb_ref.so not built (needs /root/reference at build time)")
+    m = _model(early_stop=True)
+    out = _search(m, 0)
+    m.destroy()
+    return out
+
+
+def test_early_stop_changes_the_candidates_request_sequences(sequential_records, sequential_records_early_stop):
+    """(so that the early-stop cases below test something: with these tolerances the rule fires,
+    candidates leave their loops earlier and end elsewhere)"""
+    assert sequential_records_early_stop[0] == sequential_records[0]
+    assert sequential_records_early_stop[1:] != sequential_records[1:]
+
+
 @pytest.mark.parametrize("in_flight", [3, 6, 17])
-def test_rounds_reproduce_the_sequential_search_on_one_rank(sequential_records, in_flight):
+@pytest.mark.parametrize("early_stop", [False, True])
+def test_rounds_reproduce_the_sequential_search_on_one_rank(sequential_records, sequential_records_early_stop,
+                                                            in_flight, early_stop):
     """no reducer: the rounds' machinery alone (one group below four candidates in flight, two
-    alternating groups from four on); a job's value does not depend on its launch"""
-    m = _model()
+    alternating groups from four on); a job's value does not depend on its launch.  With and
+    without the early-stop rule (it changes when a candidate posts "next candidate")"""
+    m = _model(early_stop=early_stop)
     m.set_lockstep_rounds(1)
-    assert _search(m, in_flight) == sequential_records
+    assert _search(m, in_flight) == (sequential_records_early_stop if early_stop else sequential_records)
     st, ls = m.round_stats(), m.lockstep_stats()
     assert st["rounds"] > 0 and st["redos"] == 0 and st["own_collectives"] == 0
     assert ls["objective_jobs"] > ls["objective_launches"] > 0 and ls["root_steps"] > ls["root_launches"] > 0
@@ -148,12 +174,42 @@ def test_rounds_reproduce_the_sequential_search_on_one_rank(sequential_records, 
     m.destroy()
 
 
-def test_rounds_with_the_rccl_communicator_as_reducer(sequential_records):
-    """the device path of a site group -- batch to device memory, ncclAllReduce queued behind it on
-    the partition's stream, the sums copied back, the event waited for with the communicator's
-    failure handling -- on a one-rank group: a one-rank sum changes nothing, so the records are
-    the sequential ones, and the collectives are counted"""
+def test_rank_order_sum_kernel_is_the_host_reducers_sum():
+    """RDAMD_COMM_SUM_GATHER = ncclAllGather + this kernel: ((v0 + v1) + v2) + ... in rank order.
+    Bit for bit the loop rd_amd's host reducer (tools/rendezvous.hpp) and dist.allreduce_lnl run
+    -- on data whose sum depends on the association"""
+    hip = _Hip()
+    rng = np.random.default_rng(11)
+    for ranks, n in ((2, 1), (8, 449), (4, 12_200), (3, 70_001)):
+        g = rng.standard_normal((ranks, n)) * 10.0 ** rng.integers(-18, 18, (ranks, n))
+        g[:, 0] = [1e16, 1.0, -1e16, 1.0, 0.5, 0.25, -1.0, 3.0][:ranks]
+        want = g[0].copy()
+        for r in range(1, ranks):
+            want = want + g[r]
+        d_g, d_out = hip.alloc(8 * ranks * n), hip.alloc(8 * n)
+        hip.write(d_g, g)
+        rd.rank_order_sum(d_g, d_out, n, ranks)
+        assert np.array_equal(hip.read(d_out, n), want)
+        rd.rank_order_sum(d_g, d_g, n, ranks)                 # in place over the first vector
+        assert np.array_equal(hip.read(d_g, n), want)
+        hip.free(d_g)
+        hip.free(d_out)
+    # pairwise or reversed association gives other bits on this data: the test would notice
+    assert ((1e16 + 1.0) + -1e16) + 1.0 != (1e16 + 1.0) + (-1e16 + 1.0)
+
+
+@pytest.mark.parametrize("mode", ["gather", "allreduce"])
+def test_rounds_with_the_rccl_communicator_as_reducer(sequential_records, mode):
+    """the device path of a site group -- batch to device memory, the collective queued behind it
+    on the partition's stream (default: ncclAllGather + the rank-order sum kernel; selectable:
+    ncclAllReduce), the sums copied back, the event waited for with the communicator's failure
+    handling -- on a one-rank group: a one-rank sum changes nothing, so the records are the
+    sequential ones, and the collectives are counted"""
     comm = rd.Comm(rd.Comm.unique_id(), 0, 1)
+    assert comm.sum_mode == rd.COMM_SUM_GATHER
+    if mode == "allreduce":
+        comm.set_sum_mode(rd.COMM_SUM_ALLREDUCE)
+        assert comm.sum_mode == rd.COMM_SUM_ALLREDUCE
     seq = _model()
     seq.set_lnl_reducer(comm.reducer, on_device=True, user=comm.handle)
     assert _search(seq, 0) == sequential_records
@@ -241,13 +297,16 @@ def _run_ranks(args, world, timeout=900):
     return stats
 
 
-@pytest.mark.parametrize("world,shards", [(2, 2), (4, 2), (8, 8), (8, 2)])
-def test_site_sharded_lock_step_equals_the_sequential_sharded_search(tmp_path, world, shards):
+@pytest.mark.parametrize("world,shards,early_stop", [(2, 2, False), (4, 2, False), (8, 8, False), (8, 2, False),
+                                                     (4, 2, True), (8, 2, True), (2, 2, True)])
+def test_site_sharded_lock_step_equals_the_sequential_sharded_search(tmp_path, world, shards, early_stop):
     """c4's layout (site blocks only: 2/2, 8/8) and c5's grid (candidate groups x site blocks:
     4/2, 8/2).  Same G, same reducer: the sums are the same numbers in the same order, so the
     lock-stepped records must be the sequential ones BIT FOR BIT whatever the tolerances; every
     rank of a site group ends with the same bits; one collective per round instead of one per
-    request."""
+    request.  early_stop: BASELINE config c5's own mode, `--exhaustive --early-stop`
+    (src/model.cpp:1187-1197) -- the break changes a candidate's request sequence, which the rounds
+    must reproduce identically on every rank."""
     if not os.path.exists(REF):
         pytest.skip("oracle/_ref/liblbfgsb_ref.so not built")
     msa, tree, n_roots = MSA, TREE, 17
@@ -269,7 +328,7 @@ def test_site_sharded_lock_step_equals_the_sequential_sharded_search(tmp_path, w
     common = ["--msa", msa, "--tree", tree, "--exhaustive", "--silent", "--rate-cats", "4",
               "--atol", "0.5", "--brtol", "0.1", "--bfgstol", "0.5", "--factor", "1e15",
               "--seed", "5", "--lbfgsb", REF, "--device", "0", "--site-shards", str(shards),
-              "--site-reduce", "host", "--stats"]
+              "--site-reduce", "host", "--stats"] + (["--early-stop"] if early_stop else [])
     seq, lock = str(tmp_path / "seq"), str(tmp_path / "lock")
     st_seq = _run_ranks([RD] + common + ["--prefix", seq, "--lockstep", "0"], world)
     in_flight = 8 if world < 8 else 4       # (eight processes x eight replicas on one device take minutes)
@@ -290,9 +349,82 @@ def test_site_sharded_lock_step_equals_the_sequential_sharded_search(tmp_path, w
         assert st_lock[g * shards]["results_digest"] == st_seq[g * shards]["results_digest"]
     per_request = int(st_seq[0]["own_collectives"])
     per_round = int(st_lock[0]["collectives"])
-    # (the model's own: the empirical frequencies and model_t::initialize, before the search)
-    assert int(st_lock[0]["own_collectives"]) <= 2 and per_round > 0
+    # (the model's own: the empirical frequencies, model_t::initialize and the group's agreement
+    # on the number of candidates in flight, before the search)
+    assert int(st_lock[0]["own_collectives"]) <= 3 and per_round > 0
     # a worker group of W candidates: up to W candidates' requests per collective (fewer towards
     # the end of a list; measured 2.7 of 3 with two groups of three)
     assert per_request > 0.45 * per_group * per_round, (per_request, per_round, per_group)
     assert open(seq + ".rooted.tree").read() == open(lock + ".rooted.tree").read()
+
+
+def test_early_stop_records_differ_from_the_plain_exhaustive_ones(tmp_path):
+    """(guards the parametrisation above: at its tolerances the early-stop rule does fire)"""
+    if not os.path.exists(REF):
+        pytest.skip("oracle/_ref/liblbfgsb_ref.so not built")
+    common = ["--msa", MSA, "--tree", TREE, "--exhaustive", "--silent", "--rate-cats", "4", "--atol", "0.5", "--brtol", "0.1",
+              "--bfgstol", "0.5", "--factor", "1e15", "--seed", "5", "--lbfgsb", REF, "--device", "0", "--lockstep", "8",
+              "--lockstep-rounds", "1"]
+    a, b = str(tmp_path / "plain"), str(tmp_path / "early")
+    for prefix, extra in ((a, []), (b, ["--early-stop"])):
+        out = subprocess.run([RD] + common + ["--prefix", prefix] + extra, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stdout + out.stderr
+    ra, rb = sorted(rd.Checkpoint(a).read_results()), sorted(rd.Checkpoint(b).read_results())
+    assert [r[0] for r in ra] == [r[0] for r in rb] == list(range(17))
+    assert ra != rb
+
+
+def test_one_ulp_on_one_rank_ends_the_run_at_once_naming_the_round(tmp_path):
+    """The rounds rest on every rank of a site group receiving the same BITS from the reducer
+    (csrc/lockstep_conductor.hpp, header).  Here rank 1's copy of the sums of its 40th reduction
+    is off by one unit in the last place (rendezvous.hpp's fault hook) -- what an all-reduce
+    without a bit-identity promise may deliver.  Unnoticed, the two ranks' optimisers part ways
+    and some later round no longer matches: a hang until the communicator's time limit.  With the
+    guard the very next round of that worker group fails on BOTH ranks, by its number, in seconds."""
+    if not os.path.exists(REF):
+        pytest.skip("oracle/_ref/liblbfgsb_ref.so not built")
+    import time
+    args = [RD, "--msa", MSA, "--tree", TREE, "--exhaustive", "--silent", "--rate-cats", "4", "--atol", "0.5", "--brtol", "0.1",
+            "--bfgstol", "0.5", "--factor", "1e15", "--seed", "5", "--lbfgsb", REF, "--device", "0", "--site-shards", "2",
+            "--site-reduce", "host", "--lockstep", "8", "--prefix", str(tmp_path / "f")]
+    s = __import__("socket").socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), GPU_MAX_HW_QUEUES="1",
+               RDAMD_FAULT_ULP="1:40")
+    t0 = time.time()
+    procs = [subprocess.Popen(args, env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.PIPE, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=120) for p in procs]
+    took = time.time() - t0
+    assert all(p.returncode != 0 for p in procs), outs
+    text = "".join(o + e for o, e in outs)
+    mt = re.search(r"lock-step round (\d+) of worker group \d+ .*has diverged -- the ranks did not receive the same bits", text)
+    assert mt, text[-3000:]
+    assert took < 60, took                  # (start-up included; the comm time limit is 600 s)
+
+
+def test_a_site_block_that_lacks_a_state(tmp_path):
+    """A replica takes the GROUP's empirical frequencies over from the model it is made from and
+    must keep them across its own tip load: here the second block of columns holds
+    no T at all -- frequencies computed from that block alone have a zero entry ("One of the state
+    frequenices is zero") and would differ per rank.  The lock-stepped search must give the
+    sequential sharded search's records, bit for bit."""
+    if not os.path.exists(REF):
+        pytest.skip("oracle/_ref/liblbfgsb_ref.so not built")
+    seqs = util.read_fasta(MSA)
+    n = len(next(iter(seqs.values())))
+    msa = str(tmp_path / "noT.fasta")
+    with open(msa, "w") as f:
+        for k, v in seqs.items():
+            half = v[n // 2:].replace("T", "C").replace("t", "c")
+            f.write(">%s\n%s\n" % (k, v[:n // 2] + half))
+    common = ["--msa", msa, "--tree", TREE, "--exhaustive", "--silent", "--rate-cats", "4", "--atol", "0.5", "--brtol", "0.1",
+              "--bfgstol", "0.5", "--factor", "1e15", "--seed", "5", "--lbfgsb", REF, "--device", "0", "--site-shards", "2",
+              "--site-reduce", "host", "--stats"]
+    seq, lock = str(tmp_path / "seq"), str(tmp_path / "lock")
+    _run_ranks([RD] + common + ["--prefix", seq, "--lockstep", "0"], 2)
+    st = _run_ranks([RD] + common + ["--prefix", lock, "--lockstep", "6"], 2)
+    assert st[0]["results_digest"] == st[1]["results_digest"]
+    assert sorted(rd.Checkpoint(seq).read_results()) == sorted(rd.Checkpoint(lock).read_results())
