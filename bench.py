@@ -106,6 +106,23 @@ def profiled_summary(kernel, batch, config, key):
     return v, name
 
 
+def predicted_for(leg, n_gpus, batch, config, sites_overridden):
+    """What this leg of the N-GPU line was PREDICTED to show (profiles/scale_prediction.json: figures
+    measured on one GPU + an assumed all-reduce latency; c2, batch 197 only), so that a hardware
+    SCALE record carries its own yardstick."""
+    if config != "c2" or batch != 197 or sites_overridden or n_gpus < 2:
+        return None
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "scale_prediction.json")))
+    except (OSError, ValueError):
+        return None
+    v = d.get(leg, {}).get(str(n_gpus))
+    if v is None:
+        return None
+    return {"value": v, "unit": "evals/s", "assumed_collective_us": d["assumed_collective_us"].get(str(n_gpus)),
+            "basis": d["basis"]}
+
+
 def profiled_traffic(kernel, batch, config):
     """HBM bytes per launch from the FETCH_SIZE / WRITE_SIZE passes, corrected per
     MI355X_MICROARCH.md."""
@@ -217,6 +234,10 @@ def main():
     ap.add_argument("--leg-timeout", type=float, default=240.0,
                     help="N>1: seconds the extra legs (site_sharded / grid / rccl_ranks) may take before the "
                          "line is printed without them")
+    ap.add_argument("--one-rank-shard-legs", action="store_true",
+                    help="with RDAMD_BENCH_PG=1 on ONE rank: run the `site_sharded` leg anyway (a one-rank site group), so "
+                         "that the code the N > 1 line runs on real links -- the library's communicator in both sum "
+                         "modes, the bare collective's latency -- is exercised on a one-GPU box (tests/test_gpu_bench.py)")
     ap.add_argument("--no-shard-legs", action="store_true",
                     help="N>1 without --shard: skip the extra `site_sharded` / `grid` objects (the same "
                          "workload site-sharded with the all-reduce of the per-block lnLs)")
@@ -651,20 +672,65 @@ def main():
         tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if host_collectives else "cuda")
         tdist.all_reduce(tt, op=tdist.ReduceOp.MAX)
         dt = float(tt.item())
+        lnl_check_default = float(rows[:, :nb].sum().item())
+        if pipe2 is not None:
+            Pipeline.check(rows)
+
+        def timed_loop():
+            sync()
+            t0_ = time.perf_counter()
+            for s2_ in range(args.warmup, args.warmup + args.steps):
+                one(s2_)
+            sync()
+            t2_ = torch.tensor([time.perf_counter() - t0_], dtype=torch.float64, device="cpu" if host_collectives else "cuda")
+            tdist.all_reduce(t2_, op=tdist.ReduceOp.MAX)
+            return float(t2_.item())
+
+        # The site group's sum, BOTH ways (csrc/comm.cpp): the default is ncclAllGather + a sum in rank
+        # order (identical bits on every rank by construction), the alternative one ncclAllReduce.  The
+        # timed loop above ran the default; here the same loop with the all-reduce, and the bare
+        # collective of nb + 1 doubles back to back in each mode -- the latency the rounds of a
+        # lock-stepped search pay once each.
+        modes = {}
+        if pipe2 is not None and pipe2.comm is not None:
+            first = lnl_check_default
+            lat = {}
+            probe = torch.zeros(nb + 1, dtype=torch.float64, device="cuda")
+            for name, mode_id in (("gather", rd.COMM_SUM_GATHER), ("allreduce", rd.COMM_SUM_ALLREDUCE)):
+                pipe2.comm.set_sum_mode(mode_id)
+                for rep in range(2):
+                    sync()
+                    t0_ = time.perf_counter()
+                    for _ in range(200 if rep else 20):
+                        pipe2.comm.allreduce_sum(C.c_void_p(probe.data_ptr()), nb + 1, pipe2.stream)
+                    p2.sync()
+                    lat[name] = round((time.perf_counter() - t0_) / 200 * 1e6, 2)
+            pipe2.comm.set_sum_mode(rd.COMM_SUM_ALLREDUCE)
+            dt_ar = timed_loop()
+            modes = {"sum_modes": {
+                "gather": {"value": round(args.steps * nb * cg / dt, 2), "ms_per_step": round(dt / args.steps * 1e3, 4),
+                           "collective_us_back_to_back": lat["gather"]},
+                "allreduce": {"value": round(args.steps * nb * cg / dt_ar, 2), "ms_per_step": round(dt_ar / args.steps * 1e3, 4),
+                              "collective_us_back_to_back": lat["allreduce"],
+                              "lnl_check_equals_gather": float(rows[:, :nb].sum().item()) == first},
+                "note": "gather = ncclAllGather + rank-order sum kernel (the default: same bits on every rank by "
+                        "construction); allreduce = one ncclAllReduce"}}
+            pipe2.comm.set_sum_mode(rd.COMM_SUM_GATHER)
         out = {"value": round(args.steps * nb * cg / dt, 2), "unit": "evals/s",
-               "ms_per_step": round(dt / args.steps * 1e3, 4),
+               "ms_per_step": round(dt / args.steps * 1e3, 4), **modes,
                "scaling": "strong" if mode == "sites" else "weak",
                "sharding": ("site blocks of all candidates + all-reduce of the per-block lnLs" if mode == "sites"
                             else "%d candidate groups x %d site shards, all-reduce inside a group" % (cg, sg)),
                "sites_per_rank": hi - lo, "batch_per_step": nb,
                "collective": ("gloo (host), blocking batches" if host_collectives else
-                              "the library's RCCL communicator: ncclAllReduce(f64, sum) of %d values queued on the "
+                              "the library's RCCL communicator: ncclAllGather + rank-order sum of %d values queued on the "
                               "partition's stream behind each batch, two batches in flight" % (nb + 1)),
-               "lnl_check": float(rows[:, :nb].sum().item())}
-        if pipe2 is not None:
-            Pipeline.check(rows)
-            if pipe2.comm is not None:
-                pipe2.comm.destroy()
+               "lnl_check": lnl_check_default}
+        pred = predicted_for("site_sharded" if mode == "sites" else "grid", world, nb, args.config, args.sites is not None)
+        if pred:
+            out["predicted"] = pred
+        if pipe2 is not None and pipe2.comm is not None:
+            pipe2.comm.destroy()
         p2.destroy()
         return out
 
@@ -677,13 +743,27 @@ def main():
         # and the uncapped ratio is stated beside it -- as is, where counters exist for the
         # command, the rate of the bytes that really crossed HBM (`counter_gbs`, filled below)
         ratio = achieved / HBM_PEAK_GBS
-        capped = {"frac_uncapped": round(ratio, 4),
-                  "frac_note": "algorithmic bytes / time exceeds the nominal HBM peak: reads are forwarded "
-                               "on chip; frac capped at 1"} if ratio > 1.0 else {}
-        return {"kernel": clv_kernel, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(min(ratio, 1.0), 4), **capped, "traffic": None,
-                "bytes_per_launch": round(bytes_clv / max(launches, 1)),
-                "avg_launch_ms": round(ms / max(launches, 1), 5), "launches": launches}
+        out = {"kernel": clv_kernel, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+               "unit": "GB/s", "frac": round(ratio, 4), "frac_basis": "algorithmic bytes", "traffic": None,
+               "bytes_per_launch": round(bytes_clv / max(launches, 1)),
+               "avg_launch_ms": round(ms / max(launches, 1), 5), "launches": launches}
+        if ratio > 1.0:
+            # More algorithmic bytes per second than the HBM can move: the algorithm's READS never
+            # leave the chip (a child produced by the previous operation stays in registers, an older
+            # sibling in LDS).  A fraction of the HBM peak must then be made of bytes that cross HBM.
+            # Until the command's counters are attached below (`hbm counters`), that is the MODEL of
+            # the minimum: every computed CLV and scaler written once, the tip codes read once.
+            W = S * R * K * 8
+            modelled = ((n - 1) * (W + 4 * S) + n * S) * evals
+            mg = modelled / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+            out.update(frac=round(mg / HBM_PEAK_GBS, 4),
+                       frac_basis="modelled HBM bytes: every CLV and scaler written once, tip codes read once "
+                                  "(the reads the algorithm counts are forwarded on chip)",
+                       modelled_gbs=round(mg, 1),
+                       algorithmic_equiv={"rate_gbs": round(achieved, 1), "ratio_to_peak": round(ratio, 4),
+                                          "note": "SURVEY 8d's algorithmic bytes (every CLV written AND read once) / "
+                                                  "time: exceeds the HBM peak because the reads stay on chip"})
+        return out
 
     extra = {}
     if use_fused:
@@ -757,7 +837,12 @@ def main():
             sustained.update(kernel_avg_launch_ms=round(sms / max(sl, 1), 4),
                              achieved_tflops=round(stf, 2), frac=round(stf / FP64_PEAK_TFLOPS, 4))
             roofline["sustained"] = sustained
-        default_cmd = args.config == "c2" and nb == 197 and (repeats or K != 4) and world == 1
+        # the committed counters belong to ONE command (profiles/collect.sh: c2, batch 197, the whole
+        # alignment on one rank, the library's class limit): any option that changes the shape of the
+        # launches -- --sites, --shard, --as-candidate-group, --repeat-classes, --no-repeats -- gets none
+        default_cmd = (args.config == "c2" and nb == 197 and (repeats or K != 4) and world == 1 and
+                       args.sites is None and args.shard == "candidates" and args.as_candidate_group is None and
+                       args.repeat_classes is None and not args.one_rank_comm)
         try:
             if default_cmd:
                 roofline.update(profiled_issue(fused_kernel, nb, args.config))
@@ -796,6 +881,9 @@ def main():
                     gbs = extra["clv_kernel"]["traffic"] / (extra["clv_kernel"]["avg_launch_ms"] * 1e-3) / 1e9
                     extra["clv_kernel"]["counter_gbs"] = round(gbs, 1)
                     extra["clv_kernel"]["counter_frac"] = round(gbs / HBM_PEAK_GBS, 4)
+                    if "algorithmic_equiv" in extra["clv_kernel"]:   # (see clv_roofline)
+                        extra["clv_kernel"]["frac"] = extra["clv_kernel"]["counter_frac"]
+                        extra["clv_kernel"]["frac_basis"] = "hbm counters"
         except StaleProfile as e:
             if not args.allow_stale_profile:
                 raise SystemExit("bench.py: " + str(e))
@@ -833,6 +921,10 @@ def main():
         "roofline": roofline,
     }
     result.update(extra)
+    if args.shard == "candidates":
+        pred = predicted_for("value", world, nb, args.config, args.sites is not None)
+        if pred:
+            result["predicted"] = pred
 
     def gpu_eval(j):
         if not use_fused:
@@ -845,10 +937,20 @@ def main():
                                               gpu_eval, data_weights)
         ideal = result["cpu_baseline"].get("one_socket_ideal")
         if ideal and ideal["value"] > 0:
-            # north star: ">= 50 x the reference single-socket CPU".  The denominator is an
-            # idealised socket (perfect scaling over its physical cores) running the reference's
-            # configuration (site repeats): the speed-up over a real socket is at least this.
-            result["cpu_baseline"]["speedup_lower_bound"] = round(value / ideal["value"], 2)
+            # north star: ">= 50 x the reference single-socket CPU".  Two UPPER bounds on what one
+            # socket running the reference's configuration (site repeats) can do: perfect scaling
+            # of the one-thread rate over its physical cores (`one_socket_ideal`), and its DRAM
+            # bandwidth over the bytes the traversal must move (`one_socket_bandwidth_bound`).  A
+            # real socket is below both, so the speed-up over it is at least GPU / the smaller.
+            bound = ideal["value"]
+            bw = result["cpu_baseline"].get("one_socket_bandwidth_bound", {}).get("value")
+            result["cpu_baseline"]["speedup_vs_one_socket_ideal"] = round(value / ideal["value"], 2)
+            if bw and bw > 0:
+                result["cpu_baseline"]["speedup_vs_one_socket_bandwidth_bound"] = round(value / bw, 2)
+                bound = min(bound, bw)
+            result["cpu_baseline"]["speedup_lower_bound"] = round(value / bound, 2)
+            result["cpu_baseline"]["speedup_lower_bound_basis"] = (
+                "one_socket_bandwidth_bound" if bw and bw < ideal["value"] else "one_socket_ideal")
             result["cpu_baseline"]["speedup_vs_one_thread_with_repeats"] = round(
                 value / result["cpu_baseline"]["with_site_repeats"]["value"], 1)
 
@@ -871,7 +973,8 @@ def main():
     # line is about, and must never cost it: if a leg raises, its object says so; if the ranks do not
     # get through the legs within --leg-timeout seconds (a collective that never completes on this
     # fabric), every rank prints / leaves on its own -- rank 0 with the line as far as it got.
-    want_legs = use_pg and world > 1 and args.shard == "candidates" and use_fused and not args.no_shard_legs
+    want_legs = (use_pg and (world > 1 or args.one_rank_shard_legs) and args.shard == "candidates" and use_fused and
+                 not args.no_shard_legs)
     if use_pg and (want_legs or not host_collectives):
         def give_up():
             for key in ("site_sharded", "grid"):
@@ -957,6 +1060,35 @@ def host_load():
         q, per = read("/sys/fs/cgroup/cpu/cpu.cfs_quota_us"), read("/sys/fs/cgroup/cpu/cpu.cfs_period_us")
         out["cgroup_cpu_max"] = "%s %s" % (q, per) if q and per else None
     return out
+
+
+def socket_dram_bandwidth():
+    """Nominal DRAM bandwidth of ONE socket of this host in GB/s, from the CPU's model name
+    (memory channels x transfer rate x 8 bytes of the platform the model belongs to; the DIMMs
+    themselves are only visible to root: dmidecode).  -> (GB/s or None, how it was derived)"""
+    model = ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    import re
+    table = [   # (pattern on the model name, channels, MT/s, platform)
+        (r"EPYC 9\d\d5", 12, 6000, "AMD EPYC 9005 (SP5): 12 channels DDR5-6000"),
+        (r"EPYC 9\d\d4", 12, 4800, "AMD EPYC 9004 (SP5): 12 channels DDR5-4800"),
+        (r"EPYC 8\d\d4", 6, 4800, "AMD EPYC 8004 (SP6): 6 channels DDR5-4800"),
+        (r"EPYC 7\d\d[23]", 8, 3200, "AMD EPYC 7002 / 7003 (SP3): 8 channels DDR4-3200"),
+        (r"EPYC 7\d\d1", 8, 2666, "AMD EPYC 7001 (SP3): 8 channels DDR4-2666"),
+        (r"Xeon.*(Platinum|Gold) [86]5\d\d", 8, 5600, "Intel Xeon 5th gen: 8 channels DDR5-5600"),
+        (r"Xeon.*(Platinum|Gold) [86]4\d\d", 8, 4800, "Intel Xeon 4th gen: 8 channels DDR5-4800"),
+        (r"Xeon.*(Platinum|Gold) [86]3\d\d", 8, 3200, "Intel Xeon 3rd gen: 8 channels DDR4-3200"),
+    ]
+    for pat, ch, mts, what in table:
+        if re.search(pat, model):
+            return ch * mts * 8 / 1000.0, "nominal, %s (model name '%s'; dmidecode needs root)" % (what, model)
+    return None, "model name '%s' not in bench.py's table" % model
 
 
 def site_repeats_class_ratio(tree, seqs, samples=3):
@@ -1064,12 +1196,14 @@ def cpu_baseline(w, tree, cmap, freqs, n, S, K, R, params, roots, budget, gpu_ev
 
         if evaluate_rep(0) != evaluate(o, 0):
             raise SystemExit("oracle: the site-repeats traversal differs from the plain one")
+        b0 = q.repeats_bytes()
         t0 = time.perf_counter()
         k = 0
         while k < 2 or (time.perf_counter() - t0 < 0.2 * budget and k < 64):
             evaluate_rep(k % len(scheds))
             k += 1
         rep_rate = k / (time.perf_counter() - t0)
+        rep_bytes = [(b1 - b0_) / k for b0_, b1 in zip(b0, q.repeats_bytes())]   # per evaluation
         out["with_site_repeats"] = {
             "value": round(rep_rate, 4), "unit": "evals/s", "cores": 1,
             "class_ratio": round(q.repeats_ratio(), 4),
@@ -1085,6 +1219,24 @@ def cpu_baseline(w, tree, cmap, freqs, n, S, K, R, params, roots, budget, gpu_ev
         out["one_socket_ideal"] = {"value": round(rep_rate * per_socket, 3), "unit": "evals/s",
                                    "cores": per_socket,
                                    "note": "with_site_repeats x the physical cores of one socket of this host"}
+        # ... and what bounds a REAL socket: its DRAM bandwidth.  The oracle counts the bytes its
+        # repeats traversal moves (orc_repeats_bytes): class CLVs, scalers and class arrays WRITTEN,
+        # plus what must be READ at least once (the children's class arrays, every class CLV of an
+        # inner child once) -- no write-allocate traffic, no child class read twice: the least a
+        # cache hierarchy far smaller than the working set (c2: 99 nodes x up to 6.4 MB per
+        # candidate and core) can get away with.  Bandwidth / those bytes is an UPPER bound on the
+        # socket's rate however many cores it has.
+        moved = rep_bytes[0] + rep_bytes[1]
+        nominal, how = socket_dram_bandwidth()
+        bb = {"unit": "evals/s", "cores": per_socket,
+              "bytes_per_evaluation": {"written": round(rep_bytes[0]), "read_at_least_once": round(rep_bytes[1]),
+                                       "moved": round(moved), "read_if_nothing_is_cached": round(rep_bytes[2])},
+              "note": "one socket's DRAM bandwidth / the bytes coraxlib's site-repeats traversal cannot avoid moving "
+                      "per evaluation (counted by the oracle: orc_repeats_bytes; no write-allocate, every child class "
+                      "read once): an upper bound on the socket's rate"}
+        if nominal:
+            bb.update(value=round(nominal * 1e9 / moved, 3), bandwidth_gbs=round(nominal, 1), bandwidth_source=how)
+        out["one_socket_bandwidth_bound"] = bb
         # (the census by another route: distinct tip patterns below every node)
         out["site_repeats_class_ratio"] = site_repeats_class_ratio(tree, w["seqs"])
         out["site_repeats_note"] = ("the reference sets CORAX_ATTRIB_SITE_REPEATS for 4-state data; `value` is the "
@@ -1113,6 +1265,25 @@ def cpu_baseline(w, tree, cmap, freqs, n, S, K, R, params, roots, budget, gpu_ev
         except (ValueError, IndexError, ZeroDivisionError):
             quota = None
     threads = int(max(1, min(len(socket0), quota or len(socket0), 0.4 * avail // per_part, len(scheds))))
+    if "one_socket_bandwidth_bound" in out:
+        # STREAM triad on the cores this process may use (pinned, first touch, 64 MB per array and
+        # thread): what the memory system gives THIS slice of the host -- beside the nominal figure,
+        # and the bound's bandwidth where the CPU model is not in the table (scaled to the socket's
+        # cores: generous, a socket saturates long before its last core)
+        from oracle_lib import stream_triad
+        tt = int(max(1, min(len(socket0), quota or len(socket0))))
+        gbs = stream_triad(socket0[:tt], 1 << 23, min(1.5, 0.1 * budget))
+        bb = out["one_socket_bandwidth_bound"]
+        bb["stream_triad"] = {"gbs": round(gbs, 1), "threads": tt,
+                              "note": "a[i] = b[i] + s c[i], 24 bytes per element, one pinned thread per physical core "
+                                      "of socket 0 the cgroup quota allows"}
+        moved = bb["bytes_per_evaluation"]["moved"]
+        bb["value_at_measured_triad"] = round(gbs * 1e9 / moved, 3)
+        if "value" not in bb:
+            scaled = gbs * per_socket / tt
+            bb.update(value=round(scaled * 1e9 / moved, 3), bandwidth_gbs=round(scaled, 1),
+                      bandwidth_source="STREAM triad of %d threads x (%d cores per socket / %d): %s"
+                                       % (tt, per_socket, tt, socket_dram_bandwidth()[1]))
     if threads > 1:
         counts = [0] * threads
         window = max(0.4 * budget, 2.0 / max(out["value"], 1e-9))

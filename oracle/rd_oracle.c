@@ -1,3 +1,4 @@
+#define _GNU_SOURCE   /* (pthread_setaffinity_np, CPU_SET: the STREAM triad at the end) */
 /*
  * rd_oracle.c -- CPU ORACLE (test infrastructure, NOT product code).
  * See rd_oracle.h for status ("parity unpinned" vs coraxlib absolute lnL;
@@ -507,6 +508,11 @@ struct orc_repeats {
   double      **tipclv;        /* [tips] per-class tip CLVs [n][R][K] */
   unsigned int *lookup;        /* ORC_REPEATS_LOOKUP_SIZE entries, all 0 between calls */
   unsigned long long class_ops, plain_ops;   /* classes computed / columns a plain loop would have */
+  /* memory the traversal moves (orc_repeats_bytes): what it WRITES (the parent's class CLVs and
+   * scalers, its column -> class array, the two class -> child-class arrays); what it MUST read at
+   * least once (the children's column -> class arrays, every class CLV of an inner child once);
+   * what it reads if no child class is ever found in a cache (two child CLVs per parent class) */
+  unsigned long long bytes_written, bytes_read_once, bytes_read_every;
 };
 
 static void orc_repeats_free(orc_partition_t *p) {
@@ -602,6 +608,14 @@ static void update_one_repeats(orc_partition_t *p, struct orc_repeats *r, const 
   const size_t span = (size_t)R * K;
   r->class_ops += pn->n;
   r->plain_ops += p->sites;
+  {
+    const unsigned long long clv_b = (unsigned long long)R * K * sizeof(double), S_ = p->sites;
+    const unsigned long long n1 = op->child1_clv_index < p->tips ? 0 : r->node[op->child1_clv_index].n;
+    const unsigned long long n2 = op->child2_clv_index < p->tips ? 0 : r->node[op->child2_clv_index].n;
+    r->bytes_written += pn->n * (clv_b + (psc ? 4u : 0u) + 8u) + 4u * S_;
+    r->bytes_read_once += 8u * S_ + (n1 + n2) * (clv_b + 4u);
+    r->bytes_read_every += 8u * S_ + (unsigned long long)pn->n * 2u * (clv_b + 4u);
+  }
 #if defined(__AVX2__)
   if (avx2 && K == 4) {
     __m256d *lcol = (__m256d *)aligned_alloc(32, sizeof(__m256d) * 8 * R);
@@ -704,6 +718,14 @@ double orc_compute_root_loglikelihood_repeats(orc_partition_t *p, unsigned int c
   return logl;
 }
 
+/* bytes the site-repeats traversals have moved since the partition was created:
+ * out[0] written, out[1] read at least once (compulsory), out[2] read if nothing is ever cached */
+void orc_repeats_bytes(const orc_partition_t *p, double out[3]) {
+  out[0] = p->rep ? (double)p->rep->bytes_written : 0.0;
+  out[1] = p->rep ? (double)p->rep->bytes_read_once : 0.0;
+  out[2] = p->rep ? (double)p->rep->bytes_read_every : 0.0;
+}
+
 /* classes computed / columns a plain loop would have computed, since the partition was created */
 double orc_repeats_ratio(const orc_partition_t *p) {
   return p->rep && p->rep->plain_ops ? (double)p->rep->class_ops / (double)p->rep->plain_ops : 1.0;
@@ -746,3 +768,71 @@ const double *orc_get_pmatrix(const orc_partition_t *p, unsigned int i) { return
 unsigned int orc_states(const orc_partition_t *p) { return p->states; }
 unsigned int orc_rate_cats(const orc_partition_t *p) { return p->rate_cats; }
 unsigned int orc_sites(const orc_partition_t *p) { return p->sites; }
+
+/* ---- STREAM triad on the host's cores (bench.py: cpu_baseline.one_socket_bandwidth_bound) ----
+ * a[i] = b[i] + s * c[i] over three arrays of `doubles` elements per thread, each thread pinned to
+ * cpus[t] (if cpus is not NULL) and touching its own arrays first; all threads run for `seconds`
+ * between two barriers.  Returns GB/s by STREAM's count (24 bytes per element: two reads and a
+ * write; the write-allocate read is not counted), summed over the threads. */
+#include <pthread.h>
+#include <sched.h>
+#include <time.h>
+struct orc_triad_arg {
+  int cpu;
+  size_t n;
+  double seconds, *a, *b, *c;
+  unsigned long long passes;
+  double elapsed;
+  pthread_barrier_t *bar;
+};
+static double orc_now(void) {
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+static void *orc_triad_thread(void *arg_) {
+  struct orc_triad_arg *x = (struct orc_triad_arg *)arg_;
+  if (x->cpu >= 0) {
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    CPU_SET(x->cpu, &set);
+    (void)pthread_setaffinity_np(pthread_self(), sizeof set, &set);
+  }
+  x->a = (double *)aligned_alloc(64, x->n * sizeof(double));
+  x->b = (double *)aligned_alloc(64, x->n * sizeof(double));
+  x->c = (double *)aligned_alloc(64, x->n * sizeof(double));
+  if (!x->a || !x->b || !x->c) { x->passes = 0; pthread_barrier_wait(x->bar); return NULL; }
+  for (size_t i = 0; i < x->n; ++i) { x->a[i] = 0.0; x->b[i] = 1.0; x->c[i] = 2.0; }
+  pthread_barrier_wait(x->bar);
+  const double t0 = orc_now();
+  double s = 3.0;
+  do {
+    double *restrict a = x->a;
+    const double *restrict b = x->b, *restrict c = x->c;
+    for (size_t i = 0; i < x->n; ++i) a[i] = b[i] + s * c[i];
+    s += 1e-9 * a[x->n / 2];   /* (a dependence the compiler cannot drop) */
+    ++x->passes;
+    x->elapsed = orc_now() - t0;
+  } while (x->elapsed < x->seconds);
+  free(x->a); free(x->b); free(x->c);
+  return NULL;
+}
+double orc_stream_triad(int threads, const int *cpus, size_t doubles, double seconds) {
+  if (threads < 1 || threads > 1024) return 0.0;
+  pthread_t th[1024];
+  struct orc_triad_arg arg[1024];
+  pthread_barrier_t bar;
+  pthread_barrier_init(&bar, NULL, (unsigned)threads);
+  for (int t = 0; t < threads; ++t) {
+    arg[t].cpu = cpus ? cpus[t] : -1; arg[t].n = doubles; arg[t].seconds = seconds;
+    arg[t].passes = 0; arg[t].elapsed = 0.0; arg[t].bar = &bar;
+    pthread_create(&th[t], NULL, orc_triad_thread, &arg[t]);
+  }
+  double gbs = 0.0;
+  for (int t = 0; t < threads; ++t) {
+    pthread_join(th[t], NULL);
+    if (arg[t].elapsed > 0.0) gbs += 24.0 * (double)doubles * (double)arg[t].passes / arg[t].elapsed / 1e9;
+  }
+  pthread_barrier_destroy(&bar);
+  return gbs;
+}

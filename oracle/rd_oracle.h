@@ -25,6 +25,7 @@
 #ifndef RD_ORACLE_H_
 #define RD_ORACLE_H_
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -115,6 +116,13 @@ double orc_compute_root_loglikelihood_repeats(orc_partition_t *p, unsigned int c
                                               const unsigned int *freqs_indices);
 /* classes computed / columns a plain loop would have computed so far (1.0: no repeats found) */
 double orc_repeats_ratio(const orc_partition_t *p);
+/* bytes the site-repeats traversals of this partition have moved so far: out[0] written (class
+ * CLVs, scalers, class arrays), out[1] read at least once (compulsory: the children's class arrays,
+ * every class CLV of an inner child once), out[2] read when no child class is found in a cache */
+void orc_repeats_bytes(const orc_partition_t *p, double out[3]);
+/* STREAM triad over `threads` pinned threads (cpus may be NULL), `doubles` elements per array and
+ * thread, for `seconds`: aggregate GB/s by STREAM's count (24 bytes per element) */
+double orc_stream_triad(int threads, const int *cpus, size_t doubles, double seconds);
 
 /* raw views for parity tests */
 const double       *orc_get_clv(const orc_partition_t *p, unsigned int idx);

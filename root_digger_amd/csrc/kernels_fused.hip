@@ -129,9 +129,18 @@ __device__ __forceinline__ void read_row(unsigned off, double (&t)[4]) {
 }
 // the class / tip code of a site, stored as the LDS byte offset of its table row: a byte
 // (code x 16 <= 240) in the arena of 16-row launches, 16 bits where tables have 64 rows
+#if defined(RDAMD_ABLATION) && defined(RDAMD_ABL_CODES8)
+// timing only (profiles/r6_codes8_ab.txt): what 8-bit codes in a 64-row launch could buy at most --
+// every code is ONE byte at a byte stride (half the arena lines per rate pass); the byte that
+// arrives is not the code, its upper four bits are a valid row offset
+constexpr bool kAblCodes8 = true;
+#else
+constexpr bool kAblCodes8 = false;
+#endif
 template <int TR>
 __device__ __forceinline__ unsigned load_code(__amdgpu_buffer_rsrc_t rs, int voff, int soff) {
   if constexpr (TR == 16) return (unsigned)__builtin_amdgcn_raw_buffer_load_b8(rs, voff, soff, 0);
+  else if constexpr (kAblCodes8) return (unsigned)__builtin_amdgcn_raw_buffer_load_b8(rs, voff, soff, 0) & 0xF0u;
   else return (unsigned)__builtin_amdgcn_raw_buffer_load_b16(rs, voff, soff, 0);
 }
 
@@ -302,6 +311,75 @@ __device__ __forceinline__ void stack_pop_wait(f64x2_t (&lo)[NS], f64x2_t (&hi)[
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(lo[0]), "+v"(hi[0]), "+v"(sc[0])::"memory");
 }
 
+// RDAMD_ABL_STAMPS (ablation builds only, profiles/step_timeline.py): WHERE INSIDE A STEP A WAVE WAITS.
+// A few waves of one job (rdamd_abl_stamps_config: job, every stride-th workgroup) read the shader
+// clock (s_memtime) at the phase boundaries of every step and leave the five readings per step in
+// `rdamd_stamp_buf`; every wave executes the reads (the instrument is the same for all of them),
+// only the chosen ones store.  A scheduling barrier on both sides of a reading keeps the compiler
+// from moving a phase's instructions across it.
+//   0 top of the step | 1 the operand tables have landed (vmcnt(0); tip-tip and running x tip
+//   steps) | 2 the table rows have come back from LDS and the next step's codes / tables / descriptor
+//   are requested | 3 the matrix-vector product(s) issued | 4 the step's last instruction issued
+#if defined(RDAMD_ABLATION) && defined(RDAMD_ABL_STAMPS)
+constexpr unsigned kStampWaves = 64, kStampSteps = 4096;
+__device__ unsigned long long rdamd_stamp_buf[kStampWaves][kStampSteps][4];   // [t0 | t1 t2 | t3 t4 | kind rate]
+__device__ unsigned rdamd_stamp_cfg[2] = {0xffffffffu, 1u};   // job, workgroup stride
+// (registers: the evaluator has 125 of the 128 VGPRs four waves per SIMD allow and no free SGPR.
+// The readings keep their low words only -- a step is far shorter than 2^32 ticks --, and the one
+// lane that stores them does so inside one asm statement with EXEC = 1: two scratch VGPRs, live
+// only there)
+// RDAMD_ABL_STAMPS is a MASK of the readings that are taken (31: all five): a reading waits for
+// its own value -- and with it for every scalar load and LDS read in flight --, so builds with
+// fewer readings cross-check what the full set says about a phase.
+#define RDAMD_STAMP(k)                                                                          \
+  if ((RDAMD_ABL_STAMPS >> (k)) & 1) {                                                          \
+    __builtin_amdgcn_sched_barrier(0);                                                          \
+    tstamp[k] = __builtin_readcyclecounter();   /* (64 bits, untouched until the store: no wait here) */ \
+    __builtin_amdgcn_sched_barrier(0);                                                          \
+  }
+#define RDAMD_STAMP_STORE(kind)                                                                 \
+  if (stamped) {                                                                                \
+    if (stamp_step < kStampSteps) {                                                             \
+      unsigned long long *rec_ = &rdamd_stamp_buf[stamp_slot][stamp_step][0];                   \
+      unsigned d0_, d1_, z_;                                                                    \
+      unsigned long long sv_;                                                                   \
+      asm volatile(                                                                             \
+          "s_mov_b64 %[sv], exec\n\t"                                                           \
+          "s_mov_b64 exec, 1\n\t"                                                               \
+          "v_mov_b32 %[z], 0\n\t"                                                               \
+          "v_mov_b32 %[d0], %[t0]\n\t"                                                          \
+          "v_mov_b32 %[d1], %[th]\n\t"                                                          \
+          "global_store_dword %[z], %[d0], %[rec]\n\t"                                          \
+          "global_store_dword %[z], %[d1], %[rec] offset:4\n\t"                                 \
+          "s_nop 1\n\t"                                                                         \
+          "v_mov_b32 %[d0], %[t1]\n\t"                                                          \
+          "v_mov_b32 %[d1], %[t2]\n\t"                                                          \
+          "global_store_dword %[z], %[d0], %[rec] offset:8\n\t"                                 \
+          "global_store_dword %[z], %[d1], %[rec] offset:12\n\t"                                \
+          "s_nop 1\n\t"                                                                         \
+          "v_mov_b32 %[d0], %[t3]\n\t"                                                          \
+          "v_mov_b32 %[d1], %[t4]\n\t"                                                          \
+          "global_store_dword %[z], %[d0], %[rec] offset:16\n\t"                                \
+          "global_store_dword %[z], %[d1], %[rec] offset:20\n\t"                                \
+          "s_nop 1\n\t"                                                                         \
+          "v_mov_b32 %[d0], %[kd]\n\t"                                                          \
+          "v_mov_b32 %[d1], %[rr]\n\t"                                                          \
+          "global_store_dword %[z], %[d0], %[rec] offset:24\n\t"                                \
+          "global_store_dword %[z], %[d1], %[rec] offset:28\n\t"                                \
+          "s_mov_b64 exec, %[sv]"                                                                \
+          : [d0] "=&v"(d0_), [d1] "=&v"(d1_), [z] "=&v"(z_), [sv] "=&s"(sv_)                     \
+          : [rec] "s"(rec_), [t0] "s"((unsigned)tstamp[0]), [th] "s"((unsigned)(tstamp[0] >> 32)),       \
+            [t1] "s"((unsigned)tstamp[1]), [t2] "s"((unsigned)tstamp[2]),                       \
+            [t3] "s"((unsigned)tstamp[3]), [t4] "s"((unsigned)tstamp[4]), [kd] "s"(kind), [rr] "s"(r) \
+          : "memory");                                                                          \
+    }                                                                                           \
+    ++stamp_step;                                                                               \
+  }
+#else
+#define RDAMD_STAMP(k)
+#define RDAMD_STAMP_STORE(kind)
+#endif
+
 // SP ("spill levels"): the LDS stack is what limits the resident waves once a program needs
 // two levels of it (13.2 KB per two-sites wave: 12 waves per CU instead of 16 -- and with
 // every wave waiting on its own dependent chain, throughput follows the wave count: c5 and
@@ -401,7 +479,7 @@ fused_dna_eval_kernel(FusedArgs a) {
   constexpr unsigned kYSlot = 32u * TR;   // the X / Y table slots sit at LDS bytes 0 and 32 TR
   int site_off[NS];
 #pragma unroll
-  for (int q = 0; q < NS; ++q) site_off[q] = (int)site[q] * (TR == 16 ? 1 : 2);
+  for (int q = 0; q < NS; ++q) site_off[q] = (int)site[q] * (TR == 16 || kAblCodes8 ? 1 : 2);
   // LDS: the table slots of all waves first, then each wave's stack
   const unsigned n_waves = RW ? R : 1u;
   double *my_stack = lds + n_waves * tab_doubles<TR>() + (size_t)wave * lds_levels * NS * 288;
@@ -416,6 +494,14 @@ fused_dna_eval_kernel(FusedArgs a) {
 
   double term[NS];   // sum_r w_r f_r 2^(-256 (s_r - smin))
   int smin[NS];
+#if defined(RDAMD_ABLATION) && defined(RDAMD_ABL_STAMPS)
+  const unsigned stamp_stride = uni(to_const(rdamd_stamp_cfg)[1]);
+  const bool stamped = uni(to_const(rdamd_stamp_cfg)[0]) == job && stamp_stride && bx % stamp_stride == 0 &&
+                       bx / stamp_stride < kStampWaves;
+  const unsigned stamp_slot = stamped ? bx / stamp_stride : 0u;
+  unsigned stamp_step = 0;
+  unsigned long long tstamp[5] = {0, 0, 0, 0, 0};
+#endif
 
   for (unsigned r = RW ? wave : 0u; r < (RW ? wave + 1u : R); ++r) {
     LaneState<NS> st;
@@ -543,7 +629,7 @@ fused_dna_eval_kernel(FusedArgs a) {
   }
 #if !(defined(RDAMD_ABLATION) && defined(RDAMD_ABL_ONE_TABLOAD))
 #define RDAMD_LOAD_TABS(op, ex, ey) \
-  if (TR > 16) __builtin_amdgcn_s_waitcnt(0xc07f);   /* lgkmcnt(0) */                           \
+  if (TR > 16) { __builtin_amdgcn_s_waitcnt(0xc07f);   /* lgkmcnt(0) */ RDAMD_WARM_M(op) }  \
   RDAMD_LOAD_TAB(op, 0u, 0x2000u, tX, ex, "s_cmp_lg_u32 %[kind], 0")       /* X: tip-tip steps only */ \
   RDAMD_LOAD_TAB(op, kYSlot, 0x4000u, tY, ey, "s_cmp_eq_u32 %[kind], 2")   /* Y: not when the step pops */
 #else
@@ -555,21 +641,52 @@ fused_dna_eval_kernel(FusedArgs a) {
     RDAMD_LOAD_TAB16(op, tX, ex) RDAMD_LOAD_TAB16(op, tY, ey)                                   \
   }
 #endif
-#define RDAMD_LOAD_TIPS(op, cx, cy, ex, ey)                                                     \
+#define RDAMD_LOAD_TIPS_NOW(op, cx, cy, ex, ey)                                                 \
   _Pragma("unroll") for (int q = 0; q < NS; ++q) {                                              \
     cx[q] = load_code<TR>(tips_rs, site_off[q], (int)uni(op.cX)) | wbase;                       \
     cy[q] = load_code<TR>(tips_rs, site_off[q], (int)uni(op.cY)) | wbase;                       \
   }                                                                                             \
   RDAMD_LOAD_TABS(op, ex, ey)
+#if defined(RDAMD_ABLATION) && defined(RDAMD_ABL_NOTIPS)
+    // timing only: the codes and tables of the program's FIRST operation serve every step -- no code
+    // load, no table DMA inside the loop: what the step costs when nothing it waits for comes from
+    // memory (the LDS row reads and the matrix's scalar load stay)
+#define RDAMD_LOAD_TIPS(op, cx, cy, ex, ey)                                                     \
+  _Pragma("unroll") for (int q = 0; q < NS; ++q) { cx[q] = cxA[q] | cxB[q]; cy[q] = cyA[q] | cyB[q]; } \
+  if (TR > 16) __builtin_amdgcn_s_waitcnt(0xc07f);
+#else
+#define RDAMD_LOAD_TIPS(op, cx, cy, ex, ey) RDAMD_LOAD_TIPS_NOW(op, cx, cy, ex, ey)
+#endif
     // (TR = 64: the descriptor of the operation after next only now -- fetched at the top of
     // the step it would sit in front of the wait above)
 #define RDAMD_LATE_DESC(cur, idx2) if (TR > 16) cur = load_const(prog + (idx2));
     // the ONE matrix an operation applies to the running CLV, into SGPRs
+#if defined(RDAMD_ABLATION) && defined(RDAMD_ABL_MSAME)   /* timing only: every matrix load hits the scalar cache */
+#define RDAMD_M_OFFSET(op) 0u
+#else
+#define RDAMD_M_OFFSET(op) uni(op.pM)
+#endif
 #define RDAMD_LOAD_M(op, M)                                                                     \
   {                                                                                             \
-    const const_as<double> pp = (const_as<double>)(pm + uni(op.pM) + roff);                     \
+    const const_as<double> pp = (const_as<double>)(pm + RDAMD_M_OFFSET(op) + roff);             \
     _Pragma("unroll") for (int k = 0; k < 16; ++k) M[k] = pp[k];                                \
   }
+    // WARM: the 128 bytes of the NEXT operation's matrix are touched (two dword loads) as soon as
+    // its descriptor is known to have arrived -- behind the step's one lgkmcnt(0) wait --, so that
+    // the 16-double load behind the matrix-vector product finds them in the scalar cache instead of
+    // in L2.  The loads land in s101: the register allocator never hands out s100 / s101 on gfx9
+    // (its limit is 100 SGPRs beside VCC; "reserved registers" to an asm clobber list) while the
+    // wave's allocation (100 + 6 rounded up to 112) holds them -- a sink that nothing else reads
+    // or writes, so no live range has to cover the loads' flight.
+#if defined(RDAMD_ABLATION) && defined(RDAMD_ABL_WARM_M)
+#define RDAMD_WARM_M(op)                                                                        \
+  if (TR > 16) {                                                                                \
+    asm volatile("s_load_dword s101, %0, 0x0\n\ts_load_dword s101, %0, 0x40"                    \
+                 :: "s"(pm + uni(op.pM) + roff) : "memory");                                    \
+  }
+#else
+#define RDAMD_WARM_M(op)
+#endif
 
     // one traversal step: `cur`/c?/e?/M hold op i (all arrived), `nxt` is the
     // descriptor of op i+1 whose tip data and matrix are fetched into
@@ -578,6 +695,7 @@ fused_dna_eval_kernel(FusedArgs a) {
 #define RDAMD_STEP(cur, nxt, cx, cy, ex, ey, ncx, ncy, nex, ney, idx2)                          \
   {                                                                                             \
     const unsigned kind = uni(cur.flags);                                                       \
+    RDAMD_STAMP(0)                                                                              \
     if (TR == 16) cur = load_const(prog + (idx2));                                              \
     unsigned rowx[NS], rowy[NS];   /* byte offsets of the rows inside the X / Y table = the codes */ \
     _Pragma("unroll") for (int q = 0; q < NS; ++q) { rowx[q] = cx[q]; rowy[q] = cy[q]; }        \
@@ -590,8 +708,10 @@ fused_dna_eval_kernel(FusedArgs a) {
       } else {   /* the tables came by DMA: the compiler does not order the reads below behind it */ \
         __builtin_amdgcn_s_waitcnt(0x0f70);   /* vmcnt(0) */                                    \
       }                                                                                         \
+      RDAMD_STAMP(1)                                                                            \
       _Pragma("unroll") for (int q = 0; q < NS; ++q) { read_row<0, TR>(rowx[q], tx[q]); read_row<kYSlot, TR>(rowy[q], ty[q]); } \
       RDAMD_LOAD_TIPS(nxt, ncx, ncy, nex, ney) RDAMD_LATE_DESC(cur, idx2)                       \
+      RDAMD_STAMP(2)                                                                            \
       if (kind & 0x100u) { /* park M . (running CLV) for the later inner-inner node */          \
         if (kind & 0x200u) { /* stack level 0 lives in registers: the product lands there */    \
           _Pragma("unroll") for (int q = 0; q < NS; ++q) {                                      \
@@ -619,6 +739,7 @@ fused_dna_eval_kernel(FusedArgs a) {
           if (SP == 0 || !(kind & 0x20000u)) ++sp;   /* (SP > 0: the private segment's entries) */ \
         }                                                                                       \
       }                                                                                         \
+      RDAMD_STAMP(3)                                                                            \
       RDAMD_LOAD_M(nxt, M)                                                                      \
       _Pragma("unroll") for (int q = 0; q < NS; ++q) {                                          \
         st.sc[q] = 0;                                                                           \
@@ -628,21 +749,30 @@ fused_dna_eval_kernel(FusedArgs a) {
     } else if (k3 == kFusedRT) {                                                                \
       if (TR == 16) ((lds_f64_ptr)(size_t)tab_wr)[4 * TR] = ey;                                 \
       else __builtin_amdgcn_s_waitcnt(0x0f70);   /* vmcnt(0): the table came by DMA */          \
+      RDAMD_STAMP(1)                                                                            \
       _Pragma("unroll") for (int q = 0; q < NS; ++q) read_row<kYSlot, TR>(rowy[q], ty[q]);      \
       RDAMD_LOAD_TIPS(nxt, ncx, ncy, nex, ney) RDAMD_LATE_DESC(cur, idx2)                       \
+      RDAMD_STAMP(2)                                                                            \
       _Pragma("unroll") for (int q = 0; q < NS; ++q) matvec(M, st.v[q], tx[q]);                 \
+      RDAMD_STAMP(3)                                                                            \
       RDAMD_LOAD_M(nxt, M)                                                                      \
       combine_sites<NS, kTestRT>(tx, ty, st.v, st.sc);                                          \
     } else { /* kFusedRP: running CLV times M, sibling already multiplied when parked */        \
       if (kind & 0x400u) { /* the sibling waits in the register slot: used in place */          \
+        RDAMD_STAMP(1)                                                                          \
         RDAMD_LOAD_TIPS(nxt, ncx, ncy, nex, ney) RDAMD_LATE_DESC(cur, idx2)                     \
+        RDAMD_STAMP(2)                                                                          \
         _Pragma("unroll") for (int q = 0; q < NS; ++q) matvec(M, st.v[q], tx[q]);               \
+        RDAMD_STAMP(3)                                                                          \
         RDAMD_LOAD_M(nxt, M)                                                                    \
         _Pragma("unroll") for (int q = 0; q < NS; ++q) st.sc[q] += s0sc[q];                     \
         combine_sites<NS, kTestRP>(tx, s0, st.v, st.sc);                                                 \
       } else if (RL >= 2 && (kind & 0x1000u)) {                                                 \
+        RDAMD_STAMP(1)                                                                          \
         RDAMD_LOAD_TIPS(nxt, ncx, ncy, nex, ney) RDAMD_LATE_DESC(cur, idx2)                     \
+        RDAMD_STAMP(2)                                                                          \
         _Pragma("unroll") for (int q = 0; q < NS; ++q) matvec(M, st.v[q], tx[q]);               \
+        RDAMD_STAMP(3)                                                                          \
         RDAMD_LOAD_M(nxt, M)                                                                    \
         _Pragma("unroll") for (int q = 0; q < NS; ++q) st.sc[q] += s1sc[q];                     \
         combine_sites<NS, kTestRP>(tx, s1, st.v, st.sc);                                                 \
@@ -660,8 +790,11 @@ fused_dna_eval_kernel(FusedArgs a) {
             scy[q] = stk_sc[(sp * NS + q) * 64];                                                \
           }                                                                                     \
         }                                                                                       \
+        RDAMD_STAMP(1)                                                                          \
         RDAMD_LOAD_TIPS(nxt, ncx, ncy, nex, ney) RDAMD_LATE_DESC(cur, idx2)                     \
+        RDAMD_STAMP(2)                                                                          \
         _Pragma("unroll") for (int q = 0; q < NS; ++q) matvec(M, st.v[q], tx[q]);               \
+        RDAMD_STAMP(3)                                                                          \
         RDAMD_LOAD_M(nxt, M)                                                                    \
         if (SP > 0) {                                                                           \
           stack_pop_wait<NS>(plo, phi, scy);                                                    \
@@ -673,6 +806,8 @@ fused_dna_eval_kernel(FusedArgs a) {
         combine_sites<NS, kTestRP>(tx, ty, st.v, st.sc);                                        \
       }                                                                                         \
     }                                                                                           \
+    RDAMD_STAMP(4)                                                                              \
+    RDAMD_STAMP_STORE(kind)                                                                     \
     if (EXPORT && (kind & 0x18000u)) {   /* a child of the root operation: leave it behind */  \
       double *ec = (kind & 0x8000u) ? a.export_clv[0] : a.export_clv[1];                        \
       unsigned *en = (kind & 0x8000u) ? a.export_cnt[0] : a.export_cnt[1];                      \
@@ -708,7 +843,11 @@ fused_dna_eval_kernel(FusedArgs a) {
     double exA = 0.5, eyA = 0.25, exB = 0.5, eyB = 0.25;
 #pragma unroll
     for (int q = 0; q < NS; ++q) { cxA[q] = cxB[q] = 1; cyA[q] = cyB[q] = 2; }
-    RDAMD_LOAD_TIPS(dA, cxA, cyA, exA, eyA)
+    RDAMD_LOAD_TIPS_NOW(dA, cxA, cyA, exA, eyA)
+#if defined(RDAMD_ABLATION) && defined(RDAMD_ABL_NOTIPS)
+#pragma unroll
+    for (int q = 0; q < NS; ++q) { cxB[q] = cxA[q]; cyB[q] = cyA[q]; }
+#endif
     double M[16];
     RDAMD_LOAD_M(dA, M)
     unsigned i = 0;
@@ -1146,3 +1285,18 @@ hipError_t launch_fused_export(const FusedArgs &a, unsigned max_depth, unsigned 
 }
 
 }  // namespace rdamd
+
+#if defined(RDAMD_ABLATION) && defined(RDAMD_ABL_STAMPS)
+// profiles/step_timeline.py: which waves stamp, and their readings ([64][4096][8] u32; zeroed by _config)
+extern "C" int rdamd_abl_stamps_config(unsigned job, unsigned stride) {
+  const unsigned cfg[2] = {job, stride};
+  void *buf = nullptr;
+  if (hipGetSymbolAddress(&buf, HIP_SYMBOL(rdamd::rdamd_stamp_buf)) != hipSuccess) return 0;
+  if (hipMemset(buf, 0, sizeof(rdamd::rdamd_stamp_buf)) != hipSuccess) return 0;
+  return hipMemcpyToSymbol(HIP_SYMBOL(rdamd::rdamd_stamp_cfg), cfg, sizeof cfg) == hipSuccess;
+}
+extern "C" int rdamd_abl_stamps_read(unsigned long long *host) {
+  if (hipDeviceSynchronize() != hipSuccess) return 0;
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(rdamd::rdamd_stamp_buf), sizeof(rdamd::rdamd_stamp_buf)) == hipSuccess;
+}
+#endif

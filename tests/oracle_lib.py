@@ -46,6 +46,8 @@ _sig("orc_compute_root_loglikelihood", C.c_double, _vp, _u, C.c_int, _pu, _pd)
 _sig("orc_update_clvs_repeats", None, _vp, C.POINTER(OrcOperation), _u, C.c_int)
 _sig("orc_compute_root_loglikelihood_repeats", C.c_double, _vp, _u, C.c_int, _pu)
 _sig("orc_repeats_ratio", C.c_double, _vp)
+_sig("orc_repeats_bytes", None, _vp, C.POINTER(C.c_double))
+_sig("orc_stream_triad", C.c_double, C.c_int, C.POINTER(C.c_int), C.c_size_t, C.c_double)
 _sig("orc_get_clv", _pd, _vp, _u)
 _sig("orc_get_scaler", _pu, _vp, _u)
 _sig("orc_get_pmatrix", _pd, _vp, _u)
@@ -168,6 +170,13 @@ class OraclePartition:
         return olib.orc_compute_root_loglikelihood_repeats(self._h, clv_index, scaler_index,
                                                            fi.ctypes.data_as(_pu))
 
+    def repeats_bytes(self):
+        """-> (written, read at least once, read if nothing is cached): bytes moved by the
+        site-repeats traversals of this partition so far (orc_repeats_bytes)"""
+        out = (C.c_double * 3)()
+        olib.orc_repeats_bytes(self._h, out)
+        return float(out[0]), float(out[1]), float(out[2])
+
     def repeats_ratio(self):
         """classes computed / columns a plain loop would have computed so far"""
         return olib.orc_repeats_ratio(self._h)
@@ -225,3 +234,9 @@ class OraclePartition:
 
     def sync(self):
         pass
+
+
+def stream_triad(cpus, doubles=1 << 24, seconds=1.0):
+    """STREAM triad on one pinned thread per entry of `cpus` (orc_stream_triad): aggregate GB/s"""
+    arr = (C.c_int * len(cpus))(*cpus)
+    return float(olib.orc_stream_triad(len(cpus), arr, doubles, seconds))

@@ -219,7 +219,8 @@ def test_rounds_with_the_rccl_communicator_as_reducer(sequential_records, mode):
     m.set_lnl_reducer(comm.reducer, on_device=True, user=comm.handle)
     assert _search(m, 17) == sequential_records
     st = m.round_stats()
-    assert st["own_collectives"] == 0 and 0 < st["collectives"] <= st["rounds"]
+    # (the model's own one: the group's agreement on the number of candidates in flight)
+    assert st["own_collectives"] == 1 and 0 < st["collectives"] <= st["rounds"]
     # (two groups of 8 - 9 candidates, each as long as its longest one: 5.6 x fewer on this data)
     assert per_request > 3 * st["collectives"], (per_request, st)
     # a model that refuses rounds refuses the lock-stepped search when it is site-sharded

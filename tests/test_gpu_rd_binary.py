@@ -17,9 +17,14 @@ REF = os.path.join(ROOT, "oracle", "_ref", "liblbfgsb_ref.so")
 MSA, TREE = os.path.join(util.DATA, "10.fasta"), os.path.join(util.DATA, "10.tree")
 
 
-def test_native_front_end_matches_the_python_one(tmp_path):
+def test_native_front_end_matches_the_python_one(tmp_path, capsys):
+    """root_digger_amd.cli is a LAUNCHER of bin/rd_amd (argument pass-through + the rank
+    environment): the same records, the same trees, the same text on stdout -- and no search
+    driver of its own"""
     from root_digger_amd import cli
     assert os.path.exists(RD), "make -C root_digger_amd/csrc builds it"
+    src = open(cli.__file__).read()
+    assert len(src.splitlines()) < 80 and "exhaustive_search" not in src and "Model" not in src
     common = ["--msa", MSA, "--tree", TREE, "--exhaustive", "--silent", "--rate-cats", "4",
               "--atol", "1e-3", "--brtol", "1e-3", "--bfgstol", "1e-3", "--factor", "1e12",
               "--seed", "5"]
@@ -28,7 +33,9 @@ def test_native_front_end_matches_the_python_one(tmp_path):
     a, b = str(tmp_path / "native"), str(tmp_path / "python")
     out = subprocess.run([RD] + common + ["--prefix", a], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout + out.stderr
+    capsys.readouterr()
     assert cli.main(common + ["--prefix", b]) == 0
+    assert capsys.readouterr().out == out.stdout.replace(a, b)      # (relayed through sys.stdout)
     ra = sorted(rd.Checkpoint(a).read_results())
     rb = sorted(rd.Checkpoint(b).read_results())
     assert [r[:3] for r in ra] == [r[:3] for r in rb] and len(ra) == 17
@@ -36,6 +43,13 @@ def test_native_front_end_matches_the_python_one(tmp_path):
     assert open(a + ".rooted.tree").read() == open(b + ".rooted.tree").read()
     assert open(a + ".lwr.tree").read() == open(b + ".lwr.tree").read()
     assert out.stdout.strip().splitlines()[-1] == open(a + ".lwr.tree").read().strip()
+    # `--workers` is `--threads`; `--gpus 2`: the launcher starts two ranks with the rank environment
+    c = str(tmp_path / "two")
+    assert cli.main(common + ["--prefix", c, "--gpus", "2", "--device", "0", "--workers", "0", "--lockstep", "0"]) == 0
+    rc = sorted(rd.Checkpoint(c).read_results())
+    assert [r[0] for r in rc] == list(range(17))
+    for x, y in zip(rc, ra):
+        assert abs(x[1] - y[1]) <= 1e-6 * abs(y[1])
     # a rerun finds everything in the log
     again = subprocess.run([RD, "--msa", "x", "--tree", "y", "--prefix", a, "--silent"],
                            capture_output=True, text=True, timeout=600)

@@ -332,8 +332,24 @@ def test_site_repeats_traversal_is_bit_identical_to_the_plain_one():
             got = b.compute_root_loglikelihood_repeats(tree.root_clv_index(), tree.root_scaler_index())
             assert got == want, (K, i, got, want)
         assert 0.0 < b.repeats_ratio() <= 1.0
+        # the bytes the three traversals moved (bench.py: cpu_baseline.one_socket_bandwidth_bound):
+        # at most what a plain loop writes and reads, compulsory reads <= uncached reads, and
+        # the written CLV bytes follow the class ratio
+        written, once, every = b.repeats_bytes()
+        n_ops, clv = 3 * (tree.tip_count() - 1), R * K * 8
+        assert 0 < once <= every
+        assert written <= n_ops * S * (clv + 4 + 8 + 4) and every <= n_ops * S * (8 + 2 * (clv + 4))
+        assert abs(written - (b.repeats_ratio() * n_ops * S * (clv + 4 + 8) + 4 * n_ops * S)) <= 4 * b.repeats_ratio() * n_ops * S
         if tree is tree10:       # 1000 columns of 10 taxa: most subtrees see few distinct patterns
             assert b.repeats_ratio() < 0.5
         if K == 4 and w is None and tree is not tree10:
             # the caterpillar's first cherries fold, its deep nodes hold a class per column
             assert b.repeats_ratio() < 1.0
+
+
+def test_stream_triad_runs_on_the_hosts_cores():
+    """bench.py's measured memory bandwidth (cpu_baseline.one_socket_bandwidth_bound.stream_triad)"""
+    from oracle_lib import stream_triad
+    cpus = sorted(os.sched_getaffinity(0))[:2]
+    gbs = stream_triad(cpus, 1 << 20, 0.1)
+    assert 0.1 < gbs < 5000.0
