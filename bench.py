@@ -79,11 +79,11 @@ class StaleProfile(Exception):
 
 def profiled_summary(kernel, batch, config, key):
     """The committed counters of `kernel` (profiles/collect.sh + profiles/summarize.py:
-    separate rocprofv3 passes of the default command -- c2, batch 197; other shapes get
-    None).  They describe the kernel as it was when they were taken: the summary carries a
+    separate rocprofv3 passes of the default command -- c2, batch 197 -- and, for the 20-state
+    evaluator, of `--config c3`; other shapes get None).  They describe the kernel as it was when they were taken: the summary carries a
     digest of the kernel's sources (profiles/sources.py), and counters of a kernel that has
     changed since are REFUSED, not published."""
-    if config != "c2" or batch != 197:
+    if config not in ("c2", "c3") or batch != 197:
         return None, None
     import glob
     sys.path.insert(0, os.path.join(ROOT, "profiles"))
@@ -93,7 +93,8 @@ def profiled_summary(kernel, batch, config, key):
         return None, None
     d = json.load(open(files[-1]))
     # (template variants share the prefix: the one that did the work is the slowest)
-    hits = [v for k, v in d.items() if k.startswith(kernel) and key in v]
+    # (an entry belongs to ONE bench command: `command`, c2 where the summary does not say)
+    hits = [v for k, v in d.items() if k.startswith(kernel) and key in v and v.get("command", "c2") == config]
     if not hits:
         return None, None
     v = max(hits, key=lambda v: v.get("avg_us", 0.0))
@@ -840,7 +841,7 @@ def main():
         # the committed counters belong to ONE command (profiles/collect.sh: c2, batch 197, the whole
         # alignment on one rank, the library's class limit): any option that changes the shape of the
         # launches -- --sites, --shard, --as-candidate-group, --repeat-classes, --no-repeats -- gets none
-        default_cmd = (args.config == "c2" and nb == 197 and (repeats or K != 4) and world == 1 and
+        default_cmd = (args.config in ("c2", "c3") and nb == 197 and (repeats or K != 4) and world == 1 and
                        args.sites is None and args.shard == "candidates" and args.as_candidate_group is None and
                        args.repeat_classes is None and not args.one_rank_comm)
         try:
@@ -848,6 +849,12 @@ def main():
                 roofline.update(profiled_issue(fused_kernel, nb, args.config))
                 roofline["traffic"], roofline["traffic_source"] = profiled_traffic(
                     fused_kernel, nb, args.config)
+                der = roofline.get("issue", {})
+                if K == 20 and "mfma_busy" in der:
+                    # north star: "MFMA-busy reported against gfx950 peak" -- the share of SIMD cycles the
+                    # FP64 matrix pipe was busy (SQ_VALU_MFMA_BUSY_CYCLES), and the CU's address unit
+                    roofline["mfma_busy"] = der["mfma_busy"]
+                    roofline["address_unit_busy"] = der.get("address_unit_busy")
         except StaleProfile as e:
             if not args.allow_stale_profile:
                 raise SystemExit("bench.py: " + str(e))

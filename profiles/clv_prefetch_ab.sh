@@ -1,4 +1,5 @@
 #!/bin/bash
+# (runs on commit 695e981: the product no longer carries the switch)
 # ON THE GPU BOX: the materialising traversal with / without "a marked memory operand is requested one
 # operation ahead, in front of the stores" (kernels_clv.hip PF, round 6) on an ABLATION build
 # (RDAMD_CLV_AHEAD: 0 never, 2 = the library's rule -- launches where >= 40 % of the operations have

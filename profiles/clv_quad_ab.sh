@@ -1,4 +1,5 @@
 #!/bin/bash
+# (runs on commit 695e981: the product no longer carries the kernel)
 # ON THE GPU BOX: the materialising traversal with the one-lane-per-state kernel for small launches
 # (clv_dna_quad_kernel; RDAMD_CLV_QUAD: 0 never, 2 = small launches only, 1 always) on an ABLATION
 # build (the environment switch), two alternating rounds.  Shapes: c2, 125.phy's, c2 / 8's shard,

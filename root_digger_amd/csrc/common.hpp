@@ -279,10 +279,8 @@ struct ListPieces {
 // most pieces per launch a list of `count` operations of this partition is worth cutting into
 // (0: run the list as it is)
 unsigned clv_traversal_pieces(const rdamd_partition *p, unsigned count);
-// look_ahead: the launch's kernel requests the memory operands the host marked (LevelOp::src* =
-// 0x100) one operation ahead, in front of the stores (kernels_clv.hip, PF)
 hipError_t launch_clv_traversal(rdamd_partition *p, const LevelOp *d_ops, const ListPieces &pieces,
-                                unsigned slots, bool look_ahead);
+                                unsigned slots);
 
 // kernels_clv_mfma.hip (20 states)
 hipError_t launch_pmat_to_mfma(rdamd_partition *p, const unsigned *d_matrix_indices, unsigned count);

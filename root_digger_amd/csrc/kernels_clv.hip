@@ -34,13 +34,9 @@ namespace rdamd {
 // so the "all entries below threshold" test is an in-wave AND.
 // ---------------------------------------------------------------------------
 // LevelOp::src* values
-// kSrcMemAhead: a memory operand the PREVIOUS operation may request ahead of its own stores (the
-// host marks it: the value was left by an earlier launch / call, or written at least two operations
-// back); the kernels without the look-ahead read it like kSrcMem
-enum : unsigned { kSrcTip = 0, kSrcMem = 1, kSrcReg = 2, kSrcPark = 3, kSrcMemAhead = 0x100 };
+enum : unsigned { kSrcTip = 0, kSrcMem = 1, kSrcReg = 2, kSrcPark = 3 };
 
 typedef unsigned v4u __attribute__((ext_vector_type(4)));
-typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ unsigned uni(unsigned x) {   // assert wave-uniformity
   return (unsigned)__builtin_amdgcn_readfirstlane((int)x);
@@ -74,10 +70,7 @@ struct TipCodes {
 // operations at a time (double-buffered, one barrier per chunk).
 constexpr unsigned kChunk = 4;
 
-// PF: the launch requests a marked memory operand one operation ahead (below: "The NEXT
-// operation's ..."): the joining launches of a cut list, where every operation reads a subtree
-// root that an earlier launch left in memory.
-template <int R, bool PF>
+template <int R>
 __global__ void __launch_bounds__(256)
 clv_dna_traversal_kernel(DeviceView v, const LevelOp *__restrict__ all_ops, ListPieces pieces,
                          unsigned slots) {
@@ -193,46 +186,16 @@ clv_dna_traversal_kernel(DeviceView v, const LevelOp *__restrict__ all_ops, List
   // operand of THIS operation: registers / prefetched memory / tip code / LDS slot
   const char *clv_bytes_base = reinterpret_cast<const char *>(v.clv);
   const char *sc_bytes_base = reinterpret_cast<const char *>(v.scaler);
-  // The NEXT operation's (first) memory operand is requested BEFORE this operation's stores.
-  // Vector-memory operations are counted in issue order (one counter for loads and stores on
-  // gfx9): a load issued behind the stores can only be waited for together with THEIR
-  // acknowledgements -- a round trip of microseconds under load, and on the tree's spine (the
-  // joining launches of a cut list) every operation reads a sibling that an earlier launch left
-  // in memory: 3.5 us per operation where the stores alone need 1.3 (round 6,
-  // profiles/r6_clv_prefetch_ab.txt).  Requested one operation ahead, in front of the stores, the
-  // wait is vmcnt(<what was issued since>) and leaves the stores in flight.  Safe: a sibling that
-  // is read back was written at least two operations earlier (the operation just before hands
-  // its result over in registers), i.e. its store precedes the request in this lane's order.
-  // Every operation issues the same three loads (through a 0-byte descriptor when it has nothing
-  // to request), so the counts are the same on every path.
-  const unsigned off_clv_ld = cidx * 32u, off_sc_ld = s * 4u;
-  auto pf_child = [](const LevelOp &q) -> unsigned {
-    return !PF ? 0u : q.src1 == kSrcMemAhead ? 1u : (q.src2 == kSrcMemAhead ? 2u : 0u);
-  };
-  auto prefetch = [&](const LevelOp &q, v4u (&pd)[2], unsigned &pdsc) {
-    const unsigned c = pf_child(q);
-    const uint64_t off = c == 2u ? q.child2_off : q.child1_off, sc_off = c == 2u ? q.child2_sc_off : q.child1_sc_off;
-    const bool sc_on = c != 0u && sc_off != kNoOffset;
-    const __amdgpu_buffer_rsrc_t rs = make_rsrc(clv_bytes_base + (c ? off : 0ull), c ? clv_bytes : 0u);
-    pd[0] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off_clv_ld, 0, 0);
-    pd[1] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off_clv_ld + 16, 0, 0);
-    pdsc = __builtin_amdgcn_raw_buffer_load_b32(make_rsrc(sc_bytes_base + (sc_on ? sc_off : 0ull), sc_on ? S * 4u : 0u),
-                                                (int)off_sc_ld, 0, 0);
-  };
-  auto operand = [&](unsigned src, bool prefetched, const v4u (&pd)[2], unsigned pdsc, uint64_t off, uint64_t sc_off,
-                     const TipCodes<NW> &t, const double (&o)[4], unsigned osc, double (&x)[4], unsigned &xsc) {
+  auto operand = [&](unsigned src, uint64_t off, uint64_t sc_off, const TipCodes<NW> &t,
+                     const double (&o)[4], unsigned osc, double (&x)[4], unsigned &xsc) {
     xsc = 0;
     if (src == kSrcReg) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) x[k] = o[k];
       xsc = osc;
-    } else if (PF && src == kSrcMemAhead && prefetched) {
-      const double2 a = __builtin_bit_cast(double2, pd[0]), b = __builtin_bit_cast(double2, pd[1]);
-      x[0] = a.x; x[1] = a.y; x[2] = b.x; x[3] = b.y;
-      xsc = pdsc;   // (0 through the empty descriptor where the child has no scaler)
-    } else if (src == kSrcMem || src == kSrcMemAhead) {
-      // (the SECOND memory operand of an operation, e.g. the two subtree roots a joining list
-      // starts with:) read here, after every earlier store of this lane in program order
+    } else if (src == kSrcMem) {
+      // a sibling that found no parking slot (or was left by an earlier call):
+      // read back here, after every earlier store of this lane in program order
       const double2 *p = reinterpret_cast<const double2 *>(clv_bytes_base + off);
       const double2 a = p[(size_t)cidx * 2], b = p[(size_t)cidx * 2 + 1];
       x[0] = a.x; x[1] = a.y; x[2] = b.x; x[3] = b.y;
@@ -282,11 +245,6 @@ clv_dna_traversal_kernel(DeviceView v, const LevelOp *__restrict__ all_ops, List
     stage_write(0, st);
     __syncthreads();
   }
-  // (the list's FIRST operation reads its memory operands where it uses them: with nothing
-  // requested in front of the loop, every wait below counts from a request issued inside it -- the
-  // same number of operations ago on every path)
-  v4u pre[2] = {v4u{0u, 0u, 0u, 0u}, v4u{0u, 0u, 0u, 0u}};
-  unsigned presc = 0;
   const unsigned sc_bytes = S * 4u;
   for (unsigned base = 0; base < nops; base += kChunk) {
     const unsigned buf = (base / kChunk) & 1u;
@@ -304,13 +262,11 @@ clv_dna_traversal_kernel(DeviceView v, const LevelOp *__restrict__ all_ops, List
       const LevelOp nx = chunk_ops[j + 1];
       double x[4], y[4];
       unsigned xsc, ysc;
-      const unsigned pfc = (j == 0 && base == 0) ? 0u : pf_child(op);
-      operand(op.src1, pfc == 1u, pre, presc, op.child1_off, op.child1_sc_off, t1, o, osc, x, xsc);
-      operand(op.src2, pfc == 2u, pre, presc, op.child2_off, op.child2_sc_off, t2, o, osc, y, ysc);
+      operand(op.src1, op.child1_off, op.child1_sc_off, t1, o, osc, x, xsc);
+      operand(op.src2, op.child2_off, op.child2_sc_off, t2, o, osc, y, ysc);
       // what the NEXT operation needs
       load_codes(nx.child1_off, nx.src1 == kSrcTip, t1);
       load_codes(nx.child2_off, nx.src2 == kSrcTip, t2);
-      if (PF) prefetch(nx, pre, presc);   // (in front of this operation's stores)
 
       double p1[4], p2[4];
       {
@@ -376,210 +332,6 @@ clv_dna_traversal_kernel(DeviceView v, const LevelOp *__restrict__ all_ops, List
     __syncthreads();
   }
 }
-
-#ifdef RDAMD_ABLATION   // (built, measured, lost: profiles/r6_clv_quad_ab.txt -- kept for the A/B only)
-// ---------------------------------------------------------------------------
-// The same traversal with ONE LANE PER STATE: four adjacent lanes (a quad) share a (site, rate)
-// pair, lane k computes entry k of the parent and stores its 8 bytes -- a wave-store is 512
-// contiguous bytes.  For the launches of a cut list that leave most of the device's wave slots
-// empty (round 6): the tree's spine is a chain no cut shortens, its joining
-// launch has one row of blocks -- three waves per SIMD on c2 --, and a launch lasts as long as ONE
-// wave needs for its list: every wave that waits (LDS reads, its turn on the SIMD, the chunk
-// barrier) is a wave that does not store.  Four times the waves, each with a quarter of the
-// registers and of the arithmetic, fill the slots (profiles/micro/clv_store_pattern.hip: the
-// store stream alone, one lane per state, 114.7 us on c2 against 125.6 in the pair-per-lane
-// pattern).  A child's other three entries come from the quad's lanes (DPP quad_perm, no LDS).
-// Same LevelOp lists, same sources (register / memory / tip / parking slot), same results.
-// R in {1, 2, 4}: a wave's 16 / R sites must start at a dword of the tip rows.
-// ---------------------------------------------------------------------------
-__device__ __forceinline__ double quad_bcast(double v, int j) {   // entry of lane j of my quad
-  const int lo = __double2loint(v), hi = __double2hiint(v);
-  int blo, bhi;
-  switch (j) {   // (the DPP control is an immediate)
-    case 0: blo = __builtin_amdgcn_mov_dpp(lo, 0x00, 0xF, 0xF, true); bhi = __builtin_amdgcn_mov_dpp(hi, 0x00, 0xF, 0xF, true); break;
-    case 1: blo = __builtin_amdgcn_mov_dpp(lo, 0x55, 0xF, 0xF, true); bhi = __builtin_amdgcn_mov_dpp(hi, 0x55, 0xF, 0xF, true); break;
-    case 2: blo = __builtin_amdgcn_mov_dpp(lo, 0xAA, 0xF, 0xF, true); bhi = __builtin_amdgcn_mov_dpp(hi, 0xAA, 0xF, 0xF, true); break;
-    default: blo = __builtin_amdgcn_mov_dpp(lo, 0xFF, 0xF, 0xF, true); bhi = __builtin_amdgcn_mov_dpp(hi, 0xFF, 0xF, 0xF, true); break;
-  }
-  return __hiloint2double(bhi, blo);
-}
-
-template <int R>
-__global__ void __launch_bounds__(256)
-clv_dna_quad_kernel(DeviceView v, const LevelOp *__restrict__ all_ops, ListPieces pieces, unsigned slots) {
-  static_assert(R == 1 || R == 2 || R == 4, "a wave's sites start at a dword of the tip rows");
-  const LevelOp *__restrict__ ops = all_ops + pieces.start[blockIdx.y];
-  const unsigned nops = pieces.len[blockIdx.y];
-  constexpr unsigned kRateStride = 18;
-  __shared__ double smat[2][kChunk][2][R * kRateStride];
-  extern __shared__ double park_q[];                 // [slot][256] doubles, then [slot][256] counts
-  const unsigned tid = threadIdx.x, lane = tid & 63;
-  const unsigned S = v.sites;
-  const unsigned total = S * R;                      // pairs; < 2^26
-  const unsigned idx = blockIdx.x * 256 + tid;       // (pair, state)
-  const unsigned pair = idx >> 2, k = idx & 3u;
-  const bool active = pair < total;
-  const unsigned cpair = active ? pair : total - 1;
-  const unsigned s = cpair / R, r = cpair % R;
-  const unsigned clv_bytes = (unsigned)(v.clv_stride * sizeof(double));
-  const unsigned off_clv_st = active ? idx * 8u : kOutOfRange;
-  const unsigned off_sc_st = (active && r == 0 && k == 0) ? s * 4u : kOutOfRange;
-  const unsigned cidx8 = cpair * 4u + k;             // my double of a CLV in memory
-
-  constexpr int kPairsPerWave = (2 * kChunk) / 4;
-  constexpr int kMatRegs = (R * 16 + 63) / 64;
-  const unsigned wave = uni(tid >> 6);
-  auto stage_load = [&](unsigned first_op, double (&st)[kPairsPerWave][kMatRegs]) {
-#pragma unroll
-    for (int q = 0; q < kPairsPerWave; ++q) {
-      const unsigned pr = wave + 4 * q, oi = first_op + pr / 2;
-      const unsigned oc = oi < nops ? oi : nops - 1;
-      const unsigned mat = (pr & 1u) ? ops[oc].child2_mat : ops[oc].child1_mat;
-#pragma unroll
-      for (int kk = 0; kk < kMatRegs; ++kk) {
-        const unsigned e = lane + 64 * kk;
-        st[q][kk] = e < R * 16 ? v.pmat[(size_t)mat * (R * 16) + e] : 0.0;
-      }
-    }
-  };
-  auto stage_write = [&](unsigned buf, const double (&st)[kPairsPerWave][kMatRegs]) {
-#pragma unroll
-    for (int q = 0; q < kPairsPerWave; ++q) {
-      const unsigned pr = wave + 4 * q;
-#pragma unroll
-      for (int kk = 0; kk < kMatRegs; ++kk) {
-        const unsigned e = lane + 64 * kk;
-        if (e < R * 16) smat[buf][pr / 2][pr & 1u][(e / 16) * kRateStride + (e % 16)] = st[q][kk];
-      }
-    }
-  };
-
-  // tip codes through the scalar cache: a wave covers 16 / R consecutive sites = NW dwords of a tip row
-  constexpr int NW = 16 / R / 4;
-  const unsigned wave_first = uni((blockIdx.x * 64 + (tid >> 6) * 16) / R);
-  const unsigned wave_site0 = wave_first < S ? wave_first : 0u;
-  const unsigned site_in_wave = (lane >> 2) / R;
-  const unsigned lane_word = site_in_wave >> 2, lane_shift = (site_in_wave & 3u) * 8u;
-  const unsigned long long tip_base = reinterpret_cast<unsigned long long>(v.tipcodes) + wave_site0;
-  auto load_codes = [&](uint64_t row_off, bool on, TipCodes<NW> &t) {
-    const unsigned long long a = tip_base + (on ? row_off : 0ull);
-    const unsigned lo = uni((unsigned)a), hi = uni((unsigned)(a >> 32));
-    const_u32_ptr p = (const_u32_ptr)(((unsigned long long)hi << 32) | lo);
-#pragma unroll
-    for (int kk = 0; kk < NW; ++kk) t.w[kk] = p[kk];
-  };
-  auto lane_code = [&](const TipCodes<NW> &t) {
-    unsigned word = 0;
-#pragma unroll
-    for (int kk = 0; kk < NW; ++kk) word |= t.w[kk] & (lane_word == (unsigned)kk ? ~0u : 0u);
-    return (word >> lane_shift) & 0xffu;
-  };
-
-  unsigned *park_sc = reinterpret_cast<unsigned *>(park_q + (size_t)slots * 256);
-  const char *clv_bytes_base = reinterpret_cast<const char *>(v.clv);
-  const char *sc_bytes_base = reinterpret_cast<const char *>(v.scaler);
-  // the four entries of an operand (every lane of the quad gets all four) and its scaler count
-  auto operand = [&](unsigned src, uint64_t off, uint64_t sc_off, const TipCodes<NW> &t, double o, unsigned osc,
-                     double (&x)[4], unsigned &xsc) {
-    xsc = 0;
-    if (src == kSrcTip) {
-      const unsigned code = lane_code(t);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int bit = (int)(code << (31 - j)) >> 31;
-        x[j] = __hiloint2double(bit & 0x3FF00000, 0);
-      }
-      return;
-    }
-    double mine;
-    if (src == kSrcReg) {
-      mine = o;
-      xsc = osc;
-    } else if (src == kSrcMem) {
-      mine = reinterpret_cast<const double *>(clv_bytes_base + off)[cidx8];
-      xsc = sc_off != kNoOffset ? reinterpret_cast<const unsigned *>(sc_bytes_base + sc_off)[s] : 0u;
-      __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), here (see the pair-per-lane kernel)
-    } else {
-      const unsigned slot = src - kSrcPark;
-      mine = park_q[slot * 256 + tid];
-      xsc = park_sc[slot * 256 + tid];
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) x[j] = quad_bcast(mine, j);
-  };
-  // lanes whose SITE (4 R adjacent lanes: R rates x 4 states) is small everywhere
-  constexpr int G = 4 * R;
-  constexpr unsigned long long kGroupMask = G == 4 ? 0x1111111111111111ull : G == 8 ? 0x0101010101010101ull
-                                                                                      : 0x0001000100010001ull;
-  auto site_small = [&](bool lane_small) {
-    unsigned long long m = __builtin_amdgcn_ballot_w64(lane_small);
-#pragma unroll
-    for (int off = 1; off < G; off <<= 1) m &= m >> off;
-    m &= kGroupMask;
-#pragma unroll
-    for (int off = 1; off < G; off <<= 1) m |= m << off;
-    return ((m >> lane) & 1ull) != 0;
-  };
-
-  double o = 0.0;
-  unsigned osc = 0;
-  TipCodes<NW> t1, t2;
-  {
-    double st[kPairsPerWave][kMatRegs];
-    stage_load(0, st);
-    const LevelOp op0 = ops[0];
-    load_codes(op0.child1_off, op0.src1 == kSrcTip, t1);
-    load_codes(op0.child2_off, op0.src2 == kSrcTip, t2);
-    stage_write(0, st);
-    __syncthreads();
-  }
-  const unsigned sc_bytes = S * 4u;
-  for (unsigned base = 0; base < nops; base += kChunk) {
-    const unsigned buf = (base / kChunk) & 1u;
-    double st[kPairsPerWave][kMatRegs];
-    stage_load(base + kChunk, st);
-    const LevelOp *chunk_ops = ops + base;
-#pragma unroll
-    for (unsigned j = 0; j < kChunk; ++j) {
-      const LevelOp op = chunk_ops[j];
-      const LevelOp nx = chunk_ops[j + 1];
-      double x[4], y[4];
-      unsigned xsc, ysc;
-      operand(op.src1, op.child1_off, op.child1_sc_off, t1, o, osc, x, xsc);
-      operand(op.src2, op.child2_off, op.child2_sc_off, t2, o, osc, y, ysc);
-      load_codes(nx.child1_off, nx.src1 == kSrcTip, t1);
-      load_codes(nx.child2_off, nx.src2 == kSrcTip, t2);
-      const double *m1 = &smat[buf][j][0][r * kRateStride + k * 4];
-      const double *m2 = &smat[buf][j][1][r * kRateStride + k * 4];
-      const double p1 = m1[0] * x[0] + m1[1] * x[1] + m1[2] * x[2] + m1[3] * x[3];
-      const double p2 = m2[0] * y[0] + m2[1] * y[1] + m2[2] * y[2] + m2[3] * y[3];
-      o = p1 * p2;
-      osc = 0;
-      const bool has_sc = op.parent_sc_off != kNoOffset && !op.noop;
-      if (op.parent_sc_off != kNoOffset) {
-        osc = xsc + ysc;
-        if (site_small((unsigned)__double2hiint(o) < 0x2FF00000u)) {
-          o *= kScaleFactor;
-          osc += 1;
-        }
-      }
-      __builtin_amdgcn_raw_buffer_store_b32(
-          osc, make_rsrc(sc_bytes_base + (has_sc ? op.parent_sc_off : 0ull), has_sc ? sc_bytes : 0u),
-          off_sc_st, 0, 0);
-      const __amdgpu_buffer_rsrc_t prs = make_rsrc(clv_bytes_base + op.parent_off, op.noop ? 0u : clv_bytes);
-      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u_t, o), prs, off_clv_st, 0, 0);
-      if (op.park) {
-        const unsigned slot = op.park - 1;
-        park_q[slot * 256 + tid] = o;
-        park_sc[slot * 256 + tid] = osc;
-      }
-    }
-    stage_write(buf ^ 1u, st);
-    __syncthreads();
-  }
-}
-
-#endif   // RDAMD_ABLATION
 
 // ---------------------------------------------------------------------------
 // Generic path (any K <= 64, any R): one lane per site, looping over rates and
@@ -655,9 +407,6 @@ static inline bool dna_fast_ok(const rdamd_partition *p) {
 }
 
 constexpr size_t kComputeUnits = 256;   // MI355X: 8 XCDs x 32 CUs
-#ifdef RDAMD_ABLATION
-constexpr size_t kQuadBelowWaves = 6144;   // RDAMD_CLV_QUAD=2: launches of fewer pair-per-lane waves than this run one lane per state
-#endif
 constexpr size_t kMaxParkSlots = 6;   // static + dynamic LDS stays under 64 KB per block
 
 // Slots are sized so that every block of the launch is resident at once (the
@@ -697,50 +446,22 @@ unsigned clv_traversal_pieces(const rdamd_partition *p, unsigned count) {
 }
 
 hipError_t launch_clv_traversal(rdamd_partition *p, const LevelOp *d_ops, const ListPieces &pieces,
-                                unsigned slots, bool look_ahead) {
+                                unsigned slots) {
   if (pieces.n == 0 || p->sites == 0) return hipSuccess;
   DeviceView v = p->view();
   const unsigned R = p->rate_cats;
   if (dna_fast_ok(p)) {
-    size_t total = (size_t)p->sites * R;
-    // One lane per STATE for the launches that leave most of the device's wave slots empty
-    // (clv_dna_quad_kernel: four times the waves) was built and measured in round 6 -- and LOST on
-    // every shape (profiles/r6_clv_quad_ab.txt: c2 +3 % with the rule below, +60 % everywhere;
-    // 125.phy +13 %): four times the vector-memory and LDS instructions for the same bytes.  The
-    // product never takes it; ablation builds do on request (RDAMD_CLV_QUAD = 1 always, 2 = the
-    // rule "fewer than kQuadBelowWaves pair-per-lane waves"), for the A/B.
-#ifdef RDAMD_ABLATION
-    const size_t waves = (total + 255) / 256 * 4 * pieces.n;
-    const int want = getenv("RDAMD_CLV_QUAD") ? atoi(getenv("RDAMD_CLV_QUAD")) : 0;
-    if (R <= 4 && (want == 1 || (want == 2 && waves <= kQuadBelowWaves))) {
-      const dim3 qgrid((unsigned)((total * 4 + 255) / 256), pieces.n);
-      const size_t qlds = (size_t)slots * 256 * (8 + 4);
-      switch (R) {
-        case 1: clv_dna_quad_kernel<1><<<qgrid, 256, qlds, p->stream>>>(v, d_ops, pieces, slots); break;
-        case 2: clv_dna_quad_kernel<2><<<qgrid, 256, qlds, p->stream>>>(v, d_ops, pieces, slots); break;
-        default: clv_dna_quad_kernel<4><<<qgrid, 256, qlds, p->stream>>>(v, d_ops, pieces, slots); break;
-      }
-      return hipGetLastError();
-    }
-#endif
     // one (site, rate) pair per lane where possible: maximum memory-level
     // parallelism; the lane -> pair map is identical for every operation
+    size_t total = (size_t)p->sites * R;
     const dim3 grid((unsigned)((total + 255) / 256), pieces.n);
     const size_t lds = (size_t)slots * 256 * (32 + 4);
-    if (look_ahead)
-      switch (R) {
-        case 1: clv_dna_traversal_kernel<1, true><<<grid, 256, lds, p->stream>>>(v, d_ops, pieces, slots); break;
-        case 2: clv_dna_traversal_kernel<2, true><<<grid, 256, lds, p->stream>>>(v, d_ops, pieces, slots); break;
-        case 4: clv_dna_traversal_kernel<4, true><<<grid, 256, lds, p->stream>>>(v, d_ops, pieces, slots); break;
-        default: clv_dna_traversal_kernel<8, true><<<grid, 256, lds, p->stream>>>(v, d_ops, pieces, slots); break;
-      }
-    else
-      switch (R) {
-        case 1: clv_dna_traversal_kernel<1, false><<<grid, 256, lds, p->stream>>>(v, d_ops, pieces, slots); break;
-        case 2: clv_dna_traversal_kernel<2, false><<<grid, 256, lds, p->stream>>>(v, d_ops, pieces, slots); break;
-        case 4: clv_dna_traversal_kernel<4, false><<<grid, 256, lds, p->stream>>>(v, d_ops, pieces, slots); break;
-        default: clv_dna_traversal_kernel<8, false><<<grid, 256, lds, p->stream>>>(v, d_ops, pieces, slots); break;
-      }
+    switch (R) {
+      case 1: clv_dna_traversal_kernel<1><<<grid, 256, lds, p->stream>>>(v, d_ops, pieces, slots); break;
+      case 2: clv_dna_traversal_kernel<2><<<grid, 256, lds, p->stream>>>(v, d_ops, pieces, slots); break;
+      case 4: clv_dna_traversal_kernel<4><<<grid, 256, lds, p->stream>>>(v, d_ops, pieces, slots); break;
+      default: clv_dna_traversal_kernel<8><<<grid, 256, lds, p->stream>>>(v, d_ops, pieces, slots); break;
+    }
   } else {
     unsigned gx = (p->sites + 255) / 256;
     for (unsigned k = 0; k < pieces.n; ++k)   // (this path never cuts its lists: one piece)

@@ -739,7 +739,6 @@ void rdamd_update_clvs(rdamd_partition_t *p, const rdamd_operation_t *ops,
   cuts.push_back(count);
   levels.push_back((unsigned)cuts.size() - 1);
   std::vector<int> producer(nclv, -1), consumer(count), which(count);
-  std::vector<int> made_by(2 * (size_t)count, -1);   // [op][child]: the op of the segment that wrote the child (-1: given)
   // one segment with `nslots` parking slots; returns the number of children it reads back from memory
   // (producer: clv -> op of this segment that wrote it; all -1 between calls)
   auto analyse = [&](unsigned lo, unsigned hi, unsigned nslots) {
@@ -756,7 +755,6 @@ void rdamd_update_clvs(rdamd_partition_t *p, const rdamd_operation_t *ops,
       for (int c = 0; c < 2; ++c) {
         if (ch[c] < p->tips || (!use_k20 && c == 1 && ch[1] == ch[0])) continue;
         const int j = producer[ch[c]];
-        made_by[2 * (size_t)i + c] = j;
         if (use_k20) {
           // the 20-state kernel keeps the results of the last TWO operations in
           // registers and forwards them to every reader (source 2: the operation
@@ -816,18 +814,6 @@ void rdamd_update_clvs(rdamd_partition_t *p, const rdamd_operation_t *ops,
       if (consumer[i] >= 0 && (which[i] ? lops[consumer[i]].src2 : lops[consumer[i]].src1) == 1u) ++readbacks;
       producer[ops[i].parent_clv_index] = -1;
     }
-    // 4 states: the FIRST memory operand of an operation may be requested by the operation in front
-    // of it, ahead of that operation's stores (kernels_clv.hip, PF) -- where that is safe: the value
-    // was there before the segment started or was stored at least two operations back (the request
-    // follows that store in the lane's order); never for a segment's first operation
-    for (unsigned i = lo + 1; !use_k20 && i < hi; ++i)
-      for (int c = 0; c < 2; ++c) {
-        unsigned &src = c ? lops[i].src2 : lops[i].src1;
-        if (src != 1u) continue;
-        const int j = made_by[2 * (size_t)i + c];
-        if (j < 0 || (int)i - j >= 2) src = 0x100u;
-        break;   // (one request per operation; a second memory operand is read where it is used)
-      }
     return readbacks;
   };
   // The pieces of a launch share one slot count: the fewest slots that leave no more read-backs than
@@ -914,17 +900,7 @@ void rdamd_update_clvs(rdamd_partition_t *p, const rdamd_operation_t *ops,
         pc.start[pc.n] = cuts[seg];
         pc.len[pc.n++] = cuts[seg + 1] - cuts[seg];
       }
-      // (a launch whose operations mostly read what earlier launches left in memory -- the joining
-      // lists of a cut, the tree's spine -- takes the kernel that requests those operands ahead)
-      unsigned ahead = 0, all = 0;
-      for (unsigned seg = levels[l]; !use_k20 && seg < levels[l + 1]; ++seg)
-        for (unsigned i = cuts[seg]; i < cuts[seg + 1]; ++i, ++all)
-          ahead += (lops[i].src1 == 0x100u || lops[i].src2 == 0x100u) && !lops[i].noop;
-      bool look_ahead = 5 * ahead >= 2 * all;
-#ifdef RDAMD_ABLATION
-      if (getenv("RDAMD_CLV_AHEAD")) look_ahead = atoi(getenv("RDAMD_CLV_AHEAD")) == 1 || (atoi(getenv("RDAMD_CLV_AHEAD")) == 2 && look_ahead);
-#endif
-      e = use_k20 ? launch_clv_k20_traversal(p, d_ops, pc) : launch_clv_traversal(p, d_ops, pc, seg_slots[levels[l]], look_ahead);
+      e = use_k20 ? launch_clv_k20_traversal(p, d_ops, pc) : launch_clv_traversal(p, d_ops, pc, seg_slots[levels[l]]);
     }
     p->last_clv_launches = (unsigned)levels.size() - 1;
     p->prof_end();

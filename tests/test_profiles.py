@@ -33,6 +33,10 @@ def test_committed_counters_belong_to_the_current_kernel_sources():
             "profiles/summarize.py on a GPU box" % (os.path.basename(name), kernel))
         checked += 1
     assert checked == 2
+    # the 20-state evaluator's counters (bench.py --config c3 publishes roofline.mfma_busy from them)
+    hits = [v for k, v in d.items() if k.startswith("fused20_eval_kernel") and v.get("command") == "c3"]
+    assert hits and all(v.get("source_digest") == source_digest("fused20_eval_kernel") for v in hits), name
+    assert all(0.0 < v["derived"]["mfma_busy"] <= 1.0 for v in hits)
 
 
 def test_digest_covers_existing_files():
