@@ -59,6 +59,17 @@ def test_bench_line_has_the_contract_fields():
         assert (k == "one_socket") == (c[k]["ratio_to_one_thread"] >= 20.0 and
                                        c[k]["cores"] >= 0.9 * c["host"]["cores_per_socket"])
     assert "loadavg" in c["host"] and "cgroup_cpu_max" in c["host"] and c["host"]["affinity_cpus"] >= 1
+    # the comparator bounded by what bounds a CPU: one socket's DRAM bandwidth over the
+    # bytes the oracle's site-repeats traversal must move; the speed-up's lower bound takes the smaller of
+    # the two socket bounds and says which
+    bb = c["one_socket_bandwidth_bound"]
+    by = bb["bytes_per_evaluation"]
+    assert by["moved"] == by["written"] + by["read_at_least_once"] and by["read_at_least_once"] <= by["read_if_nothing_is_cached"]
+    assert bb["value"] > 0 and bb["bandwidth_gbs"] > 0 and bb["stream_triad"]["gbs"] > 0 and bb["stream_triad"]["threads"] >= 1
+    assert abs(bb["value"] - bb["bandwidth_gbs"] * 1e9 / by["moved"]) <= 1e-3 * bb["value"]
+    low = min(bb["value"], c["one_socket_ideal"]["value"])
+    assert abs(c["speedup_lower_bound"] - d["value"] / low) <= 0.01 * c["speedup_lower_bound"] + 0.01
+    assert c["speedup_lower_bound_basis"] in ("one_socket_bandwidth_bound", "one_socket_ideal")
     # BASELINE's second metric: algorithmic-equivalent and executed (site repeats fold operations)
     assert 0 < d["site_clv_updates_per_sec_executed"] <= d["site_clv_updates_per_sec"]
     assert r["schedule"]["max_classes"] == 64       # the library's effective limit, not null
