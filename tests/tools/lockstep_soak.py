@@ -33,7 +33,11 @@ while time.time() - t0 < budget:
             v[rng.random(S) < 0.02] = ord(str(rng.choice(list("RYKMSW"))))
             w["seqs"][k] = v.tobytes().decode()
     tree = rd.Tree.from_newick(w["newick"])
-    m = rd.Model(tree, w["seqs"], rate_cats=R, seed=int(rng.integers(1 << 20)))
+    # (round 6: half of the models stop early -- BASELINE c5's mode, src/model.cpp:1187-1197 -- and the
+    # one-rank communicator alternates between its two sum modes: gather + rank-order kernel / ncclAllReduce)
+    early = bool(rng.random() < 0.5)
+    early_models = globals().get("early_models", 0) + int(early)
+    m = rd.Model(tree, w["seqs"], rate_cats=R, seed=int(rng.integers(1 << 20)), early_stop=early)
     m.initialize_partitions()
     m.set_lbfgsb(lb.setulb)
     m.compute_lh(tree.root_location(0))
@@ -56,6 +60,7 @@ while time.time() - t0 < budget:
     m.set_lockstep_rounds(-1)
     m.set_lockstep_groups(0)
     if rounds % 3 == 0:   # ... and as a site-sharded model would run it: the RCCL reducer behind every round
+        comm.set_sum_mode(rd.COMM_SUM_ALLREDUCE if sharded % 2 else rd.COMM_SUM_GATHER)
         m.set_lnl_reducer(comm.reducer, on_device=True, user=comm.handle)
         lock = m.exhaustive_search(*tol, lockstep=int(rng.integers(2, 12)))
         assert np.array_equal(lock["llh"], seq["llh"][order]) and np.array_equal(lock["alpha"], seq["alpha"][order]), (n, S, R, "rccl rounds")
@@ -64,5 +69,6 @@ while time.time() - t0 < budget:
     rounds += 1
     cands += len(seq["root_id"])
 print("%d random models, %d candidates each searched sequentially, twice in lock step (arrival order) and once in "
-      "deterministic rounds (%d of the models also with the one-rank RCCL reducer behind every round): identical records; %.0f s"
-      % (rounds, cands, sharded, time.time() - t0))
+      "deterministic rounds (%d of the models also with the one-rank RCCL reducer behind every round, both sum modes; %d of "
+      "the models with --early-stop): identical records; %.0f s"
+      % (rounds, cands, sharded, early_models, time.time() - t0))
