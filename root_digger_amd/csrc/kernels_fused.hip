@@ -189,56 +189,6 @@ constexpr bool kTestRT = false, kTestRP = RDAMD_ABL_NOCHECK < 2;
 #else
 constexpr bool kTestRT = true, kTestRP = true;
 #endif
-// RDAMD_ABL_TEST_EVERY = N (a power of two; ablation builds, timing only): the rescale test on every
-// N-th step, chosen by a scalar branch on the step's index -- what a test that runs only where a
-// lower bound of the running CLV says it may fire would cost and buy (profiles/r6_step_timeline.md)
-#if defined(RDAMD_ABLATION) && defined(RDAMD_ABL_TEST_EVERY)
-// (as a source-level `if` around combine_sites the two-sites kernel needs 129 VGPRs -- three waves per
-// SIMD; so the test sits in ONE asm statement with the scalar skip inside: it leaves the sites' lane
-// masks in two SGPR pairs, zero when skipped, and the rare rescale runs behind them as before)
-template <int NS>
-__device__ __forceinline__ void combine_sites_gated(const double (&tx)[NS][4], const double (&ty)[NS][4],
-                                                    double (&v)[NS][4], int (&sc)[NS], unsigned need) {
-#pragma unroll
-  for (int q = 0; q < NS; ++q)
-#pragma unroll
-    for (int k = 0; k < 4; ++k) v[q][k] = tx[q][k] * ty[q][k];
-  unsigned long long m[2] = {0ull, 0ull};
-  unsigned t0, t1;
-  const int q1 = NS - 1;   // (one site per lane: the second half tests site 0 again)
-  asm volatile(
-      "s_mov_b64 %[m0], 0\n\t"
-      "s_mov_b64 %[m1], 0\n\t"
-      "s_cmp_eq_u32 %[need], 0\n\t"
-      "s_cbranch_scc1 1f\n\t"
-      "v_max_u32 %[t0], %[a2], %[a3]\n\t"
-      "v_max_u32 %[t1], %[b2], %[b3]\n\t"
-      "v_max3_u32 %[t0], %[a0], %[a1], %[t0]\n\t"
-      "v_max3_u32 %[t1], %[b0], %[b1], %[t1]\n\t"
-      "v_cmp_gt_u32 %[m0], %[thr], %[t0]\n\t"
-      "v_cmp_gt_u32 %[m1], %[thr], %[t1]\n"
-      "1:"
-      : [m0] "=&s"(m[0]), [m1] "=&s"(m[1]), [t0] "=&v"(t0), [t1] "=&v"(t1)
-      : [need] "s"(need), [thr] "s"(0x2FF00000u),
-        [a0] "v"(__double2hiint(v[0][0])), [a1] "v"(__double2hiint(v[0][1])), [a2] "v"(__double2hiint(v[0][2])), [a3] "v"(__double2hiint(v[0][3])),
-        [b0] "v"(__double2hiint(v[q1][0])), [b1] "v"(__double2hiint(v[q1][1])), [b2] "v"(__double2hiint(v[q1][2])), [b3] "v"(__double2hiint(v[q1][3]))
-      : "scc");
-  if ((m[0] | m[1]) != 0ull) {
-    const unsigned lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-#pragma unroll
-    for (int q = 0; q < NS; ++q)
-      if ((m[q] >> lane) & 1ull) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) v[q][k] *= kScaleFactor;
-        sc[q] += 1;
-      }
-  }
-}
-#define RDAMD_COMBINE(T, a, b, idx2) \
-  combine_sites_gated<NS>(a, b, st.v, st.sc, uni(((((idx2) - 2u) & (RDAMD_ABL_TEST_EVERY - 1u)) == 0u) ? 1u : 0u));
-#else
-#define RDAMD_COMBINE(T, a, b, idx2) combine_sites<NS, T>(a, b, st.v, st.sc);
-#endif
 
 // TTCHECK: rescale test on tip-tip steps too.  A variant is queued over all jobs of a batch
 // (the one with the test only if the batch raised a flag at all, launch_fused_eval_ns); a
@@ -806,7 +756,7 @@ fused_dna_eval_kernel(FusedArgs a) {
       _Pragma("unroll") for (int q = 0; q < NS; ++q) matvec(M, st.v[q], tx[q]);                 \
       RDAMD_STAMP(3)                                                                            \
       RDAMD_LOAD_M(nxt, M)                                                                      \
-      RDAMD_COMBINE(kTestRT, tx, ty, idx2)                                                      \
+      combine_sites<NS, kTestRT>(tx, ty, st.v, st.sc);                                          \
     } else { /* kFusedRP: running CLV times M, sibling already multiplied when parked */        \
       if (kind & 0x400u) { /* the sibling waits in the register slot: used in place */          \
         RDAMD_STAMP(1)                                                                          \
@@ -816,7 +766,7 @@ fused_dna_eval_kernel(FusedArgs a) {
         RDAMD_STAMP(3)                                                                          \
         RDAMD_LOAD_M(nxt, M)                                                                    \
         _Pragma("unroll") for (int q = 0; q < NS; ++q) st.sc[q] += s0sc[q];                     \
-        RDAMD_COMBINE(kTestRP, tx, s0, idx2)                                                    \
+        combine_sites<NS, kTestRP>(tx, s0, st.v, st.sc);                                                 \
       } else if (RL >= 2 && (kind & 0x1000u)) {                                                 \
         RDAMD_STAMP(1)                                                                          \
         RDAMD_LOAD_TIPS(nxt, ncx, ncy, nex, ney) RDAMD_LATE_DESC(cur, idx2)                     \
@@ -825,7 +775,7 @@ fused_dna_eval_kernel(FusedArgs a) {
         RDAMD_STAMP(3)                                                                          \
         RDAMD_LOAD_M(nxt, M)                                                                    \
         _Pragma("unroll") for (int q = 0; q < NS; ++q) st.sc[q] += s1sc[q];                     \
-        RDAMD_COMBINE(kTestRP, tx, s1, idx2)                                                    \
+        combine_sites<NS, kTestRP>(tx, s1, st.v, st.sc);                                                 \
       } else {                                                                                  \
         int scy[NS];                                                                            \
         f64x2_t plo[NS], phi[NS];                                                               \
@@ -853,7 +803,7 @@ fused_dna_eval_kernel(FusedArgs a) {
           }                                                                                     \
         }                                                                                       \
         _Pragma("unroll") for (int q = 0; q < NS; ++q) st.sc[q] += scy[q];                      \
-        RDAMD_COMBINE(kTestRP, tx, ty, idx2)                                                    \
+        combine_sites<NS, kTestRP>(tx, ty, st.v, st.sc);                                        \
       }                                                                                         \
     }                                                                                           \
     RDAMD_STAMP(4)                                                                              \
