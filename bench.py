@@ -372,7 +372,7 @@ def main():
     params = [synth.random_params(K * K - K, rng) for _ in range(len(mine))]
     roots = [tree.root_location(i) for i in mine]
 
-    use_fused = K == 4 or (K == 20 and R <= 4)   # the shapes the fused evaluators take
+    use_fused = K == 4 or (K == 20 and R <= 8)   # the shapes the fused evaluators take
     fused_kernel = "fused_dna_eval_kernel" if K == 4 else "fused20_eval_kernel"
     clv_kernel = ("clv_dna_traversal_kernel" if K == 4 else
                   "clv_k20_traversal_kernel" if K == 20 else "clv_generic_traversal_kernel")

@@ -228,7 +228,7 @@ int rdamd_compute_root_loglikelihoods(rdamd_partition_t *p, unsigned int count,
  * parameter set -- in ONE fused launch that never writes a CLV to HBM.  They
  * are stateless with respect to the partition: its CLV / P-matrix / parameter
  * state is neither read nor changed (tip states and pattern weights are).
- * 4-state (and embedded binary) data, and 20-state data with up to 4 rate
+ * 4-state (and embedded binary) data, and 20-state data with up to 8 rate
  * categories; other shapes use the three calls above.
  * --------------------------------------------------------------------- */
 typedef struct rdamd_schedule rdamd_schedule_t;
@@ -354,7 +354,7 @@ int rdamd_evaluate_batch_finish_device(rdamd_partition_t *p, unsigned int slot);
  * corax_update_prob_matrices + corax_update_clvs + corax_compute_root_loglikelihood
  * (src/model.cpp:357-409) where only the root's children are read afterwards -- 13 MB written
  * instead of 1.3 GB moved on BASELINE c2.  Parameters as one job of rdamd_evaluate_batch.
- * 4-state and binary partitions, and 20-state ones with up to 4 rate categories (the fused
+ * 4-state and binary partitions, and 20-state ones with up to 8 rate categories (the fused
  * evaluators' shapes); the children need scale buffers.  *lnl_out = the tree's
  * log-likelihood (every operation of the list evaluated, the reference's rescaling rule at
  * every step). */

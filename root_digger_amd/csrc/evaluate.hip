@@ -203,10 +203,10 @@ static rdamd_schedule_t *schedule_create_impl(rdamd_partition_t *p, const rdamd_
                                               unsigned int n_matrices, bool allow_repeats) {
   // (clade cache, code arenas and the block pool belong to the partition: one thread at a time)
   std::lock_guard<std::mutex> guard(p->launch_mu);
-  const bool k20 = p->states == 20 && p->rate_cats <= 4;
+  const bool k20 = p->states == 20 && p->rate_cats <= 8;
   if (p->states != 4 && !k20) {
     set_error(40, "rdamd_schedule_create: the fused evaluator handles 4-state data and 20-state "
-                  "data with up to 4 rate categories; use rdamd_update_clvs for %u states, %u "
+                  "data with up to 8 rate categories; use rdamd_update_clvs for %u states, %u "
                   "categories", p->states, p->rate_cats);
     return nullptr;
   }
@@ -571,9 +571,9 @@ static int batch_submit_impl(rdamd_partition_t *p, FusedWorkspace *&slot, bool p
                              const double *subst, const double *freqs,
                              const double *rates, const double *rate_weights,
                              bool host_out, void *lnl_device, bool export_children, double *mirror) {
-  const bool k20 = p->states == 20 && p->rate_cats <= 4;
+  const bool k20 = p->states == 20 && p->rate_cats <= 8;
   if (p->states != 4 && !k20) {
-    set_error(40, "rdamd_evaluate_batch: 4-state data, or 20-state data with up to 4 rate categories");
+    set_error(40, "rdamd_evaluate_batch: 4-state data, or 20-state data with up to 8 rate categories");
     return RDAMD_FAILURE;
   }
   const unsigned R = p->rate_cats, K = p->states, NP = K * K - K;
@@ -738,7 +738,7 @@ static int batch_submit_impl(rdamd_partition_t *p, FusedWorkspace *&slot, bool p
       // (operand layout: rdamd_evaluate_root_children only takes partitions that keep it)
       const rdamd_schedule_t *s0 = schedules[0];
       if (n_jobs != 1 || pipelined || !p->mfma_layout) {
-        set_error(50, "rdamd_evaluate_root_children: one job on the partition's stream (20 states: up to 4 rate categories)");
+        set_error(50, "rdamd_evaluate_root_children: one job on the partition's stream (20 states: up to 8 rate categories)");
         return RDAMD_FAILURE;
       }
       unsigned phys_clv[2] = {0, 0};
@@ -991,8 +991,8 @@ int rdamd_evaluate_root_children(rdamd_partition_t *p, const rdamd_operation_t *
                                  unsigned int n_matrices, const double *subst, const double *freqs,
                                  const double *rates, const double *rate_weights, double *lnl_out) {
   clear_error();
-  if (!(p->states == 4 && !p->mfma_layout) && !(p->states == 20 && p->rate_cats <= 4 && p->mfma_layout)) {
-    set_error(50, "rdamd_evaluate_root_children: 4-state (or binary) partitions, and 20-state ones with up to 4 rate categories");
+  if (!(p->states == 4 && !p->mfma_layout) && !(p->states == 20 && p->rate_cats <= 8 && p->mfma_layout)) {
+    set_error(50, "rdamd_evaluate_root_children: 4-state (or binary) partitions, and 20-state ones with up to 8 rate categories");
     return RDAMD_FAILURE;
   }
   // a schedule for this one launch: the plain program (its block comes from the partition's pool)

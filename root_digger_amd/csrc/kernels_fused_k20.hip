@@ -330,8 +330,11 @@ fused20_pmatrix_kernel(const double *__restrict__ qpow, const double *__restrict
 // the root operation's two children) also store the running CLV -- in the partition's operand
 // layout -- and its rescale count: what the root-only steps of the search read afterwards
 // (src/model.cpp:415-446), instead of a traversal that materialises every CLV.
-template <int NT, bool EXPORT>
-__global__ void __launch_bounds__(256)
+// THREADS: 256 for up to four rate categories (the shape every measurement of DESIGN 4.6 is about),
+// 512 for five to eight -- a workgroup is R waves (round 6: `rd --rate-cats N` takes any N,
+// src/main.cpp:256-266; beyond eight the traversal kernels serve).
+template <int NT, bool EXPORT, int THREADS>
+__global__ void __launch_bounds__(THREADS)
 fused20_eval_kernel(Fused20Args a, unsigned depth) {
   extern __shared__ char lds_raw[];
   const unsigned R = a.rate_cats, S = a.sites;
@@ -707,25 +710,34 @@ size_t fused20_lds_bytes(unsigned R, unsigned depth) {
          (size_t)R * (kCopyLds + (size_t)depth * kFused20Tiles * kLevelBytes);
 }
 
-hipError_t launch_fused20_eval(const Fused20Args &a, unsigned n_jobs, unsigned max_depth,
-                               double *d_out, hipStream_t stream) {
-  if (!n_jobs) return hipSuccess;
+// one instantiation: its LDS limit raised when a launch needs more than 64 KB (raised, never lowered:
+// partitions launch from their own host threads), then the launch
+template <bool EXPORT, int THREADS>
+static hipError_t launch_fused20_variant(const Fused20Args &a, unsigned n_jobs, unsigned max_depth, hipStream_t stream) {
   const size_t lds = fused20_lds_bytes(a.rate_cats, max_depth);
-  {   // more than 64 KB of LDS per workgroup has to be asked for -- raised, never lowered: partitions
-      // launch from their own host threads
+  if (lds > 160u * 1024u) return hipErrorInvalidValue;   // (deep stacks at many rate categories)
+  {
     static std::mutex lds_mu;
     static size_t lds_allowed = 64 * 1024;
     std::lock_guard<std::mutex> guard(lds_mu);
     if (lds > lds_allowed) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fused20_eval_kernel<kFused20Tiles, false>),
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fused20_eval_kernel<kFused20Tiles, EXPORT, THREADS>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return e;
       lds_allowed = lds;
     }
   }
   const unsigned groups = (a.tiles + kFused20Tiles - 1) / kFused20Tiles;
-  fused20_eval_kernel<kFused20Tiles, false><<<dim3(groups, n_jobs), 64 * a.rate_cats, lds, stream>>>(a, max_depth);
-  hipError_t e = hipGetLastError();
+  fused20_eval_kernel<kFused20Tiles, EXPORT, THREADS><<<dim3(groups, n_jobs), 64 * a.rate_cats, lds, stream>>>(a, max_depth);
+  return hipGetLastError();
+}
+
+hipError_t launch_fused20_eval(const Fused20Args &a, unsigned n_jobs, unsigned max_depth,
+                               double *d_out, hipStream_t stream) {
+  if (!n_jobs) return hipSuccess;
+  if (a.rate_cats > 8) return hipErrorInvalidValue;
+  hipError_t e = a.rate_cats <= 4 ? launch_fused20_variant<false, 256>(a, n_jobs, max_depth, stream)
+                                  : launch_fused20_variant<false, 512>(a, n_jobs, max_depth, stream);
   if (e != hipSuccess) return e;
   fused20_finish_kernel<<<n_jobs, 256, 0, stream>>>(a.partials, a.tiles, d_out);
   return hipGetLastError();
@@ -733,21 +745,9 @@ hipError_t launch_fused20_eval(const Fused20Args &a, unsigned n_jobs, unsigned m
 
 hipError_t launch_fused20_export(const Fused20Args &a, unsigned max_depth, unsigned *const d_scaler[2],
                                  double *d_out, hipStream_t stream) {
-  const size_t lds = fused20_lds_bytes(a.rate_cats, max_depth);
-  {
-    static std::mutex lds_mu;
-    static size_t lds_allowed = 64 * 1024;
-    std::lock_guard<std::mutex> guard(lds_mu);
-    if (lds > lds_allowed) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fused20_eval_kernel<kFused20Tiles, true>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e != hipSuccess) return e;
-      lds_allowed = lds;
-    }
-  }
-  const unsigned groups = (a.tiles + kFused20Tiles - 1) / kFused20Tiles;
-  fused20_eval_kernel<kFused20Tiles, true><<<dim3(groups, 1), 64 * a.rate_cats, lds, stream>>>(a, max_depth);
-  hipError_t e = hipGetLastError();
+  if (a.rate_cats > 8) return hipErrorInvalidValue;
+  hipError_t e = a.rate_cats <= 4 ? launch_fused20_variant<true, 256>(a, 1, max_depth, stream)
+                                  : launch_fused20_variant<true, 512>(a, 1, max_depth, stream);
   if (e != hipSuccess) return e;
   fused20_finish_kernel<<<1, 256, 0, stream>>>(a.partials, a.tiles, d_out);
   if (a.export_clv[0] || a.export_clv[1]) {

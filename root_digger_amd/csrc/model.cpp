@@ -63,7 +63,7 @@ model_t::model_t(rooted_tree_t tree, const std::vector<msa_t> &msas,
     unsigned int attributes = RDAMD_ATTRIB_NONREV;
     if (msa.states == 4) attributes |= RDAMD_ATTRIB_SITE_REPEATS;
     // (the shapes rdamd_evaluate_root_children takes: what compute_lh_for_root_steps runs on)
-    if (_sparse && (msa.states == 4 || msa.states == 2 || (msa.states == 20 && _rate_rates[p].size() <= 4)))
+    if (_sparse && (msa.states == 4 || msa.states == 2 || (msa.states == 20 && _rate_rates[p].size() <= 8)))
       attributes |= RDAMD_ATTRIB_SPARSE_CLVS;
     rdamd_partition_t *part = rdamd_partition_create(
         _tree.tip_count(), _tree.branch_count(), msa.states, (unsigned)msa.length(), 1,
@@ -340,7 +340,7 @@ double model_t::compute_lh_for_root_steps(const root_location_t &root_location) 
   for (size_t i = 0; i < _partitions.size(); ++i) {
     rdamd_partition_t *part = _partitions[i];
     const unsigned st = rdamd_partition_states(part);
-    if (st == 4 || st == 2 || (st == 20 && rdamd_partition_rate_cats(part) <= 4)) {
+    if (st == 4 || st == 2 || (st == 20 && rdamd_partition_rate_cats(part) <= 8)) {
       double v = 0.0;
       // (a replica's sparse partition: the children of the LAST root, and whatever else an earlier
       // call named, give their memory back -- nothing reads them after this call)
@@ -1046,12 +1046,12 @@ void model_t::optimize_params(std::vector<partition_parameters_t> &params,
     throw std::runtime_error("optimize_params: lock step in rounds takes single-partition models");
   for (size_t i = 0; i < _partitions.size(); ++i) {
     // The batched objective runs on the fused evaluators: 4-state and binary data, and 20
-    // states with up to four rate categories (the 381 finite-difference evaluations of a
+    // states with up to eight rate categories (the 381 finite-difference evaluations of a
     // 20-state rate matrix are one launch of fused20_eval_kernel, src/model.cpp:1490-1502).
     const unsigned st = rdamd_partition_states(_partitions[i]);
-    if (st != 4 && st != 2 && !(st == 20 && rdamd_partition_rate_cats(_partitions[i]) <= 4))
+    if (st != 4 && st != 2 && !(st == 20 && rdamd_partition_rate_cats(_partitions[i]) <= 8))
       throw std::runtime_error("optimize_params: the batched objective handles 4-state and binary data, and "
-                               "20-state data with up to 4 rate categories");
+                               "20-state data with up to 8 rate categories");
     batch_combiner_t *combiner = _combiners.empty() ? nullptr : _combiners[i];
     // (lock step: this candidate is inside partition i's objective phase from here on)
     batch_combiner_t::scope_t in_lockstep(combiner);

@@ -454,7 +454,7 @@ unsigned int rdamd_model_max_replicas(const rdamd_model_t *m, unsigned int reque
     // evaluator's workspace for the one job that writes them
     const unsigned R = (unsigned)ratehets[std::min(i, ratehets.size() - 1)].rate_cats;
     const bool sparse = replicas_are_sparse(m) &&
-                        (msas[i].states == 4 || msas[i].states == 2 || (msas[i].states == 20 && R <= 4));
+                        (msas[i].states == 4 || msas[i].states == 2 || (msas[i].states == 20 && R <= 8));
     per_replica += rdamd_partition_footprint(tips, sparse ? 4u : branches, msas[i].states, (unsigned)msas[i].length(),
                                              branches, R, sparse ? 4u : branches);
     if (sparse) {

@@ -405,10 +405,13 @@ def test_fused_batch_vs_oracle(n, S, R, seed):
         assert util.rel_err(got2[j], want) < LNL_TOL
 
 
-@pytest.mark.parametrize("n,S,R,seed", [(40, 300, 4, 46), (25, 77, 2, 47), (12, 16, 1, 48), (70, 130, 3, 49)])
+@pytest.mark.parametrize("n,S,R,seed", [(40, 300, 4, 46), (25, 77, 2, 47), (12, 16, 1, 48), (70, 130, 3, 49),
+                                         (40, 200, 8, 146), (21, 50, 5, 147), (33, 129, 7, 148)])
 def test_fused_batch_20_states_vs_oracle(n, S, R, seed):
     """the 20-state fused evaluator (kernels_fused_k20.hip): batched jobs with
-    their own parameters, rates and category weights, ragged last tile."""
+    their own parameters, rates and category weights, ragged last tile.  One to four rate
+    categories run 256-thread workgroups (a wave per category), five to eight the 512-thread
+    instantiation (round 6: `rd --rate-cats N` takes any N, src/main.cpp:256-266)."""
     w = synth.workload(n, S, 20, R, seed)
     tree = rd.Tree.from_newick(w["newick"])
     rng = np.random.default_rng(seed)

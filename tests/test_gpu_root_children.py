@@ -118,9 +118,9 @@ def test_root_children_binary_and_errors():
     ops, pmi, brl = tree.generate_operations(tree.root_location(0))
     with pytest.raises(rd.RdamdError):
         g.evaluate_root_children([ops[len(ops) - 1]], pmi, brl, [0.7, 1.9], g.empirical_frequencies(), w["rates"])
-    # 20 states with more than four rate categories, and general state counts, are refused (the
+    # 20 states with more than eight rate categories, and general state counts, are refused (the
     # searches keep the traversal there)
-    for K, R in ((20, 8), (5, 2)):
+    for K, R in ((20, 9), (5, 2)):
         wk = synth.workload(12, 40, K, R, 6)
         tk = rd.Tree.from_newick(wk["newick"])
         gk = rd.Partition.for_tree(tk, K, 40, R)
@@ -130,7 +130,8 @@ def test_root_children_binary_and_errors():
             gk.evaluate_root_children(ops, pmi, brl, wk["subst"], [1.0 / K] * K, wk["rates"])
 
 
-@pytest.mark.parametrize("n,S,R,seed", [(30, 500, 4, 131), (9, 33, 1, 132), (64, 130, 2, 133), (200, 300, 4, 134)])
+@pytest.mark.parametrize("n,S,R,seed", [(30, 500, 4, 131), (9, 33, 1, 132), (64, 130, 2, 133), (200, 300, 4, 134),
+                                         (30, 200, 8, 135), (17, 97, 6, 136)])   # (five to eight categories: the 512-thread variant)
 def test_root_children_20_states_vs_oracle(n, S, R, seed):
     """the exporting variant of fused20_eval_kernel -- the searches' compute_lh in
     front of the root-only steps on protein data (src/model.cpp:415-446) is one job of the fused
