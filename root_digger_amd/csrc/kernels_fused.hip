@@ -163,22 +163,6 @@ __device__ __forceinline__ void combine_sites(const double (&tx)[NS][4], const d
       for (int k = 0; k < 4; ++k) v[q][k] = tx[q][k] * ty[q][k];
     return;
   }
-#if defined(RDAMD_ABLATION) && defined(RDAMD_ABL_BRANCHFREE)
-  // A/B (profiles/r6_step_timeline.md 4.6): the rescale without a branch -- every site multiplies by
-  // 2^256 or by 1.0 (exact either way: the same bits), eight more FP64 instructions per step
-#pragma unroll
-  for (int q = 0; q < NS; ++q) {
-#pragma unroll
-    for (int k = 0; k < 4; ++k) v[q][k] = tx[q][k] * ty[q][k];
-    const unsigned h = max(max((unsigned)__double2hiint(v[q][0]), (unsigned)__double2hiint(v[q][1])),
-                           max((unsigned)__double2hiint(v[q][2]), (unsigned)__double2hiint(v[q][3])));
-    const int e = h < 0x2FF00000u ? 256 : 0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) v[q][k] = __builtin_amdgcn_ldexp(v[q][k], e);   // (v_ldexp_f64: exact, x 1 where e = 0)
-    sc[q] += e >> 8;
-  }
-  return;
-#endif
   unsigned hmax[NS];
   bool any_small = false;
 #pragma unroll
