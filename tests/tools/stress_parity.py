@@ -89,11 +89,11 @@ while time.time() - t0 < budget:
     la = g.compute_root_loglikelihood(tree.root_clv_index(), tree.root_scaler_index())
     lb = o.compute_root_loglikelihood(tree.root_clv_index(), tree.root_scaler_index())
     fused = lb
-    if K != 20 or R <= 4:        # the shapes the fused evaluators take
+    if K != 20 or R <= 8:        # the shapes the fused evaluators take (20 states: up to eight rate categories since round 6)
         fused = g.evaluate_batch([g.schedule(ops, pmi, brl)], [w["subst"]], [freqs])[0]
     err = max(abs(la - lb), abs(fused - lb)) / abs(lb)
     assert err < 1e-11, (n, S, R, K, la, lb, fused)
-    if K != 20 or R <= 4:        # the root's children left behind by the exporting evaluators (4 / 2 / 20 states)
+    if K != 20 or R <= 8:        # the root's children left behind by the exporting evaluators (4 / 2 / 20 states)
         # (rdamd_evaluate_root_children): the value, the two CLVs up to their scalers, and the
         # root-only evaluation on top of them, with other parameters than the traversal above
         subst2 = [v * float(rng.uniform(0.5, 2.0)) for v in w["subst"]]
