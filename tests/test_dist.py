@@ -294,6 +294,56 @@ def test_rd_amd_ranks_notice_a_dead_rank(tmp_path, world, victim):
             assert p.returncode == 3 and out.strip() == "%d lost" % r, (r, p.returncode, out)
 
 
+def _rendezvous_exe(tmp_path):
+    import subprocess
+    root = os.path.dirname(HERE)
+    exe = str(tmp_path / "rendezvous_check")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I",
+                           os.path.join(root, "root_digger_amd", "csrc", "tools"),
+                           os.path.join(HERE, "cpp", "rendezvous_check.cpp"), "-o", exe, "-lpthread"])
+    return exe
+
+
+@pytest.mark.parametrize("world,odd", [(2, 1), (3, 0), (4, 2)])
+def test_host_site_group_refuses_vectors_of_different_length(tmp_path, world, odd):
+    """Ranks whose rounds have diverged arrive with vectors of different length: a device
+    collective would hang or corrupt there, the host reducer's leader compares the lengths and
+    refuses -- and no member is left waiting (the leader's failure closes the group's sockets)."""
+    import subprocess
+    import time
+    exe = _rendezvous_exe(tmp_path)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    t0 = time.monotonic()
+    procs = [subprocess.Popen([exe, str(r), str(world), "mismatch", str(odd)], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(world)]
+    outs = [p.communicate(timeout=60) for p in procs]
+    assert time.monotonic() - t0 < 15
+    for r, (p, (out, err)) in enumerate(zip(procs, outs)):
+        assert p.returncode == 5 and out.strip() == "%d refused" % r, (r, p.returncode, out, err)
+    assert "differ in length" in outs[0][1]
+
+
+@pytest.mark.parametrize("world,absent", [(2, 1), (3, 0), (4, 3)])
+def test_host_site_group_abort_hook_frees_a_blocked_reducer(tmp_path, world, absent):
+    """rdamd_model_set_lnl_reducer_abort's contract on the host reducer: a rank that waits in a
+    reduction another rank never joins (that rank's round failed a moment earlier) gets out as
+    soon as its own abort hook is called from another thread."""
+    import subprocess
+    import time
+    exe = _rendezvous_exe(tmp_path)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    t0 = time.monotonic()
+    procs = [subprocess.Popen([exe, str(r), str(world), "abort", str(absent)], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(world)]
+    outs = [p.communicate(timeout=60) for p in procs]
+    assert time.monotonic() - t0 < 15
+    for r, (p, (out, err)) in enumerate(zip(procs, outs)):
+        if r == absent:
+            assert p.returncode == 0
+        else:
+            assert p.returncode == 6 and out.strip() == "%d aborted" % r, (r, p.returncode, out, err)
+
+
 @pytest.mark.parametrize("world,group", [(2, 2), (4, 2), (3, 1)])
 def test_rd_amd_rendezvous_and_host_site_group_sum(tmp_path, world, group):
     """rd_amd's own channel (csrc/tools/rendezvous.hpp): TCP star allgather + the
