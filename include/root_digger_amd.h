@@ -766,8 +766,10 @@ extern const uint64_t rdamd_map_bin[256];
  *   ncclAllReduce(values, values, n, ncclDouble, ncclSum, comm, stream)).
  * EVERY RANK OF THE GROUP MUST RECEIVE THE SAME BITS: the optimisers branch on these sums.  A
  * reducer that cannot promise that (see RDAMD_COMM_SUM_ALLREDUCE) forks the ranks' trajectories;
- * the lock-stepped search checks for it every round and fails at once (divergence guard,
- * csrc/lockstep_conductor.hpp) instead of waiting in a collective that no longer matches.
+ * the searches check for it with every reduction and fail at once (divergence guard: two or three
+ * extra words ride behind the values of every vector handed to the reducer -- csrc/model.cpp
+ * guard_check, csrc/lockstep_conductor.hpp) instead of waiting in a collective that no longer
+ * matches.
  * Return RDAMD_SUCCESS.  A site-sharded model runs its candidates sequentially
  * (rdamd_model_exhaustive_search) or in lock step in deterministic rounds
  * (rdamd_model_exhaustive_search_lockstep; every rank of the group with the same `in_flight`);

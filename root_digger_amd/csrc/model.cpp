@@ -101,6 +101,27 @@ double *model_t::reduce_scratch(size_t n) {
   return _d_reduce;
 }
 
+// The guard: every rank of the group must receive the same BITS from the
+// reducer -- the optimisers branch on them.  Two words ride behind every vector the model itself has
+// summed: 1.0 (comes back as the number of ranks G) and a 40-bit hash of the bits the PREVIOUS
+// reduction handed to this rank (must come back as G x own: exact, small integers in doubles).  A rank
+// whose copy differed by one ulp is found by the next reduction, on every rank, before its requests
+// can differ -- a failure with a reason instead of a collective that no longer matches.  (The rounds
+// of a lock-stepped search carry their own: lockstep_conductor.hpp.)
+constexpr size_t kGuardWords = 2;
+void model_t::guard_check(const double *sums, size_t n) {
+  const double ranks = sums[n];
+  if (!(ranks >= 1.0) || ranks != std::floor(ranks) || sums[n + 1] != ranks * _guard_prev)
+    throw std::runtime_error("site-group reduction " + std::to_string(_n_collectives) +
+                             ": the ranks did not receive the same bits from the previous reduction "
+                             "(every rank must get identical sums from the reducer; the library's default, "
+                             "ncclAllGather + a sum in rank order, does by construction)");
+  uint64_t h = 1469598103934665603ull;
+  const unsigned char *b = reinterpret_cast<const unsigned char *>(sums);
+  for (size_t i = 0; i < n * sizeof(double); ++i) h = (h ^ b[i]) * 1099511628211ull;
+  _guard_prev = (double)((h ^ (h >> 40)) & ((1ull << 40) - 1));
+}
+
 // host values in, their sums over the site group out (identical on every rank)
 void model_t::reduce_values(double *values, size_t n) {
   if (n == 0) return;
@@ -111,18 +132,26 @@ void model_t::reduce_values(double *values, size_t n) {
   if (!_reduce) return;
   ++_n_collectives;
   if (!_reduce_device) {
-    if (_reduce(values, (unsigned)n, nullptr, _reduce_user) != RDAMD_SUCCESS)
+    std::vector<double> v(values, values + n);
+    v.resize(n + kGuardWords);
+    guard_fill(v.data() + n);
+    if (_reduce(v.data(), (unsigned)v.size(), nullptr, _reduce_user) != RDAMD_SUCCESS)
       throw std::runtime_error("site-group reduction failed");
+    guard_check(v.data(), n);
+    std::copy(v.begin(), v.begin() + n, values);
     return;
   }
-  double *d = reduce_scratch(n);
+  const size_t m = n + kGuardWords;
+  double *d = reduce_scratch(m);
   hipStream_t st = (hipStream_t)rdamd_partition_stream(_partitions[0]);
   std::copy(values, values + n, _h_reduce);
-  if (hipMemcpyAsync(d, _h_reduce, n * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess ||
-      _reduce(d, (unsigned)n, st, _reduce_user) != RDAMD_SUCCESS ||
-      hipMemcpyAsync(_h_reduce, d, n * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess ||
+  guard_fill(_h_reduce + n);
+  if (hipMemcpyAsync(d, _h_reduce, m * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess ||
+      _reduce(d, (unsigned)m, st, _reduce_user) != RDAMD_SUCCESS ||
+      hipMemcpyAsync(_h_reduce, d, m * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess ||
       hipStreamSynchronize(st) != hipSuccess)
     throw std::runtime_error(std::string("site-group reduction failed: ") + rdamd_errmsg());
+  guard_check(_h_reduce, n);
   std::copy(_h_reduce, _h_reduce + n, values);
 }
 
@@ -947,17 +976,22 @@ double model_t::bfgs_params(model_params_t &initial, size_t pi, bfgs_target what
                           weights.data(), out.data());
     } else if (_reduce && _reduce_device) {
       ++_n_collectives;
-      // site-sharded: the per-block lnLs stay on the device, the all-reduce is queued
-      // behind the batch on the partition's stream, one copy brings the sums back
-      double *d = reduce_scratch(m);
+      // site-sharded: the per-block lnLs stay on the device, the group's sum is queued
+      // behind the batch on the partition's stream (the guard's two words behind the lnLs),
+      // one copy brings the sums back
+      double *d = reduce_scratch(m + kGuardWords);
       hipStream_t st = (hipStream_t)rdamd_partition_stream(part);
       if (rdamd_evaluate_batch_device(part, (unsigned)m, scheds.data(), subst.data(), freqs.data(),
                                       rates.data(), weights.data(), d) != RDAMD_SUCCESS)
         fail("evaluate_batch");
-      if (_reduce(d, (unsigned)m, st, _reduce_user) != RDAMD_SUCCESS ||
-          hipMemcpyAsync(out.data(), d, m * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess ||
+      guard_fill(_h_reduce + m);
+      if (hipMemcpyAsync(d + m, _h_reduce + m, kGuardWords * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess ||
+          _reduce(d, (unsigned)(m + kGuardWords), st, _reduce_user) != RDAMD_SUCCESS ||
+          hipMemcpyAsync(_h_reduce, d, (m + kGuardWords) * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess ||
           hipStreamSynchronize(st) != hipSuccess)
-        throw std::runtime_error("site-group reduction failed");
+        throw std::runtime_error(std::string("site-group reduction failed: ") + rdamd_errmsg());
+      guard_check(_h_reduce, m);
+      std::copy(_h_reduce, _h_reduce + m, out.begin());
     } else {
       if (rdamd_evaluate_batch(part, (unsigned)m, scheds.data(), subst.data(), freqs.data(),
                                rates.data(), weights.data(), out.data()) != RDAMD_SUCCESS)

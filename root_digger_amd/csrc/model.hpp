@@ -307,6 +307,11 @@ private:
   std::vector<model_params_t>            _empirical;           // [partition]: empirical frequencies, once computed
   bool                                   _empirical_adopted = false;   // ... by the model this replica was made from
   uint64_t                               _n_collectives = 0;
+  // the divergence guard of the model's OWN reductions (model.cpp, reduce_values): two words ride
+  // behind every vector -- 1.0 and a 40-bit hash of the bits the previous reduction returned
+  double                                 _guard_prev = 0.0;
+  void guard_fill(double *tail) const { tail[0] = 1.0; tail[1] = _guard_prev; }
+  void guard_check(const double *sums, size_t n);   // throws; then remembers sums[0 .. n)
   double                                *_d_reduce = nullptr;
   size_t                                 _d_reduce_cap = 0;
   double                                *_h_reduce = nullptr;   // pinned twin of _d_reduce

@@ -375,19 +375,22 @@ def test_early_stop_records_differ_from_the_plain_exhaustive_ones(tmp_path):
     assert ra != rb
 
 
-def test_one_ulp_on_one_rank_ends_the_run_at_once_naming_the_round(tmp_path):
+@pytest.mark.parametrize("lockstep", ["8", "0"])
+def test_one_ulp_on_one_rank_ends_the_run_at_once_naming_the_round(tmp_path, lockstep):
     """The rounds rest on every rank of a site group receiving the same BITS from the reducer
     (csrc/lockstep_conductor.hpp, header).  Here rank 1's copy of the sums of its 40th reduction
     is off by one unit in the last place (rendezvous.hpp's fault hook) -- what an all-reduce
     without a bit-identity promise may deliver.  Unnoticed, the two ranks' optimisers part ways
     and some later round no longer matches: a hang until the communicator's time limit.  With the
-    guard the very next round of that worker group fails on BOTH ranks, by its number, in seconds."""
+    guard the very next round of that worker group fails on BOTH ranks, by its number, in seconds.
+    lockstep 0: the sequential sharded search (a collective per request) -- the model's own
+    reductions carry the same two guard words (csrc/model.cpp, guard_check) and name the reduction."""
     if not os.path.exists(REF):
         pytest.skip("oracle/_ref/liblbfgsb_ref.so not built")
     import time
     args = [RD, "--msa", MSA, "--tree", TREE, "--exhaustive", "--silent", "--rate-cats", "4", "--atol", "0.5", "--brtol", "0.1",
             "--bfgstol", "0.5", "--factor", "1e15", "--seed", "5", "--lbfgsb", REF, "--device", "0", "--site-shards", "2",
-            "--site-reduce", "host", "--lockstep", "8", "--prefix", str(tmp_path / "f")]
+            "--site-reduce", "host", "--lockstep", lockstep, "--prefix", str(tmp_path / "f")]
     s = __import__("socket").socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
@@ -401,7 +404,10 @@ def test_one_ulp_on_one_rank_ends_the_run_at_once_naming_the_round(tmp_path):
     took = time.time() - t0
     assert all(p.returncode != 0 for p in procs), outs
     text = "".join(o + e for o, e in outs)
-    mt = re.search(r"lock-step round (\d+) of worker group \d+ .*has diverged -- the ranks did not receive the same bits", text)
+    if lockstep == "0":
+        mt = re.search(r"site-group reduction (\d+): the ranks did not receive the same bits from the previous reduction", text)
+    else:
+        mt = re.search(r"lock-step round (\d+) of worker group \d+ .*has diverged -- the ranks did not receive the same bits", text)
     assert mt, text[-3000:]
     assert took < 60, took                  # (start-up included; the comm time limit is 600 s)
 
