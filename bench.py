@@ -215,6 +215,9 @@ def main():
     ap.add_argument("--no-repeats", action="store_true",
                     help="4-state partitions: without RDAMD_ATTRIB_SITE_REPEATS (the reference sets "
                          "CORAX_ATTRIB_SITE_REPEATS for every 4-state run, src/model.cpp:145-149; A/B only)")
+    ap.add_argument("--rescale-speculation", type=int, default=-1, choices=(-1, 0, 1),
+                    help="rdamd_partition_set_rescale_speculation: -1 the library's default (on up to 256 "
+                         "tips), 0 rescale tests on every step, 1 on (A/B only)")
     ap.add_argument("--allow-stale-profile", action="store_true",
                     help="publish the line without `traffic` / `issue` when the committed counter "
                          "summary was taken from other kernel sources (default: fail)")
@@ -346,6 +349,8 @@ def main():
     part = rd.Partition.for_tree(tree, K, S, R, attributes=rd.ATTRIB_SITE_REPEATS if repeats else 0)
     if repeats and args.repeat_classes is not None:
         part.set_site_repeats(args.repeat_classes)
+    if K == 4 and args.rescale_speculation != -1:
+        part.set_rescale_speculation(args.rescale_speculation)
     for label, seq in w["seqs"].items():
         part.set_tip_states(tree.tip_index(label), cmap, seq)
     if data_weights is not None:
@@ -843,7 +848,7 @@ def main():
         # launches -- --sites, --shard, --as-candidate-group, --repeat-classes, --no-repeats -- gets none
         default_cmd = (args.config in ("c2", "c3") and nb == 197 and (repeats or K != 4) and world == 1 and
                        args.sites is None and args.shard == "candidates" and args.as_candidate_group is None and
-                       args.repeat_classes is None and not args.one_rank_comm)
+                       args.repeat_classes is None and not args.one_rank_comm and args.rescale_speculation == -1)
         try:
             if default_cmd:
                 roofline.update(profiled_issue(fused_kernel, nb, args.config))

@@ -291,6 +291,18 @@ int rdamd_evaluate_batch(rdamd_partition_t *p, unsigned int n_jobs,
                          const double *subst, const double *freqs,
                          const double *rates, const double *rate_weights,
                          double *lnl_out);
+/* The 4-state evaluator's rescaling policy.  The reference's 2^256 rule keeps
+ * CLVs of large trees inside the FP64 range; up to a few hundred tips nothing comes near its end
+ * (2^-1022), and the rule only moves exponents.  mode 1: a batch's first pass runs WITHOUT the
+ * rescale tests and checks every site's rate sum at the root instead; a job with a sum below 2^-900
+ * (or zero) is evaluated again by the second pass -- plain program, every test --, as a job with
+ * tiny table entries always was: no result is ever taken from a traversal that came near the
+ * range's end.  mode 0: tests on every step (rounds 1 - 5).  mode -1 (the default): 1 for
+ * partitions of up to 256 tips, 0 beyond (a 500-tip tree sends every job to the second pass).
+ * A job's value depends on the job and the partition's mode only, never on what shares its batch.
+ * rdamd_evaluate_second_passes: batches of this partition that needed their second pass so far. */
+int rdamd_partition_set_rescale_speculation(rdamd_partition_t *p, int mode);
+unsigned long long rdamd_evaluate_second_passes(const rdamd_partition_t *p);
 /* Same, but the n_jobs results are left in DEVICE memory at d_lnl_out (e.g. a
  * tensor that an RCCL all-reduce sums over site-sharded ranks next).  The call BLOCKS like
  * rdamd_evaluate_batch: it returns after the partition's stream has finished writing the

@@ -116,6 +116,8 @@ _sig("rdamd_evaluate_batch_finish_device", C.c_int, _vp, _u)
 _sig("rdamd_partition_discard_clvs", None, _vp)
 _sig("rdamd_partition_clv_bytes", C.c_uint64, _vp)
 _sig("rdamd_update_clvs_launches", C.c_uint, _vp)
+_sig("rdamd_partition_set_rescale_speculation", C.c_int, _vp, C.c_int)
+_sig("rdamd_evaluate_second_passes", C.c_ulonglong, _vp)
 _sig("rdamd_evaluate_root_children", C.c_int, _vp, _pop, _u, _pu, _pd, _u, _pd, _pd, _pd, _pd, _pd)
 _sig("rdamd_get_clv", C.c_int, _vp, _u, _pd)
 _sig("rdamd_get_scaler", C.c_int, _vp, _u, _pu)
@@ -858,6 +860,16 @@ class Partition:
         """kernel launches the last update_clvs call took (a list that leaves the device empty is
         cut into independent subtrees, one launch per level of the cut)"""
         return int(lib.rdamd_update_clvs_launches(self._h))
+
+    def set_rescale_speculation(self, mode):
+        """-1 default (on up to 256 tips), 0 rescale tests on every step, 1 no tests in the first pass
+        + a check of every site's sum at the root (include/root_digger_amd.h)"""
+        if lib.rdamd_partition_set_rescale_speculation(self._h, int(mode)) != 1:
+            _fail("set_rescale_speculation")
+
+    def second_passes(self):
+        """batches of this partition that needed their second evaluator pass so far"""
+        return int(lib.rdamd_evaluate_second_passes(self._h))
 
     def clv_bytes(self):
         """device bytes the CLV and scale buffers hold right now"""

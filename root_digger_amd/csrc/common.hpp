@@ -138,6 +138,8 @@ struct rdamd_partition {
   std::vector<int> clv_slot, sc_slot;            // caller's index -> slot, or -1
   unsigned  clv_slots_used = 0, clv_slots_cap = 0, sc_slots_used = 0, sc_slots_cap = 0;
   unsigned  last_clv_launches = 0;   // rdamd_update_clvs_launches
+  int       rescale_speculation = -1;   // rdamd_partition_set_rescale_speculation
+  std::atomic<unsigned long long> second_passes{0};   // rdamd_evaluate_second_passes
   double   *d_pmat = nullptr;
   double   *d_tiptab = nullptr;
   double   *d_pmat_mfma = nullptr;   // 20-state only: MFMA-ready copy of d_pmat

@@ -53,6 +53,8 @@ namespace rdamd {
 // doubles in front of the tables: the 64-row evaluator's buffer descriptor starts kFusedDmaBias
 // bytes before a job's tables (kernels_fused.hip, RDAMD_LOAD_TABS64)
 constexpr size_t kTiptabPad = kFusedDmaBias / 8;
+// tips up to which a partition speculates by default (include/root_digger_amd.h, rdamd_partition_set_rescale_speculation)
+constexpr unsigned kSpeculateTips = 256;
 
 struct FusedWorkspace {
   unsigned cap_jobs = 0, blocks_x = 0;
@@ -812,6 +814,15 @@ static int batch_submit_impl(rdamd_partition_t *p, FusedWorkspace *&slot, bool p
 #ifdef RDAMD_ABLATION
     if (getenv("RDAMD_FUSED_RW")) a.rates_across_waves = atoi(getenv("RDAMD_FUSED_RW")) != 0 && R >= 2 && R <= 8;
 #endif
+    // No rescale tests in the first pass, a check of every site's sum at the root instead
+    // (kernels_fused.hip, SPEC; include/root_digger_amd.h): where a tree is small enough that the
+    // check practically never fails -- per-site likelihoods of a 256-tip alignment stay hundreds of
+    // binades above 2^-900 --, never for the launches with one wave per rate category (deep trees), and
+    // for the 64-row schedules only (the two-sites 16-row kernel needs 129 VGPRs without the tests, 126
+    // with them: it would lose its fourth wave per SIMD; a schedule's row count is the job's own, so the
+    // rule still looks at nothing but the job).
+    a.speculate = (p->rescale_speculation < 0 ? p->tips <= kSpeculateTips : p->rescale_speculation > 0) &&
+                  !a.rates_across_waves && table_rows > 16;
     unsigned *export_scaler[2] = {nullptr, nullptr};
     if (export_children) {
       // where the root operation's inner children go: the partition's own CLV / scaler buffers
@@ -841,6 +852,7 @@ static int batch_submit_impl(rdamd_partition_t *p, FusedWorkspace *&slot, bool p
       }
       a.rates_across_waves = 0;
       a.job_major = 0;
+      a.speculate = 0;
     }
     if (!pipelined) p->prof_begin(4);
     e = launch_fused_pmatrix(a, w->d_q, w->d_rates, n_jobs, p->prob_matrices, pipelined, pre);
@@ -946,6 +958,7 @@ static int batch_wait(rdamd_partition_t *p, FusedWorkspace *w, bool pipelined, d
   else WAIT_TRY(sync_main(p));
   const unsigned *h_flag = (const unsigned *)(w->h_out + w->cap_jobs);
   if (!pd.k20 && *h_flag) {
+    p->second_passes.fetch_add(1, std::memory_order_relaxed);
     hipError_t e = hipSuccess;
     {
       std::lock_guard<std::mutex> guard(p->launch_mu);
@@ -974,6 +987,21 @@ static int batch_wait(rdamd_partition_t *p, FusedWorkspace *w, bool pipelined, d
   completed();
   if (lnl_host && pd.host_out) memcpy(lnl_host, w->h_out, sizeof(double) * pd.n_jobs);
   return RDAMD_SUCCESS;
+}
+
+int rdamd_partition_set_rescale_speculation(rdamd_partition_t *p, int mode) {
+  clear_error();
+  if (mode < -1 || mode > 1) {
+    set_error(51, "rdamd_partition_set_rescale_speculation: mode %d (-1 default, 0 off, 1 on)", mode);
+    return RDAMD_FAILURE;
+  }
+  std::lock_guard<std::mutex> guard(p->launch_mu);
+  p->rescale_speculation = mode;
+  return RDAMD_SUCCESS;
+}
+
+unsigned long long rdamd_evaluate_second_passes(const rdamd_partition_t *p) {
+  return p->second_passes.load(std::memory_order_relaxed);
 }
 
 int rdamd_evaluate_batch(rdamd_partition_t *p, unsigned int n_jobs,
@@ -1059,6 +1087,7 @@ int rdamd_evaluate_batch_redo_device(rdamd_partition_t *p, unsigned int slot, vo
   const unsigned *h_flag = (const unsigned *)(w->h_out + w->cap_jobs);
   std::lock_guard<std::mutex> guard(p->launch_mu);
   if (!pd.k20 && *h_flag) {   // THIS rank's jobs need the pass (batch_wait has the notes)
+    p->second_passes.fetch_add(1, std::memory_order_relaxed);
     const bool wide_codes = pd.a.table_rows > 16;
     if (wide_codes) RDAMD_HIP_TRY(ensure_wide_arena(p), RDAMD_FAILURE);
     pd.a.tipcodes = wide_codes ? p->d_codes_wide : p->d_tipcodes16;

@@ -99,6 +99,8 @@ struct FusedArgs {
   unsigned job_major;                // 1: every XCD walks WHOLE jobs (job j on XCD j % 8) instead of an eighth of
                                      // the sites of every job: its L2 then sees the tables of the one or two jobs it
                                      // is working on (deep trees: 4 MB of tables per job) -- grid.y is padded to x8
+  unsigned speculate;                // 1: the first pass runs WITHOUT rescale tests and sends a job whose smallest site sum
+                                     // is below 2^-900 to the second pass (kernels_fused.hip, SPEC; evaluate.hip decides)
   // the exporting variant only (rdamd_evaluate_root_children): where the CLVs of the root operation's
   // two children go ([site][rate][4], the partition's own buffers; null for a tip child) and their
   // rescale counts per (site, rate) ([site][rate]; launch_fused_export turns them into per-site scalers)

@@ -222,13 +222,31 @@ constexpr bool kTestRT = true, kTestRP = true;
 // these memory instructions: its own counted waits only get stricter by them, and the pop
 // waits for its data itself.
 typedef double f64x2_t __attribute__((ext_vector_type(2)));
-template <int NS>
+// CNT = false (the speculative variant: every rescale count is zero): the entry without its count
+template <int NS, bool CNT = true>
 __device__ __forceinline__ void stack_push(unsigned sp, unsigned flags, int q, unsigned stk_lds,
                                            unsigned stksc_lds, unsigned spill_off, const double (&v)[4], int sc) {
   const f64x2_t lo = {v[0], v[1]}, hi = {v[2], v[3]};
   const unsigned la = stk_lds + q * 2048u, lsc = stksc_lds + q * 256u;
   sp = uni(sp);   // (wave-uniform by construction; not every variant's compiler pass sees it)
   const unsigned so = spill_off + (sp * NS + q) * 48u;
+  if constexpr (!CNT) {
+    asm volatile(
+        "s_bitcmp1_b32 %[fl], 17\n\t"   /* 0x20000: into the LDS slot */
+        "s_cbranch_scc1 1f\n\t"
+        "scratch_store_dwordx4 off, %[lo], %[so]\n\t"
+        "scratch_store_dwordx4 off, %[hi], %[so] offset:16\n\t"
+        "s_branch 2f\n"
+        "1:\n\t"
+        "ds_write_b128 %[la], %[lo]\n\t"
+        "ds_write_b128 %[la], %[hi] offset:1024\n"
+        "2:\n\t"
+        "s_nop 0"
+        :
+        : [fl] "s"(uni(flags)), [lo] "v"(lo), [hi] "v"(hi), [so] "s"(so), [la] "v"(la)
+        : "memory", "scc");
+    return;
+  }
   asm volatile(
       "s_bitcmp1_b32 %[fl], 17\n\t"   /* 0x20000: into the LDS slot */
       "s_cbranch_scc1 1f\n\t"
@@ -279,13 +297,30 @@ __device__ __forceinline__ void stack_pop(unsigned sp, unsigned flags, int q, un
 // evicted from L2 takes a microsecond to come back, and with the wait inside the pop nothing of
 // the wave's own work covered it.  (The wait statement takes the values as in / out operands:
 // that is what orders their uses behind it.)
-template <int NS>
+template <int NS, bool CNT = true>
 __device__ __forceinline__ void stack_pop_issue(unsigned sp, unsigned flags, int q, unsigned stk_lds,
                                                 unsigned stksc_lds, unsigned spill_off, f64x2_t &lo, f64x2_t &hi,
                                                 int &sc) {
   const unsigned la = stk_lds + q * 2048u, lsc = stksc_lds + q * 256u;
   sp = uni(sp);
   const unsigned so = spill_off + (sp * NS + q) * 48u;
+  if constexpr (!CNT) {
+    sc = 0;
+    asm volatile(
+        "s_bitcmp1_b32 %[fl], 18\n\t"   /* 0x40000: from the LDS slot */
+        "s_cbranch_scc1 1f\n\t"
+        "scratch_load_dwordx4 %[lo], off, %[so]\n\t"
+        "scratch_load_dwordx4 %[hi], off, %[so] offset:16\n\t"
+        "s_branch 2f\n"
+        "1:\n\t"
+        "ds_read_b128 %[lo], %[la]\n\t"
+        "ds_read_b128 %[hi], %[la] offset:1024\n"
+        "2:"
+        : [lo] "=&v"(lo), [hi] "=&v"(hi)
+        : [fl] "s"(uni(flags)), [so] "s"(so), [la] "v"(la)
+        : "memory", "scc");
+    return;
+  }
   asm volatile(
       "s_bitcmp1_b32 %[fl], 18\n\t"   /* 0x40000: from the LDS slot */
       "s_cbranch_scc1 1f\n\t"
@@ -302,9 +337,14 @@ __device__ __forceinline__ void stack_pop_issue(unsigned sp, unsigned flags, int
       : [fl] "s"(uni(flags)), [so] "s"(so), [la] "v"(la), [lsc] "v"(lsc)
       : "memory", "scc");
 }
-template <int NS>
+template <int NS, bool CNT = true>
 __device__ __forceinline__ void stack_pop_wait(f64x2_t (&lo)[NS], f64x2_t (&hi)[NS], int (&sc)[NS]) {
-  if constexpr (NS == 2)
+  if constexpr (!CNT) {
+    if constexpr (NS == 2)
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(lo[0]), "+v"(hi[0]), "+v"(lo[1]), "+v"(hi[1])::"memory");
+    else
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(lo[0]), "+v"(hi[0])::"memory");
+  } else if constexpr (NS == 2)
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)"
                  : "+v"(lo[0]), "+v"(hi[0]), "+v"(sc[0]), "+v"(lo[1]), "+v"(hi[1]), "+v"(sc[1])::"memory");
   else
@@ -394,9 +434,23 @@ __device__ unsigned rdamd_stamp_cfg[2] = {0xffffffffu, 1u};   // job, workgroup 
 // EXPORT (rdamd_evaluate_root_children): the steps the host flagged (0x8000 / 0x10000: they compute the
 // root operation's two children) also store the running CLV and its rescale count -- the one thing
 // of a traversal the root-only steps of the search need afterwards (a6, src/model.cpp:415-446).
-template <int NS, bool TTCHECK, int RL, int TR, bool RW, int SP, bool EXPORT = false>
+// SPEC ("speculative", round 6; FusedArgs::speculate, evaluate.hip decides): NO rescale test at all in
+// the variant on the programs with pseudo-tips.  FP64 reaches down to 2^-1022 and the largest entry of
+// a (site, rate) vector can only shrink on the way to the root (the rows of a P-matrix sum to 1, every
+// entry lies in [0, 1]): if a site's rate sum AT THE ROOT is still >= 2^-900, nothing that matters to
+// it has come near the end of the range -- a category that did underflow on the way is < 2^-1021 in
+// truth and as computed, 2^-121 of the sum -- and the 2^256 rule, whose factors are exact powers of
+// two, would have changed exponents only.  A wave that finds a smaller sum raises its job's
+// tt_unsafe flag and the batch's word, exactly as a small table entry does: the job then runs in the
+// second pass, plain program, every test (the flag is per job, whatever the launch looks like, so a
+// job's value still depends on the job alone).  What it buys: the tests are 6 of a step's 59 vector
+// instructions, and without them the step loses a branch and the rescale arm behind every product
+// (profiles/r6_speculative_rescale.md: c2 2.45 -> 2.25 ms per launch).
+template <int NS, bool TTCHECK, int RL, int TR, bool RW, int SP, bool EXPORT = false, bool SPEC = false>
 __global__ void __launch_bounds__(RW ? 512 : 64)
 fused_dna_eval_kernel(FusedArgs a) {
+  static_assert(!SPEC || (!TTCHECK && !RW && !EXPORT), "the speculative variant: first pass, one wave per workgroup");
+  constexpr bool kRT = kTestRT && !SPEC, kRP = kTestRP && !SPEC;
   extern __shared__ double lds[];
   // (read_row<> and the table writes address LDS bytes 0 and 32 TR absolutely: that
   // is the dynamic block only while this kernel has no static __shared__ in front of
@@ -716,24 +770,24 @@ fused_dna_eval_kernel(FusedArgs a) {
         if (kind & 0x200u) { /* stack level 0 lives in registers: the product lands there */    \
           _Pragma("unroll") for (int q = 0; q < NS; ++q) {                                      \
             matvec(M, st.v[q], s0[q]);                                                          \
-            s0sc[q] = st.sc[q];                                                                 \
+            if (!SPEC) s0sc[q] = st.sc[q];                                                      \
           }                                                                                     \
         } else if (RL >= 2 && (kind & 0x800u)) { /* ... and so does level 1 */                  \
           _Pragma("unroll") for (int q = 0; q < NS; ++q) {                                      \
             matvec(M, st.v[q], s1[q]);                                                          \
-            s1sc[q] = st.sc[q];                                                                 \
+            if (!SPEC) s1sc[q] = st.sc[q];                                                      \
           }                                                                                     \
         } else {                                                                                \
           _Pragma("unroll") for (int q = 0; q < NS; ++q) {                                      \
             double tp[4];                                                                       \
             matvec(M, st.v[q], tp);                                                             \
             if (SP > 0) {                                                                       \
-              stack_push<NS>(sp, kind, q, stk_lds, stksc_lds, spill_off, tp, st.sc[q]);         \
+              stack_push<NS, !SPEC>(sp, kind, q, stk_lds, stksc_lds, spill_off, tp, st.sc[q]);  \
             } else {                                                                            \
               double2 *d = stk + (size_t)(sp * NS + q) * 128;                                   \
               d[0] = make_double2(tp[0], tp[1]);                                                \
               d[64] = make_double2(tp[2], tp[3]);                                               \
-              stk_sc[(sp * NS + q) * 64] = st.sc[q];                                            \
+              if (!SPEC) stk_sc[(sp * NS + q) * 64] = st.sc[q];                                 \
             }                                                                                   \
           }                                                                                     \
           if (SP == 0 || !(kind & 0x20000u)) ++sp;   /* (SP > 0: the private segment's entries) */ \
@@ -756,7 +810,7 @@ fused_dna_eval_kernel(FusedArgs a) {
       _Pragma("unroll") for (int q = 0; q < NS; ++q) matvec(M, st.v[q], tx[q]);                 \
       RDAMD_STAMP(3)                                                                            \
       RDAMD_LOAD_M(nxt, M)                                                                      \
-      combine_sites<NS, kTestRT>(tx, ty, st.v, st.sc);                                          \
+      combine_sites<NS, kRT>(tx, ty, st.v, st.sc);                                          \
     } else { /* kFusedRP: running CLV times M, sibling already multiplied when parked */        \
       if (kind & 0x400u) { /* the sibling waits in the register slot: used in place */          \
         RDAMD_STAMP(1)                                                                          \
@@ -765,8 +819,8 @@ fused_dna_eval_kernel(FusedArgs a) {
         _Pragma("unroll") for (int q = 0; q < NS; ++q) matvec(M, st.v[q], tx[q]);               \
         RDAMD_STAMP(3)                                                                          \
         RDAMD_LOAD_M(nxt, M)                                                                    \
-        _Pragma("unroll") for (int q = 0; q < NS; ++q) st.sc[q] += s0sc[q];                     \
-        combine_sites<NS, kTestRP>(tx, s0, st.v, st.sc);                                                 \
+        if (!SPEC) { _Pragma("unroll") for (int q = 0; q < NS; ++q) st.sc[q] += s0sc[q]; }      \
+        combine_sites<NS, kRP>(tx, s0, st.v, st.sc);                                                 \
       } else if (RL >= 2 && (kind & 0x1000u)) {                                                 \
         RDAMD_STAMP(1)                                                                          \
         RDAMD_LOAD_TIPS(nxt, ncx, ncy, nex, ney) RDAMD_LATE_DESC(cur, idx2)                     \
@@ -774,20 +828,20 @@ fused_dna_eval_kernel(FusedArgs a) {
         _Pragma("unroll") for (int q = 0; q < NS; ++q) matvec(M, st.v[q], tx[q]);               \
         RDAMD_STAMP(3)                                                                          \
         RDAMD_LOAD_M(nxt, M)                                                                    \
-        _Pragma("unroll") for (int q = 0; q < NS; ++q) st.sc[q] += s1sc[q];                     \
-        combine_sites<NS, kTestRP>(tx, s1, st.v, st.sc);                                                 \
+        if (!SPEC) { _Pragma("unroll") for (int q = 0; q < NS; ++q) st.sc[q] += s1sc[q]; }      \
+        combine_sites<NS, kRP>(tx, s1, st.v, st.sc);                                                 \
       } else {                                                                                  \
         int scy[NS];                                                                            \
         f64x2_t plo[NS], phi[NS];                                                               \
         if (SP == 0 || !(kind & 0x40000u)) --sp;                                                \
         _Pragma("unroll") for (int q = 0; q < NS; ++q) {                                        \
           if (SP > 0) {   /* issued here, awaited behind the product (stack_pop_issue) */       \
-            stack_pop_issue<NS>(sp, kind, q, stk_lds, stksc_lds, spill_off, plo[q], phi[q], scy[q]); \
+            stack_pop_issue<NS, !SPEC>(sp, kind, q, stk_lds, stksc_lds, spill_off, plo[q], phi[q], scy[q]); \
           } else {                                                                              \
             const double2 *d = stk + (size_t)(sp * NS + q) * 128;                               \
             const double2 lo = d[0], hi = d[64];                                                \
             ty[q][0] = lo.x; ty[q][1] = lo.y; ty[q][2] = hi.x; ty[q][3] = hi.y;                 \
-            scy[q] = stk_sc[(sp * NS + q) * 64];                                                \
+            scy[q] = SPEC ? 0 : stk_sc[(sp * NS + q) * 64];                                     \
           }                                                                                     \
         }                                                                                       \
         RDAMD_STAMP(1)                                                                          \
@@ -797,13 +851,13 @@ fused_dna_eval_kernel(FusedArgs a) {
         RDAMD_STAMP(3)                                                                          \
         RDAMD_LOAD_M(nxt, M)                                                                    \
         if (SP > 0) {                                                                           \
-          stack_pop_wait<NS>(plo, phi, scy);                                                    \
+          stack_pop_wait<NS, !SPEC>(plo, phi, scy);                                             \
           _Pragma("unroll") for (int q = 0; q < NS; ++q) {                                      \
             ty[q][0] = plo[q].x; ty[q][1] = plo[q].y; ty[q][2] = phi[q].x; ty[q][3] = phi[q].y; \
           }                                                                                     \
         }                                                                                       \
-        _Pragma("unroll") for (int q = 0; q < NS; ++q) st.sc[q] += scy[q];                      \
-        combine_sites<NS, kTestRP>(tx, ty, st.v, st.sc);                                        \
+        if (!SPEC) { _Pragma("unroll") for (int q = 0; q < NS; ++q) st.sc[q] += scy[q]; }       \
+        combine_sites<NS, kRP>(tx, ty, st.v, st.sc);                                        \
       }                                                                                         \
     }                                                                                           \
     RDAMD_STAMP(4)                                                                              \
@@ -912,6 +966,15 @@ fused_dna_eval_kernel(FusedArgs a) {
           smin[q] = sc;
         }
       }
+    }
+  }
+  if constexpr (SPEC) {   // a site whose sum is below 2^-900 (or 0): the job goes to the second pass
+    bool low = false;
+#pragma unroll
+    for (int q = 0; q < NS; ++q) low = low || (valid[q] && (unsigned)__double2hiint(term[q]) < 0x07B00000u);
+    if (__builtin_amdgcn_ballot_w64(low) != 0ull && lane == 0) {
+      const_cast<FusedJob *>(a.jobs)[job].tt_unsafe = 1u;   // (every writer stores the same value)
+      *a.any_unsafe = 1u;
     }
   }
   // One partial sum per 64-SITE BLOCK, whatever the number of sites per lane: a job's value
@@ -1173,7 +1236,7 @@ hipError_t launch_fused_pmatrix(const FusedArgs &a, const double *d_q, const dou
   return hipGetLastError();
 }
 
-template <int NS, bool TTCHECK, int RL, int TR, bool RW, int SP, bool EXPORT = false>
+template <int NS, bool TTCHECK, int RL, int TR, bool RW, int SP, bool EXPORT = false, bool SPEC = false>
 static hipError_t launch_fused_variant(const FusedArgs &a, unsigned n_jobs, unsigned max_depth, unsigned gx,
                                        hipStream_t stream) {
   const unsigned n_waves = RW ? a.rate_cats : 1u;
@@ -1187,7 +1250,7 @@ static hipError_t launch_fused_variant(const FusedArgs &a, unsigned n_jobs, unsi
     static size_t lds_allowed = 48 * 1024;
     std::lock_guard<std::mutex> guard(lds_mu);
     if (lds > lds_allowed) {
-      hipError_t e = hipFuncSetAttribute((const void *)fused_dna_eval_kernel<NS, TTCHECK, RL, TR, RW, SP, EXPORT>,
+      hipError_t e = hipFuncSetAttribute((const void *)fused_dna_eval_kernel<NS, TTCHECK, RL, TR, RW, SP, EXPORT, SPEC>,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return e;
       lds_allowed = lds;
@@ -1195,11 +1258,11 @@ static hipError_t launch_fused_variant(const FusedArgs &a, unsigned n_jobs, unsi
   }
   static const bool lds_starts_at_zero = [] {   // see the note at the top of the kernel
     hipFuncAttributes attr;
-    return hipFuncGetAttributes(&attr, (const void *)fused_dna_eval_kernel<NS, TTCHECK, RL, TR, RW, SP, EXPORT>) == hipSuccess &&
+    return hipFuncGetAttributes(&attr, (const void *)fused_dna_eval_kernel<NS, TTCHECK, RL, TR, RW, SP, EXPORT, SPEC>) == hipSuccess &&
            attr.sharedSizeBytes == 0;
   }();
   if (!lds_starts_at_zero) return hipErrorInvalidValue;
-  fused_dna_eval_kernel<NS, TTCHECK, RL, TR, RW, SP, EXPORT><<<dim3(gx, a.job_major ? (n_jobs + 7u) / 8u * 8u : n_jobs), 64 * n_waves, lds, stream>>>(a);
+  fused_dna_eval_kernel<NS, TTCHECK, RL, TR, RW, SP, EXPORT, SPEC><<<dim3(gx, a.job_major ? (n_jobs + 7u) / 8u * 8u : n_jobs), 64 * n_waves, lds, stream>>>(a);
   return hipGetLastError();
 }
 
@@ -1222,6 +1285,12 @@ static hipError_t launch_fused_variant_rl(const FusedArgs &a, unsigned n_jobs, u
     return reg_levels >= 2 ? launch_fused_variant<NS, TTCHECK, 2, TR, true, 0>(a, n_jobs, max_depth, gx, stream)
                            : launch_fused_variant<NS, TTCHECK, 1, TR, true, 0>(a, n_jobs, max_depth, gx, stream);
   }
+  if constexpr (!TTCHECK)
+    if (a.speculate) {   // (never with rates across waves: evaluate.hip)
+      if (spill) return launch_fused_variant<NS, false, 1, TR, false, kFusedSpillLevels, false, true>(a, n_jobs, max_depth, gx, stream);
+      return reg_levels >= 2 ? launch_fused_variant<NS, false, 2, TR, false, 0, false, true>(a, n_jobs, max_depth, gx, stream)
+                             : launch_fused_variant<NS, false, 1, TR, false, 0, false, true>(a, n_jobs, max_depth, gx, stream);
+    }
   if (spill) return launch_fused_variant<NS, TTCHECK, 1, TR, false, kFusedSpillLevels>(a, n_jobs, max_depth, gx, stream);
   return reg_levels >= 2 ? launch_fused_variant<NS, TTCHECK, 2, TR, false, 0>(a, n_jobs, max_depth, gx, stream)
                          : launch_fused_variant<NS, TTCHECK, 1, TR, false, 0>(a, n_jobs, max_depth, gx, stream);
