@@ -822,7 +822,7 @@ static int batch_submit_impl(rdamd_partition_t *p, FusedWorkspace *&slot, bool p
     // with them: it would lose its fourth wave per SIMD; a schedule's row count is the job's own, so the
     // rule still looks at nothing but the job).
     a.speculate = (p->rescale_speculation < 0 ? p->tips <= kSpeculateTips : p->rescale_speculation > 0) &&
-                  !a.rates_across_waves && table_rows > 16;
+                  !a.rates_across_waves;
     unsigned *export_scaler[2] = {nullptr, nullptr};
     if (export_children) {
       // where the root operation's inner children go: the partition's own CLV / scaler buffers
