@@ -817,12 +817,11 @@ static int batch_submit_impl(rdamd_partition_t *p, FusedWorkspace *&slot, bool p
     // No rescale tests in the first pass, a check of every site's sum at the root instead
     // (kernels_fused.hip, SPEC; include/root_digger_amd.h): where a tree is small enough that the
     // check practically never fails -- per-site likelihoods of a 256-tip alignment stay hundreds of
-    // binades above 2^-900 --, never for the launches with one wave per rate category (deep trees), and
-    // for the 64-row schedules only (the two-sites 16-row kernel needs 129 VGPRs without the tests, 126
-    // with them: it would lose its fourth wave per SIMD; a schedule's row count is the job's own, so the
-    // rule still looks at nothing but the job).
-    a.speculate = (p->rescale_speculation < 0 ? p->tips <= kSpeculateTips : p->rescale_speculation > 0) &&
-                  !a.rates_across_waves;
+    // binades above 2^-900.  The rule looks at the partition's mode and tip count only -- nothing a
+    // batch, or a code arena that grows as schedules are compiled, could change; the speculative
+    // kernels are one-wave workgroups, so such a launch does without one wave per rate category.
+    a.speculate = p->rescale_speculation < 0 ? p->tips <= kSpeculateTips : p->rescale_speculation > 0;
+    if (a.speculate) a.rates_across_waves = 0;
     unsigned *export_scaler[2] = {nullptr, nullptr};
     if (export_children) {
       // where the root operation's inner children go: the partition's own CLV / scaler buffers

@@ -446,6 +446,8 @@ __device__ unsigned rdamd_stamp_cfg[2] = {0xffffffffu, 1u};   // job, workgroup 
 // job's value still depends on the job alone).  What it buys: the tests are 6 of a step's 59 vector
 // instructions, and without them the step loses a branch and the rescale arm behind every product
 // (profiles/r6_speculative_rescale.md: c2 2.45 -> 2.25 ms per launch).
+// (amdgpu_waves_per_eu: left alone, the two-sites 16-row variant comes out at 129 VGPRs without the
+// tests -- 126 with them -- and loses its fourth wave per SIMD; asked for four it takes 120.)
 template <int NS, bool TTCHECK, int RL, int TR, bool RW, int SP, bool EXPORT = false, bool SPEC = false>
 __global__ void __launch_bounds__(RW ? 512 : 64) __attribute__((amdgpu_waves_per_eu((SPEC && NS == 2 && RL == 1 && TR == 16) ? 4 : 1)))
 fused_dna_eval_kernel(FusedArgs a) {
@@ -652,39 +654,6 @@ fused_dna_eval_kernel(FusedArgs a) {
     // each: profiles/r5_tabload_ab.txt; the ISA budget: profiles/r5_fused_step_isa.md).  The scalar
     // unit is not what a step waits for.  RDAMD_LOAD_TABS64 stays for the A/B (ablation builds,
     // -DRDAMD_ABL_ONE_TABLOAD).
-#if defined(RDAMD_ABLATION) && defined(RDAMD_ABL_EXEC_TABLOAD)
-    // A/B: no branch on the table's size -- both sizes are 16-byte pieces, a 16-row half table (256
-    // bytes) is the piece of lanes 0 - 15 (EXEC = 0xffff), a 64-row one the piece of all lanes
-#define RDAMD_LOAD_TAB(op, SLOT, WIDE, tOFF, e, SKIP_IF)                                        \
-  if (TR == 16) {                                                                               \
-    e = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(                         \
-        tab_rs, lane8, (int)((uni(op.tOFF) + roff) * 4u), 0));                                  \
-  } else {                                                                                      \
-    const unsigned wide = uni(op.flags) & WIDE;                                                 \
-    const int so = (int)((uni(op.tOFF) + (wide ? roff * 4u : roff)) * 4u) + (int)kFusedDmaBias; \
-    unsigned m0_saved, so2;                                                                     \
-    unsigned long long ex_saved;                                                                \
-    asm volatile(                                                                               \
-        SKIP_IF "\n\t"   /* an operand the step does not have: nothing to load */               \
-        "s_cbranch_scc1 3f\n\t"                                                               \
-        "s_mov_b32 %[sv], m0\n\t"                                                             \
-        "s_mov_b32 m0, %[m]\n\t"                                                              \
-        "s_mov_b64 %[xs], exec\n\t"                                                           \
-        "s_cmp_lg_u32 %[w], 0\n\t"                                                            \
-        "s_cselect_b32 %[so2], 0, 0x300\n\t"                                                  \
-        "s_cselect_b64 exec, -1, 0xffff\n\t"                                                  \
-        "s_sub_u32 %[so2], %[so], %[so2]\n\t"                                                 \
-        "buffer_load_dwordx4 %[vo16], %[rs], %[so] offen lds\n\t"                             \
-        "buffer_load_dwordx4 %[vo16], %[rs], %[so2] offen offset:1024 lds\n\t"                \
-        "s_mov_b64 exec, %[xs]\n\t"                                                           \
-        "s_mov_b32 m0, %[sv]\n"                                                                \
-        "3:"                                                                                    \
-        : [sv] "=&s"(m0_saved), [so2] "=&s"(so2), [xs] "=&s"(ex_saved)                          \
-        : [m] "s"((unsigned)(SLOT) + wbase), [w] "s"(wide), [vo16] "v"(lane16), [rs] "s"(tab_desc), \
-          [so] "s"(so), [kind] "s"(uni(op.flags) & 3u)                                          \
-        : "memory", "scc");                                                                     \
-  }
-#else
 #define RDAMD_LOAD_TAB(op, SLOT, WIDE, tOFF, e, SKIP_IF)                                        \
   if (TR == 16) {                                                                               \
     e = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(                         \
@@ -714,15 +683,9 @@ fused_dna_eval_kernel(FusedArgs a) {
           [so] "s"(so), [so2] "s"(so - 768), [kind] "s"(uni(op.flags) & 3u)                     \
         : "memory", "scc");                                                                     \
   }
-#endif
 #if !(defined(RDAMD_ABLATION) && defined(RDAMD_ABL_ONE_TABLOAD))
-#if defined(RDAMD_ABLATION) && defined(RDAMD_ABL_NO_SLOT_WAIT)   /* timing only: the next tables may land on rows still being read */
-#define RDAMD_SLOT_WAIT
-#else
-#define RDAMD_SLOT_WAIT __builtin_amdgcn_s_waitcnt(0xc07f);   /* lgkmcnt(0) */
-#endif
 #define RDAMD_LOAD_TABS(op, ex, ey) \
-  if (TR > 16) { RDAMD_SLOT_WAIT RDAMD_WARM_M(op) }  \
+  if (TR > 16) { __builtin_amdgcn_s_waitcnt(0xc07f);   /* lgkmcnt(0) */ RDAMD_WARM_M(op) }  \
   RDAMD_LOAD_TAB(op, 0u, 0x2000u, tX, ex, "s_cmp_lg_u32 %[kind], 0")       /* X: tip-tip steps only */ \
   RDAMD_LOAD_TAB(op, kYSlot, 0x4000u, tY, ey, "s_cmp_eq_u32 %[kind], 2")   /* Y: not when the step pops */
 #else

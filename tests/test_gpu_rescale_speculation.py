@@ -21,9 +21,12 @@ LNL_TOL = 1e-11
 
 
 def pair(tree, seqs, R, classes=64):
+    """classes: the pseudo-tips' class limit (64: the 64-row kernels, 16: the 16-row ones), 0: a
+    partition without site repeats"""
     S = len(next(iter(seqs.values())))
-    a = rd.Partition.for_tree(tree, 4, S, R, attributes=rd.ATTRIB_SITE_REPEATS)
-    a.set_site_repeats(classes)
+    a = rd.Partition.for_tree(tree, 4, S, R, attributes=rd.ATTRIB_SITE_REPEATS if classes else 0)
+    if classes:
+        a.set_site_repeats(classes)
     o = OraclePartition.for_tree(tree, 4, S, R)
     util.load_tips(a, tree, seqs, rd.MAP_NT)
     util.load_tips(o, tree, seqs, ORC_MAP_NT)
@@ -44,15 +47,16 @@ def params(rng, J, R):
             np.tile(rd.compute_gamma_cats(1.0, R), (J, 1)))
 
 
+@pytest.mark.parametrize("classes", [64, 16, 0])
 @pytest.mark.parametrize("n,S,R,seed", [(100, 3000, 4, 601), (37, 1000, 1, 602), (125, 777, 2, 603), (9, 130, 4, 604)])
-def test_the_two_modes_give_the_oracles_values(n, S, R, seed):
+def test_the_two_modes_give_the_oracles_values(n, S, R, seed, classes):
     """simulated alignments of ordinary trees: nothing is flagged, the speculative pass is the
     only pass; (site, rate) vectors that the tests would have rescaled on the way (a slow category
     at a fast site: c2 has ~0.3 % of them) come out with the same mantissas -- the factors of the
     rule are exact powers of two -- so the two modes agree to the last bit here"""
     w = synth.workload(n, S, 4, R, seed)
     tree = rd.Tree.from_newick(w["newick"])
-    a, o = pair(tree, w["seqs"], R)
+    a, o = pair(tree, w["seqs"], R, classes)
     rng = np.random.default_rng(seed)
     J = 5
     subst, freqs, rates = params(rng, J, R)
@@ -103,7 +107,8 @@ def test_sites_between_the_rules_line_and_the_checks_line():
     o.destroy()
 
 
-def test_a_sum_below_the_line_sends_the_job_to_the_second_pass():
+@pytest.mark.parametrize("classes", [64, 16, 0])
+def test_a_sum_below_the_line_sends_the_job_to_the_second_pass(classes):
     """branches of 1e-7 under unrelated sequences: every change costs 2^-23, a site of 100 tips
     ends near 2^-1700 -- beyond the FP64 range without the rule.  The speculative pass must not
     answer for such a job: its flag goes up, the second pass walks the plain program with every
@@ -111,7 +116,7 @@ def test_a_sum_below_the_line_sends_the_job_to_the_second_pass():
     the bit, whether it shares the batch or runs alone."""
     w = synth.workload(100, 500, 4, 4, 621, simulate_seqs=False)
     tree = rd.Tree.from_newick(w["newick"])
-    a, o = pair(tree, w["seqs"], 4)
+    a, o = pair(tree, w["seqs"], 4, classes)
     rng = np.random.default_rng(621)
     subst, freqs, rates = params(rng, 3, 4)
     rl = tree.root_location(11).with_ratio(0.4)
