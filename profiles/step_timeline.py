@@ -39,6 +39,8 @@ def main():
     ap.add_argument("--stride", type=int, default=None, help="every stride-th workgroup of the job stamps (64 at most)")
     ap.add_argument("--json", default=None)
     ap.add_argument("--label", default="")
+    ap.add_argument("--repeat-classes", type=int, default=None, help="class limit of the pseudo-tips (16: the 16-row kernel)")
+    ap.add_argument("--rescale-speculation", type=int, default=-1)
     args = ap.parse_args()
     if not hasattr(rd.lib, "rdamd_abl_stamps_config"):
         raise SystemExit("the library in place was not built with -DRDAMD_ABLATION -DRDAMD_ABL_STAMPS=<mask>")
@@ -49,6 +51,9 @@ def main():
     w = synth.workload(n, S, K, R, 0xD166E5 + sh["seed_index"])
     tree = rd.Tree.from_newick(w["newick"])
     part = rd.Partition.for_tree(tree, K, S, R, attributes=rd.ATTRIB_SITE_REPEATS)
+    if args.repeat_classes is not None:
+        part.set_site_repeats(args.repeat_classes)
+    part.set_rescale_speculation(args.rescale_speculation)
     for label, seq in w["seqs"].items():
         part.set_tip_states(tree.tip_index(label), rd.MAP_NT, seq)
     freqs = part.empirical_frequencies()

@@ -648,12 +648,16 @@ fused_dna_eval_kernel(FusedArgs a) {
           [vo4] "v"(lane4), [vo16] "v"(lane16), [rs] "s"(tab_desc)                              \
         : "memory", "scc");                                                                     \
   }
-    // THE PRODUCT'S FORM: one statement per operand, M0 saved and restored around it, the offsets
-    // worked out in the loop -- 15 scalar instructions per step more than RDAMD_LOAD_TABS64 above
-    // and 1.5 - 2 % FASTER on c2 and c5's shard, equal on c4's and 125.phy (same box, two rounds
-    // each: profiles/r5_tabload_ab.txt; the ISA budget: profiles/r5_fused_step_isa.md).  The scalar
-    // unit is not what a step waits for.  RDAMD_LOAD_TABS64 stays for the A/B (ablation builds,
-    // -DRDAMD_ABL_ONE_TABLOAD).
+    // THE FORM OF THE KERNELS WITH THE RESCALE TESTS: one statement per operand, M0 saved and restored
+    // around it, the offsets worked out in the loop -- 15 scalar instructions per step more than
+    // RDAMD_LOAD_TABS64 above and 1.5 - 2 % FASTER on c2 and c5's shard, equal on c4's and 125.phy (same
+    // box, two rounds each: profiles/r5_tabload_ab.txt; the ISA budget: profiles/r5_fused_step_isa.md):
+    // there the vector unit is oversubscribed and the scalar unit is not what a step waits for.  The
+    // SPECULATIVE kernels (no tests: 48 vector instructions per step instead of 59, issue slots 65 %
+    // full) are bound by a wave's own chain instead, and there RDAMD_LOAD_TABS64 wins: c2 +2.6 %, 125.phy
+    // +2 % alone, c2 +7.7 % / 125.phy +4.4 % / c2's 6 250-site shard +5.6 % with the early descriptor
+    // (round 6, profiles/r6_speculative_rescale.md).  -DRDAMD_ABL_ONE_TABLOAD (ablation builds) forces it
+    // everywhere for the A/B.
 #define RDAMD_LOAD_TAB(op, SLOT, WIDE, tOFF, e, SKIP_IF)                                        \
   if (TR == 16) {                                                                               \
     e = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(                         \
@@ -685,9 +689,14 @@ fused_dna_eval_kernel(FusedArgs a) {
   }
 #if !(defined(RDAMD_ABLATION) && defined(RDAMD_ABL_ONE_TABLOAD))
 #define RDAMD_LOAD_TABS(op, ex, ey) \
-  if (TR > 16) { __builtin_amdgcn_s_waitcnt(0xc07f);   /* lgkmcnt(0) */ RDAMD_WARM_M(op) }  \
-  RDAMD_LOAD_TAB(op, 0u, 0x2000u, tX, ex, "s_cmp_lg_u32 %[kind], 0")       /* X: tip-tip steps only */ \
-  RDAMD_LOAD_TAB(op, kYSlot, 0x4000u, tY, ey, "s_cmp_eq_u32 %[kind], 2")   /* Y: not when the step pops */
+  if (TR > 16 && SPEC) {                                                                        \
+    __builtin_amdgcn_s_waitcnt(0xc07f);   /* lgkmcnt(0) */                                      \
+    RDAMD_LOAD_TABS64(op)                                                                       \
+  } else {                                                                                      \
+    if (TR > 16) { __builtin_amdgcn_s_waitcnt(0xc07f);   /* lgkmcnt(0) */ RDAMD_WARM_M(op) }    \
+    RDAMD_LOAD_TAB(op, 0u, 0x2000u, tX, ex, "s_cmp_lg_u32 %[kind], 0")       /* X: tip-tip steps only */ \
+    RDAMD_LOAD_TAB(op, kYSlot, 0x4000u, tY, ey, "s_cmp_eq_u32 %[kind], 2")   /* Y: not when the step pops */ \
+  }
 #else
 #define RDAMD_LOAD_TABS(op, ex, ey) \
   if (TR > 16) {                                                                                \
@@ -715,7 +724,17 @@ fused_dna_eval_kernel(FusedArgs a) {
 #endif
     // (TR = 64: the descriptor of the operation after next only now -- fetched at the top of
     // the step it would sit in front of the wait above)
-#define RDAMD_LATE_DESC(cur, idx2) if (TR > 16) cur = load_const(prog + (idx2));
+#if defined(RDAMD_ABLATION) && defined(RDAMD_ABL_EARLY_DESC)   /* A/B: the 64-row kernels fetch it at the top too */
+#define RDAMD_LATE_DESC(cur, idx2)
+#define RDAMD_EARLY_DESC(cur, idx2) cur = load_const(prog + (idx2));
+#else
+    // (the speculative 64-row kernels fetch it at the top like the 16-row ones: without the rescale
+    // tests a step waits more than it computes, and the earlier request pays -- c2 +3.8 % alone, +7.7 %
+    // together with the one-statement table loads below; the kernels WITH the tests lose 6 % on the
+    // deep shapes that way: profiles/r6_speculative_rescale.md, section 4)
+#define RDAMD_LATE_DESC(cur, idx2) if (TR > 16 && !SPEC) cur = load_const(prog + (idx2));
+#define RDAMD_EARLY_DESC(cur, idx2) if (TR == 16 || SPEC) cur = load_const(prog + (idx2));
+#endif
     // the ONE matrix an operation applies to the running CLV, into SGPRs
 #if defined(RDAMD_ABLATION) && defined(RDAMD_ABL_MSAME)   /* timing only: every matrix load hits the scalar cache */
 #define RDAMD_M_OFFSET(op) 0u
@@ -752,7 +771,7 @@ fused_dna_eval_kernel(FusedArgs a) {
   {                                                                                             \
     const unsigned kind = uni(cur.flags);                                                       \
     RDAMD_STAMP(0)                                                                              \
-    if (TR == 16) cur = load_const(prog + (idx2));                                              \
+    RDAMD_EARLY_DESC(cur, idx2)                                                                 \
     unsigned rowx[NS], rowy[NS];   /* byte offsets of the rows inside the X / Y table = the codes */ \
     _Pragma("unroll") for (int q = 0; q < NS; ++q) { rowx[q] = cx[q]; rowy[q] = cy[q]; }        \
     double tx[NS][4], ty[NS][4];                                                                \
