@@ -184,6 +184,8 @@ private:
     double *out = nullptr;    // objective / root: results; reduce: the values, in place
     long candidate = -1;      // next
     bool done = false;
+    bool in_round = false;    // taken out of `posted` by the thread that runs the group's round: it holds the
+                              // address until it sets `done` -- the poster must not leave before that
   };
   struct group_t {
     unsigned live = 0;
@@ -233,8 +235,9 @@ private:
     _cv.notify_all();
     for (;;) {
       if (req.done) break;
-      if (!_error.empty()) {
-        // (`req` lives on the caller's stack: nothing may keep its address)
+      if (!_error.empty() && !req.in_round) {
+        // (`req` lives on the caller's stack: nothing may keep its address -- and while a round that was
+        // started before the error holds it, this thread stays: the round's thread ends it, error or not)
         grp.posted.erase(std::remove(grp.posted.begin(), grp.posted.end(), &req), grp.posted.end());
         throw std::runtime_error(_error);
       }
@@ -242,6 +245,7 @@ private:
         // everybody of the group has asked and it is the group's turn: this thread runs the round
         std::vector<request_t *> round;
         round.swap(grp.posted);
+        for (request_t *r : round) r->in_round = true;
         grp.busy = true;
         try {
           run_round(g, round, lk);
