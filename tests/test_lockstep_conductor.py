@@ -98,3 +98,17 @@ def test_one_ulp_on_one_rank_fails_every_rank_at_once(tmp_path, mode, ranks, wor
     assert out.returncode == 1 and "conductor FAILED" in out.stdout, out.stdout + out.stderr[-2000:]
     named = [ln for ln in out.stderr.splitlines() if "has diverged" in ln and "lock-step round" in ln]
     assert named and "did not receive the same bits" in named[0], out.stderr[-2000:]
+
+
+@pytest.mark.skipif(shutil.which("g++") is None, reason="needs g++")
+def test_failure_path_is_clean_under_address_sanitizer(tmp_path):
+    """a round that fails while the OTHER worker group's round is under way: the posters whose requests
+    that round holds must stay until it ends (their requests live on their stacks) -- round 6: one run in
+    five corrupted the heap there.  Every fault position of the test above, repeated, under ASan."""
+    exe = _build(tmp_path, "conductor_check_asan", ["-fsanitize=address"])
+    for mode in ("host", "device"):
+        for ranks, workers, groups, fault in [(2, 6, 2, "1:7"), (4, 5, 1, "2:3"), (3, 4, 2, "0:40")]:
+            for _ in range(6):
+                out = _run_raw(exe, ranks, workers, groups, 23, 1, mode, fault, timeout=60)
+                assert "Sanitizer" not in out.stderr, out.stderr[-3000:]
+                assert out.returncode == 1 and "conductor FAILED" in out.stdout, out.stdout + out.stderr[-2000:]
