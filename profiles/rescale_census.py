@@ -41,4 +41,5 @@ for j in range(6):
     # true magnitude = m * 2^(-256 sc)
     log2m = np.log2(np.maximum(m, 1e-300)) - 256.0 * sc[:, None]
     print(name, "job", j, "sites with scaler>0:", int((sc > 0).sum()), "min log2 max-entry per (site,rate):", log2m.min(),
-          "pairs below 2^-255:", int((log2m < -255).sum()), "of", S * R)
+          "pairs below 2^-255:", int((log2m < -255).sum()), "of", S * R,
+          "| smallest SITE (its best rate):", log2m.max(axis=1).min(), "sites below 2^-900:", int((log2m.max(axis=1) < -900).sum()))
