@@ -300,6 +300,9 @@ int rdamd_evaluate_batch(rdamd_partition_t *p, unsigned int n_jobs,
  * range's end.  mode 0: tests on every step (rounds 1 - 5).  mode -1 (the default): 1 for
  * partitions of up to 256 tips, 0 beyond (a 500-tip tree sends every job to the second pass).
  * A job's value depends on the job and the partition's mode only, never on what shares its batch.
+ * Partitions a caller does not create itself (rdamd_model_t's and its replicas') take their mode
+ * from the environment when they are created: RDAMD_RESCALE_SPECULATION=0 (tests on every step,
+ * whatever the tree) or =1; unset: the default rule.
  * rdamd_evaluate_second_passes: batches of this partition that needed their second pass so far. */
 int rdamd_partition_set_rescale_speculation(rdamd_partition_t *p, int mode);
 unsigned long long rdamd_evaluate_second_passes(const rdamd_partition_t *p);

@@ -283,6 +283,12 @@ rdamd_partition_t *rdamd_partition_create(unsigned int tips, unsigned int clv_bu
   p->tips = tips; p->clv_buffers = clv_buffers; p->states = states; p->sites = sites;
   p->rate_matrices = rate_matrices; p->prob_matrices = prob_matrices;
   p->rate_cats = rate_cats; p->scale_buffers = scale_buffers; p->attributes = attributes;
+  // (rdamd_partition_set_rescale_speculation's mode for partitions a caller does not reach itself --
+  // model_t's, its replicas' --: RDAMD_RESCALE_SPECULATION=0|1 in the environment, read here)
+  if (const char *e = getenv("RDAMD_RESCALE_SPECULATION")) {
+    const int mode = atoi(e);
+    p->rescale_speculation = mode <= 0 ? 0 : 1;
+  }
   p->ncodes_cap = states == 4 ? 16 : 64;
   const unsigned K = states, R = rate_cats;
   const size_t S = sites;

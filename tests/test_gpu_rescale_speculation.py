@@ -206,3 +206,25 @@ def test_the_flag_travels_with_a_stream_ordered_batch():
     rt.hipFree(d)
     a.destroy()
     o.destroy()
+
+
+def test_the_environment_sets_the_mode_of_partitions_created_under_it(monkeypatch):
+    """RDAMD_RESCALE_SPECULATION: for the partitions a caller never sees (the model's, its replicas');
+    observable through the second pass a 100-tip job on branches of 1e-7 needs under speculation only"""
+    w = synth.workload(100, 300, 4, 4, 651, simulate_seqs=False)
+    tree = rd.Tree.from_newick(w["newick"])
+    rng = np.random.default_rng(651)
+    subst, freqs, rates = params(rng, 1, 4)
+    ops, pmi, brl = tree.generate_operations(tree.root_location(7).with_ratio(0.4))
+    got = {}
+    for env, passes in (("0", 0), ("1", 1), (None, 1)):
+        if env is None:
+            monkeypatch.delenv("RDAMD_RESCALE_SPECULATION", raising=False)
+        else:
+            monkeypatch.setenv("RDAMD_RESCALE_SPECULATION", env)
+        a, o = pair(tree, w["seqs"], 4)
+        got[env] = a.evaluate_batch([a.schedule(ops, pmi, np.asarray(brl) * 0 + 1e-7)], subst, freqs, rates)[0]
+        assert a.second_passes() == passes, env
+        a.destroy()
+        o.destroy()
+    assert got["1"] == got[None] and abs(got["0"] - got["1"]) <= 1e-13 * abs(got["1"])
